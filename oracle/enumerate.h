@@ -1,0 +1,178 @@
+/* oracle/enumerate.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of the enumeration proposal that the reference generates per
+ * (class, block, observed-key-set) in src/inference/proposal_compiler.jl:5-418
+ * and re-scores in src/inference/block_proposal.jl:24-157, specialised to the
+ * static plan IR of include/pclean_hip.h and to the fixed-point draw rule of
+ * include/pclean_detmath.h ("batched-schedule" semantics: latent tables frozen,
+ * the evidence row's own reference removed).
+ *
+ * score_node() = one ForeignKeyNode / RandomChoiceNode enumeration:
+ *   proposal_compiler.jl:131-252 (FK: candidate loop 198-219, blind new-row
+ *   branch 221-230, logsumexp + categorical 233-245) and 55-129 (discrete
+ *   RandomChoiceNode: option loop 96-113, choice 115-127).
+ * eval_tree() = process_plan! recursion (363-388): children of a "new row"
+ *   are enumerated independently and their log-marginals added.
+ */
+#ifndef PCLEAN_ORACLE_ENUMERATE_H
+#define PCLEAN_ORACLE_ENUMERATE_H
+
+#include <cstdint>
+#include <vector>
+
+#include "../include/pclean_detmath.h"
+#include "../include/pclean_hip.h"
+#include "../include/pclean_philox.h"
+#include "densities.h"
+
+namespace pco {
+
+struct OPair {
+  int n_obs = 0, n_lat = 0;
+  std::vector<uint16_t> d;        /* [n_obs][n_lat] */
+  std::vector<uint16_t> lat_len;  /* [n_lat] */
+};
+struct OTable {
+  bool is_options = false;
+  int n_rows = 0, n_cols = 0;
+  std::vector<int32_t> cols;  /* [n_cols][n_rows] */
+  std::vector<int64_t> counts;
+  std::vector<double> logc_full, logc_m1;
+  double scal[4] = {0, 0, 0, 0};
+};
+struct OFn {
+  int n_a = 0, n_b = 0;
+  std::vector<int32_t> fn;
+};
+struct OBlock {
+  std::vector<pclean_node> nodes;
+  std::vector<pclean_term> terms;
+  std::vector<int32_t> children;
+  std::vector<int32_t> colmap; /* pairs (child node, child col) per table column of each FK node */
+  int n_ctx = 0;
+  int ctx_src_block[PCLEAN_MAX_CTX] = {-1, -1};
+  int ctx_src_col[PCLEAN_MAX_CTX] = {-1, -1};
+};
+
+struct World {
+  int n_rows = 0, n_cols = 0;
+  std::vector<int32_t> obs; /* [n_cols][n_rows] */
+  /* AddTypos density pieces: handed over from the product (pclean_get_density_tables)
+   * so both sides add bit-identical doubles; checked against densities.h in tests. */
+  int max_r = 0, max_d = 0, max_len = 0;
+  std::vector<double> nb, logl;
+  std::vector<OPair> pair;
+  std::vector<OTable> table;
+  std::vector<OFn> fn;
+  std::vector<OBlock> block;
+  World() : pair(64), table(64), fn(64), block(8) {}
+};
+
+static const double HALF_LOG26 = 1.629048269010741; /* log(26)/2, add_typos.jl:63 */
+
+inline double term_density(const World& w, const pclean_term& tm, const OPair& pt, int d, int val) {
+  if (tm.dens_kind == PCLEAN_DENS_EQUAL) return d == 0 ? 0.0 : NEG_INF;
+  if (tm.max_typos >= 0 && d > tm.max_typos) return IMPOSSIBLE; /* add_typos.jl:57-59 */
+  const int L = pt.lat_len[val];
+  const int r = (L + 4) / 5; /* ceil(length(word)/5), add_typos.jl:61 */
+  double l = w.nb[(size_t)r * (w.max_d + 1) + d];
+  l -= w.logl[L] * (double)d;  /* add_typos.jl:62 */
+  l -= HALF_LOG26 * (double)d; /* add_typos.jl:63 */
+  return l;
+}
+
+/* Scores of all candidates (+ new-row candidate for FK nodes, last) of one
+ * node for one work item.  out.size() == n_rows + (FK ? 1 : 0). */
+inline void node_scores(const World& w, int block_id, int node_id, int row, const int32_t* ctxv, int excl,
+                        double snew_in, std::vector<double>& out) {
+  const OBlock& b = w.block[block_id];
+  const pclean_node& nd = b.nodes[node_id];
+  const OTable& t = w.table[nd.table];
+  const int n = t.n_rows;
+  const bool fk = nd.kind == PCLEAN_NODE_FK;
+  out.assign(n + (fk ? 1 : 0), NEG_INF);
+  if (fk) {
+    const bool excluded = excl >= 0;
+    const bool deleted = excluded && t.counts[excl] <= 1; /* dependency_tracking.jl:189-201 */
+    const double logden = excluded ? t.scal[1] : t.scal[0];
+    for (int k = 0; k < n; ++k) {
+      if (t.counts[k] == 0) continue;
+      if (k == excl)
+        out[k] = deleted ? NEG_INF : t.logc_m1[k] - logden;
+      else
+        out[k] = t.logc_full[k] - logden;
+    }
+    out[n] = ((deleted ? t.scal[3] : t.scal[2]) - logden) + snew_in;
+  } else {
+    for (int k = 0; k < n; ++k) out[k] = t.logc_full[k];
+  }
+  for (int ti = 0; ti < nd.n_terms; ++ti) {
+    const pclean_term& tm = b.terms[nd.term_begin + ti];
+    const int o = w.obs[(size_t)tm.obs_col * w.n_rows + row];
+    if (o < 0) continue; /* explicitly missing observation: add_typos.jl:51-53 */
+    const OPair& pt = w.pair[tm.pair_table];
+    for (int k = 0; k < n; ++k) {
+      int val = t.cols[(size_t)tm.cand_col * n + k];
+      if (tm.ctx_slot >= 0) {
+        const OFn& f = w.fn[tm.fn_table];
+        val = f.fn[(size_t)ctxv[tm.ctx_slot] * f.n_b + val];
+      }
+      const int d = pt.d[(size_t)o * pt.n_lat + val];
+      out[k] += term_density(w, tm, pt, d, val);
+    }
+  }
+}
+
+struct FixSum {
+  double m;
+  uint64_t U;
+};
+inline FixSum fix_sum(const std::vector<double>& s) {
+  FixSum f{NEG_INF, 0};
+  for (double v : s)
+    if (v > f.m) f.m = v;
+  if (f.m == NEG_INF) return f;
+  for (double v : s) f.U += pclean_fixw(v - f.m);
+  return f;
+}
+/* min{k : u_0+..+u_k > x}; falls back to the last candidate when U == 0. */
+inline int fix_draw(const std::vector<double>& s, const FixSum& f, uint64_t R) {
+  const int n = (int)s.size();
+  if (f.U == 0) return n - 1;
+  const uint64_t x = pclean_mulhi64(R, f.U);
+  uint64_t acc = 0;
+  for (int k = 0; k < n; ++k) {
+    acc += pclean_fixw(s[k] - f.m);
+    if (acc > x) return k;
+  }
+  return n - 1;
+}
+
+inline int score_node(const World& w, int block_id, int node_id, int n_items, const int32_t* rows,
+                      const int32_t* ctxv, const int32_t* excl, const double* snew, uint64_t seed, uint32_t sweep,
+                      int n_draws, double* lse, double* scores, int32_t* draws) {
+  const OBlock& b = w.block[block_id];
+  const pclean_node& nd = b.nodes[node_id];
+  const OTable& t = w.table[nd.table];
+  const bool fk = nd.kind == PCLEAN_NODE_FK;
+  const int nc = t.n_rows + (fk ? 1 : 0);
+  std::vector<double> s;
+  for (int it = 0; it < n_items; ++it) {
+    node_scores(w, block_id, node_id, rows[it], ctxv ? ctxv + (size_t)it * PCLEAN_MAX_CTX : nullptr,
+                excl ? excl[it] : -1, snew ? snew[it] : NEG_INF, s);
+    FixSum f = fix_sum(s);
+    if (lse) lse[it] = pclean_lse_from_fix(f.m, f.U);
+    if (scores)
+      for (int k = 0; k < nc; ++k) scores[(size_t)it * nc + k] = s[k];
+    for (int j = 0; j < n_draws; ++j) {
+      uint64_t R = pclean_rand64(seed, (uint32_t)rows[it], PCLEAN_SITE_NODE(block_id, node_id), (uint32_t)(j + 1),
+                                 sweep);
+      int k = fix_draw(s, f, R);
+      draws[(size_t)it * n_draws + j] = (fk && k == t.n_rows) ? PCLEAN_CHOICE_NEW : k;
+    }
+  }
+  return 0;
+}
+
+} /* namespace pco */
+#endif

@@ -1,0 +1,176 @@
+/* oracle/pclean_oracle.cpp — TEST INFRASTRUCTURE ONLY.
+ *
+ * C entry points (ctypes-loaded by tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg ONLY) over the single-thread CPU restatement of
+ * PClean's hot path.  The product (pclean_amd/) never links or loads this.
+ * PARITY UNPINNED — see oracle/densities.h header and DESIGN.md §Oracle.
+ */
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../include/pclean_detmath.h"
+#include "../include/pclean_philox.h"
+#include "densities.h"
+#include "enumerate.h"
+
+extern "C" {
+
+/* ---- string distances -------------------------------------------------- */
+int pco_osa(const uint16_t* a, int la, const uint16_t* b, int lb) { return pco::osa_distance(a, la, b, lb); }
+int pco_dl(const uint16_t* a, int la, const uint16_t* b, int lb) { return pco::dl_distance(a, la, b, lb); }
+
+/* D[u][v] for a whole pair table (what the memo dict add_typos.jl:47 ends up holding). */
+void pco_pair_table(const uint16_t* sym, const int64_t* off, int n_obs, const int32_t* obs_ids, int n_lat,
+                    const int32_t* lat_ids, int mode, uint16_t* out) {
+  for (int u = 0; u < n_obs; ++u)
+    for (int v = 0; v < n_lat; ++v) {
+      const uint16_t* a = sym + off[obs_ids[u]];
+      const uint16_t* b = sym + off[lat_ids[v]];
+      int la = (int)(off[obs_ids[u] + 1] - off[obs_ids[u]]), lb = (int)(off[lat_ids[v] + 1] - off[lat_ids[v]]);
+      out[(size_t)u * n_lat + v] =
+          (uint16_t)(mode == 0 ? pco::osa_distance(a, la, b, lb) : pco::dl_distance(a, la, b, lb));
+    }
+}
+
+/* ---- densities --------------------------------------------------------- */
+double pco_negbin_logpdf(double r, double p, int k) { return pco::negbin_logpdf(r, p, k); }
+double pco_normal_logpdf(double x, double mu, double sigma) { return pco::normal_logpdf(x, mu, sigma); }
+double pco_add_typos(int num_typos, int word_len, int max_typos) {
+  return pco::add_typos_from_distance(num_typos, word_len, max_typos);
+}
+double pco_string_prior(const uint8_t* lm, int len, int min_len, int max_len, const double* init_p,
+                        const double* trans_p) {
+  return pco::string_prior_logdensity(lm, len, min_len, max_len, init_p, trans_p);
+}
+double pco_dummy_logmass(const double* atom_logps, int n) { return pco::dummy_logmass(atom_logps, (size_t)n); }
+double pco_choose_uniformly(int n) { return pco::choose_uniformly_logdensity(n); }
+double pco_choose_proportionally(int observed, const int32_t* options, const double* probs, int n) {
+  return pco::choose_proportionally_logdensity(observed, options, probs, n);
+}
+double pco_transformed_gaussian(double backward_obs, double abs_deriv, double mean, double std) {
+  return pco::transformed_gaussian_logdensity(backward_obs, abs_deriv, mean, std);
+}
+double pco_maybe_swap(int obs_missing, int val_in_options, int same, int n_options, double prob) {
+  return pco::maybe_swap_logdensity(obs_missing != 0, val_in_options != 0, same != 0, n_options, prob);
+}
+int pco_time_regex(const uint32_t* s, int n) { return pco::time_regex_match(s, n) ? 1 : 0; }
+double pco_time_prior(void) { return pco::time_prior_logdensity(); }
+double pco_logsumexp(const double* x, int n) { return pco::logsumexp(x, (size_t)n); }
+double pco_py_existing(int64_t count, int64_t total, double strength, double discount) {
+  return pco::py_existing_logprob(count, total, strength, discount);
+}
+double pco_py_new(int64_t n_rows, int64_t total, double strength, double discount) {
+  return pco::py_new_logprob(n_rows, total, strength, discount);
+}
+double pco_pitman_yor_score(double strength, double discount, const int64_t* counts, int n) {
+  return pco::pitman_yor_score(strength, discount, counts, (size_t)n);
+}
+double pco_ess(const double* logw, int n) { return pco::effective_sample_size(logw, (size_t)n); }
+
+/* ---- deterministic math / rng contract (include/) ----------------------- */
+double pco_det_exp(double x) { return pclean_exp(x); }
+double pco_det_log(double x) { return pclean_log(x); }
+uint64_t pco_fixw(double d) { return pclean_fixw(d); }
+void pco_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t* out4) {
+  pclean_u32x4 o = pclean_philox4x32_10(c0, c1, c2, c3, k0, k1);
+  memcpy(out4, o.v, 16);
+}
+uint64_t pco_rand64(uint64_t seed, uint32_t row, uint32_t site, uint32_t particle, uint32_t sweep) {
+  return pclean_rand64(seed, row, site, particle, sweep);
+}
+
+/* ---- world construction (host copies of what the product uploads) ------- */
+pco::World* pco_world_create(void) { return new pco::World(); }
+void pco_world_destroy(pco::World* w) { delete w; }
+void pco_world_set_obs(pco::World* w, int n_rows, int n_cols, const int32_t* obs) {
+  w->n_rows = n_rows;
+  w->n_cols = n_cols;
+  w->obs.assign(obs, obs + (size_t)n_rows * n_cols);
+}
+void pco_world_set_density(pco::World* w, int max_r, int max_d, int max_len, const double* nb, const double* logl) {
+  w->max_r = max_r;
+  w->max_d = max_d;
+  w->max_len = max_len;
+  w->nb.assign(nb, nb + (size_t)(max_r + 1) * (max_d + 1));
+  w->logl.assign(logl, logl + max_len + 1);
+}
+void pco_world_set_pair(pco::World* w, int id, int n_obs, int n_lat, const uint16_t* d, const uint16_t* lat_len) {
+  pco::OPair& p = w->pair[id];
+  p.n_obs = n_obs;
+  p.n_lat = n_lat;
+  p.d.assign(d, d + (size_t)n_obs * n_lat);
+  p.lat_len.assign(lat_len, lat_len + n_lat);
+}
+void pco_world_set_table(pco::World* w, int id, int n_rows, int n_cols, const int32_t* cols, const int64_t* counts,
+                         const double* logc_full, const double* logc_m1, const double* scal4) {
+  pco::OTable& t = w->table[id];
+  t.is_options = false;
+  t.n_rows = n_rows;
+  t.n_cols = n_cols;
+  t.cols.assign(cols, cols + (size_t)n_rows * n_cols);
+  t.counts.assign(counts, counts + n_rows);
+  t.logc_full.assign(logc_full, logc_full + n_rows);
+  t.logc_m1.assign(logc_m1, logc_m1 + n_rows);
+  memcpy(t.scal, scal4, sizeof t.scal);
+}
+void pco_world_set_options(pco::World* w, int id, int n, const int32_t* values, const double* logp) {
+  pco::OTable& t = w->table[id];
+  t.is_options = true;
+  t.n_rows = n;
+  t.n_cols = 1;
+  t.cols.assign(values, values + n);
+  t.counts.assign(n, 1);
+  t.logc_full.assign(logp, logp + n);
+  t.logc_m1.clear();
+}
+void pco_world_set_fn(pco::World* w, int id, int n_a, int n_b, const int32_t* fn) {
+  pco::OFn& f = w->fn[id];
+  f.n_a = n_a;
+  f.n_b = n_b;
+  f.fn.assign(fn, fn + (size_t)n_a * n_b);
+}
+void pco_world_load_block(pco::World* w, int id, int n_nodes, const pclean_node* nodes, int n_terms,
+                          const pclean_term* terms, int n_children, const int32_t* children, int n_colmap,
+                          const int32_t* colmap, int n_ctx, const int32_t* ctx_src_block,
+                          const int32_t* ctx_src_col) {
+  pco::OBlock& b = w->block[id];
+  b.nodes.assign(nodes, nodes + n_nodes);
+  b.terms.assign(terms, terms + n_terms);
+  b.children.assign(children, children + n_children);
+  b.colmap.assign(colmap, colmap + n_colmap);
+  b.n_ctx = n_ctx;
+  for (int s = 0; s < n_ctx; ++s) {
+    b.ctx_src_block[s] = ctx_src_block[s];
+    b.ctx_src_col[s] = ctx_src_col[s];
+  }
+}
+/* CRP prior pieces computed the oracle's own way (densities.h), for checking
+ * what the product uploads (pclean_get_table_priors). */
+void pco_table_priors(int n_rows, const int64_t* counts, double strength, double discount, double* logc_full,
+                      double* logc_m1, double* scal4) {
+  int64_t total = 0, live = 0;
+  for (int k = 0; k < n_rows; ++k) {
+    total += counts[k];
+    live += counts[k] > 0;
+  }
+  for (int k = 0; k < n_rows; ++k) {
+    logc_full[k] = counts[k] > 0 ? std::log((double)counts[k] - discount) : pco::NEG_INF;
+    logc_m1[k] = counts[k] > 1 ? std::log((double)(counts[k] - 1) - discount) : pco::NEG_INF;
+  }
+  scal4[0] = std::log((double)total + strength);
+  scal4[1] = std::log((double)(total - 1) + strength);
+  scal4[2] = std::log(strength + discount * (double)live);
+  scal4[3] = std::log(strength + discount * (double)(live - 1));
+}
+
+/* ---- batched enumeration spec (enumerate.h) ------------------------------ */
+int pco_score_node(const pco::World* w, int block_id, int node_id, int n_items, const int32_t* rows,
+                   const int32_t* ctxv, const int32_t* excl, const double* snew, uint64_t seed, uint32_t sweep,
+                   int n_draws, double* lse, double* scores, int32_t* draws) {
+  return pco::score_node(*w, block_id, node_id, n_items, rows, ctxv, excl, snew, seed, sweep, n_draws, lse, scores,
+                         draws);
+}
+
+} /* extern "C" */

@@ -1,0 +1,292 @@
+"""ctypes binding of libpclean_hip.so (the C ABI declared in include/pclean_hip.h).
+
+There is deliberately no CPU fallback: if the shared object is missing or no
+gfx950 device is visible, every compute call raises `PCleanHipError`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpclean_hip.so")
+
+MAX_CTX = 2
+CHOICE_NEW = -1
+DIST_OSA, DIST_DL = 0, 1
+DENS_ADD_TYPOS, DENS_EQUAL = 0, 1
+NODE_FK, NODE_LEAF = 0, 1
+
+
+class PCleanHipError(RuntimeError):
+    pass
+
+
+class Term(C.Structure):
+    _fields_ = [("obs_col", C.c_int32), ("cand_col", C.c_int32), ("pair_table", C.c_int32),
+                ("dens_kind", C.c_int32), ("max_typos", C.c_int32), ("ctx_slot", C.c_int32),
+                ("fn_table", C.c_int32), ("reserved", C.c_int32)]
+
+
+class Node(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("table", C.c_int32), ("term_begin", C.c_int32), ("n_terms", C.c_int32),
+                ("child_begin", C.c_int32), ("n_children", C.c_int32), ("parent", C.c_int32),
+                ("parent_fk_col", C.c_int32), ("cacheable", C.c_int32), ("colmap_begin", C.c_int32),
+                ("reserved", C.c_int32 * 2)]
+
+
+class InferConfig(C.Structure):
+    _fields_ = [("num_iters", C.c_int32), ("num_particles", C.c_int32), ("use_dd_proposals", C.c_int32),
+                ("use_lo_sweeps", C.c_int32), ("use_mh_instead_of_pg", C.c_int32), ("rejuv_frequency", C.c_int32),
+                ("reporting_frequency", C.c_int32)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("total_ms", C.c_float), ("hot_kernel_ms", C.c_float), ("hot_kernel_launches", C.c_int32),
+                ("reserved", C.c_int32), ("hot_kernel_alg_bytes", C.c_double)]
+
+
+TERM_DTYPE = np.dtype([("obs_col", "<i4"), ("cand_col", "<i4"), ("pair_table", "<i4"), ("dens_kind", "<i4"),
+                       ("max_typos", "<i4"), ("ctx_slot", "<i4"), ("fn_table", "<i4"), ("reserved", "<i4")])
+NODE_DTYPE = np.dtype([("kind", "<i4"), ("table", "<i4"), ("term_begin", "<i4"), ("n_terms", "<i4"),
+                       ("child_begin", "<i4"), ("n_children", "<i4"), ("parent", "<i4"), ("parent_fk_col", "<i4"),
+                       ("cacheable", "<i4"), ("colmap_begin", "<i4"), ("reserved0", "<i4"), ("reserved1", "<i4")])
+
+_lib = None
+
+
+def _p(arr, ctype):
+    if arr is None:
+        return None
+    return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def load_library(path=None):
+    """dlopen the HIP library; raises PCleanHipError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise PCleanHipError(
+            f"{path} not found: build it with `python -m pclean_amd.build` (hipcc, gfx950). "
+            "pclean_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    lib.pclean_last_error.restype = C.c_char_p
+    lib.pclean_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(ctx_handle, rc, what):
+    if rc != 0:
+        lib = load_library()
+        msg = lib.pclean_last_error(ctx_handle).decode() if ctx_handle else ""
+        raise PCleanHipError(f"{what} failed with status {rc}: {msg}")
+
+
+class HipContext:
+    """Owns one `pclean_ctx` (one GPU)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        rc = self.lib.pclean_ctx_create(C.c_int(device), C.byref(self.h))
+        if rc != 0:
+            raise PCleanHipError(
+                f"pclean_ctx_create(device={device}) failed with status {rc}"
+                + (" (no gfx950 device visible; pclean_amd has no CPU fallback)" if rc == -3 else ""))
+
+    def close(self):
+        if self.h:
+            self.lib.pclean_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- data ---------------------------------------------------------------
+    def load_strings(self, sym, off):
+        sym = np.ascontiguousarray(sym, dtype=np.uint16)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        check(self.h, self.lib.pclean_load_strings(self.h, C.c_int32(len(off) - 1), _p(sym, C.c_uint16),
+                                                   _p(off, C.c_int64)), "pclean_load_strings")
+
+    def load_columns(self, obs):
+        obs = np.ascontiguousarray(obs, dtype=np.int32)  # [n_cols][n_rows]
+        n_cols, n_rows = obs.shape
+        check(self.h, self.lib.pclean_load_columns(self.h, C.c_int32(n_rows), C.c_int32(n_cols), _p(obs, C.c_int32)),
+              "pclean_load_columns")
+
+    def build_pair_table(self, table_id, obs_ids, lat_ids, mode=DIST_OSA):
+        obs_ids = np.ascontiguousarray(obs_ids, dtype=np.int32)
+        lat_ids = np.ascontiguousarray(lat_ids, dtype=np.int32)
+        check(self.h, self.lib.pclean_build_pair_table(self.h, C.c_int32(table_id), C.c_int32(len(obs_ids)),
+                                                       _p(obs_ids, C.c_int32), C.c_int32(len(lat_ids)),
+                                                       _p(lat_ids, C.c_int32), C.c_int32(mode)),
+              "pclean_build_pair_table")
+
+    def set_pair_table(self, table_id, table):
+        table = np.ascontiguousarray(table, dtype=np.uint8)
+        check(self.h, self.lib.pclean_set_pair_table(self.h, C.c_int32(table_id), C.c_int32(table.shape[0]),
+                                                     C.c_int32(table.shape[1]), _p(table, C.c_uint8)),
+              "pclean_set_pair_table")
+
+    def get_pair_table(self, table_id, n_obs, n_lat):
+        out = np.empty((n_obs, n_lat), dtype=np.uint16)
+        check(self.h, self.lib.pclean_get_pair_table(self.h, C.c_int32(table_id), _p(out, C.c_uint16)),
+              "pclean_get_pair_table")
+        return out
+
+    def get_density_tables(self):
+        mr, md, ml = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.h, self.lib.pclean_get_density_tables(self.h, C.byref(mr), C.byref(md), C.byref(ml), None, None),
+              "pclean_get_density_tables")
+        nb = np.empty((mr.value + 1, md.value + 1), dtype=np.float64)
+        logl = np.empty(ml.value + 1, dtype=np.float64)
+        check(self.h, self.lib.pclean_get_density_tables(self.h, C.byref(mr), C.byref(md), C.byref(ml),
+                                                         _p(nb, C.c_double), _p(logl, C.c_double)),
+              "pclean_get_density_tables")
+        return mr.value, md.value, ml.value, nb, logl
+
+    def string_prior_scores(self, lm, off, min_len, max_len, init_logp, trans_logp):
+        lm = np.ascontiguousarray(lm, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        init_logp = np.ascontiguousarray(init_logp, dtype=np.float64)
+        trans_logp = np.ascontiguousarray(trans_logp, dtype=np.float64)
+        n = len(off) - 1
+        out = np.empty(n, dtype=np.float64)
+        check(self.h, self.lib.pclean_string_prior_scores(self.h, C.c_int32(n), _p(lm, C.c_uint8), _p(off, C.c_int64),
+                                                          C.c_int32(min_len), C.c_int32(max_len),
+                                                          _p(init_logp, C.c_double), _p(trans_logp, C.c_double),
+                                                          _p(out, C.c_double)), "pclean_string_prior_scores")
+        return out
+
+    # -- candidate tables -----------------------------------------------------
+    def set_table(self, table_id, cols, counts, strength, discount):
+        cols = np.ascontiguousarray(cols, dtype=np.int32)  # [n_cols][n_rows]
+        counts = np.ascontiguousarray(counts, dtype=np.int64)
+        n_cols, n_rows = cols.shape if cols.ndim == 2 else (0, len(counts))
+        check(self.h, self.lib.pclean_set_table(self.h, C.c_int32(table_id), C.c_int32(n_rows), C.c_int32(n_cols),
+                                                _p(cols, C.c_int32), _p(counts, C.c_int64), C.c_double(strength),
+                                                C.c_double(discount)), "pclean_set_table")
+
+    def set_options(self, table_id, values, logp):
+        values = np.ascontiguousarray(values, dtype=np.int32)
+        logp = np.ascontiguousarray(logp, dtype=np.float64)
+        check(self.h, self.lib.pclean_set_options(self.h, C.c_int32(table_id), C.c_int32(len(values)),
+                                                  _p(values, C.c_int32), _p(logp, C.c_double)), "pclean_set_options")
+
+    def set_fn_table(self, fn_id, fn):
+        fn = np.ascontiguousarray(fn, dtype=np.int32)
+        check(self.h, self.lib.pclean_set_fn_table(self.h, C.c_int32(fn_id), C.c_int32(fn.shape[0]),
+                                                   C.c_int32(fn.shape[1]), _p(fn, C.c_int32)), "pclean_set_fn_table")
+
+    def get_table_priors(self, table_id, n_rows, is_options=False):
+        full = np.empty(n_rows, dtype=np.float64)
+        m1 = np.empty(n_rows, dtype=np.float64)
+        scal = np.empty(4, dtype=np.float64)
+        check(self.h, self.lib.pclean_get_table_priors(self.h, C.c_int32(table_id), _p(full, C.c_double),
+                                                       None if is_options else _p(m1, C.c_double),
+                                                       _p(scal, C.c_double)), "pclean_get_table_priors")
+        return full, m1, scal
+
+    def load_block(self, block_id, nodes, terms, children, colmap, ctx_src_block=(), ctx_src_col=()):
+        nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+        terms = np.ascontiguousarray(terms, dtype=TERM_DTYPE)
+        children = np.ascontiguousarray(children, dtype=np.int32)
+        colmap = np.ascontiguousarray(colmap, dtype=np.int32)
+        csb = np.ascontiguousarray(ctx_src_block, dtype=np.int32)
+        csc = np.ascontiguousarray(ctx_src_col, dtype=np.int32)
+        check(self.h, self.lib.pclean_load_block(
+            self.h, C.c_int32(block_id), C.c_int32(len(nodes)), nodes.ctypes.data_as(C.c_void_p),
+            C.c_int32(len(terms)), terms.ctypes.data_as(C.c_void_p), C.c_int32(len(children)),
+            _p(children, C.c_int32), C.c_int32(len(colmap)), _p(colmap, C.c_int32), C.c_int32(len(csb)),
+            _p(csb, C.c_int32), _p(csc, C.c_int32)), "pclean_load_block")
+
+    # -- enumeration / sweep ---------------------------------------------------
+    def score_node(self, block_id, node_id, rows, ctxv=None, excl=None, snew=None, seed=0, sweep=0, n_draws=0,
+                   n_cand=None, want_scores=False):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        n = len(rows)
+        ctxv = None if ctxv is None else np.ascontiguousarray(ctxv, dtype=np.int32)
+        excl = None if excl is None else np.ascontiguousarray(excl, dtype=np.int32)
+        snew = None if snew is None else np.ascontiguousarray(snew, dtype=np.float64)
+        lse = np.empty(n, dtype=np.float64)
+        scores = np.empty((n, n_cand), dtype=np.float64) if want_scores else None
+        draws = np.empty((n, n_draws), dtype=np.int32) if n_draws else None
+        check(self.h, self.lib.pclean_score_node(
+            self.h, C.c_int32(block_id), C.c_int32(node_id), C.c_int32(n), _p(rows, C.c_int32), _p(ctxv, C.c_int32),
+            _p(excl, C.c_int32), _p(snew, C.c_double), C.c_uint64(seed), C.c_uint32(sweep), C.c_int32(n_draws),
+            _p(lse, C.c_double), _p(scores, C.c_double), _p(draws, C.c_int32)), "pclean_score_node")
+        return lse, scores, draws
+
+    def sweep(self, cfg, seed, sweep_idx, cur):
+        cur = np.ascontiguousarray(cur, dtype=np.int32)  # [n_blocks][n_rows]
+        n_blocks, n_rows = cur.shape
+        choice = np.empty_like(cur)
+        chosen = np.empty(n_rows, dtype=np.int32)
+        logml = np.empty(n_rows, dtype=np.float64)
+        check(self.h, self.lib.pclean_sweep(self.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep_idx),
+                                            C.c_int32(n_blocks), _p(cur, C.c_int32), _p(choice, C.c_int32),
+                                            _p(chosen, C.c_int32), _p(logml, C.c_double)), "pclean_sweep")
+        return choice, chosen, logml
+
+    def get_new_rows(self, block_id, n_nodes):
+        n = C.c_int32()
+        check(self.h, self.lib.pclean_get_new_rows(self.h, C.c_int32(block_id), C.byref(n), None, None),
+              "pclean_get_new_rows")
+        rows = np.empty(n.value, dtype=np.int32)
+        vals = np.empty((n.value, n_nodes), dtype=np.int32)
+        if n.value:
+            check(self.h, self.lib.pclean_get_new_rows(self.h, C.c_int32(block_id), C.byref(n), _p(rows, C.c_int32),
+                                                       _p(vals, C.c_int32)), "pclean_get_new_rows")
+        return rows, vals
+
+    def get_timing(self):
+        t = Timing()
+        check(self.h, self.lib.pclean_get_timing(self.h, C.byref(t)), "pclean_get_timing")
+        return t
+
+    def maybe_resample(self, logw, retain_first, seed, sweep, block):
+        logw = np.ascontiguousarray(logw, dtype=np.float64)
+        n, p = logw.shape
+        anc = np.empty((n, p), dtype=np.int32)
+        inc = np.empty(n, dtype=np.float64)
+        ess = np.empty(n, dtype=np.float64)
+        check(self.h, self.lib.pclean_maybe_resample(self.h, C.c_int32(n), C.c_int32(p), _p(logw, C.c_double),
+                                                     C.c_int32(int(retain_first)), C.c_uint64(seed), C.c_uint32(sweep),
+                                                     C.c_uint32(block), _p(anc, C.c_int32), _p(inc, C.c_double),
+                                                     _p(ess, C.c_double)), "pclean_maybe_resample")
+        return anc, inc, ess
+
+    def final_choice(self, logw, use_mh, is_csmc, seed, sweep):
+        logw = np.ascontiguousarray(logw, dtype=np.float64)
+        n, p = logw.shape
+        chosen = np.empty(n, dtype=np.int32)
+        tot = np.empty(n, dtype=np.float64)
+        check(self.h, self.lib.pclean_final_choice(self.h, C.c_int32(n), C.c_int32(p), _p(logw, C.c_double),
+                                                   C.c_int32(int(use_mh)), C.c_int32(int(is_csmc)), C.c_uint64(seed),
+                                                   C.c_uint32(sweep), _p(chosen, C.c_int32), _p(tot, C.c_double)),
+              "pclean_final_choice")
+        return chosen, tot
+
+    def debug_detmath(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        e = np.empty_like(x)
+        l = np.empty_like(x)
+        f = np.empty(len(x), dtype=np.uint64)
+        check(self.h, self.lib.pclean_debug_detmath(self.h, C.c_int32(len(x)), _p(x, C.c_double), _p(e, C.c_double),
+                                                    _p(l, C.c_double), _p(f, C.c_uint64)), "pclean_debug_detmath")
+        return e, l, f
+
+    def debug_rand64(self, seed, rows, site, particle, sweep):
+        rows = np.ascontiguousarray(rows, dtype=np.uint32)
+        out = np.empty(len(rows), dtype=np.uint64)
+        check(self.h, self.lib.pclean_debug_rand64(self.h, C.c_int32(len(rows)), C.c_uint64(seed), _p(rows, C.c_uint32),
+                                                   C.c_uint32(site), C.c_uint32(particle), C.c_uint32(sweep),
+                                                   _p(out, C.c_uint64)), "pclean_debug_rand64")
+        return out

@@ -1,0 +1,423 @@
+// C ABI entry points: lifecycle, string pool, observed columns, pair tables,
+// density tables, StringPrior scores, candidate tables, plan upload.
+// The enumeration / sweep entry points live in sweep.hip.
+#include <cmath>
+#include <limits>
+
+#include "ctx.h"
+
+static const double kNegInf = -std::numeric_limits<double>::infinity();
+
+extern "C" const char* pclean_version(void) { return "pclean-hip 0.1 (gfx950)"; }
+
+extern "C" int pclean_ctx_create(int device_id, pclean_ctx** out) {
+  if (!out) return PCLEAN_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return PCLEAN_ERR_NO_DEVICE;
+  if (device_id < 0 || device_id >= n) return PCLEAN_ERR_ARG;
+  if (hipSetDevice(device_id) != hipSuccess) return PCLEAN_ERR_HIP;
+  pclean_ctx* ctx = new pclean_ctx();
+  ctx->device = device_id;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete ctx;
+    return PCLEAN_ERR_HIP;
+  }
+  *out = ctx;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_ctx_destroy(pclean_ctx* ctx) {
+  if (!ctx) return PCLEAN_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  pclean_sweep_state_free(ctx);
+  ctx->sym.release();
+  ctx->off.release();
+  ctx->obs.release();
+  ctx->iota.release();
+  ctx->nb.release();
+  ctx->logl.release();
+  for (auto& p : ctx->pair) {
+    p.d.release();
+    p.lat_len.release();
+  }
+  for (auto& c : ctx->cand) {
+    c.cols.release();
+    c.counts.release();
+    c.logc_full.release();
+    c.logc_m1.release();
+    c.stats.release();
+  }
+  for (auto& f : ctx->fn) f.fn.release();
+  for (auto& b : ctx->block) {
+    b.d_terms.release();
+    for (auto& l : b.leaf_cache) l.release();
+  }
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return PCLEAN_OK;
+}
+
+extern "C" const char* pclean_last_error(const pclean_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+// ---------------------------------------------------------------------------
+extern "C" int pclean_load_strings(pclean_ctx* ctx, int32_t n_strings, const uint16_t* sym, const int64_t* off) {
+  if (!ctx || n_strings < 0 || !off || (n_strings > 0 && !sym && off[n_strings] > 0))
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_load_strings: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int64_t total = off[n_strings];
+  int nsym = 0;
+  for (int64_t i = 0; i < total; ++i) nsym = std::max(nsym, (int)sym[i] + 1);
+  if (nsym >= 0xfffe) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "too many distinct symbols");
+  if (ctx->sym.alloc((size_t)std::max<int64_t>(total, 1)) || ctx->off.alloc((size_t)n_strings + 1))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  if (total) HIPCHK(ctx, hipMemcpy(ctx->sym.p, sym, total * sizeof(uint16_t), hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->off.p, off, ((size_t)n_strings + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+  ctx->h_off.assign(off, off + n_strings + 1);
+  ctx->n_strings = n_strings;
+  ctx->n_symbols = nsym;
+  return PCLEAN_OK;
+}
+
+__global__ void iota_kernel(int32_t* p, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = i;
+}
+
+extern "C" int pclean_load_columns(pclean_ctx* ctx, int32_t n_rows, int32_t n_cols, const int32_t* obs) {
+  if (!ctx || n_rows < 0 || n_cols < 0 || (!obs && (int64_t)n_rows * n_cols > 0))
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_load_columns: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)n_rows * n_cols;
+  if (ctx->obs.alloc(std::max<size_t>(n, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  if (n) HIPCHK(ctx, hipMemcpy(ctx->obs.p, obs, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  ctx->n_rows = n_rows;
+  ctx->n_cols = n_cols;
+  return PCLEAN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// AddTypos density pieces (add_typos.jl:61-63), computed once with host libm
+// and shared bit-for-bit by the kernels and (via pclean_get_density_tables) by
+// the parity oracle.
+int pclean_ensure_density(pclean_ctx* ctx, int max_len) {
+  if (max_len <= ctx->max_len) return PCLEAN_OK;
+  const int ml = std::max(max_len, 64);
+  const int mr = (ml + 4) / 5, md = ml;
+  std::vector<double> nb((size_t)(mr + 1) * (md + 1)), logl(ml + 1);
+  for (int r = 0; r <= mr; ++r)
+    for (int d = 0; d <= md; ++d) {
+      double v;
+      if (r == 0)
+        v = d == 0 ? 0.0 : kNegInf;
+      else
+        v = std::lgamma((double)d + r) - std::lgamma(d + 1.0) - std::lgamma((double)r) + r * std::log(0.9) +
+            d * std::log1p(-0.9);
+      nb[(size_t)r * (md + 1) + d] = v;
+    }
+  logl[0] = 0.0;
+  for (int L = 1; L <= ml; ++L) logl[L] = std::log((double)L);
+  if (ctx->nb.alloc(nb.size()) || ctx->logl.alloc(logl.size()))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemcpy(ctx->nb.p, nb.data(), nb.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->logl.p, logl.data(), logl.size() * sizeof(double), hipMemcpyHostToDevice));
+  ctx->h_nb.swap(nb);
+  ctx->h_logl.swap(logl);
+  ctx->max_r = mr;
+  ctx->max_d = md;
+  ctx->max_len = ml;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_get_density_tables(pclean_ctx* ctx, int32_t* max_r, int32_t* max_d, int32_t* max_len,
+                                         double* nb, double* logl) {
+  if (!ctx) return PCLEAN_ERR_ARG;
+  if (ctx->max_len < 0) {
+    int rc = pclean_ensure_density(ctx, 64);
+    if (rc) return rc;
+  }
+  if (max_r) *max_r = ctx->max_r;
+  if (max_d) *max_d = ctx->max_d;
+  if (max_len) *max_len = ctx->max_len;
+  if (nb) memcpy(nb, ctx->h_nb.data(), ctx->h_nb.size() * sizeof(double));
+  if (logl) memcpy(logl, ctx->h_logl.data(), ctx->h_logl.size() * sizeof(double));
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_build_pair_table(pclean_ctx* ctx, int32_t table_id, int32_t n_obs, const int32_t* obs_ids,
+                                       int32_t n_lat, const int32_t* lat_ids, int32_t dist_mode) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || n_obs <= 0 || n_lat <= 0 || !obs_ids || !lat_ids ||
+      (dist_mode != PCLEAN_DIST_OSA && dist_mode != PCLEAN_DIST_DL))
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_build_pair_table: bad arguments");
+  if (ctx->n_strings == 0) return pclean_fail(ctx, PCLEAN_ERR_STATE, "load strings first");
+  if (n_obs > 65535) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "n_obs > 65535 not supported yet");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  PairTable& pt = ctx->pair[table_id];
+  int max_la = 0, max_lb = 0;
+  for (int i = 0; i < n_obs; ++i) {
+    if (obs_ids[i] < 0 || obs_ids[i] >= ctx->n_strings) return pclean_fail(ctx, PCLEAN_ERR_ARG, "obs id out of range");
+    max_la = std::max(max_la, (int)(ctx->h_off[obs_ids[i] + 1] - ctx->h_off[obs_ids[i]]));
+  }
+  for (int i = 0; i < n_lat; ++i) {
+    if (lat_ids[i] < 0 || lat_ids[i] >= ctx->n_strings) return pclean_fail(ctx, PCLEAN_ERR_ARG, "lat id out of range");
+    max_lb = std::max(max_lb, (int)(ctx->h_off[lat_ids[i] + 1] - ctx->h_off[lat_ids[i]]));
+  }
+  pt.n_obs = n_obs;
+  pt.n_lat = n_lat;
+  pt.max_obs_len = max_la;
+  pt.max_lat_len = max_lb;
+  pt.elem_bytes = std::max(max_la, max_lb) <= 255 ? 1 : 2;
+  int rc = pclean_ensure_density(ctx, std::max(max_la, max_lb));
+  if (rc) return rc;
+  if (pt.d.alloc((size_t)n_obs * n_lat * pt.elem_bytes) || pt.lat_len.alloc(n_lat))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  DevBuf<int32_t> d_obs, d_lat;
+  if (d_obs.alloc(n_obs) || d_lat.alloc(n_lat)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemcpy(d_obs.p, obs_ids, n_obs * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(d_lat.p, lat_ids, n_lat * sizeof(int32_t), hipMemcpyHostToDevice));
+  rc = pclean_launch_dist(ctx, pt, d_obs.p, d_lat.p, dist_mode);
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  d_obs.release();
+  d_lat.release();
+  if (rc) return rc;
+  if (e != hipSuccess) return pclean_fail(ctx, PCLEAN_ERR_HIP, "distance kernel failed: %s", hipGetErrorString(e));
+  pt.valid = true;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_set_pair_table(pclean_ctx* ctx, int32_t table_id, int32_t n_obs, int32_t n_lat,
+                                     const uint8_t* table) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || n_obs <= 0 || n_lat <= 0 || !table)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_pair_table: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  PairTable& pt = ctx->pair[table_id];
+  pt.n_obs = n_obs;
+  pt.n_lat = n_lat;
+  pt.elem_bytes = 1;
+  pt.max_lat_len = pt.max_obs_len = 0;
+  int rc = pclean_ensure_density(ctx, 64);
+  if (rc) return rc;
+  if (pt.d.alloc((size_t)n_obs * n_lat) || pt.lat_len.alloc(n_lat))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemcpy(pt.d.p, table, (size_t)n_obs * n_lat, hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemset(pt.lat_len.p, 0, n_lat * sizeof(uint16_t)));
+  pt.valid = true;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_get_pair_table(pclean_ctx* ctx, int32_t table_id, uint16_t* out) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || !out || !ctx->pair[table_id].valid)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_get_pair_table: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  PairTable& pt = ctx->pair[table_id];
+  const size_t n = (size_t)pt.n_obs * pt.n_lat;
+  if (pt.elem_bytes == 2) {
+    HIPCHK(ctx, hipMemcpy(out, pt.d.p, n * 2, hipMemcpyDeviceToHost));
+  } else {
+    std::vector<uint8_t> tmp(n);
+    HIPCHK(ctx, hipMemcpy(tmp.data(), pt.d.p, n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) out[i] = tmp[i];
+  }
+  return PCLEAN_OK;
+}
+
+// ---------------------------------------------------------------------------
+// StringPrior (string_prior.jl:43-61): one lane per string, sequential bigram
+// chain (the sum order is part of the parity contract).
+__global__ void string_prior_kernel(const uint8_t* __restrict__ lm, const int64_t* __restrict__ off, int n,
+                                    int min_len, int max_len, double base, double log28,
+                                    const double* __restrict__ init_logp, const double* __restrict__ trans_logp,
+                                    double* __restrict__ out) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n) return;
+  const int64_t o = off[s];
+  const int len = (int)(off[s + 1] - o);
+  if (len < min_len || len > max_len) {
+    out[s] = -__builtin_inf();
+    return;
+  }
+  double score = base;
+  int prev = -1;
+  for (int i = 0; i < len; ++i) {
+    const double* dist = prev < 0 ? init_logp : trans_logp + prev * 28;
+    const uint8_t c = lm[o + i];
+    prev = c == 255 ? -1 : (int)c;
+    score += prev < 0 ? -log28 : dist[prev];
+  }
+  out[s] = score;
+}
+
+extern "C" int pclean_string_prior_scores(pclean_ctx* ctx, int32_t n_strings, const uint8_t* lm, const int64_t* off,
+                                          int32_t min_len, int32_t max_len, const double* init_logp,
+                                          const double* trans_logp, double* out) {
+  if (!ctx || n_strings < 0 || !off || !init_logp || !trans_logp || !out || max_len < min_len)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_string_prior_scores: bad arguments");
+  if (n_strings == 0) return PCLEAN_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DevBuf<uint8_t> d_lm;
+  DevBuf<int64_t> d_off;
+  DevBuf<double> d_init, d_trans, d_out;
+  const int64_t total = off[n_strings];
+  int rc = PCLEAN_OK;
+  if (d_lm.alloc(std::max<int64_t>(total, 1)) || d_off.alloc(n_strings + 1) || d_init.alloc(28) ||
+      d_trans.alloc(28 * 28) || d_out.alloc(n_strings))
+    rc = pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  hipError_t e = hipSuccess;
+  if (!rc) {
+    if (total) e = hipMemcpy(d_lm.p, lm, total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_off.p, off, (n_strings + 1) * sizeof(int64_t), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_init.p, init_logp, 28 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_trans.p, trans_logp, 28 * 28 * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+      const double base = -std::log((double)(max_len - min_len + 1));
+      hipLaunchKernelGGL(string_prior_kernel, dim3((n_strings + 255) / 256), dim3(256), 0, ctx->stream, d_lm.p,
+                         d_off.p, n_strings, min_len, max_len, base, std::log(28.0), d_init.p, d_trans.p, d_out.p);
+      e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, d_out.p, n_strings * sizeof(double), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) rc = pclean_fail(ctx, PCLEAN_ERR_HIP, "string prior kernel failed: %s", hipGetErrorString(e));
+  }
+  d_lm.release();
+  d_off.release();
+  d_init.release();
+  d_trans.release();
+  d_out.release();
+  return rc;
+}
+
+// ---------------------------------------------------------------------------
+// Candidate tables.  CRP prior pieces follow proposal_compiler.jl:165-171:
+//   existing k: log(count_k - discount) - log(total + strength)
+//   new       : log(strength + discount * n_rows) - log(total + strength)
+// with the evidence row's own reference removed first (row_inference.jl:115-126),
+// hence the "_m1" variants.
+extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_rows, int32_t n_cols,
+                                const int32_t* cols, const int64_t* counts, double strength, double discount) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || n_rows < 0 || n_cols < 0 || !counts ||
+      (!cols && (int64_t)n_rows * n_cols > 0))
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_table: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CandTable& t = ctx->cand[table_id];
+  t.is_options = false;
+  t.n_rows = n_rows;
+  t.n_cols = n_cols;
+  const size_t n = (size_t)n_rows * n_cols;
+  const size_t nr = std::max<size_t>(n_rows, 1);
+  if (t.cols.alloc(std::max<size_t>(n, 1)) || t.counts.alloc(nr) || t.logc_full.alloc(nr) || t.logc_m1.alloc(nr) ||
+      t.stats.alloc(nr))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  int64_t total = 0, live = 0;
+  t.h_counts.assign(counts, counts + n_rows);
+  t.h_logc_full.resize(n_rows);
+  t.h_logc_m1.resize(n_rows);
+  for (int k = 0; k < n_rows; ++k) {
+    const int64_t c = counts[k];
+    if (c < 0) return pclean_fail(ctx, PCLEAN_ERR_ARG, "negative reference count");
+    total += c;
+    live += c > 0;
+    t.h_logc_full[k] = c > 0 ? std::log((double)c - discount) : kNegInf;
+    t.h_logc_m1[k] = c > 1 ? std::log((double)(c - 1) - discount) : kNegInf;
+  }
+  t.scal[0] = std::log((double)total + strength);
+  t.scal[1] = std::log((double)(total - 1) + strength);
+  t.scal[2] = std::log(strength + discount * (double)live);
+  t.scal[3] = std::log(strength + discount * (double)(live - 1));
+  if (n) HIPCHK(ctx, hipMemcpy(t.cols.p, cols, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (n_rows) {
+    HIPCHK(ctx, hipMemcpy(t.counts.p, counts, n_rows * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(t.logc_full.p, t.h_logc_full.data(), n_rows * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(ctx, hipMemcpy(t.logc_m1.p, t.h_logc_m1.data(), n_rows * sizeof(double), hipMemcpyHostToDevice));
+  }
+  t.valid = true;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_set_options(pclean_ctx* ctx, int32_t table_id, int32_t n_options, const int32_t* values,
+                                  const double* logp) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || n_options <= 0 || !values || !logp)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_options: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CandTable& t = ctx->cand[table_id];
+  t.is_options = true;
+  t.n_rows = n_options;
+  t.n_cols = 1;
+  if (t.cols.alloc(n_options) || t.logc_full.alloc(n_options))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemcpy(t.cols.p, values, n_options * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(t.logc_full.p, logp, n_options * sizeof(double), hipMemcpyHostToDevice));
+  t.h_logc_full.assign(logp, logp + n_options);
+  t.h_logc_m1.clear();
+  t.h_counts.clear();
+  t.scal[0] = t.scal[1] = 0.0;
+  t.scal[2] = t.scal[3] = kNegInf;
+  t.valid = true;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_set_fn_table(pclean_ctx* ctx, int32_t fn_id, int32_t n_a, int32_t n_b, const int32_t* fn) {
+  if (!ctx || fn_id < 0 || fn_id >= PCLEAN_MAX_TABLES || n_a <= 0 || n_b <= 0 || !fn)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_fn_table: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  FnTable& f = ctx->fn[fn_id];
+  if (f.fn.alloc((size_t)n_a * n_b)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemcpy(f.fn.p, fn, (size_t)n_a * n_b * sizeof(int32_t), hipMemcpyHostToDevice));
+  f.n_a = n_a;
+  f.n_b = n_b;
+  f.valid = true;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_get_table_priors(pclean_ctx* ctx, int32_t table_id, double* logc_full, double* logc_m1,
+                                       double* scal4) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || !ctx->cand[table_id].valid)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_get_table_priors: bad arguments");
+  CandTable& t = ctx->cand[table_id];
+  if (logc_full) memcpy(logc_full, t.h_logc_full.data(), t.h_logc_full.size() * sizeof(double));
+  if (logc_m1 && !t.is_options) memcpy(logc_m1, t.h_logc_m1.data(), t.h_logc_m1.size() * sizeof(double));
+  if (scal4) memcpy(scal4, t.scal, 4 * sizeof(double));
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_load_block(pclean_ctx* ctx, int32_t block_id, int32_t n_nodes, const pclean_node* nodes,
+                                 int32_t n_terms, const pclean_term* terms, int32_t n_children,
+                                 const int32_t* children, int32_t n_colmap, const int32_t* colmap, int32_t n_ctx,
+                                 const int32_t* ctx_src_block, const int32_t* ctx_src_col) {
+  if (!ctx || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || n_nodes <= 0 || !nodes || n_terms < 0 ||
+      (n_terms > 0 && !terms) || n_children < 0 || (n_children > 0 && !children) || n_colmap < 0 ||
+      (n_colmap > 0 && !colmap) || (n_colmap & 1) || n_ctx < 0 || n_ctx > PCLEAN_MAX_CTX)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_load_block: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Block& b = ctx->block[block_id];
+  for (int i = 0; i < n_nodes; ++i) {
+    const pclean_node& nd = nodes[i];
+    if (nd.table < 0 || nd.table >= PCLEAN_MAX_TABLES || nd.term_begin < 0 || nd.term_begin + nd.n_terms > n_terms ||
+        nd.child_begin < 0 || nd.child_begin + nd.n_children > n_children || nd.parent >= n_nodes)
+      return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_load_block: node %d malformed", i);
+  }
+  for (int i = 0; i < n_children; ++i)
+    if (children[i] <= 0 || children[i] >= n_nodes)
+      return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_load_block: child id out of range");
+  for (int i = 0; i < n_terms; ++i) {
+    const pclean_term& tm = terms[i];
+    if (tm.pair_table < 0 || tm.pair_table >= PCLEAN_MAX_TABLES || tm.ctx_slot >= n_ctx ||
+        (tm.ctx_slot >= 0 && (tm.fn_table < 0 || tm.fn_table >= PCLEAN_MAX_TABLES)))
+      return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_load_block: term %d malformed", i);
+  }
+  b.nodes.assign(nodes, nodes + n_nodes);
+  b.terms.assign(terms, terms + n_terms);
+  b.children.assign(children, children + n_children);
+  b.colmap.assign(colmap, colmap + n_colmap);
+  b.n_ctx = n_ctx;
+  for (int s = 0; s < n_ctx; ++s) {
+    b.ctx_src_block[s] = ctx_src_block[s];
+    b.ctx_src_col[s] = ctx_src_col[s];
+  }
+  if (b.d_terms.alloc(std::max(n_terms, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  if (n_terms) HIPCHK(ctx, hipMemcpy(b.d_terms.p, terms, n_terms * sizeof(pclean_term), hipMemcpyHostToDevice));
+  for (auto& l : b.leaf_cache) l.release();
+  b.leaf_cache.clear();
+  b.leaf_cache.resize(n_nodes);
+  b.valid = true;
+  return PCLEAN_OK;
+}

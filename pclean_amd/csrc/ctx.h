@@ -1,0 +1,142 @@
+// Internal state of libpclean_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pclean_hip.h"
+
+#define PCLEAN_MAX_TABLES 64
+#define PCLEAN_MAX_BLOCKS 8
+
+// RAII-less device buffer: freed by ctx destroy / reassign.
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(size_t count) {
+    if (count <= n && p) return 0;
+    release();
+    if (count == 0) return 0;
+    if (hipMalloc((void**)&p, count * sizeof(T)) != hipSuccess) {
+      p = nullptr;
+      n = 0;
+      return -1;
+    }
+    n = count;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+};
+
+struct PairTable {
+  bool valid = false;
+  int32_t n_obs = 0, n_lat = 0;
+  int32_t elem_bytes = 1;     // 1: uint8 distances, 2: uint16
+  DevBuf<uint8_t> d;          // [n_obs][n_lat] * elem_bytes
+  DevBuf<uint16_t> lat_len;   // word length (characters) of each latent value
+  int32_t max_lat_len = 0, max_obs_len = 0;
+};
+
+struct CandTable {
+  bool valid = false;
+  bool is_options = false;
+  int32_t n_rows = 0, n_cols = 0;
+  DevBuf<int32_t> cols;       // column-major [n_cols][n_rows]
+  DevBuf<int64_t> counts;     // FK tables
+  DevBuf<double> logc_full;   // FK: log(count-discount); options: logp
+  DevBuf<double> logc_m1;     // FK only
+  double scal[4] = {0, 0, 0, 0};  // logden_full, logden_m1, lognew_n, lognew_nm1
+  std::vector<int64_t> h_counts;
+  std::vector<double> h_logc_full, h_logc_m1;
+  DevBuf<int64_t> stats;      // delta reference counts of last sweep
+};
+
+struct FnTable {
+  bool valid = false;
+  int32_t n_a = 0, n_b = 0;
+  DevBuf<int32_t> fn;
+};
+
+struct Block {
+  bool valid = false;
+  std::vector<pclean_node> nodes;
+  std::vector<pclean_term> terms;
+  std::vector<int32_t> children;
+  std::vector<int32_t> colmap;
+  int32_t n_ctx = 0;
+  int32_t ctx_src_block[PCLEAN_MAX_CTX] = {-1, -1};
+  int32_t ctx_src_col[PCLEAN_MAX_CTX] = {-1, -1};
+  DevBuf<pclean_term> d_terms;
+  // per-sweep work buffers live in Sweep state (sweep.hip)
+  std::vector<DevBuf<double>> leaf_cache;  // per node: marginal per unique observed value
+  std::vector<int32_t> new_rows_host, new_vals_host;
+};
+
+struct pclean_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // string pool
+  int32_t n_strings = 0;
+  DevBuf<uint16_t> sym;
+  DevBuf<int64_t> off;
+  std::vector<int64_t> h_off;
+  int32_t n_symbols = 0;
+
+  // observed columns
+  int32_t n_rows = 0, n_cols = 0;
+  DevBuf<int32_t> obs;  // [n_cols][n_rows]
+  DevBuf<int32_t> iota; // identity column for per-unique-value leaf caches
+
+  // density tables
+  int32_t max_r = -1, max_d = -1, max_len = -1;
+  std::vector<double> h_nb, h_logl;
+  DevBuf<double> nb, logl;
+
+  PairTable pair[PCLEAN_MAX_TABLES];
+  CandTable cand[PCLEAN_MAX_TABLES];
+  FnTable fn[PCLEAN_MAX_TABLES];
+  Block block[PCLEAN_MAX_BLOCKS];
+
+  pclean_timing timing = {};
+  void* sweep_state = nullptr;  // owned by sweep.hip
+};
+
+inline int pclean_fail(pclean_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    ctx->err = buf;
+  }
+  return code;
+}
+
+#define HIPCHK(ctx, call)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return pclean_fail(ctx, PCLEAN_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                         __FILE__, __LINE__);                                                  \
+  } while (0)
+
+// dist_kernels.hip
+int pclean_launch_dist(pclean_ctx* ctx, PairTable& pt, const int32_t* d_obs_ids, const int32_t* d_lat_ids,
+                       int dist_mode);
+// density tables (api.hip)
+int pclean_ensure_density(pclean_ctx* ctx, int max_len);
+// sweep.hip
+void pclean_sweep_state_free(pclean_ctx* ctx);
