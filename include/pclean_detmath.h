@@ -28,7 +28,7 @@
 #include <string.h>
 
 #if defined(__HIPCC__)
-#define PCLEAN_HD __host__ __device__ __forceinline__
+#define PCLEAN_HD __attribute__((host)) __attribute__((device)) inline __attribute__((always_inline))
 #else
 #define PCLEAN_HD static inline
 #endif
@@ -39,12 +39,12 @@
 
 PCLEAN_HD double pclean_bits2d(uint64_t b) {
   double d;
-  memcpy(&d, &b, 8);
+  __builtin_memcpy(&d, &b, 8);
   return d;
 }
 PCLEAN_HD uint64_t pclean_d2bits(double d) {
   uint64_t b;
-  memcpy(&b, &d, 8);
+  __builtin_memcpy(&b, &d, 8);
   return b;
 }
 
@@ -148,11 +148,10 @@ PCLEAN_HD double pclean_lse_from_fix(double m, uint64_t U) {
 
 /* floor(R * U / 2^64): a uniform integer in [0, U) from 64 random bits. */
 PCLEAN_HD uint64_t pclean_mulhi64(uint64_t a, uint64_t b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __umul64hi(a, b);
-#else
-  return (uint64_t)(((unsigned __int128)a * (unsigned __int128)b) >> 64);
-#endif
+  const uint64_t a0 = a & 0xffffffffull, a1 = a >> 32, b0 = b & 0xffffffffull, b1 = b >> 32;
+  const uint64_t p00 = a0 * b0, p01 = a0 * b1, p10 = a1 * b0, p11 = a1 * b1;
+  const uint64_t mid = (p00 >> 32) + (p01 & 0xffffffffull) + (p10 & 0xffffffffull);
+  return p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
 }
 
 /* 53-bit uniform double in [0,1) from 64 random bits. */

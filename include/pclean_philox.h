@@ -17,7 +17,7 @@
 #include <stdint.h>
 
 #if defined(__HIPCC__)
-#define PCLEAN_RNG_HD __host__ __device__ __forceinline__
+#define PCLEAN_RNG_HD __attribute__((host)) __attribute__((device)) inline __attribute__((always_inline))
 #else
 #define PCLEAN_RNG_HD static inline
 #endif

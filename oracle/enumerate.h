@@ -112,6 +112,7 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
     if (o < 0) continue; /* explicitly missing observation: add_typos.jl:51-53 */
     const OPair& pt = w.pair[tm.pair_table];
     for (int k = 0; k < n; ++k) {
+      if (fk && t.counts[k] == 0) continue; /* free slot of the latent table */
       int val = t.cols[(size_t)tm.cand_col * n + k];
       if (tm.ctx_slot >= 0) {
         const OFn& f = w.fn[tm.fn_table];
@@ -165,8 +166,7 @@ inline int score_node(const World& w, int block_id, int node_id, int n_items, co
     if (scores)
       for (int k = 0; k < nc; ++k) scores[(size_t)it * nc + k] = s[k];
     for (int j = 0; j < n_draws; ++j) {
-      uint64_t R = pclean_rand64(seed, (uint32_t)rows[it], PCLEAN_SITE_NODE(block_id, node_id), (uint32_t)(j + 1),
-                                 sweep);
+      uint64_t R = pclean_rand64(seed, (uint32_t)rows[it], PCLEAN_SITE_NODE(block_id, node_id), (uint32_t)j, sweep);
       int k = fix_draw(s, f, R);
       draws[(size_t)it * n_draws + j] = (fk && k == t.n_rows) ? PCLEAN_CHOICE_NEW : k;
     }

@@ -14,6 +14,7 @@
 #include "../include/pclean_philox.h"
 #include "densities.h"
 #include "enumerate.h"
+#include "sweep.h"
 
 extern "C" {
 
@@ -171,6 +172,62 @@ int pco_score_node(const pco::World* w, int block_id, int node_id, int n_items, 
                    int n_draws, double* lse, double* scores, int32_t* draws) {
   return pco::score_node(*w, block_id, node_id, n_items, rows, ctxv, excl, snew, seed, sweep, n_draws, lse, scores,
                          draws);
+}
+
+/* ---- particle primitives -------------------------------------------------- */
+void pco_maybe_resample(int n_rows, int P, const double* logw, int retain_first, uint64_t seed, uint32_t sweep,
+                        uint32_t block, int64_t row_offset, int32_t* ancestors, double* logml_inc, double* ess) {
+  for (int i = 0; i < n_rows; ++i) {
+    std::vector<double> w(logw + (size_t)i * P, logw + (size_t)(i + 1) * P);
+    std::vector<int> anc;
+    double inc, e;
+    pco::maybe_resample(w, retain_first != 0, seed, (uint32_t)(i + row_offset), sweep, block, anc, inc, &e);
+    for (int p = 0; p < P; ++p) ancestors[(size_t)i * P + p] = anc[p];
+    logml_inc[i] = inc;
+    if (ess) ess[i] = e;
+  }
+}
+void pco_final_choice(int n_rows, int P, const double* logw, int use_mh, int is_csmc, uint64_t seed, uint32_t sweep,
+                      int64_t row_offset, int32_t* chosen, double* log_total) {
+  for (int i = 0; i < n_rows; ++i) {
+    std::vector<double> w(logw + (size_t)i * P, logw + (size_t)(i + 1) * P);
+    double lt;
+    chosen[i] = pco::final_choice(w, use_mh != 0, is_csmc != 0, seed, (uint32_t)(i + row_offset), sweep, &lt);
+    if (log_total) log_total[i] = lt;
+  }
+}
+
+/* ---- whole sweep, batched schedule (the GPU's parity target) --------------- */
+static std::vector<pco::NewRow> g_new_rows;
+int pco_sweep_batched(const pco::World* w, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep, int n_blocks,
+                      int64_t row_offset, const int32_t* cur, int32_t* choice, int32_t* chosen, double* logml) {
+  const int N = w->n_rows;
+  g_new_rows.clear();
+  std::vector<int32_t> c(n_blocks), ch(n_blocks);
+  for (int i = 0; i < N; ++i) {
+    for (int b = 0; b < n_blocks; ++b) c[b] = cur[(size_t)b * N + i];
+    int cp;
+    double ml;
+    pco::run_smc_row(*w, *cfg, seed, sweep, n_blocks, i, row_offset, c.data(), ch.data(), &cp, &ml, g_new_rows);
+    for (int b = 0; b < n_blocks; ++b) choice[(size_t)b * N + i] = ch[b];
+    if (chosen) chosen[i] = cp;
+    if (logml) logml[i] = ml;
+  }
+  return 0;
+}
+int pco_new_rows_count(int block) {
+  int n = 0;
+  for (auto& r : g_new_rows) n += r.block == block;
+  return n;
+}
+void pco_new_rows_get(int block, int n_nodes, int32_t* rows, int32_t* vals) {
+  int j = 0;
+  for (auto& r : g_new_rows)
+    if (r.block == block) {
+      rows[j] = r.row;
+      for (int k = 0; k < n_nodes; ++k) vals[(size_t)j * n_nodes + k] = r.vals[k];
+      ++j;
+    }
 }
 
 } /* extern "C" */

@@ -1,0 +1,275 @@
+/* oracle/sweep.h — TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement of one rejuvenation sweep over the rows of the observed
+ * class: pgibbs_sweep!'s inner loop (src/inference/inference.jl:66-79) calling
+ * run_smc! (src/inference/row_inference.jl:108-187) with
+ *   - block proposals by enumeration (proposal_compiler.jl, restated in enumerate.h),
+ *   - the incremental weight p - q of a fully enumerated block = its log marginal
+ *     (block_proposal.jl:160-190),
+ *   - maybe_resample between blocks (row_inference.jl:87-105,152-155),
+ *   - final Categorical / MH choice (row_inference.jl:158-165),
+ *   - return value log_ml + log_total - log P (186).
+ *
+ * Two schedules:
+ *   batched     — every row is updated against the latent tables as given (what
+ *                 the GPU computes; bit-exact parity target);
+ *   sequential  — row i sees the reference counts left by rows < i, as the
+ *                 reference does (row_inference.jl:169-185); used as the
+ *                 single-thread CPU baseline.  New-row creation / deletion inside
+ *                 the sequential sweep is applied to counts only when the
+ *                 chosen referent exists.
+ */
+#ifndef PCLEAN_ORACLE_SWEEP_H
+#define PCLEAN_ORACLE_SWEEP_H
+
+#include <cmath>
+#include <vector>
+
+#include "enumerate.h"
+
+namespace pco {
+
+struct RowCtx {
+  const World* w;
+  int block;
+  int row;
+  const int32_t* ctxv;
+  uint64_t seed;
+  uint32_t sweep;
+  int64_t row_offset;
+};
+
+inline int child_excl_of(const World& w, const OBlock& b, int parent_node, int child_node, int parent_excl) {
+  const pclean_node& pn = b.nodes[parent_node];
+  const pclean_node& cn = b.nodes[child_node];
+  if (cn.kind != PCLEAN_NODE_FK || parent_excl < 0) return -1;
+  const OTable& t = w.table[pn.table];
+  if (t.counts[parent_excl] > 1) return -1;
+  return t.cols[(size_t)cn.parent_fk_col * t.n_rows + parent_excl];
+}
+
+/* scores of a node with its new-row branch evaluated recursively (process_plan!) */
+inline double eval_tree(const RowCtx& rc, int node, int excl, std::vector<double>* scores_out);
+
+inline double snew_of(const RowCtx& rc, int node, int excl) {
+  const OBlock& b = rc.w->block[rc.block];
+  const pclean_node& nd = b.nodes[node];
+  double snew = 0.0;
+  for (int c = 0; c < nd.n_children; ++c) {
+    const int cid = b.children[nd.child_begin + c];
+    snew += eval_tree(rc, cid, child_excl_of(*rc.w, b, node, cid, excl), nullptr);
+  }
+  return snew;
+}
+
+inline double eval_tree(const RowCtx& rc, int node, int excl, std::vector<double>* scores_out) {
+  const OBlock& b = rc.w->block[rc.block];
+  const pclean_node& nd = b.nodes[node];
+  double snew = NEG_INF;
+  if (nd.kind == PCLEAN_NODE_FK) snew = snew_of(rc, node, excl);
+  std::vector<double> s;
+  node_scores(*rc.w, rc.block, node, rc.row, rc.ctxv, excl, snew, s);
+  FixSum f = fix_sum(s);
+  if (scores_out) scores_out->swap(s);
+  return pclean_lse_from_fix(f.m, f.U);
+}
+
+/* draw sub-choices of a freshly proposed row of `node`'s table */
+inline void sample_new(const RowCtx& rc, int node, int excl, uint32_t particle, int32_t* vals) {
+  const OBlock& b = rc.w->block[rc.block];
+  const pclean_node& nd = b.nodes[node];
+  const uint32_t rr = (uint32_t)((int64_t)rc.row + rc.row_offset);
+  for (int c = 0; c < nd.n_children; ++c) {
+    const int cid = b.children[nd.child_begin + c];
+    const pclean_node& cn = b.nodes[cid];
+    const int cex = child_excl_of(*rc.w, b, node, cid, excl);
+    std::vector<double> s;
+    eval_tree(rc, cid, cex, &s);
+    FixSum f = fix_sum(s);
+    const int k = fix_draw(s, f, pclean_rand64(rc.seed, rr, PCLEAN_SITE_NODE(rc.block, cid), particle, rc.sweep));
+    const int n = rc.w->table[cn.table].n_rows;
+    if (cn.kind == PCLEAN_NODE_FK && k == n) {
+      vals[cid] = PCLEAN_CHOICE_NEW;
+      sample_new(rc, cid, cex, particle, vals);
+    } else {
+      vals[cid] = k;
+    }
+  }
+}
+
+inline int32_t resolve_new_value(const World& w, const OBlock& b, int node, int col, const int32_t* vals) {
+  for (int depth = 0; depth < 16; ++depth) {
+    const int cn = b.colmap[2 * (b.nodes[node].colmap_begin + col)];
+    const int cc = b.colmap[2 * (b.nodes[node].colmap_begin + col) + 1];
+    if (cn < 0) return -1;
+    const int choice = vals[cn];
+    const OTable& t = w.table[b.nodes[cn].table];
+    if (b.nodes[cn].kind == PCLEAN_NODE_LEAF) return t.cols[choice];
+    if (choice >= 0) return t.cols[(size_t)cc * t.n_rows + choice];
+    node = cn;
+    col = cc;
+  }
+  return -1;
+}
+
+struct NewRow {
+  int block, row;
+  std::vector<int32_t> vals;
+};
+
+struct PartW {
+  double m;
+  uint64_t U;
+  std::vector<uint64_t> u;
+};
+inline PartW part_weights(const std::vector<double>& w) {
+  PartW p{NEG_INF, 0, std::vector<uint64_t>(w.size())};
+  for (double v : w) p.m = v > p.m ? v : p.m;
+  for (size_t i = 0; i < w.size(); ++i) {
+    p.u[i] = p.m == NEG_INF ? 0 : pclean_fixw(w[i] - p.m);
+    p.U += p.u[i];
+  }
+  return p;
+}
+inline int part_pick(const PartW& p, uint64_t R) {
+  const int P = (int)p.u.size();
+  if (p.U == 0) return P - 1;
+  const uint64_t x = pclean_mulhi64(R, p.U);
+  uint64_t acc = 0;
+  for (int i = 0; i < P; ++i) {
+    acc += p.u[i];
+    if (acc > x) return i;
+  }
+  return P - 1;
+}
+
+/* maybe_resample (row_inference.jl:87-105) in the fixed-point contract */
+inline bool maybe_resample(const std::vector<double>& w, bool retain_first, uint64_t seed, uint32_t rr, uint32_t sweep,
+                           uint32_t block, std::vector<int>& anc, double& inc, double* ess_out) {
+  const int P = (int)w.size();
+  PartW pw = part_weights(w);
+  const double Ud = (double)pw.U;
+  double s2 = 0.0;
+  for (int p = 0; p < P; ++p) s2 += (double)pw.u[p] * (double)pw.u[p];
+  const double ess = pw.U ? (Ud * Ud) / s2 : 0.0;
+  if (ess_out) *ess_out = ess;
+  anc.resize(P);
+  if (ess < (double)P / 2.0) {
+    for (int p = 0; p < P; ++p)
+      anc[p] = (p == 0 && retain_first) ? 0
+                                        : part_pick(pw, pclean_rand64(seed, rr, PCLEAN_SITE_RESAMPLE(block), (uint32_t)p,
+                                                                      sweep));
+    inc = pclean_lse_from_fix(pw.m, pw.U) - pclean_log((double)P);
+    return true;
+  }
+  for (int p = 0; p < P; ++p) anc[p] = p;
+  inc = 0.0;
+  return false;
+}
+
+inline int final_choice(const std::vector<double>& w, bool use_mh, bool csmc, uint64_t seed, uint32_t rr, uint32_t sweep,
+                        double* log_total) {
+  const int P = (int)w.size();
+  PartW pw = part_weights(w);
+  if (log_total) *log_total = pclean_lse_from_fix(pw.m, pw.U);
+  if (use_mh && csmc && P >= 2) { /* row_inference.jl:161-162 */
+    const double Ud = (double)pw.U;
+    const double w0 = (double)pw.u[0] / Ud, w1 = (double)pw.u[1] / Ud;
+    double ratio = w1 / (1e-10 + w0);
+    if (ratio > 1.0) ratio = 1.0;
+    const double x = pclean_u01(pclean_rand64(seed, rr, PCLEAN_SITE_MH, 0u, sweep));
+    return (pw.U != 0 && x < ratio) ? 1 : 0;
+  }
+  return part_pick(pw, pclean_rand64(seed, rr, PCLEAN_SITE_FINAL, 0u, sweep));
+}
+
+/* One row of run_smc! (CSMC when cur >= 0).  Outputs the chosen referent per block and
+ * the sampled contents of new rows. */
+inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t seed, uint32_t sweep, int n_blocks,
+                        int row, int64_t row_offset, const int32_t* cur /*[n_blocks]*/, int32_t* choice /*[n_blocks]*/,
+                        int32_t* chosen_particle, double* logml, std::vector<NewRow>& new_rows) {
+  const bool use_mh = cfg.use_mh_instead_of_pg != 0;
+  const int P = use_mh ? 2 : cfg.num_particles;
+  const uint32_t rr = (uint32_t)((int64_t)row + row_offset);
+  std::vector<double> wts(P, 0.0);
+  std::vector<std::vector<int32_t>> pch(n_blocks, std::vector<int32_t>(P));
+  std::vector<std::vector<std::vector<int32_t>>> pvals(n_blocks, std::vector<std::vector<int32_t>>(P));
+  double acc = 0.0;
+  for (int bi = 0; bi < n_blocks; ++bi) {
+    const OBlock& b = w.block[bi];
+    const int n_root = w.table[b.nodes[0].table].n_rows;
+    const int excl = cur[bi];
+    auto ctx_of = [&](int p, int32_t* out) {
+      for (int s = 0; s < PCLEAN_MAX_CTX; ++s) {
+        out[s] = 0;
+        if (s >= b.n_ctx) continue;
+        const int sb = b.ctx_src_block[s], sc = b.ctx_src_col[s];
+        const OBlock& src = w.block[sb];
+        const OTable& rt = w.table[src.nodes[0].table];
+        const int ch = pch[sb][p];
+        out[s] = ch >= 0 ? rt.cols[(size_t)sc * rt.n_rows + ch] : resolve_new_value(w, src, 0, sc, pvals[sb][p].data());
+      }
+    };
+    auto finish_particle = [&](int p, const RowCtx& rc, const std::vector<double>& s, const FixSum& f) {
+      int k = fix_draw(s, f, pclean_rand64(seed, rr, PCLEAN_SITE_NODE(bi, 0), (uint32_t)p, sweep));
+      int c = k == n_root ? PCLEAN_CHOICE_NEW : k;
+      if (p == 0 && cur[bi] >= 0) c = cur[bi]; /* retained particle, row_inference.jl:143-145 */
+      pch[bi][p] = c;
+      if (c == PCLEAN_CHOICE_NEW) {
+        pvals[bi][p].assign(b.nodes.size(), -2);
+        pvals[bi][p][0] = PCLEAN_CHOICE_NEW;
+        sample_new(rc, 0, excl, (uint32_t)p, pvals[bi][p].data());
+      }
+    };
+    if (b.n_ctx == 0) {
+      RowCtx rc{&w, bi, row, nullptr, seed, sweep, row_offset};
+      std::vector<double> s;
+      const double lse = eval_tree(rc, 0, excl, &s);
+      FixSum f = fix_sum(s);
+      for (int p = 0; p < P; ++p) {
+        finish_particle(p, rc, s, f);
+        wts[p] += lse;
+      }
+    } else {
+      for (int p = 0; p < P; ++p) {
+        int32_t cv[PCLEAN_MAX_CTX];
+        ctx_of(p, cv);
+        RowCtx rc{&w, bi, row, cv, seed, sweep, row_offset};
+        std::vector<double> s;
+        const double lse = eval_tree(rc, 0, excl, &s);
+        FixSum f = fix_sum(s);
+        finish_particle(p, rc, s, f);
+        wts[p] += lse;
+      }
+    }
+    if (!use_mh && bi < n_blocks - 1) {
+      std::vector<int> anc;
+      double inc;
+      if (maybe_resample(wts, cur[bi] >= 0, seed, rr, sweep, (uint32_t)bi, anc, inc, nullptr)) {
+        for (int k = 0; k <= bi; ++k) {
+          std::vector<int32_t> nc(P);
+          std::vector<std::vector<int32_t>> nv(P);
+          for (int p = 0; p < P; ++p) {
+            nc[p] = pch[k][anc[p]];
+            nv[p] = pvals[k][anc[p]];
+          }
+          pch[k].swap(nc);
+          pvals[k].swap(nv);
+        }
+        for (int p = 0; p < P; ++p) wts[p] = 0.0;
+      }
+      acc += inc;
+    }
+  }
+  double log_total;
+  const int c = final_choice(wts, use_mh, cur[0] >= 0, seed, rr, sweep, &log_total);
+  if (chosen_particle) *chosen_particle = c;
+  if (logml) *logml = acc + log_total - pclean_log((double)P);
+  for (int bi = 0; bi < n_blocks; ++bi) {
+    choice[bi] = pch[bi][c];
+    if (pch[bi][c] == PCLEAN_CHOICE_NEW) new_rows.push_back(NewRow{bi, row, pvals[bi][c]});
+  }
+}
+
+} /* namespace pco */
+#endif

@@ -1,0 +1,195 @@
+// Enumeration kernel: rows x candidate-referents proposal scoring, per-item
+// fixed-point log-sum-exp and inverse-CDF categorical draws.
+//
+// Takes over the enumeration loops the reference JIT-generates per block
+// (src/inference/proposal_compiler.jl:131-252 ForeignKeyNode, 55-129 discrete
+// RandomChoiceNode) plus the CRP prior (165-171) and the AddTypos densities
+// they call (src/distributions/add_typos.jl:50-66, via the pair tables).
+//
+// One workgroup (256 lanes = 4 wavefronts) per work item:
+//   phase 1  lane-strided over candidates: coalesced loads of the flattened
+//            latent table columns, gather of the pair-table byte, fp64 density
+//            epilogue, score -> LDS
+//   phase 2  wave-shuffle + LDS max reduction
+//   phase 3  u_k = floor(exp(s_k - m) 2^40) in place (uint64, integer sums are
+//            order independent => bit-identical to the sequential oracle)
+//   phase 4  per-lane contiguous chunk sums, shuffle scan across the block
+//   phase 5  lse = m + log(U 2^-40); Philox draws located by the owning lane
+#include "../../include/pclean_detmath.h"
+#include "../../include/pclean_philox.h"
+#include "enum.h"
+
+#define HALF_LOG26 1.629048269010741
+#define ADD_TYPOS_IMPOSSIBLE (-1e5)
+
+__device__ __forceinline__ double wave_max(double v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ double term_density(const TermDev& tm, const DensDev& dn, int d, int val) {
+  if (tm.dens_kind == PCLEAN_DENS_EQUAL) return d == 0 ? 0.0 : -__builtin_inf();
+  if (tm.max_typos >= 0 && d > tm.max_typos) return ADD_TYPOS_IMPOSSIBLE;
+  const int L = tm.lat_len[val];
+  const int r = (L + 4) / 5;
+  double l = dn.nb[(size_t)r * dn.nb_stride + d];
+  l -= dn.logl[L] * (double)d;
+  l -= HALF_LOG26 * (double)d;
+  return l;
+}
+
+__global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
+                                                        const ChildrenDev ch, uint64_t seed, uint32_t sweep,
+                                                        uint32_t site, int n_draws, double* __restrict__ lse_out,
+                                                        double* __restrict__ scores_out,
+                                                        int32_t* __restrict__ draws_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.x;
+  const int n = nd.n_cand;
+  const bool fk = nd.kind == PCLEAN_NODE_FK;
+  const int nc = n + (fk ? 1 : 0);
+  double* s = (double*)smem;                            // [nc]
+  uint64_t* u = (uint64_t*)smem;                        // same storage, after phase 3
+  double* red = (double*)(smem + (size_t)((nc + 1) & ~1) * 8);  // [8]
+  uint64_t* wsum = (uint64_t*)(red + 8);                // [8]
+
+  const int row = it.row ? it.row[t] : t;
+  const int excl = it.excl ? it.excl[t] : -1;
+  const int32_t* ctxv = it.ctx ? it.ctx + (size_t)t * PCLEAN_MAX_CTX : nullptr;
+
+  bool deleted = false;
+  double logden = 0.0;
+  if (fk) {
+    const bool excluded = excl >= 0;
+    deleted = excluded && nd.counts[excl] <= 1;
+    logden = excluded ? nd.scal[1] : nd.scal[0];
+  }
+
+  // ---- phase 1: scores ----------------------------------------------------
+  double lmax = -__builtin_inf();
+  for (int k = tid; k < n; k += 256) {
+    double sk;
+    bool live = true;
+    if (fk) {
+      if (nd.counts[k] == 0) {
+        sk = -__builtin_inf();
+        live = false;
+      } else if (k == excl) {
+        sk = deleted ? -__builtin_inf() : nd.logc_m1[k] - logden;
+      } else {
+        sk = nd.logc_full[k] - logden;
+      }
+    } else {
+      sk = nd.logc_full[k];
+    }
+    if (live) {
+      for (int ti = 0; ti < nd.n_terms; ++ti) {
+        const TermDev& tm = nd.terms[ti];
+        const int o = tm.obs_col[row];
+        if (o < 0) continue;
+        int val = tm.cand_col[k];
+        if (tm.ctx_slot >= 0) val = tm.fn[(size_t)ctxv[tm.ctx_slot] * tm.fn_nb + val];
+        const size_t idx = (size_t)o * tm.n_lat + val;
+        const int d = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
+        sk += term_density(tm, dn, d, val);
+      }
+    }
+    s[k] = sk;
+    if (scores_out) scores_out[(size_t)t * nc + k] = sk;
+    lmax = fmax(lmax, sk);
+  }
+  if (fk && tid == 0) {
+    double snew = 0.0;
+    for (int c = 0; c < ch.n; ++c) {
+      size_t idx = (size_t)t;
+      if (ch.obs_col[c]) {
+        const int o = ch.obs_col[c][row];
+        idx = o < 0 ? (size_t)ch.n_obs[c] : (size_t)o;
+      }
+      snew += ch.arr[c][idx];
+    }
+    const double sn = ((deleted ? nd.scal[3] : nd.scal[2]) - logden) + snew;
+    s[n] = sn;
+    if (scores_out) scores_out[(size_t)t * nc + n] = sn;
+    lmax = fmax(lmax, sn);
+  }
+
+  // ---- phase 2: max ----------------------------------------------------------
+  lmax = wave_max(lmax);
+  if (lane == 0) red[wave] = lmax;
+  __syncthreads();
+  const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+
+  // ---- phase 3: fixed-point weights in place ----------------------------------
+  for (int k = tid; k < nc; k += 256) {
+    const double sk = s[k];
+    u[k] = (m == -__builtin_inf()) ? 0ull : pclean_fixw(sk - m);
+  }
+  __syncthreads();
+
+  // ---- phase 4: chunk sums + block scan ---------------------------------------
+  const int chunk = (nc + 255) / 256;
+  const int lo = min(tid * chunk, nc), hi = min(lo + chunk, nc);
+  uint64_t part = 0;
+  for (int k = lo; k < hi; ++k) part += u[k];
+  uint64_t incl = part;
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint64_t base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const uint64_t U = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  const uint64_t pre = base + incl - part;  // exclusive prefix of this lane's chunk
+
+  // ---- phase 5: lse + draws ----------------------------------------------------
+  if (tid == 0 && lse_out) lse_out[t] = pclean_lse_from_fix(m, U);
+  if (n_draws > 0) {
+    const uint32_t rng_row = (uint32_t)((int64_t)row + it.row_offset);
+    for (int j = 0; j < n_draws; ++j) {
+      const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)j;
+      int32_t* dst = draws_out + (size_t)t * n_draws + j;
+      if (U == 0) {
+        if (tid == 0) *dst = fk ? PCLEAN_CHOICE_NEW : n - 1;
+        continue;
+      }
+      const uint64_t R = pclean_rand64(seed, rng_row, site, pid, sweep);
+      const uint64_t x = pclean_mulhi64(R, U);
+      if (x >= pre && x < pre + part) {
+        uint64_t acc = pre;
+        int k = lo;
+        for (; k < hi; ++k) {
+          acc += u[k];
+          if (acc > x) break;
+        }
+        *dst = (fk && k == n) ? PCLEAN_CHOICE_NEW : k;
+      }
+    }
+  }
+}
+
+int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const ChildrenDev& ch, uint64_t seed,
+                       uint32_t sweep, uint32_t site, int n_draws, double* lse_out, double* scores_out,
+                       int32_t* draws_out) {
+  if (it.n <= 0) return PCLEAN_OK;
+  const int nc = nd.n_cand + (nd.kind == PCLEAN_NODE_FK ? 1 : 0);
+  const size_t lds = (size_t)((nc + 1) & ~1) * 8 + 16 * 8;
+  if (lds > 160 * 1024)
+    return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "candidate table with %d rows exceeds the LDS-resident enumeration kernel",
+                       nd.n_cand);
+  DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0};
+  static size_t lds_set = 0;
+  if (lds > lds_set) {
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)enum_node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024));
+    lds_set = 160 * 1024;
+  }
+  hipLaunchKernelGGL(enum_node_kernel, dim3(it.n), dim3(256), lds, ctx->stream, nd, dn, it, ch, seed, sweep, site,
+                     n_draws, lse_out, scores_out, draws_out);
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}

@@ -1,41 +1,974 @@
-// Enumeration / sweep entry points (stage-1 placeholder; filled in next).
-#include "ctx.h"
+// Batched rejuvenation sweep of the observed class: host orchestration of the
+// static enumeration plan + the small particle kernels.
+//
+// Reference semantics followed (files under /root/reference/src):
+//   run_smc!           inference/row_inference.jl:108-187 (particles, blocks, final choice)
+//   maybe_resample     row_inference.jl:87-105 (ESS < P/2, multinomial, retained first)
+//   make_block_proposal! / propose_non_enumerable!  block_proposal.jl:24-191: when every
+//       latent choice of a block is enumerated the incremental weight p - q equals the
+//       block's log-marginal (SURVEY §3.3 "key structural fact"), so one enumeration per
+//       (row, block, context) serves all particles and only the draws are per particle.
+//   process_plan!      proposal_compiler.jl:363-388 (children of a new row enumerated
+//       independently; log-marginals added)
+#include <algorithm>
+#include <map>
 
-void pclean_sweep_state_free(pclean_ctx* ctx) { (void)ctx; }
+#include "../../include/pclean_detmath.h"
+#include "../../include/pclean_philox.h"
+#include "enum.h"
 
-extern "C" int pclean_score_node(pclean_ctx* ctx, int32_t, int32_t, int32_t, const int32_t*, const int32_t*,
-                                 const int32_t*, const double*, uint64_t, uint32_t, int32_t, double*, double*,
-                                 int32_t*) {
-  return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_score_node: not built yet");
+// ---------------------------------------------------------------------------
+// device-side plan description for resolving values of freshly sampled rows
+struct PlanDev {
+  int32_t n_nodes;
+  const int32_t* kind;          // [n_nodes]
+  const int32_t* const* cols;   // [n_nodes] base pointer of the node's table columns
+  const int32_t* n_rows;        // [n_nodes] column stride
+  const int32_t* colmap_begin;  // [n_nodes]
+  const int32_t* colmap;        // pairs
+};
+
+__device__ int32_t resolve_new_value(const PlanDev& pl, int node, int col, const int32_t* vals) {
+  for (int depth = 0; depth < 16; ++depth) {
+    const int cn = pl.colmap[2 * (pl.colmap_begin[node] + col)];
+    const int cc = pl.colmap[2 * (pl.colmap_begin[node] + col) + 1];
+    if (cn < 0) return -1;
+    const int choice = vals[cn];
+    if (pl.kind[cn] == PCLEAN_NODE_LEAF) return pl.cols[cn][choice];
+    if (choice >= 0) return pl.cols[cn][(size_t)cc * pl.n_rows[cn] + choice];
+    node = cn;
+    col = cc;
+  }
+  return -1;
 }
-extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config*, uint64_t, uint32_t, int32_t, const int32_t*,
-                            int32_t*, int32_t*, double*) {
-  return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_sweep: not built yet");
+
+// ---------------------------------------------------------------------------
+// small kernels
+__global__ void iota_missing_kernel(int32_t* p, int n_obs) {  // [0..n_obs-1, -1]
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n_obs) p[i] = i < n_obs ? i : -1;
 }
-extern "C" int pclean_get_new_rows(pclean_ctx* ctx, int32_t, int32_t*, int32_t*, int32_t*) {
-  return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_get_new_rows: not built yet");
+
+__global__ void fill_i32_kernel(int32_t* p, size_t n, int32_t v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
 }
-extern "C" int pclean_stats_device_ptr(pclean_ctx* ctx, int32_t, void**, int64_t*) {
-  return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_stats_device_ptr: not built yet");
+__global__ void fill_f64_kernel(double* p, size_t n, double v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
 }
+
+// excl_child[t] = row of the child's table that loses a reference because the
+// parent's excluded row is garbage-collected (dependency_tracking.jl:189-201)
+__global__ void derive_excl_kernel(int n, const int32_t* parent_excl, const int64_t* parent_counts,
+                                   const int32_t* parent_fk_col, int32_t* out) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int e = parent_excl ? parent_excl[t] : -1;
+  out[t] = (e >= 0 && parent_counts[e] <= 1) ? parent_fk_col[e] : -1;
+}
+
+// items of a ctx-dependent block: one per (row, particle)
+__global__ void build_ctx_items_kernel(int n_rows, int P, const int32_t* cur_b, int32_t* it_row, int32_t* it_particle,
+                                       int32_t* it_excl) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n_rows * P) return;
+  const int i = (int)(t / P);
+  it_row[t] = i;
+  it_particle[t] = (int)(t % P);
+  it_excl[t] = cur_b ? cur_b[i] : -1;
+}
+
+struct CtxSrc {
+  int32_t n_ctx;
+  const int32_t* pchoice[PCLEAN_MAX_CTX];  // [n_rows*P] of the source block
+  const int32_t* pnewpos[PCLEAN_MAX_CTX];
+  const int32_t* vals[PCLEAN_MAX_CTX];     // [n_new][n_nodes] of the source block
+  int32_t n_nodes[PCLEAN_MAX_CTX];
+  const int32_t* root_col[PCLEAN_MAX_CTX];  // column of the source block's root table
+  int32_t col[PCLEAN_MAX_CTX];
+  PlanDev plan[PCLEAN_MAX_CTX];
+};
+
+__global__ void gather_ctx_kernel(size_t n_items, CtxSrc cs, int32_t* it_ctx) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_items) return;
+  for (int s = 0; s < PCLEAN_MAX_CTX; ++s) {
+    int32_t v = 0;
+    if (s < cs.n_ctx) {
+      const int choice = cs.pchoice[s][t];
+      if (choice >= 0)
+        v = cs.root_col[s][choice];
+      else
+        v = resolve_new_value(cs.plan[s], 0, cs.col[s], cs.vals[s] + (size_t)cs.pnewpos[s][t] * cs.n_nodes[s]);
+    }
+    it_ctx[t * PCLEAN_MAX_CTX + s] = v;
+  }
+}
+
+// root draws [n_rows][P] (or [n_rows*P][1]) -> particle choices; particle 0 keeps
+// the retained referent under CSMC (row_inference.jl:143-145)
+__global__ void set_pchoice_kernel(int n_rows, int P, const int32_t* draws, const int32_t* cur_b, int32_t* pchoice) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n_rows * P) return;
+  const int i = (int)(t / P), p = (int)(t % P);
+  int c = draws[t];
+  if (p == 0 && cur_b && cur_b[i] >= 0) c = cur_b[i];
+  pchoice[t] = c;
+}
+
+__global__ void add_weight_shared_kernel(int n_rows, int P, const double* lse, double* w) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (size_t)n_rows * P) return;
+  w[t] += lse[t / P];
+}
+__global__ void add_weight_kernel(size_t n, const double* lse, double* w) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) w[t] += lse[t];
+}
+
+// compaction of NEW choices: pass 0 counts, pass 1 fills
+__global__ void compact_new_kernel(size_t n, const int32_t* choice, int fill, unsigned int* counter, int32_t* list,
+                                   int32_t* pos_out) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  if (choice[t] != PCLEAN_CHOICE_NEW) {
+    if (fill && pos_out) pos_out[t] = -1;
+    return;
+  }
+  const unsigned int pos = atomicAdd(counter, 1u);
+  if (fill) {
+    list[pos] = (int32_t)t;
+    if (pos_out) pos_out[t] = (int32_t)pos;
+  }
+}
+
+// sub-list items from a parent list: list[j] indexes the parent's items
+__global__ void sublist_items_kernel(int n, const int32_t* list, const int32_t* p_row, const int32_t* p_ctx,
+                                     const int32_t* p_particle, const int32_t* p_origin, int32_t* row, int32_t* ctxv,
+                                     int32_t* particle, int32_t* origin) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int s = list[j];
+  row[j] = p_row ? p_row[s] : s;
+  particle[j] = p_particle[s];
+  origin[j] = p_origin ? p_origin[s] : j;
+  for (int c = 0; c < PCLEAN_MAX_CTX; ++c) ctxv[j * PCLEAN_MAX_CTX + c] = p_ctx ? p_ctx[s * PCLEAN_MAX_CTX + c] : 0;
+}
+
+// first-level new list from (row, particle) slots of a block
+__global__ void rootlist_items_kernel(int n, int P, const int32_t* list, const int32_t* b_ctx, int ctx_per_item,
+                                      const int32_t* cur_b, int32_t* row, int32_t* ctxv, int32_t* particle,
+                                      int32_t* origin, int32_t* excl) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int slot = list[j];
+  const int i = slot / P;
+  row[j] = i;
+  particle[j] = slot % P;
+  origin[j] = j;
+  excl[j] = cur_b ? cur_b[i] : -1;
+  for (int c = 0; c < PCLEAN_MAX_CTX; ++c)
+    ctxv[j * PCLEAN_MAX_CTX + c] = (b_ctx && ctx_per_item) ? b_ctx[(size_t)slot * PCLEAN_MAX_CTX + c] : 0;
+}
+
+__global__ void scatter_vals_kernel(int n, const int32_t* origin, const int32_t* draws, int n_nodes, int node,
+                                    int32_t* vals) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) vals[(size_t)origin[j] * n_nodes + node] = draws[j];
+}
+__global__ void set_col_kernel(int n, int n_nodes, int node, int32_t v, int32_t* vals) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) vals[(size_t)j * n_nodes + node] = v;
+}
+__global__ void gather_i32_kernel(int n, const int32_t* list, const int32_t* src, int32_t* dst) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) dst[j] = src[list[j]];
+}
+
+// ---- particle kernels ----------------------------------------------------------
+struct FixW {
+  double m;
+  uint64_t U;
+};
+__device__ FixW fix_weights(const double* w, int P, uint64_t* u) {
+  FixW f{-__builtin_inf(), 0};
+  for (int p = 0; p < P; ++p) f.m = fmax(f.m, w[p]);
+  for (int p = 0; p < P; ++p) {
+    u[p] = f.m == -__builtin_inf() ? 0ull : pclean_fixw(w[p] - f.m);
+    f.U += u[p];
+  }
+  return f;
+}
+__device__ int fix_pick(const uint64_t* u, int P, uint64_t U, uint64_t R) {
+  if (U == 0) return P - 1;
+  const uint64_t x = pclean_mulhi64(R, U);
+  uint64_t acc = 0;
+  for (int p = 0; p < P; ++p) {
+    acc += u[p];
+    if (acc > x) return p;
+  }
+  return P - 1;
+}
+
+#define MAXP 64
+
+// row_inference.jl:87-105
+__global__ void maybe_resample_kernel(int n_rows, int P, const double* logw, int retain_first, const int32_t* csmc_flag,
+                                      uint64_t seed, uint32_t sweep, uint32_t block, int64_t row_offset,
+                                      int32_t* ancestors, double* logml_inc, double* ess_out, int32_t* did) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  uint64_t u[MAXP];
+  const double* w = logw + (size_t)i * P;
+  FixW f = fix_weights(w, P, u);
+  const double Ud = (double)f.U;
+  double s2 = 0.0;
+  for (int p = 0; p < P; ++p) s2 += (double)u[p] * (double)u[p];
+  const double ess = f.U ? (Ud * Ud) / s2 : 0.0;
+  if (ess_out) ess_out[i] = ess;
+  const bool retain = csmc_flag ? (csmc_flag[i] >= 0) : (retain_first != 0);
+  if (ess < (double)P / 2.0) {
+    const uint32_t rr = (uint32_t)((int64_t)i + row_offset);
+    for (int p = 0; p < P; ++p) {
+      if (p == 0 && retain)
+        ancestors[(size_t)i * P] = 0;
+      else
+        ancestors[(size_t)i * P + p] =
+            fix_pick(u, P, f.U, pclean_rand64(seed, rr, PCLEAN_SITE_RESAMPLE(block), (uint32_t)p, sweep));
+    }
+    logml_inc[i] = pclean_lse_from_fix(f.m, f.U) - pclean_log((double)P);
+    if (did) did[i] = 1;
+  } else {
+    for (int p = 0; p < P; ++p) ancestors[(size_t)i * P + p] = p;
+    logml_inc[i] = 0.0;
+    if (did) did[i] = 0;
+  }
+}
+
+// apply ancestors: particle-indexed int32 arrays and weights (clone_with_zero_weight, 17-21)
+__global__ void apply_ancestors_kernel(int n_rows, int P, const int32_t* ancestors, int n_arrays, int32_t** arrays,
+                                       double* w, const int32_t* did) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  if (!did[i]) return;
+  int32_t tmp[MAXP];
+  for (int a = 0; a < n_arrays; ++a) {
+    int32_t* arr = arrays[a] + (size_t)i * P;
+    for (int p = 0; p < P; ++p) tmp[p] = arr[ancestors[(size_t)i * P + p]];
+    for (int p = 0; p < P; ++p) arr[p] = tmp[p];
+  }
+  for (int p = 0; p < P; ++p) w[(size_t)i * P + p] = 0.0;
+}
+
+// row_inference.jl:158-165 + return value 186
+__global__ void final_choice_kernel(int n_rows, int P, const double* logw, int use_mh, int is_csmc,
+                                    const int32_t* csmc_flag, uint64_t seed, uint32_t sweep, int64_t row_offset,
+                                    int32_t* chosen, double* log_total) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  uint64_t u[MAXP];
+  FixW f = fix_weights(logw + (size_t)i * P, P, u);
+  const uint32_t rr = (uint32_t)((int64_t)i + row_offset);
+  const bool csmc = csmc_flag ? (csmc_flag[i] >= 0) : (is_csmc != 0);
+  int c;
+  if (use_mh && csmc && P >= 2) {
+    const double Ud = (double)f.U;
+    const double w0 = (double)u[0] / Ud, w1 = (double)u[1] / Ud;
+    double ratio = w1 / (1e-10 + w0);
+    if (ratio > 1.0) ratio = 1.0;
+    const double x = pclean_u01(pclean_rand64(seed, rr, PCLEAN_SITE_MH, 0u, sweep));
+    c = (f.U != 0 && x < ratio) ? 1 : 0;
+  } else {
+    c = fix_pick(u, P, f.U, pclean_rand64(seed, rr, PCLEAN_SITE_FINAL, 0u, sweep));
+  }
+  chosen[i] = c;
+  if (log_total) log_total[i] = pclean_lse_from_fix(f.m, f.U);
+}
+
+__global__ void finish_logml_kernel(int n_rows, int P, const double* log_total, const double* inc, double* logml) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_rows) logml[i] = (inc ? inc[i] : 0.0) + log_total[i] - pclean_log((double)P);
+}
+
+__global__ void select_choice_kernel(int n_rows, int P, const int32_t* chosen, const int32_t* pchoice,
+                                     const int32_t* pnewpos, int32_t* choice, int32_t* chosen_newpos) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const size_t s = (size_t)i * P + chosen[i];
+  choice[i] = pchoice[s];
+  chosen_newpos[i] = pchoice[s] == PCLEAN_CHOICE_NEW ? pnewpos[s] : -1;
+}
+
+__global__ void stats_kernel(int n_rows, const int32_t* cur_b, const int32_t* choice, unsigned long long* stats) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const int o = cur_b ? cur_b[i] : -1, c = choice[i];
+  if (o == c) return;
+  if (o >= 0) atomicAdd(&stats[o], (unsigned long long)(-1ll));
+  if (c >= 0) atomicAdd(&stats[c], 1ull);
+}
+
+__global__ void gather_new_rows_kernel(int n, const int32_t* list, const int32_t* chosen_newpos, const int32_t* vals,
+                                       int n_nodes, int32_t* rows_out, int32_t* vals_out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int i = list[j];
+  rows_out[j] = i;
+  const int32_t* v = vals + (size_t)chosen_newpos[i] * n_nodes;
+  for (int k = 0; k < n_nodes; ++k) vals_out[(size_t)j * n_nodes + k] = v[k];
+}
+__global__ void mark_new_kernel(int n_rows, const int32_t* chosen_newpos, int32_t* flag) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_rows) flag[i] = chosen_newpos[i] >= 0 ? PCLEAN_CHOICE_NEW : 0;
+}
+
+// ---------------------------------------------------------------------------
+// host side
+static inline dim3 grid1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+struct ItemList {  // device arrays describing enumeration work items
+  int n = 0;
+  const int32_t* row = nullptr;
+  const int32_t* ctx = nullptr;
+  const int32_t* particle = nullptr;
+  const int32_t* origin = nullptr;
+};
+
+struct BlockRun {  // per-block device state of one sweep
+  DevBuf<int32_t> pchoice, pnewpos, draws, it_row, it_particle, it_excl, it_ctx, choice, chosen_newpos, vals;
+  DevBuf<double> lse;
+  int n_new = 0;  // rows of vals
+  DevBuf<int32_t> plan_kind, plan_nrows, plan_cmb, plan_colmap;
+  DevBuf<const int32_t*> plan_cols;
+  PlanDev plan{};
+  bool plan_ready = false;
+};
+
+struct SweepState {
+  std::vector<DevBuf<unsigned char>> pool;  // scratch buffers, recycled per sweep
+  size_t pool_used = 0;
+  BlockRun run[PCLEAN_MAX_BLOCKS];
+  DevBuf<int32_t> cur, chosen, ancestors, csmc_flag, did;
+  DevBuf<double> w, log_total, logml_inc, logml_acc, logml;
+  DevBuf<unsigned int> counter;
+  DevBuf<int32_t*> arr_ptrs;
+  std::map<int, DevBuf<int32_t>> leaf_iota;  // key = block*256+node
+  std::map<int, uint64_t> leaf_version;
+  int64_t row_offset = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evs = nullptr, eve = nullptr;
+};
+
+static SweepState* st(pclean_ctx* ctx) {
+  if (!ctx->sweep_state) ctx->sweep_state = new SweepState();
+  return (SweepState*)ctx->sweep_state;
+}
+
+void pclean_sweep_state_free(pclean_ctx* ctx) {
+  if (!ctx->sweep_state) return;
+  SweepState* s = (SweepState*)ctx->sweep_state;
+  for (auto& b : s->pool) b.release();
+  for (auto& r : s->run) {
+    r.pchoice.release(); r.pnewpos.release(); r.draws.release(); r.it_row.release(); r.it_particle.release();
+    r.it_excl.release(); r.it_ctx.release(); r.choice.release(); r.chosen_newpos.release(); r.vals.release();
+    r.lse.release(); r.plan_kind.release(); r.plan_nrows.release(); r.plan_cmb.release(); r.plan_colmap.release();
+    r.plan_cols.release();
+  }
+  s->did.release(); s->cur.release(); s->chosen.release(); s->ancestors.release(); s->csmc_flag.release(); s->w.release();
+  s->log_total.release(); s->logml_inc.release(); s->logml_acc.release(); s->logml.release(); s->counter.release();
+  s->arr_ptrs.release();
+  for (auto& kv : s->leaf_iota) kv.second.release();
+  if (s->ev0) (void)hipEventDestroy(s->ev0);
+  if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->evs) (void)hipEventDestroy(s->evs);
+  if (s->eve) (void)hipEventDestroy(s->eve);
+  delete s;
+  ctx->sweep_state = nullptr;
+}
+
+// bump-style scratch: buffers persist across sweeps, handed out in order
+template <typename T>
+static T* scratch(pclean_ctx* ctx, size_t count) {
+  SweepState* s = st(ctx);
+  if (s->pool_used == s->pool.size()) s->pool.emplace_back();
+  DevBuf<unsigned char>& b = s->pool[s->pool_used++];
+  if (b.alloc(std::max<size_t>(count * sizeof(T), 16))) return nullptr;
+  return (T*)b.p;
+}
+
+static int build_node_dev(pclean_ctx* ctx, const Block& b, int node_id, NodeDev& nd) {
+  const pclean_node& n = b.nodes[node_id];
+  const CandTable& t = ctx->cand[n.table];
+  if (!t.valid) return pclean_fail(ctx, PCLEAN_ERR_STATE, "node %d: candidate table %d not set", node_id, n.table);
+  if (n.n_terms > PCLEAN_MAX_TERMS) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "too many terms on one node");
+  if ((n.kind == PCLEAN_NODE_FK) == t.is_options)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "node %d: kind does not match table %d", node_id, n.table);
+  nd.kind = n.kind;
+  nd.n_cand = t.n_rows;
+  nd.n_terms = n.n_terms;
+  nd.counts = t.counts.p;
+  nd.logc_full = t.logc_full.p;
+  nd.logc_m1 = t.logc_m1.p;
+  memcpy(nd.scal, t.scal, sizeof nd.scal);
+  for (int i = 0; i < n.n_terms; ++i) {
+    const pclean_term& tm = b.terms[n.term_begin + i];
+    const PairTable& pt = ctx->pair[tm.pair_table];
+    if (!pt.valid) return pclean_fail(ctx, PCLEAN_ERR_STATE, "pair table %d not built", tm.pair_table);
+    if (tm.obs_col < 0 || tm.obs_col >= ctx->n_cols || tm.cand_col < 0 || tm.cand_col >= t.n_cols)
+      return pclean_fail(ctx, PCLEAN_ERR_ARG, "term %d: column out of range", n.term_begin + i);
+    TermDev& td = nd.terms[i];
+    td.obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows;
+    td.cand_col = t.cols.p + (size_t)tm.cand_col * t.n_rows;
+    td.pair = pt.d.p;
+    td.lat_len = pt.lat_len.p;
+    td.n_lat = pt.n_lat;
+    td.elem_bytes = pt.elem_bytes;
+    td.dens_kind = tm.dens_kind;
+    td.max_typos = tm.max_typos;
+    td.ctx_slot = tm.ctx_slot;
+    td.fn = nullptr;
+    td.fn_nb = 0;
+    if (tm.ctx_slot >= 0) {
+      const FnTable& f = ctx->fn[tm.fn_table];
+      if (!f.valid) return pclean_fail(ctx, PCLEAN_ERR_STATE, "fn table %d not set", tm.fn_table);
+      td.fn = f.fn.p;
+      td.fn_nb = f.n_b;
+    }
+  }
+  return PCLEAN_OK;
+}
+
+// Per-unique-observed-value marginal of a cacheable leaf (one term, no ctx):
+// cache[u] for u < n_obs, cache[n_obs] for a missing observation.
+static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const double** out, const int32_t** obs_col,
+                             int* n_obs) {
+  Block& b = ctx->block[block_id];
+  const pclean_node& n = b.nodes[node_id];
+  if (n.n_terms != 1) return pclean_fail(ctx, PCLEAN_ERR_ARG, "cacheable leaf %d must have exactly one term", node_id);
+  const pclean_term& tm = b.terms[n.term_begin];
+  if (tm.ctx_slot >= 0) return pclean_fail(ctx, PCLEAN_ERR_ARG, "cacheable leaf %d must not use ctx", node_id);
+  const PairTable& pt = ctx->pair[tm.pair_table];
+  SweepState* s = st(ctx);
+  const int key = block_id * 256 + node_id;
+  const int U = pt.n_obs;
+  DevBuf<int32_t>& io = s->leaf_iota[key];
+  if (io.n < (size_t)U + 1) {
+    if (io.alloc(U + 1)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "alloc");
+    hipLaunchKernelGGL(iota_missing_kernel, grid1(U + 1), dim3(256), 0, ctx->stream, io.p, U);
+  }
+  DevBuf<double>& cache = b.leaf_cache[node_id];
+  if (cache.alloc(U + 1)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "alloc");
+  NodeDev nd;
+  int rc = build_node_dev(ctx, b, node_id, nd);
+  if (rc) return rc;
+  nd.terms[0].obs_col = io.p;  // item t observes value t (or missing for t == U)
+  ItemsDev it{U + 1, 0, nullptr, nullptr, nullptr, nullptr, 0};
+  ChildrenDev ch{};
+  rc = pclean_launch_enum(ctx, nd, it, ch, 0, 0, 0, 0, cache.p, nullptr, nullptr);
+  if (rc) return rc;
+  *out = cache.p;
+  *obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows;
+  *n_obs = U;
+  return PCLEAN_OK;
+}
+
+struct EvalOut {
+  double* lse = nullptr;
+};
+
+// Bottom-up evaluation of one plan sub-tree for a list of items
+// (process_plan!, proposal_compiler.jl:363-388).  excl = per-item excluded row of
+// THIS node's table (device, may be null).  When n_draws > 0 the node also draws.
+static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
+                     uint64_t seed, uint32_t sweep, int n_draws, double* lse_out, int32_t* draws_out,
+                     double* scores_out, const double* snew_override, bool time_it) {
+  Block& b = ctx->block[block_id];
+  const pclean_node& n = b.nodes[node_id];
+  SweepState* s = st(ctx);
+  NodeDev nd;
+  int rc = build_node_dev(ctx, b, node_id, nd);
+  if (rc) return rc;
+  ChildrenDev ch{};
+  if (n.kind == PCLEAN_NODE_FK) {
+    if (snew_override) {
+      ch.n = 1;
+      ch.arr[0] = snew_override;
+      ch.obs_col[0] = nullptr;
+    } else {
+      if (n.n_children > PCLEAN_MAX_CHILDREN) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "too many children");
+      ch.n = n.n_children;
+      const CandTable& t = ctx->cand[n.table];
+      for (int c = 0; c < n.n_children; ++c) {
+        const int cid = b.children[n.child_begin + c];
+        const pclean_node& cn = b.nodes[cid];
+        if (cn.kind == PCLEAN_NODE_LEAF && cn.cacheable) {
+          rc = ensure_leaf_cache(ctx, block_id, cid, &ch.arr[c], &ch.obs_col[c], &ch.n_obs[c]);
+          if (rc) return rc;
+        } else {
+          double* child_lse = scratch<double>(ctx, il.n);
+          if (!child_lse) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+          const int32_t* child_excl = nullptr;
+          if (cn.kind == PCLEAN_NODE_FK && excl) {
+            if (cn.parent_fk_col < 0 || cn.parent_fk_col >= t.n_cols)
+              return pclean_fail(ctx, PCLEAN_ERR_ARG, "node %d: parent_fk_col out of range", cid);
+            int32_t* ce = scratch<int32_t>(ctx, il.n);
+            if (!ce) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+            hipLaunchKernelGGL(derive_excl_kernel, grid1(il.n), dim3(256), 0, ctx->stream, il.n, excl, t.counts.p,
+                               t.cols.p + (size_t)cn.parent_fk_col * t.n_rows, ce);
+            child_excl = ce;
+          }
+          rc = eval_node(ctx, block_id, cid, il, child_excl, seed, sweep, 0, child_lse, nullptr, nullptr, nullptr,
+                         false);
+          if (rc) return rc;
+          ch.arr[c] = child_lse;
+          ch.obs_col[c] = nullptr;
+        }
+      }
+    }
+  }
+  ItemsDev it{il.n, 0, il.row, il.ctx, excl, n_draws == 1 ? il.particle : nullptr, s->row_offset};
+  if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
+  rc = pclean_launch_enum(ctx, nd, it, ch, seed, sweep, PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out,
+                          scores_out, draws_out);
+  if (time_it) (void)hipEventRecord(s->ev1, ctx->stream);
+  return rc;
+}
+
+// Top-down sampling of the children of freshly proposed rows
+// (the per-branch draws of proposal_compiler.jl:115-127 / 233-245 for the blind
+// new-row branch, done lazily only for (row, particle) pairs that picked it).
+static int sample_children(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
+                           uint64_t seed, uint32_t sweep, int32_t* vals, int n_nodes) {
+  Block& b = ctx->block[block_id];
+  const pclean_node& n = b.nodes[node_id];
+  const CandTable& t = ctx->cand[n.table];
+  SweepState* s = st(ctx);
+  for (int c = 0; c < n.n_children; ++c) {
+    const int cid = b.children[n.child_begin + c];
+    const pclean_node& cn = b.nodes[cid];
+    int32_t* draws = scratch<int32_t>(ctx, il.n);
+    if (!draws) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    const int32_t* child_excl = nullptr;
+    if (cn.kind == PCLEAN_NODE_FK && excl) {
+      int32_t* ce = scratch<int32_t>(ctx, il.n);
+      if (!ce) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      hipLaunchKernelGGL(derive_excl_kernel, grid1(il.n), dim3(256), 0, ctx->stream, il.n, excl, t.counts.p,
+                         t.cols.p + (size_t)cn.parent_fk_col * t.n_rows, ce);
+      child_excl = ce;
+    }
+    int rc = eval_node(ctx, block_id, cid, il, child_excl, seed, sweep, 1, nullptr, draws, nullptr, nullptr, false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(scatter_vals_kernel, grid1(il.n), dim3(256), 0, ctx->stream, il.n, il.origin, draws, n_nodes,
+                       cid, vals);
+    if (cn.kind == PCLEAN_NODE_FK && cn.n_children > 0) {
+      // rows of this child that were themselves proposed as NEW
+      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+      hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, draws, 0,
+                         s->counter.p, nullptr, nullptr);
+      unsigned int cnt = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&cnt, s->counter.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (cnt) {
+        int32_t* list = scratch<int32_t>(ctx, cnt);
+        int32_t* row = scratch<int32_t>(ctx, cnt);
+        int32_t* cx = scratch<int32_t>(ctx, (size_t)cnt * PCLEAN_MAX_CTX);
+        int32_t* part = scratch<int32_t>(ctx, cnt);
+        int32_t* org = scratch<int32_t>(ctx, cnt);
+        int32_t* sub_excl = scratch<int32_t>(ctx, cnt);
+        if (!list || !row || !cx || !part || !org || !sub_excl) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+        HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+        hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, draws, 1,
+                           s->counter.p, list, nullptr);
+        hipLaunchKernelGGL(sublist_items_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, list, il.row, il.ctx,
+                           il.particle, il.origin, row, cx, part, org);
+        // exclusion of the child's table for the sub-list = gather of child_excl
+        if (child_excl)
+          hipLaunchKernelGGL(gather_i32_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, list, child_excl,
+                             sub_excl);
+        ItemList sub{(int)cnt, row, cx, part, org};
+        rc = sample_children(ctx, block_id, cid, sub, child_excl ? sub_excl : nullptr, seed, sweep, vals, n_nodes);
+        if (rc) return rc;
+      }
+    }
+  }
+  return PCLEAN_OK;
+}
+
+static int ensure_plan_dev(pclean_ctx* ctx, int block_id) {
+  SweepState* s = st(ctx);
+  BlockRun& r = s->run[block_id];
+  const Block& b = ctx->block[block_id];
+  const int nn = (int)b.nodes.size();
+  std::vector<int32_t> kind(nn), nrows(nn), cmb(nn);
+  std::vector<const int32_t*> cols(nn);
+  for (int i = 0; i < nn; ++i) {
+    const CandTable& t = ctx->cand[b.nodes[i].table];
+    kind[i] = b.nodes[i].kind;
+    nrows[i] = t.n_rows;
+    cmb[i] = b.nodes[i].colmap_begin;
+    cols[i] = t.cols.p;
+  }
+  if (r.plan_kind.alloc(nn) || r.plan_nrows.alloc(nn) || r.plan_cmb.alloc(nn) || r.plan_cols.alloc(nn) ||
+      r.plan_colmap.alloc(std::max<size_t>(b.colmap.size(), 2)))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "alloc");
+  HIPCHK(ctx, hipMemcpyAsync(r.plan_kind.p, kind.data(), nn * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(r.plan_nrows.p, nrows.data(), nn * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(r.plan_cmb.p, cmb.data(), nn * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(r.plan_cols.p, cols.data(), nn * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+  if (!b.colmap.empty())
+    HIPCHK(ctx, hipMemcpyAsync(r.plan_colmap.p, b.colmap.data(), b.colmap.size() * 4, hipMemcpyHostToDevice,
+                               ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+  r.plan = PlanDev{nn, r.plan_kind.p, r.plan_cols.p, r.plan_nrows.p, r.plan_cmb.p, r.plan_colmap.p};
+  return PCLEAN_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int pclean_set_row_offset(pclean_ctx* ctx, int64_t row_offset) {
+  if (!ctx || row_offset < 0) return pclean_fail(ctx, PCLEAN_ERR_ARG, "bad row offset");
+  st(ctx)->row_offset = row_offset;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_score_node(pclean_ctx* ctx, int32_t block_id, int32_t node_id, int32_t n_items,
+                                 const int32_t* rows, const int32_t* ctxv, const int32_t* excl, const double* snew,
+                                 uint64_t seed, uint32_t sweep, int32_t n_draws, double* lse, double* scores,
+                                 int32_t* draws) {
+  if (!ctx || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid || n_items <= 0 || !rows ||
+      n_draws < 0 || (n_draws > 0 && !draws))
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_score_node: bad arguments");
+  Block& b = ctx->block[block_id];
+  if (node_id < 0 || node_id >= (int)b.nodes.size()) return pclean_fail(ctx, PCLEAN_ERR_ARG, "bad node id");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  SweepState* s = st(ctx);
+  s->pool_used = 0;
+  const pclean_node& n = b.nodes[node_id];
+  const CandTable& t = ctx->cand[n.table];
+  const int nc = t.n_rows + (n.kind == PCLEAN_NODE_FK ? 1 : 0);
+  int32_t* d_rows = scratch<int32_t>(ctx, n_items);
+  int32_t* d_ctx = ctxv ? scratch<int32_t>(ctx, (size_t)n_items * PCLEAN_MAX_CTX) : nullptr;
+  int32_t* d_excl = excl ? scratch<int32_t>(ctx, n_items) : nullptr;
+  double* d_snew = snew ? scratch<double>(ctx, n_items) : nullptr;
+  double* d_lse = scratch<double>(ctx, n_items);
+  double* d_scores = scores ? scratch<double>(ctx, (size_t)n_items * nc) : nullptr;
+  int32_t* d_draws = n_draws ? scratch<int32_t>(ctx, (size_t)n_items * n_draws) : nullptr;
+  if (!d_rows || !d_lse || (ctxv && !d_ctx) || (excl && !d_excl) || (snew && !d_snew) || (scores && !d_scores) ||
+      (n_draws && !d_draws))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  HIPCHK(ctx, hipMemcpyAsync(d_rows, rows, n_items * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (ctxv) HIPCHK(ctx, hipMemcpyAsync(d_ctx, ctxv, (size_t)n_items * PCLEAN_MAX_CTX * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (excl) HIPCHK(ctx, hipMemcpyAsync(d_excl, excl, n_items * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (snew) HIPCHK(ctx, hipMemcpyAsync(d_snew, snew, n_items * 8, hipMemcpyHostToDevice, ctx->stream));
+  ItemList il{n_items, d_rows, d_ctx, nullptr, nullptr};
+  // snew given: score this node alone; snew null on an FK node: evaluate its sub-tree
+  int rc = eval_node(ctx, block_id, node_id, il, d_excl, seed, sweep, n_draws, d_lse, d_draws, d_scores,
+                     (n.kind == PCLEAN_NODE_FK && snew) ? d_snew : nullptr, false);
+  if (rc) return rc;
+  if (lse) HIPCHK(ctx, hipMemcpyAsync(lse, d_lse, n_items * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (scores) HIPCHK(ctx, hipMemcpyAsync(scores, d_scores, (size_t)n_items * nc * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (n_draws) HIPCHK(ctx, hipMemcpyAsync(draws, d_draws, (size_t)n_items * n_draws * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLEAN_OK;
+}
+
+// ---------------------------------------------------------------------------
+extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
+                            int32_t n_blocks, const int32_t* cur, int32_t* choice, int32_t* chosen_particle,
+                            double* logml) {
+  if (!ctx || !cfg || n_blocks <= 0 || n_blocks > PCLEAN_MAX_BLOCKS || !cur || !choice)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: bad arguments");
+  const int N = ctx->n_rows;
+  int P = cfg->num_particles;
+  const int use_mh = cfg->use_mh_instead_of_pg != 0;
+  if (use_mh) P = 2;  // infer_config.jl:11-13
+  if (N <= 0) return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_sweep: no observed rows loaded");
+  if (P < 1 || P > MAXP) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: num_particles must be in 1..%d", MAXP);
+  for (int b = 0; b < n_blocks; ++b)
+    if (!ctx->block[b].valid) return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_sweep: block %d not loaded", b);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  SweepState* s = st(ctx);
+  s->pool_used = 0;
+  if (!s->ev0) {
+    HIPCHK(ctx, hipEventCreate(&s->ev0));
+    HIPCHK(ctx, hipEventCreate(&s->ev1));
+    HIPCHK(ctx, hipEventCreate(&s->evs));
+    HIPCHK(ctx, hipEventCreate(&s->eve));
+  }
+  const size_t NP = (size_t)N * P;
+  if (s->cur.alloc((size_t)N * n_blocks) || s->chosen.alloc(N) || s->ancestors.alloc(NP) || s->w.alloc(NP) ||
+      s->log_total.alloc(N) || s->logml_inc.alloc(N) || s->logml_acc.alloc(N) || s->logml.alloc(N) ||
+      s->counter.alloc(4) || s->arr_ptrs.alloc(2 * PCLEAN_MAX_BLOCKS) || s->did.alloc(N))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemcpyAsync(s->cur.p, cur, (size_t)N * n_blocks * 4, hipMemcpyHostToDevice, ctx->stream));
+  (void)hipEventRecord(s->evs, ctx->stream);
+  hipLaunchKernelGGL(fill_f64_kernel, grid1(NP), dim3(256), 0, ctx->stream, s->w.p, NP, 0.0);
+  hipLaunchKernelGGL(fill_f64_kernel, grid1(N), dim3(256), 0, ctx->stream, s->logml_acc.p, (size_t)N, 0.0);
+  ctx->timing = pclean_timing{};
+  float hot_ms = 0.f;
+
+  for (int bi = 0; bi < n_blocks; ++bi) {
+    Block& b = ctx->block[bi];
+    BlockRun& r = s->run[bi];
+    const int nn = (int)b.nodes.size();
+    const int32_t* cur_b = s->cur.p + (size_t)bi * N;
+    if (r.pchoice.alloc(NP) || r.pnewpos.alloc(NP) || r.choice.alloc(N) || r.chosen_newpos.alloc(N))
+      return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+    int rc = ensure_plan_dev(ctx, bi);
+    if (rc) return rc;
+    const bool has_ctx = b.n_ctx > 0;
+    ItemList il;
+    const int32_t* excl;
+    if (!has_ctx) {
+      il = ItemList{N, nullptr, nullptr, nullptr, nullptr};
+      excl = cur_b;
+      if (r.draws.alloc(NP) || r.lse.alloc(N)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+      rc = eval_node(ctx, bi, 0, il, excl, seed, sweep_idx, P, r.lse.p, r.draws.p, nullptr, nullptr, bi == 0);
+      if (rc) return rc;
+      if (bi == 0) {
+        HIPCHK(ctx, hipEventSynchronize(s->ev1));
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, s->ev0, s->ev1));
+        hot_ms += ms;
+        ctx->timing.hot_kernel_launches += 1;
+      }
+      hipLaunchKernelGGL(add_weight_shared_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, r.lse.p, s->w.p);
+    } else {
+      if (r.it_row.alloc(NP) || r.it_particle.alloc(NP) || r.it_excl.alloc(NP) ||
+          r.it_ctx.alloc(NP * PCLEAN_MAX_CTX) || r.draws.alloc(NP) || r.lse.alloc(NP))
+        return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+      hipLaunchKernelGGL(build_ctx_items_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, cur_b, r.it_row.p,
+                         r.it_particle.p, r.it_excl.p);
+      CtxSrc cs{};
+      cs.n_ctx = b.n_ctx;
+      for (int c = 0; c < b.n_ctx; ++c) {
+        const int sb = b.ctx_src_block[c];
+        if (sb < 0 || sb >= bi) return pclean_fail(ctx, PCLEAN_ERR_ARG, "block %d: ctx source must be an earlier block", bi);
+        const Block& src = ctx->block[sb];
+        const CandTable& rt = ctx->cand[src.nodes[0].table];
+        if (b.ctx_src_col[c] < 0 || b.ctx_src_col[c] >= rt.n_cols) return pclean_fail(ctx, PCLEAN_ERR_ARG, "ctx column out of range");
+        cs.pchoice[c] = s->run[sb].pchoice.p;
+        cs.pnewpos[c] = s->run[sb].pnewpos.p;
+        cs.vals[c] = s->run[sb].vals.p;
+        cs.n_nodes[c] = (int)src.nodes.size();
+        cs.root_col[c] = rt.cols.p + (size_t)b.ctx_src_col[c] * rt.n_rows;
+        cs.col[c] = b.ctx_src_col[c];
+        cs.plan[c] = s->run[sb].plan;
+      }
+      hipLaunchKernelGGL(gather_ctx_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, cs, r.it_ctx.p);
+      il = ItemList{(int)NP, r.it_row.p, r.it_ctx.p, r.it_particle.p, nullptr};
+      excl = r.it_excl.p;
+      rc = eval_node(ctx, bi, 0, il, excl, seed, sweep_idx, 1, r.lse.p, r.draws.p, nullptr, nullptr, false);
+      if (rc) return rc;
+      hipLaunchKernelGGL(add_weight_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, r.lse.p, s->w.p);
+    }
+    hipLaunchKernelGGL(set_pchoice_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, r.draws.p, cur_b, r.pchoice.p);
+
+    // ---- particles that proposed a NEW referent: sample the new row's contents
+    HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(compact_new_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, r.pchoice.p, 0, s->counter.p,
+                       nullptr, nullptr);
+    unsigned int n_new = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n_new, s->counter.p, sizeof n_new, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    r.n_new = (int)n_new;
+    if (r.vals.alloc(std::max<size_t>((size_t)n_new * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+    {
+      int32_t* list = scratch<int32_t>(ctx, std::max(n_new, 1u));
+      if (!list) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+      hipLaunchKernelGGL(compact_new_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, r.pchoice.p, 1, s->counter.p,
+                         list, r.pnewpos.p);
+      if (n_new) {
+        hipLaunchKernelGGL(fill_i32_kernel, grid1((size_t)n_new * nn), dim3(256), 0, ctx->stream, r.vals.p,
+                           (size_t)n_new * nn, -2);
+        int32_t* row = scratch<int32_t>(ctx, n_new);
+        int32_t* cx = scratch<int32_t>(ctx, (size_t)n_new * PCLEAN_MAX_CTX);
+        int32_t* part = scratch<int32_t>(ctx, n_new);
+        int32_t* org = scratch<int32_t>(ctx, n_new);
+        int32_t* ex = scratch<int32_t>(ctx, n_new);
+        if (!row || !cx || !part || !org || !ex) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+        hipLaunchKernelGGL(rootlist_items_kernel, grid1(n_new), dim3(256), 0, ctx->stream, (int)n_new, P, list,
+                           has_ctx ? r.it_ctx.p : nullptr, has_ctx ? 1 : 0, cur_b, row, cx, part, org, ex);
+        hipLaunchKernelGGL(set_col_kernel, grid1(n_new), dim3(256), 0, ctx->stream, (int)n_new, nn, 0,
+                           (int32_t)PCLEAN_CHOICE_NEW, r.vals.p);
+        ItemList sub{(int)n_new, row, cx, part, org};
+        rc = sample_children(ctx, bi, 0, sub, ex, seed, sweep_idx, r.vals.p, nn);
+        if (rc) return rc;
+      }
+    }
+
+    // ---- resampling between blocks (row_inference.jl:152-155)
+    if (!use_mh && bi < n_blocks - 1) {
+      hipLaunchKernelGGL(maybe_resample_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p, 1, cur_b, seed,
+                         sweep_idx, (uint32_t)bi, s->row_offset, s->ancestors.p, s->logml_inc.p, (double*)nullptr,
+                         s->did.p);
+      hipLaunchKernelGGL(add_weight_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, s->logml_inc.p,
+                         s->logml_acc.p);
+      std::vector<int32_t*> ptrs;
+      for (int k = 0; k <= bi; ++k) {
+        ptrs.push_back(s->run[k].pchoice.p);
+        ptrs.push_back(s->run[k].pnewpos.p);
+      }
+      HIPCHK(ctx, hipMemcpyAsync(s->arr_ptrs.p, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice,
+                                 ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      hipLaunchKernelGGL(apply_ancestors_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->ancestors.p,
+                         (int)ptrs.size(), s->arr_ptrs.p, s->w.p, s->did.p);
+    }
+  }
+
+  // ---- final choice + outputs
+  hipLaunchKernelGGL(final_choice_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p, use_mh, 1, s->cur.p, seed,
+                     sweep_idx, s->row_offset, s->chosen.p, s->log_total.p);
+  hipLaunchKernelGGL(finish_logml_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->log_total.p, s->logml_acc.p,
+                     s->logml.p);
+  for (int bi = 0; bi < n_blocks; ++bi) {
+    BlockRun& r = s->run[bi];
+    const int32_t* cur_b = s->cur.p + (size_t)bi * N;
+    hipLaunchKernelGGL(select_choice_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->chosen.p, r.pchoice.p,
+                       r.pnewpos.p, r.choice.p, r.chosen_newpos.p);
+    CandTable& rt = ctx->cand[ctx->block[bi].nodes[0].table];
+    HIPCHK(ctx, hipMemsetAsync(rt.stats.p, 0, (size_t)std::max(rt.n_rows, 1) * 8, ctx->stream));
+    hipLaunchKernelGGL(stats_kernel, grid1(N), dim3(256), 0, ctx->stream, N, cur_b, r.choice.p,
+                       (unsigned long long*)rt.stats.p);
+    HIPCHK(ctx, hipMemcpyAsync(choice + (size_t)bi * N, r.choice.p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  (void)hipEventRecord(s->eve, ctx->stream);
+  if (chosen_particle) HIPCHK(ctx, hipMemcpyAsync(chosen_particle, s->chosen.p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (logml) HIPCHK(ctx, hipMemcpyAsync(logml, s->logml.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+
+  // ---- new-row records of the chosen particles -> host
+  for (int bi = 0; bi < n_blocks; ++bi) {
+    BlockRun& r = s->run[bi];
+    Block& b = ctx->block[bi];
+    const int nn = (int)b.nodes.size();
+    b.new_rows_host.clear();
+    b.new_vals_host.clear();
+    if (r.n_new == 0) continue;
+    int32_t* flag = scratch<int32_t>(ctx, N);
+    if (!flag) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    hipLaunchKernelGGL(mark_new_kernel, grid1(N), dim3(256), 0, ctx->stream, N, r.chosen_newpos.p, flag);
+    HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 0, s->counter.p, nullptr,
+                       nullptr);
+    unsigned int cnt = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&cnt, s->counter.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!cnt) continue;
+    int32_t* list = scratch<int32_t>(ctx, cnt);
+    int32_t* rows_d = scratch<int32_t>(ctx, cnt);
+    int32_t* vals_d = scratch<int32_t>(ctx, (size_t)cnt * nn);
+    if (!list || !rows_d || !vals_d) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 1, s->counter.p, list,
+                       nullptr);
+    hipLaunchKernelGGL(gather_new_rows_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, list, r.chosen_newpos.p,
+                       r.vals.p, nn, rows_d, vals_d);
+    b.new_rows_host.resize(cnt);
+    b.new_vals_host.resize((size_t)cnt * nn);
+    HIPCHK(ctx, hipMemcpyAsync(b.new_rows_host.data(), rows_d, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(b.new_vals_host.data(), vals_d, (size_t)cnt * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // deterministic order (atomic compaction order is not)
+    std::vector<int> order(cnt);
+    for (unsigned i = 0; i < cnt; ++i) order[i] = (int)i;
+    std::sort(order.begin(), order.end(), [&](int a, int c) { return b.new_rows_host[a] < b.new_rows_host[c]; });
+    std::vector<int32_t> rs(cnt), vs((size_t)cnt * nn);
+    for (unsigned i = 0; i < cnt; ++i) {
+      rs[i] = b.new_rows_host[order[i]];
+      memcpy(&vs[(size_t)i * nn], &b.new_vals_host[(size_t)order[i] * nn], nn * 4);
+    }
+    b.new_rows_host.swap(rs);
+    b.new_vals_host.swap(vs);
+  }
+  float tot = 0;
+  HIPCHK(ctx, hipEventElapsedTime(&tot, s->evs, s->eve));
+  ctx->timing.total_ms = tot;
+  ctx->timing.hot_kernel_ms = hot_ms;
+  {
+    // bytes(row) = sum_b [4 F_b + (K_b+1)(8 F_b + 4)] + 8 P; the dominant kernel is block 0's root
+    const Block& b0 = ctx->block[0];
+    const double F = b0.nodes[0].n_terms, K = ctx->cand[b0.nodes[0].table].n_rows;
+    ctx->timing.hot_kernel_alg_bytes = (double)N * (4.0 * F + (K + 1.0) * (8.0 * F + 4.0) + 8.0 * P);
+  }
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_get_new_rows(pclean_ctx* ctx, int32_t block_id, int32_t* n_out, int32_t* rows_out,
+                                   int32_t* vals_out) {
+  if (!ctx || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid || !n_out)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_get_new_rows: bad arguments");
+  const Block& b = ctx->block[block_id];
+  *n_out = (int32_t)b.new_rows_host.size();
+  if (rows_out && !b.new_rows_host.empty()) memcpy(rows_out, b.new_rows_host.data(), b.new_rows_host.size() * 4);
+  if (vals_out && !b.new_vals_host.empty()) memcpy(vals_out, b.new_vals_host.data(), b.new_vals_host.size() * 4);
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_stats_device_ptr(pclean_ctx* ctx, int32_t table_id, void** dptr, int64_t* n) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || !ctx->cand[table_id].valid || !dptr || !n)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_stats_device_ptr: bad arguments");
+  *dptr = ctx->cand[table_id].stats.p;
+  *n = ctx->cand[table_id].n_rows;
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_get_timing(pclean_ctx* ctx, pclean_timing* out) {
   if (!ctx || !out) return PCLEAN_ERR_ARG;
   *out = ctx->timing;
   return PCLEAN_OK;
 }
-extern "C" int pclean_maybe_resample(pclean_ctx* ctx, int32_t, int32_t, const double*, int32_t, uint64_t, uint32_t,
-                                     uint32_t, int32_t*, double*, double*) {
-  return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_maybe_resample: not built yet");
+
+// ---- particle primitives exposed for parity ------------------------------------
+extern "C" int pclean_maybe_resample(pclean_ctx* ctx, int32_t n_rows, int32_t n_particles, const double* logw,
+                                     int32_t retain_first, uint64_t seed, uint32_t sweep, uint32_t block,
+                                     int32_t* ancestors, double* logml_inc, double* ess) {
+  if (!ctx || n_rows <= 0 || n_particles <= 0 || n_particles > MAXP || !logw || !ancestors || !logml_inc)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_maybe_resample: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  SweepState* s = st(ctx);
+  s->pool_used = 0;
+  const size_t NP = (size_t)n_rows * n_particles;
+  double* d_w = scratch<double>(ctx, NP);
+  int32_t* d_a = scratch<int32_t>(ctx, NP);
+  double* d_inc = scratch<double>(ctx, n_rows);
+  double* d_ess = scratch<double>(ctx, n_rows);
+  if (!d_w || !d_a || !d_inc || !d_ess) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  HIPCHK(ctx, hipMemcpyAsync(d_w, logw, NP * 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(maybe_resample_kernel, grid1(n_rows), dim3(256), 0, ctx->stream, n_rows, n_particles, d_w,
+                     retain_first, (const int32_t*)nullptr, seed, sweep, block, s->row_offset, d_a, d_inc, d_ess,
+                     (int32_t*)nullptr);
+  HIPCHK(ctx, hipMemcpyAsync(ancestors, d_a, NP * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(logml_inc, d_inc, (size_t)n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (ess) HIPCHK(ctx, hipMemcpyAsync(ess, d_ess, (size_t)n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLEAN_OK;
 }
-extern "C" int pclean_final_choice(pclean_ctx* ctx, int32_t, int32_t, const double*, int32_t, int32_t, uint64_t,
-                                   uint32_t, int32_t*, double*) {
-  return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_final_choice: not built yet");
+
+extern "C" int pclean_final_choice(pclean_ctx* ctx, int32_t n_rows, int32_t n_particles, const double* logw,
+                                   int32_t use_mh, int32_t is_csmc, uint64_t seed, uint32_t sweep, int32_t* chosen,
+                                   double* log_total) {
+  if (!ctx || n_rows <= 0 || n_particles <= 0 || n_particles > MAXP || !logw || !chosen)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_final_choice: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  SweepState* s = st(ctx);
+  s->pool_used = 0;
+  const size_t NP = (size_t)n_rows * n_particles;
+  double* d_w = scratch<double>(ctx, NP);
+  int32_t* d_c = scratch<int32_t>(ctx, n_rows);
+  double* d_t = scratch<double>(ctx, n_rows);
+  if (!d_w || !d_c || !d_t) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  HIPCHK(ctx, hipMemcpyAsync(d_w, logw, NP * 8, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(final_choice_kernel, grid1(n_rows), dim3(256), 0, ctx->stream, n_rows, n_particles, d_w, use_mh,
+                     is_csmc, (const int32_t*)nullptr, seed, sweep, s->row_offset, d_c, d_t);
+  HIPCHK(ctx, hipMemcpyAsync(chosen, d_c, (size_t)n_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (log_total) HIPCHK(ctx, hipMemcpyAsync(log_total, d_t, (size_t)n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLEAN_OK;
 }
 
 // ---- numeric-contract probes -------------------------------------------------
-#include "../../include/pclean_detmath.h"
-#include "../../include/pclean_philox.h"
-
 __global__ void debug_detmath_kernel(int n, const double* x, double* e, double* l, uint64_t* f) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;

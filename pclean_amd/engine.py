@@ -1,0 +1,113 @@
+"""Host driver of the HIP path: uploads a lowered model + trace and runs batched
+rejuvenation sweeps of the observed class (pgibbs_sweep!'s loop over the rows of
+the observed class, src/inference/inference.jl:60-81 + row_inference.jl:108-187).
+"""
+import numpy as np
+
+from . import _lib
+from ._lib import HipContext, InferConfig
+from .encode import lm_log_tables
+from .model import ChooseProportionally, ChooseUniformly, StringPrior
+
+
+def _logsumexp(x):
+    m = np.max(x)
+    if not np.isfinite(m):
+        return m
+    return m + np.log(np.sum(np.exp(x - m)))
+
+
+class InferenceConfig:
+    """src/inference/infer_config.jl:1-16 — same 7 fields, same defaults."""
+
+    def __init__(self, num_iters, num_particles, use_dd_proposals=True, use_lo_sweeps=True,
+                 use_mh_instead_of_pg=False, rejuv_frequency=50, reporting_frequency=100):
+        if use_mh_instead_of_pg:
+            num_particles = 2
+        self.num_iters, self.num_particles = int(num_iters), int(num_particles)
+        self.use_dd_proposals, self.use_lo_sweeps = bool(use_dd_proposals), bool(use_lo_sweeps)
+        self.use_mh_instead_of_pg = bool(use_mh_instead_of_pg)
+        self.rejuv_frequency, self.reporting_frequency = int(rejuv_frequency), int(reporting_frequency)
+
+    def as_c(self):
+        return InferConfig(self.num_iters, self.num_particles, int(self.use_dd_proposals), int(self.use_lo_sweeps),
+                           int(self.use_mh_instead_of_pg), self.rejuv_frequency, self.reporting_frequency)
+
+
+class Engine:
+    def __init__(self, lowered, obs, device=0, dist_mode=_lib.DIST_DL, row_offset=0):
+        self.lw = lowered
+        self.obs = np.ascontiguousarray(obs, dtype=np.int32)
+        self.hip = HipContext(device)
+        self.dist_mode = dist_mode
+        self.option_logp = {}
+        self._upload_static()
+        if row_offset:
+            _lib.check(self.hip.h, self.hip.lib.pclean_set_row_offset(self.hip.h, _lib.C.c_int64(row_offset)),
+                       "pclean_set_row_offset")
+
+    def close(self):
+        self.hip.close()
+
+    # -- static data ----------------------------------------------------------
+    def _upload_static(self):
+        lw, hip = self.lw, self.hip
+        sym, off, lm, _ = lw.pool.arrays()
+        hip.load_strings(sym, off)
+        hip.load_columns(self.obs)
+        for key, (pid, odom, ldom) in lw.pair_id.items():
+            hip.build_pair_table(pid, odom.id_array(), ldom.id_array(), self.dist_mode)
+        for fid, fn in lw.fn_tables.items():
+            hip.set_fn_table(fid, fn)
+        init_l, trans_l = lm_log_tables()
+        m = lw.model
+        for (cname, aname), dom in lw.latent_dom.items():
+            d = m.classes[cname].attr(aname).dist
+            tid = lw.option_id[(cname, aname)]
+            if isinstance(d, StringPrior):
+                # discrete_proposal(::StringPrior): atom scores + dummy mass (string_prior.jl:16-22)
+                ids = dom.id_array()[:-1]
+                offs = np.zeros(len(ids) + 1, dtype=np.int64)
+                lens = lw.pool.lens[ids]
+                np.cumsum(lens, out=offs[1:])
+                lmcat = np.concatenate([lm[off[i]:off[i + 1]] for i in ids]) if len(ids) else np.zeros(0, np.uint8)
+                scores = hip.string_prior_scores(lmcat, offs, d.min_len, d.max_len, init_l, trans_l)
+                with np.errstate(divide="ignore"):
+                    dummy = np.log1p(-np.exp(_logsumexp(scores)))
+                logp = np.concatenate([scores, [dummy]])
+            elif isinstance(d, ChooseUniformly):
+                logp = np.full(len(dom), -np.log(len(d.options)))
+            elif isinstance(d, ChooseProportionally):
+                continue  # depends on the parameter value: uploaded with the trace
+            else:
+                raise NotImplementedError(type(d))
+            self.option_logp[(cname, aname)] = logp
+            hip.set_options(tid, lw.option_values[(cname, aname)], logp)
+        for bi in range(len(lw.blocks)):
+            hip.load_block(bi, *lw.block_arrays(bi))
+
+    # -- dynamic data ---------------------------------------------------------
+    def upload_trace(self, trace):
+        lw, hip = self.lw, self.hip
+        m = lw.model
+        for cname, t in trace.tables.items():
+            cols, counts = t.view()
+            hip.set_table(lw.table_id[cname], np.ascontiguousarray(cols), counts, t.strength, t.discount)
+        for (cname, aname), dom in lw.latent_dom.items():
+            d = m.classes[cname].attr(aname).dist
+            if isinstance(d, ChooseProportionally):
+                with np.errstate(divide="ignore"):
+                    logp = np.log(trace.params[(cname, d.param)].value)  # logprobs(), utils.jl:33-36
+                self.option_logp[(cname, aname)] = logp
+                hip.set_options(lw.option_id[(cname, aname)], lw.option_values[(cname, aname)], logp)
+
+    def sweep(self, trace, config, seed, sweep_idx):
+        """One batched sweep over the observed rows. Returns (choice, chosen_particle, logml, new_rows)."""
+        cfg = config.as_c() if isinstance(config, InferenceConfig) else config
+        choice, chosen, logml = self.hip.sweep(cfg, seed, sweep_idx, trace.cur)
+        new_rows = {}
+        for bi, blk in enumerate(self.lw.blocks):
+            rows, vals = self.hip.get_new_rows(bi, len(blk["nodes"]))
+            if len(rows):
+                new_rows[bi] = (rows, vals)
+        return choice, chosen, logml, new_rows

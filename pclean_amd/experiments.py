@@ -1,0 +1,103 @@
+"""The reference's experiment programs restated with the pclean_amd DSL mirror.
+
+hospital: /root/reference/experiments/hospital/{load_data,run}.jl
+"""
+import os
+
+import pandas as pd
+
+from .model import (AddTypos, ChooseProportionally, ChooseUniformly, Model, ProportionsParameter, Query, StringPrior)
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "datasets")
+
+
+def load_table(path):
+    """CSV -> dict of column -> list of str | None (None = missing)."""
+    df = pd.read_csv(path, dtype=str, keep_default_na=False)
+    return {c: [None if v == "" else v for v in df[c].tolist()] for c in df.columns}
+
+
+def possibilities_of(table):
+    """load_data.jl:17-18: unique non-missing dirty values per column, first-seen order."""
+    return {c: list(dict.fromkeys(v for v in vals if v is not None)) for c, vals in table.items()}
+
+
+def hospital_data():
+    dirty = load_table(os.path.join(DATA_DIR, "hospital_dirty.csv"))
+    clean = load_table(os.path.join(DATA_DIR, "hospital_clean.csv"))
+    return dirty, clean
+
+
+def hospital_model(poss):
+    """experiments/hospital/run.jl:5-56."""
+    m = Model()
+    c = m.add_class("County")
+    c.param("state_proportions", ProportionsParameter())
+    c.choice("state", ChooseProportionally(poss["State"], "state_proportions"))
+    c.choice("county", StringPrior(3, 30, poss["CountyName"]))
+    c = m.add_class("Place")
+    c.fk("county", "County")
+    c.choice("city", StringPrior(3, 30, poss["City"]))
+    c = m.add_class("Condition")
+    c.choice("desc", StringPrior(5, 35, poss["Condition"]))
+    c = m.add_class("Measure")
+    c.choice("code", ChooseUniformly(poss["MeasureCode"]))
+    c.choice("name", ChooseUniformly(poss["MeasureName"]))
+    c.fk("condition", "Condition")
+    c = m.add_class("HospitalType")
+    c.choice("desc", StringPrior(10, 30, poss["HospitalType"]))
+    c = m.add_class("Hospital")
+    c.param("owner_dist", ProportionsParameter())
+    c.param("service_dist", ProportionsParameter())
+    c.fk("loc", "Place")
+    c.fk("type", "HospitalType")
+    c.choice("provider", ChooseUniformly(poss["ProviderNumber"]))
+    c.choice("name", StringPrior(3, 50, poss["HospitalName"]))
+    c.choice("addr", StringPrior(10, 30, poss["Address1"]))
+    c.choice("phone", StringPrior(10, 10, poss["PhoneNumber"]))
+    c.choice("owner", ChooseProportionally(poss["HospitalOwner"], "owner_dist"))
+    c.choice("zip", ChooseUniformly(poss["ZipCode"]))
+    c.choice("service", ChooseProportionally(poss["EmergencyService"], "service_dist"))
+    r = m.add_class("Record")
+    with r.block():
+        r.fk("hosp", "Hospital")
+        r.choice("service", AddTypos("hosp.service"))
+        r.choice("provider", AddTypos("hosp.provider"))
+        r.choice("name", AddTypos("hosp.name"))
+        r.choice("addr", AddTypos("hosp.addr"))
+        r.choice("city", AddTypos("hosp.loc.city"))
+        r.choice("state", AddTypos("hosp.loc.county.state"))
+        r.choice("zip", AddTypos("hosp.zip"))
+        r.choice("county", AddTypos("hosp.loc.county.county"))
+        r.choice("phone", AddTypos("hosp.phone"))
+        r.choice("type", AddTypos("hosp.type.desc"))
+        r.choice("owner", AddTypos("hosp.owner"))
+    with r.block():
+        r.fk("metric", "Measure")
+        r.choice("code", AddTypos("metric.code"))
+        r.choice("mname", AddTypos("metric.name"))
+        r.choice("condition", AddTypos("metric.condition.desc"))
+        r.julia("stateavg", lambda state, code: f"{state}_{code}", ["hosp.loc.county.state", "metric.code"])
+        r.choice("stateavg_obs", AddTypos("stateavg"))
+    return m
+
+
+def hospital_query(m):
+    """experiments/hospital/run.jl:58-74."""
+    return Query(m, "Record", {
+        "ProviderNumber": ("hosp.provider", "provider"),
+        "HospitalName": ("hosp.name", "name"),
+        "HospitalType": ("hosp.type.desc", "type"),
+        "HospitalOwner": ("hosp.owner", "owner"),
+        "Address1": ("hosp.addr", "addr"),
+        "PhoneNumber": ("hosp.phone", "phone"),
+        "EmergencyService": ("hosp.service", "service"),
+        "City": ("hosp.loc.city", "city"),
+        "CountyName": ("hosp.loc.county.county", "county"),
+        "State": ("hosp.loc.county.state", "state"),
+        "ZipCode": ("hosp.zip", "zip"),
+        "Condition": ("metric.condition.desc", "condition"),
+        "MeasureCode": ("metric.code", "code"),
+        "MeasureName": ("metric.name", "mname"),
+        "Stateavg": ("stateavg", "stateavg_obs"),
+    })

@@ -1,0 +1,396 @@
+"""Relational model definition mirroring PClean's `@model` / `@query` DSL, and its
+lowering to the static enumeration plan consumed by libpclean_hip.so.
+
+Reference mapping (files under /root/reference/src):
+  Model / ClassDef        dsl/syntax.jl:106-161 (`@model`, `@class`), dsl/builder.jl:37-258
+  ClassDef.param          `@learned x::ProportionsParameter`   (builder.jl:182-202)
+  ClassDef.choice         `x ~ Dist(args...)`                  (builder.jl:234-258)
+  ClassDef.fk             `x ~ OtherClass`  (builder.jl:123-175: the target's nodes are
+                          inlined, i.e. a row stores a flattened copy of its referents)
+  ClassDef.julia          `x = expr`                            (builder.jl:205-231)
+  ClassDef.block()        `begin ... end`                       (builder.jl:13-20)
+  Query                   dsl/query.jl:1-43
+The reference JIT-compiles one Julia function per (class, block, observed set)
+(inference/proposal_compiler.jl); here the same enumeration structure is emitted
+once as flat arrays (nodes / terms / children / colmap, include/pclean_hip.h).
+"""
+from contextlib import contextmanager
+
+import numpy as np
+
+from . import _lib
+from .encode import Domain, StringPool
+
+
+# ---------------------------------------------------------------------------
+# distributions (src/distributions/*.jl) — declarative descriptors
+class StringPrior:
+    """string_prior.jl: StringPrior(min_length, max_length, proposal_atoms)."""
+
+    def __init__(self, min_len, max_len, atoms):
+        self.min_len, self.max_len, self.atoms = int(min_len), int(max_len), list(atoms)
+
+    def dummy_value(self):  # string_prior.jl:24-26
+        return "*" * ((self.min_len + self.max_len) // 2)
+
+
+class ChooseUniformly:
+    """choose_uniformly.jl: ChooseUniformly(options)."""
+
+    def __init__(self, options):
+        self.options = list(options)
+
+
+class ChooseProportionally:
+    """choose_proportionally.jl: ChooseProportionally(options, probs::ProportionsParameter)."""
+
+    def __init__(self, options, param):
+        self.options, self.param = list(options), param
+
+
+class AddTypos:
+    """add_typos.jl: AddTypos(word[, max_typos]); `ref` names the clean value."""
+
+    def __init__(self, ref, max_typos=None):
+        self.ref, self.max_typos = ref, max_typos
+
+
+class ProportionsParameter:
+    """choose_proportionally.jl:31-74 (Dirichlet prior, default concentration 1.0)."""
+
+    def __init__(self, concentration=1.0):
+        self.concentration = float(concentration)
+
+
+# ---------------------------------------------------------------------------
+class Attr:
+    def __init__(self, kind, name, **kw):
+        self.kind, self.name = kind, name
+        self.__dict__.update(kw)
+
+
+class ClassDef:
+    def __init__(self, model, name):
+        self.model, self.name = model, name
+        self.attrs = []        # in declaration order
+        self.blocks = []       # list of lists of attr names; [] => whole class is one block
+        self._open = None
+        self.py_strength, self.py_discount = 1.0, 0.0  # builder.jl:39
+
+    def _add(self, attr):
+        if any(a.name == attr.name for a in self.attrs):
+            raise ValueError(f"{self.name}.{attr.name} declared twice")
+        self.attrs.append(attr)
+        if attr.kind != "param":
+            if self._open is not None:
+                self._open.append(attr.name)
+            elif self.blocks and self._implicit:
+                self.blocks[-1].append(attr.name)
+            else:
+                self.blocks.append([attr.name])
+                self._implicit = True
+        return attr
+
+    _implicit = False
+
+    def param(self, name, prior):
+        return self._add(Attr("param", name, prior=prior))
+
+    def choice(self, name, dist):
+        return self._add(Attr("choice", name, dist=dist))
+
+    def fk(self, name, target):
+        if target not in self.model.classes:
+            raise ValueError(f"class {target} must be defined before it is referenced")
+        return self._add(Attr("fk", name, target=target))
+
+    def julia(self, name, fn, args):
+        return self._add(Attr("julia", name, fn=fn, args=list(args)))
+
+    @contextmanager
+    def block(self):
+        self._open = []
+        self._implicit = False
+        self.blocks.append(self._open)
+        try:
+            yield self
+        finally:
+            self._open = None
+
+    def attr(self, name):
+        for a in self.attrs:
+            if a.name == name:
+                return a
+        raise KeyError(f"{self.name}.{name}")
+
+
+class Model:
+    def __init__(self):
+        self.classes = {}
+        self.class_order = []
+
+    def add_class(self, name):
+        c = ClassDef(self, name)
+        self.classes[name] = c
+        self.class_order.append(name)
+        return c
+
+    def resolve(self, cls, path):
+        """Follow a dotted reference from class `cls`; returns (class name, attr)."""
+        parts = path.split(".")
+        c = self.classes[cls]
+        for p in parts[:-1]:
+            a = c.attr(p)
+            if a.kind != "fk":
+                raise ValueError(f"{path}: {p} is not a reference slot")
+            c = self.classes[a.target]
+        return c.name, c.attr(parts[-1])
+
+
+class Query:
+    """`@query Model.Class [ column clean_expr dirty_expr ]` (dsl/query.jl:15-38).
+    bindings: column -> (clean reference, dirty attribute name)."""
+
+    def __init__(self, model, cls, bindings):
+        self.model, self.cls = model, cls
+        self.cleanmap, self.obsmap = {}, {}
+        for col, b in bindings.items():
+            clean, dirty = (b, b) if isinstance(b, str) else b
+            self.cleanmap[col] = clean
+            self.obsmap[col] = dirty
+
+
+# ---------------------------------------------------------------------------
+# lowering
+class Column:
+    """One flattened column of a latent table."""
+
+    def __init__(self, name, kind, cls, attr, target=None):
+        self.name, self.kind, self.cls, self.attr, self.target = name, kind, cls, attr, target
+
+
+class LoweredModel:
+    """Domains, flattened table layouts, option tables and per-block plans."""
+
+    def __init__(self, model, query, dirty_columns, pool=None):
+        self.model, self.query = model, query
+        self.pool = pool or StringPool()
+        self.latent_dom = {}   # (class, attr) -> Domain of latent values
+        self.obs_dom = {}      # dirty attr name -> Domain of observed values
+        self.layout = {}       # class -> [Column]
+        self.colidx = {}       # class -> {dotted name: index}
+        self.table_id = {}     # class -> candidate table id
+        self.option_id = {}    # (class, attr) -> option table id
+        self.pair_id = {}      # (dirty attr) -> pair table id
+        self.fn_tables = {}    # fn id -> ndarray
+        self.blocks = []       # dicts: nodes, terms, children, colmap, ctx_src_block, ctx_src_col, root_class
+        self.obs_cols = []     # dirty attr name per observed column id
+        self.obs_index = {}
+        self._next_table = 0
+        self._next_pair = 0
+        self._build_domains(dirty_columns)
+        self._build_layouts()
+        self._build_blocks()
+
+    # -- domains ------------------------------------------------------------
+    def _build_domains(self, dirty_columns):
+        m = self.model
+        for cname in m.class_order:
+            for a in m.classes[cname].attrs:
+                if a.kind != "choice":
+                    continue
+                d = a.dist
+                if isinstance(d, StringPrior):
+                    dom = Domain(self.pool, d.atoms)
+                    dom.add(d.dummy_value())
+                elif isinstance(d, (ChooseUniformly, ChooseProportionally)):
+                    dom = Domain(self.pool, d.options)
+                else:
+                    continue
+                self.latent_dom[(cname, a.name)] = dom
+        ocls = m.classes[self.query.cls]
+        for col, dirty in self.query.obsmap.items():
+            a = ocls.attr(dirty)
+            if not isinstance(a.dist, AddTypos):
+                raise NotImplementedError("only AddTypos observations are lowered so far")
+            vals = [v for v in dirty_columns[col] if v is not None]
+            self.obs_dom[dirty] = Domain(self.pool, list(dict.fromkeys(vals)))
+            self.obs_index[dirty] = len(self.obs_cols)
+            self.obs_cols.append(dirty)
+        self.query_columns = {dirty: col for col, dirty in self.query.obsmap.items()}
+
+    def encode_observations(self, dirty_columns):
+        """[n_cols][n_rows] int32 observed-domain indices, -1 = missing."""
+        n_rows = len(next(iter(dirty_columns.values())))
+        obs = np.full((len(self.obs_cols), n_rows), -1, dtype=np.int32)
+        for j, dirty in enumerate(self.obs_cols):
+            dom = self.obs_dom[dirty]
+            col = dirty_columns[self.query_columns[dirty]]
+            obs[j] = [(-1 if v is None else dom.get(v)) for v in col]
+        return obs
+
+    # -- layouts ------------------------------------------------------------
+    def _build_layouts(self):
+        m = self.model
+        for cname in m.class_order:
+            if cname == self.query.cls:
+                continue
+            cols = []
+            for a in m.classes[cname].attrs:
+                if a.kind == "fk":
+                    cols.append(Column(a.name, "fk", cname, a.name, a.target))
+                    for c in self.layout[a.target]:
+                        cols.append(Column(a.name + "." + c.name, c.kind, c.cls, c.attr, c.target))
+                elif a.kind == "choice":
+                    cols.append(Column(a.name, "val", cname, a.name))
+            self.layout[cname] = cols
+            self.colidx[cname] = {c.name: i for i, c in enumerate(cols)}
+            self.table_id[cname] = self._next_table
+            self._next_table += 1
+        self.option_values = {}
+        for (cname, aname), dom in self.latent_dom.items():
+            self.option_id[(cname, aname)] = self._next_table
+            self._next_table += 1
+            # option k of discrete_proposal(dist, ...) is latent-domain value k (atoms are unique,
+            # string_prior.jl:15; the dummy value, if any, is last)
+            self.option_values[(cname, aname)] = np.arange(len(dom), dtype=np.int32)
+
+    # -- plans --------------------------------------------------------------
+    def _obs_terms_of_block(self, ocls, names):
+        """Observation choices of a block as (dirty attr, kind, payload)."""
+        out = []
+        for n in names:
+            a = ocls.attr(n)
+            if a.kind == "choice" and isinstance(a.dist, AddTypos):
+                out.append(a)
+        return out
+
+    def _pair_for(self, dirty, lat_dom_key, lat_dom):
+        key = (dirty, lat_dom_key)
+        if key not in self.pair_id:
+            self.pair_id[key] = (self._next_pair, self.obs_dom[dirty], lat_dom)
+            self._next_pair += 1
+        return self.pair_id[key][0]
+
+    def _build_blocks(self):
+        m = self.model
+        ocls = m.classes[self.query.cls]
+        root_of_block = []
+        fk_block = {}
+        for bi, names in enumerate(ocls.blocks):
+            fks = [n for n in names if ocls.attr(n).kind == "fk"]
+            if len(fks) != 1:
+                raise NotImplementedError("each observed-class block must hold exactly one reference slot (so far)")
+            root_of_block.append(fks[0])
+            fk_block[fks[0]] = bi
+        for bi, names in enumerate(ocls.blocks):
+            root_fk = ocls.attr(root_of_block[bi])
+            blk = dict(nodes=[], terms=[], children=[], colmap=[], ctx_src_block=[], ctx_src_col=[],
+                       root_class=root_fk.target, root_fk=root_fk.name, node_info=[])
+            # collect observation terms of this block: (dirty attr, path below root, ctx spec)
+            terms = []
+            for a in self._obs_terms_of_block(ocls, names):
+                ref = a.dist.ref
+                if "." in ref:
+                    head, rest = ref.split(".", 1)
+                    if head != root_fk.name:
+                        raise NotImplementedError(f"{a.name}: reference outside the block's root slot")
+                    cname, la = m.resolve(root_fk.target, rest)
+                    pid = self._pair_for(a.name, (cname, la.name), self.latent_dom[(cname, la.name)])
+                    terms.append(dict(obs=a.name, path=rest, pair=pid, max_typos=a.dist.max_typos, ctx=None))
+                else:
+                    j = ocls.attr(ref)
+                    if j.kind != "julia":
+                        raise NotImplementedError(f"{a.name}: AddTypos of a non-reference")
+                    local = [x for x in j.args if x.split(".", 1)[0] == root_fk.name]
+                    other = [x for x in j.args if x.split(".", 1)[0] != root_fk.name]
+                    if len(local) != 1 or len(other) > 1:
+                        raise NotImplementedError("julia nodes must combine one value of this block with at most one "
+                                                  "value of an earlier block (so far)")
+                    lc, la = m.resolve(root_fk.target, local[0].split(".", 1)[1])
+                    ldom = self.latent_dom[(lc, la.name)]
+                    if other:
+                        ohead, orest = other[0].split(".", 1)
+                        sb = fk_block[ohead]
+                        if sb >= bi:
+                            raise NotImplementedError("ctx must come from an earlier block")
+                        ocn, oa = m.resolve(ocls.attr(ohead).target, orest)
+                        odom = self.latent_dom[(ocn, oa.name)]
+                        slot = len(blk["ctx_src_block"])
+                        blk["ctx_src_block"].append(sb)
+                        blk["ctx_src_col"].append(self.colidx[ocls.attr(ohead).target][orest])
+                        order = [j.args.index(other[0]), j.args.index(local[0])]
+                        jdom = Domain(self.pool)
+                        fn = np.zeros((len(odom), len(ldom)), dtype=np.int32)
+                        for x in range(len(odom)):
+                            for y in range(len(ldom)):
+                                argv = [None, None]
+                                argv[order[0]] = odom.string(x)
+                                argv[order[1]] = ldom.string(y)
+                                fn[x, y] = jdom.add(j.fn(*argv))
+                        fid = len(self.fn_tables)
+                        self.fn_tables[fid] = fn
+                        pid = self._pair_for(a.name, ("julia", j.name), jdom)
+                        terms.append(dict(obs=a.name, path=local[0].split(".", 1)[1], pair=pid,
+                                          max_typos=a.dist.max_typos, ctx=(slot, fid)))
+                    else:
+                        raise NotImplementedError("single-argument julia nodes are not lowered yet")
+            self._emit_fk_node(blk, root_fk.target, "", terms, parent=-1, parent_fk_col=-1)
+            self.blocks.append(blk)
+
+    def _emit_term(self, blk, t, cand_col):
+        blk["terms"].append((self.obs_index[t["obs"]], cand_col, t["pair"], _lib.DENS_ADD_TYPOS,
+                             -1 if t["max_typos"] is None else int(t["max_typos"]),
+                             -1 if t["ctx"] is None else t["ctx"][0], -1 if t["ctx"] is None else t["ctx"][1], 0))
+
+    def _emit_fk_node(self, blk, cname, prefix, terms, parent, parent_fk_col):
+        """Node enumerating rows of latent class `cname`; `terms` are the observation
+        terms whose clean value lives in this sub-tree (paths relative to it)."""
+        m = self.model
+        nid = len(blk["nodes"])
+        blk["nodes"].append(None)
+        blk["node_info"].append(dict(kind="fk", cls=cname, attr=None))
+        tb = len(blk["terms"])
+        for t in terms:
+            self._emit_term(blk, t, self.colidx[cname][t["path"]])
+        nt = len(blk["terms"]) - tb
+        # children: own attributes of the class, in declaration order
+        kids = []
+        colsrc = {}
+        for a in m.classes[cname].attrs:
+            if a.kind == "fk":
+                sub = [dict(t, path=t["path"].split(".", 1)[1]) for t in terms if t["path"].split(".", 1)[0] == a.name
+                       and "." in t["path"]]
+                cid = self._emit_fk_node(blk, a.target, prefix + a.name + ".", sub, nid, self.colidx[cname][a.name])
+                kids.append(cid)
+                colsrc[a.name] = (-1, -1)
+                for c in self.layout[a.target]:
+                    colsrc[a.name + "." + c.name] = (cid, self.colidx[a.target][c.name])
+            elif a.kind == "choice":
+                sub = [t for t in terms if t["path"] == a.name]
+                cid = len(blk["nodes"])
+                ltb = len(blk["terms"])
+                for t in sub:
+                    self._emit_term(blk, t, 0)
+                cacheable = int(len(sub) == 1 and sub[0]["ctx"] is None)
+                blk["nodes"].append((_lib.NODE_LEAF, self.option_id[(cname, a.name)], ltb, len(sub), 0, 0, nid, -1,
+                                     cacheable, 0, 0, 0))
+                blk["node_info"].append(dict(kind="leaf", cls=cname, attr=a.name))
+                kids.append(cid)
+                colsrc[a.name] = (cid, 0)
+        cb = len(blk["children"])
+        blk["children"].extend(kids)
+        cmb = len(blk["colmap"]) // 2
+        for c in self.layout[cname]:
+            blk["colmap"].extend(colsrc[c.name])
+        blk["nodes"][nid] = (_lib.NODE_FK, self.table_id[cname], tb, nt, cb, len(kids), parent, parent_fk_col, 0, cmb,
+                             0, 0)
+        return nid
+
+    # -- arrays for the C ABI -------------------------------------------------
+    def block_arrays(self, bi):
+        blk = self.blocks[bi]
+        nodes = np.array(blk["nodes"], dtype=_lib.NODE_DTYPE)
+        terms = np.array(blk["terms"], dtype=_lib.TERM_DTYPE) if blk["terms"] else np.zeros(0, dtype=_lib.TERM_DTYPE)
+        return (nodes, terms, np.array(blk["children"], dtype=np.int32), np.array(blk["colmap"], dtype=np.int32),
+                np.array(blk["ctx_src_block"], dtype=np.int32), np.array(blk["ctx_src_col"], dtype=np.int32))

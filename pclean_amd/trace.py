@@ -1,0 +1,227 @@
+"""Latent database state (host side) and its batched commit.
+
+Mirrors src/model/trace.jl:24-50 (TableTrace / PCleanTrace) with flat arrays:
+per latent class a column-major int32 table of flattened rows
+(dependency_tracking.jl:88-96), int64 reference counts, Pitman–Yor parameters;
+per observed row the current referent of each block's root reference slot.
+`commit` restates incorporate_row!/unincorporate_row!/refer_to_row!/unrefer_to_row!
+(dependency_tracking.jl:26-126,162-236) for a whole sweep at once: reference
+counts move, new latent rows are created recursively, rows whose count reaches
+zero are garbage-collected recursively, conjugate counts follow.
+"""
+import numpy as np
+
+from .model import ChooseProportionally, ChooseUniformly, StringPrior
+
+CHOICE_NEW = -1
+
+
+class ProportionsState:
+    """choose_proportionally.jl:36-74: Dirichlet-categorical parameter."""
+
+    def __init__(self, n_options, concentration, rng):
+        self.alpha = np.full(n_options, concentration, dtype=np.float64)
+        self.counts = np.zeros(n_options, dtype=np.int64)
+        self.value = rng.dirichlet(self.alpha)  # lazy init in the reference (48-55), eager here
+
+    def resample(self, rng):  # resample_value!, 70-74
+        self.value = rng.dirichlet(self.alpha + self.counts)
+
+
+class LatentTable:
+    def __init__(self, n_cols, strength=1.0, discount=0.0, cap=16):
+        self.n_cols = n_cols
+        self.cols = np.zeros((n_cols, cap), dtype=np.int32)
+        self.counts = np.zeros(cap, dtype=np.int64)
+        self.live = np.zeros(cap, dtype=bool)
+        self.n = 0          # high-water mark
+        self.free = []
+        self.strength, self.discount = strength, discount
+
+    def alloc(self):
+        if self.free:
+            return self.free.pop()
+        if self.n == self.cols.shape[1]:
+            cap = max(16, 2 * self.n)
+            self.cols = np.concatenate([self.cols, np.zeros((self.n_cols, cap - self.n), np.int32)], axis=1)
+            self.counts = np.concatenate([self.counts, np.zeros(cap - self.n, np.int64)])
+            self.live = np.concatenate([self.live, np.zeros(cap - self.n, bool)])
+        self.n += 1
+        return self.n - 1
+
+    def view(self):
+        return self.cols[:, :self.n], self.counts[:self.n]
+
+    @property
+    def n_live(self):
+        return int(np.sum(self.counts[:self.n] > 0))
+
+
+class Trace:
+    def __init__(self, lowered, n_rows, seed=0):
+        self.lw = lowered
+        self.rng = np.random.default_rng(seed)
+        m = lowered.model
+        self.tables = {c: LatentTable(len(lowered.layout[c]), m.classes[c].py_strength, m.classes[c].py_discount)
+                       for c in lowered.layout}
+        self.params = {}
+        for cname in m.class_order:
+            for a in m.classes[cname].attrs:
+                if a.kind == "choice" and isinstance(a.dist, ChooseProportionally):
+                    prior = m.classes[cname].attr(a.dist.param).prior
+                    self.params[(cname, a.dist.param)] = ProportionsState(len(a.dist.options), prior.concentration,
+                                                                         self.rng)
+        self.cur = np.full((len(lowered.blocks), n_rows), -1, dtype=np.int32)
+
+    # -- own-choice sufficient statistics (update_sufficient_statistics!, dependency_tracking.jl:6-21)
+    def _own_choice_stats(self, cname, row, sign):
+        m = self.lw.model
+        t = self.tables[cname]
+        for a in m.classes[cname].attrs:
+            if a.kind == "choice" and isinstance(a.dist, ChooseProportionally):
+                v = t.cols[self.lw.colidx[cname][a.name], row]
+                self.params[(cname, a.dist.param)].counts[v] += sign
+
+    def _dedup_key(self, cname, values):
+        return (cname,) + tuple(int(v) for v in values)
+
+    def insert_row(self, cname, values):
+        """Create one latent row with flattened `values` (FK columns hold target row
+        ids whose counts are incremented) — refer_to_row!, dependency_tracking.jl:205-236."""
+        t = self.tables[cname]
+        r = t.alloc()
+        t.cols[:, r] = values
+        t.counts[r] = 0
+        t.live[r] = True
+        for j, c in enumerate(self.lw.layout[cname]):
+            if c.kind == "fk" and "." not in c.name:
+                self.tables[c.target].counts[values[j]] += 1
+        self._own_choice_stats(cname, r, +1)
+        return r
+
+    def delete_row(self, cname, r):
+        """unrefer_to_row! tail (dependency_tracking.jl:189-201): drop the row, release its referents."""
+        t = self.tables[cname]
+        assert t.counts[r] == 0 and t.live[r]
+        self._own_choice_stats(cname, r, -1)
+        t.live[r] = False
+        t.free.append(int(r))
+        for j, c in enumerate(self.lw.layout[cname]):
+            if c.kind == "fk" and "." not in c.name:
+                tgt = self.tables[c.target]
+                k = int(t.cols[j, r])
+                tgt.counts[k] -= 1
+                if tgt.counts[k] == 0:
+                    self.delete_row(c.target, k)
+
+    # -- building a new row from the sampled node choices of a block ---------
+    def _materialise(self, bi, node, vals):
+        blk = self.lw.blocks[bi]
+        nodes = blk["nodes"]
+        cname = blk["node_info"][node]["cls"]
+        layout = self.lw.layout[cname]
+        cmb = nodes[node][9]
+        values = np.zeros(len(layout), dtype=np.int32)
+        child_rows = {}
+        for j, c in enumerate(layout):
+            cn, cc = blk["colmap"][2 * (cmb + j)], blk["colmap"][2 * (cmb + j) + 1]
+            if cn < 0:
+                continue
+            if nodes[cn][0] == 1:  # leaf: option index -> latent value
+                ocls, oattr = blk["node_info"][cn]["cls"], blk["node_info"][cn]["attr"]
+                values[j] = self.lw.option_values[(ocls, oattr)][vals[cn]]
+            else:
+                if cn not in child_rows:
+                    ch = int(vals[cn])
+                    if ch == CHOICE_NEW:
+                        ch = self._materialise(bi, cn, vals)
+                    child_rows[cn] = ch
+                values[j] = self.tables[blk["node_info"][cn]["cls"]].cols[cc, child_rows[cn]]
+        for j, c in enumerate(layout):
+            if c.kind == "fk" and "." not in c.name:
+                # the direct child node for this slot
+                for k in range(nodes[node][4], nodes[node][4] + nodes[node][5]):
+                    cid = blk["children"][k]
+                    if nodes[cid][0] == 0 and nodes[cid][7] == j:
+                        if cid not in child_rows:
+                            ch = int(vals[cid])
+                            if ch == CHOICE_NEW:
+                                ch = self._materialise(bi, cid, vals)
+                            child_rows[cid] = ch
+                        values[j] = child_rows[cid]
+        return self.insert_row(cname, values)
+
+    def commit(self, choice, new_rows):
+        """Apply one batched sweep: choice [n_blocks][n_rows] (row id or CHOICE_NEW),
+        new_rows[b] = (rows, vals[n][n_nodes]).  Returns the number of changed referents."""
+        changed = 0
+        for bi, blk in enumerate(self.lw.blocks):
+            cname = blk["root_class"]
+            t = self.tables[cname]
+            ch = np.array(choice[bi], dtype=np.int64)
+            rows_new, vals_new = new_rows.get(bi, (np.zeros(0, np.int32), None))
+            for j, i in enumerate(rows_new):
+                ch[i] = self._materialise(bi, 0, vals_new[j])
+            cur = self.cur[bi]
+            moved = np.nonzero(ch != cur)[0]
+            changed += len(moved)
+            if len(moved):
+                olds = cur[moved]
+                np.add.at(t.counts, ch[moved], 1)
+                np.subtract.at(t.counts, olds[olds >= 0], 1)
+                self.cur[bi, moved] = ch[moved]
+                for k in np.unique(olds[olds >= 0]):
+                    if t.counts[k] == 0 and t.live[k]:
+                        self.delete_row(cname, int(k))
+            # rows created but immediately unreferenced cannot happen: each new row has its creator
+        return changed
+
+    # -- parameter moves (inference.jl:72-77 -> resample_value!) ----------------
+    def resample_parameters(self):
+        for p in self.params.values():
+            p.resample(self.rng)
+
+    # -- initial state from known clean values (tests / synthetic bench) --------
+    @classmethod
+    def from_clean_values(cls, lowered, clean_by_path, n_rows, seed=0):
+        """clean_by_path: {block index: {path below root: list of strings per row}}.
+        Latent tables are the de-duplicated tuples; counts follow."""
+        tr = cls(lowered, n_rows, seed)
+        memo = {}
+
+        def build(cname, getter):
+            """row id of the (possibly new) latent row of class cname whose values come from getter(path)."""
+            layout = lowered.layout[cname]
+            values = np.zeros(len(layout), dtype=np.int32)
+            for j, c in enumerate(layout):
+                if c.kind == "fk" and "." not in c.name:
+                    values[j] = build(c.target, lambda p, pre=c.name: getter(pre + "." + p))
+            for j, c in enumerate(layout):
+                if c.kind == "val":
+                    if "." in c.name:
+                        head, rest = c.name.split(".", 1)
+                        values[j] = tr.tables[lowered.layout[cname][lowered.colidx[cname][head]].target].cols[
+                            lowered.colidx[lowered.layout[cname][lowered.colidx[cname][head]].target][rest],
+                            values[lowered.colidx[cname][head]]]
+                    else:
+                        values[j] = lowered.latent_dom[(cname, c.name)].index_of(getter(c.name))
+                elif "." in c.name:  # nested fk id
+                    head, rest = c.name.split(".", 1)
+                    tgt = lowered.layout[cname][lowered.colidx[cname][head]].target
+                    values[j] = tr.tables[tgt].cols[lowered.colidx[tgt][rest], values[lowered.colidx[cname][head]]]
+            key = tr._dedup_key(cname, values)
+            r = memo.get(key)
+            if r is None:
+                r = tr.insert_row(cname, values)
+                memo[key] = r
+            return r
+
+        for bi, blk in enumerate(lowered.blocks):
+            cname = blk["root_class"]
+            t = tr.tables[cname]
+            paths = clean_by_path[bi]
+            for i in range(n_rows):
+                r = build(cname, lambda p, i=i: paths[p][i])
+                t.counts[r] += 1
+                tr.cur[bi, i] = r
+        return tr

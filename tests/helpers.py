@@ -1,0 +1,108 @@
+"""Shared test scaffolding: build the hospital program, an initial trace, and
+mirror the uploaded state into the CPU oracle's World."""
+import numpy as np
+
+from pclean_amd import experiments as ex
+from pclean_amd.model import LoweredModel
+from pclean_amd.trace import Trace
+
+
+def hospital_setup(n_rows=None, seed=0):
+    dirty, clean = ex.hospital_data()
+    if n_rows is not None:
+        dirty = {c: v[:n_rows] for c, v in dirty.items()}
+        clean = {c: v[:n_rows] for c, v in clean.items()}
+    poss = ex.possibilities_of(dirty)
+    m = ex.hospital_model(poss)
+    q = ex.hospital_query(m)
+    lw = LoweredModel(m, q, dirty)
+    obs = lw.encode_observations(dirty)
+    n = obs.shape[1]
+    # initial latent state: clean value where it is a possible latent value, else the dirty one
+    by_path = [{}, {}]
+    ocls = m.classes[q.cls]
+    for col, ref in q.cleanmap.items():
+        if "." not in ref:
+            continue
+        head, rest = ref.split(".", 1)
+        bi = 0 if head == "hosp" else 1
+        cname, attr = m.resolve(ocls.attr(head).target, rest)
+        dom = lw.latent_dom[(cname, attr.name)]
+        vals = []
+        for i in range(n):
+            v = clean[col][i]
+            vals.append(v if (v is not None and dom.get(v) >= 0) else dirty[col][i])
+        by_path[bi][rest] = vals
+    tr = Trace.from_clean_values(lw, by_path, n, seed)
+    return dict(dirty=dirty, clean=clean, model=m, query=q, lw=lw, obs=obs, trace=tr)
+
+
+def density_tables_cpu(oracle, max_len):
+    L = oracle.lib()
+    ml = max(max_len, 64)
+    mr, md = (ml + 4) // 5, ml
+    nb = np.zeros((mr + 1, md + 1))
+    nb[0, 1:] = -np.inf
+    for r in range(1, mr + 1):
+        for d in range(md + 1):
+            nb[r, d] = L.pco_negbin_logpdf(float(r), 0.9, d)
+    logl = np.zeros(ml + 1)
+    logl[1:] = np.log(np.arange(1, ml + 1, dtype=np.float64))
+    return mr, md, ml, nb, logl
+
+
+def mirror_world(oracle, lw, obs, trace, engine=None, dist_mode=1, option_logp=None):
+    """Oracle World holding exactly what the product uploaded.  With an engine the
+    double-valued tables are read back from the library (bit-identical inputs);
+    without one (CPU tests) they are computed by the oracle itself."""
+    w = oracle.World()
+    w.set_obs(obs)
+    sym, off, lm, _ = lw.pool.arrays()
+    max_len = int(lw.pool.lens.max())
+    if engine is not None:
+        mr, md, ml, nb, logl = engine.hip.get_density_tables()
+    else:
+        mr, md, ml, nb, logl = density_tables_cpu(oracle, max_len)
+    w.set_density(mr, md, ml, nb, logl)
+    for key, (pid, odom, ldom) in lw.pair_id.items():
+        if engine is not None:
+            d = engine.hip.get_pair_table(pid, len(odom), len(ldom))
+        else:
+            d = oracle.pair_table(sym, off, odom.id_array(), ldom.id_array(), dist_mode)
+        w.set_pair(pid, d, lw.pool.lens[ldom.id_array()].astype(np.uint16))
+    for fid, fn in lw.fn_tables.items():
+        w.set_fn(fid, fn)
+    for cname, t in trace.tables.items():
+        cols, counts = t.view()
+        if engine is not None:
+            full, m1, scal = engine.hip.get_table_priors(lw.table_id[cname], len(counts))
+        else:
+            full, m1, scal = oracle.table_priors(counts, t.strength, t.discount)
+        w.set_table(lw.table_id[cname], np.ascontiguousarray(cols), counts, full, m1, scal)
+    logps = engine.option_logp if engine is not None else option_logp
+    for (cname, aname), dom in lw.latent_dom.items():
+        w.set_options(lw.option_id[(cname, aname)], lw.option_values[(cname, aname)], logps[(cname, aname)])
+    for bi in range(len(lw.blocks)):
+        w.load_block(bi, *lw.block_arrays(bi))
+    return w
+
+
+def option_logp_cpu(oracle, lw, trace):
+    """discrete_proposal log-probabilities computed by the oracle (CPU tests)."""
+    from pclean_amd.encode import load_lm_params
+    from pclean_amd.model import ChooseProportionally, ChooseUniformly, StringPrior
+    init, trans = load_lm_params()
+    _, off, lm, _ = lw.pool.arrays()
+    out = {}
+    for (cname, aname), dom in lw.latent_dom.items():
+        d = lw.model.classes[cname].attr(aname).dist
+        if isinstance(d, StringPrior):
+            ids = dom.id_array()[:-1]
+            sc = np.array([oracle.string_prior(lm[off[i]:off[i + 1]], d.min_len, d.max_len, init, trans) for i in ids])
+            out[(cname, aname)] = np.concatenate([sc, [oracle.dummy_logmass(sc)]])
+        elif isinstance(d, ChooseUniformly):
+            out[(cname, aname)] = np.full(len(dom), oracle.lib().pco_choose_uniformly(len(d.options)))
+        elif isinstance(d, ChooseProportionally):
+            with np.errstate(divide="ignore"):
+                out[(cname, aname)] = np.log(trace.params[(cname, d.param)].value)
+    return out

@@ -1,0 +1,153 @@
+"""GPU parity of the enumeration kernel and of the whole batched sweep against the
+CPU oracle on hospital_dirty.csv (configs[0]/[1] of BASELINE.json): index draws
+bit-exact, log-weights bit-exact by construction (asserted to 1e-12 relative, the
+north-star tolerance being 1e-5)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+from pclean_amd._lib import InferConfig
+from pclean_amd.engine import Engine, InferenceConfig
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def setup(oracle):
+    S = helpers.hospital_setup()
+    eng = Engine(S["lw"], S["obs"], dist_mode=1)
+    eng.upload_trace(S["trace"])
+    S["engine"] = eng
+    S["world"] = helpers.mirror_world(oracle, S["lw"], S["obs"], S["trace"], eng)
+    yield S
+    eng.close()
+
+
+def oracle_sweep(oracle, world, cfg, seed, sweep, cur, n_nodes):
+    nb, n = cur.shape
+    choice = np.empty((nb, n), dtype=np.int32)
+    chosen = np.empty(n, dtype=np.int32)
+    logml = np.empty(n)
+    c = InferConfig(cfg.num_iters, cfg.num_particles, 1, 1, int(cfg.use_mh_instead_of_pg), 50, 100)
+    oracle.lib().pco_sweep_batched(world.h, C.byref(c), C.c_uint64(seed), C.c_uint32(sweep), nb, C.c_int64(0),
+                                   oracle._p(np.ascontiguousarray(cur), C.c_int32), oracle._p(choice, C.c_int32),
+                                   oracle._p(chosen, C.c_int32), oracle._p(logml, C.c_double))
+    new_rows = {}
+    for b in range(nb):
+        k = oracle.lib().pco_new_rows_count(b)
+        if k:
+            rows = np.empty(k, dtype=np.int32)
+            vals = np.empty((k, n_nodes[b]), dtype=np.int32)
+            oracle.lib().pco_new_rows_get(b, n_nodes[b], oracle._p(rows, C.c_int32), oracle._p(vals, C.c_int32))
+            new_rows[b] = (rows, vals)
+    return choice, chosen, logml, new_rows
+
+
+def test_uploaded_tables_match_oracle_formulas(setup, oracle):
+    """CRP prior pieces / option log-probs the library uploads == the oracle's own restatement."""
+    lw, tr, eng = setup["lw"], setup["trace"], setup["engine"]
+    for cname, t in tr.tables.items():
+        cols, counts = t.view()
+        full, m1, scal = eng.hip.get_table_priors(lw.table_id[cname], len(counts))
+        ofull, om1, oscal = oracle.table_priors(counts, t.strength, t.discount)
+        assert np.array_equal(full, ofull) and np.array_equal(m1, om1) and np.array_equal(scal, oscal)
+    cpu = helpers.option_logp_cpu(oracle, lw, tr)
+    for key, lp in eng.option_logp.items():
+        np.testing.assert_allclose(lp, cpu[key], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("block,node", [(0, 0), (0, 1), (0, 2), (0, 9), (1, 0), (1, 1), (1, 3)])
+def test_score_node_parity(setup, oracle, block, node):
+    lw, tr, eng, world = setup["lw"], setup["trace"], setup["engine"], setup["world"]
+    blk = lw.blocks[block]
+    info = blk["node_info"][node]
+    fk = blk["nodes"][node][0] == 0
+    ncand = (tr.tables[info["cls"]].n + 1) if fk else len(lw.latent_dom[(info["cls"], info["attr"])])
+    rnd = np.random.default_rng(block * 100 + node)
+    rows = rnd.integers(0, setup["obs"].shape[1], 64).astype(np.int32)
+    n_state = len(lw.latent_dom[("County", "state")])
+    ctxv = np.stack([rnd.integers(0, n_state, 64), np.zeros(64)], axis=1).astype(np.int32)
+    excl = np.where(rnd.random(64) < 0.7, rnd.integers(0, max(ncand - 1, 1), 64), -1).astype(np.int32) if fk else None
+    snew = rnd.normal(-20, 5, 64) if fk else None
+    got = eng.hip.score_node(block, node, rows, ctxv, excl, snew, seed=99, sweep=3, n_draws=7, n_cand=ncand,
+                             want_scores=True)
+    want = world.score_node(block, node, rows, ctxv, excl, snew, seed=99, sweep=3, n_draws=7, n_cand=ncand,
+                            want_scores=True)
+    assert np.array_equal(got[1], want[1]), "candidate scores differ"
+    assert np.array_equal(got[0], want[0]), "lse differs"
+    assert np.array_equal(got[2], want[2]), "draws differ"
+
+
+@pytest.mark.parametrize("particles,mh", [(2, True), (20, False), (5, False)])
+def test_sweep_parity_hospital(setup, oracle, particles, mh):
+    """configs[0] (MH, 2 particles) and configs[1] (PG, 20 particles) of BASELINE.json."""
+    lw, tr, eng, world = setup["lw"], setup["trace"], setup["engine"], setup["world"]
+    cfg = InferenceConfig(1, particles, use_mh_instead_of_pg=mh)
+    n_nodes = [len(b["nodes"]) for b in lw.blocks]
+    for sweep in (0, 1):
+        choice, chosen, logml, new_rows = eng.sweep(tr, cfg, 20250926, sweep)
+        ochoice, ochosen, ologml, onew = oracle_sweep(oracle, world, cfg, 20250926, sweep, tr.cur, n_nodes)
+        assert np.array_equal(chosen, ochosen), "chosen particle differs"
+        assert np.array_equal(choice, ochoice), "chosen referents differ"
+        np.testing.assert_allclose(logml, ologml, rtol=1e-12, atol=0)
+        assert np.array_equal(logml, ologml)
+        assert set(new_rows) == set(onew)
+        for b in new_rows:
+            assert np.array_equal(new_rows[b][0], onew[b][0]) and np.array_equal(new_rows[b][1], onew[b][1])
+        assert (choice != tr.cur).sum() > 0  # the sweep does move something
+
+
+def test_sweep_after_commit_parity(oracle):
+    """Commit a sweep (new rows, GC), re-upload, sweep again: still bit-exact, counts consistent."""
+    S = helpers.hospital_setup(n_rows=400)
+    lw, tr = S["lw"], S["trace"]
+    eng = Engine(lw, S["obs"], dist_mode=1)
+    cfg = InferenceConfig(1, 8)
+    n_nodes = [len(b["nodes"]) for b in lw.blocks]
+    try:
+        for sweep in range(3):
+            eng.upload_trace(tr)
+            world = helpers.mirror_world(oracle, lw, S["obs"], tr, eng)
+            choice, chosen, logml, new_rows = eng.sweep(tr, cfg, 7, sweep)
+            o = oracle_sweep(oracle, world, cfg, 7, sweep, tr.cur, n_nodes)
+            assert np.array_equal(choice, o[0]) and np.array_equal(chosen, o[1]) and np.array_equal(logml, o[2])
+            tr.commit(choice, new_rows)
+            for bi, blk in enumerate(lw.blocks):
+                t = tr.tables[blk["root_class"]]
+                assert np.array_equal(np.bincount(tr.cur[bi], minlength=t.n), t.counts[:t.n])
+            for cname, t in tr.tables.items():
+                assert np.all(t.counts[:t.n] >= 0) and np.all((t.counts[:t.n] > 0) == t.live[:t.n])
+    finally:
+        eng.close()
+
+
+def test_particle_primitives_parity(hip, oracle):
+    rnd = np.random.default_rng(1)
+    n, P = 500, 20
+    logw = rnd.normal(-50, 1.0, (n, P))
+    logw[::3] += rnd.normal(0, 8.0, (n // 3 + (n % 3 > 0), P))  # some rows degenerate -> ESS < P/2
+    logw[5] = -np.inf
+    anc, inc, ess = hip.maybe_resample(logw, True, 11, 2, 1)
+    oanc = np.empty((n, P), dtype=np.int32)
+    oinc = np.empty(n)
+    oess = np.empty(n)
+    oracle.lib().pco_maybe_resample(n, P, oracle._p(logw, C.c_double), 1, C.c_uint64(11), C.c_uint32(2), C.c_uint32(1),
+                                    C.c_int64(0), oracle._p(oanc, C.c_int32), oracle._p(oinc, C.c_double),
+                                    oracle._p(oess, C.c_double))
+    assert np.array_equal(anc, oanc) and np.array_equal(inc, oinc) and np.array_equal(ess, oess)
+    assert (ess < P / 2).sum() > 20 and (ess >= P / 2).sum() > 20
+    assert np.all(anc[ess < P / 2][:, 0] == 0)  # retained particle survives
+    # ESS agrees with the float formula of row_inference.jl:82-85
+    k = 1
+    assert ess[k] == pytest.approx(oracle.ess(logw[k]), rel=1e-6)
+    for (mh, csmc, pp) in [(0, 1, 20), (1, 1, 2), (1, 0, 2)]:
+        lw_ = logw[:, :pp].copy()
+        ch, tot = hip.final_choice(lw_, mh, csmc, 5, 9)
+        och = np.empty(n, dtype=np.int32)
+        otot = np.empty(n)
+        oracle.lib().pco_final_choice(n, pp, oracle._p(lw_, C.c_double), mh, csmc, C.c_uint64(5), C.c_uint32(9),
+                                      C.c_int64(0), oracle._p(och, C.c_int32), oracle._p(otot, C.c_double))
+        assert np.array_equal(ch, och) and np.array_equal(tot, otot)
+        np.testing.assert_allclose(tot[1], oracle.logsumexp(lw_[1]), rtol=1e-9)
