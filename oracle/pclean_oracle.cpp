@@ -215,6 +215,12 @@ int pco_sweep_batched(const pco::World* w, const pclean_infer_config* cfg, uint6
   }
   return 0;
 }
+/* sequential schedule = CPU baseline (bench.py cpu_baseline leg) */
+int pco_sweep_sequential(pco::World* w, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep, int n_blocks,
+                         int64_t row_offset, int32_t* cur, const double* py, int64_t* n_moved, int64_t* n_new) {
+  pco::sweep_sequential(*w, *cfg, seed, sweep, n_blocks, row_offset, cur, py, n_moved, n_new);
+  return 0;
+}
 int pco_new_rows_count(int block) {
   int n = 0;
   for (auto& r : g_new_rows) n += r.block == block;

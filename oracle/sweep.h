@@ -271,5 +271,44 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
   }
 }
 
+/* Sequential-schedule sweep (the reference's schedule, row_inference.jl:169-185):
+ * after each row the reference counts and CRP prior pieces of the referents it
+ * left / joined are updated, so row i+1 sees them.  Rows that choose a NEW referent
+ * keep their old referent here (creating latent rows is bookkeeping outside the
+ * timed scoring work; counted in n_new).  Used as the single-thread CPU baseline. */
+inline void sweep_sequential(World& w, const pclean_infer_config& cfg, uint64_t seed, uint32_t sweep, int n_blocks,
+                             int64_t row_offset, int32_t* cur /*[n_blocks][N] in/out*/, const double* py /*[64][2]*/,
+                             int64_t* n_moved, int64_t* n_new) {
+  const int N = w.n_rows;
+  std::vector<int32_t> c(n_blocks), ch(n_blocks);
+  std::vector<NewRow> news;
+  *n_moved = 0;
+  *n_new = 0;
+  for (int i = 0; i < N; ++i) {
+    for (int b = 0; b < n_blocks; ++b) c[b] = cur[(size_t)b * N + i];
+    news.clear();
+    run_smc_row(w, cfg, seed, sweep, n_blocks, i, row_offset, c.data(), ch.data(), nullptr, nullptr, news);
+    for (int b = 0; b < n_blocks; ++b) {
+      if (ch[b] == PCLEAN_CHOICE_NEW) {
+        ++*n_new;
+        continue;
+      }
+      if (ch[b] == c[b]) continue;
+      ++*n_moved;
+      OTable& t = w.table[w.block[b].nodes[0].table];
+      const double discount = py[2 * w.block[b].nodes[0].table + 1];
+      const int upd[2] = {c[b], ch[b]};
+      t.counts[c[b]] -= 1;
+      t.counts[ch[b]] += 1;
+      for (int k : upd) {
+        const int64_t cnt = t.counts[k];
+        t.logc_full[k] = cnt > 0 ? std::log((double)cnt - discount) : NEG_INF;
+        t.logc_m1[k] = cnt > 1 ? std::log((double)(cnt - 1) - discount) : NEG_INF;
+      }
+      cur[(size_t)b * N + i] = ch[b];
+    }
+  }
+}
+
 } /* namespace pco */
 #endif

@@ -141,6 +141,17 @@ class HipContext:
               "pclean_get_pair_table")
         return out
 
+    def get_pair_rows(self, table_id, obs_rows, n_lat):
+        obs_rows = np.ascontiguousarray(obs_rows, dtype=np.int32)
+        out = np.empty((len(obs_rows), n_lat), dtype=np.uint16)
+        check(self.h, self.lib.pclean_get_pair_rows(self.h, C.c_int32(table_id), C.c_int32(len(obs_rows)),
+                                                    _p(obs_rows, C.c_int32), _p(out, C.c_uint16)),
+              "pclean_get_pair_rows")
+        return out
+
+    def set_row_offset(self, row_offset):
+        check(self.h, self.lib.pclean_set_row_offset(self.h, C.c_int64(row_offset)), "pclean_set_row_offset")
+
     def get_density_tables(self):
         mr, md, ml = C.c_int32(), C.c_int32(), C.c_int32()
         check(self.h, self.lib.pclean_get_density_tables(self.h, C.byref(mr), C.byref(md), C.byref(ml), None, None),
@@ -245,6 +256,18 @@ class HipContext:
             check(self.h, self.lib.pclean_get_new_rows(self.h, C.c_int32(block_id), C.byref(n), _p(rows, C.c_int32),
                                                        _p(vals, C.c_int32)), "pclean_get_new_rows")
         return rows, vals
+
+    def get_stats(self, table_id, n_rows):
+        out = np.zeros(n_rows, dtype=np.int64)
+        check(self.h, self.lib.pclean_get_stats(self.h, C.c_int32(table_id), _p(out, C.c_int64)), "pclean_get_stats")
+        return out
+
+    def stats_device_ptr(self, table_id):
+        ptr = C.c_void_p()
+        n = C.c_int64()
+        check(self.h, self.lib.pclean_stats_device_ptr(self.h, C.c_int32(table_id), C.byref(ptr), C.byref(n)),
+              "pclean_stats_device_ptr")
+        return ptr.value, n.value
 
     def get_timing(self):
         t = Timing()

@@ -1,0 +1,81 @@
+"""evaluate_accuracy (src/analysis.jl:36-88) over the flat trace, vectorised.
+
+Counts follow the reference exactly: `errors` over every column common to the
+dirty and clean tables (queried or not), `changed` / `cleaned` over queried
+columns, imputations for missing dirty cells; F1 = harmonic mean.
+"""
+import numpy as np
+
+
+def reconstructed_pool_ids(lowered, trace, row_slice=None):
+    """{query column: pool id of the value PClean currently believes, per local row}."""
+    lw = lowered
+    m, q = lw.model, lw.query
+    ocls = m.classes[q.cls]
+    fk_block = {blk["root_fk"]: bi for bi, blk in enumerate(lw.blocks)}
+    out = {}
+    for col, ref in q.cleanmap.items():
+        if "." in ref:
+            head, rest = ref.split(".", 1)
+            bi = fk_block[head]
+            cname = lw.blocks[bi]["root_class"]
+            t = trace.tables[cname]
+            vals = t.cols[lw.colidx[cname][rest], trace.cur[bi]]
+            c2, a2 = m.resolve(cname, rest)
+            out[col] = lw.latent_dom[(c2, a2.name)].id_array()[vals]
+        else:
+            j = ocls.attr(ref)  # julia node: recompute from its arguments
+            parts = []
+            for arg in j.args:
+                head, rest = arg.split(".", 1)
+                bi = fk_block[head]
+                cname = lw.blocks[bi]["root_class"]
+                t = trace.tables[cname]
+                c2, a2 = m.resolve(cname, rest)
+                dom = lw.latent_dom[(c2, a2.name)]
+                parts.append([dom.string(v) for v in t.cols[lw.colidx[cname][rest], trace.cur[bi]]])
+            strs = [j.fn(*xs) for xs in zip(*parts)]
+            out[col] = np.array([lw.pool.index.get(s, -2) for s in strs], dtype=np.int64)
+    return out
+
+
+def accuracy_counts(lowered, trace, dirty, clean):
+    """The five counters of evaluate_accuracy for the rows held by `trace`."""
+    lw = lowered
+    ours = reconstructed_pool_ids(lw, trace)
+    n = trace.cur.shape[1]
+    errors = changed = cleaned = imputed = imputed_ok = 0
+    for col in clean:
+        if col not in dirty:
+            continue
+        d, c = dirty[col], clean[col]
+        dmiss = np.array([v is None for v in d[:n]])
+        ne = np.array([(x != y) for x, y in zip(d[:n], c[:n])])
+        errors += int(np.sum(ne & ~dmiss))
+        if col not in ours:
+            continue
+        idx = lw.pool.index
+        d_id = np.array([idx.get(v, -3) if v is not None else -4 for v in d[:n]], dtype=np.int64)
+        c_id = np.array([idx.get(v, -5) if v is not None else -6 for v in c[:n]], dtype=np.int64)
+        o = ours[col]
+        cmiss = c_id == -6
+        imputed += int(np.sum(dmiss & ~cmiss))
+        imputed_ok += int(np.sum(dmiss & ~cmiss & (o == c_id)))
+        ch = (~dmiss) & (o != d_id)
+        changed += int(np.sum(ch))
+        cleaned += int(np.sum(ch & (o == c_id)))
+    return np.array([errors, changed, cleaned, imputed, imputed_ok], dtype=np.int64)
+
+
+def f1_from_counts(cnt):
+    errors, changed, cleaned, imputed, imputed_ok = [float(x) for x in cnt]
+    num = cleaned + imputed_ok
+    precision = num / (changed + imputed) if (changed + imputed) > 0 else float("nan")
+    recall = num / (errors + imputed) if (errors + imputed) > 0 else float("nan")
+    f1 = 2.0 / (1 / precision + 1 / recall) if num > 0 else 0.0
+    return dict(f1=f1, errors=int(errors), changed=int(changed), cleaned=int(cleaned), precision=precision,
+                recall=recall, imputed=int(imputed), correctly_imputed=int(imputed_ok))
+
+
+def evaluate_accuracy(lowered, trace, dirty, clean):
+    return f1_from_counts(accuracy_counts(lowered, trace, dirty, clean))

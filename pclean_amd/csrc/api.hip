@@ -222,6 +222,27 @@ extern "C" int pclean_get_pair_table(pclean_ctx* ctx, int32_t table_id, uint16_t
   return PCLEAN_OK;
 }
 
+extern "C" int pclean_get_pair_rows(pclean_ctx* ctx, int32_t table_id, int32_t n, const int32_t* obs_rows,
+                                    uint16_t* out) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || !out || n <= 0 || !obs_rows ||
+      !ctx->pair[table_id].valid)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_get_pair_rows: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  PairTable& pt = ctx->pair[table_id];
+  std::vector<uint8_t> tmp((size_t)pt.n_lat * pt.elem_bytes);
+  for (int j = 0; j < n; ++j) {
+    if (obs_rows[j] < 0 || obs_rows[j] >= pt.n_obs) return pclean_fail(ctx, PCLEAN_ERR_ARG, "obs row out of range");
+    HIPCHK(ctx, hipMemcpy(tmp.data(), pt.d.p + (size_t)obs_rows[j] * pt.n_lat * pt.elem_bytes, tmp.size(),
+                          hipMemcpyDeviceToHost));
+    uint16_t* o = out + (size_t)j * pt.n_lat;
+    if (pt.elem_bytes == 2)
+      memcpy(o, tmp.data(), tmp.size());
+    else
+      for (int v = 0; v < pt.n_lat; ++v) o[v] = tmp[v];
+  }
+  return PCLEAN_OK;
+}
+
 // ---------------------------------------------------------------------------
 // StringPrior (string_prior.jl:43-61): one lane per string, sequential bigram
 // chain (the sum order is part of the parity contract).

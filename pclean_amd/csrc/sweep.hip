@@ -914,6 +914,15 @@ extern "C" int pclean_stats_device_ptr(pclean_ctx* ctx, int32_t table_id, void**
   return PCLEAN_OK;
 }
 
+extern "C" int pclean_get_stats(pclean_ctx* ctx, int32_t table_id, int64_t* out) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || !ctx->cand[table_id].valid || !out)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_get_stats: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const CandTable& t = ctx->cand[table_id];
+  if (t.n_rows) HIPCHK(ctx, hipMemcpy(out, t.stats.p, (size_t)t.n_rows * 8, hipMemcpyDeviceToHost));
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_get_timing(pclean_ctx* ctx, pclean_timing* out) {
   if (!ctx || !out) return PCLEAN_ERR_ARG;
   *out = ctx->timing;

@@ -111,3 +111,8 @@ class Engine:
             if len(rows):
                 new_rows[bi] = (rows, vals)
         return choice, chosen, logml, new_rows
+
+    def sweep_stats(self, trace):
+        """Delta reference counts of the last sweep per block root table (the all-reduce payload)."""
+        return {bi: self.hip.get_stats(self.lw.table_id[blk["root_class"]], trace.tables[blk["root_class"]].n)
+                for bi, blk in enumerate(self.lw.blocks)}

@@ -220,8 +220,18 @@ class Trace:
             cname = blk["root_class"]
             t = tr.tables[cname]
             paths = clean_by_path[bi]
-            for i in range(n_rows):
-                r = build(cname, lambda p, i=i: paths[p][i])
-                t.counts[r] += 1
-                tr.cur[bi, i] = r
+            names = sorted(paths)
+            cols = [paths[p] for p in names]
+            root_memo = {}
+            cur = np.empty(n_rows, dtype=np.int32)
+            for i, key in enumerate(zip(*cols)):
+                r = root_memo.get(key)
+                if r is None:
+                    vals = dict(zip(names, key))
+                    r = build(cname, lambda p, vals=vals: vals[p])
+                    root_memo[key] = r
+                cur[i] = r
+            tr.cur[bi] = cur
+            t = tr.tables[cname]
+            t.counts[:t.n] += np.bincount(cur, minlength=t.n)
         return tr
