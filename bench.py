@@ -60,6 +60,40 @@ def build_workload(n_rows, n_hosp, seed):
     return dirty, clean, lw, obs, tr
 
 
+def oracle_world_for_rows(orc, lw, obs_local, tr, eng, rows):
+    """Oracle World (test infrastructure) holding the given observed rows and the full latent
+    state currently uploaded to `eng`; pair-table rows and double tables are read back from the
+    library so both sides score with bit-identical inputs.  Returns (world, py-params array)."""
+    sub = obs_local[:, rows]
+    w = orc.World()
+    sub_local = np.empty_like(sub)
+    remap = {}
+    for j, dirty_attr in enumerate(lw.obs_cols):  # remap each column to the values present in the sample
+        u, inv = np.unique(sub[j], return_inverse=True)
+        assert u.size == 0 or u[0] >= 0, "missing observations are not expected in the synthetic table"
+        remap[dirty_attr] = u
+        sub_local[j] = inv
+    w.set_obs(np.ascontiguousarray(sub_local))
+    mr, md, ml, nb, logl = eng.hip.get_density_tables()
+    w.set_density(mr, md, ml, nb, logl)
+    for key, (pid, odom, ldom) in lw.pair_id.items():
+        d = eng.hip.get_pair_rows(pid, remap[key[0]], len(ldom))
+        w.set_pair(pid, d, lw.pool.lens[ldom.id_array()].astype(np.uint16))
+    for fid, fn in lw.fn_tables.items():
+        w.set_fn(fid, fn)
+    py = np.zeros((64, 2))
+    for cname, t in tr.tables.items():
+        cols, counts = t.view()
+        full, m1, scal = eng.hip.get_table_priors(lw.table_id[cname], len(counts))
+        w.set_table(lw.table_id[cname], np.ascontiguousarray(cols), counts, full, m1, scal)
+        py[lw.table_id[cname]] = (t.strength, t.discount)
+    for (cname, aname), dom in lw.latent_dom.items():
+        w.set_options(lw.option_id[(cname, aname)], lw.option_values[(cname, aname)], eng.option_logp[(cname, aname)])
+    for bi in range(len(lw.blocks)):
+        w.load_block(bi, *lw.block_arrays(bi))
+    return w, py
+
+
 def cpu_baseline(lw, obs_local, tr, eng, cfg, seed, target_seconds):
     """Oracle, sequential schedule, single thread, on a prefix sample of the rows."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -70,35 +104,7 @@ def cpu_baseline(lw, obs_local, tr, eng, cfg, seed, target_seconds):
     eng.upload_trace(tr)  # the tables the oracle copies are the ones currently in the trace
 
     def run(n_sample):
-        sub = obs_local[:, :n_sample]
-        w = orc.World()
-        # remap each observed column to the unique values present in the sample
-        sub_local = np.empty_like(sub)
-        remap = {}
-        for j, dirty_attr in enumerate(lw.obs_cols):
-            u, inv = np.unique(sub[j], return_inverse=True)
-            remap[dirty_attr] = u
-            sub_local[j] = inv
-        w.set_obs(np.ascontiguousarray(sub_local))
-        mr, md, ml, nb, logl = eng.hip.get_density_tables()
-        w.set_density(mr, md, ml, nb, logl)
-        for key, (pid, odom, ldom) in lw.pair_id.items():
-            rows = remap[key[0]]
-            d = eng.hip.get_pair_rows(pid, rows, len(ldom))
-            w.set_pair(pid, d, lw.pool.lens[ldom.id_array()].astype(np.uint16))
-        for fid, fn in lw.fn_tables.items():
-            w.set_fn(fid, fn)
-        py = np.zeros((64, 2))
-        for cname, t in tr.tables.items():
-            cols, counts = t.view()
-            full, m1, scal = eng.hip.get_table_priors(lw.table_id[cname], len(counts))
-            w.set_table(lw.table_id[cname], np.ascontiguousarray(cols), counts, full, m1, scal)
-            py[lw.table_id[cname]] = (t.strength, t.discount)
-        for (cname, aname), dom in lw.latent_dom.items():
-            w.set_options(lw.option_id[(cname, aname)], lw.option_values[(cname, aname)],
-                          eng.option_logp[(cname, aname)])
-        for bi in range(len(lw.blocks)):
-            w.load_block(bi, *lw.block_arrays(bi))
+        w, py = oracle_world_for_rows(orc, lw, obs_local, tr, eng, np.arange(n_sample))
         cur = np.ascontiguousarray(tr.cur[:, :n_sample].copy())
         c = InferConfig(1, cfg.num_particles, 1, 1, int(cfg.use_mh_instead_of_pg), 50, 100)
         moved, new = C.c_int64(), C.c_int64()
@@ -164,6 +170,9 @@ def main():
         choice, chosen, logml, new_rows = eng.sweep(tr, cfg, args.seed, idx)
         stats = eng.sweep_stats(tr)
         tm = eng.hip.get_timing()
+        if os.environ.get("PCLEAN_BENCH_DEBUG"):
+            log("[bench] moved per block", (choice != tr.cur).sum(axis=1), "new per block", (choice < 0).sum(axis=1),
+                "chosen particle hist", np.bincount(chosen, minlength=cfg.num_particles)[:6])
         changed = exchange_and_commit(tr, lw, comm, lo, choice, stats, new_rows)
         return tm, changed
 

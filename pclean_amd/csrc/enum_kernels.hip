@@ -1,22 +1,28 @@
-// Enumeration kernel: rows x candidate-referents proposal scoring, per-item
+// Enumeration kernels: rows x candidate-referents proposal scoring, per-item
 // fixed-point log-sum-exp and inverse-CDF categorical draws.
 //
-// Takes over the enumeration loops the reference JIT-generates per block
+// Take over the enumeration loops the reference JIT-generates per block
 // (src/inference/proposal_compiler.jl:131-252 ForeignKeyNode, 55-129 discrete
 // RandomChoiceNode) plus the CRP prior (165-171) and the AddTypos densities
 // they call (src/distributions/add_typos.jl:50-66, via the pair tables).
 //
-// One workgroup (256 lanes = 4 wavefronts) per work item:
+// enum_node_kernel — one workgroup (256 lanes = 4 wavefronts) per work item,
+// candidate scores resident in LDS (<= ~20k candidates):
 //   phase 1  lane-strided over candidates: coalesced loads of the flattened
 //            latent table columns, gather of the pair-table byte, fp64 density
 //            epilogue, score -> LDS
 //   phase 2  wave-shuffle + LDS max reduction
-//   phase 3  u_k = floor(exp(s_k - m) 2^40) in place (uint64, integer sums are
+//   phase 3  u_k = floor(exp(s_k - m) 2^40) in place (uint64; integer sums are
 //            order independent => bit-identical to the sequential oracle)
 //   phase 4  per-lane contiguous chunk sums, shuffle scan across the block
 //   phase 5  lse = m + log(U 2^-40); Philox draws located by the owning lane
+// enum_node_big_kernel — same contract for candidate sets that do not fit in
+// LDS (large option lists of StringPrior / ChooseUniformly leaves): scores are
+// recomputed per pass instead of stored (max pass, weight pass, locate pass).
 #include "../../include/pclean_detmath.h"
 #include "../../include/pclean_philox.h"
+#include <algorithm>
+
 #include "enum.h"
 
 #define HALF_LOG26 1.629048269010741
@@ -38,118 +44,140 @@ __device__ __forceinline__ double term_density(const TermDev& tm, const DensDev&
   return l;
 }
 
+struct ItemView {
+  int row, excl;
+  const int32_t* ctxv;
+  bool deleted;
+  double logden;
+};
+
+__device__ __forceinline__ ItemView item_view(const NodeDev& nd, const ItemsDev& it, int t) {
+  ItemView v;
+  v.row = it.row ? it.row[t] : t;
+  v.excl = it.excl ? it.excl[t] : -1;
+  v.ctxv = it.ctx ? it.ctx + (size_t)t * PCLEAN_MAX_CTX : nullptr;
+  v.deleted = false;
+  v.logden = 0.0;
+  if (nd.kind == PCLEAN_NODE_FK) {
+    const bool excluded = v.excl >= 0;
+    v.deleted = excluded && nd.counts[v.excl] <= 1;
+    v.logden = excluded ? nd.scal[1] : nd.scal[0];
+  }
+  return v;
+}
+
+// score of existing candidate k (the single definition both kernels use, so the
+// fp64 operation order — prior, then terms in plan order — is identical)
+__device__ __forceinline__ double candidate_score(const NodeDev& nd, const DensDev& dn, const ItemView& v, int k) {
+  double sk;
+  if (nd.kind == PCLEAN_NODE_FK) {
+    if (nd.counts[k] == 0) return -__builtin_inf();  // free slot
+    if (k == v.excl)
+      sk = v.deleted ? -__builtin_inf() : nd.logc_m1[k] - v.logden;
+    else
+      sk = nd.logc_full[k] - v.logden;
+  } else {
+    sk = nd.logc_full[k];
+  }
+  for (int ti = 0; ti < nd.n_terms; ++ti) {
+    const TermDev& tm = nd.terms[ti];
+    const int o = tm.obs_col[v.row];
+    if (o < 0) continue;  // explicitly missing observation (add_typos.jl:51-53)
+    int val = tm.cand_col[k];
+    if (tm.ctx_slot >= 0) val = tm.fn[(size_t)v.ctxv[tm.ctx_slot] * tm.fn_nb + val];
+    const size_t idx = (size_t)o * tm.n_lat + val;
+    const int d = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
+    sk += term_density(tm, dn, d, val);
+  }
+  return sk;
+}
+
+// score of the "new row" candidate (proposal_compiler.jl:221-230): CRP new-table
+// term + log-marginals of the children, added in plan order
+__device__ __forceinline__ double new_score(const NodeDev& nd, const ChildrenDev& ch, const ItemView& v, int t) {
+  double snew = 0.0;
+  for (int c = 0; c < ch.n; ++c) {
+    size_t idx = (size_t)t;
+    if (ch.obs_col[c]) {
+      const int o = ch.obs_col[c][v.row];
+      idx = o < 0 ? (size_t)ch.n_obs[c] : (size_t)o;
+    }
+    snew += ch.arr[c][idx];
+  }
+  return ((v.deleted ? nd.scal[3] : nd.scal[2]) - v.logden) + snew;
+}
+
+// exclusive block scan of one uint64 per lane (256 lanes); returns lane prefix, sets total
+__device__ __forceinline__ uint64_t block_excl_scan(uint64_t part, uint64_t* wsum, uint64_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long incl = part;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long x = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += x;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint64_t base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  return base + incl - part;
+}
+
 __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
                                                         const ChildrenDev ch, uint64_t seed, uint32_t sweep,
-                                                        uint32_t site, int n_draws, double* __restrict__ lse_out,
+                                                        uint32_t site, int n_draws, int item_base,
+                                                        double* __restrict__ lse_out,
                                                         double* __restrict__ scores_out,
                                                         int32_t* __restrict__ draws_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int t = blockIdx.x;
+  const int t = blockIdx.x + item_base;
   const int n = nd.n_cand;
   const bool fk = nd.kind == PCLEAN_NODE_FK;
   const int nc = n + (fk ? 1 : 0);
-  double* s = (double*)smem;                            // [nc]
-  uint64_t* u = (uint64_t*)smem;                        // same storage, after phase 3
+  double* s = (double*)smem;                                    // [nc]
+  uint64_t* u = (uint64_t*)smem;                                // same storage, after phase 3
   double* red = (double*)(smem + (size_t)((nc + 1) & ~1) * 8);  // [8]
-  uint64_t* wsum = (uint64_t*)(red + 8);                // [8]
-
-  const int row = it.row ? it.row[t] : t;
-  const int excl = it.excl ? it.excl[t] : -1;
-  const int32_t* ctxv = it.ctx ? it.ctx + (size_t)t * PCLEAN_MAX_CTX : nullptr;
-
-  bool deleted = false;
-  double logden = 0.0;
-  if (fk) {
-    const bool excluded = excl >= 0;
-    deleted = excluded && nd.counts[excl] <= 1;
-    logden = excluded ? nd.scal[1] : nd.scal[0];
-  }
+  uint64_t* wsum = (uint64_t*)(red + 8);                        // [8]
+  const ItemView v = item_view(nd, it, t);
 
   // ---- phase 1: scores ----------------------------------------------------
   double lmax = -__builtin_inf();
   for (int k = tid; k < n; k += 256) {
-    double sk;
-    bool live = true;
-    if (fk) {
-      if (nd.counts[k] == 0) {
-        sk = -__builtin_inf();
-        live = false;
-      } else if (k == excl) {
-        sk = deleted ? -__builtin_inf() : nd.logc_m1[k] - logden;
-      } else {
-        sk = nd.logc_full[k] - logden;
-      }
-    } else {
-      sk = nd.logc_full[k];
-    }
-    if (live) {
-      for (int ti = 0; ti < nd.n_terms; ++ti) {
-        const TermDev& tm = nd.terms[ti];
-        const int o = tm.obs_col[row];
-        if (o < 0) continue;
-        int val = tm.cand_col[k];
-        if (tm.ctx_slot >= 0) val = tm.fn[(size_t)ctxv[tm.ctx_slot] * tm.fn_nb + val];
-        const size_t idx = (size_t)o * tm.n_lat + val;
-        const int d = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
-        sk += term_density(tm, dn, d, val);
-      }
-    }
+    const double sk = candidate_score(nd, dn, v, k);
     s[k] = sk;
     if (scores_out) scores_out[(size_t)t * nc + k] = sk;
     lmax = fmax(lmax, sk);
   }
   if (fk && tid == 0) {
-    double snew = 0.0;
-    for (int c = 0; c < ch.n; ++c) {
-      size_t idx = (size_t)t;
-      if (ch.obs_col[c]) {
-        const int o = ch.obs_col[c][row];
-        idx = o < 0 ? (size_t)ch.n_obs[c] : (size_t)o;
-      }
-      snew += ch.arr[c][idx];
-    }
-    const double sn = ((deleted ? nd.scal[3] : nd.scal[2]) - logden) + snew;
+    const double sn = new_score(nd, ch, v, t);
     s[n] = sn;
     if (scores_out) scores_out[(size_t)t * nc + n] = sn;
     lmax = fmax(lmax, sn);
   }
-
   // ---- phase 2: max ----------------------------------------------------------
   lmax = wave_max(lmax);
   if (lane == 0) red[wave] = lmax;
   __syncthreads();
   const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-
   // ---- phase 3: fixed-point weights in place ----------------------------------
   for (int k = tid; k < nc; k += 256) {
     const double sk = s[k];
     u[k] = (m == -__builtin_inf()) ? 0ull : pclean_fixw(sk - m);
   }
   __syncthreads();
-
   // ---- phase 4: chunk sums + block scan ---------------------------------------
   const int chunk = (nc + 255) / 256;
   const int lo = min(tid * chunk, nc), hi = min(lo + chunk, nc);
   uint64_t part = 0;
   for (int k = lo; k < hi; ++k) part += u[k];
-  uint64_t incl = part;
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint64_t v = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += v;
-  }
-  if (lane == 63) wsum[wave] = incl;
-  __syncthreads();
-  uint64_t base = 0;
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-  const uint64_t U = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-  const uint64_t pre = base + incl - part;  // exclusive prefix of this lane's chunk
-
+  uint64_t U;
+  const uint64_t pre = block_excl_scan(part, wsum, &U);
   // ---- phase 5: lse + draws ----------------------------------------------------
   if (tid == 0 && lse_out) lse_out[t] = pclean_lse_from_fix(m, U);
   if (n_draws > 0) {
-    const uint32_t rng_row = (uint32_t)((int64_t)row + it.row_offset);
+    const uint32_t rng_row = (uint32_t)((int64_t)v.row + it.row_offset);
     for (int j = 0; j < n_draws; ++j) {
       const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)j;
       int32_t* dst = draws_out + (size_t)t * n_draws + j;
@@ -172,24 +200,102 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   }
 }
 
+__global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
+                                                            const ChildrenDev ch, uint64_t seed, uint32_t sweep,
+                                                            uint32_t site, int n_draws, int item_base,
+                                                            double* __restrict__ lse_out,
+                                                            double* __restrict__ scores_out,
+                                                            int32_t* __restrict__ draws_out) {
+  __shared__ double red[8];
+  __shared__ uint64_t wsum[8];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.x + item_base;
+  const int n = nd.n_cand;
+  const bool fk = nd.kind == PCLEAN_NODE_FK;
+  const int nc = n + (fk ? 1 : 0);
+  const ItemView v = item_view(nd, it, t);
+  const double sn = fk ? new_score(nd, ch, v, t) : -__builtin_inf();
+
+  // pass A: max (lane-strided, coalesced)
+  double lmax = -__builtin_inf();
+  for (int k = tid; k < n; k += 256) {
+    const double sk = candidate_score(nd, dn, v, k);
+    if (scores_out) scores_out[(size_t)t * nc + k] = sk;
+    lmax = fmax(lmax, sk);
+  }
+  if (fk) {
+    lmax = fmax(lmax, sn);
+    if (scores_out && tid == 0) scores_out[(size_t)t * nc + n] = sn;
+  }
+  lmax = wave_max(lmax);
+  if (lane == 0) red[wave] = lmax;
+  __syncthreads();
+  const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+
+  // pass B: fixed-point weights over contiguous per-lane chunks (natural order prefix)
+  const int chunk = (nc + 255) / 256;
+  const int lo = min(tid * chunk, nc), hi = min(lo + chunk, nc);
+  uint64_t part = 0;
+  if (m != -__builtin_inf())
+    for (int k = lo; k < hi; ++k) {
+      const double sk = (k == n) ? sn : candidate_score(nd, dn, v, k);
+      part += pclean_fixw(sk - m);
+    }
+  uint64_t U;
+  const uint64_t pre = block_excl_scan(part, wsum, &U);
+  if (tid == 0 && lse_out) lse_out[t] = pclean_lse_from_fix(m, U);
+
+  // pass C: draws, located by recomputing the owning lane's chunk
+  if (n_draws > 0) {
+    const uint32_t rng_row = (uint32_t)((int64_t)v.row + it.row_offset);
+    for (int j = 0; j < n_draws; ++j) {
+      const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)j;
+      int32_t* dst = draws_out + (size_t)t * n_draws + j;
+      if (U == 0) {
+        if (tid == 0) *dst = fk ? PCLEAN_CHOICE_NEW : n - 1;
+        continue;
+      }
+      const uint64_t R = pclean_rand64(seed, rng_row, site, pid, sweep);
+      const uint64_t x = pclean_mulhi64(R, U);
+      if (x >= pre && x < pre + part) {
+        uint64_t acc = pre;
+        int k = lo;
+        for (; k < hi; ++k) {
+          const double sk = (k == n) ? sn : candidate_score(nd, dn, v, k);
+          acc += pclean_fixw(sk - m);
+          if (acc > x) break;
+        }
+        *dst = (fk && k == n) ? PCLEAN_CHOICE_NEW : k;
+      }
+    }
+  }
+}
+
 int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const ChildrenDev& ch, uint64_t seed,
                        uint32_t sweep, uint32_t site, int n_draws, double* lse_out, double* scores_out,
                        int32_t* draws_out) {
   if (it.n <= 0) return PCLEAN_OK;
   const int nc = nd.n_cand + (nd.kind == PCLEAN_NODE_FK ? 1 : 0);
   const size_t lds = (size_t)((nc + 1) & ~1) * 8 + 16 * 8;
-  if (lds > 160 * 1024)
-    return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "candidate table with %d rows exceeds the LDS-resident enumeration kernel",
-                       nd.n_cand);
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0};
-  static size_t lds_set = 0;
-  if (lds > lds_set) {
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)enum_node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-    lds_set = 160 * 1024;
+  // a launch may not exceed 2^32 threads: chunk the items (grid = chunk, 256 lanes each)
+  const int kMaxBlocks = 4 * 1024 * 1024;
+  if (lds > 160 * 1024) {
+    for (int base = 0; base < it.n; base += kMaxBlocks)
+      hipLaunchKernelGGL(enum_node_big_kernel, dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), 0, ctx->stream, nd,
+                         dn, it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out);
+  } else {
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)enum_node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024));
+      attr_set = true;
+    }
+    for (int base = 0; base < it.n; base += kMaxBlocks)
+      hipLaunchKernelGGL(enum_node_kernel, dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), lds, ctx->stream, nd, dn,
+                         it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out);
   }
-  hipLaunchKernelGGL(enum_node_kernel, dim3(it.n), dim3(256), lds, ctx->stream, nd, dn, it, ch, seed, sweep, site,
-                     n_draws, lse_out, scores_out, draws_out);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }

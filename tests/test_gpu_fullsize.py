@@ -1,0 +1,67 @@
+"""Full-size (BASELINE.json configs[4]: 1M rows, 10k latent hospitals, 20 particles)
+checks through size-independent properties: determinism, bit-exact parity with the
+oracle on row chunks spread over the table (first / middle / last rows), conservation
+of the reference-count deltas, and sanity of the moved fraction."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_million_row_sweep_properties(oracle):
+    sys.path.insert(0, ROOT)
+    import bench
+    from pclean_amd import _lib
+    from pclean_amd._lib import InferConfig
+    from pclean_amd.engine import Engine, InferenceConfig
+    n_rows, n_hosp, P, seed = 1_000_000, 10_000, 20, 20250926
+    dirty, clean, lw, obs, tr = bench.build_workload(n_rows, n_hosp, seed)
+    eng = Engine(lw, obs, dist_mode=_lib.DIST_OSA)
+    try:
+        eng.upload_trace(tr)
+        cfg = InferenceConfig(1, P)
+        choice, chosen, logml, new_rows = eng.sweep(tr, cfg, seed, 0)
+        stats = eng.sweep_stats(tr)
+        # (a) determinism
+        choice2, chosen2, logml2, _ = eng.sweep(tr, cfg, seed, 0)
+        assert np.array_equal(choice, choice2) and np.array_equal(chosen, chosen2) and np.array_equal(logml, logml2)
+        # (b) parity on chunks spread over the table
+        c = InferConfig(1, P, 1, 1, 0, 50, 100)
+        for start in (0, n_rows // 2 - 37, n_rows - 120):
+            rows = np.arange(start, start + 120)
+            w, _ = bench.oracle_world_for_rows(oracle, lw, obs, tr, eng, rows)
+            cur = np.ascontiguousarray(tr.cur[:, rows])
+            och = np.empty((2, len(rows)), dtype=np.int32)
+            ocp = np.empty(len(rows), dtype=np.int32)
+            oml = np.empty(len(rows))
+            oracle.lib().pco_sweep_batched(w.h, C.byref(c), C.c_uint64(seed), C.c_uint32(0), 2, C.c_int64(start),
+                                           oracle._p(cur, C.c_int32), oracle._p(och, C.c_int32),
+                                           oracle._p(ocp, C.c_int32), oracle._p(oml, C.c_double))
+            assert np.array_equal(choice[:, rows], och), start
+            assert np.array_equal(chosen[rows], ocp), start
+            assert np.array_equal(logml[rows], oml), start
+        # (c) conservation: every moved row takes one reference away and (unless NEW) adds one
+        for bi, blk in enumerate(lw.blocks):
+            t = tr.tables[blk["root_class"]]
+            moved = choice[bi] != tr.cur[bi]
+            want = -np.bincount(tr.cur[bi][moved], minlength=t.n)
+            ex = moved & (choice[bi] >= 0)
+            want = want + np.bincount(choice[bi][ex], minlength=t.n)
+            assert np.array_equal(stats[bi], want)
+            assert stats[bi].sum() == -int((choice[bi] < 0).sum())
+            got_new = new_rows.get(bi, (np.zeros(0, np.int32), None))[0]
+            assert np.array_equal(np.sort(got_new), np.nonzero(choice[bi] < 0)[0])
+        # (d) started from the true entities: a sweep must leave almost every row where it is
+        assert (choice[0] != tr.cur[0]).mean() < 0.01
+        assert (choice[1] != tr.cur[1]).mean() < 0.05
+        # chosen particle is uniform-ish over the 20 particles (weights equal within a context)
+        hist = np.bincount(chosen, minlength=P) / n_rows
+        assert hist.min() > 0.03 and hist.max() < 0.07
+    finally:
+        eng.close()

@@ -151,3 +151,42 @@ def test_particle_primitives_parity(hip, oracle):
                                       C.c_int64(0), oracle._p(och, C.c_int32), oracle._p(otot, C.c_double))
         assert np.array_equal(ch, och) and np.array_equal(tot, otot)
         np.testing.assert_allclose(tot[1], oracle.logsumexp(lw_[1]), rtol=1e-9)
+
+
+def test_big_option_list_kernel_parity(oracle):
+    """Option lists too large for LDS go through enum_node_big_kernel: same results."""
+    from pclean_amd.model import AddTypos, ChooseUniformly, LoweredModel, Model, Query
+    from pclean_amd.trace import Trace
+    rnd = np.random.default_rng(3)
+    words = list(dict.fromkeys("".join(rnd.choice(list("abcdefgh"), size=rnd.integers(4, 9))) for _ in range(40000)))[:24000]
+    m = Model()
+    a = m.add_class("A")
+    a.choice("x", ChooseUniformly(words))
+    o = m.add_class("Obs")
+    o.fk("a", "A")
+    o.choice("y", AddTypos("a.x"))
+    q = Query(m, "Obs", {"Y": ("a.x", "y")})
+    n = 300
+    clean = [words[i % 50] for i in range(n)]
+    dirty = {"Y": [w if i % 7 else w[:-1] + "x" for i, w in enumerate(clean)]}
+    lw = LoweredModel(m, q, dirty)
+    obs = lw.encode_observations(dirty)
+    tr = Trace.from_clean_values(lw, [{"x": clean}], n, 0)
+    eng = Engine(lw, obs, dist_mode=0)
+    try:
+        eng.upload_trace(tr)
+        world = helpers.mirror_world(oracle, lw, obs, tr, eng)
+        cfg = InferenceConfig(1, 6)
+        choice, chosen, logml, new_rows = eng.sweep(tr, cfg, 5, 0)
+        oc = oracle_sweep(oracle, world, cfg, 5, 0, tr.cur, [len(b["nodes"]) for b in lw.blocks])
+        assert np.array_equal(choice, oc[0]) and np.array_equal(chosen, oc[1]) and np.array_equal(logml, oc[2])
+        assert set(new_rows) == set(oc[3]) and len(new_rows) > 0
+        for b in new_rows:
+            assert np.array_equal(new_rows[b][0], oc[3][b][0]) and np.array_equal(new_rows[b][1], oc[3][b][1])
+        # direct node check incl. draws on the big leaf
+        rows = np.arange(0, 40, dtype=np.int32)
+        got = eng.hip.score_node(0, 1, rows, seed=1, sweep=2, n_draws=3, n_cand=len(words), want_scores=True)
+        want = world.score_node(0, 1, rows, seed=1, sweep=2, n_draws=3, n_cand=len(words), want_scores=True)
+        assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]) and np.array_equal(got[2], want[2])
+    finally:
+        eng.close()
