@@ -168,7 +168,8 @@ def test_big_option_list_kernel_parity(oracle):
     q = Query(m, "Obs", {"Y": ("a.x", "y")})
     n = 300
     clean = [words[i % 50] for i in range(n)]
-    dirty = {"Y": [w if i % 7 else w[:-1] + "x" for i, w in enumerate(clean)]}
+    # every 7th row observes an atom that no latent row holds yet -> its particles propose a NEW row
+    dirty = {"Y": [w if i % 7 else words[1000 + i] for i, w in enumerate(clean)]}
     lw = LoweredModel(m, q, dirty)
     obs = lw.encode_observations(dirty)
     tr = Trace.from_clean_values(lw, [{"x": clean}], n, 0)
