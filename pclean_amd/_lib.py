@@ -177,10 +177,17 @@ class HipContext:
         return out
 
     # -- candidate tables -----------------------------------------------------
-    def set_table(self, table_id, cols, counts, strength, discount):
-        cols = np.ascontiguousarray(cols, dtype=np.int32)  # [n_cols][n_rows]
+    def force_generic(self, on):
+        check(self.h, self.lib.pclean_debug_force_generic(self.h, C.c_int32(int(on))), "pclean_debug_force_generic")
+
+    def set_table(self, table_id, cols, counts, strength, discount, n_cols=None):
+        """cols None (with n_cols given) keeps the columns uploaded before and refreshes the counts only."""
         counts = np.ascontiguousarray(counts, dtype=np.int64)
-        n_cols, n_rows = cols.shape if cols.ndim == 2 else (0, len(counts))
+        if cols is None:
+            n_rows = len(counts)
+        else:
+            cols = np.ascontiguousarray(cols, dtype=np.int32)  # [n_cols][n_rows]
+            n_cols, n_rows = cols.shape if cols.ndim == 2 else (0, len(counts))
         check(self.h, self.lib.pclean_set_table(self.h, C.c_int32(table_id), C.c_int32(n_rows), C.c_int32(n_cols),
                                                 _p(cols, C.c_int32), _p(counts, C.c_int64), C.c_double(strength),
                                                 C.c_double(discount)), "pclean_set_table")

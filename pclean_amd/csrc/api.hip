@@ -7,6 +7,7 @@
 #include "ctx.h"
 
 static const double kNegInf = -std::numeric_limits<double>::infinity();
+uint64_t g_pclean_version = 0;
 
 extern "C" const char* pclean_version(void) { return "pclean-hip 0.1 (gfx950)"; }
 
@@ -183,6 +184,7 @@ extern "C" int pclean_build_pair_table(pclean_ctx* ctx, int32_t table_id, int32_
   if (rc) return rc;
   if (e != hipSuccess) return pclean_fail(ctx, PCLEAN_ERR_HIP, "distance kernel failed: %s", hipGetErrorString(e));
   pt.valid = true;
+  pt.version = ++g_pclean_version;
   return PCLEAN_OK;
 }
 
@@ -203,6 +205,7 @@ extern "C" int pclean_set_pair_table(pclean_ctx* ctx, int32_t table_id, int32_t 
   HIPCHK(ctx, hipMemcpy(pt.d.p, table, (size_t)n_obs * n_lat, hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemset(pt.lat_len.p, 0, n_lat * sizeof(uint16_t)));
   pt.valid = true;
+  pt.version = ++g_pclean_version;
   return PCLEAN_OK;
 }
 
@@ -315,11 +318,14 @@ extern "C" int pclean_string_prior_scores(pclean_ctx* ctx, int32_t n_strings, co
 // hence the "_m1" variants.
 extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_rows, int32_t n_cols,
                                 const int32_t* cols, const int64_t* counts, double strength, double discount) {
-  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || n_rows < 0 || n_cols < 0 || !counts ||
-      (!cols && (int64_t)n_rows * n_cols > 0))
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || n_rows < 0 || n_cols < 0 || !counts)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_table: bad arguments");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   CandTable& t = ctx->cand[table_id];
+  // cols == NULL: keep the columns uploaded before (same shape), refresh counts / CRP pieces only
+  const bool keep_cols = !cols && (int64_t)n_rows * n_cols > 0;
+  if (keep_cols && (!t.valid || t.is_options || t.n_rows != n_rows || t.n_cols != n_cols))
+    return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_set_table: cols == NULL needs a previous upload of the same shape");
   t.is_options = false;
   t.n_rows = n_rows;
   t.n_cols = n_cols;
@@ -344,13 +350,15 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
   t.scal[1] = std::log((double)(total - 1) + strength);
   t.scal[2] = std::log(strength + discount * (double)live);
   t.scal[3] = std::log(strength + discount * (double)(live - 1));
-  if (n) HIPCHK(ctx, hipMemcpy(t.cols.p, cols, n * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (n && !keep_cols) HIPCHK(ctx, hipMemcpy(t.cols.p, cols, n * sizeof(int32_t), hipMemcpyHostToDevice));
   if (n_rows) {
     HIPCHK(ctx, hipMemcpy(t.counts.p, counts, n_rows * sizeof(int64_t), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(t.logc_full.p, t.h_logc_full.data(), n_rows * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(t.logc_m1.p, t.h_logc_m1.data(), n_rows * sizeof(double), hipMemcpyHostToDevice));
   }
   t.valid = true;
+  t.version = ++g_pclean_version;
+  if (!keep_cols) t.cols_version = t.version;
   return PCLEAN_OK;
 }
 
@@ -373,6 +381,7 @@ extern "C" int pclean_set_options(pclean_ctx* ctx, int32_t table_id, int32_t n_o
   t.scal[0] = t.scal[1] = 0.0;
   t.scal[2] = t.scal[3] = kNegInf;
   t.valid = true;
+  t.version = ++g_pclean_version;
   return PCLEAN_OK;
 }
 

@@ -38,8 +38,11 @@ struct DevBuf {
   }
 };
 
+extern uint64_t g_pclean_version;  // bumped whenever a table is (re)uploaded; keys the leaf caches
+
 struct PairTable {
   bool valid = false;
+  uint64_t version = 0;
   int32_t n_obs = 0, n_lat = 0;
   int32_t elem_bytes = 1;     // 1: uint8 distances, 2: uint16
   DevBuf<uint8_t> d;          // [n_obs][n_lat] * elem_bytes
@@ -49,6 +52,8 @@ struct PairTable {
 
 struct CandTable {
   bool valid = false;
+  uint64_t version = 0;       // any re-upload (counts / priors)
+  uint64_t cols_version = 0;  // re-upload of the value columns
   bool is_options = false;
   int32_t n_rows = 0, n_cols = 0;
   DevBuf<int32_t> cols;       // column-major [n_cols][n_rows]
@@ -110,6 +115,7 @@ struct pclean_ctx {
   Block block[PCLEAN_MAX_BLOCKS];
 
   pclean_timing timing = {};
+  bool force_generic = false;  // debug: never take the compact-table root kernel
   void* sweep_state = nullptr;  // owned by sweep.hip
 };
 

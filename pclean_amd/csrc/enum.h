@@ -50,6 +50,34 @@ struct ChildrenDev {
   int32_t n_obs[PCLEAN_MAX_CHILDREN];
 };
 
+// Fast path for a block root with many candidates (the dominant kernel): per term a
+// candidate-compact byte table comp[o][k] = D[o][value of candidate k] (rebuilt only when
+// the latent table's columns change) so a work item streams F contiguous byte rows instead
+// of gathering, plus the candidates' word lengths clen[k].
+struct FastTermDev {
+  const uint8_t* comp;     // [n_obs][kpad]
+  const uint8_t* clen;     // [kpad]
+  const int32_t* obs_col;  // [n_rows]
+  int32_t max_typos, pad;
+};
+struct FastRootDev {
+  int32_t n_cand, kpad, n_terms, lmax, dstride, pad;
+  const double* prior_e;  // [kpad] log(count-discount) - logden_m1, -inf for free slots / padding
+  const double* prior_n;  // [kpad] same with logden_full (no exclusion)
+  const double* logc_m1;
+  const int64_t* counts;
+  double scal[4];
+  FastTermDev terms[PCLEAN_MAX_TERMS];
+};
+
+int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
+                            uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
+                            int32_t* draws_out);
+int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_lat, const int32_t* cand_col,
+                         const uint16_t* lat_len, int n_cand, int kpad, uint8_t* comp, uint8_t* clen);
+int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* logc_full, int n_cand, int kpad,
+                        double logden_e, double logden_n, double* prior_e, double* prior_n);
+
 int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const ChildrenDev& ch, uint64_t seed,
                        uint32_t sweep, uint32_t site, int n_draws, double* lse_out, double* scores_out,
                        int32_t* draws_out);

@@ -106,6 +106,44 @@ __global__ void gather_ctx_kernel(size_t n_items, CtxSrc cs, int32_t* it_ctx) {
   }
 }
 
+// distinct contexts among the particles of a row: rep[s] = first slot of the row with the
+// same ctx tuple; repflag[s] = -1 (compaction marker) for representatives, 0 otherwise
+__global__ void dedup_ctx_kernel(int n_rows, int P, const int32_t* it_ctx, int32_t* repflag, int32_t* rep) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const size_t base = (size_t)i * P;
+  for (int p = 0; p < P; ++p) {
+    int q = 0;
+    for (; q < p; ++q) {
+      bool same = true;
+      for (int c = 0; c < PCLEAN_MAX_CTX; ++c)
+        same &= it_ctx[(base + p) * PCLEAN_MAX_CTX + c] == it_ctx[(base + q) * PCLEAN_MAX_CTX + c];
+      if (same) break;
+    }
+    rep[base + p] = (int32_t)(base + q);
+    repflag[base + p] = q == p ? PCLEAN_CHOICE_NEW : 0;
+  }
+}
+__global__ void ctx_items_kernel(int n, int P, const int32_t* list, const int32_t* it_ctx, const int32_t* cur_b,
+                                 int32_t* row, int32_t* ctxv, int32_t* excl) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int slot = list[j];
+  const int i = slot / P;
+  row[j] = i;
+  excl[j] = cur_b ? cur_b[i] : -1;
+  for (int c = 0; c < PCLEAN_MAX_CTX; ++c) ctxv[j * PCLEAN_MAX_CTX + c] = it_ctx[(size_t)slot * PCLEAN_MAX_CTX + c];
+}
+// particle slot s takes the log-marginal of its context's item and its own draw (particle id = s % P)
+__global__ void expand_ctx_kernel(size_t n_slots, int P, const int32_t* rep, const int32_t* pos, const double* lse_item,
+                                  const int32_t* draws_item, int32_t* draws, double* w) {
+  size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_slots) return;
+  const int item = pos[rep[s]];
+  draws[s] = draws_item[(size_t)item * P + (s % P)];
+  w[s] += lse_item[item];
+}
+
 // root draws [n_rows][P] (or [n_rows*P][1]) -> particle choices; particle 0 keeps
 // the retained referent under CSMC (row_inference.jl:143-145)
 __global__ void set_pchoice_kernel(int n_rows, int P, const int32_t* draws, const int32_t* cur_b, int32_t* pchoice) {
@@ -345,7 +383,16 @@ struct BlockRun {  // per-block device state of one sweep
   bool plan_ready = false;
 };
 
+struct FastRoot {  // candidate-compact tables of a block root (root_fast.hip)
+  std::vector<DevBuf<uint8_t>> comp, clen;
+  std::vector<uint64_t> ver;
+  DevBuf<double> prior_e, prior_n;
+  uint64_t prior_ver = 0;
+  int kpad = 0;
+};
+
 struct SweepState {
+  FastRoot fast[PCLEAN_MAX_BLOCKS];
   std::vector<DevBuf<unsigned char>> pool;  // scratch buffers, recycled per sweep
   size_t pool_used = 0;
   BlockRun run[PCLEAN_MAX_BLOCKS];
@@ -378,6 +425,12 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
   s->log_total.release(); s->logml_inc.release(); s->logml_acc.release(); s->logml.release(); s->counter.release();
   s->arr_ptrs.release();
   for (auto& kv : s->leaf_iota) kv.second.release();
+  for (auto& f : s->fast) {
+    for (auto& c : f.comp) c.release();
+    for (auto& c : f.clen) c.release();
+    f.prior_e.release();
+    f.prior_n.release();
+  }
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->evs) (void)hipEventDestroy(s->evs);
@@ -457,24 +510,93 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
     hipLaunchKernelGGL(iota_missing_kernel, grid1(U + 1), dim3(256), 0, ctx->stream, io.p, U);
   }
   DevBuf<double>& cache = b.leaf_cache[node_id];
-  if (cache.alloc(U + 1)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "alloc");
-  NodeDev nd;
-  int rc = build_node_dev(ctx, b, node_id, nd);
-  if (rc) return rc;
-  nd.terms[0].obs_col = io.p;  // item t observes value t (or missing for t == U)
-  ItemsDev it{U + 1, 0, nullptr, nullptr, nullptr, nullptr, 0};
-  ChildrenDev ch{};
-  rc = pclean_launch_enum(ctx, nd, it, ch, 0, 0, 0, 0, cache.p, nullptr, nullptr);
-  if (rc) return rc;
+  // the marginal only depends on the option table and the pair table: recompute when either was re-uploaded
+  const uint64_t ver = ctx->cand[n.table].version * 1000003ull + pt.version;
+  auto itv = s->leaf_version.find(key);
+  if (itv == s->leaf_version.end() || itv->second != ver || cache.n < (size_t)U + 1) {
+    if (cache.alloc(U + 1)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "alloc");
+    NodeDev nd;
+    int rc = build_node_dev(ctx, b, node_id, nd);
+    if (rc) return rc;
+    nd.terms[0].obs_col = io.p;  // item t observes value t (or missing for t == U)
+    ItemsDev it{U + 1, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    ChildrenDev ch{};
+    rc = pclean_launch_enum(ctx, nd, it, ch, 0, 0, 0, 0, cache.p, nullptr, nullptr);
+    if (rc) return rc;
+    s->leaf_version[key] = ver;
+  }
   *out = cache.p;
   *obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows;
   *n_obs = U;
   return PCLEAN_OK;
 }
 
-struct EvalOut {
-  double* lse = nullptr;
-};
+// Fast path of a block root (root_fast.hip): returns 1 and fills `fr` when the node is an FK
+// with many candidates whose terms are all plain AddTypos lookups in byte tables; 0 otherwise.
+static int try_fast_root(pclean_ctx* ctx, int block_id, FastRootDev& fr) {
+  Block& b = ctx->block[block_id];
+  const pclean_node& n = b.nodes[0];
+  const CandTable& t = ctx->cand[n.table];
+  if (n.kind != PCLEAN_NODE_FK || !t.valid || t.n_rows < 1024 || n.n_terms < 1 || n.n_terms > PCLEAN_MAX_TERMS)
+    return 0;
+  int lmax = 0, dmax = 0;
+  for (int i = 0; i < n.n_terms; ++i) {
+    const pclean_term& tm = b.terms[n.term_begin + i];
+    const PairTable& pt = ctx->pair[tm.pair_table];
+    if (!pt.valid || tm.dens_kind != PCLEAN_DENS_ADD_TYPOS || tm.ctx_slot >= 0 || pt.elem_bytes != 1) return 0;
+    lmax = std::max(lmax, pt.max_lat_len);
+    dmax = std::max(dmax, std::max(pt.max_lat_len, pt.max_obs_len));
+  }
+  if (lmax > 255 || dmax > 255) return 0;
+  const int kpad = (t.n_rows + 15) & ~15;
+  const size_t lds = (size_t)((t.n_rows + 2) & ~1) * 8 + (size_t)(((lmax + 1) * (dmax + 1) + 1) & ~1) * 8 + 256;
+  if (lds > 160 * 1024) return 0;
+  FastRoot& f = st(ctx)->fast[block_id];
+  if ((int)f.comp.size() != n.n_terms || f.kpad != kpad) {
+    for (auto& c : f.comp) c.release();
+    for (auto& c : f.clen) c.release();
+    f.comp.assign(n.n_terms, DevBuf<uint8_t>());
+    f.clen.assign(n.n_terms, DevBuf<uint8_t>());
+    f.ver.assign(n.n_terms, 0);
+    f.kpad = kpad;
+    f.prior_ver = 0;
+  }
+  for (int i = 0; i < n.n_terms; ++i) {
+    const pclean_term& tm = b.terms[n.term_begin + i];
+    const PairTable& pt = ctx->pair[tm.pair_table];
+    const uint64_t ver = t.cols_version * 1000003ull + pt.version;
+    if (f.ver[i] != ver || !f.comp[i].p) {
+      if (f.comp[i].alloc((size_t)pt.n_obs * kpad) || f.clen[i].alloc(kpad))
+        return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed (compact tables)");
+      int rc = pclean_build_compact(ctx, pt.d.p, pt.n_obs, pt.n_lat, t.cols.p + (size_t)tm.cand_col * t.n_rows,
+                                    pt.lat_len.p, t.n_rows, kpad, f.comp[i].p, f.clen[i].p);
+      if (rc) return rc;
+      f.ver[i] = ver;
+    }
+    fr.terms[i].comp = f.comp[i].p;
+    fr.terms[i].clen = f.clen[i].p;
+    fr.terms[i].obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows;
+    fr.terms[i].max_typos = tm.max_typos;
+  }
+  if (f.prior_ver != t.version || !f.prior_e.p) {
+    if (f.prior_e.alloc(kpad) || f.prior_n.alloc(kpad)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+    int rc = pclean_build_priors(ctx, t.counts.p, t.logc_full.p, t.n_rows, kpad, t.scal[1], t.scal[0], f.prior_e.p,
+                                 f.prior_n.p);
+    if (rc) return rc;
+    f.prior_ver = t.version;
+  }
+  fr.n_cand = t.n_rows;
+  fr.kpad = kpad;
+  fr.n_terms = n.n_terms;
+  fr.lmax = lmax;
+  fr.dstride = dmax + 1;
+  fr.prior_e = f.prior_e.p;
+  fr.prior_n = f.prior_n.p;
+  fr.logc_m1 = t.logc_m1.p;
+  fr.counts = t.counts.p;
+  memcpy(fr.scal, t.scal, sizeof fr.scal);
+  return 1;
+}
 
 // Bottom-up evaluation of one plan sub-tree for a list of items
 // (process_plan!, proposal_compiler.jl:363-388).  excl = per-item excluded row of
@@ -527,9 +649,19 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     }
   }
   ItemsDev it{il.n, 0, il.row, il.ctx, excl, n_draws == 1 ? il.particle : nullptr, s->row_offset};
+  FastRootDev fr;
+  int fast = 0;
+  if (node_id == 0 && !scores_out && !snew_override && !ctx->force_generic) {
+    fast = try_fast_root(ctx, block_id, fr);
+    if (fast < 0) return fast;
+  }
   if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
-  rc = pclean_launch_enum(ctx, nd, it, ch, seed, sweep, PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out,
-                          scores_out, draws_out);
+  if (fast)
+    rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out,
+                                 draws_out);
+  else
+    rc = pclean_launch_enum(ctx, nd, it, ch, seed, sweep, PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out,
+                            scores_out, draws_out);
   if (time_it) (void)hipEventRecord(s->ev1, ctx->stream);
   return rc;
 }
@@ -624,6 +756,12 @@ static int ensure_plan_dev(pclean_ctx* ctx, int block_id) {
 }
 
 // ---------------------------------------------------------------------------
+extern "C" int pclean_debug_force_generic(pclean_ctx* ctx, int32_t on) {
+  if (!ctx) return PCLEAN_ERR_ARG;
+  ctx->force_generic = on != 0;
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_set_row_offset(pclean_ctx* ctx, int64_t row_offset) {
   if (!ctx || row_offset < 0) return pclean_fail(ctx, PCLEAN_ERR_ARG, "bad row offset");
   st(ctx)->row_offset = row_offset;
@@ -755,11 +893,37 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         cs.plan[c] = s->run[sb].plan;
       }
       hipLaunchKernelGGL(gather_ctx_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, cs, r.it_ctx.p);
-      il = ItemList{(int)NP, r.it_row.p, r.it_ctx.p, r.it_particle.p, nullptr};
-      excl = r.it_excl.p;
-      rc = eval_node(ctx, bi, 0, il, excl, seed, sweep_idx, 1, r.lse.p, r.draws.p, nullptr, nullptr, false);
+      // One enumeration per distinct (row, context): particles whose earlier choices give the same
+      // context share the candidate scores and differ only in their Philox draws.
+      int32_t* repflag = scratch<int32_t>(ctx, NP);
+      int32_t* rep = scratch<int32_t>(ctx, NP);
+      int32_t* pos = scratch<int32_t>(ctx, NP);
+      if (!repflag || !rep || !pos) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      hipLaunchKernelGGL(dedup_ctx_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, r.it_ctx.p, repflag, rep);
+      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+      hipLaunchKernelGGL(compact_new_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, repflag, 0, s->counter.p,
+                         nullptr, nullptr);
+      unsigned int n_items = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&n_items, s->counter.p, sizeof n_items, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      int32_t* list = scratch<int32_t>(ctx, n_items);
+      int32_t* d_row = scratch<int32_t>(ctx, n_items);
+      int32_t* d_ctx = scratch<int32_t>(ctx, (size_t)n_items * PCLEAN_MAX_CTX);
+      int32_t* d_excl = scratch<int32_t>(ctx, n_items);
+      double* lse_item = scratch<double>(ctx, n_items);
+      int32_t* draws_item = scratch<int32_t>(ctx, (size_t)n_items * P);
+      if (!list || !d_row || !d_ctx || !d_excl || !lse_item || !draws_item)
+        return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+      hipLaunchKernelGGL(compact_new_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, repflag, 1, s->counter.p, list,
+                         pos);
+      hipLaunchKernelGGL(ctx_items_kernel, grid1(n_items), dim3(256), 0, ctx->stream, (int)n_items, P, list,
+                         r.it_ctx.p, cur_b, d_row, d_ctx, d_excl);
+      il = ItemList{(int)n_items, d_row, d_ctx, nullptr, nullptr};
+      rc = eval_node(ctx, bi, 0, il, d_excl, seed, sweep_idx, P, lse_item, draws_item, nullptr, nullptr, false);
       if (rc) return rc;
-      hipLaunchKernelGGL(add_weight_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, r.lse.p, s->w.p);
+      hipLaunchKernelGGL(expand_ctx_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, P, rep, pos, lse_item,
+                         draws_item, r.draws.p, s->w.p);
     }
     hipLaunchKernelGGL(set_pchoice_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, r.draws.p, cur_b, r.pchoice.p);
 

@@ -41,6 +41,7 @@ class Engine:
         self.hip = HipContext(device)
         self.dist_mode = dist_mode
         self.option_logp = {}
+        self._uploaded_shape = {}
         self._upload_static()
         if row_offset:
             _lib.check(self.hip.h, self.hip.lib.pclean_set_row_offset(self.hip.h, _lib.C.c_int64(row_offset)),
@@ -92,7 +93,13 @@ class Engine:
         m = lw.model
         for cname, t in trace.tables.items():
             cols, counts = t.view()
-            hip.set_table(lw.table_id[cname], np.ascontiguousarray(cols), counts, t.strength, t.discount)
+            key = (cname, t.n)
+            if t.cols_dirty or self._uploaded_shape.get(cname) != key:
+                hip.set_table(lw.table_id[cname], np.ascontiguousarray(cols), counts, t.strength, t.discount)
+                t.cols_dirty = False
+                self._uploaded_shape[cname] = key
+            else:  # only reference counts moved: keep the device columns and their compact byte tables
+                hip.set_table(lw.table_id[cname], None, counts, t.strength, t.discount, n_cols=t.n_cols)
         for (cname, aname), dom in lw.latent_dom.items():
             d = m.classes[cname].attr(aname).dist
             if isinstance(d, ChooseProportionally):

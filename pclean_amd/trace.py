@@ -37,6 +37,7 @@ class LatentTable:
         self.n = 0          # high-water mark
         self.free = []
         self.strength, self.discount = strength, discount
+        self.cols_dirty = True  # value columns changed since the last upload to the device
 
     def alloc(self):
         if self.free:
@@ -91,6 +92,7 @@ class Trace:
         t = self.tables[cname]
         r = t.alloc()
         t.cols[:, r] = values
+        t.cols_dirty = True
         t.counts[r] = 0
         t.live[r] = True
         for j, c in enumerate(self.lw.layout[cname]):
