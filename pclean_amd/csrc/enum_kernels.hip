@@ -177,24 +177,33 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   // ---- phase 5: lse + draws ----------------------------------------------------
   if (tid == 0 && lse_out) lse_out[t] = pclean_lse_from_fix(m, U);
   if (n_draws > 0) {
+    // one Philox evaluation per draw for the whole workgroup (lane j of wave 0), broadcast through LDS
+    uint64_t* xs = wsum + 8;  // [64]
     const uint32_t rng_row = (uint32_t)((int64_t)v.row + it.row_offset);
-    for (int j = 0; j < n_draws; ++j) {
-      const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)j;
-      int32_t* dst = draws_out + (size_t)t * n_draws + j;
-      if (U == 0) {
-        if (tid == 0) *dst = fk ? PCLEAN_CHOICE_NEW : n - 1;
-        continue;
+    for (int j0 = 0; j0 < n_draws; j0 += 64) {
+      __syncthreads();
+      if (tid < 64 && j0 + tid < n_draws) {
+        const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)(j0 + tid);
+        xs[tid] = U ? pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U) : 0ull;
       }
-      const uint64_t R = pclean_rand64(seed, rng_row, site, pid, sweep);
-      const uint64_t x = pclean_mulhi64(R, U);
-      if (x >= pre && x < pre + part) {
-        uint64_t acc = pre;
-        int k = lo;
-        for (; k < hi; ++k) {
-          acc += u[k];
-          if (acc > x) break;
+      __syncthreads();
+      const int jn = min(64, n_draws - j0);
+      for (int j = 0; j < jn; ++j) {
+        int32_t* dst = draws_out + (size_t)t * n_draws + j0 + j;
+        if (U == 0) {
+          if (tid == 0) *dst = fk ? PCLEAN_CHOICE_NEW : n - 1;
+          continue;
         }
-        *dst = (fk && k == n) ? PCLEAN_CHOICE_NEW : k;
+        const uint64_t x = xs[j];
+        if (x >= pre && x < pre + part) {
+          uint64_t acc = pre;
+          int k = lo;
+          for (; k < hi; ++k) {
+            acc += u[k];
+            if (acc > x) break;
+          }
+          *dst = (fk && k == n) ? PCLEAN_CHOICE_NEW : k;
+        }
       }
     }
   }
@@ -277,7 +286,7 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
                        int32_t* draws_out) {
   if (it.n <= 0) return PCLEAN_OK;
   const int nc = nd.n_cand + (nd.kind == PCLEAN_NODE_FK ? 1 : 0);
-  const size_t lds = (size_t)((nc + 1) & ~1) * 8 + 16 * 8;
+  const size_t lds = (size_t)((nc + 1) & ~1) * 8 + (16 + 64) * 8;
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0};
   // a launch may not exceed 2^32 threads: chunk the items (grid = chunk, 256 lanes each)
   const int kMaxBlocks = 4 * 1024 * 1024;

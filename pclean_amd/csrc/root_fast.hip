@@ -92,6 +92,8 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   const int lut_n = (fr.lmax + 1) * fr.dstride;
   double* red = lut + ((lut_n + 1) & ~1);                       // [16]
   uint64_t* wsum = (uint64_t*)(red + FAST_MAX_WAVES);           // [16]
+  uint64_t* xs = wsum + FAST_MAX_WAVES;                         // [64] draw thresholds
+  uint64_t* rowp = xs + 64;                                     // [16] comp row pointers (0 = missing obs)
 
   // density LUT: the fp64 operation order of term_density() (enum_kernels.hip)
   for (int i = tid; i < lut_n; i += T) {
@@ -108,6 +110,14 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   const bool deleted = excluded && fr.counts[excl] <= 1;
   const double logden = excluded ? fr.scal[1] : fr.scal[0];
   const double* prior = excluded ? fr.prior_e : fr.prior_n;
+  if (tid < PCLEAN_MAX_TERMS) {
+    uint64_t p = 0;
+    if (tid < fr.n_terms) {
+      const int o = fr.terms[tid].obs_col[row];
+      if (o >= 0) p = (uint64_t)(fr.terms[tid].comp + (size_t)o * fr.kpad);
+    }
+    rowp[tid] = p;
+  }
   __syncthreads();
 
   // ---- phase 1: scores, 4 consecutive candidates per lane per round -----------
@@ -122,21 +132,25 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
     acc[1] = p01.y;
     acc[2] = p23.x;
     acc[3] = p23.y;
-    if (excluded && (unsigned)(excl - k0) < 4u) acc[excl - k0] = deleted ? -__builtin_inf() : fr.logc_m1[excl] - logden;
+    if (excluded && (unsigned)(excl - k0) < 4u) {
+      const double pe = deleted ? -__builtin_inf() : fr.logc_m1[excl] - logden;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (k0 + e == excl) acc[e] = pe;
+    }
     uint32_t c4[PCLEAN_MAX_TERMS], l4[PCLEAN_MAX_TERMS];
 #pragma unroll
     for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) {
       if (f < fr.n_terms) {
-        const int o = fr.terms[f].obs_col[row];
-        c4[f] = o < 0 ? 0u : reinterpret_cast<const uint32_t*>(fr.terms[f].comp + (size_t)o * fr.kpad)[slot];
+        const uint32_t* rp = reinterpret_cast<const uint32_t*>(rowp[f]);
+        c4[f] = rp ? rp[slot] : 0u;
         l4[f] = reinterpret_cast<const uint32_t*>(fr.terms[f].clen)[slot];
       }
     }
 #pragma unroll
     for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) {
       if (f < fr.n_terms) {
-        const int o = fr.terms[f].obs_col[row];
-        if (o >= 0) {  // explicitly missing observation contributes nothing (add_typos.jl:51-53)
+        if (rowp[f]) {  // explicitly missing observation contributes nothing (add_typos.jl:51-53)
           const int mt = fr.terms[f].max_typos;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -202,24 +216,32 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   // ---- phase 5: lse + draws -------------------------------------------------------------
   if (tid == 0 && lse_out) lse_out[t] = pclean_lse_from_fix(m, U);
   if (n_draws > 0) {
+    // one Philox evaluation per draw for the whole workgroup (lane j of wave 0), broadcast through LDS
     const uint32_t rng_row = (uint32_t)((int64_t)row + it.row_offset);
-    for (int j = 0; j < n_draws; ++j) {
-      const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)j;
-      int32_t* dst = draws_out + (size_t)t * n_draws + j;
-      if (U == 0) {
-        if (tid == 0) *dst = PCLEAN_CHOICE_NEW;
-        continue;
+    for (int j0 = 0; j0 < n_draws; j0 += 64) {
+      __syncthreads();
+      if (tid < 64 && j0 + tid < n_draws) {
+        const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)(j0 + tid);
+        xs[tid] = U ? pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U) : 0ull;
       }
-      const uint64_t R = pclean_rand64(seed, rng_row, site, pid, sweep);
-      const uint64_t x = pclean_mulhi64(R, U);
-      if (x >= pre && x < pre + part) {
-        uint64_t acc = pre;
-        int k = lo;
-        for (; k < hi; ++k) {
-          acc += u[k];
-          if (acc > x) break;
+      __syncthreads();
+      const int jn = min(64, n_draws - j0);
+      for (int j = 0; j < jn; ++j) {
+        int32_t* dst = draws_out + (size_t)t * n_draws + j0 + j;
+        if (U == 0) {
+          if (tid == 0) *dst = PCLEAN_CHOICE_NEW;
+          continue;
         }
-        *dst = k == n ? PCLEAN_CHOICE_NEW : k;
+        const uint64_t x = xs[j];
+        if (x >= pre && x < pre + part) {
+          uint64_t acc = pre;
+          int k = lo;
+          for (; k < hi; ++k) {
+            acc += u[k];
+            if (acc > x) break;
+          }
+          *dst = k == n ? PCLEAN_CHOICE_NEW : k;
+        }
       }
     }
   }
@@ -231,7 +253,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   if (it.n <= 0) return PCLEAN_OK;
   const int nc = fr.n_cand + 1;
   const int lut_n = (fr.lmax + 1) * fr.dstride;
-  const size_t lds = (size_t)((nc + 1) & ~1) * 8 + (size_t)((lut_n + 1) & ~1) * 8 + 2 * FAST_MAX_WAVES * 8;
+  const size_t lds = (size_t)((nc + 1) & ~1) * 8 + (size_t)((lut_n + 1) & ~1) * 8 + (2 * FAST_MAX_WAVES + 64 + 16) * 8;
   // lanes: as few rounds of 4-candidate slots as possible with little idle tail
   const int nslots = fr.kpad >> 2;
   const int rounds = (nslots + 1023) / 1024;

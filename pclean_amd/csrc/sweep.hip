@@ -392,7 +392,7 @@ struct FastRoot {  // candidate-compact tables of a block root (root_fast.hip)
 };
 
 struct SweepState {
-  FastRoot fast[PCLEAN_MAX_BLOCKS];
+  FastRoot fast[PCLEAN_MAX_BLOCKS * 64];  // [block * 64 + node]
   std::vector<DevBuf<unsigned char>> pool;  // scratch buffers, recycled per sweep
   size_t pool_used = 0;
   BlockRun run[PCLEAN_MAX_BLOCKS];
@@ -533,9 +533,10 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
 
 // Fast path of a block root (root_fast.hip): returns 1 and fills `fr` when the node is an FK
 // with many candidates whose terms are all plain AddTypos lookups in byte tables; 0 otherwise.
-static int try_fast_root(pclean_ctx* ctx, int block_id, FastRootDev& fr) {
+static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev& fr) {
   Block& b = ctx->block[block_id];
-  const pclean_node& n = b.nodes[0];
+  if (node_id >= 64) return 0;
+  const pclean_node& n = b.nodes[node_id];
   const CandTable& t = ctx->cand[n.table];
   if (n.kind != PCLEAN_NODE_FK || !t.valid || t.n_rows < 1024 || n.n_terms < 1 || n.n_terms > PCLEAN_MAX_TERMS)
     return 0;
@@ -549,9 +550,9 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, FastRootDev& fr) {
   }
   if (lmax > 255 || dmax > 255) return 0;
   const int kpad = (t.n_rows + 15) & ~15;
-  const size_t lds = (size_t)((t.n_rows + 2) & ~1) * 8 + (size_t)(((lmax + 1) * (dmax + 1) + 1) & ~1) * 8 + 256;
+  const size_t lds = (size_t)((t.n_rows + 2) & ~1) * 8 + (size_t)(((lmax + 1) * (dmax + 1) + 1) & ~1) * 8 + 1024;
   if (lds > 160 * 1024) return 0;
-  FastRoot& f = st(ctx)->fast[block_id];
+  FastRoot& f = st(ctx)->fast[block_id * 64 + node_id];
   if ((int)f.comp.size() != n.n_terms || f.kpad != kpad) {
     for (auto& c : f.comp) c.release();
     for (auto& c : f.clen) c.release();
@@ -651,8 +652,8 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   ItemsDev it{il.n, 0, il.row, il.ctx, excl, n_draws == 1 ? il.particle : nullptr, s->row_offset};
   FastRootDev fr;
   int fast = 0;
-  if (node_id == 0 && !scores_out && !snew_override && !ctx->force_generic) {
-    fast = try_fast_root(ctx, block_id, fr);
+  if (!scores_out && !snew_override && !ctx->force_generic) {
+    fast = try_fast_root(ctx, block_id, node_id, fr);
     if (fast < 0) return fast;
   }
   if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
