@@ -1,0 +1,99 @@
+"""CPU tests (gloo, world_size 2) of the row-sharded sweep: block partition, all-reduce of the
+CRP sufficient statistics (delta reference counts), all-gather + ordered merge of new-row records.
+The compute engine here is the CPU oracle (test infrastructure) standing in for the HIP engine;
+the exchange/commit code under test is the product's pclean_amd/parallel.py.  Result must be
+identical to the single-process sweep for any number of ranks (global-row-keyed RNG, integer stats)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_ROWS = 240
+
+
+def _sweep_shard(orc, helpers, S, lo, hi, cfg, seed, sweep):
+    """Oracle batched sweep of rows [lo, hi) against the current (replicated) trace."""
+    from pclean_amd._lib import InferConfig
+    lw, tr = S["lw"], S["trace"]
+    obs = np.ascontiguousarray(S["obs"][:, lo:hi])
+    logp = helpers.option_logp_cpu(orc, lw, tr)
+    w = helpers.mirror_world(orc, lw, obs, tr, None, 1, logp)
+    nb, n = tr.cur.shape
+    choice = np.empty((nb, n), dtype=np.int32)
+    c = InferConfig(1, cfg, 1, 1, 0, 50, 100)
+    orc.lib().pco_sweep_batched(w.h, C.byref(c), C.c_uint64(seed), C.c_uint32(sweep), nb, C.c_int64(lo),
+                                orc._p(np.ascontiguousarray(tr.cur), C.c_int32), orc._p(choice, C.c_int32), None, None)
+    new_rows, stats = {}, {}
+    for b, blk in enumerate(lw.blocks):
+        k = orc.lib().pco_new_rows_count(b)
+        if k:
+            rows = np.empty(k, dtype=np.int32)
+            vals = np.empty((k, len(blk["nodes"])), dtype=np.int32)
+            orc.lib().pco_new_rows_get(b, len(blk["nodes"]), orc._p(rows, C.c_int32), orc._p(vals, C.c_int32))
+            new_rows[b] = (rows, vals)
+        t = tr.tables[blk["root_class"]]
+        moved = choice[b] != tr.cur[b]
+        d = -np.bincount(tr.cur[b][moved], minlength=t.n).astype(np.int64)
+        ex = moved & (choice[b] >= 0)
+        stats[b] = d + np.bincount(choice[b][ex], minlength=t.n)
+    return choice, stats, new_rows
+
+
+def _run(rank, world, port, out_path):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import helpers
+    import oracle as orc
+    from pclean_amd.parallel import Comm, exchange_and_commit, shard_bounds
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    comm = Comm()
+    S = helpers.hospital_setup(n_rows=N_ROWS, seed=3)
+    lw, tr = S["lw"], S["trace"]
+    lo, hi = shard_bounds(N_ROWS, rank, world)
+    tr.cur = np.ascontiguousarray(tr.cur[:, lo:hi])
+    changed = []
+    for sweep in range(3):
+        choice, stats, new_rows = _sweep_shard(orc, helpers, S, lo, hi, 6, 99, sweep)
+        changed.append(exchange_and_commit(tr, lw, comm, lo, choice, stats, new_rows))
+    cur_all = comm.allgather_varlen_i32(tr.cur[0]), comm.allgather_varlen_i32(tr.cur[1])
+    if rank == 0:
+        np.savez(out_path, cur0=cur_all[0], cur1=cur_all[1], changed=np.array(changed),
+                 **{f"cols_{c}": t.cols[:, :t.n] for c, t in tr.tables.items()},
+                 **{f"counts_{c}": t.counts[:t.n] for c, t in tr.tables.items()})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_all_rows():
+    from pclean_amd.parallel import shard_bounds
+    for n in (0, 1, 7, 240, 1000003):
+        for w in (1, 2, 3, 8):
+            b = [shard_bounds(n, r, w) for r in range(w)]
+            assert b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sweep_equals_single_process(tmp_path, oracle):
+    import torch.multiprocessing as mp
+    single = str(tmp_path / "single.npz")
+    _run(0, 1, 0, single)
+    multi = str(tmp_path / "multi.npz")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_run, args=(2, port, multi), nprocs=2, join=True)
+    a, b = np.load(single), np.load(multi)
+    assert set(a.files) == set(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["changed"].sum() > 0
+    # reference counts are consistent with the referents after the exchange
+    assert np.array_equal(np.bincount(a["cur0"], minlength=len(a["counts_Hospital"])), a["counts_Hospital"])
+    assert np.array_equal(np.bincount(a["cur1"], minlength=len(a["counts_Measure"])), a["counts_Measure"])
