@@ -179,7 +179,7 @@ def main():
     for i in range(args.warmup):
         tm, changed = step(i)
         log(f"[bench] warmup sweep {i}: device {tm.total_ms:.1f} ms, hot kernel {tm.hot_kernel_ms:.1f} ms, "
-            f"{changed} referents changed")
+            f"{changed} referents changed, {tm.reserved} items re-run by the generic kernel")
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -39,6 +39,7 @@ struct ItemsDev {
   const int32_t* excl;
   const int32_t* particle;
   int64_t row_offset;  // global id of local row 0 (RNG counter), multi-GPU sharding
+  const int32_t* out_pos;  // where item t writes its outputs (identity when null)
 };
 
 // Log-marginals of the children of a "new row": either one value per item, or a
@@ -72,7 +73,8 @@ struct FastRootDev {
 
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
-                            int32_t* draws_out);
+                            int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count);
+size_t pclean_fast_lds_bytes(int lmax, int dstride);
 int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_lat, const int32_t* cand_col,
                          const uint16_t* lat_len, int n_cand, int kpad, uint8_t* comp, uint8_t* clen);
 int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* logc_full, int n_cand, int kpad,

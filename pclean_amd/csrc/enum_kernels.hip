@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int t = blockIdx.x + item_base;
+  const int to = it.out_pos ? it.out_pos[t] : t;  // output slot of this item
   const int n = nd.n_cand;
   const bool fk = nd.kind == PCLEAN_NODE_FK;
   const int nc = n + (fk ? 1 : 0);
@@ -147,13 +148,13 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   for (int k = tid; k < n; k += 256) {
     const double sk = candidate_score(nd, dn, v, k);
     s[k] = sk;
-    if (scores_out) scores_out[(size_t)t * nc + k] = sk;
+    if (scores_out) scores_out[(size_t)to * nc + k] = sk;
     lmax = fmax(lmax, sk);
   }
   if (fk && tid == 0) {
-    const double sn = new_score(nd, ch, v, t);
+    const double sn = new_score(nd, ch, v, to);
     s[n] = sn;
-    if (scores_out) scores_out[(size_t)t * nc + n] = sn;
+    if (scores_out) scores_out[(size_t)to * nc + n] = sn;
     lmax = fmax(lmax, sn);
   }
   // ---- phase 2: max ----------------------------------------------------------
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   uint64_t U;
   const uint64_t pre = block_excl_scan(part, wsum, &U);
   // ---- phase 5: lse + draws ----------------------------------------------------
-  if (tid == 0 && lse_out) lse_out[t] = pclean_lse_from_fix(m, U);
+  if (tid == 0 && lse_out) lse_out[to] = pclean_lse_from_fix(m, U);
   if (n_draws > 0) {
     // one Philox evaluation per draw for the whole workgroup (lane j of wave 0), broadcast through LDS
     uint64_t* xs = wsum + 8;  // [64]
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
       __syncthreads();
       const int jn = min(64, n_draws - j0);
       for (int j = 0; j < jn; ++j) {
-        int32_t* dst = draws_out + (size_t)t * n_draws + j0 + j;
+        int32_t* dst = draws_out + (size_t)to * n_draws + j0 + j;
         if (U == 0) {
           if (tid == 0) *dst = fk ? PCLEAN_CHOICE_NEW : n - 1;
           continue;
@@ -220,22 +221,23 @@ __global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, co
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int t = blockIdx.x + item_base;
+  const int to = it.out_pos ? it.out_pos[t] : t;  // output slot of this item
   const int n = nd.n_cand;
   const bool fk = nd.kind == PCLEAN_NODE_FK;
   const int nc = n + (fk ? 1 : 0);
   const ItemView v = item_view(nd, it, t);
-  const double sn = fk ? new_score(nd, ch, v, t) : -__builtin_inf();
+  const double sn = fk ? new_score(nd, ch, v, to) : -__builtin_inf();
 
   // pass A: max (lane-strided, coalesced)
   double lmax = -__builtin_inf();
   for (int k = tid; k < n; k += 256) {
     const double sk = candidate_score(nd, dn, v, k);
-    if (scores_out) scores_out[(size_t)t * nc + k] = sk;
+    if (scores_out) scores_out[(size_t)to * nc + k] = sk;
     lmax = fmax(lmax, sk);
   }
   if (fk) {
     lmax = fmax(lmax, sn);
-    if (scores_out && tid == 0) scores_out[(size_t)t * nc + n] = sn;
+    if (scores_out && tid == 0) scores_out[(size_t)to * nc + n] = sn;
   }
   lmax = wave_max(lmax);
   if (lane == 0) red[wave] = lmax;
@@ -253,14 +255,14 @@ __global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, co
     }
   uint64_t U;
   const uint64_t pre = block_excl_scan(part, wsum, &U);
-  if (tid == 0 && lse_out) lse_out[t] = pclean_lse_from_fix(m, U);
+  if (tid == 0 && lse_out) lse_out[to] = pclean_lse_from_fix(m, U);
 
   // pass C: draws, located by recomputing the owning lane's chunk
   if (n_draws > 0) {
     const uint32_t rng_row = (uint32_t)((int64_t)v.row + it.row_offset);
     for (int j = 0; j < n_draws; ++j) {
       const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)j;
-      int32_t* dst = draws_out + (size_t)t * n_draws + j;
+      int32_t* dst = draws_out + (size_t)to * n_draws + j;
       if (U == 0) {
         if (tid == 0) *dst = fk ? PCLEAN_CHOICE_NEW : n - 1;
         continue;

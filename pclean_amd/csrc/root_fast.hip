@@ -1,23 +1,32 @@
 // fk_root_fast_kernel — the dominant kernel: rows x candidate referents of a block
-// root (hospital Record block 1: K ~ 1e4 latent hospitals x 11 AddTypos terms).
+// root (hospital Record block 1: K ~ 1e4 latent hospitals x 11 AddTypos terms) and of
+// the nested reference slots of its new-row branch.
 //
 // Same contract and bit-identical results as enum_node_kernel (enum_kernels.hip),
-// restructured for the memory system of MI355X:
+// restructured for MI355X:
 //   * candidate-compact byte tables comp_f[o][k] (built by compact_pair_kernel when
 //     the latent table's columns change) turn the pair-table gather into F
 //     contiguous byte streams per row: every lane reads one dword = 4 candidates,
-//     a wave reads 256 consecutive bytes -> fully coalesced, HBM/L2 friendly
-//     (consecutive rows of the same hospital re-read the same byte rows from L2);
+//     a wave reads 256 consecutive bytes -> fully coalesced; consecutive rows of one
+//     hospital re-read the same byte rows from L2 (measured HBM traffic ~10 GB per
+//     1M-row launch, profiles/r01_d_pmc_root_kernel.txt);
 //   * candidate word lengths clen_f[k] are streamed the same way (L2 resident);
 //   * the AddTypos density (add_typos.jl:61-63) is a (length, distance) LUT built
 //     once per workgroup in LDS with the very fp64 operation order of
 //     term_density(), so per term the inner loop is: 2 dword loads, 4 byte
 //     extracts, 4 ds_read_b64, 4 fp64 adds;
 //   * CRP priors are precomputed per candidate (prior_e / prior_n);
-//   * one workgroup of up to 1024 lanes (16 wavefronts) per row keeps the score
-//     vector (8 B x K) in LDS at 1 workgroup/CU with enough waves to hide latency.
-// Scores are stored to LDS and then go through exactly the phases 2-5 of the generic
-// kernel (max, fixed-point weights, natural-order chunk scan, Philox draws).
+//   * SURVIVOR COMPACTION: a candidate whose score is more than 28.5 nats below the
+//     maximum has fixed-point weight floor(exp(s-m) 2^40) == 0 exactly
+//     (pclean_fixw), so it can influence neither the log-sum-exp nor a draw.  Each
+//     lane keeps the candidates within 28.5 of its running maximum (a lower bound of
+//     the true maximum) in a 4-entry register window; after the block-wide max the
+//     windows are filtered into a small LDS list, rank-sorted by candidate index
+//     (natural order of the inverse CDF), prefix-summed and binary-searched per draw.
+//     The 8 B x K score vector never exists: LDS drops from ~100 KB to ~45 KB (2
+//     resident workgroups per CU) and the K-sized weight / scan phases disappear.
+//     Items whose windows or list overflow (flat posteriors) are flagged and re-run by
+//     the host with the LDS-resident generic kernel — results are identical either way.
 #include <algorithm>
 
 #include "../../include/pclean_detmath.h"
@@ -27,6 +36,8 @@
 #define HALF_LOG26 1.629048269010741
 #define ADD_TYPOS_IMPOSSIBLE (-1e5)
 #define FAST_MAX_WAVES 16
+#define SURV2_CAP 1024     // after filtering with the true maximum
+#define FIX_CUTOFF 28.5    // pclean_fixw(d) == 0 for d < -28.5
 
 __global__ void compact_pair_kernel(const uint8_t* __restrict__ pair, int n_obs, int n_lat,
                                     const int32_t* __restrict__ cand_col, int n_cand, int kpad,
@@ -76,25 +87,31 @@ __device__ __forceinline__ double wave_max64(double v) {
   return v;
 }
 
+template <int NT>
 __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr, const DensDev dn, const ItemsDev it,
                                                             const ChildrenDev ch, uint64_t seed, uint32_t sweep,
                                                             uint32_t site, int n_draws, int item_base,
                                                             double* __restrict__ lse_out,
-                                                            int32_t* __restrict__ draws_out) {
+                                                            int32_t* __restrict__ draws_out,
+                                                            int32_t* __restrict__ overflow_flag,
+                                                            unsigned int* __restrict__ overflow_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T = blockDim.x, nw = T >> 6;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int t = blockIdx.x + item_base;
-  const int n = fr.n_cand, nc = n + 1;
-  double* s = (double*)smem;                                   // [nc] scores, later uint64 weights
-  uint64_t* u = (uint64_t*)smem;
-  double* lut = (double*)(smem + (size_t)((nc + 1) & ~1) * 8);  // [(lmax+1) * dstride]
+  const int n = fr.n_cand;
+  // LDS carve (all offsets multiples of 16 bytes)
   const int lut_n = (fr.lmax + 1) * fr.dstride;
+  double* lut = (double*)smem;                                  // [(lmax+1)*dstride]
   double* red = lut + ((lut_n + 1) & ~1);                       // [16]
-  uint64_t* wsum = (uint64_t*)(red + FAST_MAX_WAVES);           // [16]
-  uint64_t* xs = wsum + FAST_MAX_WAVES;                         // [64] draw thresholds
-  uint64_t* rowp = xs + 64;                                     // [16] comp row pointers (0 = missing obs)
+  uint64_t* xs = (uint64_t*)(red + FAST_MAX_WAVES);             // [64] draw thresholds
+  uint64_t* u2 = xs + 64;                                       // [SURV2_CAP] sorted weights, then inclusive prefix
+  double* sc2 = (double*)(u2 + SURV2_CAP);                      // [SURV2_CAP] second-stage scores
+  int32_t* k2 = (int32_t*)(sc2 + SURV2_CAP);                    // [SURV2_CAP] survivor ids (unsorted)
+  int32_t* ks = k2 + SURV2_CAP;                                 // [SURV2_CAP] sorted ids
+  unsigned int* cnt = (unsigned int*)(ks + SURV2_CAP);          // [4] counters
 
+  if (tid < 4) cnt[tid] = 0;
   // density LUT: the fp64 operation order of term_density() (enum_kernels.hip)
   for (int i = tid; i < lut_n; i += T) {
     const int L = i / fr.dstride, d = i - L * fr.dstride;
@@ -110,18 +127,51 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   const bool deleted = excluded && fr.counts[excl] <= 1;
   const double logden = excluded ? fr.scal[1] : fr.scal[0];
   const double* prior = excluded ? fr.prior_e : fr.prior_n;
-  if (tid < PCLEAN_MAX_TERMS) {
-    uint64_t p = 0;
-    if (tid < fr.n_terms) {
-      const int o = fr.terms[tid].obs_col[row];
-      if (o >= 0) p = (uint64_t)(fr.terms[tid].comp + (size_t)o * fr.kpad);
+  // per-term row pointers (wave-uniform -> scalar registers)
+  const uint32_t* crow[NT];
+  const uint32_t* lrow[NT];
+  int mt[NT];
+#pragma unroll
+  for (int f = 0; f < NT; ++f) {
+    crow[f] = nullptr;
+    lrow[f] = nullptr;
+    mt[f] = -1;
+    if (f < fr.n_terms) {
+      const int o = fr.terms[f].obs_col[row];
+      if (o >= 0) crow[f] = reinterpret_cast<const uint32_t*>(fr.terms[f].comp + (size_t)o * fr.kpad);
+      lrow[f] = reinterpret_cast<const uint32_t*>(fr.terms[f].clen);
+      mt[f] = fr.terms[f].max_typos;
     }
-    rowp[tid] = p;
   }
   __syncthreads();
 
-  // ---- phase 1: scores, 4 consecutive candidates per lane per round -----------
-  double lmax = -__builtin_inf();
+  // A lower bound of the maximum, to keep the first-stage list short: the approximate score of
+  // the retained referent (the row's current hospital is almost always the best candidate) minus a
+  // safety margin.  Wave-uniform scalar work; only used as a filter, never as a score.
+  double bound = -__builtin_inf();
+  if (excluded && !deleted) {
+    double b = fr.logc_m1[excl] - logden;
+#pragma unroll
+    for (int f = 0; f < NT; ++f)
+      if (crow[f]) {
+        const int d = reinterpret_cast<const uint8_t*>(crow[f])[excl], L = reinterpret_cast<const uint8_t*>(lrow[f])[excl];
+        b += (mt[f] >= 0 && d > mt[f]) ? ADD_TYPOS_IMPOSSIBLE : lut[L * fr.dstride + d];
+      }
+    bound = b - 1.0;
+  }
+
+  // ---- phase 1: scores, 4 consecutive candidates per lane per round.  Each lane keeps the
+  // candidates within FIX_CUTOFF of its running maximum in a 4-entry register window.
+  double tmax = bound;      // filter threshold base (lower bound of the maximum)
+  double wS[4];
+  int wK[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    wS[i] = -__builtin_inf();
+    wK[i] = -1;
+  }
+  bool lost = false;        // a window candidate had to be dropped
+  double lost_max = -__builtin_inf();
   const int nslots = fr.kpad >> 2;
   for (int slot = tid; slot < nslots; slot += T) {
     const int k0 = slot << 2;
@@ -138,38 +188,47 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
       for (int e = 0; e < 4; ++e)
         if (k0 + e == excl) acc[e] = pe;
     }
-    uint32_t c4[PCLEAN_MAX_TERMS], l4[PCLEAN_MAX_TERMS];
+    uint32_t c4[NT], l4[NT];
 #pragma unroll
-    for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) {
-      if (f < fr.n_terms) {
-        const uint32_t* rp = reinterpret_cast<const uint32_t*>(rowp[f]);
-        c4[f] = rp ? rp[slot] : 0u;
-        l4[f] = reinterpret_cast<const uint32_t*>(fr.terms[f].clen)[slot];
-      }
+    for (int f = 0; f < NT; ++f) {
+      c4[f] = crow[f] ? crow[f][slot] : 0u;
+      l4[f] = lrow[f] ? lrow[f][slot] : 0u;
     }
 #pragma unroll
-    for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) {
-      if (f < fr.n_terms) {
-        if (rowp[f]) {  // explicitly missing observation contributes nothing (add_typos.jl:51-53)
-          const int mt = fr.terms[f].max_typos;
+    for (int f = 0; f < NT; ++f) {
+      if (crow[f]) {  // an explicitly missing observation contributes nothing (add_typos.jl:51-53)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int d = (c4[f] >> (8 * e)) & 255, L = (l4[f] >> (8 * e)) & 255;
-            double dens = lut[L * fr.dstride + d];
-            if (mt >= 0 && d > mt) dens = ADD_TYPOS_IMPOSSIBLE;
-            acc[e] += dens;
-          }
+        for (int e = 0; e < 4; ++e) {
+          const int d = (c4[f] >> (8 * e)) & 255, L = (l4[f] >> (8 * e)) & 255;
+          double dens = lut[L * fr.dstride + d];
+          if (mt[f] >= 0 && d > mt[f]) dens = ADD_TYPOS_IMPOSSIBLE;
+          acc[e] += dens;
         }
       }
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e)
-      if (k0 + e < n) {
-        s[k0 + e] = acc[e];
-        lmax = fmax(lmax, acc[e]);
+      if (k0 + e < n) tmax = fmax(tmax, acc[e]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (k0 + e < n && acc[e] >= tmax - FIX_CUTOFF && acc[e] > -__builtin_inf()) {
+        // insert into the window: reuse a slot that is empty or has fallen out of the window
+        bool placed = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (!placed && (wK[i] < 0 || wS[i] < tmax - FIX_CUTOFF)) {
+            wS[i] = acc[e];
+            wK[i] = k0 + e;
+            placed = true;
+          }
+        if (!placed) {
+          lost = true;
+          lost_max = fmax(lost_max, acc[e]);
+        }
       }
   }
-  if (tid == 0) {
+  double sn = -__builtin_inf();
+  if (tid == 0) {  // the "new row" candidate (index n, last in natural order)
     double snew = 0.0;
     for (int c = 0; c < ch.n; ++c) {
       size_t idx = (size_t)t;
@@ -179,97 +238,132 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
       }
       snew += ch.arr[c][idx];
     }
-    const double sn = ((deleted ? fr.scal[3] : fr.scal[2]) - logden) + snew;
-    s[n] = sn;
-    lmax = fmax(lmax, sn);
+    sn = ((deleted ? fr.scal[3] : fr.scal[2]) - logden) + snew;
+    tmax = fmax(tmax, sn);
   }
-  // ---- phase 2: max ------------------------------------------------------------
-  lmax = wave_max64(lmax);
-  if (lane == 0) red[wave] = lmax;
+  // ---- phase 2: block max -----------------------------------------------------------
+  {
+    const double wm = wave_max64(tmax);
+    if (lane == 0) red[wave] = wm;
+  }
   __syncthreads();
   double m = red[0];
   for (int w = 1; w < nw; ++w) m = fmax(m, red[w]);
-  // ---- phase 3: fixed-point weights in place --------------------------------------
-  for (int k = tid; k < nc; k += T) {
-    const double sk = s[k];
-    u[k] = (m == -__builtin_inf()) ? 0ull : pclean_fixw(sk - m);
+  // ---- phase 3: candidates with non-zero fixed-point weight -> LDS list ----------------------
+  if (lost && lost_max - m >= -FIX_CUTOFF) atomicAdd(&cnt[2], 1u);  // a dropped candidate mattered
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (wK[i] >= 0 && wS[i] - m >= -FIX_CUTOFF) {
+      const unsigned int pos = atomicAdd(&cnt[1], 1u);
+      if (pos < SURV2_CAP) {
+        sc2[pos] = wS[i];
+        k2[pos] = wK[i];
+      }
+    }
+  if (tid == 0 && sn - m >= -FIX_CUTOFF) {
+    const unsigned int pos = atomicAdd(&cnt[1], 1u);
+    if (pos < SURV2_CAP) {
+      sc2[pos] = sn;
+      k2[pos] = n;
+    }
   }
   __syncthreads();
-  // ---- phase 4: contiguous chunk sums + block scan -----------------------------------
-  const int chunk = (nc + T - 1) / T;
-  const int lo = min(tid * chunk, nc), hi = min(lo + chunk, nc);
-  uint64_t part = 0;
-  for (int k = lo; k < hi; ++k) part += u[k];
-  unsigned long long incl = part;
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned long long x = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += x;
+  const unsigned int n2 = cnt[1];
+  if (n2 > SURV2_CAP || cnt[2] != 0) {  // flat posterior: the host re-runs this item with the generic kernel
+    if (tid == 0) {
+      overflow_flag[t] = PCLEAN_CHOICE_NEW;  // marker understood by compact_new_kernel
+      atomicAdd(overflow_count, 1u);
+    }
+    return;
   }
-  if (lane == 63) wsum[wave] = incl;
+  if (tid == 0) overflow_flag[t] = 0;
+  // ---- phase 4: rank sort by candidate index (natural order), weights ------------------------
+  for (unsigned int i = tid; i < n2; i += T) {
+    const int ki = k2[i];
+    unsigned int rank = 0;
+    for (unsigned int j = 0; j < n2; ++j) rank += k2[j] < ki ? 1u : 0u;
+    ks[rank] = ki;
+    u2[rank] = pclean_fixw(sc2[i] - m);
+  }
   __syncthreads();
-  uint64_t base = 0, U = 0;
-  for (int w = 0; w < nw; ++w) {
-    if (w < wave) base += wsum[w];
-    U += wsum[w];
+  // inclusive prefix (n2 is small: one wave, chunked)
+  if (wave == 0) {
+    const unsigned int chunk = (n2 + 63) / 64;
+    const unsigned int lo = min(lane * chunk, n2), hi = min(lo + chunk, n2);
+    unsigned long long part = 0;
+    for (unsigned int i = lo; i < hi; ++i) part += u2[i];
+    unsigned long long incl = part;
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned long long x = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += x;
+    }
+    unsigned long long run = incl - part;
+    for (unsigned int i = lo; i < hi; ++i) {
+      run += u2[i];
+      u2[i] = run;
+    }
   }
-  const uint64_t pre = base + incl - part;
-  // ---- phase 5: lse + draws -------------------------------------------------------------
+  __syncthreads();
+  const uint64_t U = n2 ? u2[n2 - 1] : 0ull;
+  // ---- phase 5: lse + draws ---------------------------------------------------------------
   if (tid == 0 && lse_out) lse_out[t] = pclean_lse_from_fix(m, U);
   if (n_draws > 0) {
-    // one Philox evaluation per draw for the whole workgroup (lane j of wave 0), broadcast through LDS
     const uint32_t rng_row = (uint32_t)((int64_t)row + it.row_offset);
-    for (int j0 = 0; j0 < n_draws; j0 += 64) {
-      __syncthreads();
-      if (tid < 64 && j0 + tid < n_draws) {
-        const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)(j0 + tid);
-        xs[tid] = U ? pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U) : 0ull;
-      }
-      __syncthreads();
-      const int jn = min(64, n_draws - j0);
-      for (int j = 0; j < jn; ++j) {
-        int32_t* dst = draws_out + (size_t)t * n_draws + j0 + j;
-        if (U == 0) {
-          if (tid == 0) *dst = PCLEAN_CHOICE_NEW;
-          continue;
+    for (int j = tid; j < n_draws; j += T) {
+      const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)j;
+      int32_t res = PCLEAN_CHOICE_NEW;
+      if (U != 0) {
+        const uint64_t x = pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U);
+        unsigned int lo = 0, hi = n2 - 1;  // smallest index with prefix > x
+        while (lo < hi) {
+          const unsigned int mid = (lo + hi) >> 1;
+          if (u2[mid] > x)
+            hi = mid;
+          else
+            lo = mid + 1;
         }
-        const uint64_t x = xs[j];
-        if (x >= pre && x < pre + part) {
-          uint64_t acc = pre;
-          int k = lo;
-          for (; k < hi; ++k) {
-            acc += u[k];
-            if (acc > x) break;
-          }
-          *dst = k == n ? PCLEAN_CHOICE_NEW : k;
-        }
+        const int k = ks[lo];
+        res = k == n ? PCLEAN_CHOICE_NEW : k;
       }
+      draws_out[(size_t)t * n_draws + j] = res;
     }
   }
 }
 
+typedef void (*fast_kernel_t)(const FastRootDev, const DensDev, const ItemsDev, const ChildrenDev, uint64_t, uint32_t,
+                              uint32_t, int, int, double*, int32_t*, int32_t*, unsigned int*);
+
+static fast_kernel_t pick_kernel(int n_terms) {
+  if (n_terms <= 2) return fk_root_fast_kernel<2>;
+  if (n_terms <= 4) return fk_root_fast_kernel<4>;
+  if (n_terms <= 8) return fk_root_fast_kernel<8>;
+  if (n_terms <= 12) return fk_root_fast_kernel<12>;
+  return fk_root_fast_kernel<16>;
+}
+
+size_t pclean_fast_lds_bytes(int lmax, int dstride) {
+  const int lut_n = (lmax + 1) * dstride;
+  return (size_t)((lut_n + 1) & ~1) * 8 + FAST_MAX_WAVES * 8 + 64 * 8 + (size_t)SURV2_CAP * 8 * 2 +
+         (size_t)SURV2_CAP * 4 * 2 + 16;
+}
+
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
-                            int32_t* draws_out) {
+                            int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count) {
   if (it.n <= 0) return PCLEAN_OK;
-  const int nc = fr.n_cand + 1;
-  const int lut_n = (fr.lmax + 1) * fr.dstride;
-  const size_t lds = (size_t)((nc + 1) & ~1) * 8 + (size_t)((lut_n + 1) & ~1) * 8 + (2 * FAST_MAX_WAVES + 64 + 16) * 8;
+  const size_t lds = pclean_fast_lds_bytes(fr.lmax, fr.dstride);
   // lanes: as few rounds of 4-candidate slots as possible with little idle tail
   const int nslots = fr.kpad >> 2;
   const int rounds = (nslots + 1023) / 1024;
   int T = ((nslots + rounds - 1) / rounds + 63) / 64 * 64;
   T = std::max(256, std::min(1024, T));
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0};
-  static bool attr_set = false;
-  if (!attr_set) {
-    HIPCHK(ctx, hipFuncSetAttribute((const void*)fk_root_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    160 * 1024));
-    attr_set = true;
-  }
+  fast_kernel_t kern = pick_kernel(fr.n_terms);
+  HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int kMaxBlocks = 2 * 1024 * 1024;  // < 2^32 threads per launch
   for (int base = 0; base < it.n; base += kMaxBlocks)
-    hipLaunchKernelGGL(fk_root_fast_kernel, dim3(std::min(kMaxBlocks, it.n - base)), dim3(T), lds, ctx->stream, fr, dn,
-                       it, ch, seed, sweep, site, n_draws, base, lse_out, draws_out);
+    hipLaunchKernelGGL(kern, dim3(std::min(kMaxBlocks, it.n - base)), dim3(T), lds, ctx->stream, fr, dn, it, ch, seed,
+                       sweep, site, n_draws, base, lse_out, draws_out, overflow_flag, overflow_count);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }

@@ -219,6 +219,18 @@ __global__ void set_col_kernel(int n, int n_nodes, int node, int32_t v, int32_t*
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) vals[(size_t)j * n_nodes + node] = v;
 }
+// item attributes of a sub-list (list[j] = index in the parent item list)
+__global__ void gather_items_kernel(int n, const int32_t* list, const int32_t* row, const int32_t* ctxv,
+                                    const int32_t* excl, const int32_t* particle, int32_t* row2, int32_t* ctx2,
+                                    int32_t* excl2, int32_t* part2) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int s = list[j];
+  row2[j] = row ? row[s] : s;
+  excl2[j] = excl ? excl[s] : -1;
+  part2[j] = particle ? particle[s] : 0;
+  for (int c = 0; c < PCLEAN_MAX_CTX; ++c) ctx2[j * PCLEAN_MAX_CTX + c] = ctxv ? ctxv[(size_t)s * PCLEAN_MAX_CTX + c] : 0;
+}
 __global__ void gather_i32_kernel(int n, const int32_t* list, const int32_t* src, int32_t* dst) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j < n) dst[j] = src[list[j]];
@@ -519,7 +531,7 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
     int rc = build_node_dev(ctx, b, node_id, nd);
     if (rc) return rc;
     nd.terms[0].obs_col = io.p;  // item t observes value t (or missing for t == U)
-    ItemsDev it{U + 1, 0, nullptr, nullptr, nullptr, nullptr, 0};
+    ItemsDev it{U + 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     ChildrenDev ch{};
     rc = pclean_launch_enum(ctx, nd, it, ch, 0, 0, 0, 0, cache.p, nullptr, nullptr);
     if (rc) return rc;
@@ -551,7 +563,8 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   if (lmax > 255 || dmax > 255) return 0;
   const int kpad = (t.n_rows + 15) & ~15;
   const size_t lds = (size_t)((t.n_rows + 2) & ~1) * 8 + (size_t)(((lmax + 1) * (dmax + 1) + 1) & ~1) * 8 + 1024;
-  if (lds > 160 * 1024) return 0;
+  (void)lds;
+  if (pclean_fast_lds_bytes(lmax, dmax + 1) > 160 * 1024) return 0;
   FastRoot& f = st(ctx)->fast[block_id * 64 + node_id];
   if ((int)f.comp.size() != n.n_terms || f.kpad != kpad) {
     for (auto& c : f.comp) c.release();
@@ -649,21 +662,49 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
       }
     }
   }
-  ItemsDev it{il.n, 0, il.row, il.ctx, excl, n_draws == 1 ? il.particle : nullptr, s->row_offset};
+  ItemsDev it{il.n, 0, il.row, il.ctx, excl, n_draws == 1 ? il.particle : nullptr, s->row_offset, nullptr};
   FastRootDev fr;
   int fast = 0;
   if (!scores_out && !snew_override && !ctx->force_generic) {
     fast = try_fast_root(ctx, block_id, node_id, fr);
     if (fast < 0) return fast;
   }
+  const uint32_t site = PCLEAN_SITE_NODE(block_id, node_id);
+  if (!fast) {
+    if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
+    rc = pclean_launch_enum(ctx, nd, it, ch, seed, sweep, site, n_draws, lse_out, scores_out, draws_out);
+    if (time_it) (void)hipEventRecord(s->ev1, ctx->stream);
+    return rc;
+  }
+  // compact-table kernel; items whose survivor list overflows are re-run with the generic kernel
+  int32_t* oflag = scratch<int32_t>(ctx, il.n);
+  if (!oflag || s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  HIPCHK(ctx, hipMemsetAsync(s->counter.p + 1, 0, sizeof(unsigned int), ctx->stream));
   if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
-  if (fast)
-    rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out,
-                                 draws_out);
-  else
-    rc = pclean_launch_enum(ctx, nd, it, ch, seed, sweep, PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out,
-                            scores_out, draws_out);
+  rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag,
+                               s->counter.p + 1);
   if (time_it) (void)hipEventRecord(s->ev1, ctx->stream);
+  if (rc) return rc;
+  unsigned int n_over = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&n_over, s->counter.p + 1, sizeof n_over, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->timing.reserved += (int32_t)n_over;  // items that fell back to the generic kernel
+  if (n_over) {
+    int32_t* list = scratch<int32_t>(ctx, n_over);
+    int32_t* row2 = scratch<int32_t>(ctx, n_over);
+    int32_t* excl2 = scratch<int32_t>(ctx, n_over);
+    int32_t* ctx2 = scratch<int32_t>(ctx, (size_t)n_over * PCLEAN_MAX_CTX);
+    int32_t* part2 = scratch<int32_t>(ctx, n_over);
+    if (!list || !row2 || !excl2 || !ctx2 || !part2) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    HIPCHK(ctx, hipMemsetAsync(s->counter.p + 1, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, oflag, 1,
+                       s->counter.p + 1, list, nullptr);
+    hipLaunchKernelGGL(gather_items_kernel, grid1(n_over), dim3(256), 0, ctx->stream, (int)n_over, list, il.row,
+                       il.ctx, excl, it.particle, row2, ctx2, excl2, part2);
+    ItemsDev it2{(int)n_over, 0, row2, il.ctx ? ctx2 : nullptr, excl ? excl2 : nullptr, it.particle ? part2 : nullptr,
+                 s->row_offset, list};
+    rc = pclean_launch_enum(ctx, nd, it2, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out);
+  }
   return rc;
 }
 
