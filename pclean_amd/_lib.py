@@ -25,7 +25,7 @@ class PCleanHipError(RuntimeError):
 class Term(C.Structure):
     _fields_ = [("obs_col", C.c_int32), ("cand_col", C.c_int32), ("pair_table", C.c_int32),
                 ("dens_kind", C.c_int32), ("max_typos", C.c_int32), ("ctx_slot", C.c_int32),
-                ("fn_table", C.c_int32), ("reserved", C.c_int32)]
+                ("fn_table", C.c_int32), ("ctx_mode", C.c_int32)]
 
 
 class Node(C.Structure):
@@ -47,7 +47,7 @@ class Timing(C.Structure):
 
 
 TERM_DTYPE = np.dtype([("obs_col", "<i4"), ("cand_col", "<i4"), ("pair_table", "<i4"), ("dens_kind", "<i4"),
-                       ("max_typos", "<i4"), ("ctx_slot", "<i4"), ("fn_table", "<i4"), ("reserved", "<i4")])
+                       ("max_typos", "<i4"), ("ctx_slot", "<i4"), ("fn_table", "<i4"), ("ctx_mode", "<i4")])
 NODE_DTYPE = np.dtype([("kind", "<i4"), ("table", "<i4"), ("term_begin", "<i4"), ("n_terms", "<i4"),
                        ("child_begin", "<i4"), ("n_children", "<i4"), ("parent", "<i4"), ("parent_fk_col", "<i4"),
                        ("cacheable", "<i4"), ("colmap_begin", "<i4"), ("reserved0", "<i4"), ("reserved1", "<i4")])
@@ -252,6 +252,27 @@ class HipContext:
                                             C.c_int32(n_blocks), _p(cur, C.c_int32), _p(choice, C.c_int32),
                                             _p(chosen, C.c_int32), _p(logml, C.c_double)), "pclean_sweep")
         return choice, chosen, logml
+
+    def set_active_rows(self, begin, count):
+        check(self.h, self.lib.pclean_set_active_rows(self.h, C.c_int32(begin), C.c_int32(count)),
+              "pclean_set_active_rows")
+
+    def sweep_latent(self, cfg, seed, sweep_idx, block_id, roots, keys, ev_off, ev_rows, ev_ctx, excl, n_nodes):
+        roots = np.ascontiguousarray(roots, dtype=np.int32)
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        ev_off = np.ascontiguousarray(ev_off, dtype=np.int32)
+        ev_rows = np.ascontiguousarray(ev_rows, dtype=np.int32)
+        ev_ctx = None if ev_ctx is None else np.ascontiguousarray(ev_ctx, dtype=np.int32)
+        excl = np.ascontiguousarray(excl, dtype=np.int32)  # [n_roots][n_items]
+        n = len(keys)
+        chosen = np.zeros(n, dtype=np.int32)
+        vals = np.full((n, n_nodes), -2, dtype=np.int32)
+        check(self.h, self.lib.pclean_sweep_latent(
+            self.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep_idx), C.c_int32(block_id), C.c_int32(len(roots)),
+            _p(roots, C.c_int32), C.c_int32(n), _p(keys, C.c_int32), _p(ev_off, C.c_int32), _p(ev_rows, C.c_int32),
+            _p(ev_ctx, C.c_int32), _p(excl, C.c_int32), _p(chosen, C.c_int32), _p(vals, C.c_int32)),
+            "pclean_sweep_latent")
+        return chosen, vals
 
     def get_new_rows(self, block_id, n_nodes):
         n = C.c_int32()

@@ -12,7 +12,7 @@
 #include "../../include/pclean_hip.h"
 
 #define PCLEAN_MAX_TABLES 64
-#define PCLEAN_MAX_BLOCKS 8
+#define PCLEAN_MAX_BLOCKS 16
 
 // RAII-less device buffer: freed by ctx destroy / reassign.
 template <typename T>
@@ -115,6 +115,7 @@ struct pclean_ctx {
   Block block[PCLEAN_MAX_BLOCKS];
 
   pclean_timing timing = {};
+  int32_t active_begin = 0, active_count = -1;  // pclean_set_active_rows window (-1 = all rows)
   bool force_generic = false;  // debug: never take the compact-table root kernel
   void* sweep_state = nullptr;  // owned by sweep.hip
 };

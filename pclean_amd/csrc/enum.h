@@ -12,6 +12,7 @@ struct TermDev {
   const uint16_t* lat_len;  // [n_lat]
   const int32_t* fn;        // ctx lookup table or nullptr
   int32_t n_lat, elem_bytes, dens_kind, max_typos, ctx_slot, fn_nb;
+  int32_t ctx_mode, pad;    // 0: ctx of the item; 1: ctx of the evidence row, fn[ctx][cand]; 2: fn[cand][ctx]
 };
 
 struct NodeDev {
@@ -40,6 +41,14 @@ struct ItemsDev {
   const int32_t* particle;
   int64_t row_offset;  // global id of local row 0 (RNG counter), multi-GPU sharding
   const int32_t* out_pos;  // where item t writes its outputs (identity when null)
+  // Evidence sets (latent-class rows scored against all observed rows that refer to them,
+  // ExternalLikelihoodNodes of proposal_compiler.jl:306-350): item t sums its terms over
+  // observed rows ev_rows[ev_lo[t] .. ev_hi[t]); ev_ctx[e*PCLEAN_MAX_CTX + s] = ctx of evidence row e.
+  const int32_t* ev_lo;   // [n] first evidence position of item t (CSR: offsets)
+  const int32_t* ev_hi;   // [n] one past the last (CSR: offsets + 1)
+  const int32_t* ev_rows;
+  const int32_t* ev_ctx;
+  const int32_t* rng_row;  // RNG row id of item t (defaults to the evidence row)
 };
 
 // Log-marginals of the children of a "new row": either one value per item, or a

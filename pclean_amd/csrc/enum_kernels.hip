@@ -49,6 +49,7 @@ struct ItemView {
   const int32_t* ctxv;
   bool deleted;
   double logden;
+  int ev_lo, ev_hi;  // evidence range (ev_lo < 0: the single row `row`)
 };
 
 __device__ __forceinline__ ItemView item_view(const NodeDev& nd, const ItemsDev& it, int t) {
@@ -58,6 +59,12 @@ __device__ __forceinline__ ItemView item_view(const NodeDev& nd, const ItemsDev&
   v.ctxv = it.ctx ? it.ctx + (size_t)t * PCLEAN_MAX_CTX : nullptr;
   v.deleted = false;
   v.logden = 0.0;
+  v.ev_lo = -1;
+  v.ev_hi = -1;
+  if (it.ev_lo) {
+    v.ev_lo = it.ev_lo[t];
+    v.ev_hi = it.ev_hi[t];
+  }
   if (nd.kind == PCLEAN_NODE_FK) {
     const bool excluded = v.excl >= 0;
     v.deleted = excluded && nd.counts[v.excl] <= 1;
@@ -68,7 +75,30 @@ __device__ __forceinline__ ItemView item_view(const NodeDev& nd, const ItemsDev&
 
 // score of existing candidate k (the single definition both kernels use, so the
 // fp64 operation order — prior, then terms in plan order — is identical)
-__device__ __forceinline__ double candidate_score(const NodeDev& nd, const DensDev& dn, const ItemView& v, int k) {
+__device__ __forceinline__ double candidate_score_ev(const NodeDev& nd, const DensDev& dn, const ItemsDev& it,
+                                                     const ItemView& v, int k, double sk) {
+  // evidence order: ascending position in the item's evidence list; terms in plan order per row
+  for (int e = v.ev_lo; e < v.ev_hi; ++e) {
+    const int row = it.ev_rows[e];
+    for (int ti = 0; ti < nd.n_terms; ++ti) {
+      const TermDev& tm = nd.terms[ti];
+      const int o = tm.obs_col[row];
+      if (o < 0) continue;
+      int val = tm.cand_col[k];
+      if (tm.ctx_slot >= 0) {
+        const int c = tm.ctx_mode == 0 ? v.ctxv[tm.ctx_slot] : it.ev_ctx[(size_t)e * PCLEAN_MAX_CTX + tm.ctx_slot];
+        val = tm.ctx_mode == 2 ? tm.fn[(size_t)val * tm.fn_nb + c] : tm.fn[(size_t)c * tm.fn_nb + val];
+      }
+      const size_t idx = (size_t)o * tm.n_lat + val;
+      const int d = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
+      sk += term_density(tm, dn, d, val);
+    }
+  }
+  return sk;
+}
+
+__device__ __forceinline__ double candidate_score(const NodeDev& nd, const DensDev& dn, const ItemsDev& it,
+                                                  const ItemView& v, int k) {
   double sk;
   if (nd.kind == PCLEAN_NODE_FK) {
     if (nd.counts[k] == 0) return -__builtin_inf();  // free slot
@@ -79,6 +109,7 @@ __device__ __forceinline__ double candidate_score(const NodeDev& nd, const DensD
   } else {
     sk = nd.logc_full[k];
   }
+  if (v.ev_lo >= 0) return candidate_score_ev(nd, dn, it, v, k, sk);
   for (int ti = 0; ti < nd.n_terms; ++ti) {
     const TermDev& tm = nd.terms[ti];
     const int o = tm.obs_col[v.row];
@@ -146,7 +177,7 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   // ---- phase 1: scores ----------------------------------------------------
   double lmax = -__builtin_inf();
   for (int k = tid; k < n; k += 256) {
-    const double sk = candidate_score(nd, dn, v, k);
+    const double sk = candidate_score(nd, dn, it, v, k);
     s[k] = sk;
     if (scores_out) scores_out[(size_t)to * nc + k] = sk;
     lmax = fmax(lmax, sk);
@@ -180,7 +211,7 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   if (n_draws > 0) {
     // one Philox evaluation per draw for the whole workgroup (lane j of wave 0), broadcast through LDS
     uint64_t* xs = wsum + 8;  // [64]
-    const uint32_t rng_row = (uint32_t)((int64_t)v.row + it.row_offset);
+    const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[t] : (uint32_t)((int64_t)v.row + it.row_offset);
     for (int j0 = 0; j0 < n_draws; j0 += 64) {
       __syncthreads();
       if (tid < 64 && j0 + tid < n_draws) {
@@ -231,7 +262,7 @@ __global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, co
   // pass A: max (lane-strided, coalesced)
   double lmax = -__builtin_inf();
   for (int k = tid; k < n; k += 256) {
-    const double sk = candidate_score(nd, dn, v, k);
+    const double sk = candidate_score(nd, dn, it, v, k);
     if (scores_out) scores_out[(size_t)to * nc + k] = sk;
     lmax = fmax(lmax, sk);
   }
@@ -250,7 +281,7 @@ __global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, co
   uint64_t part = 0;
   if (m != -__builtin_inf())
     for (int k = lo; k < hi; ++k) {
-      const double sk = (k == n) ? sn : candidate_score(nd, dn, v, k);
+      const double sk = (k == n) ? sn : candidate_score(nd, dn, it, v, k);
       part += pclean_fixw(sk - m);
     }
   uint64_t U;
@@ -259,7 +290,7 @@ __global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, co
 
   // pass C: draws, located by recomputing the owning lane's chunk
   if (n_draws > 0) {
-    const uint32_t rng_row = (uint32_t)((int64_t)v.row + it.row_offset);
+    const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[t] : (uint32_t)((int64_t)v.row + it.row_offset);
     for (int j = 0; j < n_draws; ++j) {
       const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)j;
       int32_t* dst = draws_out + (size_t)to * n_draws + j;
@@ -273,7 +304,7 @@ __global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, co
         uint64_t acc = pre;
         int k = lo;
         for (; k < hi; ++k) {
-          const double sk = (k == n) ? sn : candidate_score(nd, dn, v, k);
+          const double sk = (k == n) ? sn : candidate_score(nd, dn, it, v, k);
           acc += pclean_fixw(sk - m);
           if (acc > x) break;
         }

@@ -184,10 +184,17 @@ __global__ void compact_new_kernel(size_t n, const int32_t* choice, int fill, un
 // sub-list items from a parent list: list[j] indexes the parent's items
 __global__ void sublist_items_kernel(int n, const int32_t* list, const int32_t* p_row, const int32_t* p_ctx,
                                      const int32_t* p_particle, const int32_t* p_origin, int32_t* row, int32_t* ctxv,
-                                     int32_t* particle, int32_t* origin) {
+                                     int32_t* particle, int32_t* origin, const int32_t* p_ev_lo,
+                                     const int32_t* p_ev_hi, const int32_t* p_rng, int32_t* ev_lo, int32_t* ev_hi,
+                                     int32_t* rng) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int s = list[j];
+  if (p_ev_lo) {
+    ev_lo[j] = p_ev_lo[s];
+    ev_hi[j] = p_ev_hi[s];
+  }
+  if (p_rng) rng[j] = p_rng[s];
   row[j] = p_row ? p_row[s] : s;
   particle[j] = p_particle[s];
   origin[j] = p_origin ? p_origin[s] : j;
@@ -383,6 +390,12 @@ struct ItemList {  // device arrays describing enumeration work items
   const int32_t* ctx = nullptr;
   const int32_t* particle = nullptr;
   const int32_t* origin = nullptr;
+  // evidence sets (latent-class sweeps): per-item [ev_lo, ev_hi) into ev_rows / ev_ctx; RNG row ids
+  const int32_t* ev_lo = nullptr;
+  const int32_t* ev_hi = nullptr;
+  const int32_t* ev_rows = nullptr;
+  const int32_t* ev_ctx = nullptr;
+  const int32_t* rng_row = nullptr;
 };
 
 struct BlockRun {  // per-block device state of one sweep
@@ -482,7 +495,9 @@ static int build_node_dev(pclean_ctx* ctx, const Block& b, int node_id, NodeDev&
     if (tm.obs_col < 0 || tm.obs_col >= ctx->n_cols || tm.cand_col < 0 || tm.cand_col >= t.n_cols)
       return pclean_fail(ctx, PCLEAN_ERR_ARG, "term %d: column out of range", n.term_begin + i);
     TermDev& td = nd.terms[i];
-    td.obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows;
+    td.obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
+    td.ctx_mode = tm.ctx_mode;
+    td.pad = 0;
     td.cand_col = t.cols.p + (size_t)tm.cand_col * t.n_rows;
     td.pair = pt.d.p;
     td.lat_len = pt.lat_len.p;
@@ -531,14 +546,14 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
     int rc = build_node_dev(ctx, b, node_id, nd);
     if (rc) return rc;
     nd.terms[0].obs_col = io.p;  // item t observes value t (or missing for t == U)
-    ItemsDev it{U + 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+    ItemsDev it{U + 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     ChildrenDev ch{};
     rc = pclean_launch_enum(ctx, nd, it, ch, 0, 0, 0, 0, cache.p, nullptr, nullptr);
     if (rc) return rc;
     s->leaf_version[key] = ver;
   }
   *out = cache.p;
-  *obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows;
+  *obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
   *n_obs = U;
   return PCLEAN_OK;
 }
@@ -589,7 +604,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     }
     fr.terms[i].comp = f.comp[i].p;
     fr.terms[i].clen = f.clen[i].p;
-    fr.terms[i].obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows;
+    fr.terms[i].obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
     fr.terms[i].max_typos = tm.max_typos;
   }
   if (f.prior_ver != t.version || !f.prior_e.p) {
@@ -662,10 +677,11 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
       }
     }
   }
-  ItemsDev it{il.n, 0, il.row, il.ctx, excl, n_draws == 1 ? il.particle : nullptr, s->row_offset, nullptr};
+  ItemsDev it{il.n, 0, il.row, il.ctx, excl, n_draws == 1 ? il.particle : nullptr, s->row_offset + ctx->active_begin,
+              nullptr, il.ev_lo, il.ev_hi, il.ev_rows, il.ev_ctx, il.rng_row};
   FastRootDev fr;
   int fast = 0;
-  if (!scores_out && !snew_override && !ctx->force_generic) {
+  if (!scores_out && !snew_override && !ctx->force_generic && !il.ev_lo) {
     fast = try_fast_root(ctx, block_id, node_id, fr);
     if (fast < 0) return fast;
   }
@@ -702,7 +718,7 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     hipLaunchKernelGGL(gather_items_kernel, grid1(n_over), dim3(256), 0, ctx->stream, (int)n_over, list, il.row,
                        il.ctx, excl, it.particle, row2, ctx2, excl2, part2);
     ItemsDev it2{(int)n_over, 0, row2, il.ctx ? ctx2 : nullptr, excl ? excl2 : nullptr, it.particle ? part2 : nullptr,
-                 s->row_offset, list};
+                 s->row_offset + ctx->active_begin, list, nullptr, nullptr, nullptr, nullptr, nullptr};
     rc = pclean_launch_enum(ctx, nd, it2, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out);
   }
   return rc;
@@ -753,13 +769,17 @@ static int sample_children(pclean_ctx* ctx, int block_id, int node_id, const Ite
         HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
         hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, draws, 1,
                            s->counter.p, list, nullptr);
+        int32_t* evl = il.ev_lo ? scratch<int32_t>(ctx, cnt) : nullptr;
+        int32_t* evh = il.ev_lo ? scratch<int32_t>(ctx, cnt) : nullptr;
+        int32_t* rng = il.rng_row ? scratch<int32_t>(ctx, cnt) : nullptr;
+        if ((il.ev_lo && (!evl || !evh)) || (il.rng_row && !rng)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
         hipLaunchKernelGGL(sublist_items_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, list, il.row, il.ctx,
-                           il.particle, il.origin, row, cx, part, org);
+                           il.particle, il.origin, row, cx, part, org, il.ev_lo, il.ev_hi, il.rng_row, evl, evh, rng);
         // exclusion of the child's table for the sub-list = gather of child_excl
         if (child_excl)
           hipLaunchKernelGGL(gather_i32_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, list, child_excl,
                              sub_excl);
-        ItemList sub{(int)cnt, row, cx, part, org};
+        ItemList sub{(int)cnt, row, cx, part, org, evl, evh, il.ev_rows, il.ev_ctx, rng};
         rc = sample_children(ctx, block_id, cid, sub, child_excl ? sub_excl : nullptr, seed, sweep, vals, n_nodes);
         if (rc) return rc;
       }
@@ -798,6 +818,168 @@ static int ensure_plan_dev(pclean_ctx* ctx, int block_id) {
 }
 
 // ---------------------------------------------------------------------------
+extern "C" int pclean_set_active_rows(pclean_ctx* ctx, int32_t begin, int32_t count) {
+  if (!ctx || begin < 0 || count < -1 || (count >= 0 && (int64_t)begin + count > ctx->n_rows))
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_active_rows: window outside the loaded rows");
+  ctx->active_begin = count < 0 ? 0 : begin;
+  ctx->active_count = count;
+  return PCLEAN_OK;
+}
+
+// particle choice of a latent row: every particle has the same weight (all sub-plans enumerated)
+__global__ void latent_choice_kernel(int n, int P, int use_mh, const int32_t* keys, uint64_t seed, uint32_t sweep,
+                                     uint32_t block_id, int32_t* chosen) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t rr = (uint32_t)keys[i];
+  const uint32_t pid = 0x1000u + block_id;
+  int c;
+  if (use_mh && P >= 2) {  // row_inference.jl:161-162 with w1 == w0
+    const double ratio = 0.5 / (1e-10 + 0.5);
+    c = pclean_u01(pclean_rand64(seed, rr, PCLEAN_SITE_MH, pid, sweep)) < ratio ? 1 : 0;
+  } else {
+    const uint64_t U = (uint64_t)P << PCLEAN_FIX_BITS;
+    c = (int)(pclean_mulhi64(pclean_rand64(seed, rr, PCLEAN_SITE_FINAL, pid, sweep), U) >> PCLEAN_FIX_BITS);
+  }
+  chosen[i] = c;
+}
+__global__ void mark_positive_kernel(int n, const int32_t* v, int32_t* flag) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = v[i] > 0 ? PCLEAN_CHOICE_NEW : 0;
+}
+__global__ void latent_items_kernel(int n, const int32_t* list, const int32_t* keys, const int32_t* ev_off,
+                                    const int32_t* chosen, int32_t* rng, int32_t* ev_lo, int32_t* ev_hi,
+                                    int32_t* particle, int32_t* origin) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int t = list[j];
+  rng[j] = keys[t];
+  ev_lo[j] = ev_off[t];
+  ev_hi[j] = ev_off[t + 1];
+  particle[j] = chosen[t];
+  origin[j] = t;
+}
+
+extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
+                                   int32_t block_id, int32_t n_roots, const int32_t* roots, int32_t n_items,
+                                   const int32_t* keys, const int32_t* ev_off, const int32_t* ev_rows,
+                                   const int32_t* ev_ctx, const int32_t* excl, int32_t* chosen, int32_t* vals) {
+  if (!ctx || !cfg || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid || n_roots <= 0 ||
+      !roots || n_items < 0 || !keys || !ev_off || !excl || !chosen || !vals)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: bad arguments");
+  if (n_items == 0) return PCLEAN_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  Block& b = ctx->block[block_id];
+  const int nn = (int)b.nodes.size();
+  int P = cfg->num_particles;
+  const int use_mh = cfg->use_mh_instead_of_pg != 0;
+  if (use_mh) P = 2;
+  if (P < 1 || P > MAXP) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: bad particle count");
+  for (int r = 0; r < n_roots; ++r)
+    if (roots[r] < 0 || roots[r] >= nn) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: bad root");
+  SweepState* s = st(ctx);
+  s->pool_used = 0;
+  if (s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  const int n_ev = ev_off[n_items];
+  if (n_ev > 0 && !ev_rows) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: evidence rows missing");
+  int32_t* d_keys = scratch<int32_t>(ctx, n_items);
+  int32_t* d_off = scratch<int32_t>(ctx, (size_t)n_items + 1);
+  int32_t* d_evr = scratch<int32_t>(ctx, std::max(n_ev, 1));
+  int32_t* d_evc = ev_ctx ? scratch<int32_t>(ctx, (size_t)std::max(n_ev, 1) * PCLEAN_MAX_CTX) : nullptr;
+  int32_t* d_excl = scratch<int32_t>(ctx, (size_t)n_roots * n_items);
+  int32_t* d_chosen = scratch<int32_t>(ctx, n_items);
+  int32_t* d_vals = scratch<int32_t>(ctx, (size_t)n_items * nn);
+  int32_t* d_flag = scratch<int32_t>(ctx, n_items);
+  if (!d_keys || !d_off || !d_evr || (ev_ctx && !d_evc) || !d_excl || !d_chosen || !d_vals || !d_flag)
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  HIPCHK(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n_items * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_off, ev_off, ((size_t)n_items + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n_ev) HIPCHK(ctx, hipMemcpyAsync(d_evr, ev_rows, (size_t)n_ev * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (ev_ctx && n_ev)
+    HIPCHK(ctx, hipMemcpyAsync(d_evc, ev_ctx, (size_t)n_ev * PCLEAN_MAX_CTX * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_excl, excl, (size_t)n_roots * n_items * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(latent_choice_kernel, grid1(n_items), dim3(256), 0, ctx->stream, n_items, P, use_mh, d_keys, seed,
+                     sweep_idx, (uint32_t)block_id, d_chosen);
+  hipLaunchKernelGGL(fill_i32_kernel, grid1((size_t)n_items * nn), dim3(256), 0, ctx->stream, d_vals,
+                     (size_t)n_items * nn, -2);
+  // rows that take a fresh particle
+  hipLaunchKernelGGL(mark_positive_kernel, grid1(n_items), dim3(256), 0, ctx->stream, n_items, d_chosen, d_flag);
+  HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+  hipLaunchKernelGGL(compact_new_kernel, grid1(n_items), dim3(256), 0, ctx->stream, (size_t)n_items, d_flag, 0,
+                     s->counter.p, nullptr, nullptr);
+  unsigned int cnt = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&cnt, s->counter.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (cnt) {
+    int32_t* list = scratch<int32_t>(ctx, cnt);
+    int32_t* rng = scratch<int32_t>(ctx, cnt);
+    int32_t* evl = scratch<int32_t>(ctx, cnt);
+    int32_t* evh = scratch<int32_t>(ctx, cnt);
+    int32_t* part = scratch<int32_t>(ctx, cnt);
+    int32_t* org = scratch<int32_t>(ctx, cnt);
+    int32_t* ex = scratch<int32_t>(ctx, cnt);
+    int32_t* draws = scratch<int32_t>(ctx, cnt);
+    if (!list || !rng || !evl || !evh || !part || !org || !ex || !draws)
+      return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(compact_new_kernel, grid1(n_items), dim3(256), 0, ctx->stream, (size_t)n_items, d_flag, 1,
+                       s->counter.p, list, nullptr);
+    hipLaunchKernelGGL(latent_items_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, list, d_keys, d_off,
+                       d_chosen, rng, evl, evh, part, org);
+    ItemList il{(int)cnt, nullptr, nullptr, part, org, evl, evh, d_evr, d_evc, rng};
+    for (int r = 0; r < n_roots; ++r) {
+      const int root = roots[r];
+      const pclean_node& rn = b.nodes[root];
+      const int32_t* rex = nullptr;
+      if (rn.kind == PCLEAN_NODE_FK) {
+        hipLaunchKernelGGL(gather_i32_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, list,
+                           d_excl + (size_t)r * n_items, ex);
+        rex = ex;
+      }
+      int rc = eval_node(ctx, block_id, root, il, rex, seed, sweep_idx, 1, nullptr, draws, nullptr, nullptr, false);
+      if (rc) return rc;
+      hipLaunchKernelGGL(scatter_vals_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, org, draws, nn, root,
+                         d_vals);
+      if (rn.kind == PCLEAN_NODE_FK && rn.n_children > 0) {
+        // referents proposed as NEW: sample their contents with the same evidence
+        HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+        hipLaunchKernelGGL(compact_new_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (size_t)cnt, draws, 0,
+                           s->counter.p, nullptr, nullptr);
+        unsigned int c2 = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&c2, s->counter.p, sizeof c2, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (c2) {
+          int32_t* l2 = scratch<int32_t>(ctx, c2);
+          int32_t* row2 = scratch<int32_t>(ctx, c2);
+          int32_t* cx2 = scratch<int32_t>(ctx, (size_t)c2 * PCLEAN_MAX_CTX);
+          int32_t* part2 = scratch<int32_t>(ctx, c2);
+          int32_t* org2 = scratch<int32_t>(ctx, c2);
+          int32_t* evl2 = scratch<int32_t>(ctx, c2);
+          int32_t* evh2 = scratch<int32_t>(ctx, c2);
+          int32_t* rng2 = scratch<int32_t>(ctx, c2);
+          int32_t* ex2 = scratch<int32_t>(ctx, c2);
+          if (!l2 || !row2 || !cx2 || !part2 || !org2 || !evl2 || !evh2 || !rng2 || !ex2)
+            return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+          HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+          hipLaunchKernelGGL(compact_new_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (size_t)cnt, draws, 1,
+                             s->counter.p, l2, nullptr);
+          hipLaunchKernelGGL(sublist_items_kernel, grid1(c2), dim3(256), 0, ctx->stream, (int)c2, l2, il.row, il.ctx,
+                             il.particle, il.origin, row2, cx2, part2, org2, il.ev_lo, il.ev_hi, il.rng_row, evl2, evh2,
+                             rng2);
+          hipLaunchKernelGGL(gather_i32_kernel, grid1(c2), dim3(256), 0, ctx->stream, (int)c2, l2, rex, ex2);
+          ItemList sub{(int)c2, nullptr, nullptr, part2, org2, evl2, evh2, d_evr, d_evc, rng2};
+          rc = sample_children(ctx, block_id, root, sub, ex2, seed, sweep_idx, d_vals, nn);
+          if (rc) return rc;
+        }
+      }
+    }
+  }
+  HIPCHK(ctx, hipMemcpyAsync(chosen, d_chosen, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(vals, d_vals, (size_t)n_items * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_debug_force_generic(pclean_ctx* ctx, int32_t on) {
   if (!ctx) return PCLEAN_ERR_ARG;
   ctx->force_generic = on != 0;
@@ -857,7 +1039,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
                             double* logml) {
   if (!ctx || !cfg || n_blocks <= 0 || n_blocks > PCLEAN_MAX_BLOCKS || !cur || !choice)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: bad arguments");
-  const int N = ctx->n_rows;
+  const int N = ctx->active_count >= 0 ? ctx->active_count : ctx->n_rows;
   int P = cfg->num_particles;
   const int use_mh = cfg->use_mh_instead_of_pg != 0;
   if (use_mh) P = 2;  // infer_config.jl:11-13
@@ -1006,7 +1188,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     // ---- resampling between blocks (row_inference.jl:152-155)
     if (!use_mh && bi < n_blocks - 1) {
       hipLaunchKernelGGL(maybe_resample_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p, 1, cur_b, seed,
-                         sweep_idx, (uint32_t)bi, s->row_offset, s->ancestors.p, s->logml_inc.p, (double*)nullptr,
+                         sweep_idx, (uint32_t)bi, s->row_offset + ctx->active_begin, s->ancestors.p, s->logml_inc.p, (double*)nullptr,
                          s->did.p);
       hipLaunchKernelGGL(add_weight_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, s->logml_inc.p,
                          s->logml_acc.p);
@@ -1025,7 +1207,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
 
   // ---- final choice + outputs
   hipLaunchKernelGGL(final_choice_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p, use_mh, 1, s->cur.p, seed,
-                     sweep_idx, s->row_offset, s->chosen.p, s->log_total.p);
+                     sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->log_total.p);
   hipLaunchKernelGGL(finish_logml_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->log_total.p, s->logml_acc.p,
                      s->logml.p);
   for (int bi = 0; bi < n_blocks; ++bi) {

@@ -86,6 +86,8 @@ class Engine:
             hip.set_options(tid, lw.option_values[(cname, aname)], logp)
         for bi in range(len(lw.blocks)):
             hip.load_block(bi, *lw.block_arrays(bi))
+        for cname, pl in lw.latent_plans.items():
+            hip.load_block(pl["block_id"], *lw.latent_block_arrays(cname))
 
     # -- dynamic data ---------------------------------------------------------
     def upload_trace(self, trace):

@@ -1,0 +1,248 @@
+"""initialize_trace / run_inference! on the HIP path (src/inference/inference.jl:3-88).
+
+Schedule differences from the reference: rows are processed in batches
+against frozen tables and committed per batch / per class sweep; parameters are
+re-sampled once per class sweep instead of every `rejuv_frequency` rows.
+
+  initialize_trace : SMC over the observed rows (inference.jl:20-37) in geometrically
+                     growing batches; within a batch identical new-row proposals are merged.
+  run_inference    : for every class in class_order (latent classes first, observed class
+                     last, inference.jl:62) one rejuvenation sweep: latent classes through
+                     pclean_sweep_latent (external likelihood over referring rows),
+                     the observed class through pclean_sweep.
+"""
+import numpy as np
+
+from .model import ChooseProportionally
+from .parallel import Comm, exchange_and_commit
+from .trace import CHOICE_NEW
+
+
+# ---------------------------------------------------------------------------
+# evidence sets
+def _follow(lw, trace, start_cls, keys, path):
+    """Row ids reached from rows `keys` of start_cls along the reference-slot path."""
+    cname = start_cls
+    for step in [p for p in path.split(".") if p]:
+        t = trace.tables[cname]
+        j = lw.colidx[cname][step]
+        keys = t.cols[j, keys]
+        cname = lw.layout[cname][j].target
+    return keys
+
+
+def build_evidence(lw, trace, cname):
+    """CSR of observed rows referring (transitively) to each live row of latent class cname,
+    plus the per-evidence-row ctx value of the cross-block JuliaNode terms."""
+    pl = lw.latent_plans[cname]
+    bi = pl["src_block"]
+    root_cls = lw.blocks[bi]["root_class"]
+    t = trace.tables[cname]
+    keys = _follow(lw, trace, root_cls, trace.cur[bi], pl["path"])
+    order = np.argsort(keys, kind="stable").astype(np.int32)
+    counts = np.bincount(keys, minlength=t.n)
+    live = np.nonzero(t.live[:t.n])[0].astype(np.int32)
+    off_all = np.zeros(t.n + 1, dtype=np.int64)
+    np.cumsum(counts, out=off_all[1:])
+    # evidence rows grouped by latent row, restricted to live rows (dead rows have none anyway)
+    ev_off = np.zeros(len(live) + 1, dtype=np.int32)
+    np.cumsum(counts[live], out=ev_off[1:])
+    seg = [order[off_all[k]:off_all[k + 1]] for k in live]
+    ev_rows = np.concatenate(seg).astype(np.int32) if seg else np.zeros(0, np.int32)
+    ev_ctx = None
+    for ct in lw.cross_terms:
+        if ct["ctx_block"] == bi:      # this class sits on the ctx-argument side: ctx = the local argument's value
+            ob, path = ct["local_block"], ct["local_path"]
+        elif ct["local_block"] == bi:  # local side: ctx = the other block's value
+            ob, path = ct["ctx_block"], ct["ctx_path"]
+        else:
+            continue
+        rc = lw.blocks[ob]["root_class"]
+        vals = trace.tables[rc].cols[lw.colidx[rc][path], trace.cur[ob]]
+        ev_ctx = np.zeros((len(ev_rows), 2), dtype=np.int32)
+        ev_ctx[:, 0] = vals[ev_rows]
+    return live, ev_off, ev_rows, ev_ctx
+
+
+# ---------------------------------------------------------------------------
+def refresh_flattened(lw, trace):
+    """Re-copy the inlined (flattened) values of every reference slot from its referent —
+    update_referring_rows_with_new_values_for_updated_row! (dependency_tracking.jl:239-257),
+    done for whole tables in class order (targets before sources)."""
+    for cname in lw.model.class_order:
+        if cname not in trace.tables:
+            continue
+        t = trace.tables[cname]
+        if t.n == 0:
+            continue
+        for j, c in enumerate(lw.layout[cname]):
+            if c.kind == "fk" and "." not in c.name:
+                tgt = trace.tables[c.target]
+                ref = t.cols[j, :t.n]
+                for jj, cc in enumerate(lw.layout[cname]):
+                    if cc.name.startswith(c.name + "."):
+                        sub = cc.name[len(c.name) + 1:]
+                        new = tgt.cols[lw.colidx[c.target][sub], ref]
+                        if not np.array_equal(new, t.cols[jj, :t.n]):
+                            t.cols[jj, :t.n] = new
+                            t.cols_dirty = True
+
+
+def _materialise_latent(lw, trace, pl, node, vals):
+    """Create the latent row proposed as NEW at `node` of a latent plan (recursively)."""
+    nodes, info = pl["nodes"], pl["node_info"]
+    cname = info[node]["cls"]
+    layout = lw.layout[cname]
+    cmb = nodes[node][9]
+    values = np.zeros(len(layout), dtype=np.int32)
+    child_rows = {}
+
+    def child_row(cn):
+        if cn not in child_rows:
+            ch = int(vals[cn])
+            if ch == CHOICE_NEW:
+                ch = _materialise_latent(lw, trace, pl, cn, vals)
+            child_rows[cn] = ch
+        return child_rows[cn]
+
+    for j, c in enumerate(layout):
+        cn, cc = pl["colmap"][2 * (cmb + j)], pl["colmap"][2 * (cmb + j) + 1]
+        if cn < 0:
+            continue
+        if nodes[cn][0] == 1:
+            values[j] = lw.option_values[(info[cn]["cls"], info[cn]["attr"])][vals[cn]]
+        else:
+            values[j] = trace.tables[info[cn]["cls"]].cols[cc, child_row(cn)]
+    for j, c in enumerate(layout):
+        if c.kind == "fk" and "." not in c.name:
+            for k in range(nodes[node][4], nodes[node][4] + nodes[node][5]):
+                cid = pl["children"][k]
+                if nodes[cid][0] == 0 and nodes[cid][7] == j:
+                    values[j] = child_row(cid)
+    return trace.insert_row(cname, values)
+
+
+def commit_latent(lw, trace, cname, live, chosen, vals):
+    """Apply a latent-class sweep: rows whose chosen particle is fresh take the sampled values
+    (run_smc! tail, row_inference.jl:169-185, for a latent row)."""
+    pl = lw.latent_plans[cname]
+    t = trace.tables[cname]
+    m = lw.model.classes[cname]
+    changed = 0
+    released = []  # (class, row) referents to release AFTER every new reference has been counted:
+    # another row of this batch may have joined a referent that this row leaves (batched schedule)
+    for idx in np.nonzero(chosen > 0)[0]:
+        h = int(live[idx])
+        trace._own_choice_stats(cname, h, -1)
+        for r, root in enumerate(pl["roots"]):
+            attr = pl["root_attr"][r]
+            j = lw.colidx[cname][attr]
+            v = int(vals[idx, root])
+            if pl["nodes"][root][0] == 1:  # leaf: option index -> latent value
+                new = int(lw.option_values[(cname, attr)][v])
+                if new != t.cols[j, h]:
+                    t.cols[j, h] = new
+                    t.cols_dirty = True
+                    changed += 1
+            else:
+                tgt_cls = lw.layout[cname][j].target
+                tgt = trace.tables[tgt_cls]
+                new = _materialise_latent(lw, trace, pl, root, vals[idx]) if v == CHOICE_NEW else v
+                old = int(t.cols[j, h])
+                if new != old:
+                    tgt = trace.tables[tgt_cls]
+                    tgt.counts[new] += 1
+                    released.append((tgt_cls, old))
+                    t.cols[j, h] = new
+                    t.cols_dirty = True
+                    changed += 1
+        trace._own_choice_stats(cname, h, +1)
+    for tgt_cls, old in released:
+        trace.tables[tgt_cls].counts[old] -= 1
+    for tgt_cls, old in released:
+        tgt = trace.tables[tgt_cls]
+        if tgt.counts[old] == 0 and tgt.live[old]:
+            trace.delete_row(tgt_cls, old)
+    refresh_flattened(lw, trace)
+    return changed
+
+
+def latent_sweep(engine, trace, cname, config, seed, sweep_idx):
+    lw = engine.lw
+    pl = lw.latent_plans[cname]
+    live, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname)
+    if len(live) == 0:
+        return 0
+    t = trace.tables[cname]
+    excl = np.full((len(pl["roots"]), len(live)), -1, dtype=np.int32)
+    for r, root in enumerate(pl["roots"]):
+        if pl["nodes"][root][0] == 0:
+            excl[r] = t.cols[lw.colidx[cname][pl["root_attr"][r]], live]
+    engine.upload_trace(trace)
+    engine.hip.set_active_rows(0, -1)
+    chosen, vals = engine.hip.sweep_latent(config.as_c(), seed, sweep_idx, pl["block_id"], pl["roots"], live, ev_off,
+                                           ev_rows, ev_ctx, excl, len(pl["nodes"]))
+    return commit_latent(lw, trace, cname, live, chosen, vals)
+
+
+# ---------------------------------------------------------------------------
+def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None, row_lo=0):
+    comm = comm or Comm()
+    engine.upload_trace(trace)
+    engine.hip.set_active_rows(0, -1)
+    choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx)
+    stats = engine.sweep_stats(trace)
+    return exchange_and_commit(trace, engine.lw, comm, row_lo, choice, stats, new_rows)
+
+
+def resample_parameters(trace):
+    """resample_value! for every learned parameter + Pitman–Yor hyper-parameters
+    (inference.jl:72-77; distributions.jl:57-61; trace.jl:80-108)."""
+    trace.resample_parameters()
+    for t in trace.tables.values():
+        trace.resample_py_params(t)
+
+
+def initialize_trace(engine, trace, config, seed, max_batch=256):
+    """SMC initialisation of the observed rows (inference.jl:3-58), batched: batch b sees the
+    latent rows created by batches < b; identical new-row proposals inside a batch are merged."""
+    lw = engine.lw
+    n = trace.cur.shape[1]
+    trace.cur[:] = -1
+    begin, size = 0, 1
+    while begin < n:
+        count = min(size, n - begin)
+        engine.upload_trace(trace)
+        engine.hip.set_active_rows(begin, count)
+        cur = np.ascontiguousarray(trace.cur[:, begin:begin + count])
+        choice, chosen, logml = engine.hip.sweep(config.as_c(), seed, 0x7fffffff, cur)
+        new_rows = {}
+        for bi, blk in enumerate(lw.blocks):
+            rows, vals = engine.hip.get_new_rows(bi, len(blk["nodes"]))
+            if len(rows):
+                new_rows[bi] = (rows, vals)
+        trace.commit_batch(begin, count, choice, new_rows, dedup=True)
+        begin += count
+        size = min(max_batch, size * 2)
+        if begin % max(config.rejuv_frequency, 1) < count:
+            resample_parameters(trace)
+    engine.hip.set_active_rows(0, -1)
+    return trace
+
+
+def run_inference(engine, trace, config, seed, verbose=False):
+    """run_inference! (inference.jl:83-88): config.num_iters sweeps over all classes."""
+    lw = engine.lw
+    for it in range(config.num_iters):
+        for cname in lw.model.class_order:
+            if cname in lw.latent_plans:
+                ch = latent_sweep(engine, trace, cname, config, seed, it)
+            elif cname == lw.query.cls:
+                ch = observed_sweep(engine, trace, config, seed, it)
+            else:
+                continue
+            resample_parameters(trace)
+            if verbose:
+                print(f"iteration {it + 1}/{config.num_iters} {cname}: {ch} changes", flush=True)
+                trace.check_consistency()
+    return trace

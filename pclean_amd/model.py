@@ -188,9 +188,12 @@ class LoweredModel:
         self.obs_index = {}
         self._next_table = 0
         self._next_pair = 0
+        self.cross_terms = []
+        self.latent_plans = {}
         self._build_domains(dirty_columns)
         self._build_layouts()
         self._build_blocks()
+        self._build_latent_plans()
 
     # -- domains ------------------------------------------------------------
     def _build_domains(self, dirty_columns):
@@ -333,6 +336,11 @@ class LoweredModel:
                         pid = self._pair_for(a.name, ("julia", j.name), jdom)
                         terms.append(dict(obs=a.name, path=local[0].split(".", 1)[1], pair=pid,
                                           max_typos=a.dist.max_typos, ctx=(slot, fid)))
+                        # the same observation also constrains the OTHER argument's class (external
+                        # likelihood of e.g. County.state through Record.stateavg_obs)
+                        self.cross_terms.append(dict(obs=a.name, pair=pid, max_typos=a.dist.max_typos, fn=fid,
+                                                     ctx_block=sb, ctx_path=orest, local_block=bi,
+                                                     local_path=local[0].split(".", 1)[1]))
                     else:
                         raise NotImplementedError("single-argument julia nodes are not lowered yet")
             self._emit_fk_node(blk, root_fk.target, "", terms, parent=-1, parent_fk_col=-1)
@@ -349,7 +357,7 @@ class LoweredModel:
         m = self.model
         nid = len(blk["nodes"])
         blk["nodes"].append(None)
-        blk["node_info"].append(dict(kind="fk", cls=cname, attr=None))
+        blk["node_info"].append(dict(kind="fk", cls=cname, attr=None, path=prefix[:-1]))
         tb = len(blk["terms"])
         for t in terms:
             self._emit_term(blk, t, self.colidx[cname][t["path"]])
@@ -375,7 +383,7 @@ class LoweredModel:
                 cacheable = int(len(sub) == 1 and sub[0]["ctx"] is None)
                 blk["nodes"].append((_lib.NODE_LEAF, self.option_id[(cname, a.name)], ltb, len(sub), 0, 0, nid, -1,
                                      cacheable, 0, 0, 0))
-                blk["node_info"].append(dict(kind="leaf", cls=cname, attr=a.name))
+                blk["node_info"].append(dict(kind="leaf", cls=cname, attr=a.name, path=prefix + a.name))
                 kids.append(cid)
                 colsrc[a.name] = (cid, 0)
         cb = len(blk["children"])
@@ -386,6 +394,82 @@ class LoweredModel:
         blk["nodes"][nid] = (_lib.NODE_FK, self.table_id[cname], tb, nt, cb, len(kids), parent, parent_fk_col, 0, cmb,
                              0, 0)
         return nid
+
+    # -- latent-class plans ------------------------------------------------------
+    def _build_latent_plans(self):
+        """For every latent class T: the sub-plans of its own attributes, scored against all
+        observed rows that (transitively) refer to a row of T — the ExternalLikelihoodNodes that
+        builder.jl:264-340 adds to T, restated as the children of T's node in the observed plan
+        with evidence sets instead of a single row."""
+        next_block = len(self.blocks)
+        for bi, blk in enumerate(self.blocks):
+            for nid, info in enumerate(blk["node_info"]):
+                if info["kind"] != "fk" or info["cls"] in self.latent_plans:
+                    continue
+                cname = info["cls"]
+                plan = dict(block_id=next_block, src_block=bi, src_node=nid, cls=cname, path=info["path"], nodes=[],
+                            terms=[], children=[], colmap=[], node_info=[], roots=[], root_attr=[])
+                node = blk["nodes"][nid]
+                for k in range(node[4], node[4] + node[5]):
+                    child = blk["children"][k]
+                    plan["roots"].append(self._copy_subtree(blk, child, plan, -1, bi))
+                    ci = blk["node_info"][child]
+                    # attribute of T this root re-proposes
+                    plan["root_attr"].append(ci["attr"] if ci["kind"] == "leaf" else ci["path"].split(".")[-1])
+                self.latent_plans[cname] = plan
+                next_block += 1
+
+    def _copy_subtree(self, blk, nid, plan, parent, bi):
+        node, info = blk["nodes"][nid], blk["node_info"][nid]
+        new_id = len(plan["nodes"])
+        plan["nodes"].append(None)
+        plan["node_info"].append(dict(info))
+        tb = len(plan["terms"])
+        for t in blk["terms"][node[2]:node[2] + node[3]]:
+            t = list(t)
+            if t[5] >= 0:
+                t[7] = 1  # ctx now comes from the evidence row (fn[ctx][candidate])
+            plan["terms"].append(tuple(t))
+        # cross-block julia observations whose other argument lives in this sub-tree
+        for ct in self.cross_terms:
+            if ct["ctx_block"] != bi:
+                continue
+            q, p = ct["ctx_path"], info["path"]
+            if info["kind"] == "leaf" and p == q:
+                col = 0
+            elif info["kind"] == "fk" and q.startswith(p + "."):
+                col = self.colidx[info["cls"]][q[len(p) + 1:]]
+            else:
+                continue
+            plan["terms"].append((self.obs_index[ct["obs"]], col, ct["pair"], _lib.DENS_ADD_TYPOS,
+                                  -1 if ct["max_typos"] is None else int(ct["max_typos"]), 0, ct["fn"], 2))
+        nt = len(plan["terms"]) - tb
+        kids = []
+        if node[0] == _lib.NODE_FK:
+            remap = {}
+            for k in range(node[4], node[4] + node[5]):
+                c = blk["children"][k]
+                remap[c] = self._copy_subtree(blk, c, plan, new_id, bi)
+                kids.append(remap[c])
+            cb = len(plan["children"])
+            plan["children"].extend(kids)
+            cmb = len(plan["colmap"]) // 2
+            ncols = len(self.layout[info["cls"]])
+            for j in range(ncols):
+                cn, cc = blk["colmap"][2 * (node[9] + j)], blk["colmap"][2 * (node[9] + j) + 1]
+                plan["colmap"].extend((remap[cn] if cn >= 0 else -1, cc))
+            plan["nodes"][new_id] = (node[0], node[1], tb, nt, cb, len(kids), parent, node[7], 0, cmb, 0, 0)
+        else:
+            plan["nodes"][new_id] = (node[0], node[1], tb, nt, 0, 0, parent, -1, 0, 0, 0, 0)
+        return new_id
+
+    def latent_block_arrays(self, cname):
+        pl = self.latent_plans[cname]
+        nodes = np.array(pl["nodes"], dtype=_lib.NODE_DTYPE)
+        terms = np.array(pl["terms"], dtype=_lib.TERM_DTYPE) if pl["terms"] else np.zeros(0, dtype=_lib.TERM_DTYPE)
+        # every latent-mode ctx term reads slot 0 of the evidence row's ctx
+        return (nodes, terms, np.array(pl["children"], dtype=np.int32), np.array(pl["colmap"], dtype=np.int32),
+                np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32))
 
     # -- arrays for the C ABI -------------------------------------------------
     def block_arrays(self, bi):

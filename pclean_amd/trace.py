@@ -178,10 +178,106 @@ class Trace:
             # rows created but immediately unreferenced cannot happen: each new row has its creator
         return changed
 
+    def check_consistency(self):
+        """Reference counts == number of referring slots; flattened copies == referent's values;
+        conjugate counts == live rows' choices.  Raises AssertionError with a description."""
+        lw = self.lw
+        want = {c: np.zeros(t.n, dtype=np.int64) for c, t in self.tables.items()}
+        for bi, blk in enumerate(lw.blocks):
+            cur = self.cur[bi]
+            cur = cur[cur >= 0]
+            want[blk["root_class"]] += np.bincount(cur, minlength=self.tables[blk["root_class"]].n)
+        for cname, t in self.tables.items():
+            live = np.nonzero(t.live[:t.n])[0]
+            for j, c in enumerate(lw.layout[cname]):
+                if c.kind == "fk" and "." not in c.name:
+                    tgt = self.tables[c.target]
+                    ref = t.cols[j, live]
+                    assert np.all(tgt.live[ref]), f"{cname}.{c.name} refers to a deleted {c.target} row"
+                    want[c.target] += np.bincount(ref, minlength=tgt.n)
+                    for jj, cc in enumerate(lw.layout[cname]):
+                        if cc.name.startswith(c.name + "."):
+                            sub = cc.name[len(c.name) + 1:]
+                            assert np.array_equal(t.cols[jj, live], tgt.cols[lw.colidx[c.target][sub], ref]), \
+                                f"{cname}.{cc.name} is not the flattened copy of its referent"
+        for cname, t in self.tables.items():
+            assert np.array_equal(want[cname], np.where(t.live[:t.n], t.counts[:t.n], want[cname])), \
+                f"{cname}: reference counts differ from the referring slots"
+            assert np.all((t.counts[:t.n] > 0) == t.live[:t.n]), f"{cname}: live flags differ from counts"
+        for (cname, pname), p in self.params.items():
+            t = self.tables[cname]
+            live = np.nonzero(t.live[:t.n])[0]
+            for a in lw.model.classes[cname].attrs:
+                if a.kind == "choice" and isinstance(a.dist, ChooseProportionally) and a.dist.param == pname:
+                    got = np.bincount(t.cols[lw.colidx[cname][a.name], live], minlength=len(p.counts))
+                    assert np.array_equal(got, p.counts), f"{cname}.{pname}: Dirichlet counts out of sync"
+
+    def commit_batch(self, begin, count, choice, new_rows, dedup=False):
+        """Commit a batch of observed rows [begin, begin+count) (initialize_trace: rows had no
+        referent before).  With dedup, identical new-row proposals of the batch become one row —
+        the sequential reference would have let the second row join the first row's new referent."""
+        for bi, blk in enumerate(self.lw.blocks):
+            cname = blk["root_class"]
+            ch = np.array(choice[bi], dtype=np.int64)
+            rows_new, vals_new = new_rows.get(bi, (np.zeros(0, np.int32), None))
+            memo = {}
+            for j, i in enumerate(rows_new):
+                key = vals_new[j].tobytes() if dedup else None
+                r = memo.get(key) if dedup else None
+                if r is None:
+                    r = self._materialise(bi, 0, vals_new[j])
+                    if dedup:
+                        memo[key] = r
+                ch[i] = r
+            t = self.tables[cname]
+            old = self.cur[bi, begin:begin + count]
+            np.add.at(t.counts, ch, 1)
+            np.subtract.at(t.counts, old[old >= 0], 1)
+            self.cur[bi, begin:begin + count] = ch
+            for k in np.unique(old[old >= 0]):
+                if t.counts[k] == 0 and t.live[k]:
+                    self.delete_row(cname, int(k))
+
     # -- parameter moves (inference.jl:72-77 -> resample_value!) ----------------
     def resample_parameters(self):
         for p in self.params.values():
             p.resample(self.rng)
+
+    @staticmethod
+    def pitman_yor_score(strength, discount, counts):
+        """trace.jl:65-78, vectorised: counts in table order (cluster j is the j-th object)."""
+        counts = np.asarray(counts, dtype=np.float64)
+        if counts.size == 0:
+            return 0.0
+        from math import lgamma
+        n_obj = np.arange(1, counts.size + 1, dtype=np.float64)
+        before = np.concatenate([[0.0], np.cumsum(counts)[:-1]])
+        lp = np.sum(np.log(n_obj * discount + strength) - np.log(before + strength))
+        # joins of each cluster: sum_{i=1}^{size-1} log(i - d) - log(before + i + s)
+        for c, b in zip(counts, before):
+            c = int(c)
+            if c > 1:
+                lp += lgamma(c - discount) - lgamma(1 - discount)
+                lp -= lgamma(b + c + strength) - lgamma(b + 1 + strength)
+        return float(lp)
+
+    def resample_py_params(self, t):
+        """resample_py_params! (trace.jl:80-108): independence MH on strength ~ Gamma(1,1) and
+        discount ~ U(0,1)."""
+        counts = t.counts[:t.n][t.counts[:t.n] > 0]
+        if counts.size == 0:
+            return
+        old = self.pitman_yor_score(t.strength, t.discount, counts)
+        s_new = self.rng.gamma(1.0, 1.0)
+        new = self.pitman_yor_score(s_new, t.discount, counts)
+        # logpdf(Gamma(1,1), x) = -x
+        alpha = new + (-t.strength) - old - (-s_new)
+        if np.log(self.rng.random()) < alpha:
+            t.strength, old = s_new, new
+        d_new = self.rng.random()
+        new = self.pitman_yor_score(t.strength, d_new, counts)
+        if np.log(self.rng.random()) < new - old:
+            t.discount = d_new
 
     # -- initial state from known clean values (tests / synthetic bench) --------
     @classmethod
