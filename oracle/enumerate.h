@@ -65,7 +65,7 @@ struct World {
   std::vector<OTable> table;
   std::vector<OFn> fn;
   std::vector<OBlock> block;
-  World() : pair(64), table(64), fn(64), block(8) {}
+  World() : pair(64), table(64), fn(64), block(16) {}
 };
 
 static const double HALF_LOG26 = 1.629048269010741; /* log(26)/2, add_typos.jl:63 */
@@ -81,10 +81,18 @@ inline double term_density(const World& w, const pclean_term& tm, const OPair& p
   return l;
 }
 
+/* Evidence set of a latent-class work item: the observed rows that refer to the latent row
+ * (ExternalLikelihoodNodes, proposal_compiler.jl:306-350; block_proposal.jl:119-155). */
+struct Evidence {
+  const int32_t* rows = nullptr; /* observed rows */
+  const int32_t* ctx = nullptr;  /* [n][PCLEAN_MAX_CTX] per-evidence-row ctx, may be null */
+  int n = 0;
+};
+
 /* Scores of all candidates (+ new-row candidate for FK nodes, last) of one
  * node for one work item.  out.size() == n_rows + (FK ? 1 : 0). */
 inline void node_scores(const World& w, int block_id, int node_id, int row, const int32_t* ctxv, int excl,
-                        double snew_in, std::vector<double>& out) {
+                        double snew_in, std::vector<double>& out, const Evidence* ev = nullptr) {
   const OBlock& b = w.block[block_id];
   const pclean_node& nd = b.nodes[node_id];
   const OTable& t = w.table[nd.table];
@@ -105,6 +113,28 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
     out[n] = ((deleted ? t.scal[3] : t.scal[2]) - logden) + snew_in;
   } else {
     for (int k = 0; k < n; ++k) out[k] = t.logc_full[k];
+  }
+  if (ev) { /* per candidate: evidence rows in list order, terms in plan order per row */
+    for (int k = 0; k < n; ++k) {
+      if (fk && t.counts[k] == 0) continue;
+      for (int e = 0; e < ev->n; ++e) {
+        const int er = ev->rows[e];
+        for (int ti = 0; ti < nd.n_terms; ++ti) {
+          const pclean_term& tm = b.terms[nd.term_begin + ti];
+          const int o = w.obs[(size_t)tm.obs_col * w.n_rows + er];
+          if (o < 0) continue;
+          const OPair& pt = w.pair[tm.pair_table];
+          int val = t.cols[(size_t)tm.cand_col * n + k];
+          if (tm.ctx_slot >= 0) {
+            const OFn& f = w.fn[tm.fn_table];
+            const int c = tm.ctx_mode == 0 ? ctxv[tm.ctx_slot] : ev->ctx[(size_t)e * PCLEAN_MAX_CTX + tm.ctx_slot];
+            val = tm.ctx_mode == 2 ? f.fn[(size_t)val * f.n_b + c] : f.fn[(size_t)c * f.n_b + val];
+          }
+          out[k] += term_density(w, tm, pt, pt.d[(size_t)o * pt.n_lat + val], val);
+        }
+      }
+    }
+    return;
   }
   for (int ti = 0; ti < nd.n_terms; ++ti) {
     const pclean_term& tm = b.terms[nd.term_begin + ti];

@@ -207,6 +207,21 @@ class World:
                                     len(colmap), _p(colmap, C.c_int32), len(csb), _p(csb, C.c_int32),
                                     _p(csc, C.c_int32))
 
+    def sweep_latent(self, cfg, seed, sweep, block_id, roots, keys, ev_off, ev_rows, ev_ctx, excl, n_nodes):
+        roots = np.ascontiguousarray(roots, np.int32)
+        keys = np.ascontiguousarray(keys, np.int32)
+        ev_off = np.ascontiguousarray(ev_off, np.int32)
+        ev_rows = np.ascontiguousarray(ev_rows, np.int32)
+        ev_ctx = None if ev_ctx is None else np.ascontiguousarray(ev_ctx, np.int32)
+        excl = np.ascontiguousarray(excl, np.int32)
+        chosen = np.zeros(len(keys), dtype=np.int32)
+        vals = np.full((len(keys), n_nodes), -2, dtype=np.int32)
+        self.L.pco_sweep_latent(self.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep), block_id, len(roots),
+                                _p(roots, C.c_int32), len(keys), _p(keys, C.c_int32), _p(ev_off, C.c_int32),
+                                _p(ev_rows, C.c_int32), _p(ev_ctx, C.c_int32), _p(excl, C.c_int32),
+                                _p(chosen, C.c_int32), _p(vals, C.c_int32))
+        return chosen, vals
+
     def score_node(self, block_id, node_id, rows, ctxv=None, excl=None, snew=None, seed=0, sweep=0, n_draws=0,
                    n_cand=None, want_scores=False):
         rows = np.ascontiguousarray(rows, np.int32)

@@ -221,6 +221,14 @@ int pco_sweep_sequential(pco::World* w, const pclean_infer_config* cfg, uint64_t
   pco::sweep_sequential(*w, *cfg, seed, sweep, n_blocks, row_offset, cur, py, n_moved, n_new);
   return 0;
 }
+int pco_sweep_latent(const pco::World* w, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep, int block_id,
+                     int n_roots, const int32_t* roots, int n_items, const int32_t* keys, const int32_t* ev_off,
+                     const int32_t* ev_rows, const int32_t* ev_ctx, const int32_t* excl, int32_t* chosen,
+                     int32_t* vals) {
+  pco::sweep_latent(*w, *cfg, seed, sweep, block_id, n_roots, roots, n_items, keys, ev_off, ev_rows, ev_ctx, excl,
+                    chosen, vals);
+  return 0;
+}
 int pco_new_rows_count(int block) {
   int n = 0;
   for (auto& r : g_new_rows) n += r.block == block;

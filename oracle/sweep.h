@@ -37,6 +37,8 @@ struct RowCtx {
   uint64_t seed;
   uint32_t sweep;
   int64_t row_offset;
+  const Evidence* ev = nullptr; /* latent-class items */
+  int64_t rng_row = -1;         /* RNG row id override (latent row key) */
 };
 
 inline int child_excl_of(const World& w, const OBlock& b, int parent_node, int child_node, int parent_excl) {
@@ -68,7 +70,7 @@ inline double eval_tree(const RowCtx& rc, int node, int excl, std::vector<double
   double snew = NEG_INF;
   if (nd.kind == PCLEAN_NODE_FK) snew = snew_of(rc, node, excl);
   std::vector<double> s;
-  node_scores(*rc.w, rc.block, node, rc.row, rc.ctxv, excl, snew, s);
+  node_scores(*rc.w, rc.block, node, rc.row, rc.ctxv, excl, snew, s, rc.ev);
   FixSum f = fix_sum(s);
   if (scores_out) scores_out->swap(s);
   return pclean_lse_from_fix(f.m, f.U);
@@ -78,7 +80,7 @@ inline double eval_tree(const RowCtx& rc, int node, int excl, std::vector<double
 inline void sample_new(const RowCtx& rc, int node, int excl, uint32_t particle, int32_t* vals) {
   const OBlock& b = rc.w->block[rc.block];
   const pclean_node& nd = b.nodes[node];
-  const uint32_t rr = (uint32_t)((int64_t)rc.row + rc.row_offset);
+  const uint32_t rr = rc.rng_row >= 0 ? (uint32_t)rc.rng_row : (uint32_t)((int64_t)rc.row + rc.row_offset);
   for (int c = 0; c < nd.n_children; ++c) {
     const int cid = b.children[nd.child_begin + c];
     const pclean_node& cn = b.nodes[cid];
@@ -268,6 +270,56 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
   for (int bi = 0; bi < n_blocks; ++bi) {
     choice[bi] = pch[bi][c];
     if (pch[bi][c] == PCLEAN_CHOICE_NEW) new_rows.push_back(NewRow{bi, row, pvals[bi][c]});
+  }
+}
+
+/* Rejuvenation of the rows of a latent class (pgibbs_sweep! over a latent class): every
+ * independent sub-plan of the class's attributes is enumerated against the referring rows; all
+ * particles get the same weight, so the chosen particle is uniform (PG) / accepted with
+ * min(1, w1/(1e-10+w0)), w0 == w1 (MH).  Only the chosen particle's draws are materialised. */
+inline void sweep_latent(const World& w, const pclean_infer_config& cfg, uint64_t seed, uint32_t sweep, int block_id,
+                         int n_roots, const int32_t* roots, int n_items, const int32_t* keys, const int32_t* ev_off,
+                         const int32_t* ev_rows, const int32_t* ev_ctx, const int32_t* excl, int32_t* chosen,
+                         int32_t* vals) {
+  const OBlock& b = w.block[block_id];
+  const int nn = (int)b.nodes.size();
+  const bool use_mh = cfg.use_mh_instead_of_pg != 0;
+  const int P = use_mh ? 2 : cfg.num_particles;
+  for (int t = 0; t < n_items; ++t) {
+    const uint32_t rr = (uint32_t)keys[t];
+    const uint32_t pid = 0x1000u + (uint32_t)block_id;
+    int c;
+    if (use_mh && P >= 2) {
+      const double ratio = 0.5 / (1e-10 + 0.5);
+      c = pclean_u01(pclean_rand64(seed, rr, PCLEAN_SITE_MH, pid, sweep)) < ratio ? 1 : 0;
+    } else {
+      const uint64_t U = (uint64_t)P << PCLEAN_FIX_BITS;
+      c = (int)(pclean_mulhi64(pclean_rand64(seed, rr, PCLEAN_SITE_FINAL, pid, sweep), U) >> PCLEAN_FIX_BITS);
+    }
+    chosen[t] = c;
+    for (int k = 0; k < nn; ++k) vals[(size_t)t * nn + k] = -2;
+    if (c == 0) continue;
+    Evidence ev;
+    ev.rows = ev_rows + ev_off[t];
+    ev.ctx = ev_ctx ? ev_ctx + (size_t)ev_off[t] * PCLEAN_MAX_CTX : nullptr;
+    ev.n = ev_off[t + 1] - ev_off[t];
+    RowCtx rc{&w, block_id, 0, nullptr, seed, sweep, 0, &ev, (int64_t)keys[t]};
+    for (int r = 0; r < n_roots; ++r) {
+      const int root = roots[r];
+      const pclean_node& rn = b.nodes[root];
+      const int rex = rn.kind == PCLEAN_NODE_FK ? excl[(size_t)r * n_items + t] : -1;
+      std::vector<double> s;
+      eval_tree(rc, root, rex, &s);
+      FixSum f = fix_sum(s);
+      const int k = fix_draw(s, f, pclean_rand64(seed, rr, PCLEAN_SITE_NODE(block_id, root), (uint32_t)c, sweep));
+      const int n = w.table[rn.table].n_rows;
+      if (rn.kind == PCLEAN_NODE_FK && k == n) {
+        vals[(size_t)t * nn + root] = PCLEAN_CHOICE_NEW;
+        sample_new(rc, root, rex, (uint32_t)c, vals + (size_t)t * nn);
+      } else {
+        vals[(size_t)t * nn + root] = k;
+      }
+    }
   }
 }
 

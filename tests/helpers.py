@@ -84,6 +84,8 @@ def mirror_world(oracle, lw, obs, trace, engine=None, dist_mode=1, option_logp=N
         w.set_options(lw.option_id[(cname, aname)], lw.option_values[(cname, aname)], logps[(cname, aname)])
     for bi in range(len(lw.blocks)):
         w.load_block(bi, *lw.block_arrays(bi))
+    for cname, pl in lw.latent_plans.items():
+        w.load_block(pl["block_id"], *lw.latent_block_arrays(cname))
     return w
 
 

@@ -1,0 +1,84 @@
+"""GPU tests of the §8f rows: latent-class rejuvenation (external likelihood over referring
+rows) bit-exact against the oracle, and the end-to-end hospital program
+(initialize_trace + run_inference! + evaluate_accuracy, experiments/hospital/run.jl)."""
+import numpy as np
+import pytest
+
+import helpers
+from pclean_amd._lib import InferConfig
+from pclean_amd.analysis import evaluate_accuracy
+from pclean_amd.engine import Engine, InferenceConfig
+from pclean_amd.inference import (build_evidence, commit_latent, initialize_trace, latent_sweep, run_inference)
+from pclean_amd.trace import Trace
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("particles,mh", [(2, True), (8, False)])
+def test_latent_sweep_parity(oracle, particles, mh):
+    """Every latent class of the hospital program, on a state with duplicated entities (so that
+    reference slots really move and new referents get proposed), then committed and re-checked."""
+    S = helpers.hospital_setup(n_rows=600)
+    lw, obs = S["lw"], S["obs"]
+    eng = Engine(lw, obs, dist_mode=1)
+    try:
+        cfg = InferenceConfig(1, particles, use_mh_instead_of_pg=mh)
+        tr = Trace(lw, obs.shape[1], 4)
+        initialize_trace(eng, tr, cfg, 4)  # batched init leaves duplicates to merge
+        tr.check_consistency()
+        moved = 0
+        for sweep in range(2):
+            for cname in lw.model.class_order:
+                if cname not in lw.latent_plans:
+                    continue
+                pl = lw.latent_plans[cname]
+                live, ev_off, ev_rows, ev_ctx = build_evidence(lw, tr, cname)
+                t = tr.tables[cname]
+                excl = np.full((len(pl["roots"]), len(live)), -1, dtype=np.int32)
+                for r, root in enumerate(pl["roots"]):
+                    if pl["nodes"][root][0] == 0:
+                        excl[r] = t.cols[lw.colidx[cname][pl["root_attr"][r]], live]
+                eng.upload_trace(tr)
+                eng.hip.set_active_rows(0, -1)
+                world = helpers.mirror_world(oracle, lw, obs, tr, eng)
+                got = eng.hip.sweep_latent(cfg.as_c(), 9, sweep, pl["block_id"], pl["roots"], live, ev_off, ev_rows,
+                                           ev_ctx, excl, len(pl["nodes"]))
+                c = InferConfig(1, particles, 1, 1, int(mh), 50, 100)
+                want = world.sweep_latent(c, 9, sweep, pl["block_id"], pl["roots"], live, ev_off, ev_rows, ev_ctx, excl,
+                                          len(pl["nodes"]))
+                assert np.array_equal(got[0], want[0]), (cname, "chosen particle")
+                assert np.array_equal(got[1], want[1]), (cname, "sampled values")
+                assert ev_off[-1] == obs.shape[1]  # every observed row is evidence of exactly one row of the class
+                moved += commit_latent(lw, tr, cname, live, got[0], got[1])
+                tr.check_consistency()
+        assert moved > 0
+    finally:
+        eng.close()
+
+
+def test_hospital_end_to_end(oracle):
+    """configs[0] of BASELINE.json (hospital_dirty.csv, InferenceConfig(1,2; MH)) + two more sweeps."""
+    S = helpers.hospital_setup()
+    lw, obs = S["lw"], S["obs"]
+    eng = Engine(lw, obs, dist_mode=1)
+    try:
+        cfg = InferenceConfig(3, 2, use_mh_instead_of_pg=True)
+        tr = Trace(lw, obs.shape[1], 0)
+        initialize_trace(eng, tr, cfg, 0)
+        tr.check_consistency()
+        f0 = evaluate_accuracy(lw, tr, S["dirty"], S["clean"])
+        run_inference(eng, tr, cfg, 0)
+        tr.check_consistency()
+        acc = evaluate_accuracy(lw, tr, S["dirty"], S["clean"])
+        assert acc["errors"] == 509
+        assert acc["f1"] > f0["f1"]            # rejuvenation repairs what the one-pass initialisation left
+        assert acc["precision"] > 0.95 and acc["f1"] > 0.8
+        # clusters consolidate towards the 45 true hospitals
+        assert tr.tables["Hospital"].n_live < 150
+        # deterministic given the seeds
+        tr2 = Trace(lw, obs.shape[1], 0)
+        initialize_trace(eng, tr2, cfg, 0)
+        run_inference(eng, tr2, cfg, 0)
+        assert np.array_equal(tr.cur, tr2.cur)
+    finally:
+        eng.close()
