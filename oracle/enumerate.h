@@ -52,9 +52,14 @@ struct OBlock {
   int n_ctx = 0;
   int ctx_src_block[PCLEAN_MAX_CTX] = {-1, -1};
   int ctx_src_col[PCLEAN_MAX_CTX] = {-1, -1};
+  std::vector<pclean_gauss> gauss; /* Gaussian terms (experiments/rents/run.jl:19-25) */
+  std::vector<int> node_gauss;     /* per node: index into gauss or -1 */
 };
 
 struct World {
+  int n_xcols = 0;
+  std::vector<double> xnum;              /* numeric observed columns [n_xcols][n_rows] */
+  std::vector<std::vector<double>> mean; /* MeanParameter value tables */
   int n_rows = 0, n_cols = 0;
   std::vector<int32_t> obs; /* [n_cols][n_rows] */
   /* AddTypos density pieces: handed over from the product (pclean_get_density_tables)
@@ -65,7 +70,7 @@ struct World {
   std::vector<OTable> table;
   std::vector<OFn> fn;
   std::vector<OBlock> block;
-  World() : pair(64), table(64), fn(64), block(16) {}
+  World() : mean(64), pair(64), table(64), fn(64), block(16) {}
 };
 
 static const double HALF_LOG26 = 1.629048269010741; /* log(26)/2, add_typos.jl:63 */
@@ -79,6 +84,68 @@ inline double term_density(const World& w, const pclean_term& tm, const OPair& p
   l -= w.logl[L] * (double)d;  /* add_typos.jl:62 */
   l -= HALF_LOG26 * (double)d; /* add_typos.jl:63 */
   return l;
+}
+
+/* ---- Gaussian term with enumerated locals (pclean_gauss): transformed_gaussian.jl:15-16,
+ * add_noise.jl:7, choose_uniformly.jl:7-10; the locals are the inner enumeration loops of
+ * proposal_compiler.jl:96-113 nested inside a candidate branch. ------------------------------ */
+struct GaussCombos {
+  int n = 0;
+  double sc[16];
+  int codes[16];
+};
+template <typename ValFn>
+inline GaussCombos gauss_combo_scores(const World& w, const pclean_gauss& g, int row, const int32_t* evctx, ValFn val) {
+  GaussCombos out;
+  const double xv = w.xnum[(size_t)g.x_col * w.n_rows + row];
+  const std::vector<double>& mu = w.mean[g.mean_table];
+  const double log_sigma = std::log(g.sigma);
+  int base = 0, lstride[2] = {0, 0};
+  for (int d = 0; d < g.n_dims; ++d) {
+    if (g.src_kind[d] == PCLEAN_GSRC_LOCAL)
+      lstride[g.src[d]] = g.stride[d];
+    else
+      base += g.stride[d] * val(d);
+  }
+  int lo[2] = {0, 0}, hi[2] = {1, 1};
+  double lp[2] = {0.0, 0.0};
+  for (int l = 0; l < g.n_locals; ++l) {
+    hi[l] = g.local_n[l];
+    lp[l] = -std::log((double)g.local_n[l]);
+    if (g.local_obs_col[l] >= 0) {
+      const int v = w.obs[(size_t)g.local_obs_col[l] * w.n_rows + row];
+      if (v >= 0) {
+        lo[l] = v;
+        hi[l] = v + 1;
+      }
+    }
+  }
+  for (int l0 = lo[0]; l0 < hi[0]; ++l0)
+    for (int l1 = lo[1]; l1 < hi[1]; ++l1) {
+      const int idx = base + lstride[0] * l0 + lstride[1] * l1;
+      int u = 0;
+      if (g.transform_src_kind == PCLEAN_GSRC_LOCAL)
+        u = g.transform_src == 0 ? l0 : l1;
+      else if (g.transform_src_kind == PCLEAN_GSRC_EVCTX)
+        u = evctx[g.transform_src];
+      double s = lp[0] + lp[1];
+      const double z = (xv * g.t_scale[u] - mu[idx]) / g.sigma;
+      s += -0.5 * z * z - log_sigma - 0.91893853320467274178;
+      s -= g.t_logabsderiv[u];
+      out.sc[out.n] = s;
+      out.codes[out.n] = l0 * 16 + l1;
+      ++out.n;
+    }
+  return out;
+}
+inline double gauss_lse(const GaussCombos& c) {
+  if (c.n == 1) return c.sc[0];
+  double m = NEG_INF;
+  for (int i = 0; i < c.n; ++i) m = c.sc[i] > m ? c.sc[i] : m;
+  if (m == NEG_INF) return m;
+  uint64_t U = 0;
+  for (int i = 0; i < c.n; ++i) U += pclean_fixw(c.sc[i] - m);
+  return pclean_lse_from_fix(m, U);
 }
 
 /* Evidence set of a latent-class work item: the observed rows that refer to the latent row
@@ -114,6 +181,8 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
   } else {
     for (int k = 0; k < n; ++k) out[k] = t.logc_full[k];
   }
+  const pclean_gauss* gs = (node_id < (int)b.node_gauss.size() && b.node_gauss[node_id] >= 0)
+                               ? &b.gauss[b.node_gauss[node_id]] : nullptr;
   if (ev) { /* per candidate: evidence rows in list order, terms in plan order per row */
     for (int k = 0; k < n; ++k) {
       if (fk && t.counts[k] == 0) continue;
@@ -131,6 +200,17 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
             val = tm.ctx_mode == 2 ? f.fn[(size_t)val * f.n_b + c] : f.fn[(size_t)c * f.n_b + val];
           }
           out[k] += term_density(w, tm, pt, pt.d[(size_t)o * pt.n_lat + val], val);
+        }
+        if (gs && out[k] > NEG_INF && w.xnum[(size_t)gs->x_col * w.n_rows + er] == w.xnum[(size_t)gs->x_col * w.n_rows + er]) {
+          const int32_t* ec = ev->ctx ? ev->ctx + (size_t)e * PCLEAN_MAX_CTX : nullptr;
+          out[k] += gauss_lse(gauss_combo_scores(w, *gs, er, ec, [&](int d) -> int {
+            switch (gs->src_kind[d]) {
+              case PCLEAN_GSRC_CAND: return t.cols[(size_t)gs->src[d] * n + k];
+              case PCLEAN_GSRC_OBS: return w.obs[(size_t)gs->src[d] * w.n_rows + er];
+              case PCLEAN_GSRC_ITEMCTX: return ctxv[gs->src[d]];
+              default: return ec[gs->src[d]];
+            }
+          }));
         }
       }
     }
@@ -152,6 +232,17 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
       out[k] += term_density(w, tm, pt, d, val);
     }
   }
+  if (gs && w.xnum[(size_t)gs->x_col * w.n_rows + row] == w.xnum[(size_t)gs->x_col * w.n_rows + row])
+    for (int k = 0; k < n; ++k) {
+      if (!(out[k] > NEG_INF)) continue;
+      out[k] += gauss_lse(gauss_combo_scores(w, *gs, row, nullptr, [&](int d) -> int {
+        switch (gs->src_kind[d]) {
+          case PCLEAN_GSRC_CAND: return t.cols[(size_t)gs->src[d] * n + k];
+          case PCLEAN_GSRC_OBS: return w.obs[(size_t)gs->src[d] * w.n_rows + row];
+          default: return ctxv[gs->src[d]];
+        }
+      }));
+    }
 }
 
 struct FixSum {

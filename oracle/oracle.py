@@ -193,6 +193,28 @@ class World:
         logp = np.ascontiguousarray(logp, np.float64)
         self.L.pco_world_set_options(self.h, tid, len(values), _p(values, C.c_int32), _p(logp, C.c_double))
 
+    def set_options_cols(self, tid, cols, logp):
+        cols = np.ascontiguousarray(cols, np.int32)
+        logp = np.ascontiguousarray(logp, np.float64)
+        self.L.pco_world_set_options_cols(self.h, tid, cols.shape[1], cols.shape[0], _p(cols, C.c_int32),
+                                          _p(logp, C.c_double))
+
+    def set_numeric(self, x):
+        x = np.ascontiguousarray(x, np.float64)
+        self.L.pco_world_set_numeric(self.h, x.shape[1], x.shape[0], _p(x, C.c_double))
+
+    def set_mean(self, tid, mean):
+        mean = np.ascontiguousarray(mean, np.float64).reshape(-1)
+        self.L.pco_world_set_mean(self.h, tid, len(mean), _p(mean, C.c_double))
+
+    def set_gauss(self, block, node, g):
+        self.L.pco_world_set_gauss(self.h, block, node, C.byref(g))
+
+    def get_locals(self, block, n_rows):
+        out = np.empty((n_rows, 2), dtype=np.int32)
+        self.L.pco_get_locals(block, n_rows, _p(out, C.c_int32))
+        return out
+
     def set_fn(self, fid, fn):
         fn = np.ascontiguousarray(fn, np.int32)
         self.L.pco_world_set_fn(self.h, fid, fn.shape[0], fn.shape[1], _p(fn, C.c_int32))

@@ -141,6 +141,8 @@ void pco_world_load_block(pco::World* w, int id, int n_nodes, const pclean_node*
   b.terms.assign(terms, terms + n_terms);
   b.children.assign(children, children + n_children);
   b.colmap.assign(colmap, colmap + n_colmap);
+  b.gauss.clear();
+  b.node_gauss.assign(n_nodes, -1);
   b.n_ctx = n_ctx;
   for (int s = 0; s < n_ctx; ++s) {
     b.ctx_src_block[s] = ctx_src_block[s];
@@ -199,16 +201,21 @@ void pco_final_choice(int n_rows, int P, const double* logw, int use_mh, int is_
 
 /* ---- whole sweep, batched schedule (the GPU's parity target) --------------- */
 static std::vector<pco::NewRow> g_new_rows;
+static std::vector<int32_t> g_locals; /* [n_rows][n_blocks][2] of the last batched sweep */
+static int g_locals_blocks = 0;
 int pco_sweep_batched(const pco::World* w, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep, int n_blocks,
                       int64_t row_offset, const int32_t* cur, int32_t* choice, int32_t* chosen, double* logml) {
   const int N = w->n_rows;
   g_new_rows.clear();
+  g_locals.assign((size_t)N * n_blocks * 2, -1);
+  g_locals_blocks = n_blocks;
   std::vector<int32_t> c(n_blocks), ch(n_blocks);
   for (int i = 0; i < N; ++i) {
     for (int b = 0; b < n_blocks; ++b) c[b] = cur[(size_t)b * N + i];
     int cp;
     double ml;
-    pco::run_smc_row(*w, *cfg, seed, sweep, n_blocks, i, row_offset, c.data(), ch.data(), &cp, &ml, g_new_rows);
+    pco::run_smc_row(*w, *cfg, seed, sweep, n_blocks, i, row_offset, c.data(), ch.data(), &cp, &ml, g_new_rows,
+                     &g_locals[(size_t)i * n_blocks * 2]);
     for (int b = 0; b < n_blocks; ++b) choice[(size_t)b * N + i] = ch[b];
     if (chosen) chosen[i] = cp;
     if (logml) logml[i] = ml;
@@ -228,6 +235,33 @@ int pco_sweep_latent(const pco::World* w, const pclean_infer_config* cfg, uint64
   pco::sweep_latent(*w, *cfg, seed, sweep, block_id, n_roots, roots, n_items, keys, ev_off, ev_rows, ev_ctx, excl,
                     chosen, vals);
   return 0;
+}
+void pco_get_locals(int block, int n_rows, int32_t* out) {
+  for (int i = 0; i < n_rows; ++i) {
+    out[2 * i] = g_locals[((size_t)i * g_locals_blocks + block) * 2];
+    out[2 * i + 1] = g_locals[((size_t)i * g_locals_blocks + block) * 2 + 1];
+  }
+}
+void pco_world_set_numeric(pco::World* w, int n_rows, int n_cols, const double* x) {
+  w->n_xcols = n_cols;
+  w->xnum.assign(x, x + (size_t)n_rows * n_cols);
+}
+void pco_world_set_mean(pco::World* w, int id, int n, const double* mean) { w->mean[id].assign(mean, mean + n); }
+void pco_world_set_gauss(pco::World* w, int block, int node, const pclean_gauss* g) {
+  pco::OBlock& b = w->block[block];
+  if (b.node_gauss.size() != b.nodes.size()) b.node_gauss.assign(b.nodes.size(), -1);
+  b.node_gauss[node] = (int)b.gauss.size();
+  b.gauss.push_back(*g);
+}
+void pco_world_set_options_cols(pco::World* w, int id, int n, int n_cols, const int32_t* cols, const double* logp) {
+  pco::OTable& t = w->table[id];
+  t.is_options = true;
+  t.n_rows = n;
+  t.n_cols = n_cols;
+  t.cols.assign(cols, cols + (size_t)n * n_cols);
+  t.counts.assign(n, 1);
+  t.logc_full.assign(logp, logp + n);
+  t.logc_m1.clear();
 }
 int pco_new_rows_count(int block) {
   int n = 0;

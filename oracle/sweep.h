@@ -189,7 +189,8 @@ inline int final_choice(const std::vector<double>& w, bool use_mh, bool csmc, ui
  * the sampled contents of new rows. */
 inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t seed, uint32_t sweep, int n_blocks,
                         int row, int64_t row_offset, const int32_t* cur /*[n_blocks]*/, int32_t* choice /*[n_blocks]*/,
-                        int32_t* chosen_particle, double* logml, std::vector<NewRow>& new_rows) {
+                        int32_t* chosen_particle, double* logml, std::vector<NewRow>& new_rows,
+                        int32_t* locals_out = nullptr /*[n_blocks][2]*/) {
   const bool use_mh = cfg.use_mh_instead_of_pg != 0;
   const int P = use_mh ? 2 : cfg.num_particles;
   const uint32_t rr = (uint32_t)((int64_t)row + row_offset);
@@ -270,6 +271,44 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
   for (int bi = 0; bi < n_blocks; ++bi) {
     choice[bi] = pch[bi][c];
     if (pch[bi][c] == PCLEAN_CHOICE_NEW) new_rows.push_back(NewRow{bi, row, pvals[bi][c]});
+    /* own enumerated choices (locals) of the chosen particle given its referent */
+    const OBlock& b = w.block[bi];
+    if (locals_out && !b.node_gauss.empty() && b.node_gauss[0] >= 0 && b.gauss[b.node_gauss[0]].n_locals > 0) {
+      const pclean_gauss& g = b.gauss[b.node_gauss[0]];
+      const OTable& rt = w.table[b.nodes[0].table];
+      const int ch = pch[bi][c];
+      GaussCombos gc;
+      const double xv = w.xnum[(size_t)g.x_col * w.n_rows + row];
+      if (xv == xv) {
+        gc = gauss_combo_scores(w, g, row, nullptr, [&](int d) -> int {
+          if (g.src_kind[d] == PCLEAN_GSRC_CAND)
+            return ch >= 0 ? rt.cols[(size_t)g.src[d] * rt.n_rows + ch]
+                           : resolve_new_value(w, b, 0, g.src[d], pvals[bi][c].data());
+          return w.obs[(size_t)g.src[d] * w.n_rows + row];
+        });
+      } else {
+        const int n0 = g.local_n[0], n1 = g.n_locals > 1 ? g.local_n[1] : 1;
+        for (int l0 = 0; l0 < n0; ++l0)
+          for (int l1 = 0; l1 < n1; ++l1) {
+            auto ok = [&](int l, int v) {
+              if (l >= g.n_locals || g.local_obs_col[l] < 0) return true;
+              const int o = w.obs[(size_t)g.local_obs_col[l] * w.n_rows + row];
+              return o < 0 || o == v;
+            };
+            if (ok(0, l0) && ok(1, l1)) {
+              gc.sc[gc.n] = 0.0;
+              gc.codes[gc.n] = l0 * 16 + l1;
+              ++gc.n;
+            }
+          }
+      }
+      std::vector<double> sv(gc.sc, gc.sc + gc.n);
+      FixSum f = fix_sum(sv);
+      int pick = gc.n - 1;
+      if (f.U) pick = fix_draw(sv, f, pclean_rand64(seed, rr, PCLEAN_SITE_LOCALS(bi), (uint32_t)c, sweep));
+      locals_out[2 * bi] = gc.n ? gc.codes[pick] >> 4 : -1;
+      locals_out[2 * bi + 1] = (gc.n && g.n_locals > 1) ? (gc.codes[pick] & 15) : -1;
+    }
   }
 }
 

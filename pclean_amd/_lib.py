@@ -35,6 +35,17 @@ class Node(C.Structure):
                 ("reserved", C.c_int32 * 2)]
 
 
+class Gauss(C.Structure):
+    _fields_ = [("x_col", C.c_int32), ("mean_table", C.c_int32), ("n_dims", C.c_int32), ("src_kind", C.c_int32 * 4),
+                ("src", C.c_int32 * 4), ("stride", C.c_int32 * 4), ("n_locals", C.c_int32), ("local_n", C.c_int32 * 2),
+                ("local_obs_col", C.c_int32 * 2), ("transform_src_kind", C.c_int32), ("transform_src", C.c_int32),
+                ("fixed_locals", C.c_int32), ("pad", C.c_int32), ("t_scale", C.c_double * 4),
+                ("t_logabsderiv", C.c_double * 4), ("sigma", C.c_double)]
+
+
+GSRC = {"cand": 0, "obs": 1, "local": 2, "itemctx": 3, "evctx": 4}
+
+
 class InferConfig(C.Structure):
     _fields_ = [("num_iters", C.c_int32), ("num_particles", C.c_int32), ("use_dd_proposals", C.c_int32),
                 ("use_lo_sweeps", C.c_int32), ("use_mh_instead_of_pg", C.c_int32), ("rejuv_frequency", C.c_int32),
@@ -197,6 +208,32 @@ class HipContext:
         logp = np.ascontiguousarray(logp, dtype=np.float64)
         check(self.h, self.lib.pclean_set_options(self.h, C.c_int32(table_id), C.c_int32(len(values)),
                                                   _p(values, C.c_int32), _p(logp, C.c_double)), "pclean_set_options")
+
+    def set_options_cols(self, table_id, cols, logp):
+        cols = np.ascontiguousarray(cols, dtype=np.int32)  # [n_cols][n_options]
+        logp = np.ascontiguousarray(logp, dtype=np.float64)
+        check(self.h, self.lib.pclean_set_options_cols(self.h, C.c_int32(table_id), C.c_int32(cols.shape[1]),
+                                                       C.c_int32(cols.shape[0]), _p(cols, C.c_int32),
+                                                       _p(logp, C.c_double)), "pclean_set_options_cols")
+
+    def load_numeric_columns(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)  # [n_cols][n_rows]
+        check(self.h, self.lib.pclean_load_numeric_columns(self.h, C.c_int32(x.shape[1]), C.c_int32(x.shape[0]),
+                                                           _p(x, C.c_double)), "pclean_load_numeric_columns")
+
+    def set_mean_table(self, table_id, mean):
+        mean = np.ascontiguousarray(mean, dtype=np.float64).reshape(-1)
+        check(self.h, self.lib.pclean_set_mean_table(self.h, C.c_int32(table_id), C.c_int32(len(mean)),
+                                                     _p(mean, C.c_double)), "pclean_set_mean_table")
+
+    def set_node_gauss(self, block_id, node_id, g):
+        check(self.h, self.lib.pclean_set_node_gauss(self.h, C.c_int32(block_id), C.c_int32(node_id), C.byref(g)),
+              "pclean_set_node_gauss")
+
+    def get_locals(self, block_id, n_rows):
+        out = np.empty((n_rows, 2), dtype=np.int32)
+        check(self.h, self.lib.pclean_get_locals(self.h, C.c_int32(block_id), _p(out, C.c_int32)), "pclean_get_locals")
+        return out
 
     def set_fn_table(self, fn_id, fn):
         fn = np.ascontiguousarray(fn, dtype=np.int32)

@@ -15,6 +15,21 @@ def reconstructed_pool_ids(lowered, trace, row_slice=None):
     fk_block = {blk["root_fk"]: bi for bi, blk in enumerate(lw.blocks)}
     out = {}
     for col, ref in q.cleanmap.items():
+        own = ocls.attr(ref) if "." not in ref else None
+        if own is not None and own.kind == "choice":  # own discrete choice (e.g. br): option -> string
+            bi = next(iter(lw.locals))
+            li = lw.locals[bi].index(ref)
+            dom = lw.latent_dom[(q.cls, ref)]
+            out[col] = dom.id_array()[np.maximum(trace.locals[bi][:, li], 0)]
+            continue
+        if own is not None and own.kind == "julia" and getattr(lw, "gauss_spec", None) is not None \
+                and lw.gauss_spec["gauss_attr"] == q.obsmap[col]:
+            # corrected = round(unit.backward(x)) (experiments/rents/run.jl:25): numeric, compared as a number
+            spec = lw.gauss_spec
+            bi = next(iter(lw.locals))
+            u = np.maximum(trace.locals[bi][:, spec["t_local"]], 0)
+            out[col] = ("numeric", np.round(lw.xnum[spec["x_col"]][:trace.cur.shape[1]] * np.asarray(spec["t_scale"])[u]))
+            continue
         if "." in ref:
             head, rest = ref.split(".", 1)
             bi = fk_block[head]
@@ -53,6 +68,16 @@ def accuracy_counts(lowered, trace, dirty, clean):
         ne = np.array([(x != y) for x, y in zip(d[:n], c[:n])])
         errors += int(np.sum(ne & ~dmiss))
         if col not in ours:
+            continue
+        if isinstance(ours[col], tuple):  # numeric column: compare numbers (Float64 == Int in the reference)
+            o = ours[col][1]
+            dn = np.array([np.nan if v is None else float(v) for v in d[:n]])
+            cn = np.array([np.nan if v is None else float(v) for v in c[:n]])
+            errors -= int(np.sum(ne & ~dmiss))
+            errors += int(np.sum((dn != cn) & ~dmiss))
+            ch = (~dmiss) & (o != dn)
+            changed += int(np.sum(ch))
+            cleaned += int(np.sum(ch & (o == cn)))
             continue
         idx = lw.pool.index
         d_id = np.array([idx.get(v, -3) if v is not None else -4 for v in d[:n]], dtype=np.int64)

@@ -385,6 +385,60 @@ extern "C" int pclean_set_options(pclean_ctx* ctx, int32_t table_id, int32_t n_o
   return PCLEAN_OK;
 }
 
+extern "C" int pclean_set_options_cols(pclean_ctx* ctx, int32_t table_id, int32_t n_options, int32_t n_cols,
+                                       const int32_t* cols, const double* logp) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || n_options <= 0 || n_cols <= 0 || !cols || !logp)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_options_cols: bad arguments");
+  int rc = pclean_set_options(ctx, table_id, n_options, cols, logp);
+  if (rc) return rc;
+  CandTable& t = ctx->cand[table_id];
+  t.n_cols = n_cols;
+  if (t.cols.alloc((size_t)n_options * n_cols)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemcpy(t.cols.p, cols, (size_t)n_options * n_cols * sizeof(int32_t), hipMemcpyHostToDevice));
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_load_numeric_columns(pclean_ctx* ctx, int32_t n_rows, int32_t n_cols, const double* x) {
+  if (!ctx || n_rows < 0 || n_cols < 0 || (!x && (int64_t)n_rows * n_cols > 0))
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_load_numeric_columns: bad arguments");
+  if (ctx->n_rows != n_rows) return pclean_fail(ctx, PCLEAN_ERR_STATE, "load the dictionary-encoded columns first (same n_rows)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)n_rows * n_cols;
+  if (ctx->xnum.alloc(std::max<size_t>(n, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  if (n) HIPCHK(ctx, hipMemcpy(ctx->xnum.p, x, n * sizeof(double), hipMemcpyHostToDevice));
+  ctx->n_xcols = n_cols;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_set_mean_table(pclean_ctx* ctx, int32_t table_id, int32_t n, const double* mean) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || n <= 0 || !mean)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_mean_table: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  MeanTable& m = ctx->mean[table_id];
+  if (m.v.alloc(n)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemcpy(m.v.p, mean, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  m.n = n;
+  m.valid = true;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_set_node_gauss(pclean_ctx* ctx, int32_t block_id, int32_t node_id, const pclean_gauss* g) {
+  if (!ctx || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid || !g)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_node_gauss: bad arguments");
+  Block& b = ctx->block[block_id];
+  if (node_id < 0 || node_id >= (int)b.nodes.size() || g->n_dims < 0 || g->n_dims > 4 || g->n_locals < 0 ||
+      g->n_locals > 2 || g->mean_table < 0 || g->mean_table >= PCLEAN_MAX_TABLES)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_node_gauss: malformed spec");
+  int combos = 1;
+  for (int l = 0; l < g->n_locals; ++l) combos *= g->local_n[l];
+  if (combos > 16 || (g->n_locals == 2 && g->local_n[1] > 16))
+    return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "pclean_set_node_gauss: more than 16 local combinations");
+  if (b.node_gauss.size() != b.nodes.size()) b.node_gauss.assign(b.nodes.size(), -1);
+  b.node_gauss[node_id] = (int32_t)b.gauss.size();
+  b.gauss.push_back(*g);
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_set_fn_table(pclean_ctx* ctx, int32_t fn_id, int32_t n_a, int32_t n_b, const int32_t* fn) {
   if (!ctx || fn_id < 0 || fn_id >= PCLEAN_MAX_TABLES || n_a <= 0 || n_b <= 0 || !fn)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_fn_table: bad arguments");
@@ -448,6 +502,8 @@ extern "C" int pclean_load_block(pclean_ctx* ctx, int32_t block_id, int32_t n_no
   for (auto& l : b.leaf_cache) l.release();
   b.leaf_cache.clear();
   b.leaf_cache.resize(n_nodes);
+  b.gauss.clear();
+  b.node_gauss.assign(n_nodes, -1);
   b.valid = true;
   return PCLEAN_OK;
 }

@@ -72,8 +72,16 @@ struct FnTable {
   DevBuf<int32_t> fn;
 };
 
+struct MeanTable {
+  bool valid = false;
+  int32_t n = 0;
+  DevBuf<double> v;
+};
+
 struct Block {
   bool valid = false;
+  std::vector<pclean_gauss> gauss;   // Gaussian terms of this block's nodes
+  std::vector<int32_t> node_gauss;   // per node: index into gauss, -1 none
   std::vector<pclean_node> nodes;
   std::vector<pclean_term> terms;
   std::vector<int32_t> children;
@@ -84,7 +92,7 @@ struct Block {
   DevBuf<pclean_term> d_terms;
   // per-sweep work buffers live in Sweep state (sweep.hip)
   std::vector<DevBuf<double>> leaf_cache;  // per node: marginal per unique observed value
-  std::vector<int32_t> new_rows_host, new_vals_host;
+  std::vector<int32_t> new_rows_host, new_vals_host, locals_host;
 };
 
 struct pclean_ctx {
@@ -103,6 +111,9 @@ struct pclean_ctx {
   int32_t n_rows = 0, n_cols = 0;
   DevBuf<int32_t> obs;  // [n_cols][n_rows]
   DevBuf<int32_t> iota; // identity column for per-unique-value leaf caches
+  int32_t n_xcols = 0;
+  DevBuf<double> xnum;  // numeric observed columns [n_xcols][n_rows]
+  MeanTable mean[PCLEAN_MAX_TABLES];
 
   // density tables
   int32_t max_r = -1, max_d = -1, max_len = -1;

@@ -15,8 +15,25 @@ struct TermDev {
   int32_t ctx_mode, pad;    // 0: ctx of the item; 1: ctx of the evidence row, fn[ctx][cand]; 2: fn[cand][ctx]
 };
 
+// Gaussian observation with enumerated locals (pclean_gauss resolved to device pointers)
+struct GaussDev {
+  int32_t on, n_dims, n_locals, t_kind;
+  const double* x;    // [n_rows]
+  const double* mu;   // mean table
+  int32_t src_kind[4];
+  const int32_t* src_ptr[4];
+  int32_t src_slot[4], stride[4];
+  int32_t local_n[2];
+  const int32_t* local_obs[2];
+  double local_logp[2];
+  int32_t t_src, pad;
+  double t_scale[4], t_lad[4];
+  double sigma, log_sigma;
+};
+
 struct NodeDev {
   int32_t kind, n_cand, n_terms, pad;
+  GaussDev g;
   const int64_t* counts;
   const double* logc_full;
   const double* logc_m1;

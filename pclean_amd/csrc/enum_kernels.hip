@@ -24,6 +24,7 @@
 #include <algorithm>
 
 #include "enum.h"
+#include "gauss_dev.h"
 
 #define HALF_LOG26 1.629048269010741
 #define ADD_TYPOS_IMPOSSIBLE (-1e5)
@@ -75,6 +76,27 @@ __device__ __forceinline__ ItemView item_view(const NodeDev& nd, const ItemsDev&
 
 // score of existing candidate k (the single definition both kernels use, so the
 // fp64 operation order — prior, then terms in plan order — is identical)
+// Gaussian term of candidate k for observed row `row` (evctx = ctx of the evidence row, may be null)
+__device__ __forceinline__ double gauss_term(const NodeDev& nd, const ItemView& v, int k, int row, const int32_t* evctx) {
+  const GaussDev& g = nd.g;
+  const double xv = g.x[row];
+  if (xv != xv) return 0.0;  // missing numeric observation
+  double sc[16];
+  int codes[16];
+  const int n = gauss_combo_scores(
+      g, row, evctx,
+      [&](int d) -> int {
+        switch (g.src_kind[d]) {
+          case PCLEAN_GSRC_CAND: return g.src_ptr[d][k];
+          case PCLEAN_GSRC_OBS: return g.src_ptr[d][row];
+          case PCLEAN_GSRC_ITEMCTX: return v.ctxv[g.src_slot[d]];
+          default: return evctx[g.src_slot[d]];
+        }
+      },
+      sc, codes);
+  return gauss_lse(sc, n);
+}
+
 __device__ __forceinline__ double candidate_score_ev(const NodeDev& nd, const DensDev& dn, const ItemsDev& it,
                                                      const ItemView& v, int k, double sk) {
   // evidence order: ascending position in the item's evidence list; terms in plan order per row
@@ -93,6 +115,8 @@ __device__ __forceinline__ double candidate_score_ev(const NodeDev& nd, const De
       const int d = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
       sk += term_density(tm, dn, d, val);
     }
+    if (nd.g.on && sk > -__builtin_inf())
+      sk += gauss_term(nd, v, k, row, it.ev_ctx ? it.ev_ctx + (size_t)e * PCLEAN_MAX_CTX : nullptr);
   }
   return sk;
 }
@@ -120,6 +144,7 @@ __device__ __forceinline__ double candidate_score(const NodeDev& nd, const DensD
     const int d = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
     sk += term_density(tm, dn, d, val);
   }
+  if (nd.g.on && sk > -__builtin_inf()) sk += gauss_term(nd, v, k, v.row, nullptr);
   return sk;
 }
 

@@ -11,11 +11,13 @@
 //   process_plan!      proposal_compiler.jl:363-388 (children of a new row enumerated
 //       independently; log-marginals added)
 #include <algorithm>
+#include <cmath>
 #include <map>
 
 #include "../../include/pclean_detmath.h"
 #include "../../include/pclean_philox.h"
 #include "enum.h"
+#include "gauss_dev.h"
 
 // ---------------------------------------------------------------------------
 // device-side plan description for resolving values of freshly sampled rows
@@ -357,6 +359,69 @@ __global__ void select_choice_kernel(int n_rows, int P, const int32_t* chosen, c
   chosen_newpos[i] = pchoice[s] == PCLEAN_CHOICE_NEW ? pnewpos[s] : -1;
 }
 
+// own enumerated choices (locals) of the chosen particle, drawn from their conditional given
+// the chosen referent: the inner draws of the nested enumeration (proposal_compiler.jl:115-127)
+__global__ void locals_tail_kernel(int n_rows, int P, GaussDev g, PlanDev plan, const int32_t* chosen,
+                                   const int32_t* pchoice, const int32_t* pnewpos, const int32_t* vals, int n_nodes,
+                                   uint64_t seed, uint32_t sweep, uint32_t block, int64_t row_offset, int32_t* locals) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const int c = chosen[i];
+  const size_t slot = (size_t)i * P + c;
+  const int choice = pchoice[slot];
+  const int32_t* v = choice >= 0 ? nullptr : vals + (size_t)pnewpos[slot] * n_nodes;
+  locals[2 * i] = locals[2 * i + 1] = -1;
+  const double xv = g.x[i];
+  double sc[16];
+  int codes[16];
+  int n = 0;
+  if (xv == xv)
+    n = gauss_combo_scores(
+        g, i, nullptr,
+        [&](int d) -> int {
+          if (g.src_kind[d] == PCLEAN_GSRC_CAND)
+            return choice >= 0 ? g.src_ptr[d][choice] : resolve_new_value(plan, 0, g.src_slot[d], v);
+          return g.src_ptr[d][i];  // PCLEAN_GSRC_OBS
+        },
+        sc, codes);
+  else {  // no numeric evidence: the locals follow their (uniform) priors, observed ones stay fixed
+    for (int l0 = 0; l0 < g.local_n[0]; ++l0)
+      for (int l1 = 0; l1 < g.local_n[1]; ++l1) {
+        const bool ok0 = !g.local_obs[0] || g.local_obs[0][i] < 0 || g.local_obs[0][i] == l0;
+        const bool ok1 = !g.local_obs[1] || g.local_obs[1][i] < 0 || g.local_obs[1][i] == l1;
+        if (ok0 && ok1) {
+          sc[n] = 0.0;
+          codes[n] = l0 * 16 + l1;
+          ++n;
+        }
+      }
+  }
+  double m = -__builtin_inf();
+  for (int k = 0; k < n; ++k) m = fmax(m, sc[k]);
+  uint64_t u[16], U = 0;
+  for (int k = 0; k < n; ++k) {
+    u[k] = m == -__builtin_inf() ? 0ull : pclean_fixw(sc[k] - m);
+    U += u[k];
+  }
+  int pick = n - 1;
+  if (U) {
+    const uint64_t x = pclean_mulhi64(
+        pclean_rand64(seed, (uint32_t)((int64_t)i + row_offset), PCLEAN_SITE_LOCALS(block), (uint32_t)c, sweep), U);
+    uint64_t acc = 0;
+    for (int k = 0; k < n; ++k) {
+      acc += u[k];
+      if (acc > x) {
+        pick = k;
+        break;
+      }
+    }
+  }
+  if (n > 0) {
+    locals[2 * i] = codes[pick] >> 4;
+    locals[2 * i + 1] = g.n_locals > 1 ? (codes[pick] & 15) : -1;
+  }
+}
+
 __global__ void stats_kernel(int n_rows, const int32_t* cur_b, const int32_t* choice, unsigned long long* stats) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows) return;
@@ -399,7 +464,7 @@ struct ItemList {  // device arrays describing enumeration work items
 };
 
 struct BlockRun {  // per-block device state of one sweep
-  DevBuf<int32_t> pchoice, pnewpos, draws, it_row, it_particle, it_excl, it_ctx, choice, chosen_newpos, vals;
+  DevBuf<int32_t> pchoice, pnewpos, draws, it_row, it_particle, it_excl, it_ctx, choice, chosen_newpos, vals, locals;
   DevBuf<double> lse;
   int n_new = 0;  // rows of vals
   DevBuf<int32_t> plan_kind, plan_nrows, plan_cmb, plan_colmap;
@@ -442,7 +507,7 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
   for (auto& b : s->pool) b.release();
   for (auto& r : s->run) {
     r.pchoice.release(); r.pnewpos.release(); r.draws.release(); r.it_row.release(); r.it_particle.release();
-    r.it_excl.release(); r.it_ctx.release(); r.choice.release(); r.chosen_newpos.release(); r.vals.release();
+    r.locals.release(); r.it_excl.release(); r.it_ctx.release(); r.choice.release(); r.chosen_newpos.release(); r.vals.release();
     r.lse.release(); r.plan_kind.release(); r.plan_nrows.release(); r.plan_cmb.release(); r.plan_colmap.release();
     r.plan_cols.release();
   }
@@ -474,6 +539,49 @@ static T* scratch(pclean_ctx* ctx, size_t count) {
   return (T*)b.p;
 }
 
+static int build_gauss_dev(pclean_ctx* ctx, const pclean_gauss& g, const CandTable* t, GaussDev& d) {
+  memset(&d, 0, sizeof d);
+  if (g.x_col < 0 || g.x_col >= ctx->n_xcols) return pclean_fail(ctx, PCLEAN_ERR_ARG, "gauss: numeric column out of range");
+  const MeanTable& m = ctx->mean[g.mean_table];
+  if (!m.valid) return pclean_fail(ctx, PCLEAN_ERR_STATE, "gauss: mean table %d not set", g.mean_table);
+  d.on = 1;
+  d.n_dims = g.n_dims;
+  d.n_locals = g.n_locals;
+  d.x = ctx->xnum.p + (size_t)g.x_col * ctx->n_rows + ctx->active_begin;
+  d.mu = m.v.p;
+  for (int i = 0; i < g.n_dims; ++i) {
+    d.src_kind[i] = g.src_kind[i];
+    d.src_slot[i] = g.src[i];
+    d.stride[i] = g.stride[i];
+    d.src_ptr[i] = nullptr;
+    if (g.src_kind[i] == PCLEAN_GSRC_CAND) {
+      if (!t || g.src[i] < 0 || g.src[i] >= t->n_cols) return pclean_fail(ctx, PCLEAN_ERR_ARG, "gauss: candidate column out of range");
+      d.src_ptr[i] = t->cols.p + (size_t)g.src[i] * t->n_rows;
+    } else if (g.src_kind[i] == PCLEAN_GSRC_OBS) {
+      if (g.src[i] < 0 || g.src[i] >= ctx->n_cols) return pclean_fail(ctx, PCLEAN_ERR_ARG, "gauss: observed column out of range");
+      d.src_ptr[i] = ctx->obs.p + (size_t)g.src[i] * ctx->n_rows + ctx->active_begin;
+    }
+  }
+  for (int l = 0; l < 2; ++l) {
+    d.local_n[l] = l < g.n_locals ? g.local_n[l] : 1;
+    d.local_logp[l] = l < g.n_locals ? -std::log((double)g.local_n[l]) : 0.0;  // choose_uniformly.jl:7-10
+    d.local_obs[l] = nullptr;
+    if (l < g.n_locals && g.local_obs_col[l] >= 0) {
+      if (g.local_obs_col[l] >= ctx->n_cols) return pclean_fail(ctx, PCLEAN_ERR_ARG, "gauss: local observed column out of range");
+      d.local_obs[l] = ctx->obs.p + (size_t)g.local_obs_col[l] * ctx->n_rows + ctx->active_begin;
+    }
+  }
+  d.t_kind = g.transform_src_kind;
+  d.t_src = g.transform_src;
+  for (int u = 0; u < 4; ++u) {
+    d.t_scale[u] = g.t_scale[u];
+    d.t_lad[u] = g.t_logabsderiv[u];
+  }
+  d.sigma = g.sigma;
+  d.log_sigma = std::log(g.sigma);
+  return PCLEAN_OK;
+}
+
 static int build_node_dev(pclean_ctx* ctx, const Block& b, int node_id, NodeDev& nd) {
   const pclean_node& n = b.nodes[node_id];
   const CandTable& t = ctx->cand[n.table];
@@ -488,6 +596,11 @@ static int build_node_dev(pclean_ctx* ctx, const Block& b, int node_id, NodeDev&
   nd.logc_full = t.logc_full.p;
   nd.logc_m1 = t.logc_m1.p;
   memcpy(nd.scal, t.scal, sizeof nd.scal);
+  memset(&nd.g, 0, sizeof nd.g);
+  if (node_id < (int)b.node_gauss.size() && b.node_gauss[node_id] >= 0) {
+    int rc = build_gauss_dev(ctx, b.gauss[b.node_gauss[node_id]], &t, nd.g);
+    if (rc) return rc;
+  }
   for (int i = 0; i < n.n_terms; ++i) {
     const pclean_term& tm = b.terms[n.term_begin + i];
     const PairTable& pt = ctx->pair[tm.pair_table];
@@ -681,7 +794,7 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
               nullptr, il.ev_lo, il.ev_hi, il.ev_rows, il.ev_ctx, il.rng_row};
   FastRootDev fr;
   int fast = 0;
-  if (!scores_out && !snew_override && !ctx->force_generic && !il.ev_lo) {
+  if (!scores_out && !snew_override && !ctx->force_generic && !il.ev_lo && !nd.g.on) {
     fast = try_fast_root(ctx, block_id, node_id, fr);
     if (fast < 0) return fast;
   }
@@ -1220,6 +1333,19 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     hipLaunchKernelGGL(stats_kernel, grid1(N), dim3(256), 0, ctx->stream, N, cur_b, r.choice.p,
                        (unsigned long long*)rt.stats.p);
     HIPCHK(ctx, hipMemcpyAsync(choice + (size_t)bi * N, r.choice.p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    Block& bb = ctx->block[bi];
+    bb.locals_host.clear();
+    if (!bb.node_gauss.empty() && bb.node_gauss[0] >= 0 && bb.gauss[bb.node_gauss[0]].n_locals > 0) {
+      GaussDev gd;
+      int rc = build_gauss_dev(ctx, bb.gauss[bb.node_gauss[0]], &rt, gd);
+      if (rc) return rc;
+      if (r.locals.alloc((size_t)N * 2)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+      hipLaunchKernelGGL(locals_tail_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, gd, r.plan, s->chosen.p,
+                         r.pchoice.p, r.pnewpos.p, r.vals.p, (int)bb.nodes.size(), seed, sweep_idx, (uint32_t)bi,
+                         s->row_offset + ctx->active_begin, r.locals.p);
+      bb.locals_host.resize((size_t)N * 2);
+      HIPCHK(ctx, hipMemcpyAsync(bb.locals_host.data(), r.locals.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
   }
   (void)hipEventRecord(s->eve, ctx->stream);
   if (chosen_particle) HIPCHK(ctx, hipMemcpyAsync(chosen_particle, s->chosen.p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1291,6 +1417,18 @@ extern "C" int pclean_get_new_rows(pclean_ctx* ctx, int32_t block_id, int32_t* n
   *n_out = (int32_t)b.new_rows_host.size();
   if (rows_out && !b.new_rows_host.empty()) memcpy(rows_out, b.new_rows_host.data(), b.new_rows_host.size() * 4);
   if (vals_out && !b.new_vals_host.empty()) memcpy(vals_out, b.new_vals_host.data(), b.new_vals_host.size() * 4);
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_get_locals(pclean_ctx* ctx, int32_t block_id, int32_t* out) {
+  if (!ctx || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid || !out)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_get_locals: bad arguments");
+  const Block& b = ctx->block[block_id];
+  const int N = ctx->active_count >= 0 ? ctx->active_count : ctx->n_rows;
+  if (b.locals_host.size() == (size_t)N * 2)
+    memcpy(out, b.locals_host.data(), (size_t)N * 8);
+  else
+    for (int i = 0; i < 2 * N; ++i) out[i] = -1;
   return PCLEAN_OK;
 }
 

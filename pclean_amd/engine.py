@@ -7,7 +7,25 @@ import numpy as np
 from . import _lib
 from ._lib import HipContext, InferConfig
 from .encode import lm_log_tables
-from .model import ChooseProportionally, ChooseUniformly, StringPrior
+from .model import ChooseProportionally, ChooseUniformly, StringPrior, Unmodeled
+
+
+def make_gauss(spec, mean_table_id=0):
+    """pclean_gauss from a lowered Gaussian spec (model.LoweredModel.gauss)."""
+    g = _lib.Gauss()
+    g.x_col, g.mean_table, g.n_dims = spec["x_col"], mean_table_id, len(spec["kinds"])
+    for i, (kind, payload) in enumerate(spec["kinds"]):
+        g.src_kind[i], g.src[i], g.stride[i] = _lib.GSRC[kind], int(payload), int(spec["strides"][i])
+    g.n_locals = spec["n_locals"]
+    for l in range(2):
+        g.local_n[l] = spec["local_n"][l] if l < len(spec["local_n"]) else 1
+        g.local_obs_col[l] = spec["local_obs"][l] if l < len(spec["local_obs"]) else -1
+    g.transform_src_kind, g.transform_src = _lib.GSRC[spec["transform"][0]], int(spec["transform"][1])
+    for u in range(4):
+        g.t_scale[u] = spec["t_scale"][u] if u < len(spec["t_scale"]) else 1.0
+        g.t_logabsderiv[u] = spec["t_lad"][u] if u < len(spec["t_lad"]) else 0.0
+    g.sigma = spec["sigma"]
+    return g
 
 
 def _logsumexp(x):
@@ -51,6 +69,11 @@ class Engine:
         self.hip.close()
 
     # -- static data ----------------------------------------------------------
+    def _upload_gauss(self):
+        lw, hip = self.lw, self.hip
+        for (bid, nid), spec in getattr(lw, "gauss", {}).items():
+            hip.set_node_gauss(bid, nid, make_gauss(spec))
+
     def _upload_static(self):
         lw, hip = self.lw, self.hip
         sym, off, lm, _ = lw.pool.arrays()
@@ -60,12 +83,38 @@ class Engine:
             hip.build_pair_table(pid, odom.id_array(), ldom.id_array(), self.dist_mode)
         for fid, fn in lw.fn_tables.items():
             hip.set_fn_table(fid, fn)
+        for key, (pid, n) in lw.eq_pairs.items():  # equality constraints: 0 on the diagonal, 1 elsewhere
+            hip.set_pair_table(pid, (1 - np.eye(n, dtype=np.uint8)))
+        if getattr(lw, "xnum", None) is not None and lw.xnum.shape[0]:
+            hip.load_numeric_columns(lw.xnum)
         init_l, trans_l = lm_log_tables()
         m = lw.model
         for (cname, aname), dom in lw.latent_dom.items():
             d = m.classes[cname].attr(aname).dist
             tid = lw.option_id[(cname, aname)]
-            if isinstance(d, StringPrior):
+            if d is None or isinstance(d, Unmodeled) or not isinstance(d, (StringPrior, ChooseUniformly, ChooseProportionally)):
+                if cname == lw.query.cls:
+                    continue  # own choices of the observed class are enumerated as locals, not as leaves
+                logp = np.zeros(len(dom))  # Unmodeled: logdensity 0 (unmodeled.jl:7-10)
+            elif isinstance(d, StringPrior) and d.keyed_by:
+                # per key: scores of its atoms + that key's dummy mass (string_prior.jl:16-22)
+                vals = lw.option_values[(cname, aname)]
+                keys = lw.option_keycol[(cname, aname)]
+                ids = dom.id_array()[vals]
+                offs = np.zeros(len(ids) + 1, dtype=np.int64)
+                np.cumsum(lw.pool.lens[ids], out=offs[1:])
+                lmcat = np.concatenate([lm[off[i]:off[i + 1]] for i in ids])
+                scores = hip.string_prior_scores(lmcat, offs, d.min_len, d.max_len, init_l, trans_l)
+                logp = scores.copy()
+                dummy = dom.get(d.dummy_value())
+                for k in np.unique(keys):
+                    sel = (keys == k) & (vals != dummy)
+                    with np.errstate(divide="ignore"):
+                        logp[(keys == k) & (vals == dummy)] = np.log1p(-np.exp(_logsumexp(scores[sel])))
+                self.option_logp[(cname, aname)] = logp
+                hip.set_options_cols(tid, np.stack([vals, keys]), logp)
+                continue
+            elif isinstance(d, StringPrior):
                 # discrete_proposal(::StringPrior): atom scores + dummy mass (string_prior.jl:16-22)
                 ids = dom.id_array()[:-1]
                 offs = np.zeros(len(ids) + 1, dtype=np.int64)
@@ -88,6 +137,7 @@ class Engine:
             hip.load_block(bi, *lw.block_arrays(bi))
         for cname, pl in lw.latent_plans.items():
             hip.load_block(pl["block_id"], *lw.latent_block_arrays(cname))
+        self._gauss_pending = bool(getattr(lw, "gauss", {}))
 
     # -- dynamic data ---------------------------------------------------------
     def upload_trace(self, trace):
@@ -109,6 +159,11 @@ class Engine:
                     logp = np.log(trace.params[(cname, d.param)].value)  # logprobs(), utils.jl:33-36
                 self.option_logp[(cname, aname)] = logp
                 hip.set_options(lw.option_id[(cname, aname)], lw.option_values[(cname, aname)], logp)
+        if getattr(lw, "gauss", None):
+            hip.set_mean_table(0, trace.mean_param.value)
+            if self._gauss_pending:  # needs the mean table to exist
+                self._upload_gauss()
+                self._gauss_pending = False
 
     def sweep(self, trace, config, seed, sweep_idx):
         """One batched sweep over the observed rows. Returns (choice, chosen_particle, logml, new_rows)."""
@@ -119,6 +174,9 @@ class Engine:
             rows, vals = self.hip.get_new_rows(bi, len(blk["nodes"]))
             if len(rows):
                 new_rows[bi] = (rows, vals)
+        if self.lw.locals:
+            for bi in self.lw.locals:
+                trace.pending_locals[bi] = self.hip.get_locals(bi, choice.shape[1])
         return choice, chosen, logml, new_rows
 
     def sweep_stats(self, trace):

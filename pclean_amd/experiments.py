@@ -101,3 +101,54 @@ def hospital_query(m):
         "MeasureName": ("metric.name", "mname"),
         "Stateavg": ("stateavg", "stateavg_obs"),
     })
+
+
+# ---------------------------------------------------------------------------
+# rents: /root/reference/experiments/rents/{load_data,run}.jl
+def rents_data():
+    dirty = load_table(os.path.join(DATA_DIR, "rents_dirty.csv"))
+    clean = load_table(os.path.join(DATA_DIR, "rents_clean.csv"))
+    # load_data.jl:9 — CountyKey = first letter of the county + last letter of its first word
+    dirty["CountyKey"] = [f"{x[0]}{x.split()[0][-1]}" for x in dirty["County"]]
+    return dirty, clean
+
+
+def rents_model(dirty):
+    """experiments/rents/run.jl:5-27."""
+    from .model import IndexedLookup, IndexedMeanParameter, TransformedGaussian, Transformation, Unmodeled
+    poss = {}
+    for k, c in zip(dirty["CountyKey"], dirty["County"]):
+        poss.setdefault(k, [])
+        if c not in poss[k]:
+            poss[k].append(c)
+    states = list(dict.fromkeys(v for v in dirty["State"] if v is not None))  # load_data.jl:17
+    room_types = ["studio", "1br", "2br", "3br", "4br"]
+    units = [Transformation(lambda x: x, lambda x: x, lambda x: 1.0),
+             Transformation(lambda x: x / 1000.0, lambda x: x * 1000.0, lambda x: 1 / 1000.0)]
+    m = Model()
+    c = m.add_class("County")
+    c.param("state_pops", ProportionsParameter())
+    c.choice("countykey", Unmodeled())
+    c.choice("name", StringPrior(10, 35, poss, keyed_by="countykey"))
+    c.choice("state", ChooseProportionally(states, "state_pops"))
+    o = m.add_class("Obs")
+    o.param("avg_rent", IndexedMeanParameter(1500, 1000))
+    o.fk("county", "County")
+    o.choice("county_name", AddTypos("county.name", 2))
+    o.choice("br", ChooseUniformly(room_types))
+    o.choice("unit", ChooseUniformly(units))
+    o.julia("rent_base", IndexedLookup("avg_rent"), ["county.state", "county.countykey", "br"])
+    o.choice("rent", TransformedGaussian("rent_base", 150.0, "unit"))
+    o.julia("corrected", lambda unit, rent: round(unit.backward(rent)), ["unit", "rent"])
+    return m
+
+
+def rents_query(m):
+    """experiments/rents/run.jl:29-35."""
+    return Query(m, "Obs", {
+        "CountyKey": "county.countykey",
+        "County": ("county.name", "county_name"),
+        "State": "county.state",
+        "Room Type": "br",
+        "Monthly Rent": ("corrected", "rent"),
+    })

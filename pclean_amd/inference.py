@@ -61,6 +61,8 @@ def build_evidence(lw, trace, cname):
         vals = trace.tables[rc].cols[lw.colidx[rc][path], trace.cur[ob]]
         ev_ctx = np.zeros((len(ev_rows), 2), dtype=np.int32)
         ev_ctx[:, 0] = vals[ev_rows]
+    if cname in getattr(lw, "latent_ev_locals", {}):  # Gaussian external likelihood: the rows' own choices
+        ev_ctx = np.ascontiguousarray(trace.locals[lw.latent_ev_locals[cname]][ev_rows]).astype(np.int32)
     return live, ev_off, ev_rows, ev_ctx
 
 
@@ -192,6 +194,7 @@ def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None, row_lo=0):
     engine.hip.set_active_rows(0, -1)
     choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx)
     stats = engine.sweep_stats(trace)
+    trace.commit_locals()
     return exchange_and_commit(trace, engine.lw, comm, row_lo, choice, stats, new_rows)
 
 
@@ -221,6 +224,9 @@ def initialize_trace(engine, trace, config, seed, max_batch=256):
             rows, vals = engine.hip.get_new_rows(bi, len(blk["nodes"]))
             if len(rows):
                 new_rows[bi] = (rows, vals)
+        for bi in lw.locals:
+            trace.pending_locals[bi] = engine.hip.get_locals(bi, count)
+        trace.commit_locals(begin, count)
         trace.commit_batch(begin, count, choice, new_rows, dedup=True)
         begin += count
         size = min(max_batch, size * 2)

@@ -25,10 +25,13 @@ from .encode import Domain, StringPool
 # ---------------------------------------------------------------------------
 # distributions (src/distributions/*.jl) — declarative descriptors
 class StringPrior:
-    """string_prior.jl: StringPrior(min_length, max_length, proposal_atoms)."""
+    """string_prior.jl: StringPrior(min_length, max_length, proposal_atoms).  With `keyed_by`
+    the atoms are a dict keyed by the value of another attribute of the same class
+    (`possibilities[countykey]`, experiments/rents/run.jl:13)."""
 
-    def __init__(self, min_len, max_len, atoms):
-        self.min_len, self.max_len, self.atoms = int(min_len), int(max_len), list(atoms)
+    def __init__(self, min_len, max_len, atoms, keyed_by=None):
+        self.min_len, self.max_len, self.keyed_by = int(min_len), int(max_len), keyed_by
+        self.atoms = {k: list(v) for k, v in atoms.items()} if keyed_by else list(atoms)
 
     def dummy_value(self):  # string_prior.jl:24-26
         return "*" * ((self.min_len + self.max_len) // 2)
@@ -53,6 +56,40 @@ class AddTypos:
 
     def __init__(self, ref, max_typos=None):
         self.ref, self.max_typos = ref, max_typos
+
+
+class Unmodeled:
+    """unmodeled.jl: logdensity 0, no proposal; must be observed."""
+
+
+class Transformation:
+    """transformed_gaussian.jl:5-9 — forward, backward, |g'|."""
+
+    def __init__(self, forward, backward, deriv):
+        self.forward, self.backward, self.deriv = forward, backward, deriv
+
+
+class TransformedGaussian:
+    """transformed_gaussian.jl: TransformedGaussian(mean, std, t); `mean` names an IndexedLookup
+    julia attribute, `unit` an own ChooseUniformly attribute over Transformations."""
+
+    def __init__(self, mean, std, unit):
+        self.mean, self.std, self.unit = mean, float(std), unit
+
+
+class IndexedMeanParameter:
+    """`@learned x::Dict{String, MeanParameter{mean, std}}` (add_noise.jl:15-45, distributions.jl:45-55)."""
+
+    def __init__(self, mean, std):
+        self.mean, self.std = float(mean), float(std)
+
+
+class IndexedLookup:
+    """Deterministic node `param[f(args...)]` (experiments/rents/run.jl:23): the parameter indexed by
+    the tuple of its discrete arguments."""
+
+    def __init__(self, param):
+        self.param = param
 
 
 class ProportionsParameter:
@@ -189,6 +226,10 @@ class LoweredModel:
         self._next_table = 0
         self._next_pair = 0
         self.cross_terms = []
+        self.eq_pairs = {}
+        self.gauss = {}        # (block id, node id) -> dict spec (resolved by the engine)
+        self.locals = {}       # block index -> [own ChooseUniformly attrs enumerated with the Gaussian]
+        self.latent_ev_locals = {}  # latent class -> block index whose locals feed the evidence ctx
         self.latent_plans = {}
         self._build_domains(dirty_columns)
         self._build_layouts()
@@ -203,28 +244,62 @@ class LoweredModel:
                 if a.kind != "choice":
                     continue
                 d = a.dist
-                if isinstance(d, StringPrior):
+                if isinstance(d, StringPrior) and d.keyed_by:
+                    dom = Domain(self.pool)
+                    for k, atoms in d.atoms.items():
+                        for s_ in atoms:
+                            dom.add(s_)
+                    dom.add(d.dummy_value())
+                elif isinstance(d, StringPrior):
                     dom = Domain(self.pool, d.atoms)
                     dom.add(d.dummy_value())
-                elif isinstance(d, (ChooseUniformly, ChooseProportionally)):
+                elif isinstance(d, ChooseProportionally):
+                    dom = Domain(self.pool, d.options)
+                elif isinstance(d, ChooseUniformly) and all(isinstance(o, str) for o in d.options):
                     dom = Domain(self.pool, d.options)
                 else:
                     continue
                 self.latent_dom[(cname, a.name)] = dom
         ocls = m.classes[self.query.cls]
+        self.direct_obs = {}   # obs name -> (path or own attr name) observed without noise (clean == dirty)
+        self.numeric_obs = {}  # own TransformedGaussian attr -> numeric column index
+        self.num_cols = []
         for col, dirty in self.query.obsmap.items():
-            a = ocls.attr(dirty)
-            if not isinstance(a.dist, AddTypos):
-                raise NotImplementedError("only AddTypos observations are lowered so far")
-            vals = [v for v in dirty_columns[col] if v is not None]
-            self.obs_dom[dirty] = Domain(self.pool, list(dict.fromkeys(vals)))
+            own = None
+            if "." not in dirty:
+                own = ocls.attr(dirty)
+            if own is not None and own.kind == "choice" and isinstance(own.dist, AddTypos):
+                vals = [v for v in dirty_columns[col] if v is not None]
+                self.obs_dom[dirty] = Domain(self.pool, list(dict.fromkeys(vals)))
+            elif own is not None and own.kind == "choice" and isinstance(own.dist, TransformedGaussian):
+                self.numeric_obs[dirty] = len(self.num_cols)
+                self.num_cols.append(col)
+                continue
+            else:
+                # direct observation of a latent value or of an own discrete choice: the observed
+                # domain IS the latent domain (proposal_compiler.jl:277-293 compares values)
+                if own is not None:
+                    key = (self.query.cls, dirty)
+                else:
+                    head, rest = dirty.split(".", 1)
+                    cn, la = m.resolve(ocls.attr(head).target, rest)
+                    key = (cn, la.name)
+                if key not in self.latent_dom:  # e.g. Unmodeled: its values are whatever is observed
+                    vals = [v for v in dirty_columns[col] if v is not None]
+                    self.latent_dom[key] = Domain(self.pool, list(dict.fromkeys(vals)))
+                self.obs_dom[dirty] = self.latent_dom[key]
+                self.direct_obs[dirty] = key
             self.obs_index[dirty] = len(self.obs_cols)
             self.obs_cols.append(dirty)
         self.query_columns = {dirty: col for col, dirty in self.query.obsmap.items()}
+        self._never_missing = {dirty for col, dirty in self.query.obsmap.items()
+                               if all(v is not None for v in dirty_columns[col])}
 
     def encode_observations(self, dirty_columns):
         """[n_cols][n_rows] int32 observed-domain indices, -1 = missing."""
         n_rows = len(next(iter(dirty_columns.values())))
+        self.xnum = np.array([[np.nan if v is None else float(v) for v in dirty_columns[c]] for c in self.num_cols],
+                             dtype=np.float64).reshape(len(self.num_cols), n_rows)
         obs = np.full((len(self.obs_cols), n_rows), -1, dtype=np.int32)
         for j, dirty in enumerate(self.obs_cols):
             dom = self.obs_dom[dirty]
@@ -251,12 +326,30 @@ class LoweredModel:
             self.table_id[cname] = self._next_table
             self._next_table += 1
         self.option_values = {}
+        self.option_keycol = {}
         for (cname, aname), dom in self.latent_dom.items():
             self.option_id[(cname, aname)] = self._next_table
             self._next_table += 1
             # option k of discrete_proposal(dist, ...) is latent-domain value k (atoms are unique,
             # string_prior.jl:15; the dummy value, if any, is last)
             self.option_values[(cname, aname)] = np.arange(len(dom), dtype=np.int32)
+            if cname in self.model.classes:
+                a = self.model.classes[cname].attr(aname)
+                d = getattr(a, "dist", None)
+                if isinstance(d, StringPrior) and d.keyed_by:
+                    # options = for every key: its atoms, then one dummy option; column 1 = key index
+                    kdom = self.latent_dom[(cname, d.keyed_by)]
+                    vals, keys = [], []
+                    dummy = dom.get(d.dummy_value())
+                    for k, atoms in d.atoms.items():
+                        ki = kdom.get(k)
+                        for s_ in atoms:
+                            vals.append(dom.get(s_))
+                            keys.append(ki)
+                        vals.append(dummy)
+                        keys.append(ki)
+                    self.option_values[(cname, aname)] = np.array(vals, dtype=np.int32)
+                    self.option_keycol[(cname, aname)] = np.array(keys, dtype=np.int32)
 
     # -- plans --------------------------------------------------------------
     def _obs_terms_of_block(self, ocls, names):
@@ -267,6 +360,14 @@ class LoweredModel:
             if a.kind == "choice" and isinstance(a.dist, AddTypos):
                 out.append(a)
         return out
+
+    def _eq_pair_for(self, dom_key):
+        """0/1 identity table over a shared domain (observed value must equal the latent value)."""
+        key = ("eq", dom_key)
+        if key not in self.eq_pairs:
+            self.eq_pairs[key] = (self._next_pair, len(self.latent_dom[dom_key]))
+            self._next_pair += 1
+        return self.eq_pairs[key][0]
 
     def _pair_for(self, dirty, lat_dom_key, lat_dom):
         key = (dirty, lat_dom_key)
@@ -343,11 +444,17 @@ class LoweredModel:
                                                      local_path=local[0].split(".", 1)[1]))
                     else:
                         raise NotImplementedError("single-argument julia nodes are not lowered yet")
+            # direct (noise-free) observations of values below the root slot: equality constraints
+            for obsname, key in self.direct_obs.items():
+                if "." in obsname and obsname.split(".", 1)[0] == root_fk.name:
+                    terms.append(dict(obs=obsname, path=obsname.split(".", 1)[1], pair=self._eq_pair_for(key),
+                                      max_typos=None, ctx=None, dens=_lib.DENS_EQUAL))
             self._emit_fk_node(blk, root_fk.target, "", terms, parent=-1, parent_fk_col=-1)
             self.blocks.append(blk)
+            self._lower_gaussian(bi, blk, ocls, names, root_fk)
 
     def _emit_term(self, blk, t, cand_col):
-        blk["terms"].append((self.obs_index[t["obs"]], cand_col, t["pair"], _lib.DENS_ADD_TYPOS,
+        blk["terms"].append((self.obs_index[t["obs"]], cand_col, t["pair"], t.get("dens", _lib.DENS_ADD_TYPOS),
                              -1 if t["max_typos"] is None else int(t["max_typos"]),
                              -1 if t["ctx"] is None else t["ctx"][0], -1 if t["ctx"] is None else t["ctx"][1], 0))
 
@@ -380,8 +487,17 @@ class LoweredModel:
                 ltb = len(blk["terms"])
                 for t in sub:
                     self._emit_term(blk, t, 0)
-                cacheable = int(len(sub) == 1 and sub[0]["ctx"] is None)
-                blk["nodes"].append((_lib.NODE_LEAF, self.option_id[(cname, a.name)], ltb, len(sub), 0, 0, nid, -1,
+                n_leaf_terms = len(sub)
+                if isinstance(a.dist, StringPrior) and a.dist.keyed_by:
+                    # atoms belong to the key they were listed under: the option's key must equal the
+                    # (directly observed) key of this row
+                    kt = [t for t in terms if t["path"] == a.dist.keyed_by and t.get("dens") == _lib.DENS_EQUAL]
+                    if len(kt) != 1:
+                        raise NotImplementedError("a keyed StringPrior needs its key attribute observed directly")
+                    self._emit_term(blk, kt[0], 1)
+                    n_leaf_terms += 1
+                cacheable = int(n_leaf_terms == 1 and sub[0]["ctx"] is None)
+                blk["nodes"].append((_lib.NODE_LEAF, self.option_id[(cname, a.name)], ltb, n_leaf_terms, 0, 0, nid, -1,
                                      cacheable, 0, 0, 0))
                 blk["node_info"].append(dict(kind="leaf", cls=cname, attr=a.name, path=prefix + a.name))
                 kids.append(cid)
@@ -394,6 +510,80 @@ class LoweredModel:
         blk["nodes"][nid] = (_lib.NODE_FK, self.table_id[cname], tb, nt, cb, len(kids), parent, parent_fk_col, 0, cmb,
                              0, 0)
         return nid
+
+    def _lower_gaussian(self, bi, blk, ocls, names, root_fk):
+        """`x ~ TransformedGaussian(param[f(root values, own choices)], std, unit)` with own
+        ChooseUniformly choices (experiments/rents/run.jl:19-25) -> pclean_gauss specs."""
+        m = self.model
+        ga = [ocls.attr(n) for n in names if ocls.attr(n).kind == "choice" and isinstance(ocls.attr(n).dist, TransformedGaussian)]
+        if not ga:
+            return
+        if len(ga) > 1:
+            raise NotImplementedError("one Gaussian observation per block (so far)")
+        g = ga[0]
+        look = ocls.attr(g.dist.mean)
+        if look.kind != "julia" or not isinstance(look.fn, IndexedLookup):
+            raise NotImplementedError("TransformedGaussian mean must be an IndexedLookup")
+        unit_attr = ocls.attr(g.dist.unit)
+        units = unit_attr.dist.options
+        locs = []  # own enumerated choices: index arguments that are own attrs, plus the unit
+        dims = []  # (kind, payload, n_values)
+        for arg in look.args:
+            if "." in arg:
+                head, rest = arg.split(".", 1)
+                cn, la = m.resolve(root_fk.target, rest)
+                dims.append(("cand", rest, len(self.latent_dom[(cn, la.name)]), (cn, la.name)))
+            else:
+                oa = ocls.attr(arg)
+                if not isinstance(oa.dist, ChooseUniformly):
+                    raise NotImplementedError("own index arguments must be ChooseUniformly choices")
+                if arg not in locs:
+                    locs.append(arg)
+                dims.append(("local", locs.index(arg), len(oa.dist.options), None))
+        if g.dist.unit not in locs:
+            locs.append(g.dist.unit)
+        if len(locs) > 2:
+            raise NotImplementedError("at most two enumerated own choices")
+        strides, acc = [], 1
+        for d in reversed(dims):
+            strides.append(acc)
+            acc *= d[2]
+        strides = strides[::-1]
+        self.locals[bi] = locs
+        spec = dict(x_col=self.numeric_obs[g.name], param=(self.query.cls, look.fn.param), n_mean=acc, dims=dims,
+                    strides=strides, locals=locs, local_n=[len(ocls.attr(l).dist.options) for l in locs],
+                    local_obs=[self.obs_index.get(l, -1) if l in self.direct_obs else -1 for l in locs],
+                    t_local=locs.index(g.dist.unit), sigma=g.dist.std, gauss_attr=g.name,
+                    t_scale=[float(u.backward(1.0)) for u in units],
+                    t_lad=[float(np.log(abs(u.deriv(u.backward(1.0))))) for u in units], units=units)
+        self.gauss_spec = spec
+        # (a) block root: candidate-side index values come from the candidate's columns
+        rc = root_fk.target
+        self.gauss[(bi, 0)] = dict(spec, kinds=[("cand", self.colidx[rc][d[1]]) if d[0] == "cand" else ("local", d[1])
+                                                 for d in dims], n_locals=len(locs), transform=("local", spec["t_local"]))
+        # (b) new-row branch: the leaf of the one candidate-side value that is not always observed
+        #     carries the term; the others are read from their direct observations
+        open_dims = [d for d in dims if d[0] == "cand" and not self._always_observed(root_fk.name + "." + d[1])]
+        if len(open_dims) != 1:
+            raise NotImplementedError("exactly one candidate-side index value may be unobserved")
+        for nid, info in enumerate(blk["node_info"]):
+            if info["kind"] == "leaf" and info["path"] == open_dims[0][1]:
+                kinds = []
+                for d in dims:
+                    if d[0] == "local":
+                        kinds.append(("local", d[1]))
+                    elif d is open_dims[0]:
+                        kinds.append(("cand", 0))
+                    else:
+                        kinds.append(("obs", self.obs_index[root_fk.name + "." + d[1]]))
+                self.gauss[(bi, nid)] = dict(spec, kinds=kinds, n_locals=len(locs), transform=("local", spec["t_local"]))
+                node = list(blk["nodes"][nid])
+                node[8] = 0  # not cacheable any more
+                blk["nodes"][nid] = tuple(node)
+                self.gauss_open = (bi, open_dims[0])
+
+    def _always_observed(self, obsname):
+        return obsname in self.direct_obs and obsname in self._never_missing
 
     # -- latent-class plans ------------------------------------------------------
     def _build_latent_plans(self):
@@ -444,6 +634,14 @@ class LoweredModel:
             plan["terms"].append((self.obs_index[ct["obs"]], col, ct["pair"], _lib.DENS_ADD_TYPOS,
                                   -1 if ct["max_typos"] is None else int(ct["max_typos"]), 0, ct["fn"], 2))
         nt = len(plan["terms"]) - tb
+        if (bi, nid) in self.gauss and info["kind"] == "leaf":
+            # latent sweep of the class owning this value: external likelihood of the referring rows'
+            # Gaussian observations, their own choices held at their current values (evidence ctx)
+            src = self.gauss[(bi, nid)]
+            kinds = [("evctx", k[1]) if k[0] == "local" else k for k in src["kinds"]]
+            self.gauss[(plan["block_id"], new_id)] = dict(src, kinds=kinds, n_locals=0,
+                                                          transform=("evctx", src["t_local"]))
+            self.latent_ev_locals[plan["cls"]] = bi
         kids = []
         if node[0] == _lib.NODE_FK:
             remap = {}

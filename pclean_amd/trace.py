@@ -28,6 +28,24 @@ class ProportionsState:
         self.value = rng.dirichlet(self.alpha + self.counts)
 
 
+class MeanTableState:
+    """IndexedParameter of MeanParameters (add_noise.jl:15-82, distributions.jl:45-55), dense over
+    the index tuple; values are initialised eagerly from the prior (the reference does it lazily)."""
+
+    def __init__(self, n, mean, std, sigma, rng):
+        self.prior_mean, self.prior_std, self.sigma = mean, std, sigma
+        self.value = rng.normal(mean, std, size=n)
+
+    def resample(self, rng, idx, xs):
+        """Gibbs update given observations xs (already transformed back) of entries idx (74-82)."""
+        n = np.bincount(idx, minlength=len(self.value)).astype(np.float64)
+        sm = np.bincount(idx, weights=xs, minlength=len(self.value))
+        var0 = self.prior_std ** 2
+        var = 1.0 / (1.0 / var0 + n / self.sigma ** 2)
+        mean = var * (self.prior_mean / var0 + sm / self.sigma ** 2)
+        self.value = rng.normal(mean, np.sqrt(var))
+
+
 class LatentTable:
     def __init__(self, n_cols, strength=1.0, discount=0.0, cap=16):
         self.n_cols = n_cols
@@ -73,6 +91,38 @@ class Trace:
                     self.params[(cname, a.dist.param)] = ProportionsState(len(a.dist.options), prior.concentration,
                                                                          self.rng)
         self.cur = np.full((len(lowered.blocks), n_rows), -1, dtype=np.int32)
+        # own enumerated choices of the observed class (e.g. br, unit) and the Gaussian mean parameter
+        self.locals = {bi: np.full((n_rows, 2), -1, dtype=np.int32) for bi in getattr(lowered, "locals", {})}
+        self.pending_locals = {}
+        self.mean_param = None
+        spec = getattr(lowered, "gauss_spec", None)
+        if spec is not None:
+            prior = m.classes[spec["param"][0]].attr(spec["param"][1]).prior
+            self.mean_param = MeanTableState(spec["n_mean"], prior.mean, prior.std, spec["sigma"], self.rng)
+
+    def commit_locals(self, begin=0, count=None):
+        for bi, loc in self.pending_locals.items():
+            n = len(loc) if count is None else count
+            self.locals[bi][begin:begin + n] = loc[:n]
+        self.pending_locals = {}
+
+    def gaussian_index(self):
+        """(rows, mean-table index, backward-transformed x) of every assigned observed row."""
+        lw = self.lw
+        spec = lw.gauss_spec
+        bi = next(iter(lw.locals))
+        rows = np.nonzero((self.cur[bi] >= 0) & (self.locals[bi][:, 0] >= 0))[0]
+        root = lw.blocks[bi]["root_class"]
+        t = self.tables[root]
+        idx = np.zeros(len(rows), dtype=np.int64)
+        for d, st in zip(spec["dims"], spec["strides"]):
+            if d[0] == "cand":
+                idx += st * t.cols[lw.colidx[root][d[1]], self.cur[bi][rows]]
+            else:
+                idx += st * self.locals[bi][rows, d[1]]
+        x = lw.xnum[spec["x_col"], rows] * np.asarray(spec["t_scale"])[self.locals[bi][rows, spec["t_local"]]]
+        ok = ~np.isnan(x)
+        return rows[ok], idx[ok], x[ok]
 
     # -- own-choice sufficient statistics (update_sufficient_statistics!, dependency_tracking.jl:6-21)
     def _own_choice_stats(self, cname, row, sign):
@@ -242,6 +292,9 @@ class Trace:
     def resample_parameters(self):
         for p in self.params.values():
             p.resample(self.rng)
+        if self.mean_param is not None:
+            _, idx, x = self.gaussian_index()
+            self.mean_param.resample(self.rng, idx, x)
 
     @staticmethod
     def pitman_yor_score(strength, discount, counts):

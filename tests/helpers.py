@@ -72,6 +72,10 @@ def mirror_world(oracle, lw, obs, trace, engine=None, dist_mode=1, option_logp=N
         w.set_pair(pid, d, lw.pool.lens[ldom.id_array()].astype(np.uint16))
     for fid, fn in lw.fn_tables.items():
         w.set_fn(fid, fn)
+    for key, (pid, n) in lw.eq_pairs.items():
+        w.set_pair(pid, (1 - np.eye(n, dtype=np.uint16)), np.zeros(n, dtype=np.uint16))
+    if getattr(lw, "xnum", None) is not None and lw.xnum.shape[0]:
+        w.set_numeric(lw.xnum[:, :obs.shape[1]])
     for cname, t in trace.tables.items():
         cols, counts = t.view()
         if engine is not None:
@@ -81,11 +85,23 @@ def mirror_world(oracle, lw, obs, trace, engine=None, dist_mode=1, option_logp=N
         w.set_table(lw.table_id[cname], np.ascontiguousarray(cols), counts, full, m1, scal)
     logps = engine.option_logp if engine is not None else option_logp
     for (cname, aname), dom in lw.latent_dom.items():
-        w.set_options(lw.option_id[(cname, aname)], lw.option_values[(cname, aname)], logps[(cname, aname)])
+        if (cname, aname) not in logps:
+            continue
+        if (cname, aname) in lw.option_keycol:
+            w.set_options_cols(lw.option_id[(cname, aname)],
+                               np.stack([lw.option_values[(cname, aname)], lw.option_keycol[(cname, aname)]]),
+                               logps[(cname, aname)])
+        else:
+            w.set_options(lw.option_id[(cname, aname)], lw.option_values[(cname, aname)], logps[(cname, aname)])
     for bi in range(len(lw.blocks)):
         w.load_block(bi, *lw.block_arrays(bi))
     for cname, pl in lw.latent_plans.items():
         w.load_block(pl["block_id"], *lw.latent_block_arrays(cname))
+    if getattr(lw, "gauss", None):
+        from pclean_amd.engine import make_gauss
+        w.set_mean(0, trace.mean_param.value)
+        for (bid, nid), spec in lw.gauss.items():
+            w.set_gauss(bid, nid, make_gauss(spec))
     return w
 
 
