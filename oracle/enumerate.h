@@ -52,11 +52,18 @@ struct OBlock {
   int n_ctx = 0;
   int ctx_src_block[PCLEAN_MAX_CTX] = {-1, -1};
   int ctx_src_col[PCLEAN_MAX_CTX] = {-1, -1};
+  bool is_score = false;           /* block without a reference slot (flights Obs block 3) */
+  struct ScoreTerm {
+    int obs_col, pair_table, val_block, val_col, key_block, key_col, nopt_fn, other_val;
+  };
+  std::vector<ScoreTerm> score_terms;
+  int prob_fn = -1, prob_a_block = -1, prob_a_col = -1, prob_b_block = -1, prob_b_col = -1;
   std::vector<pclean_gauss> gauss; /* Gaussian terms (experiments/rents/run.jl:19-25) */
   std::vector<int> node_gauss;     /* per node: index into gauss or -1 */
 };
 
 struct World {
+  std::vector<double> prob; /* MaybeSwap error probabilities (ProbParameter values / constants) */
   int n_xcols = 0;
   std::vector<double> xnum;              /* numeric observed columns [n_xcols][n_rows] */
   std::vector<std::vector<double>> mean; /* MeanParameter value tables */
@@ -84,6 +91,11 @@ inline double term_density(const World& w, const pclean_term& tm, const OPair& p
   l -= w.logl[L] * (double)d;  /* add_typos.jl:62 */
   l -= HALF_LOG26 * (double)d; /* add_typos.jl:63 */
   return l;
+}
+
+/* ---- MaybeSwap: maybe_swap.jl:13-28 (o < 0: explicitly missing observation) ------------------ */
+inline double maybe_swap_term(const World& w, bool missing, bool same, bool val_in_options, int n_options, int pidx) {
+  return maybe_swap_logdensity(missing, val_in_options, same, n_options, w.prob[pidx]);
 }
 
 /* ---- Gaussian term with enumerated locals (pclean_gauss): transformed_gaussian.jl:15-16,
@@ -191,6 +203,14 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
         for (int ti = 0; ti < nd.n_terms; ++ti) {
           const pclean_term& tm = b.terms[nd.term_begin + ti];
           const int o = w.obs[(size_t)tm.obs_col * w.n_rows + er];
+          if (tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP) {
+            const OPair& ptm = w.pair[tm.pair_table];
+            const int v2 = t.cols[(size_t)tm.cand_col * n + k];
+            const int c = tm.ctx_mode == 0 ? ctxv[tm.ctx_slot] : ev->ctx[(size_t)e * PCLEAN_MAX_CTX + tm.ctx_slot];
+            const bool same = o >= 0 && ptm.d[(size_t)o * ptm.n_lat + v2] == 0;
+            out[k] += maybe_swap_term(w, o < 0, same, v2 != tm.fn_table, t.cols[(size_t)tm.max_typos * n + k], c);
+            continue;
+          }
           if (o < 0) continue;
           const OPair& pt = w.pair[tm.pair_table];
           int val = t.cols[(size_t)tm.cand_col * n + k];

@@ -134,6 +134,11 @@ def time_regex(s):
     return bool(lib().pco_time_regex(_p(a, C.c_uint32), len(a)))
 
 
+def time_prior_atom(s):
+    """discrete_proposal(::TimePrior) atom score (time_prior.jl:10)."""
+    return lib().pco_time_prior() if time_regex(s) else -np.inf
+
+
 def philox(c, k):
     out = np.empty(4, dtype=np.uint32)
     lib().pco_philox(C.c_uint32(c[0]), C.c_uint32(c[1]), C.c_uint32(c[2]), C.c_uint32(c[3]), C.c_uint32(k[0]),
@@ -214,6 +219,18 @@ class World:
         out = np.empty((n_rows, 2), dtype=np.int32)
         self.L.pco_get_locals(block, n_rows, _p(out, C.c_int32))
         return out
+
+    def set_prob(self, p):
+        p = np.ascontiguousarray(p, np.float64)
+        self.L.pco_world_set_prob(self.h, len(p), _p(p, C.c_double))
+
+    def load_score_block(self, bid, obs_col, pair_table, val_src, key_src, nopt_fn, other_val, prob_fn, prob_a_src,
+                         prob_b_src):
+        a = [np.ascontiguousarray(x, np.int32).reshape(-1) for x in
+             (obs_col, pair_table, val_src, key_src, nopt_fn, other_val, prob_a_src, prob_b_src)]
+        self.L.pco_world_load_score_block(self.h, bid, len(a[0]), _p(a[0], C.c_int32), _p(a[1], C.c_int32),
+                                          _p(a[2], C.c_int32), _p(a[3], C.c_int32), _p(a[4], C.c_int32),
+                                          _p(a[5], C.c_int32), prob_fn, _p(a[6], C.c_int32), _p(a[7], C.c_int32))
 
     def set_fn(self, fid, fn):
         fn = np.ascontiguousarray(fn, np.int32)

@@ -263,6 +263,22 @@ void pco_world_set_options_cols(pco::World* w, int id, int n, int n_cols, const 
   t.logc_full.assign(logp, logp + n);
   t.logc_m1.clear();
 }
+void pco_world_set_prob(pco::World* w, int n, const double* p) { w->prob.assign(p, p + n); }
+void pco_world_load_score_block(pco::World* w, int id, int n_terms, const int32_t* obs_col, const int32_t* pair_table,
+                                const int32_t* val_src, const int32_t* key_src, const int32_t* nopt_fn,
+                                const int32_t* other_val, int prob_fn, const int32_t* pa, const int32_t* pb) {
+  pco::OBlock& b = w->block[id];
+  b = pco::OBlock();
+  b.is_score = true;
+  for (int t = 0; t < n_terms; ++t)
+    b.score_terms.push_back({obs_col[t], pair_table[t], val_src[2 * t], val_src[2 * t + 1], key_src[2 * t],
+                             key_src[2 * t + 1], nopt_fn[t], other_val[t]});
+  b.prob_fn = prob_fn;
+  b.prob_a_block = pa[0];
+  b.prob_a_col = pa[1];
+  b.prob_b_block = pb[0];
+  b.prob_b_col = pb[1];
+}
 int pco_new_rows_count(int block) {
   int n = 0;
   for (auto& r : g_new_rows) n += r.block == block;

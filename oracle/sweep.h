@@ -200,6 +200,29 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
   double acc = 0.0;
   for (int bi = 0; bi < n_blocks; ++bi) {
     const OBlock& b = w.block[bi];
+    if (b.is_score) { /* p += logdensity(...) of the block's observed choices (block_proposal.jl:62-64) */
+      auto src = [&](int blk, int col, int p) {
+        const OBlock& sbk = w.block[blk];
+        const OTable& rt = w.table[sbk.nodes[0].table];
+        const int ch = pch[blk][p];
+        return ch >= 0 ? rt.cols[(size_t)col * rt.n_rows + ch] : resolve_new_value(w, sbk, 0, col, pvals[blk][p].data());
+      };
+      const OFn& pf = w.fn[b.prob_fn];
+      for (int p = 0; p < P; ++p) {
+        const int pidx = pf.fn[(size_t)src(b.prob_a_block, b.prob_a_col, p) * pf.n_b + src(b.prob_b_block, b.prob_b_col, p)];
+        double acc2 = 0.0;
+        for (const auto& stt : b.score_terms) {
+          const int val = src(stt.val_block, stt.val_col, p);
+          const int o = w.obs[(size_t)stt.obs_col * w.n_rows + row];
+          const OPair& pt = w.pair[stt.pair_table];
+          const bool same = o >= 0 && pt.d[(size_t)o * pt.n_lat + val] == 0;
+          const int nopt = w.fn[stt.nopt_fn].fn[src(stt.key_block, stt.key_col, p)];
+          acc2 += maybe_swap_term(w, o < 0, same, val != stt.other_val, nopt, pidx);
+        }
+        wts[p] += acc2;
+      }
+      continue;
+    }
     const int n_root = w.table[b.nodes[0].table].n_rows;
     const int excl = cur[bi];
     auto ctx_of = [&](int p, int32_t* out) {
@@ -250,6 +273,7 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
       double inc;
       if (maybe_resample(wts, cur[bi] >= 0, seed, rr, sweep, (uint32_t)bi, anc, inc, nullptr)) {
         for (int k = 0; k <= bi; ++k) {
+          if (w.block[k].is_score) continue;
           std::vector<int32_t> nc(P);
           std::vector<std::vector<int32_t>> nv(P);
           for (int p = 0; p < P; ++p) {
@@ -269,6 +293,10 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
   if (chosen_particle) *chosen_particle = c;
   if (logml) *logml = acc + log_total - pclean_log((double)P);
   for (int bi = 0; bi < n_blocks; ++bi) {
+    if (w.block[bi].is_score) {
+      choice[bi] = 0;
+      continue;
+    }
     choice[bi] = pch[bi][c];
     if (pch[bi][c] == PCLEAN_CHOICE_NEW) new_rows.push_back(NewRow{bi, row, pvals[bi][c]});
     /* own enumerated choices (locals) of the chosen particle given its referent */

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libpclean_hip.so")
 MAX_CTX = 2
 CHOICE_NEW = -1
 DIST_OSA, DIST_DL = 0, 1
-DENS_ADD_TYPOS, DENS_EQUAL = 0, 1
+DENS_ADD_TYPOS, DENS_EQUAL, DENS_MAYBE_SWAP = 0, 1, 2
 NODE_FK, NODE_LEAF = 0, 1
 
 
@@ -239,6 +239,20 @@ class HipContext:
         fn = np.ascontiguousarray(fn, dtype=np.int32)
         check(self.h, self.lib.pclean_set_fn_table(self.h, C.c_int32(fn_id), C.c_int32(fn.shape[0]),
                                                    C.c_int32(fn.shape[1]), _p(fn, C.c_int32)), "pclean_set_fn_table")
+
+    def set_prob_table(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        check(self.h, self.lib.pclean_set_prob_table(self.h, C.c_int32(len(p)), _p(p, C.c_double)),
+              "pclean_set_prob_table")
+
+    def load_score_block(self, block_id, obs_col, pair_table, val_src, key_src, nopt_fn, other_val, prob_fn,
+                         prob_a_src, prob_b_src):
+        a = [np.ascontiguousarray(x, dtype=np.int32).reshape(-1) for x in
+             (obs_col, pair_table, val_src, key_src, nopt_fn, other_val, prob_a_src, prob_b_src)]
+        check(self.h, self.lib.pclean_load_score_block(
+            self.h, C.c_int32(block_id), C.c_int32(len(a[0])), _p(a[0], C.c_int32), _p(a[1], C.c_int32),
+            _p(a[2], C.c_int32), _p(a[3], C.c_int32), _p(a[4], C.c_int32), _p(a[5], C.c_int32), C.c_int32(prob_fn),
+            _p(a[6], C.c_int32), _p(a[7], C.c_int32)), "pclean_load_score_block")
 
     def get_table_priors(self, table_id, n_rows, is_options=False):
         full = np.empty(n_rows, dtype=np.float64)

@@ -12,7 +12,7 @@ def reconstructed_pool_ids(lowered, trace, row_slice=None):
     lw = lowered
     m, q = lw.model, lw.query
     ocls = m.classes[q.cls]
-    fk_block = {blk["root_fk"]: bi for bi, blk in enumerate(lw.blocks)}
+    fk_block = {blk["root_fk"]: bi for bi, blk in enumerate(lw.blocks) if not blk.get("score")}
     out = {}
     for col, ref in q.cleanmap.items():
         own = ocls.attr(ref) if "." not in ref else None

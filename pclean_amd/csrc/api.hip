@@ -439,6 +439,53 @@ extern "C" int pclean_set_node_gauss(pclean_ctx* ctx, int32_t block_id, int32_t 
   return PCLEAN_OK;
 }
 
+extern "C" int pclean_set_prob_table(pclean_ctx* ctx, int32_t n, const double* p) {
+  if (!ctx || n <= 0 || !p) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_prob_table: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->h_prob_same.resize(n);
+  ctx->h_prob_diff.resize(n);
+  for (int i = 0; i < n; ++i) {
+    if (!(p[i] > 0.0 && p[i] < 1.0)) return pclean_fail(ctx, PCLEAN_ERR_ARG, "probability %d outside (0,1)", i);
+    ctx->h_prob_same[i] = std::log1p(-p[i]);  // maybe_swap.jl:25
+    ctx->h_prob_diff[i] = std::log(p[i]);     // maybe_swap.jl:27
+  }
+  if (ctx->h_logn.empty()) {
+    ctx->h_logn.resize(4096);
+    ctx->h_logn[0] = 0.0;
+    for (int k = 1; k < 4096; ++k) ctx->h_logn[k] = std::log((double)k);
+    if (ctx->logn.alloc(4096)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+    HIPCHK(ctx, hipMemcpy(ctx->logn.p, ctx->h_logn.data(), 4096 * sizeof(double), hipMemcpyHostToDevice));
+  }
+  if (ctx->prob_same.alloc(n) || ctx->prob_diff.alloc(n)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemcpy(ctx->prob_same.p, ctx->h_prob_same.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->prob_diff.p, ctx->h_prob_diff.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  ctx->n_prob = n;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_load_score_block(pclean_ctx* ctx, int32_t block_id, int32_t n_terms, const int32_t* obs_col,
+                                       const int32_t* pair_table, const int32_t* val_src, const int32_t* key_src,
+                                       const int32_t* nopt_fn, const int32_t* other_val, int32_t prob_fn,
+                                       const int32_t* prob_a_src, const int32_t* prob_b_src) {
+  if (!ctx || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || n_terms <= 0 || n_terms > 8 || !obs_col || !pair_table ||
+      !val_src || !key_src || !nopt_fn || !other_val || !prob_a_src || !prob_b_src || prob_fn < 0 ||
+      prob_fn >= PCLEAN_MAX_TABLES)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_load_score_block: bad arguments");
+  Block& b = ctx->block[block_id];
+  b = Block();
+  b.is_score = true;
+  for (int t = 0; t < n_terms; ++t)
+    b.score_terms.push_back(ScoreTerm{obs_col[t], pair_table[t], val_src[2 * t], val_src[2 * t + 1], key_src[2 * t],
+                                      key_src[2 * t + 1], nopt_fn[t], other_val[t]});
+  b.prob_fn = prob_fn;
+  b.prob_a_block = prob_a_src[0];
+  b.prob_a_col = prob_a_src[1];
+  b.prob_b_block = prob_b_src[0];
+  b.prob_b_col = prob_b_src[1];
+  b.valid = true;
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_set_fn_table(pclean_ctx* ctx, int32_t fn_id, int32_t n_a, int32_t n_b, const int32_t* fn) {
   if (!ctx || fn_id < 0 || fn_id >= PCLEAN_MAX_TABLES || n_a <= 0 || n_b <= 0 || !fn)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_fn_table: bad arguments");
@@ -484,6 +531,12 @@ extern "C" int pclean_load_block(pclean_ctx* ctx, int32_t block_id, int32_t n_no
       return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_load_block: child id out of range");
   for (int i = 0; i < n_terms; ++i) {
     const pclean_term& tm = terms[i];
+    if (tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP) {  // ctx = evidence-row prob index, fn_table = "other" value
+      if (tm.pair_table < 0 || tm.pair_table >= PCLEAN_MAX_TABLES || tm.ctx_slot < 0 || tm.ctx_slot >= PCLEAN_MAX_CTX ||
+          tm.ctx_mode != 1 || tm.max_typos < 0)
+        return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_load_block: MaybeSwap term %d malformed", i);
+      continue;
+    }
     if (tm.pair_table < 0 || tm.pair_table >= PCLEAN_MAX_TABLES || tm.ctx_slot >= n_ctx ||
         (tm.ctx_slot >= 0 && (tm.fn_table < 0 || tm.fn_table >= PCLEAN_MAX_TABLES)))
       return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_load_block: term %d malformed", i);

@@ -78,8 +78,15 @@ struct MeanTable {
   DevBuf<double> v;
 };
 
+struct ScoreTerm {
+  int32_t obs_col, pair_table, val_block, val_col, key_block, key_col, nopt_fn, other_val;
+};
+
 struct Block {
   bool valid = false;
+  bool is_score = false;             // no reference slot: only scores observed choices (flights Obs block 3)
+  std::vector<ScoreTerm> score_terms;
+  int32_t prob_fn = -1, prob_a_block = -1, prob_a_col = -1, prob_b_block = -1, prob_b_col = -1;
   std::vector<pclean_gauss> gauss;   // Gaussian terms of this block's nodes
   std::vector<int32_t> node_gauss;   // per node: index into gauss, -1 none
   std::vector<pclean_node> nodes;
@@ -114,6 +121,9 @@ struct pclean_ctx {
   int32_t n_xcols = 0;
   DevBuf<double> xnum;  // numeric observed columns [n_xcols][n_rows]
   MeanTable mean[PCLEAN_MAX_TABLES];
+  int32_t n_prob = 0;
+  DevBuf<double> prob_same, prob_diff, logn;  // log1p(-p), log(p), log(n)
+  std::vector<double> h_prob_same, h_prob_diff, h_logn;
 
   // density tables
   int32_t max_r = -1, max_d = -1, max_len = -1;

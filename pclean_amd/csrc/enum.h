@@ -13,6 +13,8 @@ struct TermDev {
   const int32_t* fn;        // ctx lookup table or nullptr
   int32_t n_lat, elem_bytes, dens_kind, max_typos, ctx_slot, fn_nb;
   int32_t ctx_mode, pad;    // 0: ctx of the item; 1: ctx of the evidence row, fn[ctx][cand]; 2: fn[cand][ctx]
+  const int32_t* aux_col;   // MAYBE_SWAP: [n_cand] number of options of the candidate's key group
+  int32_t other_val, pad2;  // MAYBE_SWAP: latent value standing for "not one of the options"
 };
 
 // Gaussian observation with enumerated locals (pclean_gauss resolved to device pointers)
@@ -45,6 +47,9 @@ struct DensDev {
   const double* nb;
   const double* logl;
   int32_t nb_stride, pad;
+  const double* prob_same;  // log1p(-p_i)
+  const double* prob_diff;  // log(p_i)
+  const double* logn;       // log(n)
 };
 
 // Work items of one enumeration launch. Item t scores evidence row row[t]

@@ -45,6 +45,14 @@ __device__ __forceinline__ double term_density(const TermDev& tm, const DensDev&
   return l;
 }
 
+// MaybeSwap (maybe_swap.jl:13-28): o = observed value index (-1 missing), same = strings equal
+__device__ __forceinline__ double maybe_swap_density(const TermDev& tm, const DensDev& dn, int o, int d, int val, int k,
+                                                     int pidx) {
+  if (o < 0) return val == tm.other_val ? -1000.0 : 0.0;
+  if (d == 0) return dn.prob_same[pidx];
+  return dn.prob_diff[pidx] - dn.logn[tm.aux_col[k]];
+}
+
 struct ItemView {
   int row, excl;
   const int32_t* ctxv;
@@ -105,6 +113,13 @@ __device__ __forceinline__ double candidate_score_ev(const NodeDev& nd, const De
     for (int ti = 0; ti < nd.n_terms; ++ti) {
       const TermDev& tm = nd.terms[ti];
       const int o = tm.obs_col[row];
+      if (tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP) {
+        const int val = tm.cand_col[k];
+        const int c = tm.ctx_mode == 0 ? v.ctxv[tm.ctx_slot] : it.ev_ctx[(size_t)e * PCLEAN_MAX_CTX + tm.ctx_slot];
+        const int d = o < 0 ? 1 : (int)tm.pair[(size_t)o * tm.n_lat + val];
+        sk += maybe_swap_density(tm, dn, o, d, val, k, c);
+        continue;
+      }
       if (o < 0) continue;
       int val = tm.cand_col[k];
       if (tm.ctx_slot >= 0) {
@@ -345,7 +360,7 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
   if (it.n <= 0) return PCLEAN_OK;
   const int nc = nd.n_cand + (nd.kind == PCLEAN_NODE_FK ? 1 : 0);
   const size_t lds = (size_t)((nc + 1) & ~1) * 8 + (16 + 64) * 8;
-  DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0};
+  DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
   // a launch may not exceed 2^32 threads: chunk the items (grid = chunk, 256 lanes each)
   const int kMaxBlocks = 4 * 1024 * 1024;
   if (lds > 160 * 1024) {

@@ -357,7 +357,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   const int rounds = (nslots + 1023) / 1024;
   int T = ((nslots + rounds - 1) / rounds + 63) / 64 * 64;
   T = std::max(256, std::min(1024, T));
-  DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0};
+  DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, nullptr, nullptr, nullptr};
   fast_kernel_t kern = pick_kernel(fr.n_terms);
   HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   const int kMaxBlocks = 2 * 1024 * 1024;  // < 2^32 threads per launch

@@ -146,6 +146,58 @@ __global__ void expand_ctx_kernel(size_t n_slots, int P, const int32_t* rep, con
   w[s] += lse_item[item];
 }
 
+// ---- pure scoring block (flights Obs block 3): p += logdensity(MaybeSwap, ...) ---------------------
+struct SrcDev {
+  const int32_t* pchoice;
+  const int32_t* pnewpos;
+  const int32_t* vals;
+  const int32_t* root_col;
+  int32_t n_nodes, col;
+  PlanDev plan;
+};
+__device__ __forceinline__ int src_value(const SrcDev& s, size_t slot) {
+  const int choice = s.pchoice[slot];
+  if (choice >= 0) return s.root_col[choice];
+  return resolve_new_value(s.plan, 0, s.col, s.vals + (size_t)s.pnewpos[slot] * s.n_nodes);
+}
+struct ScoreTermDev {
+  const int32_t* obs_col;
+  const uint8_t* pair;
+  const int32_t* nopt_fn;
+  int32_t n_lat, other_val;
+  SrcDev val, key;
+};
+struct ScoreBlockDev {
+  int32_t n_terms, prob_nb;
+  const int32_t* prob_fn;
+  const double* prob_same;
+  const double* prob_diff;
+  const double* logn;
+  SrcDev pa, pb;
+  ScoreTermDev t[8];
+};
+__global__ void score_block_kernel(int n_rows, int P, ScoreBlockDev sb, double* w) {
+  size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= (size_t)n_rows * P) return;
+  const int i = (int)(slot / P);
+  const int pidx = sb.prob_fn[(size_t)src_value(sb.pa, slot) * sb.prob_nb + src_value(sb.pb, slot)];
+  double acc = 0.0;
+  for (int k = 0; k < sb.n_terms; ++k) {
+    const ScoreTermDev& t = sb.t[k];
+    const int val = src_value(t.val, slot);
+    const int o = t.obs_col[i];
+    double dens;
+    if (o < 0)
+      dens = val == t.other_val ? -1000.0 : 0.0;
+    else if (t.pair[(size_t)o * t.n_lat + val] == 0)
+      dens = sb.prob_same[pidx];
+    else
+      dens = sb.prob_diff[pidx] - sb.logn[t.nopt_fn[src_value(t.key, slot)]];
+    acc += dens;
+  }
+  w[slot] += acc;
+}
+
 // root draws [n_rows][P] (or [n_rows*P][1]) -> particle choices; particle 0 keeps
 // the retained referent under CSMC (row_inference.jl:143-145)
 __global__ void set_pchoice_kernel(int n_rows, int P, const int32_t* draws, const int32_t* cur_b, int32_t* pchoice) {
@@ -621,6 +673,17 @@ static int build_node_dev(pclean_ctx* ctx, const Block& b, int node_id, NodeDev&
     td.ctx_slot = tm.ctx_slot;
     td.fn = nullptr;
     td.fn_nb = 0;
+    td.aux_col = nullptr;
+    td.other_val = -1;
+    td.pad2 = 0;
+    if (tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP) {
+      if (tm.max_typos < 0 || tm.max_typos >= t.n_cols || tm.ctx_slot < 0 || ctx->n_prob == 0)
+        return pclean_fail(ctx, PCLEAN_ERR_ARG, "MaybeSwap term %d: needs an option-count column, a ctx slot and a prob table",
+                           n.term_begin + i);
+      td.aux_col = t.cols.p + (size_t)tm.max_typos * t.n_rows;
+      td.other_val = tm.fn_table;
+      continue;
+    }
     if (tm.ctx_slot >= 0) {
       const FnTable& f = ctx->fn[tm.fn_table];
       if (!f.valid) return pclean_fail(ctx, PCLEAN_ERR_STATE, "fn table %d not set", tm.fn_table);
@@ -1184,6 +1247,46 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   for (int bi = 0; bi < n_blocks; ++bi) {
     Block& b = ctx->block[bi];
     BlockRun& r = s->run[bi];
+    if (b.is_score) {
+      // pure scoring block: every particle's weight += sum of its observed choices' log-densities
+      if (bi != n_blocks - 1) return pclean_fail(ctx, PCLEAN_ERR_ARG, "a scoring block must be the last block");
+      ScoreBlockDev sb{};
+      auto make_src = [&](int blk, int col, SrcDev& out) -> int {
+        if (blk < 0 || blk >= bi || ctx->block[blk].is_score) return pclean_fail(ctx, PCLEAN_ERR_ARG, "score block: bad source block");
+        const CandTable& rt = ctx->cand[ctx->block[blk].nodes[0].table];
+        if (col < 0 || col >= rt.n_cols) return pclean_fail(ctx, PCLEAN_ERR_ARG, "score block: bad source column");
+        out = SrcDev{s->run[blk].pchoice.p, s->run[blk].pnewpos.p, s->run[blk].vals.p, rt.cols.p + (size_t)col * rt.n_rows,
+                     (int)ctx->block[blk].nodes.size(), col, s->run[blk].plan};
+        return 0;
+      };
+      const FnTable& pf = ctx->fn[b.prob_fn];
+      if (!pf.valid || ctx->n_prob == 0) return pclean_fail(ctx, PCLEAN_ERR_STATE, "score block: prob fn / prob table not set");
+      sb.n_terms = (int)b.score_terms.size();
+      sb.prob_nb = pf.n_b;
+      sb.prob_fn = pf.fn.p;
+      sb.prob_same = ctx->prob_same.p;
+      sb.prob_diff = ctx->prob_diff.p;
+      sb.logn = ctx->logn.p;
+      int rc2 = make_src(b.prob_a_block, b.prob_a_col, sb.pa);
+      if (!rc2) rc2 = make_src(b.prob_b_block, b.prob_b_col, sb.pb);
+      for (int k = 0; k < sb.n_terms && !rc2; ++k) {
+        const ScoreTerm& st_ = b.score_terms[k];
+        const PairTable& pt = ctx->pair[st_.pair_table];
+        const FnTable& nf = ctx->fn[st_.nopt_fn];
+        if (!pt.valid || !nf.valid || st_.obs_col < 0 || st_.obs_col >= ctx->n_cols)
+          return pclean_fail(ctx, PCLEAN_ERR_ARG, "score block: term %d malformed", k);
+        sb.t[k].obs_col = ctx->obs.p + (size_t)st_.obs_col * ctx->n_rows + ctx->active_begin;
+        sb.t[k].pair = pt.d.p;
+        sb.t[k].n_lat = pt.n_lat;
+        sb.t[k].nopt_fn = nf.fn.p;
+        sb.t[k].other_val = st_.other_val;
+        rc2 = make_src(st_.val_block, st_.val_col, sb.t[k].val);
+        if (!rc2) rc2 = make_src(st_.key_block, st_.key_col, sb.t[k].key);
+      }
+      if (rc2) return rc2;
+      hipLaunchKernelGGL(score_block_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, sb, s->w.p);
+      continue;
+    }
     const int nn = (int)b.nodes.size();
     const int32_t* cur_b = s->cur.p + (size_t)bi * N;
     if (r.pchoice.alloc(NP) || r.pnewpos.alloc(NP) || r.choice.alloc(N) || r.chosen_newpos.alloc(N))
@@ -1307,6 +1410,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
                          s->logml_acc.p);
       std::vector<int32_t*> ptrs;
       for (int k = 0; k <= bi; ++k) {
+        if (ctx->block[k].is_score) continue;
         ptrs.push_back(s->run[k].pchoice.p);
         ptrs.push_back(s->run[k].pnewpos.p);
       }
@@ -1326,6 +1430,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   for (int bi = 0; bi < n_blocks; ++bi) {
     BlockRun& r = s->run[bi];
     const int32_t* cur_b = s->cur.p + (size_t)bi * N;
+    if (ctx->block[bi].is_score) {
+      for (int i = 0; i < N; ++i) choice[(size_t)bi * N + i] = 0;
+      continue;
+    }
     hipLaunchKernelGGL(select_choice_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->chosen.p, r.pchoice.p,
                        r.pnewpos.p, r.choice.p, r.chosen_newpos.p);
     CandTable& rt = ctx->cand[ctx->block[bi].nodes[0].table];
@@ -1359,7 +1467,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     const int nn = (int)b.nodes.size();
     b.new_rows_host.clear();
     b.new_vals_host.clear();
-    if (r.n_new == 0) continue;
+    if (b.is_score || r.n_new == 0) continue;
     int32_t* flag = scratch<int32_t>(ctx, N);
     if (!flag) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
     hipLaunchKernelGGL(mark_new_kernel, grid1(N), dim3(256), 0, ctx->stream, N, r.chosen_newpos.p, flag);

@@ -2,12 +2,17 @@
 rejuvenation sweeps of the observed class (pgibbs_sweep!'s loop over the rows of
 the observed class, src/inference/inference.jl:60-81 + row_inference.jl:108-187).
 """
+import re
+
 import numpy as np
 
 from . import _lib
 from ._lib import HipContext, InferConfig
 from .encode import lm_log_tables
-from .model import ChooseProportionally, ChooseUniformly, StringPrior, Unmodeled
+from .model import ChooseProportionally, ChooseUniformly, StringPrior, TimePrior, Unmodeled
+
+# time_prior.jl:10 — atoms matching this pattern score -log(1440), everything else -Inf
+_TIME_RE = re.compile(r"^[0-9]?[0-9]:[0-9][0-9] [ap]\.m\.$")
 
 
 def make_gauss(spec, mean_table_id=0):
@@ -85,6 +90,8 @@ class Engine:
             hip.set_fn_table(fid, fn)
         for key, (pid, n) in lw.eq_pairs.items():  # equality constraints: 0 on the diagonal, 1 elsewhere
             hip.set_pair_table(pid, (1 - np.eye(n, dtype=np.uint8)))
+        for pid in lw.same_pairs:  # MaybeSwap: 0 iff the observed string is the latent value
+            hip.set_pair_table(pid, lw.same_pair_table(pid))
         if getattr(lw, "xnum", None) is not None and lw.xnum.shape[0]:
             hip.load_numeric_columns(lw.xnum)
         init_l, trans_l = lm_log_tables()
@@ -92,6 +99,20 @@ class Engine:
         for (cname, aname), dom in lw.latent_dom.items():
             d = m.classes[cname].attr(aname).dist
             tid = lw.option_id[(cname, aname)]
+            if isinstance(d, TimePrior):
+                # per key: its atoms' scores + that key's dummy mass (time_prior.jl:8-22)
+                vals = lw.option_values[(cname, aname)]
+                keys = lw.option_keycol[(cname, aname)]
+                dummy = dom.get(d.dummy_value())
+                scores = np.array([-np.log(1440.0) if _TIME_RE.match(dom.string(v)) else -np.inf for v in vals])
+                logp = scores.copy()
+                for k in np.unique(keys):
+                    sel = (keys == k) & (vals != dummy)
+                    with np.errstate(divide="ignore"):
+                        logp[(keys == k) & (vals == dummy)] = np.log1p(-np.exp(_logsumexp(scores[sel])))
+                self.option_logp[(cname, aname)] = logp
+                hip.set_options_cols(tid, np.stack([vals, keys, lw.option_ncol[(cname, aname)]]), logp)
+                continue
             if d is None or isinstance(d, Unmodeled) or not isinstance(d, (StringPrior, ChooseUniformly, ChooseProportionally)):
                 if cname == lw.query.cls:
                     continue  # own choices of the observed class are enumerated as locals, not as leaves
@@ -133,10 +154,7 @@ class Engine:
                 raise NotImplementedError(type(d))
             self.option_logp[(cname, aname)] = logp
             hip.set_options(tid, lw.option_values[(cname, aname)], logp)
-        for bi in range(len(lw.blocks)):
-            hip.load_block(bi, *lw.block_arrays(bi))
-        for cname, pl in lw.latent_plans.items():
-            hip.load_block(pl["block_id"], *lw.latent_block_arrays(cname))
+        lw.load_blocks_into(hip)
         self._gauss_pending = bool(getattr(lw, "gauss", {}))
 
     # -- dynamic data ---------------------------------------------------------
@@ -159,6 +177,8 @@ class Engine:
                     logp = np.log(trace.params[(cname, d.param)].value)  # logprobs(), utils.jl:33-36
                 self.option_logp[(cname, aname)] = logp
                 hip.set_options(lw.option_id[(cname, aname)], lw.option_values[(cname, aname)], logp)
+        if lw.prob_spec is not None:
+            hip.set_prob_table(trace.prob_table())
         if getattr(lw, "gauss", None):
             hip.set_mean_table(0, trace.mean_param.value)
             if self._gauss_pending:  # needs the mean table to exist
@@ -171,6 +191,8 @@ class Engine:
         choice, chosen, logml = self.hip.sweep(cfg, seed, sweep_idx, trace.cur)
         new_rows = {}
         for bi, blk in enumerate(self.lw.blocks):
+            if blk.get("score"):
+                continue
             rows, vals = self.hip.get_new_rows(bi, len(blk["nodes"]))
             if len(rows):
                 new_rows[bi] = (rows, vals)
@@ -182,4 +204,4 @@ class Engine:
     def sweep_stats(self, trace):
         """Delta reference counts of the last sweep per block root table (the all-reduce payload)."""
         return {bi: self.hip.get_stats(self.lw.table_id[blk["root_class"]], trace.tables[blk["root_class"]].n)
-                for bi, blk in enumerate(self.lw.blocks)}
+                for bi, blk in enumerate(self.lw.blocks) if not blk.get("score")}

@@ -152,3 +152,62 @@ def rents_query(m):
         "Room Type": "br",
         "Monthly Rent": ("corrected", "rent"),
     })
+
+
+# ---------------------------------------------------------------------------
+# flights: /root/reference/experiments/flights/{load_data,run}.jl
+FLIGHT_FIELDS = ["sched_dep_time", "sched_arr_time", "act_dep_time", "act_arr_time"]
+
+
+def flights_data():
+    dirty = load_table(os.path.join(DATA_DIR, "flights_dirty.csv"))
+    clean = load_table(os.path.join(DATA_DIR, "flights_clean.csv"))
+    return dirty, clean
+
+
+def flights_model(dirty):
+    """experiments/flights/run.jl:5-36 (+ load_data.jl:9-17)."""
+    from .model import IndexedProbParameter, MaybeSwap, ProbLookup, TimePrior
+    flight_ids = list(dict.fromkeys(dirty["flight"]))
+    websites = list(dict.fromkeys(dirty["src"]))
+    times = {f: {fl: [] for fl in flight_ids} for f in FLIGHT_FIELDS}
+    for i, fl in enumerate(dirty["flight"]):
+        for f in FLIGHT_FIELDS:
+            v = dirty[f][i]
+            if v is not None and v not in times[f][fl]:
+                times[f][fl].append(v)
+    m = Model()
+    w = m.add_class("TrackingWebsite")
+    w.choice("name", StringPrior(2, 30, websites))
+    fl = m.add_class("Flight")
+    with fl.block():
+        fl.choice("flight_id", StringPrior(10, 20, flight_ids))
+    fl.choice("sdt", TimePrior(times["sched_dep_time"], "flight_id"))
+    fl.choice("sat", TimePrior(times["sched_arr_time"], "flight_id"))
+    fl.choice("adt", TimePrior(times["act_dep_time"], "flight_id"))
+    fl.choice("aat", TimePrior(times["act_arr_time"], "flight_id"))
+    o = m.add_class("Obs")
+    o.param("error_probs", IndexedProbParameter(10.0, 50.0))
+    with o.block():
+        o.fk("flight", "Flight")
+    o.fk("src", "TrackingWebsite")
+    o.julia("error_prob", ProbLookup("error_probs", lambda src, fid: 1e-5 if src.lower() == fid[:2].lower() else src),
+            ["src.name", "flight.flight_id"])
+    with o.block():
+        o.choice("sdt", MaybeSwap("flight.sdt", times["sched_dep_time"], "flight.flight_id", "error_prob"))
+        o.choice("sat", MaybeSwap("flight.sat", times["sched_arr_time"], "flight.flight_id", "error_prob"))
+        o.choice("adt", MaybeSwap("flight.adt", times["act_dep_time"], "flight.flight_id", "error_prob"))
+        o.choice("aat", MaybeSwap("flight.aat", times["act_arr_time"], "flight.flight_id", "error_prob"))
+    return m
+
+
+def flights_query(m):
+    """experiments/flights/run.jl:38-45."""
+    return Query(m, "Obs", {
+        "sched_dep_time": ("flight.sdt", "sdt"),
+        "sched_arr_time": ("flight.sat", "sat"),
+        "act_dep_time": ("flight.adt", "adt"),
+        "act_arr_time": ("flight.aat", "aat"),
+        "flight": "flight.flight_id",
+        "src": "src.name",
+    })

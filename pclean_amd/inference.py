@@ -61,6 +61,9 @@ def build_evidence(lw, trace, cname):
         vals = trace.tables[rc].cols[lw.colidx[rc][path], trace.cur[ob]]
         ev_ctx = np.zeros((len(ev_rows), 2), dtype=np.int32)
         ev_ctx[:, 0] = vals[ev_rows]
+    if cname in lw.latent_ev_prob:  # MaybeSwap external likelihood: the rows' error-probability index
+        ev_ctx = np.zeros((len(ev_rows), 2), dtype=np.int32)
+        ev_ctx[:, 0] = trace.prob_index()[ev_rows]
     if cname in getattr(lw, "latent_ev_locals", {}):  # Gaussian external likelihood: the rows' own choices
         ev_ctx = np.ascontiguousarray(trace.locals[lw.latent_ev_locals[cname]][ev_rows]).astype(np.int32)
     return live, ev_off, ev_rows, ev_ctx
@@ -221,6 +224,8 @@ def initialize_trace(engine, trace, config, seed, max_batch=256):
         choice, chosen, logml = engine.hip.sweep(config.as_c(), seed, 0x7fffffff, cur)
         new_rows = {}
         for bi, blk in enumerate(lw.blocks):
+            if blk.get("score"):
+                continue
             rows, vals = engine.hip.get_new_rows(bi, len(blk["nodes"]))
             if len(rows):
                 new_rows[bi] = (rows, vals)

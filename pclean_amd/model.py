@@ -58,6 +58,42 @@ class AddTypos:
         self.ref, self.max_typos = ref, max_typos
 
 
+class TimePrior:
+    """time_prior.jl: TimePrior(proposal_atoms); atoms keyed by another attribute of the class
+    (`times_for_flight["$flight_id-field"]`, experiments/flights/run.jl:17-20)."""
+    keyed = True
+
+    def __init__(self, atoms, keyed_by):
+        self.atoms = {k: list(v) for k, v in atoms.items()}
+        self.keyed_by = keyed_by
+
+    def dummy_value(self):  # time_prior.jl:17-19
+        return "**:** p.m."
+
+
+class MaybeSwap:
+    """maybe_swap.jl: MaybeSwap(val, options, prob). `val` references the clean value, `options`
+    are keyed by the value of `key` (same dict as the TimePrior atoms), `prob` names a ProbLookup."""
+
+    def __init__(self, val, options, key, prob):
+        self.val, self.options, self.key, self.prob = val, {k: list(v) for k, v in options.items()}, key, prob
+
+
+class IndexedProbParameter:
+    """`@learned x::Dict{String, ProbParameter{a, b}}` (maybe_swap.jl:36-52)."""
+
+    def __init__(self, a, b):
+        self.a, self.b = float(a), float(b)
+
+
+class ProbLookup:
+    """Deterministic node choosing an error probability: fn(*args) returns a float constant or the
+    key of the indexed ProbParameter (experiments/flights/run.jl:28)."""
+
+    def __init__(self, param, fn):
+        self.param, self.fn = param, fn
+
+
 class Unmodeled:
     """unmodeled.jl: logdensity 0, no proposal; must be observed."""
 
@@ -227,9 +263,12 @@ class LoweredModel:
         self._next_pair = 0
         self.cross_terms = []
         self.eq_pairs = {}
+        self.same_pairs = {}   # pair id -> (observed domain, latent domain): 0 iff same string
+        self.prob_spec = None
         self.gauss = {}        # (block id, node id) -> dict spec (resolved by the engine)
         self.locals = {}       # block index -> [own ChooseUniformly attrs enumerated with the Gaussian]
         self.latent_ev_locals = {}  # latent class -> block index whose locals feed the evidence ctx
+        self.latent_ev_prob = {}    # latent class -> scoring block whose error-prob index feeds the evidence ctx
         self.latent_plans = {}
         self._build_domains(dirty_columns)
         self._build_layouts()
@@ -244,7 +283,7 @@ class LoweredModel:
                 if a.kind != "choice":
                     continue
                 d = a.dist
-                if isinstance(d, StringPrior) and d.keyed_by:
+                if (isinstance(d, StringPrior) and d.keyed_by) or isinstance(d, TimePrior):
                     dom = Domain(self.pool)
                     for k, atoms in d.atoms.items():
                         for s_ in atoms:
@@ -268,7 +307,7 @@ class LoweredModel:
             own = None
             if "." not in dirty:
                 own = ocls.attr(dirty)
-            if own is not None and own.kind == "choice" and isinstance(own.dist, AddTypos):
+            if own is not None and own.kind == "choice" and isinstance(own.dist, (AddTypos, MaybeSwap)):
                 vals = [v for v in dirty_columns[col] if v is not None]
                 self.obs_dom[dirty] = Domain(self.pool, list(dict.fromkeys(vals)))
             elif own is not None and own.kind == "choice" and isinstance(own.dist, TransformedGaussian):
@@ -305,6 +344,7 @@ class LoweredModel:
             dom = self.obs_dom[dirty]
             col = dirty_columns[self.query_columns[dirty]]
             obs[j] = [(-1 if v is None else dom.get(v)) for v in col]
+        self.obs_host = obs  # host copy for the sufficient statistics of observation-level parameters
         return obs
 
     # -- layouts ------------------------------------------------------------
@@ -327,6 +367,7 @@ class LoweredModel:
             self._next_table += 1
         self.option_values = {}
         self.option_keycol = {}
+        self.option_ncol = {}
         for (cname, aname), dom in self.latent_dom.items():
             self.option_id[(cname, aname)] = self._next_table
             self._next_table += 1
@@ -336,7 +377,7 @@ class LoweredModel:
             if cname in self.model.classes:
                 a = self.model.classes[cname].attr(aname)
                 d = getattr(a, "dist", None)
-                if isinstance(d, StringPrior) and d.keyed_by:
+                if (isinstance(d, StringPrior) and d.keyed_by) or isinstance(d, TimePrior):
                     # options = for every key: its atoms, then one dummy option; column 1 = key index
                     kdom = self.latent_dom[(cname, d.keyed_by)]
                     vals, keys = [], []
@@ -350,6 +391,9 @@ class LoweredModel:
                         keys.append(ki)
                     self.option_values[(cname, aname)] = np.array(vals, dtype=np.int32)
                     self.option_keycol[(cname, aname)] = np.array(keys, dtype=np.int32)
+                    # column 2: number of atoms of the option's key group (MaybeSwap's length(options))
+                    nk = {kdom.get(k): len(atoms) for k, atoms in d.atoms.items()}
+                    self.option_ncol[(cname, aname)] = np.array([nk[k] for k in keys], dtype=np.int32)
 
     # -- plans --------------------------------------------------------------
     def _obs_terms_of_block(self, ocls, names):
@@ -381,13 +425,20 @@ class LoweredModel:
         ocls = m.classes[self.query.cls]
         root_of_block = []
         fk_block = {}
+        self.score_blocks = {}
         for bi, names in enumerate(ocls.blocks):
             fks = [n for n in names if ocls.attr(n).kind == "fk"]
-            if len(fks) != 1:
-                raise NotImplementedError("each observed-class block must hold exactly one reference slot (so far)")
-            root_of_block.append(fks[0])
-            fk_block[fks[0]] = bi
+            if len(fks) > 1:
+                raise NotImplementedError("at most one reference slot per observed-class block (so far)")
+            root_of_block.append(fks[0] if fks else None)
+            if fks:
+                fk_block[fks[0]] = bi
         for bi, names in enumerate(ocls.blocks):
+            if root_of_block[bi] is None:
+                self._lower_score_block(bi, ocls, names, fk_block)
+                self.blocks.append(dict(score=True, nodes=[], terms=[], children=[], colmap=[], node_info=[],
+                                        root_class=None, root_fk=None, ctx_src_block=[], ctx_src_col=[]))
+                continue
             root_fk = ocls.attr(root_of_block[bi])
             blk = dict(nodes=[], terms=[], children=[], colmap=[], ctx_src_block=[], ctx_src_col=[],
                        root_class=root_fk.target, root_fk=root_fk.name, node_info=[])
@@ -488,15 +539,15 @@ class LoweredModel:
                 for t in sub:
                     self._emit_term(blk, t, 0)
                 n_leaf_terms = len(sub)
-                if isinstance(a.dist, StringPrior) and a.dist.keyed_by:
+                if (isinstance(a.dist, StringPrior) and a.dist.keyed_by) or isinstance(a.dist, TimePrior):
                     # atoms belong to the key they were listed under: the option's key must equal the
                     # (directly observed) key of this row
                     kt = [t for t in terms if t["path"] == a.dist.keyed_by and t.get("dens") == _lib.DENS_EQUAL]
                     if len(kt) != 1:
-                        raise NotImplementedError("a keyed StringPrior needs its key attribute observed directly")
+                        raise NotImplementedError("keyed atoms need their key attribute observed directly")
                     self._emit_term(blk, kt[0], 1)
                     n_leaf_terms += 1
-                cacheable = int(n_leaf_terms == 1 and sub[0]["ctx"] is None)
+                cacheable = int(n_leaf_terms == 1 and len(sub) == 1 and sub[0]["ctx"] is None)
                 blk["nodes"].append((_lib.NODE_LEAF, self.option_id[(cname, a.name)], ltb, n_leaf_terms, 0, 0, nid, -1,
                                      cacheable, 0, 0, 0))
                 blk["node_info"].append(dict(kind="leaf", cls=cname, attr=a.name, path=prefix + a.name))
@@ -510,6 +561,91 @@ class LoweredModel:
         blk["nodes"][nid] = (_lib.NODE_FK, self.table_id[cname], tb, nt, cb, len(kids), parent, parent_fk_col, 0, cmb,
                              0, 0)
         return nid
+
+    def score_block_args(self, bi):
+        """Arguments of pclean_load_score_block for scoring block bi."""
+        sb = self.score_blocks[bi]
+        t, pr = sb["terms"], sb["prob"]
+        return (bi, [x["obs"] for x in t], [x["pair"] for x in t], [c for x in t for c in x["val"]],
+                [c for x in t for c in x["key"]], [x["nopt_fn"] for x in t], [x["other"] for x in t], pr["fn"],
+                list(pr["a"]), list(pr["b"]))
+
+    def load_blocks_into(self, target):
+        """Upload every block plan (observed-class blocks, scoring blocks, latent-class plans) into an
+        object exposing load_block / load_score_block (the HIP context or the oracle world)."""
+        for bi, blk in enumerate(self.blocks):
+            if blk.get("score"):
+                target.load_score_block(*self.score_block_args(bi))
+            else:
+                target.load_block(bi, *self.block_arrays(bi))
+        for cname, pl in self.latent_plans.items():
+            target.load_block(pl["block_id"], *self.latent_block_arrays(cname))
+
+    def same_pair_table(self, pid):
+        odom, vdom = self.same_pairs[pid]
+        return (odom.id_array()[:, None] != vdom.id_array()[None, :]).astype(np.uint8)
+
+    def _lower_score_block(self, bi, ocls, names, fk_block):
+        """Block without a reference slot: MaybeSwap observations of values chosen in earlier blocks
+        (experiments/flights/run.jl:29-34)."""
+        m = self.model
+        terms = []
+        prob_spec = None
+        for n in names:
+            a = ocls.attr(n)
+            if a.kind != "choice":
+                continue
+            if not isinstance(a.dist, MaybeSwap):
+                raise NotImplementedError("a block without a reference slot may only hold MaybeSwap observations")
+            vh, vrest = a.dist.val.split(".", 1)
+            kh, krest = a.dist.key.split(".", 1)
+            vcls, vattr = m.resolve(ocls.attr(vh).target, vrest)
+            kcls, kattr = m.resolve(ocls.attr(kh).target, krest)
+            vdom, kdom = self.latent_dom[(vcls, vattr.name)], self.latent_dom[(kcls, kattr.name)]
+            # 0/1 "same string" table between the observed values and the latent domain
+            odom = self.obs_dom[n]
+            pid = self._next_pair
+            self._next_pair += 1
+            self.same_pairs[pid] = (odom, vdom)
+            nopt = np.ones((len(kdom), 1), dtype=np.int32)
+            for k, opts in a.dist.options.items():
+                if kdom.get(k) >= 0:
+                    nopt[kdom.get(k), 0] = len(opts)
+            fid = len(self.fn_tables)
+            self.fn_tables[fid] = nopt
+            terms.append(dict(obs=self.obs_index[n], pair=pid, val=(fk_block[vh], self.colidx[ocls.attr(vh).target][vrest]),
+                              key=(fk_block[kh], self.colidx[ocls.attr(kh).target][krest]), nopt_fn=fid,
+                              other=vdom.get(vattr.dist.dummy_value()), attr=n, val_ref=a.dist.val))
+            pl = ocls.attr(a.dist.prob)
+            if pl.kind != "julia" or not isinstance(pl.fn, ProbLookup):
+                raise NotImplementedError("MaybeSwap prob must be a ProbLookup")
+            if prob_spec is None:
+                (ah, arest), (bh, brest) = [x.split(".", 1) for x in pl.args]
+                acls, aattr = m.resolve(ocls.attr(ah).target, arest)
+                bcls, battr = m.resolve(ocls.attr(bh).target, brest)
+                adom, bdom = self.latent_dom[(acls, aattr.name)], self.latent_dom[(bcls, battr.name)]
+                keys, consts = [], []
+                pf = np.zeros((len(adom), len(bdom)), dtype=np.int32)
+                for x in range(len(adom)):
+                    for y in range(len(bdom)):
+                        r = pl.fn.fn(adom.string(x), bdom.string(y))
+                        if isinstance(r, float):
+                            if r not in consts:
+                                consts.append(r)
+                            pf[x, y] = consts.index(r)
+                        else:
+                            if r not in keys:
+                                keys.append(r)
+                            pf[x, y] = -1 - keys.index(r)
+                # prob table layout: constants first, then one entry per parameter key
+                pf = np.where(pf < 0, len(consts) + (-1 - pf), pf).astype(np.int32)
+                pfid = len(self.fn_tables)
+                self.fn_tables[pfid] = pf
+                prob_spec = dict(fn=pfid, a=(fk_block[ah], self.colidx[ocls.attr(ah).target][arest]),
+                                 b=(fk_block[bh], self.colidx[ocls.attr(bh).target][brest]), consts=consts, keys=keys,
+                                 param=(self.query.cls, pl.fn.param))
+        self.score_blocks[bi] = dict(terms=terms, prob=prob_spec)
+        self.prob_spec = prob_spec
 
     def _lower_gaussian(self, bi, blk, ocls, names, root_fk):
         """`x ~ TransformedGaussian(param[f(root values, own choices)], std, unit)` with own
@@ -593,6 +729,8 @@ class LoweredModel:
         with evidence sets instead of a single row."""
         next_block = len(self.blocks)
         for bi, blk in enumerate(self.blocks):
+            if blk.get("score"):
+                continue
             for nid, info in enumerate(blk["node_info"]):
                 if info["kind"] != "fk" or info["cls"] in self.latent_plans:
                     continue
@@ -633,6 +771,13 @@ class LoweredModel:
                 continue
             plan["terms"].append((self.obs_index[ct["obs"]], col, ct["pair"], _lib.DENS_ADD_TYPOS,
                                   -1 if ct["max_typos"] is None else int(ct["max_typos"]), 0, ct["fn"], 2))
+        # MaybeSwap observations (scoring blocks) of this value: external likelihood of the referring rows,
+        # each with its own error probability (evidence ctx slot 0 = index into the prob table)
+        for sbi, sb in getattr(self, "score_blocks", {}).items():
+            for t in sb["terms"]:
+                if info["kind"] == "leaf" and t["val"][0] == bi and t["val_ref"].split(".", 1)[1] == info["path"]:
+                    plan["terms"].append((t["obs"], 0, t["pair"], _lib.DENS_MAYBE_SWAP, 2, 0, t["other"], 1))
+                    self.latent_ev_prob[plan["cls"]] = sbi
         nt = len(plan["terms"]) - tb
         if (bi, nid) in self.gauss and info["kind"] == "leaf":
             # latent sweep of the class owning this value: external likelihood of the referring rows'

@@ -80,6 +80,8 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
     Returns the global number of rows whose referent changed."""
     changed = 0
     for bi, blk in enumerate(lowered.blocks):
+        if blk.get("score"):
+            continue
         cname = blk["root_class"]
         t = trace.tables[cname]
         nn = len(blk["nodes"])

@@ -46,6 +46,18 @@ class MeanTableState:
         self.value = rng.normal(mean, np.sqrt(var))
 
 
+class ProbTableState:
+    """Dict{String, ProbParameter{a, b}} (maybe_swap.jl:36-52): one Beta-Bernoulli error probability per key;
+    heads = the observation differs from the clean value.  Eager initialisation from the prior."""
+
+    def __init__(self, n_keys, a, b, rng):
+        self.a, self.b = a, b
+        self.value = rng.beta(a, b, size=n_keys)
+
+    def resample(self, rng, heads, tails):  # resample_value!, maybe_swap.jl:50-52
+        self.value = rng.beta(self.a + heads, self.b + tails)
+
+
 class LatentTable:
     def __init__(self, n_cols, strength=1.0, discount=0.0, cap=16):
         self.n_cols = n_cols
@@ -95,10 +107,48 @@ class Trace:
         self.locals = {bi: np.full((n_rows, 2), -1, dtype=np.int32) for bi in getattr(lowered, "locals", {})}
         self.pending_locals = {}
         self.mean_param = None
+        self.prob_param = None
+        if lowered.prob_spec is not None:
+            pp = m.classes[lowered.prob_spec["param"][0]].attr(lowered.prob_spec["param"][1]).prior
+            self.prob_param = ProbTableState(len(lowered.prob_spec["keys"]), pp.a, pp.b, self.rng)
         spec = getattr(lowered, "gauss_spec", None)
         if spec is not None:
             prior = m.classes[spec["param"][0]].attr(spec["param"][1]).prior
             self.mean_param = MeanTableState(spec["n_mean"], prior.mean, prior.std, spec["sigma"], self.rng)
+
+    # -- MaybeSwap error probabilities -------------------------------------------------------------
+    def _root_values(self, src):
+        bi, col = src
+        t = self.tables[self.lw.blocks[bi]["root_class"]]
+        return t.cols[col, np.maximum(self.cur[bi], 0)]
+
+    def prob_index(self):
+        """Index into prob_table() of every observed row's error probability (the JuliaNode `error_prob`)."""
+        pr = self.lw.prob_spec
+        return self.lw.fn_tables[pr["fn"]][self._root_values(pr["a"]), self._root_values(pr["b"])]
+
+    def prob_table(self):
+        return np.concatenate([np.asarray(self.lw.prob_spec["consts"], dtype=np.float64), self.prob_param.value])
+
+    def resample_prob_param(self):
+        """heads/tails of every parameter key from the current trace (update_sufficient_statistics!
+        of MaybeSwap, maybe_swap.jl:44-48), then the conjugate Beta draw."""
+        lw = self.lw
+        pr = lw.prob_spec
+        nc = len(pr["consts"])
+        pidx = self.prob_index()
+        assigned = np.all(self.cur[[b for b, blk in enumerate(lw.blocks) if not blk.get("score")]] >= 0, axis=0)
+        heads = np.zeros(len(pr["keys"]), dtype=np.int64)
+        tails = np.zeros(len(pr["keys"]), dtype=np.int64)
+        for sb in lw.score_blocks.values():
+            for t in sb["terms"]:
+                o = lw.obs_host[t["obs"]]
+                v = self._root_values(t["val"])
+                ok = assigned & (o >= 0) & (pidx >= nc)
+                same = lw.same_pair_table(t["pair"])[np.maximum(o, 0), v] == 0
+                heads += np.bincount(pidx[ok & ~same] - nc, minlength=len(heads))
+                tails += np.bincount(pidx[ok & same] - nc, minlength=len(tails))
+        self.prob_param.resample(self.rng, heads, tails)
 
     def commit_locals(self, begin=0, count=None):
         for bi, loc in self.pending_locals.items():
@@ -208,6 +258,8 @@ class Trace:
         new_rows[b] = (rows, vals[n][n_nodes]).  Returns the number of changed referents."""
         changed = 0
         for bi, blk in enumerate(self.lw.blocks):
+            if blk.get("score"):
+                continue
             cname = blk["root_class"]
             t = self.tables[cname]
             ch = np.array(choice[bi], dtype=np.int64)
@@ -234,6 +286,8 @@ class Trace:
         lw = self.lw
         want = {c: np.zeros(t.n, dtype=np.int64) for c, t in self.tables.items()}
         for bi, blk in enumerate(lw.blocks):
+            if blk.get("score"):
+                continue
             cur = self.cur[bi]
             cur = cur[cur >= 0]
             want[blk["root_class"]] += np.bincount(cur, minlength=self.tables[blk["root_class"]].n)
@@ -267,6 +321,9 @@ class Trace:
         referent before).  With dedup, identical new-row proposals of the batch become one row —
         the sequential reference would have let the second row join the first row's new referent."""
         for bi, blk in enumerate(self.lw.blocks):
+            if blk.get("score"):
+                self.cur[bi, begin:begin + count] = 0
+                continue
             cname = blk["root_class"]
             ch = np.array(choice[bi], dtype=np.int64)
             rows_new, vals_new = new_rows.get(bi, (np.zeros(0, np.int32), None))
@@ -292,6 +349,8 @@ class Trace:
     def resample_parameters(self):
         for p in self.params.values():
             p.resample(self.rng)
+        if self.prob_param is not None:
+            self.resample_prob_param()
         if self.mean_param is not None:
             _, idx, x = self.gaussian_index()
             self.mean_param.resample(self.rng, idx, x)
@@ -368,6 +427,9 @@ class Trace:
             return r
 
         for bi, blk in enumerate(lowered.blocks):
+            if blk.get("score"):
+                tr.cur[bi] = 0
+                continue
             cname = blk["root_class"]
             t = tr.tables[cname]
             paths = clean_by_path[bi]

@@ -88,15 +88,18 @@ def mirror_world(oracle, lw, obs, trace, engine=None, dist_mode=1, option_logp=N
         if (cname, aname) not in logps:
             continue
         if (cname, aname) in lw.option_keycol:
-            w.set_options_cols(lw.option_id[(cname, aname)],
-                               np.stack([lw.option_values[(cname, aname)], lw.option_keycol[(cname, aname)]]),
-                               logps[(cname, aname)])
+            cols = [lw.option_values[(cname, aname)], lw.option_keycol[(cname, aname)]]
+            if (cname, aname) in lw.option_ncol:
+                cols.append(lw.option_ncol[(cname, aname)])
+            w.set_options_cols(lw.option_id[(cname, aname)], np.stack(cols), logps[(cname, aname)])
         else:
             w.set_options(lw.option_id[(cname, aname)], lw.option_values[(cname, aname)], logps[(cname, aname)])
-    for bi in range(len(lw.blocks)):
-        w.load_block(bi, *lw.block_arrays(bi))
-    for cname, pl in lw.latent_plans.items():
-        w.load_block(pl["block_id"], *lw.latent_block_arrays(cname))
+    for pid in lw.same_pairs:
+        d = lw.same_pair_table(pid)
+        w.set_pair(pid, d.astype(np.uint16), np.zeros(d.shape[1], dtype=np.uint16))
+    if lw.prob_spec is not None:
+        w.set_prob(trace.prob_table())
+    lw.load_blocks_into(w)
     if getattr(lw, "gauss", None):
         from pclean_amd.engine import make_gauss
         w.set_mean(0, trace.mean_param.value)
@@ -108,13 +111,21 @@ def mirror_world(oracle, lw, obs, trace, engine=None, dist_mode=1, option_logp=N
 def option_logp_cpu(oracle, lw, trace):
     """discrete_proposal log-probabilities computed by the oracle (CPU tests)."""
     from pclean_amd.encode import load_lm_params
-    from pclean_amd.model import ChooseProportionally, ChooseUniformly, StringPrior
+    from pclean_amd.model import ChooseProportionally, ChooseUniformly, StringPrior, TimePrior
     init, trans = load_lm_params()
     _, off, lm, _ = lw.pool.arrays()
     out = {}
     for (cname, aname), dom in lw.latent_dom.items():
         d = lw.model.classes[cname].attr(aname).dist
-        if isinstance(d, StringPrior):
+        if isinstance(d, TimePrior):
+            vals, keys = lw.option_values[(cname, aname)], lw.option_keycol[(cname, aname)]
+            dummy = dom.get(d.dummy_value())
+            sc = np.array([oracle.time_prior_atom(dom.string(v)) for v in vals])
+            lp = sc.copy()
+            for k in np.unique(keys):
+                lp[(keys == k) & (vals == dummy)] = oracle.dummy_logmass(sc[(keys == k) & (vals != dummy)])
+            out[(cname, aname)] = lp
+        elif isinstance(d, StringPrior):
             ids = dom.id_array()[:-1]
             sc = np.array([oracle.string_prior(lm[off[i]:off[i + 1]], d.min_len, d.max_len, init, trans) for i in ids])
             out[(cname, aname)] = np.concatenate([sc, [oracle.dummy_logmass(sc)]])
