@@ -139,6 +139,58 @@ def time_prior_atom(s):
     return lib().pco_time_prior() if time_regex(s) else -np.inf
 
 
+class RandomOracle:
+    """Drop-in for the six HipContext.random_* methods, computed by the CPU restatement (random.h)."""
+
+    def random_add_typos(self, cp, off, max_typos, seed, stream, stride):
+        cp = np.ascontiguousarray(cp, np.uint32)
+        off = np.ascontiguousarray(off, np.int64)
+        n = len(off) - 1
+        out = np.zeros((n, stride), np.uint32)
+        lens = np.zeros(n, np.int32)
+        lib().pco_random_add_typos(n, _p(cp, C.c_uint32), _p(off, C.c_int64), int(max_typos), C.c_uint64(seed),
+                                   C.c_uint32(stream), int(stride), _p(out, C.c_uint32), _p(lens, C.c_int32))
+        return out, lens
+
+    def random_string_prior(self, n, min_len, max_len, init_p, trans_p, seed, stream):
+        init_p = np.ascontiguousarray(init_p, np.float64)
+        trans_p = np.ascontiguousarray(trans_p, np.float64)
+        stride = max(int(max_len), 1)
+        out = np.zeros((n, stride), np.uint8)
+        lens = np.zeros(n, np.int32)
+        lib().pco_random_string_prior(n, int(min_len), int(max_len), _p(init_p, C.c_double), _p(trans_p, C.c_double),
+                                      C.c_uint64(seed), C.c_uint32(stream), stride, _p(out, C.c_uint8),
+                                      _p(lens, C.c_int32))
+        return out, lens
+
+    def random_categorical(self, n, logp, seed, stream):
+        logp = np.ascontiguousarray(logp, np.float64)
+        out = np.zeros(n, np.int32)
+        lib().pco_random_categorical(n, len(logp), _p(logp, C.c_double), C.c_uint64(seed), C.c_uint32(stream),
+                                     _p(out, C.c_int32))
+        return out
+
+    def random_normal(self, mean, std, fwd_scale, seed, stream):
+        mean = np.ascontiguousarray(mean, np.float64)
+        out = np.zeros(len(mean), np.float64)
+        lib().pco_random_normal(len(mean), _p(mean, C.c_double), C.c_double(std), C.c_double(fwd_scale), C.c_uint64(seed),
+                                C.c_uint32(stream), _p(out, C.c_double))
+        return out
+
+    def random_maybe_swap(self, prob, n_options, seed, stream):
+        prob = np.ascontiguousarray(prob, np.float64)
+        n_options = np.ascontiguousarray(n_options, np.int32)
+        out = np.zeros(len(prob), np.int32)
+        lib().pco_random_maybe_swap(len(prob), _p(prob, C.c_double), _p(n_options, C.c_int32), C.c_uint64(seed),
+                                    C.c_uint32(stream), _p(out, C.c_int32))
+        return out
+
+    def random_time_prior(self, n, seed, stream):
+        out = np.zeros((n, 3), np.int32)
+        lib().pco_random_time_prior(n, C.c_uint64(seed), C.c_uint32(stream), _p(out, C.c_int32))
+        return out
+
+
 def philox(c, k):
     out = np.empty(4, dtype=np.uint32)
     lib().pco_philox(C.c_uint32(c[0]), C.c_uint32(c[1]), C.c_uint32(c[2]), C.c_uint32(c[3]), C.c_uint32(k[0]),

@@ -295,3 +295,39 @@ void pco_new_rows_get(int block, int n_nodes, int32_t* rows, int32_t* vals) {
 }
 
 } /* extern "C" */
+
+/* ---- random(dist, args...) (random.h) ------------------------------------ */
+#include "random.h"
+extern "C" {
+void pco_random_add_typos(int n, const uint32_t* cp, const int64_t* off, int max_typos, uint64_t seed, uint32_t stream,
+                          int stride, uint32_t* out_cp, int32_t* out_len) {
+  for (int i = 0; i < n; ++i) {
+    std::vector<uint32_t> w = pco::random_add_typos(cp + off[i], (int)(off[i + 1] - off[i]), max_typos, seed,
+                                                    (uint32_t)i, stream, (size_t)stride);
+    for (size_t k = 0; k < (size_t)stride; ++k) out_cp[(size_t)i * stride + k] = k < w.size() ? w[k] : 0u;
+    out_len[i] = (int32_t)w.size();
+  }
+}
+void pco_random_string_prior(int n, int min_len, int max_len, const double* init, const double* trans, uint64_t seed,
+                             uint32_t stream, int stride, uint8_t* out, int32_t* out_len) {
+  for (int i = 0; i < n; ++i) {
+    std::vector<uint8_t> w = pco::random_string_prior(min_len, max_len, init, trans, seed, (uint32_t)i, stream);
+    for (size_t k = 0; k < (size_t)stride; ++k) out[(size_t)i * stride + k] = k < w.size() ? w[k] : 0;
+    out_len[i] = (int32_t)w.size();
+  }
+}
+void pco_random_categorical(int n, int n_options, const double* logp, uint64_t seed, uint32_t stream, int32_t* out) {
+  for (int i = 0; i < n; ++i) out[i] = pco::random_categorical(logp, n_options, seed, (uint32_t)i, stream);
+}
+void pco_random_normal(int n, const double* mean, double std, double fwd_scale, uint64_t seed, uint32_t stream,
+                       double* out) {
+  for (int i = 0; i < n; ++i) out[i] = pco::random_normal(mean[i], std, fwd_scale, seed, (uint32_t)i, stream);
+}
+void pco_random_maybe_swap(int n, const double* prob, const int32_t* n_options, uint64_t seed, uint32_t stream,
+                           int32_t* out) {
+  for (int i = 0; i < n; ++i) out[i] = pco::random_maybe_swap(prob[i], n_options[i], seed, (uint32_t)i, stream);
+}
+void pco_random_time_prior(int n, uint64_t seed, uint32_t stream, int32_t* out) {
+  for (int i = 0; i < n; ++i) pco::random_time_prior(seed, (uint32_t)i, stream, out + 3 * i);
+}
+}

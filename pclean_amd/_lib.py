@@ -254,6 +254,61 @@ class HipContext:
             _p(a[2], C.c_int32), _p(a[3], C.c_int32), _p(a[4], C.c_int32), _p(a[5], C.c_int32), C.c_int32(prob_fn),
             _p(a[6], C.c_int32), _p(a[7], C.c_int32)), "pclean_load_score_block")
 
+    # -- random(dist, args...) -------------------------------------------------------
+    def random_add_typos(self, cp, off, max_typos, seed, stream, stride):
+        cp = np.ascontiguousarray(cp, dtype=np.uint32)
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        n = len(off) - 1
+        out = np.zeros((n, stride), dtype=np.uint32)
+        lens = np.zeros(n, dtype=np.int32)
+        check(self.h, self.lib.pclean_random_add_typos(
+            self.h, C.c_int32(n), _p(cp, C.c_uint32), _p(off, C.c_int64), C.c_int32(max_typos), C.c_uint64(seed),
+            C.c_uint32(stream), C.c_int32(stride), _p(out, C.c_uint32), _p(lens, C.c_int32)), "pclean_random_add_typos")
+        return out, lens
+
+    def random_string_prior(self, n, min_len, max_len, init_p, trans_p, seed, stream):
+        init_p = np.ascontiguousarray(init_p, dtype=np.float64)
+        trans_p = np.ascontiguousarray(trans_p, dtype=np.float64)
+        stride = max(int(max_len), 1)
+        out = np.zeros((n, stride), dtype=np.uint8)
+        lens = np.zeros(n, dtype=np.int32)
+        check(self.h, self.lib.pclean_random_string_prior(
+            self.h, C.c_int32(n), C.c_int32(min_len), C.c_int32(max_len), _p(init_p, C.c_double),
+            _p(trans_p, C.c_double), C.c_uint64(seed), C.c_uint32(stream), C.c_int32(stride), _p(out, C.c_uint8),
+            _p(lens, C.c_int32)), "pclean_random_string_prior")
+        return out, lens
+
+    def random_categorical(self, n, logp, seed, stream):
+        logp = np.ascontiguousarray(logp, dtype=np.float64)
+        out = np.zeros(n, dtype=np.int32)
+        check(self.h, self.lib.pclean_random_categorical(self.h, C.c_int32(n), C.c_int32(len(logp)), _p(logp, C.c_double),
+                                                         C.c_uint64(seed), C.c_uint32(stream), _p(out, C.c_int32)),
+              "pclean_random_categorical")
+        return out
+
+    def random_normal(self, mean, std, fwd_scale, seed, stream):
+        mean = np.ascontiguousarray(mean, dtype=np.float64)
+        out = np.zeros(len(mean), dtype=np.float64)
+        check(self.h, self.lib.pclean_random_normal(self.h, C.c_int32(len(mean)), _p(mean, C.c_double), C.c_double(std),
+                                                    C.c_double(fwd_scale), C.c_uint64(seed), C.c_uint32(stream),
+                                                    _p(out, C.c_double)), "pclean_random_normal")
+        return out
+
+    def random_maybe_swap(self, prob, n_options, seed, stream):
+        prob = np.ascontiguousarray(prob, dtype=np.float64)
+        n_options = np.ascontiguousarray(n_options, dtype=np.int32)
+        out = np.zeros(len(prob), dtype=np.int32)
+        check(self.h, self.lib.pclean_random_maybe_swap(self.h, C.c_int32(len(prob)), _p(prob, C.c_double),
+                                                        _p(n_options, C.c_int32), C.c_uint64(seed), C.c_uint32(stream),
+                                                        _p(out, C.c_int32)), "pclean_random_maybe_swap")
+        return out
+
+    def random_time_prior(self, n, seed, stream):
+        out = np.zeros((n, 3), dtype=np.int32)
+        check(self.h, self.lib.pclean_random_time_prior(self.h, C.c_int32(n), C.c_uint64(seed), C.c_uint32(stream),
+                                                        _p(out, C.c_int32)), "pclean_random_time_prior")
+        return out
+
     def get_table_priors(self, table_id, n_rows, is_options=False):
         full = np.empty(n_rows, dtype=np.float64)
         m1 = np.empty(n_rows, dtype=np.float64)
