@@ -185,10 +185,20 @@ class Engine:
                 self._upload_gauss()
                 self._gauss_pending = False
 
-    def sweep(self, trace, config, seed, sweep_idx):
-        """One batched sweep over the observed rows. Returns (choice, chosen_particle, logml, new_rows)."""
+    def sweep(self, trace, config, seed, sweep_idx, lo=0, hi=None):
+        """One batched sweep over the observed rows [lo, hi) of the trace (default: all of them).
+        Returns (choice, chosen_particle, logml, new_rows), all indexed relative to lo."""
         cfg = config.as_c() if isinstance(config, InferenceConfig) else config
-        choice, chosen, logml = self.hip.sweep(cfg, seed, sweep_idx, trace.cur)
+        hi = trace.cur.shape[1] if hi is None else hi
+        if hi <= lo:  # a rank may own no row of a small batch
+            for bi in self.lw.locals:
+                trace.pending_locals[bi] = np.zeros((0, 2), dtype=np.int32)
+            self._empty_sweep = True
+            nb = trace.cur.shape[0]
+            return np.zeros((nb, 0), np.int32), np.zeros(0, np.int32), np.zeros(0), {}
+        self._empty_sweep = False
+        self.hip.set_active_rows(lo, hi - lo)
+        choice, chosen, logml = self.hip.sweep(cfg, seed, sweep_idx, np.ascontiguousarray(trace.cur[:, lo:hi]))
         new_rows = {}
         for bi, blk in enumerate(self.lw.blocks):
             if blk.get("score"):
@@ -201,7 +211,19 @@ class Engine:
                 trace.pending_locals[bi] = self.hip.get_locals(bi, choice.shape[1])
         return choice, chosen, logml, new_rows
 
+    def sweep_latent(self, trace, cname, config, seed, sweep_idx, live, ev_off, ev_rows, ev_ctx, excl):
+        """Rejuvenation of the latent rows `live` of class cname against their evidence sets
+        (pclean_sweep_latent).  Returns (chosen particle, sampled node values) per latent row."""
+        pl = self.lw.latent_plans[cname]
+        cfg = config.as_c() if isinstance(config, InferenceConfig) else config
+        self.hip.set_active_rows(0, -1)
+        return self.hip.sweep_latent(cfg, seed, sweep_idx, pl["block_id"], pl["roots"], live, ev_off, ev_rows, ev_ctx,
+                                     excl, len(pl["nodes"]))
+
     def sweep_stats(self, trace):
         """Delta reference counts of the last sweep per block root table (the all-reduce payload)."""
+        if getattr(self, "_empty_sweep", False):
+            return {bi: np.zeros(trace.tables[blk["root_class"]].n, dtype=np.int64)
+                    for bi, blk in enumerate(self.lw.blocks) if not blk.get("score")}
         return {bi: self.hip.get_stats(self.lw.table_id[blk["root_class"]], trace.tables[blk["root_class"]].n)
                 for bi, blk in enumerate(self.lw.blocks) if not blk.get("score")}

@@ -14,7 +14,7 @@ re-sampled once per class sweep instead of every `rejuv_frequency` rows.
 import numpy as np
 
 from .model import ChooseProportionally
-from .parallel import Comm, exchange_and_commit
+from .parallel import Comm, exchange_and_commit, shard_bounds
 from .trace import CHOICE_NEW
 
 
@@ -172,7 +172,12 @@ def commit_latent(lw, trace, cname, live, chosen, vals):
     return changed
 
 
-def latent_sweep(engine, trace, cname, config, seed, sweep_idx):
+def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None):
+    """One rejuvenation sweep of latent class cname.  With several ranks the live latent rows are
+    block-partitioned: a rank scores its rows against their complete evidence sets (observations and
+    trace are replicated), then (chosen particle, sampled values) are all-gathered and every rank
+    applies the same commit — no floating-point reduction, identical result for any rank count."""
+    comm = comm or Comm()
     lw = engine.lw
     pl = lw.latent_plans[cname]
     live, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname)
@@ -184,21 +189,43 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx):
         if pl["nodes"][root][0] == 0:
             excl[r] = t.cols[lw.colidx[cname][pl["root_attr"][r]], live]
     engine.upload_trace(trace)
-    engine.hip.set_active_rows(0, -1)
-    chosen, vals = engine.hip.sweep_latent(config.as_c(), seed, sweep_idx, pl["block_id"], pl["roots"], live, ev_off,
-                                           ev_rows, ev_ctx, excl, len(pl["nodes"]))
+    lo, hi = shard_bounds(len(live), comm.rank, comm.world)
+    e0, e1 = int(ev_off[lo]), int(ev_off[hi])
+    chosen = np.zeros(0, np.int32)
+    vals = np.zeros((0, len(pl["nodes"])), np.int32)
+    if hi > lo:
+        chosen, vals = engine.sweep_latent(trace, cname, config, seed, sweep_idx, live[lo:hi], ev_off[lo:hi + 1] - e0,
+                                           ev_rows[e0:e1], None if ev_ctx is None else ev_ctx[e0:e1],
+                                           np.ascontiguousarray(excl[:, lo:hi]))
+    if comm.world > 1:
+        chosen = comm.allgather_varlen_i32(chosen)
+        vals = comm.allgather_varlen_i32(vals).reshape(-1, len(pl["nodes"]))
     return commit_latent(lw, trace, cname, live, chosen, vals)
 
 
 # ---------------------------------------------------------------------------
-def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None, row_lo=0):
+def _gather_locals(trace, comm, begin, n_local, lo):
+    """Own enumerated choices (e.g. br, unit) of the rows just swept: every rank learns all of them."""
+    for bi in sorted(trace.pending_locals):  # same keys, same order on every rank (collectives inside)
+        loc = trace.pending_locals[bi]
+        if comm.world > 1:
+            loc = comm.allgather_varlen_i32(loc[:n_local]).reshape(-1, 2)
+            trace.locals[bi][begin:begin + len(loc)] = loc
+        else:
+            trace.locals[bi][lo:lo + n_local] = loc[:n_local]
+    trace.pending_locals = {}
+
+
+def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None):
+    """One rejuvenation sweep of the observed class; rows block-partitioned over the ranks."""
     comm = comm or Comm()
+    n = trace.cur.shape[1]
+    lo, hi = shard_bounds(n, comm.rank, comm.world)
     engine.upload_trace(trace)
-    engine.hip.set_active_rows(0, -1)
-    choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx)
+    choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi)
     stats = engine.sweep_stats(trace)
-    trace.commit_locals()
-    return exchange_and_commit(trace, engine.lw, comm, row_lo, choice, stats, new_rows)
+    _gather_locals(trace, comm, 0, hi - lo, lo)
+    return exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True)
 
 
 def resample_parameters(trace):
@@ -209,47 +236,54 @@ def resample_parameters(trace):
         trace.resample_py_params(t)
 
 
-def initialize_trace(engine, trace, config, seed, max_batch=256):
+def initialize_trace(engine, trace, config, seed, max_batch=256, comm=None):
     """SMC initialisation of the observed rows (inference.jl:3-58), batched: batch b sees the
-    latent rows created by batches < b; identical new-row proposals inside a batch are merged."""
+    latent rows created by batches < b; identical new-row proposals inside a batch are merged.
+    With several ranks each batch is block-partitioned; choices and new-row records of the batch are
+    all-gathered and every rank applies the same commit."""
+    comm = comm or Comm()
     lw = engine.lw
     n = trace.cur.shape[1]
+    nb = len(lw.blocks)
     trace.cur[:] = -1
     begin, size = 0, 1
     while begin < n:
         count = min(size, n - begin)
+        lo, hi = shard_bounds(count, comm.rank, comm.world)
         engine.upload_trace(trace)
-        engine.hip.set_active_rows(begin, count)
-        cur = np.ascontiguousarray(trace.cur[:, begin:begin + count])
-        choice, chosen, logml = engine.hip.sweep(config.as_c(), seed, 0x7fffffff, cur)
-        new_rows = {}
-        for bi, blk in enumerate(lw.blocks):
-            if blk.get("score"):
-                continue
-            rows, vals = engine.hip.get_new_rows(bi, len(blk["nodes"]))
-            if len(rows):
-                new_rows[bi] = (rows, vals)
-        for bi in lw.locals:
-            trace.pending_locals[bi] = engine.hip.get_locals(bi, count)
-        trace.commit_locals(begin, count)
+        choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, 0x7fffffff, begin + lo, begin + hi)
+        _gather_locals(trace, comm, begin, hi - lo, begin + lo)
+        if comm.world > 1:
+            choice = comm.allgather_varlen_i32(np.ascontiguousarray(choice.T)).reshape(-1, nb).T
+            merged = {}
+            for bi, blk in enumerate(lw.blocks):
+                if blk.get("score"):
+                    continue
+                nn = len(blk["nodes"])
+                rows, vals = new_rows.get(bi, (np.zeros(0, np.int32), np.zeros((0, nn), np.int32)))
+                g_rows = comm.allgather_varlen_i32(np.asarray(rows, np.int32) + lo)
+                g_vals = comm.allgather_varlen_i32(np.asarray(vals, np.int32)).reshape(-1, nn)
+                if len(g_rows):
+                    merged[bi] = (g_rows, g_vals)  # rank order == row order (contiguous shards)
+            new_rows = merged
         trace.commit_batch(begin, count, choice, new_rows, dedup=True)
         begin += count
         size = min(max_batch, size * 2)
         if begin % max(config.rejuv_frequency, 1) < count:
             resample_parameters(trace)
-    engine.hip.set_active_rows(0, -1)
     return trace
 
 
-def run_inference(engine, trace, config, seed, verbose=False):
-    """run_inference! (inference.jl:83-88): config.num_iters sweeps over all classes."""
+def run_inference(engine, trace, config, seed, verbose=False, comm=None):
+    """run_inference! (inference.jl:83-88): config.num_iters sweeps over all classes.  `comm` shards
+    every class sweep over the ranks of a torch.distributed job (one process per GPU)."""
     lw = engine.lw
     for it in range(config.num_iters):
         for cname in lw.model.class_order:
             if cname in lw.latent_plans:
-                ch = latent_sweep(engine, trace, cname, config, seed, it)
+                ch = latent_sweep(engine, trace, cname, config, seed, it, comm)
             elif cname == lw.query.cls:
-                ch = observed_sweep(engine, trace, config, seed, it)
+                ch = observed_sweep(engine, trace, config, seed, it, comm)
             else:
                 continue
             resample_parameters(trace)

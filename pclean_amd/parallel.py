@@ -71,14 +71,19 @@ class Comm:
         return float(t.item())
 
 
-def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local, new_rows_local):
+def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local, new_rows_local, global_cur=False):
     """Apply one sweep's result to the replicated trace.
 
     choice_local [n_blocks][n_local]: chosen referents of this rank's rows;
     stats_local  {block: int64 delta counts over the root table} from the kernel;
     new_rows_local {block: (local rows, vals)}.
+    global_cur=False: trace.cur holds only this rank's rows (observed-class sweeps only, bench.py);
+    global_cur=True : trace.cur holds every observed row on every rank (needed by the latent-class
+    sweeps, whose evidence sets span all rows): the (row, new referent) pairs of the rows that moved
+    are all-gathered as well, so the whole trace stays replicated.
     Returns the global number of rows whose referent changed."""
     changed = 0
+    n_local = np.asarray(choice_local).shape[1]
     for bi, blk in enumerate(lowered.blocks):
         if blk.get("score"):
             continue
@@ -102,9 +107,17 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
         ch = np.array(choice_local[bi], dtype=np.int64)
         for i in np.nonzero(ch < 0)[0]:
             ch[i] = created[int(i) + row_lo]
-        cur = trace.cur[bi]
-        changed += int(np.sum(ch != cur))
-        trace.cur[bi] = ch.astype(np.int32)
+        if global_cur:
+            cur = trace.cur[bi, row_lo:row_lo + n_local]
+            moved = np.nonzero(ch != cur)[0]
+            changed += len(moved)
+            g_moved = comm.allgather_varlen_i32(moved.astype(np.int32) + row_lo)
+            g_new = comm.allgather_varlen_i32(ch[moved].astype(np.int32))
+            trace.cur[bi, g_moved] = g_new
+        else:
+            cur = trace.cur[bi]
+            changed += int(np.sum(ch != cur))
+            trace.cur[bi] = ch.astype(np.int32)
         # garbage-collect rows nobody refers to any more (ascending id: deterministic)
         dead = np.nonzero((t.counts[:t.n] == 0) & t.live[:t.n])[0]
         for k in dead:

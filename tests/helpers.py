@@ -51,7 +51,7 @@ def density_tables_cpu(oracle, max_len):
     return mr, md, ml, nb, logl
 
 
-def mirror_world(oracle, lw, obs, trace, engine=None, dist_mode=1, option_logp=None):
+def mirror_world(oracle, lw, obs, trace, engine=None, dist_mode=1, option_logp=None, row_lo=0):
     """Oracle World holding exactly what the product uploaded.  With an engine the
     double-valued tables are read back from the library (bit-identical inputs);
     without one (CPU tests) they are computed by the oracle itself."""
@@ -75,7 +75,7 @@ def mirror_world(oracle, lw, obs, trace, engine=None, dist_mode=1, option_logp=N
     for key, (pid, n) in lw.eq_pairs.items():
         w.set_pair(pid, (1 - np.eye(n, dtype=np.uint16)), np.zeros(n, dtype=np.uint16))
     if getattr(lw, "xnum", None) is not None and lw.xnum.shape[0]:
-        w.set_numeric(lw.xnum[:, :obs.shape[1]])
+        w.set_numeric(lw.xnum[:, row_lo:row_lo + obs.shape[1]])
     for cname, t in trace.tables.items():
         cols, counts = t.view()
         if engine is not None:
@@ -111,7 +111,7 @@ def mirror_world(oracle, lw, obs, trace, engine=None, dist_mode=1, option_logp=N
 def option_logp_cpu(oracle, lw, trace):
     """discrete_proposal log-probabilities computed by the oracle (CPU tests)."""
     from pclean_amd.encode import load_lm_params
-    from pclean_amd.model import ChooseProportionally, ChooseUniformly, StringPrior, TimePrior
+    from pclean_amd.model import ChooseProportionally, ChooseUniformly, StringPrior, TimePrior, Unmodeled
     init, trans = load_lm_params()
     _, off, lm, _ = lw.pool.arrays()
     out = {}
@@ -125,10 +125,21 @@ def option_logp_cpu(oracle, lw, trace):
             for k in np.unique(keys):
                 lp[(keys == k) & (vals == dummy)] = oracle.dummy_logmass(sc[(keys == k) & (vals != dummy)])
             out[(cname, aname)] = lp
+        elif isinstance(d, StringPrior) and d.keyed_by:
+            vals, keys = lw.option_values[(cname, aname)], lw.option_keycol[(cname, aname)]
+            dummy = dom.get(d.dummy_value())
+            ids = dom.id_array()[vals]
+            sc = np.array([oracle.string_prior(lm[off[i]:off[i + 1]], d.min_len, d.max_len, init, trans) for i in ids])
+            lp = sc.copy()
+            for k in np.unique(keys):
+                lp[(keys == k) & (vals == dummy)] = oracle.dummy_logmass(sc[(keys == k) & (vals != dummy)])
+            out[(cname, aname)] = lp
         elif isinstance(d, StringPrior):
             ids = dom.id_array()[:-1]
             sc = np.array([oracle.string_prior(lm[off[i]:off[i + 1]], d.min_len, d.max_len, init, trans) for i in ids])
             out[(cname, aname)] = np.concatenate([sc, [oracle.dummy_logmass(sc)]])
+        elif isinstance(d, Unmodeled) and cname != lw.query.cls:
+            out[(cname, aname)] = np.zeros(len(dom))  # unmodeled.jl:7-10
         elif isinstance(d, ChooseUniformly):
             out[(cname, aname)] = np.full(len(dom), oracle.lib().pco_choose_uniformly(len(d.options)))
         elif isinstance(d, ChooseProportionally):

@@ -1,0 +1,79 @@
+"""Stand-in for pclean_amd.engine.Engine whose compute is the CPU oracle (TEST INFRASTRUCTURE).
+
+It lets the CPU suite drive the product's host code — inference.initialize_trace / run_inference,
+parallel.exchange_and_commit, trace commits, parameter moves — end to end, single process or
+gloo world_size 2, without a GPU.  Only the four methods inference.py uses are provided."""
+import ctypes as C
+
+import numpy as np
+
+import helpers
+from pclean_amd._lib import InferConfig
+
+
+class OracleEngine:
+    def __init__(self, oracle, lowered, obs):
+        self.oracle, self.lw, self.obs = oracle, lowered, np.ascontiguousarray(obs, dtype=np.int32)
+        self._choice = None
+
+    def upload_trace(self, trace):
+        pass  # worlds are rebuilt from the trace at every sweep
+
+    def _cfg(self, config):
+        return InferConfig(config.num_iters, config.num_particles, 1, 1, int(config.use_mh_instead_of_pg),
+                           config.rejuv_frequency, config.reporting_frequency)
+
+    def _world(self, trace, lo, hi):
+        logp = helpers.option_logp_cpu(self.oracle, self.lw, trace)
+        return helpers.mirror_world(self.oracle, self.lw, np.ascontiguousarray(self.obs[:, lo:hi]), trace, None, 1, logp, row_lo=lo)
+
+    def sweep(self, trace, config, seed, sweep_idx, lo=0, hi=None):
+        orc, lw = self.oracle, self.lw
+        hi = trace.cur.shape[1] if hi is None else hi
+        n, nb = hi - lo, trace.cur.shape[0]
+        choice = np.empty((nb, n), dtype=np.int32)
+        chosen = np.empty(n, dtype=np.int32)
+        logml = np.empty(n)
+        new_rows = {}
+        if n:
+            w = self._world(trace, lo, hi)
+            cfg = self._cfg(config)
+            cur = np.ascontiguousarray(trace.cur[:, lo:hi])
+            orc.lib().pco_sweep_batched(w.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep_idx), nb, C.c_int64(lo),
+                                        orc._p(cur, C.c_int32), orc._p(choice, C.c_int32), orc._p(chosen, C.c_int32),
+                                        orc._p(logml, C.c_double))
+            for b, blk in enumerate(lw.blocks):
+                if blk.get("score"):
+                    continue
+                k = orc.lib().pco_new_rows_count(b)
+                if k:
+                    rows = np.empty(k, dtype=np.int32)
+                    vals = np.empty((k, len(blk["nodes"])), dtype=np.int32)
+                    orc.lib().pco_new_rows_get(b, len(blk["nodes"]), orc._p(rows, C.c_int32), orc._p(vals, C.c_int32))
+                    new_rows[b] = (rows, vals)
+            for bi in lw.locals:
+                trace.pending_locals[bi] = w.get_locals(bi, n)
+        else:
+            for bi in lw.locals:
+                trace.pending_locals[bi] = np.zeros((0, 2), dtype=np.int32)
+        self._choice, self._cur = choice, np.ascontiguousarray(trace.cur[:, lo:hi])
+        return choice, chosen, logml, new_rows
+
+    def sweep_stats(self, trace):
+        """Delta reference counts of the last sweep per block root table (what stats_kernel produces)."""
+        out = {}
+        for b, blk in enumerate(self.lw.blocks):
+            if blk.get("score"):
+                continue
+            t = trace.tables[blk["root_class"]]
+            ch, cur = self._choice[b], self._cur[b]
+            moved = ch != cur
+            d = -np.bincount(cur[moved & (cur >= 0)], minlength=t.n).astype(np.int64)
+            out[b] = d + np.bincount(ch[moved & (ch >= 0)], minlength=t.n)
+        return out
+
+    def sweep_latent(self, trace, cname, config, seed, sweep_idx, live, ev_off, ev_rows, ev_ctx, excl):
+        pl = self.lw.latent_plans[cname]
+        w = self._world(trace, 0, self.obs.shape[1])
+        return w.sweep_latent(self._cfg(config), seed, sweep_idx, pl["block_id"], pl["roots"], live, ev_off, ev_rows,
+                              ev_ctx, excl, len(pl["nodes"]))

@@ -97,3 +97,84 @@ def test_two_rank_sweep_equals_single_process(tmp_path, oracle):
     # reference counts are consistent with the referents after the exchange
     assert np.array_equal(np.bincount(a["cur0"], minlength=len(a["counts_Hospital"])), a["counts_Hospital"])
     assert np.array_equal(np.bincount(a["cur1"], minlength=len(a["counts_Measure"])), a["counts_Measure"])
+
+
+# ---------------------------------------------------------------------------
+# whole inference (initialize_trace + run_inference over every class) on 2 ranks
+def _program(name):
+    from pclean_amd import experiments as ex
+    from pclean_amd.model import LoweredModel
+    if name == "flights":
+        dirty, clean = ex.flights_data()
+        dirty = {c: v[:600] for c, v in dirty.items()}
+        m = ex.flights_model(dirty)
+        q = ex.flights_query(m)
+    elif name == "rents":
+        dirty, clean = ex.rents_data()
+        dirty = {c: v[:400] for c, v in dirty.items()}
+        m = ex.rents_model(dirty)
+        q = ex.rents_query(m)
+    else:
+        dirty, clean = ex.hospital_data()
+        dirty = {c: v[:200] for c, v in dirty.items()}
+        m = ex.hospital_model(ex.possibilities_of(dirty))
+        q = ex.hospital_query(m)
+    lw = LoweredModel(m, q, dirty)
+    return lw, lw.encode_observations(dirty)
+
+
+def _run_inference(rank, world, port, out_path, name):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import oracle as orc
+    from oracle_engine import OracleEngine
+    from pclean_amd.engine import InferenceConfig
+    from pclean_amd.inference import initialize_trace, run_inference
+    from pclean_amd.parallel import Comm
+    from pclean_amd.trace import Trace
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    comm = Comm()
+    lw, obs = _program(name)
+    eng = OracleEngine(orc, lw, obs)  # every rank holds all observations; the work is sharded
+    tr = Trace(lw, obs.shape[1], 5)
+    cfg = InferenceConfig(2, 3, rejuv_frequency=100)
+    initialize_trace(eng, tr, cfg, 17, max_batch=64, comm=comm)
+    tr.check_consistency()
+    run_inference(eng, tr, cfg, 17, comm=comm)
+    tr.check_consistency()
+    if rank == world - 1:  # the LAST rank's replica: must equal the single-process result too
+        extra = {}
+        for bi, loc in tr.locals.items():
+            extra[f"locals_{bi}"] = loc
+        if tr.prob_param is not None:
+            extra["prob"] = tr.prob_param.value
+        if tr.mean_param is not None:
+            extra["mean"] = tr.mean_param.value
+        np.savez(out_path, cur=tr.cur,
+                 **{f"cols_{c}": t.cols[:, :t.n] for c, t in tr.tables.items()},
+                 **{f"counts_{c}": t.counts[:t.n] for c, t in tr.tables.items()},
+                 **{f"param_{c}_{p}": v.value for (c, p), v in tr.params.items()}, **extra)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["flights", "hospital", "rents"])
+def test_two_rank_inference_equals_single_process(tmp_path, oracle, name):
+    """BASELINE.json configs[3] at plumbing scale: observed rows AND latent rows of every class sweep are
+    block-partitioned over the ranks; the replicated traces must end bit-identical to one process."""
+    import torch.multiprocessing as mp
+    single = str(tmp_path / "single.npz")
+    _run_inference(0, 1, 0, single, name)
+    multi = str(tmp_path / "multi.npz")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_run_inference, args=(2, port, multi, name), nprocs=2, join=True)
+    a, b = np.load(single), np.load(multi)
+    assert set(a.files) == set(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    assert (a["cur"] >= 0).all()
