@@ -99,6 +99,10 @@ struct FastRootDev {
   const double* logc_m1;
   const int64_t* counts;
   double scal[4];
+  // integer pre-filter (root_fast.hip): terms whose byte rows are summed, 1 / (smallest cost of one
+  // edit), and the largest prior with / without an excluded reference
+  int32_t n_pre, pre[3];
+  double inv_c, prior_max_e, prior_max_n;
   FastTermDev terms[PCLEAN_MAX_TERMS];
 };
 

@@ -28,6 +28,7 @@
 //     Items whose windows or list overflow (flat posteriors) are flagged and re-run by
 //     the host with the LDS-resident generic kernel — results are identical either way.
 #include <algorithm>
+#include <cstdlib>
 
 #include "../../include/pclean_detmath.h"
 #include "../../include/pclean_philox.h"
@@ -87,6 +88,15 @@ __device__ __forceinline__ double wave_max64(double v) {
   return v;
 }
 
+__device__ __forceinline__ double add_typos_dens(const DensDev& dn, int L, int d) {
+  // the fp64 operation order of term_density() (enum_kernels.hip), add_typos.jl:61-63
+  const int r = (L + 4) / 5;
+  double l = dn.nb[(size_t)r * dn.nb_stride + d];
+  l -= dn.logl[L] * (double)d;
+  l -= HALF_LOG26 * (double)d;
+  return l;
+}
+
 template <int NT>
 __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr, const DensDev dn, const ItemsDev it,
                                                             const ChildrenDev ch, uint64_t seed, uint32_t sweep,
@@ -101,32 +111,23 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   const int t = blockIdx.x + item_base;
   const int n = fr.n_cand;
   // LDS carve (all offsets multiples of 16 bytes)
-  const int lut_n = (fr.lmax + 1) * fr.dstride;
-  double* lut = (double*)smem;                                  // [(lmax+1)*dstride]
-  double* red = lut + ((lut_n + 1) & ~1);                       // [16]
-  uint64_t* xs = (uint64_t*)(red + FAST_MAX_WAVES);             // [64] draw thresholds
-  uint64_t* u2 = xs + 64;                                       // [SURV2_CAP] sorted weights, then inclusive prefix
+  double* red = (double*)smem;                                  // [16] per-wave maxima
+  uint64_t* redk = (uint64_t*)(red + FAST_MAX_WAVES);           // [16] per-wave (distance, candidate) minima
+  uint64_t* u2 = redk + FAST_MAX_WAVES;                         // [SURV2_CAP] sorted weights, then inclusive prefix
   double* sc2 = (double*)(u2 + SURV2_CAP);                      // [SURV2_CAP] second-stage scores
   int32_t* k2 = (int32_t*)(sc2 + SURV2_CAP);                    // [SURV2_CAP] survivor ids (unsorted)
   int32_t* ks = k2 + SURV2_CAP;                                 // [SURV2_CAP] sorted ids
   unsigned int* cnt = (unsigned int*)(ks + SURV2_CAP);          // [4] counters
+  double* bnd = (double*)(cnt + 4);                             // [1] lower bound of the maximum
 
   if (tid < 4) cnt[tid] = 0;
-  // density LUT: the fp64 operation order of term_density() (enum_kernels.hip)
-  for (int i = tid; i < lut_n; i += T) {
-    const int L = i / fr.dstride, d = i - L * fr.dstride;
-    const int r = (L + 4) / 5;
-    double l = dn.nb[(size_t)r * dn.nb_stride + d];
-    l -= dn.logl[L] * (double)d;
-    l -= HALF_LOG26 * (double)d;
-    lut[i] = l;
-  }
   const int row = it.row ? it.row[t] : t;
   const int excl = it.excl ? it.excl[t] : -1;
   const bool excluded = excl >= 0;
   const bool deleted = excluded && fr.counts[excl] <= 1;
   const double logden = excluded ? fr.scal[1] : fr.scal[0];
   const double* prior = excluded ? fr.prior_e : fr.prior_n;
+  const double pmax = excluded ? fr.prior_max_e : fr.prior_max_n;
   // per-term row pointers (wave-uniform -> scalar registers)
   const uint32_t* crow[NT];
   const uint32_t* lrow[NT];
@@ -143,21 +144,83 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
       mt[f] = fr.terms[f].max_typos;
     }
   }
-  __syncthreads();
-
-  // A lower bound of the maximum, to keep the first-stage list short: the approximate score of
-  // the retained referent (the row's current hospital is almost always the best candidate) minus a
-  // safety margin.  Wave-uniform scalar work; only used as a filter, never as a score.
-  double bound = -__builtin_inf();
-  if (excluded && !deleted) {
-    double b = fr.logc_m1[excl] - logden;
+  // the (up to 3) most discriminating terms: byte rows summed by the integer pre-filter
+  const uint32_t* prow[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    prow[p] = nullptr;
+    if (p < fr.n_pre) {
+      const int f = fr.pre[p];
+      const int o = fr.terms[f].obs_col[row];
+      if (o >= 0) prow[p] = reinterpret_cast<const uint32_t*>(fr.terms[f].comp + (size_t)o * fr.kpad);
+    }
+  }
+  // exact score of one candidate, in the operation order of the main loop
+  auto exact_score = [&](int k, double pr) {
+    double b = pr;
 #pragma unroll
     for (int f = 0; f < NT; ++f)
       if (crow[f]) {
-        const int d = reinterpret_cast<const uint8_t*>(crow[f])[excl], L = reinterpret_cast<const uint8_t*>(lrow[f])[excl];
-        b += (mt[f] >= 0 && d > mt[f]) ? ADD_TYPOS_IMPOSSIBLE : lut[L * fr.dstride + d];
+        const int d = reinterpret_cast<const uint8_t*>(crow[f])[k], L = reinterpret_cast<const uint8_t*>(lrow[f])[k];
+        b += (mt[f] >= 0 && d > mt[f]) ? ADD_TYPOS_IMPOSSIBLE : add_typos_dens(dn, L, d);
       }
-    bound = b - 1.0;
+    return b;
+  };
+  const int nslots = fr.kpad >> 2;
+
+  // ---- phase 0: a lower bound of the maximum = the exact score of one good candidate.
+  // With a retained referent (rejuvenation of an assigned row) that candidate is the referent;
+  // otherwise (nested reference slots of a new row, initialisation) the candidate with the smallest
+  // summed edit distance over the pre-filter terms.  Only ever used as a filter, never as a score.
+  double bound = -__builtin_inf();
+  if (excluded && !deleted) {
+    bound = exact_score(excl, fr.logc_m1[excl] - logden) - 1.0;
+  } else if (fr.n_pre > 0) {
+    uint64_t best = ~0ull;
+    for (int slot = tid; slot < nslots; slot += T) {
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        if (prow[p]) {
+          const uint32_t c = prow[p][slot];
+          lo += c & 0x00ff00ffu;
+          hi += (c >> 8) & 0x00ff00ffu;
+        }
+      const uint32_t D[4] = {lo & 0xffffu, hi & 0xffffu, lo >> 16, hi >> 16};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = (slot << 2) + e;
+        const uint64_t key = ((uint64_t)D[e] << 32) | (uint32_t)k;
+        if (key < best && k < n && k != excl && prior[k] > -__builtin_inf()) best = key;
+      }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t other = __shfl_xor(best, o, 64);
+      best = other < best ? other : best;
+    }
+    if (lane == 0) redk[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+      uint64_t b = redk[0];
+      for (int w = 1; w < nw; ++w) b = redk[w] < b ? redk[w] : b;
+      double v = -__builtin_inf();
+      if (b != ~0ull) {
+        const int k = (int)(uint32_t)b;
+        v = exact_score(k, prior[k]) - 1.0;
+      }
+      bnd[0] = v;
+    }
+    __syncthreads();
+    bound = bnd[0];
+  }
+  // Pre-filter threshold: a candidate whose summed edit distance D over the pre-filter terms exceeds
+  // dcut scores at most pmax - c_min * D < bound - FIX_CUTOFF <= max - FIX_CUTOFF, i.e. its fixed-point
+  // weight is exactly 0 (c_min = smallest cost of one edit, fr.inv_c = 1 / c_min; terms not summed
+  // and missing observations only lower the score further).
+  uint32_t dcut = 0xffffu;
+  if (fr.n_pre > 0 && bound > -__builtin_inf()) {
+    const double x = (pmax - bound + FIX_CUTOFF) * fr.inv_c;
+    if (x >= 0.0 && x < 60000.0) dcut = (uint32_t)x + 2u;
   }
 
   // ---- phase 1: scores, 4 consecutive candidates per lane per round.  Each lane keeps the
@@ -172,8 +235,30 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   }
   bool lost = false;        // a window candidate had to be dropped
   double lost_max = -__builtin_inf();
-  const int nslots = fr.kpad >> 2;
-  for (int slot = tid; slot < nslots; slot += T) {
+  // 1a: branch-free integer scan (loads of several rounds in flight): bit r of `alive` = the lane's
+  //     r-th slot holds a candidate that may carry weight
+  uint64_t alive = 0;
+  {
+    int r = 0;
+#pragma unroll 4
+    for (int slot = tid; slot < nslots; slot += T, ++r) {
+      uint32_t lo = 0, hi = 0;
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        if (prow[p]) {
+          const uint32_t c = prow[p][slot];
+          lo += c & 0x00ff00ffu;
+          hi += (c >> 8) & 0x00ff00ffu;
+        }
+      const bool pass = (lo & 0xffffu) <= dcut || (hi & 0xffffu) <= dcut || (lo >> 16) <= dcut || (hi >> 16) <= dcut;
+      alive |= (uint64_t)(pass ? 1u : 0u) << r;
+    }
+  }
+  // 1b: exact fp64 scores of the surviving slots
+  while (alive) {
+    const int r = __builtin_ctzll(alive);
+    alive &= alive - 1;
+    const int slot = tid + r * T;
     const int k0 = slot << 2;
     double acc[4];
     const double2 p01 = *reinterpret_cast<const double2*>(prior + k0);
@@ -188,19 +273,14 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
       for (int e = 0; e < 4; ++e)
         if (k0 + e == excl) acc[e] = pe;
     }
-    uint32_t c4[NT], l4[NT];
-#pragma unroll
-    for (int f = 0; f < NT; ++f) {
-      c4[f] = crow[f] ? crow[f][slot] : 0u;
-      l4[f] = lrow[f] ? lrow[f][slot] : 0u;
-    }
 #pragma unroll
     for (int f = 0; f < NT; ++f) {
       if (crow[f]) {  // an explicitly missing observation contributes nothing (add_typos.jl:51-53)
+        const uint32_t c4 = crow[f][slot], l4 = lrow[f][slot];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int d = (c4[f] >> (8 * e)) & 255, L = (l4[f] >> (8 * e)) & 255;
-          double dens = lut[L * fr.dstride + d];
+          const int d = (c4 >> (8 * e)) & 255, L = (l4 >> (8 * e)) & 255;
+          double dens = add_typos_dens(dn, L, d);
           if (mt[f] >= 0 && d > mt[f]) dens = ADD_TYPOS_IMPOSSIBLE;
           acc[e] += dens;
         }
@@ -342,9 +422,9 @@ static fast_kernel_t pick_kernel(int n_terms) {
 }
 
 size_t pclean_fast_lds_bytes(int lmax, int dstride) {
-  const int lut_n = (lmax + 1) * dstride;
-  return (size_t)((lut_n + 1) & ~1) * 8 + FAST_MAX_WAVES * 8 + 64 * 8 + (size_t)SURV2_CAP * 8 * 2 +
-         (size_t)SURV2_CAP * 4 * 2 + 16;
+  (void)lmax;
+  (void)dstride;  // the density LUT no longer lives in LDS
+  return (size_t)FAST_MAX_WAVES * 8 * 2 + (size_t)SURV2_CAP * 8 * 2 + (size_t)SURV2_CAP * 4 * 2 + 16 + 16;
 }
 
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
@@ -352,11 +432,13 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count) {
   if (it.n <= 0) return PCLEAN_OK;
   const size_t lds = pclean_fast_lds_bytes(fr.lmax, fr.dstride);
-  // lanes: as few rounds of 4-candidate slots as possible with little idle tail
+  // lanes: small workgroups (more of them resident per CU hide the per-row latency chain), at most
+  // 64 rounds of 4-candidate slots per lane (the survivor bitmask is one 64-bit word)
   const int nslots = fr.kpad >> 2;
-  const int rounds = (nslots + 1023) / 1024;
-  int T = ((nslots + rounds - 1) / rounds + 63) / 64 * 64;
-  T = std::max(256, std::min(1024, T));
+  int T = 256;
+  if (const char* e = getenv("PCLEAN_FAST_T")) T = std::max(64, std::min(1024, atoi(e) / 64 * 64));
+  while (T < 1024 && (nslots + T - 1) / T > 64) T += 64;
+  if ((nslots + T - 1) / T > 64) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "fast root kernel: too many candidates");
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, nullptr, nullptr, nullptr};
   fast_kernel_t kern = pick_kernel(fr.n_terms);
   HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

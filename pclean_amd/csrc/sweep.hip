@@ -13,6 +13,9 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <set>
+
+#include <hipcub/hipcub.hpp>
 
 #include "../../include/pclean_detmath.h"
 #include "../../include/pclean_philox.h"
@@ -531,6 +534,7 @@ struct FastRoot {  // candidate-compact tables of a block root (root_fast.hip)
   DevBuf<double> prior_e, prior_n;
   uint64_t prior_ver = 0;
   int kpad = 0;
+  double logc_max = 0.0;  // max over candidates of log(count - discount)
 };
 
 struct SweepState {
@@ -741,7 +745,8 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   if (node_id >= 64) return 0;
   const pclean_node& n = b.nodes[node_id];
   const CandTable& t = ctx->cand[n.table];
-  if (n.kind != PCLEAN_NODE_FK || !t.valid || t.n_rows < 1024 || n.n_terms < 1 || n.n_terms > PCLEAN_MAX_TERMS)
+  if (n.kind != PCLEAN_NODE_FK || !t.valid || t.n_rows < 1024 || t.n_rows > 260000 || n.n_terms < 1 ||
+      n.n_terms > PCLEAN_MAX_TERMS)
     return 0;
   int lmax = 0, dmax = 0;
   for (int i = 0; i < n.n_terms; ++i) {
@@ -789,6 +794,38 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
                                  f.prior_n.p);
     if (rc) return rc;
     f.prior_ver = t.version;
+    f.logc_max = -INFINITY;
+    for (double v : t.h_logc_full) f.logc_max = std::max(f.logc_max, v);
+  }
+  // pre-filter: the three terms with the longest latent strings discriminate best; c_min = the
+  // smallest density cost of one edit over every (length, distance) the tables hold
+  {
+    int order[PCLEAN_MAX_TERMS];
+    for (int i = 0; i < n.n_terms; ++i) order[i] = i;
+    std::stable_sort(order, order + n.n_terms, [&](int a, int c) {
+      return ctx->pair[b.terms[n.term_begin + a].pair_table].max_lat_len >
+             ctx->pair[b.terms[n.term_begin + c].pair_table].max_lat_len;
+    });
+    fr.n_pre = std::min(3, (int)n.n_terms);
+    for (int p = 0; p < 3; ++p) fr.pre[p] = p < fr.n_pre ? order[p] : 0;
+    double cmin = INFINITY;
+    const int stride = ctx->max_d + 1;
+    for (int L = 1; L <= lmax; ++L)
+      for (int d = 1; d <= dmax; ++d) {
+        const int r = (L + 4) / 5;
+        double l = ctx->h_nb[(size_t)r * stride + d];
+        l -= ctx->h_logl[L] * (double)d;
+        l -= 1.629048269010741 * (double)d;
+        if (l == l) cmin = std::min(cmin, -l / (double)d);
+      }
+    if (!(cmin > 1e-6) || !std::isfinite(cmin)) {
+      fr.n_pre = 0;  // no usable bound: evaluate every candidate exactly
+      fr.inv_c = 0.0;
+    } else {
+      fr.inv_c = 1.0 / (cmin * (1.0 - 1e-9));
+    }
+    fr.prior_max_e = f.logc_max - t.scal[1];
+    fr.prior_max_n = f.logc_max - t.scal[0];
   }
   fr.n_cand = t.n_rows;
   fr.kpad = kpad;
@@ -806,6 +843,8 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
 // Bottom-up evaluation of one plan sub-tree for a list of items
 // (process_plan!, proposal_compiler.jl:363-388).  excl = per-item excluded row of
 // THIS node's table (device, may be null).  When n_draws > 0 the node also draws.
+static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
+                         uint64_t seed, uint32_t sweep, double* lse_out);
 static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
                      uint64_t seed, uint32_t sweep, int n_draws, double* lse_out, int32_t* draws_out,
                      double* scores_out, const double* snew_override, bool time_it) {
@@ -844,8 +883,7 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
                                t.cols.p + (size_t)cn.parent_fk_col * t.n_rows, ce);
             child_excl = ce;
           }
-          rc = eval_node(ctx, block_id, cid, il, child_excl, seed, sweep, 0, child_lse, nullptr, nullptr, nullptr,
-                         false);
+          rc = eval_node_lse(ctx, block_id, cid, il, child_excl, seed, sweep, child_lse);
           if (rc) return rc;
           ch.arr[c] = child_lse;
           ch.obs_col[c] = nullptr;
@@ -881,6 +919,9 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   HIPCHK(ctx, hipMemcpyAsync(&n_over, s->counter.p + 1, sizeof n_over, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timing.reserved += (int32_t)n_over;  // items that fell back to the generic kernel
+  if (n_over && getenv("PCLEAN_DEBUG_OVERFLOW"))
+    fprintf(stderr, "[pclean] block %d node %d: %u of %d items re-run by the generic kernel\n", block_id, node_id, n_over,
+            il.n);
   if (n_over) {
     int32_t* list = scratch<int32_t>(ctx, n_over);
     int32_t* row2 = scratch<int32_t>(ctx, n_over);
@@ -898,6 +939,144 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     rc = pclean_launch_enum(ctx, nd, it2, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out);
   }
   return rc;
+}
+
+// ---- item de-duplication ------------------------------------------------------------------------
+// The log marginal of a plan sub-tree is a pure function of (observed values of the sub-tree's
+// terms, ctx values, excluded row).  On a 1M-row table most rows share that tuple with other rows
+// (same hospital, same dirty cells), so the sub-tree is evaluated once per distinct tuple and the
+// result scattered back.  Distinct tuples are found by sorting a 64-bit hash and comparing adjacent
+// tuples exactly (a hash collision can only split a group, never merge two).
+struct KeyColsDev {
+  int32_t n_cols, use_ctx;
+  const int32_t* col[32];
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t h, uint32_t v) {
+  h ^= (uint64_t)v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+  h *= 0xff51afd7ed558ccdull;
+  return h ^ (h >> 32);
+}
+__global__ void item_key_kernel(int n, KeyColsDev kc, const int32_t* row, const int32_t* ctxv, const int32_t* excl,
+                                uint64_t* key, int32_t* idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r = row ? row[i] : i;
+  uint64_t h = 0x2545f4914f6cdd1dull;
+  for (int c = 0; c < kc.n_cols; ++c) h = mix64(h, (uint32_t)kc.col[c][r]);
+  if (kc.use_ctx && ctxv)
+    for (int s = 0; s < PCLEAN_MAX_CTX; ++s) h = mix64(h, (uint32_t)ctxv[(size_t)i * PCLEAN_MAX_CTX + s]);
+  if (excl) h = mix64(h, (uint32_t)excl[i]);
+  key[i] = h;
+  idx[i] = i;
+}
+__global__ void item_head_kernel(int n, KeyColsDev kc, const int32_t* row, const int32_t* ctxv, const int32_t* excl,
+                                 const uint64_t* key, const int32_t* idx, int32_t* head) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int h = 1;
+  if (j > 0 && key[j] == key[j - 1]) {
+    const int a = idx[j], b = idx[j - 1];
+    const int ra = row ? row[a] : a, rb = row ? row[b] : b;
+    bool same = true;
+    for (int c = 0; c < kc.n_cols && same; ++c) same = kc.col[c][ra] == kc.col[c][rb];
+    if (same && kc.use_ctx && ctxv)
+      for (int s = 0; s < PCLEAN_MAX_CTX && same; ++s)
+        same = ctxv[(size_t)a * PCLEAN_MAX_CTX + s] == ctxv[(size_t)b * PCLEAN_MAX_CTX + s];
+    if (same && excl) same = excl[a] == excl[b];
+    h = same ? 0 : 1;
+  }
+  head[j] = h;
+}
+__global__ void item_unique_kernel(int n, const int32_t* idx, const int32_t* head, const int32_t* uid_incl,
+                                   const int32_t* row, const int32_t* ctxv, const int32_t* excl, int32_t* uid_of_item,
+                                   int32_t* row2, int32_t* ctx2, int32_t* excl2) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int i = idx[j], u = uid_incl[j] - 1;
+  uid_of_item[i] = u;
+  if (head[j]) {
+    row2[u] = row ? row[i] : i;
+    if (ctxv)
+      for (int s = 0; s < PCLEAN_MAX_CTX; ++s) ctx2[(size_t)u * PCLEAN_MAX_CTX + s] = ctxv[(size_t)i * PCLEAN_MAX_CTX + s];
+    if (excl) excl2[u] = excl[i];
+  }
+}
+__global__ void gather_f64_kernel(int n, const int32_t* src_of, const double* src, double* dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[src_of[i]];
+}
+
+// observed columns / ctx use of a plan sub-tree; false when the sub-tree cannot be keyed (numeric terms)
+static bool subtree_key(pclean_ctx* ctx, const Block& b, int node_id, std::set<int>& cols, bool& use_ctx) {
+  const pclean_node& n = b.nodes[node_id];
+  if (node_id < (int)b.node_gauss.size() && b.node_gauss[node_id] >= 0) return false;
+  for (int i = 0; i < n.n_terms; ++i) {
+    const pclean_term& tm = b.terms[n.term_begin + i];
+    if (tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP) return false;
+    cols.insert(tm.obs_col);
+    if (tm.ctx_slot >= 0) use_ctx = true;
+  }
+  for (int c = 0; c < n.n_children; ++c)
+    if (!subtree_key(ctx, b, b.children[n.child_begin + c], cols, use_ctx)) return false;
+  return true;
+}
+
+// log marginal of sub-tree `node_id` for every item (no draws), evaluated once per distinct item tuple
+static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
+                         uint64_t seed, uint32_t sweep, double* lse_out) {
+  Block& b = ctx->block[block_id];
+  std::set<int> cols;
+  bool use_ctx = false;
+  static const bool disabled = getenv("PCLEAN_NO_DEDUP") != nullptr;
+  if (disabled || il.n < 32768 || il.ev_lo || !subtree_key(ctx, b, node_id, cols, use_ctx) || cols.size() > 32)
+    return eval_node(ctx, block_id, node_id, il, excl, seed, sweep, 0, lse_out, nullptr, nullptr, nullptr, false);
+  const int n = il.n;
+  KeyColsDev kc{};
+  kc.use_ctx = use_ctx ? 1 : 0;
+  for (int c : cols) {
+    if (c < 0 || c >= ctx->n_cols) return pclean_fail(ctx, PCLEAN_ERR_ARG, "term column out of range");
+    kc.col[kc.n_cols++] = ctx->obs.p + (size_t)c * ctx->n_rows + ctx->active_begin;
+  }
+  uint64_t* key = scratch<uint64_t>(ctx, n);
+  uint64_t* key_s = scratch<uint64_t>(ctx, n);
+  int32_t* idx = scratch<int32_t>(ctx, n);
+  int32_t* idx_s = scratch<int32_t>(ctx, n);
+  int32_t* head = scratch<int32_t>(ctx, n);
+  int32_t* uid = scratch<int32_t>(ctx, n);
+  int32_t* uid_of_item = scratch<int32_t>(ctx, n);
+  if (!key || !key_s || !idx || !idx_s || !head || !uid || !uid_of_item)
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  hipLaunchKernelGGL(item_key_kernel, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, key, idx);
+  size_t tmp_sort = 0, tmp_scan = 0;
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, key, key_s, idx, idx_s, n, 0, 64, ctx->stream));
+  HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan, head, uid, n, ctx->stream));
+  unsigned char* tmp = scratch<unsigned char>(ctx, std::max(tmp_sort, tmp_scan));
+  if (!tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_sort, key, key_s, idx, idx_s, n, 0, 64, ctx->stream));
+  hipLaunchKernelGGL(item_head_kernel, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, key_s, idx_s, head);
+  HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(tmp, tmp_scan, head, uid, n, ctx->stream));
+  int32_t n_unique = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&n_unique, uid + (n - 1), sizeof n_unique, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_unique <= 0 || (double)n_unique > 0.75 * n)  // not worth the indirection
+    return eval_node(ctx, block_id, node_id, il, excl, seed, sweep, 0, lse_out, nullptr, nullptr, nullptr, false);
+  int32_t* row2 = scratch<int32_t>(ctx, n_unique);
+  int32_t* ctx2 = scratch<int32_t>(ctx, (size_t)n_unique * PCLEAN_MAX_CTX);
+  int32_t* excl2 = scratch<int32_t>(ctx, n_unique);
+  double* lse_u = scratch<double>(ctx, n_unique);
+  if (!row2 || !ctx2 || !excl2 || !lse_u) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  hipLaunchKernelGGL(item_unique_kernel, grid1(n), dim3(256), 0, ctx->stream, n, idx_s, head, uid, il.row, il.ctx, excl,
+                     uid_of_item, row2, ctx2, excl2);
+  ItemList il2;
+  il2.n = n_unique;
+  il2.row = row2;
+  il2.ctx = il.ctx ? ctx2 : nullptr;
+  int rc = eval_node(ctx, block_id, node_id, il2, excl ? excl2 : nullptr, seed, sweep, 0, lse_u, nullptr, nullptr, nullptr,
+                     false);
+  if (rc) return rc;
+  hipLaunchKernelGGL(gather_f64_kernel, grid1(n), dim3(256), 0, ctx->stream, n, uid_of_item, lse_u, lse_out);
+  return PCLEAN_OK;
 }
 
 // Top-down sampling of the children of freshly proposed rows
