@@ -71,6 +71,11 @@ struct ItemsDev {
   const int32_t* ev_rows;
   const int32_t* ev_ctx;
   const int32_t* rng_row;  // RNG row id of item t (defaults to the evidence row)
+  // Grouped launch (items with identical score vectors): workgroup g scores item members[grp_off[g]]
+  // once and emits the log marginal and the draws of every member item members[grp_off[g] ..
+  // grp_off[g+1]) — each with its own RNG row / particle.  Null: one item per workgroup, n = items.
+  const int32_t* grp_off;
+  const int32_t* members;
 };
 
 // Log-marginals of the children of a "new row": either one value per item, or a

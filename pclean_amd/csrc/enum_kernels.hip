@@ -203,8 +203,10 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int t = blockIdx.x + item_base;
-  const int to = it.out_pos ? it.out_pos[t] : t;  // output slot of this item
+  const int g = blockIdx.x + item_base;
+  const int m_lo = it.grp_off ? it.grp_off[g] : g, m_hi = it.grp_off ? it.grp_off[g + 1] : g + 1;
+  const int t = it.grp_off ? it.members[m_lo] : g;  // the item whose scores stand for the whole group
+  const int to = it.out_pos ? it.out_pos[t] : t;    // output slot of this item
   const int n = nd.n_cand;
   const bool fk = nd.kind == PCLEAN_NODE_FK;
   const int nc = n + (fk ? 1 : 0);
@@ -246,22 +248,27 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   for (int k = lo; k < hi; ++k) part += u[k];
   uint64_t U;
   const uint64_t pre = block_excl_scan(part, wsum, &U);
-  // ---- phase 5: lse + draws ----------------------------------------------------
-  if (tid == 0 && lse_out) lse_out[to] = pclean_lse_from_fix(m, U);
-  if (n_draws > 0) {
+  // ---- phase 5: lse + draws (of every member item of the group) --------------------------------
+  const double lse = pclean_lse_from_fix(m, U);
+  for (int mi = m_lo; mi < m_hi; ++mi) {
+    const int tm = it.grp_off ? it.members[mi] : t;
+    const int tom = it.out_pos ? it.out_pos[tm] : tm;
+    if (tid == 0 && lse_out) lse_out[tom] = lse;
+    if (n_draws <= 0) continue;
     // one Philox evaluation per draw for the whole workgroup (lane j of wave 0), broadcast through LDS
     uint64_t* xs = wsum + 8;  // [64]
-    const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[t] : (uint32_t)((int64_t)v.row + it.row_offset);
+    const int row_m = it.row ? it.row[tm] : tm;
+    const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[tm] : (uint32_t)((int64_t)row_m + it.row_offset);
     for (int j0 = 0; j0 < n_draws; j0 += 64) {
       __syncthreads();
       if (tid < 64 && j0 + tid < n_draws) {
-        const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)(j0 + tid);
+        const uint32_t pid = it.particle ? (uint32_t)it.particle[tm] : (uint32_t)(j0 + tid);
         xs[tid] = U ? pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U) : 0ull;
       }
       __syncthreads();
       const int jn = min(64, n_draws - j0);
       for (int j = 0; j < jn; ++j) {
-        int32_t* dst = draws_out + (size_t)to * n_draws + j0 + j;
+        int32_t* dst = draws_out + (size_t)tom * n_draws + j0 + j;
         if (U == 0) {
           if (tid == 0) *dst = fk ? PCLEAN_CHOICE_NEW : n - 1;
           continue;

@@ -108,7 +108,9 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T = blockDim.x, nw = T >> 6;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = blockIdx.x + item_base;
+  const int g = blockIdx.x + item_base;
+  const int m_lo = it.grp_off ? it.grp_off[g] : g, m_hi = it.grp_off ? it.grp_off[g + 1] : g + 1;
+  const int t = it.grp_off ? it.members[m_lo] : g;  // the item whose scores stand for the whole group
   const int n = fr.n_cand;
   // LDS carve (all offsets multiples of 16 bytes)
   double* red = (double*)smem;                                  // [16] per-wave maxima
@@ -349,14 +351,13 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   }
   __syncthreads();
   const unsigned int n2 = cnt[1];
-  if (n2 > SURV2_CAP || cnt[2] != 0) {  // flat posterior: the host re-runs this item with the generic kernel
-    if (tid == 0) {
-      overflow_flag[t] = PCLEAN_CHOICE_NEW;  // marker understood by compact_new_kernel
-      atomicAdd(overflow_count, 1u);
-    }
+  if (n2 > SURV2_CAP || cnt[2] != 0) {  // flat posterior: the host re-runs these items with the generic kernel
+    for (int mi = m_lo + tid; mi < m_hi; mi += T)
+      overflow_flag[it.grp_off ? it.members[mi] : t] = PCLEAN_CHOICE_NEW;  // marker understood by compact_new_kernel
+    if (tid == 0) atomicAdd(overflow_count, (unsigned int)(m_hi - m_lo));
     return;
   }
-  if (tid == 0) overflow_flag[t] = 0;
+  for (int mi = m_lo + tid; mi < m_hi; mi += T) overflow_flag[it.grp_off ? it.members[mi] : t] = 0;
   // ---- phase 4: rank sort by candidate index (natural order), weights ------------------------
   for (unsigned int i = tid; i < n2; i += T) {
     const int ki = k2[i];
@@ -386,11 +387,16 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   __syncthreads();
   const uint64_t U = n2 ? u2[n2 - 1] : 0ull;
   // ---- phase 5: lse + draws ---------------------------------------------------------------
-  if (tid == 0 && lse_out) lse_out[t] = pclean_lse_from_fix(m, U);
-  if (n_draws > 0) {
-    const uint32_t rng_row = (uint32_t)((int64_t)row + it.row_offset);
-    for (int j = tid; j < n_draws; j += T) {
-      const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)j;
+  const double lse = pclean_lse_from_fix(m, U);
+  const int n_out = (m_hi - m_lo) * (n_draws > 0 ? n_draws : 1);
+  for (int q = tid; q < n_out; q += T) {  // (member item, draw) pairs of the group
+    const int mi = m_lo + (n_draws > 0 ? q / n_draws : q), j = n_draws > 0 ? q % n_draws : 0;
+    const int tm = it.grp_off ? it.members[mi] : t;
+    if (j == 0 && lse_out) lse_out[tm] = lse;
+    if (n_draws > 0) {
+      const int row_m = it.row ? it.row[tm] : tm;
+      const uint32_t rng_row = (uint32_t)((int64_t)row_m + it.row_offset);
+      const uint32_t pid = it.particle ? (uint32_t)it.particle[tm] : (uint32_t)j;
       int32_t res = PCLEAN_CHOICE_NEW;
       if (U != 0) {
         const uint64_t x = pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U);
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
         const int k = ks[lo];
         res = k == n ? PCLEAN_CHOICE_NEW : k;
       }
-      draws_out[(size_t)t * n_draws + j] = res;
+      draws_out[(size_t)tm * n_draws + j] = res;
     }
   }
 }

@@ -845,6 +845,15 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
 // THIS node's table (device, may be null).  When n_draws > 0 the node also draws.
 static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
                          uint64_t seed, uint32_t sweep, double* lse_out);
+struct ItemGroups {
+  int n_groups = 0;              // 0: grouping not applicable / not worth it
+  const int32_t* grp_off = nullptr;  // [n_groups + 1] into members
+  const int32_t* members = nullptr;  // [n] item ids, groups contiguous
+  const int32_t* head = nullptr;     // [n] 1 at the first member of each group (sorted order)
+  const int32_t* uid = nullptr;      // [n] inclusive scan of head
+};
+static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
+                            ItemGroups& g);
 static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
                      uint64_t seed, uint32_t sweep, int n_draws, double* lse_out, int32_t* draws_out,
                      double* scores_out, const double* snew_override, bool time_it) {
@@ -892,12 +901,28 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     }
   }
   ItemsDev it{il.n, 0, il.row, il.ctx, excl, n_draws == 1 ? il.particle : nullptr, s->row_offset + ctx->active_begin,
-              nullptr, il.ev_lo, il.ev_hi, il.ev_rows, il.ev_ctx, il.rng_row};
+              nullptr, il.ev_lo, il.ev_hi, il.ev_rows, il.ev_ctx, il.rng_row, nullptr, nullptr};
   FastRootDev fr;
   int fast = 0;
   if (!scores_out && !snew_override && !ctx->force_generic && !il.ev_lo && !nd.g.on) {
     fast = try_fast_root(ctx, block_id, node_id, fr);
     if (fast < 0) return fast;
+  }
+  // Items with identical score vectors (same observed tuple, ctx and excluded row) share one
+  // workgroup: scores once, draws per member item.
+  {
+    const int nc = nd.n_cand + (n.kind == PCLEAN_NODE_FK ? 1 : 0);
+    const bool lds_kernel = (size_t)((nc + 1) & ~1) * 8 + (16 + 64) * 8 <= 160 * 1024;
+    if (n_draws > 0 && !scores_out && !snew_override && !ctx->force_generic && !il.rng_row && (fast || lds_kernel)) {
+      ItemGroups g;
+      rc = make_item_groups(ctx, block_id, node_id, il, excl, g);
+      if (rc) return rc;
+      if (g.n_groups > 0) {
+        it.n = g.n_groups;
+        it.grp_off = g.grp_off;
+        it.members = g.members;
+      }
+    }
   }
   const uint32_t site = PCLEAN_SITE_NODE(block_id, node_id);
   if (!fast) {
@@ -1022,15 +1047,26 @@ static bool subtree_key(pclean_ctx* ctx, const Block& b, int node_id, std::set<i
   return true;
 }
 
-// log marginal of sub-tree `node_id` for every item (no draws), evaluated once per distinct item tuple
-static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
-                         uint64_t seed, uint32_t sweep, double* lse_out) {
+__global__ void group_offsets_kernel(int n, const int32_t* head, const int32_t* uid, int32_t* grp_off) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j > n) return;
+  if (j == n)
+    grp_off[uid[n - 1]] = n;
+  else if (head[j])
+    grp_off[uid[j] - 1] = j;
+}
+
+// Groups the items of `il` by (observed values of the sub-tree of node_id, ctx, excl).  g.n_groups == 0
+// when the sub-tree cannot be keyed, the list is small, or fewer than a quarter of the items are duplicates.
+static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
+                            ItemGroups& g) {
   Block& b = ctx->block[block_id];
   std::set<int> cols;
   bool use_ctx = false;
   static const bool disabled = getenv("PCLEAN_NO_DEDUP") != nullptr;
+  g = ItemGroups();
   if (disabled || il.n < 32768 || il.ev_lo || !subtree_key(ctx, b, node_id, cols, use_ctx) || cols.size() > 32)
-    return eval_node(ctx, block_id, node_id, il, excl, seed, sweep, 0, lse_out, nullptr, nullptr, nullptr, false);
+    return PCLEAN_OK;
   const int n = il.n;
   KeyColsDev kc{};
   kc.use_ctx = use_ctx ? 1 : 0;
@@ -1044,9 +1080,7 @@ static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemL
   int32_t* idx_s = scratch<int32_t>(ctx, n);
   int32_t* head = scratch<int32_t>(ctx, n);
   int32_t* uid = scratch<int32_t>(ctx, n);
-  int32_t* uid_of_item = scratch<int32_t>(ctx, n);
-  if (!key || !key_s || !idx || !idx_s || !head || !uid || !uid_of_item)
-    return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  if (!key || !key_s || !idx || !idx_s || !head || !uid) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   hipLaunchKernelGGL(item_key_kernel, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, key, idx);
   size_t tmp_sort = 0, tmp_scan = 0;
   HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, key, key_s, idx, idx_s, n, 0, 64, ctx->stream));
@@ -1059,8 +1093,33 @@ static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemL
   int32_t n_unique = 0;
   HIPCHK(ctx, hipMemcpyAsync(&n_unique, uid + (n - 1), sizeof n_unique, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (n_unique <= 0 || (double)n_unique > 0.75 * n)  // not worth the indirection
+  if (n_unique <= 0 || (double)n_unique > 0.75 * n) return PCLEAN_OK;  // not worth the indirection
+  int32_t* grp_off = scratch<int32_t>(ctx, (size_t)n_unique + 1);
+  if (!grp_off) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  hipLaunchKernelGGL(group_offsets_kernel, grid1((size_t)n + 1), dim3(256), 0, ctx->stream, n, head, uid, grp_off);
+  g.n_groups = n_unique;
+  g.grp_off = grp_off;
+  g.members = idx_s;
+  g.head = head;
+  g.uid = uid;
+  return PCLEAN_OK;
+}
+
+// log marginal of sub-tree `node_id` for every item (no draws), evaluated once per distinct item tuple
+static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
+                         uint64_t seed, uint32_t sweep, double* lse_out) {
+  ItemGroups g;
+  int rc0 = make_item_groups(ctx, block_id, node_id, il, excl, g);
+  if (rc0) return rc0;
+  if (g.n_groups == 0)
     return eval_node(ctx, block_id, node_id, il, excl, seed, sweep, 0, lse_out, nullptr, nullptr, nullptr, false);
+  const int n = il.n;
+  const int32_t n_unique = g.n_groups;
+  const int32_t* idx_s = g.members;
+  const int32_t* head = g.head;
+  const int32_t* uid = g.uid;
+  int32_t* uid_of_item = scratch<int32_t>(ctx, n);
+  if (!uid_of_item) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   int32_t* row2 = scratch<int32_t>(ctx, n_unique);
   int32_t* ctx2 = scratch<int32_t>(ctx, (size_t)n_unique * PCLEAN_MAX_CTX);
   int32_t* excl2 = scratch<int32_t>(ctx, n_unique);

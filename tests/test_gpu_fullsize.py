@@ -33,7 +33,17 @@ def test_million_row_sweep_properties(oracle):
         assert np.array_equal(choice, choice2) and np.array_equal(chosen, chosen2) and np.array_equal(logml, logml2)
         # (b) parity on chunks spread over the table
         c = InferConfig(1, P, 1, 1, 0, 50, 100)
-        for start in (0, n_rows // 2 - 37, n_rows - 120):
+        # ... plus rows the sweep moved and rows that picked a brand-new referent (grouped launches, the
+        # integer pre-filter and the generic fallback all meet here); chunks must be contiguous for the
+        # oracle's row-keyed RNG, so take the 120-row window around such rows
+        moved = np.nonzero((choice != tr.cur).any(axis=0))[0]
+        fresh = np.nonzero((choice < 0).any(axis=0))[0]
+        starts = [0, n_rows // 2 - 37, n_rows - 120]
+        for special in (moved[:1], moved[len(moved) // 2:len(moved) // 2 + 1], fresh[:1], fresh[-1:]):
+            if len(special):
+                starts.append(int(min(max(special[0] - 60, 0), n_rows - 120)))
+        assert len(moved) > 100 and len(fresh) > 10
+        for start in starts:
             rows = np.arange(start, start + 120)
             w, _ = bench.oracle_world_for_rows(oracle, lw, obs, tr, eng, rows)
             cur = np.ascontiguousarray(tr.cur[:, rows])
