@@ -166,14 +166,22 @@ def main():
     cfg = InferenceConfig(args.warmup + args.steps, args.particles)
 
     def step(idx):
+        t_a = time.perf_counter()
         eng.upload_trace(tr)
-        choice, chosen, logml, new_rows = eng.sweep(tr, cfg, args.seed, idx)
+        t_b = time.perf_counter()
+        choice, chosen, logml, new_rows = eng.sweep(tr, cfg, args.seed, idx, reuse_buffers=True)
+        t_c = time.perf_counter()
         stats = eng.sweep_stats(tr)
         tm = eng.hip.get_timing()
+        t_d = time.perf_counter()
         if os.environ.get("PCLEAN_BENCH_DEBUG"):
             log("[bench] moved per block", (choice != tr.cur).sum(axis=1), "new per block", (choice < 0).sum(axis=1),
                 "chosen particle hist", np.bincount(chosen, minlength=cfg.num_particles)[:6])
         changed = exchange_and_commit(tr, lw, comm, lo, choice, stats, new_rows)
+        t_e = time.perf_counter()
+        if os.environ.get("PCLEAN_BENCH_DEBUG"):
+            log(f"[bench] host phases ms: upload {1e3 * (t_b - t_a):.2f} sweep call {1e3 * (t_c - t_b):.2f} "
+                f"(device span {tm.total_ms:.2f}) stats {1e3 * (t_d - t_c):.2f} exchange+commit {1e3 * (t_e - t_d):.2f}")
         return tm, changed
 
     for i in range(args.warmup):

@@ -101,6 +101,7 @@ class HipContext:
 
     def __init__(self, device=0):
         self.lib = load_library()
+        self._pinned, self._io = [], {}
         self.h = C.c_void_p()
         rc = self.lib.pclean_ctx_create(C.c_int(device), C.byref(self.h))
         if rc != 0:
@@ -110,6 +111,9 @@ class HipContext:
 
     def close(self):
         if self.h:
+            for a in self._pinned:
+                self.lib.pclean_unpin_host(self.h, C.c_void_p(a.ctypes.data))
+            self._pinned, self._io = [], {}
             self.lib.pclean_ctx_destroy(self.h)
             self.h = C.c_void_p()
 
@@ -348,12 +352,40 @@ class HipContext:
             _p(lse, C.c_double), _p(scores, C.c_double), _p(draws, C.c_int32)), "pclean_score_node")
         return lse, scores, draws
 
-    def sweep(self, cfg, seed, sweep_idx, cur):
-        cur = np.ascontiguousarray(cur, dtype=np.int32)  # [n_blocks][n_rows]
-        n_blocks, n_rows = cur.shape
-        choice = np.empty_like(cur)
-        chosen = np.empty(n_rows, dtype=np.int32)
-        logml = np.empty(n_rows, dtype=np.float64)
+    def pinned_empty(self, shape, dtype):
+        """numpy array whose buffer is page-locked for this context (released with the context)."""
+        a = np.empty(shape, dtype=dtype)
+        if a.nbytes:
+            check(self.h, self.lib.pclean_pin_host(self.h, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes)),
+                  "pclean_pin_host")
+            self._pinned.append(a)
+        return a
+
+    def _io_buffers(self, n_blocks, n_rows):
+        key = (n_blocks, n_rows)
+        if self._io.get("key") != key:
+            for a in self._io.get("arrays", ()):
+                self.lib.pclean_unpin_host(self.h, C.c_void_p(a.ctypes.data))
+                self._pinned = [p for p in self._pinned if p is not a]
+            arrays = (self.pinned_empty((n_blocks, n_rows), np.int32), self.pinned_empty((n_blocks, n_rows), np.int32),
+                      self.pinned_empty(n_rows, np.int32), self.pinned_empty(n_rows, np.float64))
+            self._io = {"key": key, "arrays": arrays}
+        return self._io["arrays"]
+
+    def sweep(self, cfg, seed, sweep_idx, cur, reuse_buffers=False):
+        """cur [n_blocks][n_rows] -> (choice, chosen particle, log marginal likelihood).  With
+        reuse_buffers the I/O goes through page-locked buffers owned by the context: the returned arrays
+        are then views that the next sweep of the same shape overwrites."""
+        n_blocks, n_rows = np.shape(cur)
+        if reuse_buffers:
+            cur_buf, choice, chosen, logml = self._io_buffers(n_blocks, n_rows)
+            np.copyto(cur_buf, cur)
+            cur = cur_buf
+        else:
+            cur = np.ascontiguousarray(cur, dtype=np.int32)
+            choice = np.empty_like(cur)
+            chosen = np.empty(n_rows, dtype=np.int32)
+            logml = np.empty(n_rows, dtype=np.float64)
         check(self.h, self.lib.pclean_sweep(self.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep_idx),
                                             C.c_int32(n_blocks), _p(cur, C.c_int32), _p(choice, C.c_int32),
                                             _p(chosen, C.c_int32), _p(logml, C.c_double)), "pclean_sweep")

@@ -410,6 +410,19 @@ extern "C" int pclean_load_numeric_columns(pclean_ctx* ctx, int32_t n_rows, int3
   return PCLEAN_OK;
 }
 
+extern "C" int pclean_pin_host(pclean_ctx* ctx, void* ptr, size_t bytes) {
+  if (!ctx || !ptr || bytes == 0) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_pin_host: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return PCLEAN_OK;
+}
+extern "C" int pclean_unpin_host(pclean_ctx* ctx, void* ptr) {
+  if (!ctx || !ptr) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_unpin_host: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipHostUnregister(ptr));
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_set_mean_table(pclean_ctx* ctx, int32_t table_id, int32_t n, const double* mean) {
   if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || n <= 0 || !mean)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_mean_table: bad arguments");

@@ -92,10 +92,16 @@ struct ChildrenDev {
 // the latent table's columns change) so a work item streams F contiguous byte rows instead
 // of gathering, plus the candidates' word lengths clen[k].
 struct FastTermDev {
-  const uint8_t* comp;     // [n_obs][kpad]
+  const uint8_t* comp;     // [n_obs][kpad]   (null for a ctx term)
   const uint8_t* clen;     // [kpad]
   const int32_t* obs_col;  // [n_rows]
-  int32_t max_typos, pad;
+  int32_t max_typos, ctx_slot;  // ctx_slot >= 0: the latent value goes through fn[ctx][value] first (a
+                                // JuliaNode of an earlier block's choice); scored by gathering, never pre-filtered
+  const uint8_t* pair;       // [n_obs][n_lat] byte distances          (ctx terms only)
+  const uint16_t* lat_len;   // [n_lat]
+  const int32_t* cand_col;   // [n_cand]
+  const int32_t* fn;         // [n_ctx][fn_nb]
+  int32_t n_lat, fn_nb;
 };
 struct FastRootDev {
   int32_t n_cand, kpad, n_terms, lmax, dstride, pad;

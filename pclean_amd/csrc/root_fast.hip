@@ -133,19 +133,36 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   // per-term row pointers (wave-uniform -> scalar registers)
   const uint32_t* crow[NT];
   const uint32_t* lrow[NT];
+  const uint8_t* grow[NT];   // ctx terms: the observed value's row of the full pair table
+  const int32_t* gfn[NT];    //            fn[ctx value][.]
   int mt[NT];
 #pragma unroll
   for (int f = 0; f < NT; ++f) {
     crow[f] = nullptr;
     lrow[f] = nullptr;
+    grow[f] = nullptr;
+    gfn[f] = nullptr;
     mt[f] = -1;
     if (f < fr.n_terms) {
       const int o = fr.terms[f].obs_col[row];
-      if (o >= 0) crow[f] = reinterpret_cast<const uint32_t*>(fr.terms[f].comp + (size_t)o * fr.kpad);
-      lrow[f] = reinterpret_cast<const uint32_t*>(fr.terms[f].clen);
       mt[f] = fr.terms[f].max_typos;
+      if (fr.terms[f].ctx_slot >= 0) {
+        if (o >= 0) {
+          grow[f] = fr.terms[f].pair + (size_t)o * fr.terms[f].n_lat;
+          gfn[f] = fr.terms[f].fn + (size_t)it.ctx[(size_t)t * PCLEAN_MAX_CTX + fr.terms[f].ctx_slot] * fr.terms[f].fn_nb;
+        }
+      } else {
+        if (o >= 0) crow[f] = reinterpret_cast<const uint32_t*>(fr.terms[f].comp + (size_t)o * fr.kpad);
+        lrow[f] = reinterpret_cast<const uint32_t*>(fr.terms[f].clen);
+      }
     }
   }
+  // density of ctx term f for candidate k (term_density() of enum_kernels.hip on the mapped value)
+  auto ctx_term = [&](int f, int k) {
+    const int val = gfn[f][fr.terms[f].cand_col[k]];
+    const int d = grow[f][val], L = fr.terms[f].lat_len[val];
+    return (mt[f] >= 0 && d > mt[f]) ? ADD_TYPOS_IMPOSSIBLE : add_typos_dens(dn, L, d);
+  };
   // the (up to 3) most discriminating terms: byte rows summed by the integer pre-filter
   const uint32_t* prow[3];
 #pragma unroll
@@ -161,11 +178,14 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   auto exact_score = [&](int k, double pr) {
     double b = pr;
 #pragma unroll
-    for (int f = 0; f < NT; ++f)
+    for (int f = 0; f < NT; ++f) {
       if (crow[f]) {
         const int d = reinterpret_cast<const uint8_t*>(crow[f])[k], L = reinterpret_cast<const uint8_t*>(lrow[f])[k];
         b += (mt[f] >= 0 && d > mt[f]) ? ADD_TYPOS_IMPOSSIBLE : add_typos_dens(dn, L, d);
+      } else if (grow[f]) {
+        b += ctx_term(f, k);
       }
+    }
     return b;
   };
   const int nslots = fr.kpad >> 2;
@@ -286,6 +306,10 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
           if (mt[f] >= 0 && d > mt[f]) dens = ADD_TYPOS_IMPOSSIBLE;
           acc[e] += dens;
         }
+      } else if (grow[f]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (k0 + e < n) acc[e] += ctx_term(f, k0 + e);
       }
     }
 #pragma unroll

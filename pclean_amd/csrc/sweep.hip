@@ -223,19 +223,31 @@ __global__ void add_weight_kernel(size_t n, const double* lse, double* w) {
 }
 
 // compaction of NEW choices: pass 0 counts, pass 1 fills
-__global__ void compact_new_kernel(size_t n, const int32_t* choice, int fill, unsigned int* counter, int32_t* list,
-                                   int32_t* pos_out) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  if (choice[t] != PCLEAN_CHOICE_NEW) {
-    if (fill && pos_out) pos_out[t] = -1;
+// (block-aggregated: one global atomic per 256 elements instead of one per hit)
+__global__ __launch_bounds__(256) void compact_new_kernel(size_t n, const int32_t* choice, int fill,
+                                                          unsigned int* counter, int32_t* list, int32_t* pos_out) {
+  __shared__ unsigned int wcnt[4];
+  __shared__ unsigned int bbase;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool hit = t < n && choice[t] == PCLEAN_CHOICE_NEW;
+  const unsigned long long mask = __ballot(hit);
+  if (lane == 0) wcnt[wave] = (unsigned int)__popcll(mask);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    bbase = total ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  if (t >= n || !fill) return;
+  if (!hit) {
+    if (pos_out) pos_out[t] = -1;
     return;
   }
-  const unsigned int pos = atomicAdd(counter, 1u);
-  if (fill) {
-    list[pos] = (int32_t)t;
-    if (pos_out) pos_out[t] = (int32_t)pos;
-  }
+  unsigned int pos = bbase + (unsigned int)__popcll(mask & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; ++w) pos += wcnt[w];
+  list[pos] = (int32_t)t;
+  if (pos_out) pos_out[t] = (int32_t)pos;
 }
 
 // sub-list items from a parent list: list[j] indexes the parent's items
@@ -752,7 +764,8 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   for (int i = 0; i < n.n_terms; ++i) {
     const pclean_term& tm = b.terms[n.term_begin + i];
     const PairTable& pt = ctx->pair[tm.pair_table];
-    if (!pt.valid || tm.dens_kind != PCLEAN_DENS_ADD_TYPOS || tm.ctx_slot >= 0 || pt.elem_bytes != 1) return 0;
+    if (!pt.valid || tm.dens_kind != PCLEAN_DENS_ADD_TYPOS || pt.elem_bytes != 1) return 0;
+    if (tm.ctx_slot >= 0 && (tm.ctx_mode != 0 || !ctx->fn[tm.fn_table].valid)) return 0;
     lmax = std::max(lmax, pt.max_lat_len);
     dmax = std::max(dmax, std::max(pt.max_lat_len, pt.max_obs_len));
   }
@@ -774,6 +787,20 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   for (int i = 0; i < n.n_terms; ++i) {
     const pclean_term& tm = b.terms[n.term_begin + i];
     const PairTable& pt = ctx->pair[tm.pair_table];
+    fr.terms[i] = FastTermDev{};
+    fr.terms[i].obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
+    fr.terms[i].max_typos = tm.max_typos;
+    fr.terms[i].ctx_slot = tm.ctx_slot;
+    if (tm.ctx_slot >= 0) {  // scored by gathering (few survivors reach it)
+      const FnTable& fnt = ctx->fn[tm.fn_table];
+      fr.terms[i].pair = (const uint8_t*)pt.d.p;
+      fr.terms[i].lat_len = pt.lat_len.p;
+      fr.terms[i].cand_col = t.cols.p + (size_t)tm.cand_col * t.n_rows;
+      fr.terms[i].fn = fnt.fn.p;
+      fr.terms[i].n_lat = pt.n_lat;
+      fr.terms[i].fn_nb = fnt.n_b;
+      continue;
+    }
     const uint64_t ver = t.cols_version * 1000003ull + pt.version;
     if (f.ver[i] != ver || !f.comp[i].p) {
       if (f.comp[i].alloc((size_t)pt.n_obs * kpad) || f.clen[i].alloc(kpad))
@@ -785,8 +812,6 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     }
     fr.terms[i].comp = f.comp[i].p;
     fr.terms[i].clen = f.clen[i].p;
-    fr.terms[i].obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
-    fr.terms[i].max_typos = tm.max_typos;
   }
   if (f.prior_ver != t.version || !f.prior_e.p) {
     if (f.prior_e.alloc(kpad) || f.prior_n.alloc(kpad)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
@@ -803,10 +828,14 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     int order[PCLEAN_MAX_TERMS];
     for (int i = 0; i < n.n_terms; ++i) order[i] = i;
     std::stable_sort(order, order + n.n_terms, [&](int a, int c) {
-      return ctx->pair[b.terms[n.term_begin + a].pair_table].max_lat_len >
-             ctx->pair[b.terms[n.term_begin + c].pair_table].max_lat_len;
+      const pclean_term& ta = b.terms[n.term_begin + a];
+      const pclean_term& tc = b.terms[n.term_begin + c];
+      if ((ta.ctx_slot >= 0) != (tc.ctx_slot >= 0)) return ta.ctx_slot < 0;  // compact-table terms first
+      return ctx->pair[ta.pair_table].max_lat_len > ctx->pair[tc.pair_table].max_lat_len;
     });
-    fr.n_pre = std::min(3, (int)n.n_terms);
+    int n_compact = 0;
+    for (int i = 0; i < n.n_terms; ++i) n_compact += b.terms[n.term_begin + i].ctx_slot < 0 ? 1 : 0;
+    fr.n_pre = std::min(3, n_compact);
     for (int p = 0; p < 3; ++p) fr.pre[p] = p < fr.n_pre ? order[p] : 0;
     double cmin = INFINITY;
     const int stride = ctx->max_d + 1;

@@ -185,9 +185,11 @@ class Engine:
                 self._upload_gauss()
                 self._gauss_pending = False
 
-    def sweep(self, trace, config, seed, sweep_idx, lo=0, hi=None):
+    def sweep(self, trace, config, seed, sweep_idx, lo=0, hi=None, reuse_buffers=False):
         """One batched sweep over the observed rows [lo, hi) of the trace (default: all of them).
-        Returns (choice, chosen_particle, logml, new_rows), all indexed relative to lo."""
+        Returns (choice, chosen_particle, logml, new_rows), all indexed relative to lo.  reuse_buffers:
+        results are views of page-locked buffers that the next sweep overwrites (callers that commit
+        the result right away: inference.py, bench.py)."""
         cfg = config.as_c() if isinstance(config, InferenceConfig) else config
         hi = trace.cur.shape[1] if hi is None else hi
         if hi <= lo:  # a rank may own no row of a small batch
@@ -198,7 +200,7 @@ class Engine:
             return np.zeros((nb, 0), np.int32), np.zeros(0, np.int32), np.zeros(0), {}
         self._empty_sweep = False
         self.hip.set_active_rows(lo, hi - lo)
-        choice, chosen, logml = self.hip.sweep(cfg, seed, sweep_idx, np.ascontiguousarray(trace.cur[:, lo:hi]))
+        choice, chosen, logml = self.hip.sweep(cfg, seed, sweep_idx, trace.cur[:, lo:hi], reuse_buffers)
         new_rows = {}
         for bi, blk in enumerate(self.lw.blocks):
             if blk.get("score"):

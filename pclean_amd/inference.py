@@ -222,7 +222,7 @@ def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None):
     n = trace.cur.shape[1]
     lo, hi = shard_bounds(n, comm.rank, comm.world)
     engine.upload_trace(trace)
-    choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi)
+    choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi, reuse_buffers=True)
     stats = engine.sweep_stats(trace)
     _gather_locals(trace, comm, 0, hi - lo, lo)
     return exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True)

@@ -104,9 +104,11 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
         t = trace.tables[cname]
         t.counts[:n_before] += delta
         # this rank's own rows
-        ch = np.array(choice_local[bi], dtype=np.int64)
-        for i in np.nonzero(ch < 0)[0]:
-            ch[i] = created[int(i) + row_lo]
+        ch = np.asarray(choice_local[bi])
+        fresh = np.flatnonzero(ch < 0)
+        if len(fresh):
+            ch = ch.copy()
+            ch[fresh] = [created[int(i) + row_lo] for i in fresh]
         if global_cur:
             cur = trace.cur[bi, row_lo:row_lo + n_local]
             moved = np.nonzero(ch != cur)[0]
@@ -116,8 +118,9 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
             trace.cur[bi, g_moved] = g_new
         else:
             cur = trace.cur[bi]
-            changed += int(np.sum(ch != cur))
-            trace.cur[bi] = ch.astype(np.int32)
+            moved = np.flatnonzero(ch != cur)
+            changed += len(moved)
+            cur[moved] = ch[moved]
         # garbage-collect rows nobody refers to any more (ascending id: deterministic)
         dead = np.nonzero((t.counts[:t.n] == 0) & t.live[:t.n])[0]
         for k in dead:
