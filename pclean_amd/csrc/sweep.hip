@@ -1094,7 +1094,7 @@ static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const It
   bool use_ctx = false;
   static const bool disabled = getenv("PCLEAN_NO_DEDUP") != nullptr;
   g = ItemGroups();
-  if (disabled || il.n < 32768 || il.ev_lo || !subtree_key(ctx, b, node_id, cols, use_ctx) || cols.size() > 32)
+  if (disabled || il.n < 4096 || il.ev_lo || !subtree_key(ctx, b, node_id, cols, use_ctx) || cols.size() > 32)
     return PCLEAN_OK;
   const int n = il.n;
   KeyColsDev kc{};

@@ -102,6 +102,7 @@ class Trace:
                     prior = m.classes[cname].attr(a.dist.param).prior
                     self.params[(cname, a.dist.param)] = ProportionsState(len(a.dist.options), prior.concentration,
                                                                          self.rng)
+        self._class_plans, self._node_plans = {}, {}
         self.cur = np.full((len(lowered.blocks), n_rows), -1, dtype=np.int32)
         # own enumerated choices of the observed class (e.g. br, unit) and the Gaussian mean parameter
         self.locals = {bi: np.full((n_rows, 2), -1, dtype=np.int32) for bi in getattr(lowered, "locals", {})}
@@ -175,13 +176,22 @@ class Trace:
         return rows[ok], idx[ok], x[ok]
 
     # -- own-choice sufficient statistics (update_sufficient_statistics!, dependency_tracking.jl:6-21)
+    def _class_plan(self, cname):
+        """(direct reference-slot columns [(col, target class)], conjugate choices [(col, parameter state)])."""
+        p = self._class_plans.get(cname)
+        if p is None:
+            lw = self.lw
+            fks = [(j, c.target) for j, c in enumerate(lw.layout[cname]) if c.kind == "fk" and "." not in c.name]
+            props = [(lw.colidx[cname][a.name], self.params[(cname, a.dist.param)])
+                     for a in lw.model.classes[cname].attrs
+                     if a.kind == "choice" and isinstance(a.dist, ChooseProportionally)]
+            p = self._class_plans[cname] = (fks, props)
+        return p
+
     def _own_choice_stats(self, cname, row, sign):
-        m = self.lw.model
         t = self.tables[cname]
-        for a in m.classes[cname].attrs:
-            if a.kind == "choice" and isinstance(a.dist, ChooseProportionally):
-                v = t.cols[self.lw.colidx[cname][a.name], row]
-                self.params[(cname, a.dist.param)].counts[v] += sign
+        for j, state in self._class_plan(cname)[1]:
+            state.counts[t.cols[j, row]] += sign
 
     def _dedup_key(self, cname, values):
         return (cname,) + tuple(int(v) for v in values)
@@ -195,9 +205,8 @@ class Trace:
         t.cols_dirty = True
         t.counts[r] = 0
         t.live[r] = True
-        for j, c in enumerate(self.lw.layout[cname]):
-            if c.kind == "fk" and "." not in c.name:
-                self.tables[c.target].counts[values[j]] += 1
+        for j, target in self._class_plan(cname)[0]:
+            self.tables[target].counts[values[j]] += 1
         self._own_choice_stats(cname, r, +1)
         return r
 
@@ -217,40 +226,55 @@ class Trace:
                     self.delete_row(c.target, k)
 
     # -- building a new row from the sampled node choices of a block ---------
+    def _node_plan(self, bi, node):
+        """Static recipe for building a row of `node`'s class from the sampled node choices:
+        (class, n_cols, leaf columns [(col, node, option values)], copied columns [(col, child node,
+        child class, child column)], reference-slot columns [(col, child node)])."""
+        key = (bi, node)
+        p = self._node_plans.get(key)
+        if p is None:
+            blk = self.lw.blocks[bi]
+            nodes, info = blk["nodes"], blk["node_info"]
+            cname = info[node]["cls"]
+            layout = self.lw.layout[cname]
+            cmb = nodes[node][9]
+            leaves, copies, slots = [], [], []
+            for j, c in enumerate(layout):
+                cn, cc = blk["colmap"][2 * (cmb + j)], blk["colmap"][2 * (cmb + j) + 1]
+                if cn >= 0:
+                    if nodes[cn][0] == 1:  # leaf: option index -> latent value
+                        leaves.append((j, cn, self.lw.option_values[(info[cn]["cls"], info[cn]["attr"])]))
+                    else:
+                        copies.append((j, cn, info[cn]["cls"], cc))
+                if c.kind == "fk" and "." not in c.name:
+                    for k in range(nodes[node][4], nodes[node][4] + nodes[node][5]):
+                        cid = blk["children"][k]
+                        if nodes[cid][0] == 0 and nodes[cid][7] == j:  # the direct child node of this slot
+                            slots.append((j, cid))
+            p = self._node_plans[key] = (cname, len(layout), leaves, copies, slots)
+        return p
+
     def _materialise(self, bi, node, vals):
-        blk = self.lw.blocks[bi]
-        nodes = blk["nodes"]
-        cname = blk["node_info"][node]["cls"]
-        layout = self.lw.layout[cname]
-        cmb = nodes[node][9]
-        values = np.zeros(len(layout), dtype=np.int32)
+        cname, n_cols, leaves, copies, slots = self._node_plan(bi, node)
+        values = np.zeros(n_cols, dtype=np.int32)
         child_rows = {}
-        for j, c in enumerate(layout):
-            cn, cc = blk["colmap"][2 * (cmb + j)], blk["colmap"][2 * (cmb + j) + 1]
-            if cn < 0:
-                continue
-            if nodes[cn][0] == 1:  # leaf: option index -> latent value
-                ocls, oattr = blk["node_info"][cn]["cls"], blk["node_info"][cn]["attr"]
-                values[j] = self.lw.option_values[(ocls, oattr)][vals[cn]]
-            else:
-                if cn not in child_rows:
-                    ch = int(vals[cn])
-                    if ch == CHOICE_NEW:
-                        ch = self._materialise(bi, cn, vals)
-                    child_rows[cn] = ch
-                values[j] = self.tables[blk["node_info"][cn]["cls"]].cols[cc, child_rows[cn]]
-        for j, c in enumerate(layout):
-            if c.kind == "fk" and "." not in c.name:
-                # the direct child node for this slot
-                for k in range(nodes[node][4], nodes[node][4] + nodes[node][5]):
-                    cid = blk["children"][k]
-                    if nodes[cid][0] == 0 and nodes[cid][7] == j:
-                        if cid not in child_rows:
-                            ch = int(vals[cid])
-                            if ch == CHOICE_NEW:
-                                ch = self._materialise(bi, cid, vals)
-                            child_rows[cid] = ch
-                        values[j] = child_rows[cid]
+
+        def child_row(cn):
+            r = child_rows.get(cn)
+            if r is None:
+                r = int(vals[cn])
+                if r == CHOICE_NEW:
+                    r = self._materialise(bi, cn, vals)
+                child_rows[cn] = r
+            return r
+
+        for j, cn, opts in leaves:
+            values[j] = opts[vals[cn]]
+        for j, cn, ccls, cc in copies:
+            r = child_row(cn)  # may create the child (and grow its table) first
+            values[j] = self.tables[ccls].cols[cc, r]
+        for j, cid in slots:
+            values[j] = child_row(cid)
         return self.insert_row(cname, values)
 
     def commit(self, choice, new_rows):
