@@ -1020,7 +1020,12 @@ __global__ void item_key_kernel(int n, KeyColsDev kc, const int32_t* row, const 
   for (int c = 0; c < kc.n_cols; ++c) h = mix64(h, (uint32_t)kc.col[c][r]);
   if (kc.use_ctx && ctxv)
     for (int s = 0; s < PCLEAN_MAX_CTX; ++s) h = mix64(h, (uint32_t)ctxv[(size_t)i * PCLEAN_MAX_CTX + s]);
-  if (excl) h = mix64(h, (uint32_t)excl[i]);
+  if (excl) {
+    // groups of one referent end up adjacent in the sorted order: their workgroups run back to back
+    // and re-read the same byte rows from L2 (the hash only has to separate tuples, order is free)
+    h = mix64(h, (uint32_t)excl[i]);
+    h = ((uint64_t)(uint32_t)(excl[i] + 1) << 40) | (h >> 24);
+  }
   key[i] = h;
   idx[i] = i;
 }
