@@ -94,6 +94,20 @@ def oracle_world_for_rows(orc, lw, obs_local, tr, eng, rows):
     return w, py
 
 
+def hbm_traffic(args, world):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/collect.sh ->
+    profiles/hbm_traffic.json); only valid for the configuration it was measured on."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        d = json.load(open(path))
+        if d.get("rows") != args.rows or d.get("hospitals") != args.hospitals or d.get("particles") != args.particles \
+                or world != 1:
+            return None
+        return float(d["bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(lw, obs_local, tr, eng, cfg, seed, target_seconds):
     """Oracle, sequential schedule, single thread, on a prefix sample of the rows."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -225,10 +239,14 @@ def main():
                        "init": "ground-truth entities", "device_ms_per_step": dev_ms / args.steps},
             "f1": acc["f1"], "accuracy": acc,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
-                         "kernel": "enum_node_kernel (block 0 root: rows x candidate hospitals)",
+                         "frac": achieved / 8000.0, "traffic": hbm_traffic(args, world),
+                         "kernel": "fk_root_fast_kernel<12> (block 0 root: rows x candidate hospitals)",
                          "alg_bytes_per_launch": per_launch_bytes, "avg_launch_ms": 1e3 * per_launch_s,
-                         "note": "achieved = SURVEY §8d algorithmic bytes / HIP-event kernel time of this rank"},
+                         "note": "achieved = SURVEY §8d algorithmic bytes (full enumeration, 920 296 B/row) / HIP-event "
+                                 "kernel time of this rank. The kernel skips most of that work exactly (integer "
+                                 "pre-filter, one workgroup per distinct row tuple), so frac > 1 is expected; "
+                                 "traffic = measured HBM bytes per launch (rocprofv3 FETCH_SIZE x2 gfx950 correction "
+                                 "+ WRITE_SIZE, profiles/hbm_traffic.json), DESIGN.md §5"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lw, obs_local, tr, eng, cfg, args.seed, args.cpu_seconds)

@@ -257,13 +257,18 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   }
   bool lost = false;        // a window candidate had to be dropped
   double lost_max = -__builtin_inf();
+  // Rounds are processed in chunks of at most 64 (fr.chunk_rounds): 1a scans a chunk, 1b scores its survivors.
+  const int rounds_total = (nslots + T - 1) / T;
+  for (int rb = 0; rb < rounds_total; rb += fr.chunk_rounds) {
   // 1a: branch-free integer scan (loads of several rounds in flight): bit r of `alive` = the lane's
-  //     r-th slot holds a candidate that may carry weight
+  //     (rb + r)-th slot holds a candidate that may carry weight
   uint64_t alive = 0;
   {
-    int r = 0;
+    const int r_end = min(fr.chunk_rounds, rounds_total - rb);
 #pragma unroll 4
-    for (int slot = tid; slot < nslots; slot += T, ++r) {
+    for (int r = 0; r < r_end; ++r) {
+      const int slot = tid + (rb + r) * T;
+      if (slot >= nslots) break;
       uint32_t lo = 0, hi = 0;
 #pragma unroll
       for (int p = 0; p < 3; ++p)
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   while (alive) {
     const int r = __builtin_ctzll(alive);
     alive &= alive - 1;
-    const int slot = tid + r * T;
+    const int slot = tid + (rb + r) * T;
     const int k0 = slot << 2;
     double acc[4];
     const double2 p01 = *reinterpret_cast<const double2*>(prior + k0);
@@ -333,6 +338,7 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
         }
       }
   }
+  }  // chunk of rounds
   double sn = -__builtin_inf();
   if (tid == 0) {  // the "new row" candidate (index n, last in natural order)
     double snew = 0.0;
@@ -468,7 +474,6 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   int T = 256;
   if (const char* e = getenv("PCLEAN_FAST_T")) T = std::max(64, std::min(1024, atoi(e) / 64 * 64));
   while (T < 1024 && (nslots + T - 1) / T > 64) T += 64;
-  if ((nslots + T - 1) / T > 64) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "fast root kernel: too many candidates");
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, nullptr, nullptr, nullptr};
   fast_kernel_t kern = pick_kernel(fr.n_terms);
   HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

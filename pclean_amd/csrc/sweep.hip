@@ -757,8 +757,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   if (node_id >= 64) return 0;
   const pclean_node& n = b.nodes[node_id];
   const CandTable& t = ctx->cand[n.table];
-  if (n.kind != PCLEAN_NODE_FK || !t.valid || t.n_rows < 1024 || t.n_rows > 260000 || n.n_terms < 1 ||
-      n.n_terms > PCLEAN_MAX_TERMS)
+  if (n.kind != PCLEAN_NODE_FK || !t.valid || t.n_rows < 1024 || n.n_terms < 1 || n.n_terms > PCLEAN_MAX_TERMS)
     return 0;
   int lmax = 0, dmax = 0;
   for (int i = 0; i < n.n_terms; ++i) {
@@ -853,6 +852,9 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     } else {
       fr.inv_c = 1.0 / (cmin * (1.0 - 1e-9));
     }
+    fr.chunk_rounds = 64;
+    if (const char* e = getenv("PCLEAN_FAST_CHUNK")) fr.chunk_rounds = std::max(1, std::min(64, atoi(e)));
+    fr.pad2 = 0;
     fr.prior_max_e = f.logc_max - t.scal[1];
     fr.prior_max_n = f.logc_max - t.scal[0];
   }
