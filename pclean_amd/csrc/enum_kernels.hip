@@ -248,43 +248,44 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   for (int k = lo; k < hi; ++k) part += u[k];
   uint64_t U;
   const uint64_t pre = block_excl_scan(part, wsum, &U);
-  // ---- phase 5: lse + draws (of every member item of the group) --------------------------------
+  // ---- phase 5: lse + draws of every member item of the group -------------------------------------
+  // The lane's chunk becomes an inclusive prefix in place; every (member item, draw) pair then locates
+  // its threshold by binary search (smallest k with prefix[k] > x — a zero-weight candidate is never hit,
+  // exactly as in the sequential scan of the oracle), one pair per lane, no further barriers.
+  {
+    uint64_t run = pre;
+    for (int k = lo; k < hi; ++k) {
+      run += u[k];
+      u[k] = run;
+    }
+  }
+  __syncthreads();
   const double lse = pclean_lse_from_fix(m, U);
-  for (int mi = m_lo; mi < m_hi; ++mi) {
+  const int nd_eff = n_draws > 0 ? n_draws : 1;
+  const int n_out = (m_hi - m_lo) * nd_eff;
+  for (int q = tid; q < n_out; q += 256) {
+    const int mi = m_lo + q / nd_eff, j = q % nd_eff;
     const int tm = it.grp_off ? it.members[mi] : t;
     const int tom = it.out_pos ? it.out_pos[tm] : tm;
-    if (tid == 0 && lse_out) lse_out[tom] = lse;
+    if (j == 0 && lse_out) lse_out[tom] = lse;
     if (n_draws <= 0) continue;
-    // one Philox evaluation per draw for the whole workgroup (lane j of wave 0), broadcast through LDS
-    uint64_t* xs = wsum + 8;  // [64]
-    const int row_m = it.row ? it.row[tm] : tm;
-    const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[tm] : (uint32_t)((int64_t)row_m + it.row_offset);
-    for (int j0 = 0; j0 < n_draws; j0 += 64) {
-      __syncthreads();
-      if (tid < 64 && j0 + tid < n_draws) {
-        const uint32_t pid = it.particle ? (uint32_t)it.particle[tm] : (uint32_t)(j0 + tid);
-        xs[tid] = U ? pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U) : 0ull;
+    int32_t res = fk ? PCLEAN_CHOICE_NEW : n - 1;
+    if (U != 0) {
+      const int row_m = it.row ? it.row[tm] : tm;
+      const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[tm] : (uint32_t)((int64_t)row_m + it.row_offset);
+      const uint32_t pid = it.particle ? (uint32_t)it.particle[tm] : (uint32_t)j;
+      const uint64_t x = pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U);
+      int a = 0, b = nc - 1;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (u[mid] > x)
+          b = mid;
+        else
+          a = mid + 1;
       }
-      __syncthreads();
-      const int jn = min(64, n_draws - j0);
-      for (int j = 0; j < jn; ++j) {
-        int32_t* dst = draws_out + (size_t)tom * n_draws + j0 + j;
-        if (U == 0) {
-          if (tid == 0) *dst = fk ? PCLEAN_CHOICE_NEW : n - 1;
-          continue;
-        }
-        const uint64_t x = xs[j];
-        if (x >= pre && x < pre + part) {
-          uint64_t acc = pre;
-          int k = lo;
-          for (; k < hi; ++k) {
-            acc += u[k];
-            if (acc > x) break;
-          }
-          *dst = (fk && k == n) ? PCLEAN_CHOICE_NEW : k;
-        }
-      }
+      res = (fk && a == n) ? PCLEAN_CHOICE_NEW : a;
     }
+    draws_out[(size_t)tom * n_draws + j] = res;
   }
 }
 

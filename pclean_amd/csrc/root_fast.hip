@@ -37,7 +37,7 @@
 #define HALF_LOG26 1.629048269010741
 #define ADD_TYPOS_IMPOSSIBLE (-1e5)
 #define FAST_MAX_WAVES 16
-#define SURV2_CAP 1024     // after filtering with the true maximum
+#define SURV2_CAP 256      // after filtering with the true maximum
 #define FIX_CUTOFF 28.5    // pclean_fixw(d) == 0 for d < -28.5
 
 __global__ void compact_pair_kernel(const uint8_t* __restrict__ pair, int n_obs, int n_lat,
@@ -471,7 +471,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   // lanes: small workgroups (more of them resident per CU hide the per-row latency chain), at most
   // 64 rounds of 4-candidate slots per lane (the survivor bitmask is one 64-bit word)
   const int nslots = fr.kpad >> 2;
-  int T = 256;
+  int T = 128;
   if (const char* e = getenv("PCLEAN_FAST_T")) T = std::max(64, std::min(1024, atoi(e) / 64 * 64));
   while (T < 1024 && (nslots + T - 1) / T > 64) T += 64;
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, nullptr, nullptr, nullptr};
