@@ -186,12 +186,22 @@ def main():
         choice, chosen, logml, new_rows = eng.sweep(tr, cfg, args.seed, idx, reuse_buffers=True)
         t_c = time.perf_counter()
         stats = eng.sweep_stats(tr)
+        moved = eng.sweep_moved()
         tm = eng.hip.get_timing()
         t_d = time.perf_counter()
         if os.environ.get("PCLEAN_BENCH_DEBUG"):
             log("[bench] moved per block", (choice != tr.cur).sum(axis=1), "new per block", (choice < 0).sum(axis=1),
                 "chosen particle hist", np.bincount(chosen, minlength=cfg.num_particles)[:6])
-        changed = exchange_and_commit(tr, lw, comm, lo, choice, stats, new_rows)
+        if os.environ.get("PCLEAN_BENCH_PROFILE") and idx == args.warmup + args.steps - 1:
+            import cProfile
+            import pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            changed = exchange_and_commit(tr, lw, comm, lo, choice, stats, new_rows, moved_local=moved)
+            pr.disable()
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(12)
+        else:
+            changed = exchange_and_commit(tr, lw, comm, lo, choice, stats, new_rows, moved_local=moved)
         t_e = time.perf_counter()
         if os.environ.get("PCLEAN_BENCH_DEBUG"):
             log(f"[bench] host phases ms: upload {1e3 * (t_b - t_a):.2f} sweep call {1e3 * (t_c - t_b):.2f} "

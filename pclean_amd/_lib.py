@@ -412,6 +412,16 @@ class HipContext:
             "pclean_sweep_latent")
         return chosen, vals
 
+    def get_moved(self, block_id):
+        n = C.c_int32()
+        check(self.h, self.lib.pclean_get_moved(self.h, C.c_int32(block_id), C.byref(n), None, None), "pclean_get_moved")
+        rows = np.empty(n.value, dtype=np.int32)
+        ch = np.empty(n.value, dtype=np.int32)
+        if n.value:
+            check(self.h, self.lib.pclean_get_moved(self.h, C.c_int32(block_id), C.byref(n), _p(rows, C.c_int32),
+                                                    _p(ch, C.c_int32)), "pclean_get_moved")
+        return rows, ch
+
     def get_new_rows(self, block_id, n_nodes):
         n = C.c_int32()
         check(self.h, self.lib.pclean_get_new_rows(self.h, C.c_int32(block_id), C.byref(n), None, None),

@@ -100,6 +100,7 @@ struct Block {
   // per-sweep work buffers live in Sweep state (sweep.hip)
   std::vector<DevBuf<double>> leaf_cache;  // per node: marginal per unique observed value
   std::vector<int32_t> new_rows_host, new_vals_host, locals_host;
+  std::vector<int32_t> moved_rows_host, moved_choice_host;  // rows whose referent changed in the last sweep
 };
 
 struct pclean_ctx {

@@ -507,6 +507,10 @@ __global__ void gather_new_rows_kernel(int n, const int32_t* list, const int32_t
   const int32_t* v = vals + (size_t)chosen_newpos[i] * n_nodes;
   for (int k = 0; k < n_nodes; ++k) vals_out[(size_t)j * n_nodes + k] = v[k];
 }
+__global__ void mark_moved_kernel(int n_rows, const int32_t* cur, const int32_t* choice, int32_t* flag) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_rows) flag[i] = choice[i] != cur[i] ? PCLEAN_CHOICE_NEW : 0;
+}
 __global__ void mark_new_kernel(int n_rows, const int32_t* chosen_newpos, int32_t* flag) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n_rows) flag[i] = chosen_newpos[i] >= 0 ? PCLEAN_CHOICE_NEW : 0;
@@ -1778,6 +1782,44 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     b.new_rows_host.swap(rs);
     b.new_vals_host.swap(vs);
   }
+  // ---- rows whose referent changed (the host commit only has to touch these) -> host, ascending
+  for (int bi = 0; bi < n_blocks; ++bi) {
+    BlockRun& r = s->run[bi];
+    Block& b = ctx->block[bi];
+    b.moved_rows_host.clear();
+    b.moved_choice_host.clear();
+    if (b.is_score) continue;
+    int32_t* flag = scratch<int32_t>(ctx, N);
+    if (!flag) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    hipLaunchKernelGGL(mark_moved_kernel, grid1(N), dim3(256), 0, ctx->stream, N, s->cur.p + (size_t)bi * N, r.choice.p, flag);
+    HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 0, s->counter.p, nullptr,
+                       nullptr);
+    unsigned int cnt = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&cnt, s->counter.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!cnt) continue;
+    int32_t* list = scratch<int32_t>(ctx, cnt);
+    int32_t* ch_d = scratch<int32_t>(ctx, cnt);
+    if (!list || !ch_d) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 1, s->counter.p, list,
+                       nullptr);
+    hipLaunchKernelGGL(gather_i32_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, list, r.choice.p, ch_d);
+    std::vector<int32_t> rows_h(cnt), ch_h(cnt);
+    HIPCHK(ctx, hipMemcpyAsync(rows_h.data(), list, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ch_h.data(), ch_d, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> order(cnt);
+    for (unsigned i = 0; i < cnt; ++i) order[i] = (int)i;
+    std::sort(order.begin(), order.end(), [&](int a, int c) { return rows_h[a] < rows_h[c]; });
+    b.moved_rows_host.resize(cnt);
+    b.moved_choice_host.resize(cnt);
+    for (unsigned i = 0; i < cnt; ++i) {
+      b.moved_rows_host[i] = rows_h[order[i]];
+      b.moved_choice_host[i] = ch_h[order[i]];
+    }
+  }
   float tot = 0;
   HIPCHK(ctx, hipEventElapsedTime(&tot, s->evs, s->eve));
   ctx->timing.total_ms = tot;
@@ -1799,6 +1841,18 @@ extern "C" int pclean_get_new_rows(pclean_ctx* ctx, int32_t block_id, int32_t* n
   *n_out = (int32_t)b.new_rows_host.size();
   if (rows_out && !b.new_rows_host.empty()) memcpy(rows_out, b.new_rows_host.data(), b.new_rows_host.size() * 4);
   if (vals_out && !b.new_vals_host.empty()) memcpy(vals_out, b.new_vals_host.data(), b.new_vals_host.size() * 4);
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_get_moved(pclean_ctx* ctx, int32_t block_id, int32_t* n_out, int32_t* rows_out,
+                                int32_t* choice_out) {
+  if (!ctx || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid || !n_out)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_get_moved: bad arguments");
+  const Block& b = ctx->block[block_id];
+  *n_out = (int32_t)b.moved_rows_host.size();
+  if (rows_out && !b.moved_rows_host.empty()) memcpy(rows_out, b.moved_rows_host.data(), b.moved_rows_host.size() * 4);
+  if (choice_out && !b.moved_choice_host.empty())
+    memcpy(choice_out, b.moved_choice_host.data(), b.moved_choice_host.size() * 4);
   return PCLEAN_OK;
 }
 

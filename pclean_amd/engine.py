@@ -213,6 +213,13 @@ class Engine:
                 trace.pending_locals[bi] = self.hip.get_locals(bi, choice.shape[1])
         return choice, chosen, logml, new_rows
 
+    def sweep_moved(self):
+        """{block: (rows relative to the swept window, new referent)} of the last sweep, rows ascending."""
+        if getattr(self, "_empty_sweep", False):
+            return {bi: (np.zeros(0, np.int32), np.zeros(0, np.int32))
+                    for bi, blk in enumerate(self.lw.blocks) if not blk.get("score")}
+        return {bi: self.hip.get_moved(bi) for bi, blk in enumerate(self.lw.blocks) if not blk.get("score")}
+
     def sweep_latent(self, trace, cname, config, seed, sweep_idx, live, ev_off, ev_rows, ev_ctx, excl):
         """Rejuvenation of the latent rows `live` of class cname against their evidence sets
         (pclean_sweep_latent).  Returns (chosen particle, sampled node values) per latent row."""

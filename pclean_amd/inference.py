@@ -224,8 +224,9 @@ def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None):
     engine.upload_trace(trace)
     choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi, reuse_buffers=True)
     stats = engine.sweep_stats(trace)
+    moved = engine.sweep_moved() if hasattr(engine, "sweep_moved") else None
     _gather_locals(trace, comm, 0, hi - lo, lo)
-    return exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True)
+    return exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True, moved_local=moved)
 
 
 def resample_parameters(trace):

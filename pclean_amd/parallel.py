@@ -71,7 +71,8 @@ class Comm:
         return float(t.item())
 
 
-def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local, new_rows_local, global_cur=False):
+def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local, new_rows_local, global_cur=False,
+                        moved_local=None):
     """Apply one sweep's result to the replicated trace.
 
     choice_local [n_blocks][n_local]: chosen referents of this rank's rows;
@@ -81,6 +82,8 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
     global_cur=True : trace.cur holds every observed row on every rank (needed by the latent-class
     sweeps, whose evidence sets span all rows): the (row, new referent) pairs of the rows that moved
     are all-gathered as well, so the whole trace stays replicated.
+    moved_local {block: (local rows ascending, new referent)} (pclean_get_moved): when given, only those rows
+    are touched and choice_local is not scanned.
     Returns the global number of rows whose referent changed."""
     changed = 0
     n_local = np.asarray(choice_local).shape[1]
@@ -95,20 +98,33 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
         rows, vals = new_rows_local.get(bi, (np.zeros(0, np.int32), np.zeros((0, nn), np.int32)))
         g_rows = comm.allgather_varlen_i32(np.asarray(rows, np.int32) + row_lo)
         g_vals = comm.allgather_varlen_i32(np.asarray(vals, np.int32)).reshape(-1, nn)
-        order = np.argsort(g_rows, kind="stable")
-        created = {}
-        for j in order:  # identical order on every rank -> identical row ids
-            r = trace._materialise(bi, 0, g_vals[j])
-            trace.tables[cname].counts[r] += 1
-            created[int(g_rows[j])] = r
+        order = np.argsort(g_rows, kind="stable")  # identical order on every rank -> identical row ids
+        g_rows = g_rows[order]
+        new_ids = trace.materialise_bulk(bi, g_vals[order])
         t = trace.tables[cname]
+        t.counts[new_ids] += 1  # each new row is referred to by its creator
         t.counts[:n_before] += delta
         # this rank's own rows
+        if moved_local is not None:
+            moved, ch_m = moved_local[bi]
+            ch_m = np.array(ch_m, dtype=np.int32)
+            fresh = np.flatnonzero(ch_m < 0)
+            if len(fresh):
+                ch_m[fresh] = new_ids[np.searchsorted(g_rows, moved[fresh] + row_lo)]
+            changed += len(moved)
+            if global_cur:
+                g_moved = comm.allgather_varlen_i32(np.asarray(moved, np.int32) + row_lo)
+                g_new = comm.allgather_varlen_i32(ch_m)
+                trace.cur[bi, g_moved] = g_new
+            else:
+                trace.cur[bi][moved] = ch_m
+            trace.delete_rows_bulk(cname, np.nonzero((t.counts[:t.n] == 0) & t.live[:t.n])[0])
+            continue
         ch = np.asarray(choice_local[bi])
         fresh = np.flatnonzero(ch < 0)
         if len(fresh):
             ch = ch.copy()
-            ch[fresh] = [created[int(i) + row_lo] for i in fresh]
+            ch[fresh] = new_ids[np.searchsorted(g_rows, fresh + row_lo)]
         if global_cur:
             cur = trace.cur[bi, row_lo:row_lo + n_local]
             moved = np.nonzero(ch != cur)[0]
@@ -122,8 +138,5 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
             changed += len(moved)
             cur[moved] = ch[moved]
         # garbage-collect rows nobody refers to any more (ascending id: deterministic)
-        dead = np.nonzero((t.counts[:t.n] == 0) & t.live[:t.n])[0]
-        for k in dead:
-            if t.live[k] and t.counts[k] == 0:
-                trace.delete_row(cname, int(k))
+        trace.delete_rows_bulk(cname, np.nonzero((t.counts[:t.n] == 0) & t.live[:t.n])[0])
     return int(comm.allreduce_sum_i64(np.array([changed], dtype=np.int64))[0])

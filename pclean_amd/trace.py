@@ -225,6 +225,71 @@ class Trace:
                 if tgt.counts[k] == 0:
                     self.delete_row(c.target, k)
 
+    # -- bulk variants (many rows of one class at once, numpy instead of a Python call per row) ------
+    def insert_rows_bulk(self, cname, values):
+        """insert_row for the rows of `values` [k][n_cols], in order; returns their row ids."""
+        t = self.tables[cname]
+        k = len(values)
+        ids = np.fromiter((t.alloc() for _ in range(k)), dtype=np.int64, count=k)
+        t.cols[:, ids] = values.T
+        t.cols_dirty = True
+        t.counts[ids] = 0
+        t.live[ids] = True
+        fks, props = self._class_plan(cname)
+        for j, target in fks:
+            np.add.at(self.tables[target].counts, values[:, j], 1)
+        for j, state in props:
+            np.add.at(state.counts, values[:, j], 1)
+        return ids
+
+    def delete_rows_bulk(self, cname, ids):
+        """delete_row for every row of `ids` (all unreferenced and live), cascading to referents that
+        lose their last reference."""
+        ids = np.asarray(ids, dtype=np.int64)
+        if len(ids) == 0:
+            return
+        t = self.tables[cname]
+        assert np.all(t.counts[ids] == 0) and np.all(t.live[ids])
+        fks, props = self._class_plan(cname)
+        for j, state in props:
+            np.subtract.at(state.counts, t.cols[j, ids], 1)
+        t.live[ids] = False
+        t.free.extend(int(r) for r in ids)
+        for j, target in fks:
+            tgt = self.tables[target]
+            ref = t.cols[j, ids]
+            np.subtract.at(tgt.counts, ref, 1)
+            cand = np.unique(ref)
+            self.delete_rows_bulk(target, cand[(tgt.counts[cand] == 0) & tgt.live[cand]])
+
+    def materialise_bulk(self, bi, vals):
+        """Rows of block bi's root class for the node choices vals [k][n_nodes] (row_inference.jl:169-185 for
+        many rows).  Proposals without a nested NEW referent are built with array operations; the rest
+        go through _materialise.  Returns the row ids, in the order of `vals`."""
+        k = len(vals)
+        out = np.empty(k, dtype=np.int64)
+        if k == 0:
+            return out
+        cname, n_cols, leaves, copies, slots = self._node_plan(bi, 0)
+        nested = [cn for _, cn, _, _ in copies] + [cid for _, cid in slots]
+        simple = np.ones(k, dtype=bool)
+        for cn in set(nested):
+            simple &= vals[:, cn] >= 0
+        idx = np.flatnonzero(simple)
+        if len(idx):
+            v = vals[idx]
+            values = np.zeros((len(idx), n_cols), dtype=np.int32)
+            for j, cn, opts in leaves:
+                values[:, j] = opts[v[:, cn]]
+            for j, cn, ccls, cc in copies:
+                values[:, j] = self.tables[ccls].cols[cc, v[:, cn]]
+            for j, cid in slots:
+                values[:, j] = v[:, cid]
+            out[idx] = self.insert_rows_bulk(cname, values)
+        for i in np.flatnonzero(~simple):
+            out[i] = self._materialise(bi, 0, vals[i])
+        return out
+
     # -- building a new row from the sampled node choices of a block ---------
     def _node_plan(self, bi, node):
         """Static recipe for building a row of `node`'s class from the sampled node choices:

@@ -28,6 +28,10 @@ def test_million_row_sweep_properties(oracle):
         cfg = InferenceConfig(1, P)
         choice, chosen, logml, new_rows = eng.sweep(tr, cfg, seed, 0)
         stats = eng.sweep_stats(tr)
+        # pclean_get_moved = exactly the rows whose referent differs from cur, ascending, with their choice
+        for bi, (rows_m, ch_m) in eng.sweep_moved().items():
+            want = np.flatnonzero(choice[bi] != tr.cur[bi])
+            assert np.array_equal(rows_m, want) and np.array_equal(ch_m, choice[bi][want])
         # (a) determinism
         choice2, chosen2, logml2, _ = eng.sweep(tr, cfg, seed, 0)
         assert np.array_equal(choice, choice2) and np.array_equal(chosen, chosen2) and np.array_equal(logml, logml2)
