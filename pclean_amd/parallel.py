@@ -59,6 +59,22 @@ class Comm:
         self.dist.all_gather(outs, buf)
         return np.concatenate([o[:s].cpu().numpy() for o, s in zip(outs, sizes)])
 
+    def allgather_list_i32(self, arr):
+        """[rank 0's vector, rank 1's vector, ...] of int32 vectors of differing length (2 collectives)."""
+        arr = np.ascontiguousarray(arr, dtype=np.int32).reshape(-1)
+        if not self.dist:
+            return [arr]
+        n = self.torch.tensor([arr.size], dtype=self.torch.int64, device=self.device)
+        sizes = [self.torch.zeros_like(n) for _ in range(self.world)]
+        self.dist.all_gather(sizes, n)
+        sizes = [int(x.item()) for x in sizes]
+        m = max(max(sizes), 1)
+        buf = self.torch.zeros(m, dtype=self.torch.int32, device=self.device)
+        buf[:arr.size] = self.torch.from_numpy(arr).to(self.device)
+        outs = [self.torch.zeros_like(buf) for _ in range(self.world)]
+        self.dist.all_gather(outs, buf)
+        return [o[:k].cpu().numpy() for o, k in zip(outs, sizes)]
+
     def barrier(self):
         if self.dist:
             self.dist.barrier()
@@ -81,62 +97,87 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
     global_cur=False: trace.cur holds only this rank's rows (observed-class sweeps only, bench.py);
     global_cur=True : trace.cur holds every observed row on every rank (needed by the latent-class
     sweeps, whose evidence sets span all rows): the (row, new referent) pairs of the rows that moved
-    are all-gathered as well, so the whole trace stays replicated.
+    are exchanged as well, so the whole trace stays replicated.
     moved_local {block: (local rows ascending, new referent)} (pclean_get_moved): when given, only those rows
     are touched and choice_local is not scanned.
+
+    Exactly three collectives per sweep, whatever the number of blocks: ONE all-reduce(sum) of the
+    concatenated int64 delta-count vectors (+ the moved-row counter) and ONE variable-length
+    all-gather (sizes + payload) of the new-row records and moved rows of all blocks.
     Returns the global number of rows whose referent changed."""
-    changed = 0
+    blocks = [bi for bi, blk in enumerate(lowered.blocks) if not blk.get("score")]
     n_local = np.asarray(choice_local).shape[1]
-    for bi, blk in enumerate(lowered.blocks):
-        if blk.get("score"):
-            continue
-        cname = blk["root_class"]
-        t = trace.tables[cname]
+    # ---- local payloads (tables are still in their pre-sweep state) --------------------------------
+    n_before, moved_of, red, msg = {}, {}, [], []
+    n_changed = 0
+    for bi in blocks:
+        blk = lowered.blocks[bi]
+        t = trace.tables[blk["root_class"]]
         nn = len(blk["nodes"])
-        n_before = t.n
-        delta = comm.allreduce_sum_i64(stats_local[bi][:n_before])
+        n_before[bi] = t.n
+        red.append(np.asarray(stats_local[bi][:t.n], dtype=np.int64))
         rows, vals = new_rows_local.get(bi, (np.zeros(0, np.int32), np.zeros((0, nn), np.int32)))
-        g_rows = comm.allgather_varlen_i32(np.asarray(rows, np.int32) + row_lo)
-        g_vals = comm.allgather_varlen_i32(np.asarray(vals, np.int32)).reshape(-1, nn)
+        if moved_local is not None:
+            moved, ch_m = moved_local[bi]
+            moved, ch_m = np.asarray(moved, np.int32), np.asarray(ch_m, np.int32)
+        else:
+            ch = np.asarray(choice_local[bi])
+            cur = trace.cur[bi, row_lo:row_lo + n_local] if global_cur else trace.cur[bi]
+            moved = np.flatnonzero(ch != cur).astype(np.int32)
+            ch_m = ch[moved].astype(np.int32)
+        moved_of[bi] = (moved, ch_m)
+        n_changed += len(moved)
+        msg += [np.array([len(rows)], np.int32), np.asarray(rows, np.int32) + row_lo, np.asarray(vals, np.int32).reshape(-1)]
+        if global_cur:
+            msg += [np.array([len(moved)], np.int32), moved + row_lo, ch_m]
+    red.append(np.array([n_changed], dtype=np.int64))
+    # ---- the exchange ------------------------------------------------------------------------------
+    total = comm.allreduce_sum_i64(np.concatenate(red))
+    parts = comm.allgather_list_i32(np.concatenate(msg))
+    # ---- identical commit on every rank ------------------------------------------------------------
+    cursor = [0] * len(parts)
+    off = 0
+    for bi in blocks:
+        blk = lowered.blocks[bi]
+        cname = blk["root_class"]
+        nn = len(blk["nodes"])
+        delta = total[off:off + n_before[bi]]
+        off += n_before[bi]
+        g_rows, g_vals, g_moved, g_new = [], [], [], []
+        for r, p in enumerate(parts):  # rank order == global row order (contiguous shards)
+            c = cursor[r]
+            k = int(p[c])
+            g_rows.append(p[c + 1:c + 1 + k])
+            g_vals.append(p[c + 1 + k:c + 1 + k + k * nn].reshape(k, nn))
+            c += 1 + k + k * nn
+            if global_cur:
+                m = int(p[c])
+                g_moved.append(p[c + 1:c + 1 + m])
+                g_new.append(p[c + 1 + m:c + 1 + 2 * m])
+                c += 1 + 2 * m
+            cursor[r] = c
+        g_rows = np.concatenate(g_rows)
+        g_vals = np.concatenate(g_vals)
         order = np.argsort(g_rows, kind="stable")  # identical order on every rank -> identical row ids
         g_rows = g_rows[order]
         new_ids = trace.materialise_bulk(bi, g_vals[order])
         t = trace.tables[cname]
         t.counts[new_ids] += 1  # each new row is referred to by its creator
-        t.counts[:n_before] += delta
-        # this rank's own rows
-        if moved_local is not None:
-            moved, ch_m = moved_local[bi]
-            ch_m = np.array(ch_m, dtype=np.int32)
-            fresh = np.flatnonzero(ch_m < 0)
+        t.counts[:n_before[bi]] += delta
+
+        def resolve(rows_global, ch):
+            ch = np.array(ch, dtype=np.int32)
+            fresh = np.flatnonzero(ch < 0)
             if len(fresh):
-                ch_m[fresh] = new_ids[np.searchsorted(g_rows, moved[fresh] + row_lo)]
-            changed += len(moved)
-            if global_cur:
-                g_moved = comm.allgather_varlen_i32(np.asarray(moved, np.int32) + row_lo)
-                g_new = comm.allgather_varlen_i32(ch_m)
-                trace.cur[bi, g_moved] = g_new
-            else:
-                trace.cur[bi][moved] = ch_m
-            trace.delete_rows_bulk(cname, np.nonzero((t.counts[:t.n] == 0) & t.live[:t.n])[0])
-            continue
-        ch = np.asarray(choice_local[bi])
-        fresh = np.flatnonzero(ch < 0)
-        if len(fresh):
-            ch = ch.copy()
-            ch[fresh] = new_ids[np.searchsorted(g_rows, fresh + row_lo)]
+                ch[fresh] = new_ids[np.searchsorted(g_rows, rows_global[fresh])]
+            return ch
+
         if global_cur:
-            cur = trace.cur[bi, row_lo:row_lo + n_local]
-            moved = np.nonzero(ch != cur)[0]
-            changed += len(moved)
-            g_moved = comm.allgather_varlen_i32(moved.astype(np.int32) + row_lo)
-            g_new = comm.allgather_varlen_i32(ch[moved].astype(np.int32))
-            trace.cur[bi, g_moved] = g_new
+            g_moved = np.concatenate(g_moved)
+            trace.cur[bi, g_moved] = resolve(g_moved, np.concatenate(g_new))
         else:
-            cur = trace.cur[bi]
-            moved = np.flatnonzero(ch != cur)
-            changed += len(moved)
-            cur[moved] = ch[moved]
-        # garbage-collect rows nobody refers to any more (ascending id: deterministic)
+            moved, ch_m = moved_of[bi]
+            trace.cur[bi][moved] = resolve(moved + row_lo, ch_m)
+        # garbage-collect rows nobody refers to any more
         trace.delete_rows_bulk(cname, np.nonzero((t.counts[:t.n] == 0) & t.live[:t.n])[0])
-    return int(comm.allreduce_sum_i64(np.array([changed], dtype=np.int64))[0])
+    return int(total[-1])
