@@ -148,8 +148,9 @@ extern "C" int pclean_get_density_tables(pclean_ctx* ctx, int32_t* max_r, int32_
 
 extern "C" int pclean_build_pair_table(pclean_ctx* ctx, int32_t table_id, int32_t n_obs, const int32_t* obs_ids,
                                        int32_t n_lat, const int32_t* lat_ids, int32_t dist_mode) {
-  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || n_obs <= 0 || n_lat <= 0 || !obs_ids || !lat_ids ||
-      (dist_mode != PCLEAN_DIST_OSA && dist_mode != PCLEAN_DIST_DL))
+  // n_obs == 0 is legal: a column whose every cell is missing has an empty observed domain
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || n_obs < 0 || n_lat <= 0 || (n_obs > 0 && !obs_ids) ||
+      !lat_ids || (dist_mode != PCLEAN_DIST_OSA && dist_mode != PCLEAN_DIST_DL))
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_build_pair_table: bad arguments");
   if (ctx->n_strings == 0) return pclean_fail(ctx, PCLEAN_ERR_STATE, "load strings first");
   if (n_obs > 65535) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "n_obs > 65535 not supported yet");
@@ -171,11 +172,11 @@ extern "C" int pclean_build_pair_table(pclean_ctx* ctx, int32_t table_id, int32_
   pt.elem_bytes = std::max(max_la, max_lb) <= 255 ? 1 : 2;
   int rc = pclean_ensure_density(ctx, std::max(max_la, max_lb));
   if (rc) return rc;
-  if (pt.d.alloc((size_t)n_obs * n_lat * pt.elem_bytes) || pt.lat_len.alloc(n_lat))
+  if (pt.d.alloc(std::max<size_t>((size_t)n_obs * n_lat * pt.elem_bytes, 16)) || pt.lat_len.alloc(n_lat))
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   DevBuf<int32_t> d_obs, d_lat;
-  if (d_obs.alloc(n_obs) || d_lat.alloc(n_lat)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-  HIPCHK(ctx, hipMemcpy(d_obs.p, obs_ids, n_obs * sizeof(int32_t), hipMemcpyHostToDevice));
+  if (d_obs.alloc(std::max(n_obs, 1)) || d_lat.alloc(n_lat)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  if (n_obs) HIPCHK(ctx, hipMemcpy(d_obs.p, obs_ids, n_obs * sizeof(int32_t), hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(d_lat.p, lat_ids, n_lat * sizeof(int32_t), hipMemcpyHostToDevice));
   rc = pclean_launch_dist(ctx, pt, d_obs.p, d_lat.p, dist_mode);
   hipError_t e = hipStreamSynchronize(ctx->stream);

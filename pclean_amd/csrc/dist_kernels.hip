@@ -144,6 +144,10 @@ int pclean_launch_dist(pclean_ctx* ctx, PairTable& pt, const int32_t* d_obs_ids,
   const int max_lb = pt.max_lat_len, max_la = pt.max_obs_len;
   hipLaunchKernelGGL(lat_len_kernel, dim3((pt.n_lat + 255) / 256), dim3(256), 0, ctx->stream, ctx->off.p,
                      d_lat_ids, pt.n_lat, pt.lat_len.p);
+  if (pt.n_obs == 0) {  // empty observed domain (every cell of the column missing): nothing to fill
+    HIPCHK(ctx, hipGetLastError());
+    return PCLEAN_OK;
+  }
   if (dist_mode == PCLEAN_DIST_OSA) {
     // LDS bytes = ((2*(max_lb+1) + max_lb) * T + max_la) * 2
     int T = 256;

@@ -68,8 +68,9 @@ __global__ void priors_kernel(const int64_t* __restrict__ counts, const double* 
 
 int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_lat, const int32_t* cand_col,
                          const uint16_t* lat_len, int n_cand, int kpad, uint8_t* comp, uint8_t* clen) {
-  hipLaunchKernelGGL(compact_pair_kernel, dim3((kpad + 255) / 256, n_obs), dim3(256), 0, ctx->stream, pair, n_obs,
-                     n_lat, cand_col, n_cand, kpad, comp);
+  if (n_obs > 0)
+    hipLaunchKernelGGL(compact_pair_kernel, dim3((kpad + 255) / 256, n_obs), dim3(256), 0, ctx->stream, pair, n_obs,
+                       n_lat, cand_col, n_cand, kpad, comp);
   hipLaunchKernelGGL(compact_len_kernel, dim3((kpad + 255) / 256), dim3(256), 0, ctx->stream, lat_len, cand_col, n_cand,
                      kpad, clen);
   HIPCHK(ctx, hipGetLastError());

@@ -806,7 +806,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     }
     const uint64_t ver = t.cols_version * 1000003ull + pt.version;
     if (f.ver[i] != ver || !f.comp[i].p) {
-      if (f.comp[i].alloc((size_t)pt.n_obs * kpad) || f.clen[i].alloc(kpad))
+      if (f.comp[i].alloc(std::max<size_t>((size_t)pt.n_obs * kpad, 16)) || f.clen[i].alloc(kpad))
         return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed (compact tables)");
       int rc = pclean_build_compact(ctx, pt.d.p, pt.n_obs, pt.n_lat, t.cols.p + (size_t)tm.cand_col * t.n_rows,
                                     pt.lat_len.p, t.n_rows, kpad, f.comp[i].p, f.clen[i].p);

@@ -1,0 +1,139 @@
+"""Edge cases of the HIP path against the oracle: very long strings (16-bit distance tables), rows with
+every cell missing, a one-row table, an empty row window, empty sampler batches, and the error paths of
+the C ABI (bad ids, calls out of order) — status codes and messages, never a crash."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+from pclean_amd import experiments as ex
+from pclean_amd._lib import HipContext, InferConfig, PCleanHipError
+from pclean_amd.encode import StringPool
+from pclean_amd.engine import Engine, InferenceConfig
+from pclean_amd.model import LoweredModel
+from pclean_amd.trace import Trace
+
+pytestmark = pytest.mark.gpu
+
+
+def test_pair_table_strings_longer_than_255(oracle):
+    """Distances above 255 need the uint16 table layout (hospital MeasureName reaches 184 symbols; this
+    goes to 300)."""
+    rnd = np.random.default_rng(1)
+    alphabet = list("abcdefgh ")
+    words = ["".join(rnd.choice(alphabet, size=n)) for n in (300, 290, 257, 256, 255, 3, 1)] + ["", "x" * 300]
+    pool = StringPool()
+    ids = pool.add_all(words)
+    sym, off, _, _ = pool.arrays()
+    hip = HipContext(0)
+    try:
+        hip.load_strings(sym, off)
+        for mode in (0, 1):
+            hip.build_pair_table(3 + mode, ids, ids, mode)
+            got = hip.get_pair_table(3 + mode, len(ids), len(ids))
+            want = oracle.pair_table(sym, off, ids, ids, mode)
+            assert np.array_equal(got, want), mode
+            assert got.max() > 255 and got[words.index(""), words.index("x" * 300)] == 300
+    finally:
+        hip.close()
+
+
+def _hospital_with_holes(n_rows, holes):
+    dirty, clean = ex.hospital_data()
+    dirty = {c: list(v[:n_rows]) for c, v in dirty.items()}
+    clean = {c: v[:n_rows] for c, v in clean.items()}
+    m = ex.hospital_model(ex.possibilities_of(dirty))
+    q = ex.hospital_query(m)
+    for i, cols in holes.items():
+        for c in (q.cleanmap if cols is None else cols):
+            dirty[c][i] = None
+    lw = LoweredModel(m, q, dirty)
+    return dirty, clean, lw, lw.encode_observations(dirty)
+
+
+def _oracle_sweep(oracle, world, c, seed, sweep, cur):
+    nb, n = cur.shape
+    choice = np.empty((nb, n), dtype=np.int32)
+    chosen = np.empty(n, dtype=np.int32)
+    logml = np.empty(n)
+    oracle.lib().pco_sweep_batched(world.h, C.byref(c), C.c_uint64(seed), C.c_uint32(sweep), nb, C.c_int64(0),
+                                   oracle._p(np.ascontiguousarray(cur), C.c_int32), oracle._p(choice, C.c_int32),
+                                   oracle._p(chosen, C.c_int32), oracle._p(logml, C.c_double))
+    return choice, chosen, logml
+
+
+@pytest.mark.parametrize("n_rows", [1, 80])
+def test_rows_with_missing_cells_and_tiny_tables(oracle, n_rows):
+    """Row 0: every queried cell missing (nothing but the priors speaks); row 5: one cell left.  From an
+    empty trace (every proposal is a new referent) and again after the commit."""
+    holes = {0: None} if n_rows == 1 else {0: None, 5: ["ProviderNumber", "HospitalName", "City", "State", "ZipCode",
+                                                         "CountyName", "PhoneNumber", "HospitalType", "HospitalOwner",
+                                                         "EmergencyService", "Condition", "MeasureCode", "MeasureName"]}
+    dirty, clean, lw, obs = _hospital_with_holes(n_rows, holes)
+    assert (obs[:, 0] < 0).all()
+    eng = Engine(lw, obs, dist_mode=1)
+    try:
+        tr = Trace(lw, n_rows, 3)
+        cfg = InferenceConfig(1, 6)
+        c = InferConfig(1, 6, 1, 1, 0, 50, 100)
+        for sweep in range(2):
+            eng.upload_trace(tr)
+            world = helpers.mirror_world(oracle, lw, obs, tr, eng)
+            choice, chosen, logml, new_rows = eng.sweep(tr, cfg, 9, sweep)
+            och, ocp, oml = _oracle_sweep(oracle, world, c, 9, sweep, tr.cur)
+            assert np.array_equal(choice, och) and np.array_equal(chosen, ocp) and np.array_equal(logml, oml)
+            assert np.isfinite(logml).all()
+            if sweep == 0:
+                assert (choice < 0).all()  # empty tables: only the new-row candidate exists
+                tr.commit_batch(0, n_rows, choice, new_rows, dedup=True)
+            else:
+                tr.commit(choice, new_rows)
+            tr.check_consistency()
+    finally:
+        eng.close()
+
+
+def test_empty_window_and_empty_batches(oracle):
+    S = helpers.hospital_setup(n_rows=40)
+    eng = Engine(S["lw"], S["obs"], dist_mode=1)
+    try:
+        eng.upload_trace(S["trace"])
+        choice, chosen, logml, new_rows = eng.sweep(S["trace"], InferenceConfig(1, 4), 1, 0, lo=7, hi=7)
+        assert choice.shape == (2, 0) and len(chosen) == 0 and len(logml) == 0 and new_rows == {}
+        assert all(len(v[0]) == 0 for v in eng.sweep_moved().values())
+        assert all(v.sum() == 0 for v in eng.sweep_stats(S["trace"]).values())
+        hip = eng.hip
+        from pclean_amd import sampling
+        assert sampling.random_add_typos(hip, [], None) == [] and sampling.random_time_prior(hip, 0) == []
+        assert len(hip.random_categorical(0, np.zeros(3), 1, 0)) == 0
+        assert len(hip.random_normal(np.zeros(0), 1.0, 1.0, 1, 0)) == 0
+    finally:
+        eng.close()
+
+
+def test_abi_error_paths():
+    hip = HipContext(0)
+    try:
+        cfg = InferConfig(1, 2, 1, 1, 0, 50, 100)
+        with pytest.raises(PCleanHipError):  # nothing loaded yet
+            hip.sweep(cfg, 1, 0, np.zeros((1, 4), np.int32))
+        with pytest.raises(PCleanHipError):
+            hip.build_pair_table(0, np.zeros(1, np.int32), np.zeros(1, np.int32), 0)  # no strings loaded
+        with pytest.raises(PCleanHipError):
+            hip.get_moved(3)  # block never loaded
+        with pytest.raises(PCleanHipError):
+            hip.random_categorical(4, np.zeros(0), 1, 0)  # no options
+        with pytest.raises(PCleanHipError):
+            hip.load_score_block(99, [0], [0], [0, 0], [0, 0], [0], [0], 0, [0, 0], [0, 0])  # block id out of range
+        msg = hip.lib.pclean_last_error(hip.h).decode()
+        assert msg  # the message of the last failure is retrievable
+        # the context is still usable after errors
+        pool = StringPool()
+        ids = pool.add_all(["abc", "abd"])
+        sym, off, _, _ = pool.arrays()
+        hip.load_strings(sym, off)
+        hip.build_pair_table(0, ids, ids, 0)
+        assert hip.get_pair_table(0, 2, 2)[0, 1] == 1
+    finally:
+        hip.close()
