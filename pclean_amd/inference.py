@@ -47,8 +47,9 @@ def build_evidence(lw, trace, cname):
     # evidence rows grouped by latent row, restricted to live rows (dead rows have none anyway)
     ev_off = np.zeros(len(live) + 1, dtype=np.int32)
     np.cumsum(counts[live], out=ev_off[1:])
-    seg = [order[off_all[k]:off_all[k + 1]] for k in live]
-    ev_rows = np.concatenate(seg).astype(np.int32) if seg else np.zeros(0, np.int32)
+    # `order` is grouped by latent row in ascending id; keep the groups of live rows (vectorised)
+    sk = keys[order]
+    ev_rows = order[(sk >= 0) & t.live[np.maximum(sk, 0)]].astype(np.int32)
     ev_ctx = None
     for ct in lw.cross_terms:
         if ct["ctx_block"] == bi:      # this class sits on the ctx-argument side: ctx = the local argument's value
@@ -129,45 +130,49 @@ def _materialise_latent(lw, trace, pl, node, vals):
 
 def commit_latent(lw, trace, cname, live, chosen, vals):
     """Apply a latent-class sweep: rows whose chosen particle is fresh take the sampled values
-    (run_smc! tail, row_inference.jl:169-185, for a latent row)."""
+    (run_smc! tail, row_inference.jl:169-185, for a latent row).  Array operations over all changed rows;
+    only proposals of a brand-new referent are built one by one."""
     pl = lw.latent_plans[cname]
     t = trace.tables[cname]
-    m = lw.model.classes[cname]
+    idx = np.flatnonzero(np.asarray(chosen) > 0)
+    if len(idx) == 0:
+        return 0
+    h = np.asarray(live, dtype=np.int64)[idx]
+    vals = np.asarray(vals)
+    fks, props = trace._class_plan(cname)
+    for j, state in props:  # own-choice sufficient statistics: take the old values out ...
+        np.subtract.at(state.counts, t.cols[j, h], 1)
     changed = 0
-    released = []  # (class, row) referents to release AFTER every new reference has been counted:
+    released = []  # (class, rows) referents to release AFTER every new reference has been counted:
     # another row of this batch may have joined a referent that this row leaves (batched schedule)
-    for idx in np.nonzero(chosen > 0)[0]:
-        h = int(live[idx])
-        trace._own_choice_stats(cname, h, -1)
-        for r, root in enumerate(pl["roots"]):
-            attr = pl["root_attr"][r]
-            j = lw.colidx[cname][attr]
-            v = int(vals[idx, root])
-            if pl["nodes"][root][0] == 1:  # leaf: option index -> latent value
-                new = int(lw.option_values[(cname, attr)][v])
-                if new != t.cols[j, h]:
-                    t.cols[j, h] = new
-                    t.cols_dirty = True
-                    changed += 1
-            else:
-                tgt_cls = lw.layout[cname][j].target
-                tgt = trace.tables[tgt_cls]
-                new = _materialise_latent(lw, trace, pl, root, vals[idx]) if v == CHOICE_NEW else v
-                old = int(t.cols[j, h])
-                if new != old:
-                    tgt = trace.tables[tgt_cls]
-                    tgt.counts[new] += 1
-                    released.append((tgt_cls, old))
-                    t.cols[j, h] = new
-                    t.cols_dirty = True
-                    changed += 1
-        trace._own_choice_stats(cname, h, +1)
+    for r, root in enumerate(pl["roots"]):
+        attr = pl["root_attr"][r]
+        j = lw.colidx[cname][attr]
+        v = vals[idx, root]
+        old = t.cols[j, h].copy()
+        if pl["nodes"][root][0] == 1:  # leaf: option index -> latent value
+            new = lw.option_values[(cname, attr)][v]
+        else:
+            new = v.astype(np.int64)
+            for k in np.flatnonzero(v == CHOICE_NEW):  # ascending row order -> deterministic row ids
+                new[k] = _materialise_latent(lw, trace, pl, root, vals[idx[k]])
+            tgt_cls = lw.layout[cname][j].target
+            moved = new != old
+            np.add.at(trace.tables[tgt_cls].counts, new[moved], 1)
+            released.append((tgt_cls, old[moved]))
+        moved = new != old
+        if moved.any():
+            t.cols[j, h[moved]] = new[moved]
+            t.cols_dirty = True
+            changed += int(moved.sum())
+    for j, state in props:  # ... and put the new ones in
+        np.add.at(state.counts, t.cols[j, h], 1)
     for tgt_cls, old in released:
-        trace.tables[tgt_cls].counts[old] -= 1
+        np.subtract.at(trace.tables[tgt_cls].counts, old, 1)
     for tgt_cls, old in released:
         tgt = trace.tables[tgt_cls]
-        if tgt.counts[old] == 0 and tgt.live[old]:
-            trace.delete_row(tgt_cls, old)
+        cand = np.unique(old)
+        trace.delete_rows_bulk(tgt_cls, cand[(tgt.counts[cand] == 0) & tgt.live[cand]])
     refresh_flattened(lw, trace)
     return changed
 

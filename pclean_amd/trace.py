@@ -416,23 +416,23 @@ class Trace:
             cname = blk["root_class"]
             ch = np.array(choice[bi], dtype=np.int64)
             rows_new, vals_new = new_rows.get(bi, (np.zeros(0, np.int32), None))
-            memo = {}
-            for j, i in enumerate(rows_new):
-                key = vals_new[j].tobytes() if dedup else None
-                r = memo.get(key) if dedup else None
-                if r is None:
-                    r = self._materialise(bi, 0, vals_new[j])
-                    if dedup:
-                        memo[key] = r
-                ch[i] = r
+            if len(rows_new):
+                vals_new = np.asarray(vals_new)
+                if dedup:  # one row per distinct proposal, created in order of first occurrence
+                    u, first, inv = np.unique(vals_new, axis=0, return_index=True, return_inverse=True)
+                    order = np.argsort(first, kind="stable")
+                    rank = np.empty(len(order), dtype=np.int64)
+                    rank[order] = np.arange(len(order))
+                    ch[rows_new] = self.materialise_bulk(bi, u[order])[rank[np.asarray(inv).reshape(-1)]]
+                else:
+                    ch[rows_new] = self.materialise_bulk(bi, vals_new)
             t = self.tables[cname]
             old = self.cur[bi, begin:begin + count]
             np.add.at(t.counts, ch, 1)
             np.subtract.at(t.counts, old[old >= 0], 1)
             self.cur[bi, begin:begin + count] = ch
-            for k in np.unique(old[old >= 0]):
-                if t.counts[k] == 0 and t.live[k]:
-                    self.delete_row(cname, int(k))
+            cand = np.unique(old[old >= 0])
+            self.delete_rows_bulk(cname, cand[(t.counts[cand] == 0) & t.live[cand]])
 
     # -- parameter moves (inference.jl:72-77 -> resample_value!) ----------------
     def resample_parameters(self):
