@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--seed", type=int, default=20250926)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--emulate-shard-of", type=int, default=0,
+                    help="diagnostic, single process: sweep only the first 1/G of the rows (what one rank of a "
+                         "G-GPU job does, without the collectives) and report the step time on stderr; no JSON")
     args = ap.parse_args()
 
     import torch
@@ -171,6 +174,8 @@ def main():
 
     dirty, clean, lw, obs, tr = build_workload(args.rows, args.hospitals, args.seed)
     lo, hi = shard_bounds(args.rows, rank, world)
+    if args.emulate_shard_of > 1 and world == 1:
+        lo, hi = shard_bounds(args.rows, 0, args.emulate_shard_of)
     obs_local = np.ascontiguousarray(obs[:, lo:hi])
     tr.cur = np.ascontiguousarray(tr.cur[:, lo:hi])
     t0 = time.time()
@@ -226,6 +231,11 @@ def main():
     comm.barrier()
     elapsed = comm.max_float(time.perf_counter() - t0)
 
+    if args.emulate_shard_of > 1 and world == 1:
+        log(f"[bench] emulated rank 0 of {args.emulate_shard_of}: {hi - lo} rows, {1e3 * elapsed / args.steps:.2f} ms per step "
+            f"(device span {dev_ms / args.steps:.2f} ms, root kernel {hot_ms / max(hot_launches, 1):.2f} ms), no collectives")
+        eng.close()
+        return
     cnt = accuracy_counts(lw, tr, {c: v[lo:hi] for c, v in dirty.items()}, {c: v[lo:hi] for c, v in clean.items()})
     cnt = comm.allreduce_sum_i64(cnt)
     acc = f1_from_counts(cnt)
