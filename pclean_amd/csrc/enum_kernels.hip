@@ -6,7 +6,8 @@
 // RandomChoiceNode) plus the CRP prior (165-171) and the AddTypos densities
 // they call (src/distributions/add_typos.jl:50-66, via the pair tables).
 //
-// enum_node_kernel — one workgroup (256 lanes = 4 wavefronts) per work item,
+// enum_node_kernel — one workgroup (256 lanes = 4 wavefronts) per work item, or per GROUP of items
+// with identical score vectors (ItemsDev::grp_off / members: scores once, draws per member item),
 // candidate scores resident in LDS (<= ~20k candidates):
 //   phase 1  lane-strided over candidates: coalesced loads of the flattened
 //            latent table columns, gather of the pair-table byte, fp64 density
@@ -15,7 +16,8 @@
 //   phase 3  u_k = floor(exp(s_k - m) 2^40) in place (uint64; integer sums are
 //            order independent => bit-identical to the sequential oracle)
 //   phase 4  per-lane contiguous chunk sums, shuffle scan across the block
-//   phase 5  lse = m + log(U 2^-40); Philox draws located by the owning lane
+//   phase 5  lse = m + log(U 2^-40); the chunk sums become an inclusive prefix in place and every
+//            (member item, draw) pair locates its Philox threshold by binary search, one pair per lane
 // enum_node_big_kernel — same contract for candidate sets that do not fit in
 // LDS (large option lists of StringPrior / ChooseUniformly leaves): scores are
 // recomputed per pass instead of stored (max pass, weight pass, locate pass).

@@ -1,32 +1,27 @@
-// fk_root_fast_kernel — the dominant kernel: rows x candidate referents of a block
-// root (hospital Record block 1: K ~ 1e4 latent hospitals x 11 AddTypos terms) and of
-// the nested reference slots of its new-row branch.
+// fk_root_fast_kernel — the dominant sweep kernel: candidate referents of a reference slot with many
+// candidates (hospital Record block 1: K ~ 1e4 latent hospitals x 11 AddTypos terms; the nested Place /
+// County slots of its new-row branch; the Measure root of block 2 including its ctx term).
 //
-// Same contract and bit-identical results as enum_node_kernel (enum_kernels.hip),
-// restructured for MI355X:
-//   * candidate-compact byte tables comp_f[o][k] (built by compact_pair_kernel when
-//     the latent table's columns change) turn the pair-table gather into F
-//     contiguous byte streams per row: every lane reads one dword = 4 candidates,
-//     a wave reads 256 consecutive bytes -> fully coalesced; consecutive rows of one
-//     hospital re-read the same byte rows from L2 (measured HBM traffic ~10 GB per
-//     1M-row launch, profiles/r01_d_pmc_root_kernel.txt);
-//   * candidate word lengths clen_f[k] are streamed the same way (L2 resident);
-//   * the AddTypos density (add_typos.jl:61-63) is a (length, distance) LUT built
-//     once per workgroup in LDS with the very fp64 operation order of
-//     term_density(), so per term the inner loop is: 2 dword loads, 4 byte
-//     extracts, 4 ds_read_b64, 4 fp64 adds;
-//   * CRP priors are precomputed per candidate (prior_e / prior_n);
-//   * SURVIVOR COMPACTION: a candidate whose score is more than 28.5 nats below the
-//     maximum has fixed-point weight floor(exp(s-m) 2^40) == 0 exactly
-//     (pclean_fixw), so it can influence neither the log-sum-exp nor a draw.  Each
-//     lane keeps the candidates within 28.5 of its running maximum (a lower bound of
-//     the true maximum) in a 4-entry register window; after the block-wide max the
-//     windows are filtered into a small LDS list, rank-sorted by candidate index
-//     (natural order of the inverse CDF), prefix-summed and binary-searched per draw.
-//     The 8 B x K score vector never exists: LDS drops from ~100 KB to ~45 KB (2
-//     resident workgroups per CU) and the K-sized weight / scan phases disappear.
-//     Items whose windows or list overflow (flat posteriors) are flagged and re-run by
-//     the host with the LDS-resident generic kernel — results are identical either way.
+// Same contract and bit-identical results as enum_node_kernel (enum_kernels.hip), restructured for
+// MI355X around three facts:
+//   * candidate-compact byte tables comp_f[o][k] (built by compact_pair_kernel when the latent table's
+//     columns change) turn the pair-table gather into contiguous byte streams: every lane reads one
+//     dword = 4 candidates, a wave reads 256 consecutive bytes -> fully coalesced, L2 resident for the
+//     rows of one referent (groups are launched sorted by referent);
+//   * a candidate whose score is more than 28.5 nats below the maximum has fixed-point weight
+//     floor(exp(s-m) 2^40) == 0 exactly (pclean_fixw), so it can influence neither the log-sum-exp nor
+//     a draw.  An INTEGER PRE-FILTER proves that for almost every candidate: score <= prior_max -
+//     c_min * (summed byte distances of the three most discriminating terms), compared with a lower
+//     bound of the maximum (the exact score of the rows' current referent, or of the candidate with the
+//     smallest summed distance).  Only the survivors (a handful per row) are scored in fp64, in plan
+//     order, with the density read from the global nb / logl tables;
+//   * rows with identical (observed tuple, ctx, referent) share the score vector: ONE WORKGROUP PER
+//     GROUP of such rows (ItemsDev::grp_off / members); every (member row, particle) pair then draws
+//     with its own Philox counter by binary search over the survivors' prefix.
+// Survivors are kept in a 4-entry register window per lane, filtered with the block maximum into a
+// small LDS list (SURV2_CAP), rank-sorted by candidate index (the natural order of the inverse CDF)
+// and prefix-summed.  Groups whose windows or list overflow (flat posteriors, < 1 % of the rows) are
+// flagged and re-run by the host with the LDS-resident generic kernel — results are identical either way.
 #include <algorithm>
 #include <cstdlib>
 
