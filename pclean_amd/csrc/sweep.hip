@@ -1028,9 +1028,13 @@ __global__ void item_key_kernel(int n, KeyColsDev kc, const int32_t* row, const 
     for (int s = 0; s < PCLEAN_MAX_CTX; ++s) h = mix64(h, (uint32_t)ctxv[(size_t)i * PCLEAN_MAX_CTX + s]);
   if (excl) {
     // groups of one referent end up adjacent in the sorted order: their workgroups run back to back
-    // and re-read the same byte rows from L2 (the hash only has to separate tuples, order is free)
+    // and re-read the same byte rows from L2 (the hash only has to separate tuples, order is free).
+    // Short keys = few radix passes: 24 hash bits below the referent id, 32 hash bits without one; a
+    // collision of two different tuples can only split a group (item_head_kernel compares exactly).
     h = mix64(h, (uint32_t)excl[i]);
-    h = ((uint64_t)(uint32_t)(excl[i] + 1) << 40) | (h >> 24);
+    h = ((uint64_t)(uint32_t)(excl[i] + 1) << 24) | (h >> 40);
+  } else {
+    h >>= 32;
   }
   key[i] = h;
   idx[i] = i;
@@ -1123,11 +1127,17 @@ static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const It
   if (!key || !key_s || !idx || !idx_s || !head || !uid) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   hipLaunchKernelGGL(item_key_kernel, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, key, idx);
   size_t tmp_sort = 0, tmp_scan = 0;
-  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, key, key_s, idx, idx_s, n, 0, 64, ctx->stream));
+  int key_bits = 32;
+  if (excl) {  // referent ids are < rows of this node's table (+1 for "none")
+    const int kmax = ctx->cand[b.nodes[node_id].table].n_rows + 2;
+    key_bits = 24;
+    while ((1ll << (key_bits - 24)) < kmax) ++key_bits;
+  }
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, key, key_s, idx, idx_s, n, 0, key_bits, ctx->stream));
   HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan, head, uid, n, ctx->stream));
   unsigned char* tmp = scratch<unsigned char>(ctx, std::max(tmp_sort, tmp_scan));
   if (!tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_sort, key, key_s, idx, idx_s, n, 0, 64, ctx->stream));
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_sort, key, key_s, idx, idx_s, n, 0, key_bits, ctx->stream));
   hipLaunchKernelGGL(item_head_kernel, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, key_s, idx_s, head);
   HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(tmp, tmp_scan, head, uid, n, ctx->stream));
   int32_t n_unique = 0;
