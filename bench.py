@@ -166,9 +166,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and pclean_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("PCLEAN_FORCE_DIST"):  # PCLEAN_FORCE_DIST: exercise RCCL with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     comm = Comm(device=f"cuda:{local_rank}")
 
@@ -271,11 +272,19 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(lw, obs_local, tr, eng, cfg, args.seed, args.cpu_seconds)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        print(json.dumps(out), flush=True)
+        json_line = json.dumps(out)
     eng.close()
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes its version banner through C stdio; flush that first so that the JSON line is the
+        # LAST line on stdout
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json_line, flush=True)
 
 
 if __name__ == "__main__":

@@ -25,10 +25,14 @@ def main(program, particles=2, mh=True, iters=2, seed=0):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     device = None
-    if world > 1:
+    if world > 1 or os.environ.get("PCLEAN_FORCE_DIST"):  # PCLEAN_FORCE_DIST: exercise RCCL with one rank
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29534")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         device = f"cuda:{local_rank}"
     comm = Comm(device)
@@ -48,8 +52,8 @@ def main(program, particles=2, mh=True, iters=2, seed=0):
     if comm.rank == 0:
         print(f"{program}: {world} rank(s), {obs.shape[1]} rows, init + {iters} iterations in {dt:.2f}s", acc, flush=True)
     eng.close()
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 
