@@ -72,6 +72,16 @@ class OracleEngine:
             out[b] = d + np.bincount(ch[moved & (ch >= 0)], minlength=t.n)
         return out
 
+    def sweep_moved(self):
+        """What pclean_get_moved returns: rows (relative to the swept window, ascending) whose referent changed."""
+        out = {}
+        for b, blk in enumerate(self.lw.blocks):
+            if blk.get("score"):
+                continue
+            rows = np.flatnonzero(self._choice[b] != self._cur[b]).astype(np.int32)
+            out[b] = (rows, self._choice[b][rows].astype(np.int32))
+        return out
+
     def sweep_latent(self, trace, cname, config, seed, sweep_idx, live, ev_off, ev_rows, ev_ctx, excl):
         pl = self.lw.latent_plans[cname]
         w = self._world(trace, 0, self.obs.shape[1])

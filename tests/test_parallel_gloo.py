@@ -42,7 +42,7 @@ def _sweep_shard(orc, helpers, S, lo, hi, cfg, seed, sweep):
     return choice, stats, new_rows
 
 
-def _run(rank, world, port, out_path):
+def _run(rank, world, port, out_path, use_moved=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -60,7 +60,13 @@ def _run(rank, world, port, out_path):
     changed = []
     for sweep in range(3):
         choice, stats, new_rows = _sweep_shard(orc, helpers, S, lo, hi, 6, 99, sweep)
-        changed.append(exchange_and_commit(tr, lw, comm, lo, choice, stats, new_rows))
+        moved = None
+        if use_moved:  # the pclean_get_moved lists instead of scanning the choice arrays (what bench.py does)
+            moved = {}
+            for b in range(choice.shape[0]):
+                rows = np.flatnonzero(choice[b] != tr.cur[b]).astype(np.int32)
+                moved[b] = (rows, choice[b][rows])
+        changed.append(exchange_and_commit(tr, lw, comm, lo, choice, stats, new_rows, moved_local=moved))
     cur_all = comm.allgather_varlen_i32(tr.cur[0]), comm.allgather_varlen_i32(tr.cur[1])
     if rank == 0:
         np.savez(out_path, cur0=cur_all[0], cur1=cur_all[1], changed=np.array(changed),
@@ -82,13 +88,14 @@ def test_shard_bounds_cover_all_rows():
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_sweep_equals_single_process(tmp_path, oracle):
+@pytest.mark.parametrize("use_moved", [False, True])
+def test_two_rank_sweep_equals_single_process(tmp_path, oracle, use_moved):
     import torch.multiprocessing as mp
     single = str(tmp_path / "single.npz")
-    _run(0, 1, 0, single)
+    _run(0, 1, 0, single, False)
     multi = str(tmp_path / "multi.npz")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_run, args=(2, port, multi), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + (97 if use_moved else 0)
+    mp.spawn(_run, args=(2, port, multi, use_moved), nprocs=2, join=True)
     a, b = np.load(single), np.load(multi)
     assert set(a.files) == set(b.files)
     for k in a.files:
