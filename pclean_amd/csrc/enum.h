@@ -113,7 +113,7 @@ struct FastRootDev {
   // integer pre-filter (root_fast.hip): terms whose byte rows are summed, 1 / (smallest cost of one
   // edit), and the largest prior with / without an excluded reference
   int32_t n_pre, pre[3];
-  int32_t chunk_rounds, pad2;  // rounds per survivor-bitmask chunk (<= 64)
+  int32_t chunk_rounds, pad2;  // rounds (of 16 candidates per lane) per survivor-bitmask chunk (<= 16)
   double inv_c, prior_max_e, prior_max_n;
   FastTermDev terms[PCLEAN_MAX_TERMS];
 };

@@ -34,6 +34,7 @@
 #define FAST_MAX_WAVES 16
 #define SURV2_CAP 256      // after filtering with the true maximum
 #define FIX_CUTOFF 28.5    // pclean_fixw(d) == 0 for d < -28.5
+#define FAST_WINDOW 8      // per-lane register window of candidates within FIX_CUTOFF of the running maximum
 
 __global__ void compact_pair_kernel(const uint8_t* __restrict__ pair, int n_obs, int n_lat,
                                     const int32_t* __restrict__ cand_col, int n_cand, int kpad,
@@ -244,44 +245,55 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   // ---- phase 1: scores, 4 consecutive candidates per lane per round.  Each lane keeps the
   // candidates within FIX_CUTOFF of its running maximum in a 4-entry register window.
   double tmax = bound;      // filter threshold base (lower bound of the maximum)
-  double wS[4];
-  int wK[4];
+  double wS[FAST_WINDOW];
+  int wK[FAST_WINDOW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < FAST_WINDOW; ++i) {
     wS[i] = -__builtin_inf();
     wK[i] = -1;
   }
   bool lost = false;        // a window candidate had to be dropped
   double lost_max = -__builtin_inf();
-  // Rounds are processed in chunks of at most 64 (fr.chunk_rounds): 1a scans a chunk, 1b scores its survivors.
-  const int rounds_total = (nslots + T - 1) / T;
+  // A lane reads 16 consecutive candidates per round (one 16-byte load per pre-filter row = 4 slots of
+  // 4 candidates).  Rounds are processed in chunks of at most 16 (fr.chunk_rounds; 4 survivor bits per
+  // round in one 64-bit word): 1a scans a chunk, 1b scores its survivors.
+  const int nquads = fr.kpad >> 4;
+  const int rounds_total = (nquads + T - 1) / T;
   for (int rb = 0; rb < rounds_total; rb += fr.chunk_rounds) {
-  // 1a: branch-free integer scan (loads of several rounds in flight): bit r of `alive` = the lane's
-  //     (rb + r)-th slot holds a candidate that may carry weight
+  // 1a: branch-free integer scan (loads of several rounds in flight): bit 4r+w of `alive` = slot w of the
+  //     lane's (rb + r)-th quad holds a candidate that may carry weight
   uint64_t alive = 0;
   {
     const int r_end = min(fr.chunk_rounds, rounds_total - rb);
-#pragma unroll 4
+#pragma unroll 2
     for (int r = 0; r < r_end; ++r) {
-      const int slot = tid + (rb + r) * T;
-      if (slot >= nslots) break;
-      uint32_t lo = 0, hi = 0;
+      const int quad = tid + (rb + r) * T;
+      if (quad >= nquads) break;
+      uint32_t lo[4] = {0u, 0u, 0u, 0u}, hi[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
       for (int p = 0; p < 3; ++p)
         if (prow[p]) {
-          const uint32_t c = prow[p][slot];
-          lo += c & 0x00ff00ffu;
-          hi += (c >> 8) & 0x00ff00ffu;
+          const uint4 c = reinterpret_cast<const uint4*>(prow[p])[quad];
+          const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            lo[w] += cw[w] & 0x00ff00ffu;
+            hi[w] += (cw[w] >> 8) & 0x00ff00ffu;
+          }
         }
-      const bool pass = (lo & 0xffffu) <= dcut || (hi & 0xffffu) <= dcut || (lo >> 16) <= dcut || (hi >> 16) <= dcut;
-      alive |= (uint64_t)(pass ? 1u : 0u) << r;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const bool pass = (lo[w] & 0xffffu) <= dcut || (hi[w] & 0xffffu) <= dcut || (lo[w] >> 16) <= dcut ||
+                          (hi[w] >> 16) <= dcut;
+        alive |= (uint64_t)(pass ? 1u : 0u) << (4 * r + w);
+      }
     }
   }
   // 1b: exact fp64 scores of the surviving slots
   while (alive) {
-    const int r = __builtin_ctzll(alive);
+    const int bit = __builtin_ctzll(alive);
     alive &= alive - 1;
-    const int slot = tid + (rb + r) * T;
+    const int slot = ((tid + (rb + (bit >> 2)) * T) << 2) + (bit & 3);
     const int k0 = slot << 2;
     double acc[4];
     const double2 p01 = *reinterpret_cast<const double2*>(prior + k0);
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
         // insert into the window: reuse a slot that is empty or has fallen out of the window
         bool placed = false;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < FAST_WINDOW; ++i)
           if (!placed && (wK[i] < 0 || wS[i] < tmax - FIX_CUTOFF)) {
             wS[i] = acc[e];
             wK[i] = k0 + e;
@@ -360,7 +372,7 @@ __global__ __launch_bounds__(1024) void fk_root_fast_kernel(const FastRootDev fr
   // ---- phase 3: candidates with non-zero fixed-point weight -> LDS list ----------------------
   if (lost && lost_max - m >= -FIX_CUTOFF) atomicAdd(&cnt[2], 1u);  // a dropped candidate mattered
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < FAST_WINDOW; ++i)
     if (wK[i] >= 0 && wS[i] - m >= -FIX_CUTOFF) {
       const unsigned int pos = atomicAdd(&cnt[1], 1u);
       if (pos < SURV2_CAP) {
@@ -466,10 +478,9 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   const size_t lds = pclean_fast_lds_bytes(fr.lmax, fr.dstride);
   // lanes: small workgroups (more of them resident per CU hide the per-row latency chain), at most
   // 64 rounds of 4-candidate slots per lane (the survivor bitmask is one 64-bit word)
-  const int nslots = fr.kpad >> 2;
-  int T = 128;
+  int T = 64;
   if (const char* e = getenv("PCLEAN_FAST_T")) T = std::max(64, std::min(1024, atoi(e) / 64 * 64));
-  while (T < 1024 && (nslots + T - 1) / T > 64) T += 64;
+  while (T < 1024 && ((fr.kpad >> 4) + T - 1) / T > 64) T += 64;  // at most 4 chunks of 16 rounds per lane
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, nullptr, nullptr, nullptr};
   fast_kernel_t kern = pick_kernel(fr.n_terms);
   HIPCHK(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -856,8 +856,8 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     } else {
       fr.inv_c = 1.0 / (cmin * (1.0 - 1e-9));
     }
-    fr.chunk_rounds = 64;
-    if (const char* e = getenv("PCLEAN_FAST_CHUNK")) fr.chunk_rounds = std::max(1, std::min(64, atoi(e)));
+    fr.chunk_rounds = 16;
+    if (const char* e = getenv("PCLEAN_FAST_CHUNK")) fr.chunk_rounds = std::max(1, std::min(16, atoi(e)));
     fr.pad2 = 0;
     fr.prior_max_e = f.logc_max - t.scal[1];
     fr.prior_max_n = f.logc_max - t.scal[0];
