@@ -104,3 +104,54 @@ def f1_from_counts(cnt):
 
 def evaluate_accuracy(lowered, trace, dirty, clean):
     return f1_from_counts(accuracy_counts(lowered, trace, dirty, clean))
+
+
+def reconstructed_table(lowered, trace, dirty):
+    """The cleaned table: every queried column replaced by what PClean believes, the others copied
+    (the DataFrame save_results writes, analysis.jl:21-30).  Values come back as strings / numbers."""
+    lw = lowered
+    ours = reconstructed_pool_ids(lw, trace)
+    n = trace.cur.shape[1]
+    out = {}
+    for col, vals in dirty.items():
+        if col not in ours:
+            out[col] = list(vals[:n])
+        elif isinstance(ours[col], tuple):
+            out[col] = [None if np.isnan(v) else (int(v) if float(v).is_integer() else float(v)) for v in ours[col][1]]
+        else:
+            out[col] = [lw.pool.strings[i] if i >= 0 else None for i in ours[col]]
+    return out
+
+
+def latent_table(lowered, trace, cname):
+    """One inferred latent table (save_tables, analysis.jl:8-13): row id + the value of every own attribute and
+    reference slot of the class (flattened copies of referents' values are left out, as the reference does
+    for its '#'-named inlined nodes)."""
+    lw = lowered
+    t = trace.tables[cname]
+    live = np.nonzero(t.live[:t.n])[0]
+    out = {"id": [int(k) for k in live]}
+    for j, c in enumerate(lw.layout[cname]):
+        if "." in c.name:
+            continue
+        if c.kind == "fk":
+            out[c.name] = [int(v) for v in t.cols[j, live]]
+        else:
+            dom = lw.latent_dom[(cname, c.name)]
+            out[c.name] = [dom.string(v) for v in t.cols[j, live]]
+    return out
+
+
+def save_results(directory, name, lowered, trace, dirty, timestamp=True):
+    """save_results (analysis.jl:15-33): reconstructed_<class>.csv + inferred_<class>.csv per latent class."""
+    import datetime
+    import os
+
+    import pandas as pd
+    d = os.path.join(directory, f"{name}-{datetime.datetime.now().isoformat()}" if timestamp else name)
+    os.makedirs(d, exist_ok=True)
+    pd.DataFrame(reconstructed_table(lowered, trace, dirty)).to_csv(
+        os.path.join(d, f"reconstructed_{lowered.query.cls}.csv"), index=False)
+    for cname in trace.tables:
+        pd.DataFrame(latent_table(lowered, trace, cname)).to_csv(os.path.join(d, f"inferred_{cname}.csv"), index=False)
+    return d

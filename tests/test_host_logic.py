@@ -106,3 +106,61 @@ def test_missing_observation_encoding():
     lw = LoweredModel(m, Query(m, "Obs", {"Y": ("a.x", "y")}), {"Y": ["aa", None, "bx"]})
     obs = lw.encode_observations({"Y": ["aa", None, "bx"]})
     assert obs.tolist() == [[0, -1, 1]]
+
+
+def test_save_results_and_bulk_commit_equivalence(S, tmp_path):
+    """save_results (analysis.jl:15-33) writes the reconstructed table and one file per latent class; the
+    array-based row creation / deletion of trace.py equals the row-by-row path."""
+    import os
+
+    import pandas as pd
+
+    from pclean_amd.analysis import reconstructed_table, save_results
+    lw, tr, dirty, clean = S["lw"], S["trace"], S["dirty"], S["clean"]
+    d = save_results(str(tmp_path), "hospital", lw, tr, dirty, timestamp=False)
+    files = sorted(os.listdir(d))
+    assert "reconstructed_Record.csv" in files and "inferred_Hospital.csv" in files and len(files) == 1 + len(tr.tables)
+    rec = pd.read_csv(os.path.join(d, "reconstructed_Record.csv"), dtype=str, keep_default_na=False)
+    assert len(rec) == tr.cur.shape[1] and list(rec.columns) == list(dirty.keys())
+    # the initial trace holds the clean values wherever they are possible latent values
+    same = sum(a == b for a, b in zip(rec["City"], clean["City"]))
+    assert same > 0.95 * len(rec)
+    assert reconstructed_table(lw, tr, dirty)["ProviderNumber"][0] == rec["ProviderNumber"][0]
+    hosp = pd.read_csv(os.path.join(d, "inferred_Hospital.csv"), dtype=str, keep_default_na=False)
+    assert len(hosp) == tr.tables["Hospital"].n_live and {"id", "loc", "type", "name", "zip"} <= set(hosp.columns)
+
+    # bulk vs sequential creation of new Measure rows (block 1), then deletion: identical tables
+    import copy
+    S2 = helpers.hospital_setup(n_rows=120, seed=2)
+    lw = S2["lw"]
+    t1, t2 = S2["trace"], copy.deepcopy(S2["trace"])
+    blk = lw.blocks[1]
+    rng = np.random.default_rng(0)
+    nn = len(blk["nodes"])
+    vals = np.zeros((40, nn), dtype=np.int32)
+    for cn, node in enumerate(blk["nodes"]):
+        if cn == 0:
+            vals[:, cn] = -1
+        elif node[0] == 1:
+            info = blk["node_info"][cn]
+            vals[:, cn] = rng.integers(0, len(lw.option_values[(info["cls"], info["attr"])]), 40)
+        else:
+            vals[:, cn] = rng.integers(0, t1.tables[blk["node_info"][cn]["cls"]].n, 40)
+    vals[::7, [cn for cn, node in enumerate(blk["nodes"]) if cn and node[0] == 0][0]] = -1  # some nested NEW referents
+    a = t1.materialise_bulk(1, vals)
+    b = np.array([t2._materialise(1, 0, v) for v in vals])
+    m1, m2 = t1.tables["Measure"], t2.tables["Measure"]
+    # row ids differ only by the order in which simple and nested proposals are created; contents must agree
+    assert sorted(map(tuple, m1.cols[:, a].T.tolist())) == sorted(map(tuple, m2.cols[:, b].T.tolist()))
+    for c in t1.tables:
+        assert t1.tables[c].n_live == t2.tables[c].n_live or c == "Measure"
+        assert t1.tables[c].counts[:t1.tables[c].n].sum() == t2.tables[c].counts[:t2.tables[c].n].sum()
+    t1.delete_rows_bulk("Measure", a)
+    for r in b:
+        t2.delete_row("Measure", int(r))
+    t1.check_consistency()
+    t2.check_consistency()
+    for c in t1.tables:
+        assert t1.tables[c].n_live == t2.tables[c].n_live
+        assert np.array_equal(np.sort(t1.tables[c].counts[:t1.tables[c].n][t1.tables[c].live[:t1.tables[c].n]]),
+                              np.sort(t2.tables[c].counts[:t2.tables[c].n][t2.tables[c].live[:t2.tables[c].n]]))
