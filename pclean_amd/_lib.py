@@ -412,6 +412,25 @@ class HipContext:
             "pclean_sweep_latent")
         return chosen, vals
 
+    # -- C-level RCCL exchange (for hosts without torch.distributed; the Python host uses parallel.Comm) --
+    def comm_unique_id(self):
+        buf = (C.c_ubyte * 128)()
+        check(self.h, self.lib.pclean_comm_unique_id(self.h, buf), "pclean_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, n_ranks, rank, unique_id):
+        buf = (C.c_ubyte * 128).from_buffer_copy(unique_id)
+        check(self.h, self.lib.pclean_comm_init(self.h, C.c_int32(n_ranks), C.c_int32(rank), buf), "pclean_comm_init")
+
+    def allreduce_stats(self, table_id, n_rows):
+        out = np.zeros(n_rows, dtype=np.int64)
+        check(self.h, self.lib.pclean_allreduce_stats(self.h, C.c_int32(table_id), _p(out, C.c_int64)),
+              "pclean_allreduce_stats")
+        return out
+
+    def comm_destroy(self):
+        check(self.h, self.lib.pclean_comm_destroy(self.h), "pclean_comm_destroy")
+
     def get_moved(self, block_id):
         n = C.c_int32()
         check(self.h, self.lib.pclean_get_moved(self.h, C.c_int32(block_id), C.byref(n), None, None), "pclean_get_moved")

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpclean_hip.so")
-SOURCES = ["api.hip", "dist_kernels.hip", "enum_kernels.hip", "root_fast.hip", "random_kernels.hip", "sweep.hip"]
+SOURCES = ["api.hip", "comm.hip", "dist_kernels.hip", "enum_kernels.hip", "root_fast.hip", "random_kernels.hip", "sweep.hip"]
 HEADERS = ["ctx.h", "../../include/pclean_hip.h", "../../include/pclean_detmath.h", "../../include/pclean_philox.h"]
 # -ffp-contract=off: the parity contract (include/pclean_detmath.h) needs plain
 # IEEE mul/add on device, identical to the gcc-built oracle.
@@ -41,7 +41,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(o)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

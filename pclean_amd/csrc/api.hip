@@ -32,6 +32,7 @@ extern "C" int pclean_ctx_destroy(pclean_ctx* ctx) {
   if (!ctx) return PCLEAN_ERR_ARG;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  (void)pclean_comm_destroy(ctx);
   pclean_sweep_state_free(ctx);
   ctx->sym.release();
   ctx->off.release();

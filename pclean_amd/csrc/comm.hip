@@ -1,0 +1,118 @@
+// Inter-GPU exchange of the CRP sufficient statistics through RCCL, for hosts that do not have
+// torch.distributed (pclean_comm_* / pclean_allreduce_stats of include/pclean_hip.h).  RCCL is resolved
+// with dlopen at the first call: a process that already carries an RCCL (PyTorch) keeps using that
+// copy, and single-GPU users never load it.
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "ctx.h"
+
+namespace {
+
+// the handful of RCCL declarations used (rccl.h: ncclUniqueId is 128 opaque bytes passed BY VALUE)
+struct UniqueId {
+  char internal[128];
+};
+typedef int (*get_unique_id_t)(UniqueId*);
+typedef int (*comm_init_rank_t)(void**, int, UniqueId, int);
+typedef int (*all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*comm_destroy_t)(void*);
+typedef const char* (*get_error_string_t)(int);
+const int kNcclInt64 = 4;  // ncclInt64
+const int kNcclSum = 0;    // ncclSum
+
+struct Rccl {
+  void* handle = nullptr;
+  get_unique_id_t get_unique_id = nullptr;
+  comm_init_rank_t comm_init_rank = nullptr;
+  all_reduce_t all_reduce = nullptr;
+  comm_destroy_t comm_destroy = nullptr;
+  get_error_string_t error_string = nullptr;
+};
+
+Rccl* rccl(pclean_ctx* ctx) {
+  static Rccl r;
+  if (r.handle) return &r;
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  for (const char* n : names) {
+    r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (r.handle) break;
+  }
+  if (!r.handle) {
+    pclean_fail(ctx, PCLEAN_ERR_STATE, "RCCL not found (dlopen librccl.so): %s", dlerror());
+    return nullptr;
+  }
+  r.get_unique_id = (get_unique_id_t)dlsym(r.handle, "ncclGetUniqueId");
+  r.comm_init_rank = (comm_init_rank_t)dlsym(r.handle, "ncclCommInitRank");
+  r.all_reduce = (all_reduce_t)dlsym(r.handle, "ncclAllReduce");
+  r.comm_destroy = (comm_destroy_t)dlsym(r.handle, "ncclCommDestroy");
+  r.error_string = (get_error_string_t)dlsym(r.handle, "ncclGetErrorString");
+  if (!r.get_unique_id || !r.comm_init_rank || !r.all_reduce || !r.comm_destroy) {
+    pclean_fail(ctx, PCLEAN_ERR_STATE, "RCCL symbols missing in librccl.so");
+    r.handle = nullptr;
+    return nullptr;
+  }
+  return &r;
+}
+
+int rccl_fail(pclean_ctx* ctx, Rccl* r, const char* what, int rc) {
+  return pclean_fail(ctx, PCLEAN_ERR_HIP, "%s failed: %s", what, r->error_string ? r->error_string(rc) : "rccl error");
+}
+
+}  // namespace
+
+extern "C" int pclean_comm_unique_id(pclean_ctx* ctx, unsigned char id_out[128]) {
+  if (!ctx || !id_out) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_comm_unique_id: bad arguments");
+  Rccl* r = rccl(ctx);
+  if (!r) return PCLEAN_ERR_STATE;
+  UniqueId id;
+  const int rc = r->get_unique_id(&id);
+  if (rc) return rccl_fail(ctx, r, "ncclGetUniqueId", rc);
+  memcpy(id_out, id.internal, 128);
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_comm_init(pclean_ctx* ctx, int32_t n_ranks, int32_t rank, const unsigned char id_in[128]) {
+  if (!ctx || n_ranks < 1 || rank < 0 || rank >= n_ranks || !id_in)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_comm_init: bad arguments");
+  if (ctx->rccl_comm) return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_comm_init: communicator already initialised");
+  Rccl* r = rccl(ctx);
+  if (!r) return PCLEAN_ERR_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  UniqueId id;
+  memcpy(id.internal, id_in, 128);
+  void* comm = nullptr;
+  const int rc = r->comm_init_rank(&comm, n_ranks, id, rank);
+  if (rc) return rccl_fail(ctx, r, "ncclCommInitRank", rc);
+  ctx->rccl_comm = comm;
+  ctx->comm_ranks = n_ranks;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_allreduce_stats(pclean_ctx* ctx, int32_t table_id, int64_t* out) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || !ctx->cand[table_id].valid)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_allreduce_stats: bad arguments");
+  if (!ctx->rccl_comm) return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_allreduce_stats: call pclean_comm_init first");
+  Rccl* r = rccl(ctx);
+  if (!r) return PCLEAN_ERR_STATE;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  CandTable& t = ctx->cand[table_id];
+  if (t.n_rows > 0) {
+    const int rc = r->all_reduce(t.stats.p, t.stats.p, (size_t)t.n_rows, kNcclInt64, kNcclSum, ctx->rccl_comm, ctx->stream);
+    if (rc) return rccl_fail(ctx, r, "ncclAllReduce", rc);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (out) HIPCHK(ctx, hipMemcpy(out, t.stats.p, (size_t)t.n_rows * 8, hipMemcpyDeviceToHost));
+  }
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_comm_destroy(pclean_ctx* ctx) {
+  if (!ctx) return PCLEAN_ERR_ARG;
+  if (!ctx->rccl_comm) return PCLEAN_OK;
+  Rccl* r = rccl(ctx);
+  if (r) (void)r->comm_destroy(ctx->rccl_comm);
+  ctx->rccl_comm = nullptr;
+  ctx->comm_ranks = 0;
+  return PCLEAN_OK;
+}

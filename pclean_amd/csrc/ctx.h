@@ -140,6 +140,8 @@ struct pclean_ctx {
   int32_t active_begin = 0, active_count = -1;  // pclean_set_active_rows window (-1 = all rows)
   bool force_generic = false;  // debug: never take the compact-table root kernel
   void* sweep_state = nullptr;  // owned by sweep.hip
+  void* rccl_comm = nullptr;    // ncclComm_t of pclean_comm_init (comm.hip)
+  int32_t comm_ranks = 0;
 };
 
 inline int pclean_fail(pclean_ctx* ctx, int code, const char* fmt, ...) {
