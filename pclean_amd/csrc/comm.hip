@@ -34,10 +34,16 @@ struct Rccl {
 Rccl* rccl(pclean_ctx* ctx) {
   static Rccl r;
   if (r.handle) return &r;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
-  for (const char* n : names) {
-    r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (r.handle) break;
+  // Never bring a second RCCL into the process: if one is already loaded (PyTorch ships its own
+  // librccl.so) ncclGetUniqueId is visible through the global scope — use that copy.
+  if (dlsym(RTLD_DEFAULT, "ncclGetUniqueId")) {
+    r.handle = dlopen(nullptr, RTLD_NOW);
+  } else {
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+      r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (r.handle) break;
+    }
   }
   if (!r.handle) {
     pclean_fail(ctx, PCLEAN_ERR_STATE, "RCCL not found (dlopen librccl.so): %s", dlerror());

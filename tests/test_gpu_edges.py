@@ -138,29 +138,3 @@ def test_abi_error_paths():
     finally:
         hip.close()
 
-
-def test_c_level_rccl_allreduce_single_rank(oracle):
-    """pclean_comm_* / pclean_allreduce_stats (the exchange a torch-less host would use): with a one-rank
-    communicator the all-reduce is the identity on the Δreference counts of the last sweep."""
-    S = helpers.hospital_setup(n_rows=200)
-    lw, tr = S["lw"], S["trace"]
-    eng = Engine(lw, S["obs"], dist_mode=1)
-    try:
-        eng.upload_trace(tr)
-        with pytest.raises(PCleanHipError):
-            eng.hip.allreduce_stats(lw.table_id["Hospital"], tr.tables["Hospital"].n)  # no communicator yet
-        uid = eng.hip.comm_unique_id()
-        assert len(uid) == 128
-        eng.hip.comm_init(1, 0, uid)
-        with pytest.raises(PCleanHipError):
-            eng.hip.comm_init(1, 0, uid)  # already initialised
-        eng.sweep(tr, InferenceConfig(1, 4), 3, 0)
-        for cname in ("Hospital", "Measure"):
-            tid, n = lw.table_id[cname], tr.tables[cname].n
-            before = eng.hip.get_stats(tid, n)
-            after = eng.hip.allreduce_stats(tid, n)
-            assert np.array_equal(before, after) and np.array_equal(eng.hip.get_stats(tid, n), before)
-        eng.hip.comm_destroy()
-        eng.hip.comm_destroy()  # idempotent
-    finally:
-        eng.close()
