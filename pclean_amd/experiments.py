@@ -17,6 +17,21 @@ def load_table(path):
     return {c: [None if v == "" else v for v in df[c].tolist()] for c in df.columns}
 
 
+def shuffle_rows(tables, seed=0):
+    """The same random permutation applied to every table of `tables` (dirty, clean, ...); returns
+    (permuted tables, perm) with permuted[c][i] = original[c][perm[i]].
+
+    Why: the batched initialize_trace lets the rows of one batch see only latent rows created by EARLIER
+    batches.  The shipped tables are sorted by entity (all records of a hospital are consecutive), the worst
+    case for that schedule — every batch meets only new entities and spawns duplicates (hospital: 349
+    latent hospitals after the init instead of ~50).  In random order the small early batches create the
+    entities and the large later ones join them.  The sequential reference is insensitive to the order."""
+    import numpy as np
+    n = len(next(iter(tables[0].values())))
+    perm = np.random.default_rng(seed).permutation(n)
+    return [{c: [v[i] for i in perm] for c, v in t.items()} for t in tables], perm
+
+
 def possibilities_of(table):
     """load_data.jl:17-18: unique non-missing dirty values per column, first-seen order."""
     return {c: list(dict.fromkeys(v for v in vals if v is not None)) for c, vals in table.items()}

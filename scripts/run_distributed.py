@@ -37,6 +37,7 @@ def main(program, particles=2, mh=True, iters=2, seed=0):
         device = f"cuda:{local_rank}"
     comm = Comm(device)
     dirty, clean = getattr(ex, f"{program}_data")()
+    (dirty, clean), _ = ex.shuffle_rows([dirty, clean], seed)  # same permutation on every rank
     m = ex.hospital_model(ex.possibilities_of(dirty)) if program == "hospital" else getattr(ex, f"{program}_model")(dirty)
     lw = LoweredModel(m, getattr(ex, f"{program}_query")(m), dirty)
     obs = lw.encode_observations(dirty)

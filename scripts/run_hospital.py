@@ -14,8 +14,10 @@ from pclean_amd.model import LoweredModel
 from pclean_amd.trace import Trace
 
 
-def main(particles=2, mh=True, iters=1, seed=0):
+def main(particles=2, mh=True, iters=1, seed=0, shuffle=True):
     dirty, clean = ex.hospital_data()
+    if shuffle:  # random row order for the batched initialisation (experiments.shuffle_rows)
+        (dirty, clean), _ = ex.shuffle_rows([dirty, clean], seed)
     m = ex.hospital_model(ex.possibilities_of(dirty))
     q = ex.hospital_query(m)
     lw = LoweredModel(m, q, dirty)
@@ -41,4 +43,5 @@ def main(particles=2, mh=True, iters=1, seed=0):
 
 if __name__ == "__main__":
     a = sys.argv[1:]
-    main(particles=int(a[0]) if a else 2, mh=(a[1] == "mh") if len(a) > 1 else True, iters=int(a[2]) if len(a) > 2 else 1)
+    main(particles=int(a[0]) if a else 2, mh=(a[1] == "mh") if len(a) > 1 else True, iters=int(a[2]) if len(a) > 2 else 1,
+         shuffle="sorted" not in a)

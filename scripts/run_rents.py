@@ -14,8 +14,10 @@ from pclean_amd.model import LoweredModel
 from pclean_amd.trace import Trace
 
 
-def main(n_rows=None, particles=2, mh=True, iters=1, seed=0):
+def main(n_rows=None, particles=2, mh=True, iters=1, seed=0, shuffle=True):
     dirty, clean = ex.rents_data()
+    if shuffle:  # random row order for the batched initialisation (experiments.shuffle_rows)
+        (dirty, clean), _ = ex.shuffle_rows([dirty, clean], seed)
     if n_rows:
         dirty = {c: v[:n_rows] for c, v in dirty.items()}
         clean = {c: v[:n_rows] for c, v in clean.items()}
@@ -44,4 +46,5 @@ def main(n_rows=None, particles=2, mh=True, iters=1, seed=0):
 if __name__ == "__main__":
     a = sys.argv[1:]
     main(n_rows=int(a[0]) if a and int(a[0]) > 0 else None, particles=int(a[1]) if len(a) > 1 else 2,
-         mh=(a[2] == "mh") if len(a) > 2 else True, iters=int(a[3]) if len(a) > 3 else 1)
+         mh=(a[2] == "mh") if len(a) > 2 else True, iters=int(a[3]) if len(a) > 3 else 1,
+         shuffle="sorted" not in a)

@@ -17,9 +17,11 @@ from pclean_amd.synth import synth_hospital
 from pclean_amd.trace import Trace
 
 
-def main(n_rows, n_hosp, particles=2, mh=True, iters=1, seed=20250926, max_batch=8192):
+def main(n_rows, n_hosp, particles=2, mh=True, iters=1, seed=20250926, max_batch=8192, shuffle=True):
     t0 = time.time()
     dirty, clean, latent = synth_hospital(n_rows, n_hosp, seed)
+    if shuffle:  # the generator emits the records of a hospital consecutively (experiments.shuffle_rows)
+        (dirty, clean), _ = ex.shuffle_rows([dirty, clean], seed)
     m = ex.hospital_model(ex.possibilities_of(dirty))
     lw = LoweredModel(m, ex.hospital_query(m), dirty)
     obs = lw.encode_observations(dirty)
@@ -48,4 +50,4 @@ def main(n_rows, n_hosp, particles=2, mh=True, iters=1, seed=20250926, max_batch
 if __name__ == "__main__":
     a = sys.argv[1:]
     main(int(a[0]), int(a[1]), particles=int(a[2]) if len(a) > 2 else 2, mh=(a[3] == "mh") if len(a) > 3 else True,
-         iters=int(a[4]) if len(a) > 4 else 1, max_batch=int(a[5]) if len(a) > 5 else 8192)
+         iters=int(a[4]) if len(a) > 4 else 1, max_batch=int(a[5]) if len(a) > 5 else 8192, shuffle="sorted" not in a)

@@ -99,3 +99,4 @@ def test_flights_oracle_inference(oracle):
     assert f1[-1] > 0.8 and f1[-1] > f1[0]
     # reliable websites end with smaller error probabilities than the prior mean 10/60 suggests for noisy ones
     assert tr.prob_param.value.min() < 0.15 < tr.prob_param.value.max()
+

@@ -164,3 +164,32 @@ def test_save_results_and_bulk_commit_equivalence(S, tmp_path):
         assert t1.tables[c].n_live == t2.tables[c].n_live
         assert np.array_equal(np.sort(t1.tables[c].counts[:t1.tables[c].n][t1.tables[c].live[:t1.tables[c].n]]),
                               np.sort(t2.tables[c].counts[:t2.tables[c].n][t2.tables[c].live[:t2.tables[c].n]]))
+
+
+def test_shuffled_rows_keep_the_batched_init_from_spawning_duplicates(oracle):
+    """The hospital table ships sorted by entity — the worst case for the batched initialize_trace (a batch
+    only sees latent rows of earlier batches).  In random order (experiments.shuffle_rows) far fewer
+    duplicate hospitals are created."""
+    from oracle_engine import OracleEngine
+    from pclean_amd import experiments as ex
+    from pclean_amd.engine import InferenceConfig
+    from pclean_amd.inference import initialize_trace
+    from pclean_amd.model import LoweredModel
+    from pclean_amd.trace import Trace
+    dirty, clean = ex.hospital_data()
+    dirty = {c: v[:400] for c, v in dirty.items()}
+    n_hosp = {}
+    for shuffled in (False, True):
+        d = dirty
+        if shuffled:
+            (d,), perm = ex.shuffle_rows([dirty], 0)
+            assert sorted(perm.tolist()) == list(range(400)) and d["City"][0] == dirty["City"][perm[0]]
+        m = ex.hospital_model(ex.possibilities_of(d))
+        lw = LoweredModel(m, ex.hospital_query(m), d)
+        obs = lw.encode_observations(d)
+        tr = Trace(lw, obs.shape[1], 0)
+        initialize_trace(OracleEngine(oracle, lw, obs), tr, InferenceConfig(1, 2, use_mh_instead_of_pg=True), 1, max_batch=128)
+        tr.check_consistency()
+        n_hosp[shuffled] = tr.tables["Hospital"].n_live
+    true_hospitals = len(set(dirty["ProviderNumber"]))  # incl. a few typo'd provider numbers
+    assert n_hosp[True] < 0.5 * n_hosp[False] and n_hosp[True] <= 2 * true_hospitals
