@@ -54,6 +54,15 @@ def reconstructed_pool_ids(lowered, trace, row_slice=None):
     return out
 
 
+def _pool_ids(index, values, unknown, missing):
+    """Pool id of every value (object array of str / None): `unknown` for strings outside the pool,
+    `missing` for None — looked up once per distinct value."""
+    import pandas as pd
+    codes, uniques = pd.factorize(values, use_na_sentinel=True)
+    table = np.array([index.get(u, unknown) for u in uniques] + [missing], dtype=np.int64)
+    return table[codes]  # code -1 (None) selects the last entry
+
+
 def accuracy_counts(lowered, trace, dirty, clean):
     """The five counters of evaluate_accuracy for the rows held by `trace`."""
     lw = lowered
@@ -63,25 +72,25 @@ def accuracy_counts(lowered, trace, dirty, clean):
     for col in clean:
         if col not in dirty:
             continue
-        d, c = dirty[col], clean[col]
-        dmiss = np.array([v is None for v in d[:n]])
-        ne = np.array([(x != y) for x, y in zip(d[:n], c[:n])])
+        d = np.asarray(dirty[col][:n], dtype=object)
+        c = np.asarray(clean[col][:n], dtype=object)
+        dmiss = np.equal(d, None)
+        ne = d != c  # element-wise Python comparison (None == None, None != any string)
         errors += int(np.sum(ne & ~dmiss))
         if col not in ours:
             continue
         if isinstance(ours[col], tuple):  # numeric column: compare numbers (Float64 == Int in the reference)
             o = ours[col][1]
-            dn = np.array([np.nan if v is None else float(v) for v in d[:n]])
-            cn = np.array([np.nan if v is None else float(v) for v in c[:n]])
+            dn = np.array([np.nan if v is None else float(v) for v in d])
+            cn = np.array([np.nan if v is None else float(v) for v in c])
             errors -= int(np.sum(ne & ~dmiss))
             errors += int(np.sum((dn != cn) & ~dmiss))
             ch = (~dmiss) & (o != dn)
             changed += int(np.sum(ch))
             cleaned += int(np.sum(ch & (o == cn)))
             continue
-        idx = lw.pool.index
-        d_id = np.array([idx.get(v, -3) if v is not None else -4 for v in d[:n]], dtype=np.int64)
-        c_id = np.array([idx.get(v, -5) if v is not None else -6 for v in c[:n]], dtype=np.int64)
+        d_id = _pool_ids(lw.pool.index, d, -3, -4)
+        c_id = _pool_ids(lw.pool.index, c, -5, -6)
         o = ours[col]
         cmiss = c_id == -6
         imputed += int(np.sum(dmiss & ~cmiss))
