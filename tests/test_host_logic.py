@@ -193,3 +193,36 @@ def test_shuffled_rows_keep_the_batched_init_from_spawning_duplicates(oracle):
         n_hosp[shuffled] = tr.tables["Hospital"].n_live
     true_hospitals = len(set(dirty["ProviderNumber"]))  # incl. a few typo'd provider numbers
     assert n_hosp[True] < 0.5 * n_hosp[False] and n_hosp[True] <= 2 * true_hospitals
+
+
+def test_rents_pipeline_on_cpu(oracle, tmp_path):
+    """rents (numeric Gaussian column, keyed atoms, missing cells) through the product's host code with the
+    oracle as engine: evaluate_accuracy's numeric comparison and save_results."""
+    import os
+
+    from oracle_engine import OracleEngine
+    from pclean_amd import experiments as ex
+    from pclean_amd.analysis import evaluate_accuracy, save_results
+    from pclean_amd.engine import InferenceConfig
+    from pclean_amd.inference import initialize_trace, run_inference
+    from pclean_amd.model import LoweredModel
+    from pclean_amd.trace import Trace
+    dirty, clean = ex.rents_data()
+    (dirty, clean), _ = ex.shuffle_rows([dirty, clean], 0)
+    dirty = {c: v[:800] for c, v in dirty.items()}
+    clean = {c: v[:800] for c, v in clean.items()}
+    m = ex.rents_model(dirty)
+    lw = LoweredModel(m, ex.rents_query(m), dirty)
+    obs = lw.encode_observations(dirty)
+    tr = Trace(lw, obs.shape[1], 0)
+    cfg = InferenceConfig(1, 2, use_mh_instead_of_pg=True, rejuv_frequency=500)
+    eng = OracleEngine(oracle, lw, obs)
+    initialize_trace(eng, tr, cfg, 0, max_batch=256)
+    run_inference(eng, tr, cfg, 0)
+    tr.check_consistency()
+    acc = evaluate_accuracy(lw, tr, dirty, clean)
+    n_missing = sum(v is None for c in ("State", "Room Type") for v in dirty[c])
+    assert acc["imputed"] == n_missing > 50 and acc["correctly_imputed"] > 0.3 * acc["imputed"]
+    assert acc["errors"] > 10 and 0.2 < acc["f1"] < 1.0
+    d = save_results(str(tmp_path), "rents", lw, tr, dirty, timestamp=False)
+    assert sorted(os.listdir(d)) == ["inferred_County.csv", "reconstructed_Obs.csv"]
