@@ -88,6 +88,8 @@ def accuracy_counts(lowered, trace, dirty, clean):
             ch = (~dmiss) & (o != dn)
             changed += int(np.sum(ch))
             cleaned += int(np.sum(ch & (o == cn)))
+            imputed += int(np.sum(dmiss & ~np.isnan(cn)))  # analysis.jl:52-60 counts numeric imputations too
+            imputed_ok += int(np.sum(dmiss & (o == cn)))
             continue
         d_id = _pool_ids(lw.pool.index, d, -3, -4)
         c_id = _pool_ids(lw.pool.index, c, -5, -6)

@@ -1,8 +1,9 @@
 """initialize_trace / run_inference! on the HIP path (src/inference/inference.jl:3-88).
 
 Schedule differences from the reference: rows are processed in batches
-against frozen tables and committed per batch / per class sweep; parameters are
-re-sampled once per class sweep instead of every `rejuv_frequency` rows.
+against frozen tables and committed per (sub-)batch; a class sweep is cut into sub-batches of
+max(rejuv_frequency, n / max_sub_batches) rows and the class's parameters are re-sampled between them
+(the reference: every `rejuv_frequency` rows, inference.jl:72-77).
 
   initialize_trace : SMC over the observed rows (inference.jl:20-37) in geometrically
                      growing batches; within a batch identical new-row proposals are merged.
@@ -51,6 +52,10 @@ def build_evidence(lw, trace, cname):
     sk = keys[order]
     ev_rows = order[(sk >= 0) & t.live[np.maximum(sk, 0)]].astype(np.int32)
     ev_ctx = None
+    n_sources = sum(1 for ct in lw.cross_terms if bi in (ct["ctx_block"], ct["local_block"])) \
+        + (cname in lw.latent_ev_prob) + (cname in getattr(lw, "latent_ev_locals", {}))
+    if n_sources > 1:  # each source would need its own ctx slot (PCLEAN_MAX_CTX); none of the three programs does
+        raise NotImplementedError(f"latent class {cname}: more than one per-evidence-row context source")
     for ct in lw.cross_terms:
         if ct["ctx_block"] == bi:      # this class sits on the ctx-argument side: ctx = the local argument's value
             ob, path = ct["local_block"], ct["local_path"]
@@ -177,7 +182,18 @@ def commit_latent(lw, trace, cname, live, chosen, vals):
     return changed
 
 
-def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None):
+def sub_batches(n, config, max_sub_batches):
+    """Row ranges of one class sweep between two parameter moves.  The reference resamples the class's
+    parameters and Pitman-Yor hyper-parameters every `rejuv_frequency` rows (inference.jl:72-77); the
+    batched schedule does it between sub-batches of max(rejuv_frequency, ceil(n / max_sub_batches)) rows —
+    exactly the reference's cadence whenever n / rejuv_frequency <= max_sub_batches."""
+    if n <= 0:
+        return []
+    size = max(int(config.rejuv_frequency), 1, -(-n // max(int(max_sub_batches), 1)))
+    return [(b, min(b + size, n)) for b in range(0, n, size)]
+
+
+def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_sub_batches=32, verbose=False):
     """One rejuvenation sweep of latent class cname.  With several ranks the live latent rows are
     block-partitioned: a rank scores its rows against their complete evidence sets (observations and
     trace are replicated), then (chosen particle, sampled values) are all-gathered and every rank
@@ -189,23 +205,31 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None):
     if len(live) == 0:
         return 0
     t = trace.tables[cname]
-    excl = np.full((len(pl["roots"]), len(live)), -1, dtype=np.int32)
-    for r, root in enumerate(pl["roots"]):
-        if pl["nodes"][root][0] == 0:
-            excl[r] = t.cols[lw.colidx[cname][pl["root_attr"][r]], live]
-    engine.upload_trace(trace)
-    lo, hi = shard_bounds(len(live), comm.rank, comm.world)
-    e0, e1 = int(ev_off[lo]), int(ev_off[hi])
-    chosen = np.zeros(0, np.int32)
-    vals = np.zeros((0, len(pl["nodes"])), np.int32)
-    if hi > lo:
-        chosen, vals = engine.sweep_latent(trace, cname, config, seed, sweep_idx, live[lo:hi], ev_off[lo:hi + 1] - e0,
-                                           ev_rows[e0:e1], None if ev_ctx is None else ev_ctx[e0:e1],
-                                           np.ascontiguousarray(excl[:, lo:hi]))
-    if comm.world > 1:
-        chosen = comm.allgather_varlen_i32(chosen)
-        vals = comm.allgather_varlen_i32(vals).reshape(-1, len(pl["nodes"]))
-    return commit_latent(lw, trace, cname, live, chosen, vals)
+    changed = 0
+    for bn, (b0, b1) in enumerate(sub_batches(len(live), config, max_sub_batches)):
+        if bn:  # inference.jl:72-77: this class's parameters and Pitman-Yor hyper-parameters
+            resample_class_parameters(trace, cname)
+            if verbose and (b0 // max(config.reporting_frequency, 1)) != ((b0 - 1) // max(config.reporting_frequency, 1)):
+                print(f"{cname}: Cleaning row {b0} of {len(live)}", flush=True)
+        excl = np.full((len(pl["roots"]), b1 - b0), -1, dtype=np.int32)
+        for r, root in enumerate(pl["roots"]):
+            if pl["nodes"][root][0] == 0:
+                excl[r] = t.cols[lw.colidx[cname][pl["root_attr"][r]], live[b0:b1]]
+        engine.upload_trace(trace)
+        lo, hi = shard_bounds(b1 - b0, comm.rank, comm.world)
+        lo, hi = lo + b0, hi + b0
+        e0, e1 = int(ev_off[lo]), int(ev_off[hi])
+        chosen = np.zeros(0, np.int32)
+        vals = np.zeros((0, len(pl["nodes"])), np.int32)
+        if hi > lo:
+            chosen, vals = engine.sweep_latent(trace, cname, config, seed, sweep_idx, live[lo:hi], ev_off[lo:hi + 1] - e0,
+                                               ev_rows[e0:e1], None if ev_ctx is None else ev_ctx[e0:e1],
+                                               np.ascontiguousarray(excl[:, lo - b0:hi - b0]))
+        if comm.world > 1:
+            chosen = comm.allgather_varlen_i32(chosen)
+            vals = comm.allgather_varlen_i32(vals).reshape(-1, len(pl["nodes"]))
+        changed += commit_latent(lw, trace, cname, live[b0:b1], chosen, vals)
+    return changed
 
 
 # ---------------------------------------------------------------------------
@@ -221,25 +245,43 @@ def _gather_locals(trace, comm, begin, n_local, lo):
     trace.pending_locals = {}
 
 
-def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None):
-    """One rejuvenation sweep of the observed class; rows block-partitioned over the ranks."""
+def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None, max_sub_batches=32, verbose=False):
+    """One rejuvenation sweep of the observed class; the rows of every sub-batch are block-partitioned over
+    the ranks, the class's parameters are resampled between sub-batches (inference.jl:72-77)."""
     comm = comm or Comm()
     n = trace.cur.shape[1]
-    lo, hi = shard_bounds(n, comm.rank, comm.world)
-    engine.upload_trace(trace)
-    choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi, reuse_buffers=True)
-    stats = engine.sweep_stats(trace)
-    moved = engine.sweep_moved() if hasattr(engine, "sweep_moved") else None
-    _gather_locals(trace, comm, 0, hi - lo, lo)
-    return exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True, moved_local=moved)
+    changed = 0
+    for bn, (b0, b1) in enumerate(sub_batches(n, config, max_sub_batches)):
+        if bn:
+            resample_class_parameters(trace, engine.lw.query.cls)
+            if verbose and (b0 // max(config.reporting_frequency, 1)) != ((b0 - 1) // max(config.reporting_frequency, 1)):
+                print(f"{engine.lw.query.cls}: Cleaning row {b0} of {n}", flush=True)
+        lo, hi = shard_bounds(b1 - b0, comm.rank, comm.world)
+        lo, hi = lo + b0, hi + b0
+        engine.upload_trace(trace)
+        choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi, reuse_buffers=True)
+        stats = engine.sweep_stats(trace)
+        moved = engine.sweep_moved() if hasattr(engine, "sweep_moved") else None
+        _gather_locals(trace, comm, b0, hi - lo, lo)
+        changed += exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True,
+                                       moved_local=moved)
+    return changed
 
 
 def resample_parameters(trace):
-    """resample_value! for every learned parameter + Pitman–Yor hyper-parameters
-    (inference.jl:72-77; distributions.jl:57-61; trace.jl:80-108)."""
+    """resample_value! for every learned parameter + Pitman–Yor hyper-parameters of every class
+    (initialize_trace's move, inference.jl:40-47; distributions.jl:57-61; trace.jl:80-108)."""
     trace.resample_parameters()
     for t in trace.tables.values():
         trace.resample_py_params(t)
+
+
+def resample_class_parameters(trace, cname):
+    """pgibbs_sweep!'s move (inference.jl:72-77): only the swept class's parameters and its table's
+    Pitman–Yor hyper-parameters."""
+    trace.resample_parameters(cname)
+    if cname in trace.tables:
+        trace.resample_py_params(trace.tables[cname])
 
 
 def initialize_trace(engine, trace, config, seed, max_batch=256, comm=None):
@@ -280,19 +322,24 @@ def initialize_trace(engine, trace, config, seed, max_batch=256, comm=None):
     return trace
 
 
-def run_inference(engine, trace, config, seed, verbose=False, comm=None):
+def run_inference(engine, trace, config, seed, verbose=False, comm=None, max_sub_batches=32):
     """run_inference! (inference.jl:83-88): config.num_iters sweeps over all classes.  `comm` shards
-    every class sweep over the ranks of a torch.distributed job (one process per GPU)."""
+    every class sweep over the ranks of a torch.distributed job (one process per GPU).  A class sweep is
+    cut into sub-batches between which the class's parameters are resampled (`sub_batches`): at most
+    max_sub_batches per class, so tables with n / rejuv_frequency <= max_sub_batches follow the reference's
+    cadence exactly.  use_lo_sweeps is, as in the reference, only read by instrumented_inference.jl (out of
+    scope): pgibbs_sweep! sweeps the latent classes regardless of it."""
     lw = engine.lw
     for it in range(config.num_iters):
+        if verbose:
+            print(f"Iteration {it + 1}/{config.num_iters}", flush=True)
         for cname in lw.model.class_order:
             if cname in lw.latent_plans:
-                ch = latent_sweep(engine, trace, cname, config, seed, it, comm)
+                ch = latent_sweep(engine, trace, cname, config, seed, it, comm, max_sub_batches, verbose)
             elif cname == lw.query.cls:
-                ch = observed_sweep(engine, trace, config, seed, it, comm)
+                ch = observed_sweep(engine, trace, config, seed, it, comm, max_sub_batches, verbose)
             else:
                 continue
-            resample_parameters(trace)
             if verbose:
                 print(f"iteration {it + 1}/{config.num_iters} {cname}: {ch} changes", flush=True)
                 trace.check_consistency()

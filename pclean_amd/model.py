@@ -662,6 +662,18 @@ class LoweredModel:
             raise NotImplementedError("TransformedGaussian mean must be an IndexedLookup")
         unit_attr = ocls.attr(g.dist.unit)
         units = unit_attr.dist.options
+        for u in units:
+            # The kernels evaluate backward(x) as x * backward(1) and log|deriv| as a constant
+            # (transformed_gaussian.jl:15-16 evaluates both per observation): only linear units qualify.
+            probes = (0.5, 2.0, -3.0, 1267.0)
+            b1 = float(u.backward(1.0))
+            d1 = float(u.deriv(b1))
+            lin = abs(float(u.backward(0.0))) <= 1e-12 and all(
+                abs(float(u.backward(x)) - x * b1) <= 1e-9 * max(1.0, abs(x * b1)) and
+                abs(float(u.deriv(u.backward(x))) - d1) <= 1e-9 * max(1.0, abs(d1)) for x in probes)
+            if not lin:
+                raise NotImplementedError("TransformedGaussian: only linear Transformations (backward(x) = c*x) are "
+                                          "supported by the HIP path")
         locs = []  # own enumerated choices: index arguments that are own attrs, plus the unit
         dims = []  # (kind, payload, n_values)
         for arg in look.args:

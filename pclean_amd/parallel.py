@@ -160,9 +160,20 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
         g_vals = np.concatenate(g_vals)
         order = np.argsort(g_rows, kind="stable")  # identical order on every rank -> identical row ids
         g_rows = g_rows[order]
-        new_ids = trace.materialise_bulk(bi, g_vals[order])
+        g_vals = g_vals[order]
+        if len(g_rows):
+            # identical new-row proposals of one sweep become ONE latent row (as commit_batch does for the
+            # initialisation): in the sequential reference the second row would have joined the first row's
+            # new referent instead of creating a duplicate entity.  Rows are created in order of first occurrence.
+            u, first, inv = np.unique(g_vals, axis=0, return_index=True, return_inverse=True)
+            uo = np.argsort(first, kind="stable")
+            rank = np.empty(len(uo), dtype=np.int64)
+            rank[uo] = np.arange(len(uo))
+            new_ids = trace.materialise_bulk(bi, u[uo])[rank[np.asarray(inv).reshape(-1)]]
+        else:
+            new_ids = np.empty(0, dtype=np.int64)
         t = trace.tables[cname]
-        t.counts[new_ids] += 1  # each new row is referred to by its creator
+        np.add.at(t.counts, new_ids, 1)  # each new row is referred to by its creator(s)
         t.counts[:n_before[bi]] += delta
 
         def resolve(rows_global, ch):

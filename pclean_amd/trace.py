@@ -435,12 +435,15 @@ class Trace:
             self.delete_rows_bulk(cname, cand[(t.counts[cand] == 0) & t.live[cand]])
 
     # -- parameter moves (inference.jl:72-77 -> resample_value!) ----------------
-    def resample_parameters(self):
-        for p in self.params.values():
-            p.resample(self.rng)
-        if self.prob_param is not None:
+    def resample_parameters(self, cname=None):
+        """resample_value! of every learned parameter (cname=None: initialize_trace, inference.jl:40-47) or
+        of the parameters declared in class cname (pgibbs_sweep!, inference.jl:72-77)."""
+        for (c, _), p in self.params.items():
+            if cname is None or c == cname:
+                p.resample(self.rng)
+        if self.prob_param is not None and (cname is None or self.lw.prob_spec["param"][0] == cname):
             self.resample_prob_param()
-        if self.mean_param is not None:
+        if self.mean_param is not None and (cname is None or self.lw.gauss_spec["param"][0] == cname):
             _, idx, x = self.gaussian_index()
             self.mean_param.resample(self.rng, idx, x)
 

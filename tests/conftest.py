@@ -12,6 +12,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box via gpurun)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`pytest tests` on a machine without a gfx950 device: GPU tests are reported as skipped, not failed
+    (there is no CPU fallback to run them on).  PCLEAN_REQUIRE_GPU=1 keeps them loud."""
+    if os.environ.get("PCLEAN_REQUIRE_GPU") == "1":
+        return
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no gfx950 device (pclean_amd has no CPU fallback)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU oracle (test infrastructure) — built on demand with g++."""
@@ -24,8 +38,16 @@ def oracle():
 @pytest.fixture(scope="session")
 def hip():
     """One HIP context on cuda:0; fails loudly when the extension or GPU is missing."""
-    from pclean_amd import HipContext
-    ctx = HipContext(0)
+    from pclean_amd import HipContext, PCleanHipError
+    try:
+        ctx = HipContext(0)
+    except PCleanHipError:
+        # CPU-only CI: a missing device is not a regression.  On a GPU box (PCLEAN_REQUIRE_GPU=1, or torch sees a
+        # device) the error stays loud.
+        import torch
+        if os.environ.get("PCLEAN_REQUIRE_GPU") == "1" or torch.cuda.is_available():
+            raise
+        pytest.skip("no gfx950 device")
     yield ctx
     ctx.close()
 

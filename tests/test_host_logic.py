@@ -226,3 +226,23 @@ def test_rents_pipeline_on_cpu(oracle, tmp_path):
     assert acc["errors"] > 10 and 0.2 < acc["f1"] < 1.0
     d = save_results(str(tmp_path), "rents", lw, tr, dirty, timestamp=False)
     assert sorted(os.listdir(d)) == ["inferred_County.csv", "reconstructed_Obs.csv"]
+
+
+def test_pitman_yor_score_lgamma_form_matches_oracle_direct_form(oracle):
+    """trace.pitman_yor_score (O(K), lgamma form) against the oracle's literal loop over every customer
+    (trace.jl:65-78) on random count vectors and hyper-parameters."""
+    import numpy as np
+
+    from pclean_amd.trace import Trace
+    rng = np.random.default_rng(5)
+    for _ in range(60):
+        k = int(rng.integers(1, 40))
+        counts = rng.integers(1, 200, size=k).astype(np.int64)
+        if rng.random() < 0.3:
+            counts[rng.integers(0, k)] = 1
+        s, d = float(rng.gamma(1.0, 1.0)) + 1e-3, float(rng.random()) * 0.999
+        if rng.random() < 0.2:
+            d = 0.0
+        got = Trace.pitman_yor_score(s, d, counts)
+        want = oracle.pitman_yor_score(s, d, counts)
+        assert abs(got - want) <= 1e-9 * max(1.0, abs(want)), (s, d, counts, got, want)
