@@ -2,21 +2,31 @@
 """bench.py — rows/sec per Gibbs sweep of the observed class on the synthetic
 hospital-shaped table (BASELINE.json metric).
 
-A "step" is one batched rejuvenation sweep of the Record class over all rows
-(strong scaling: the 1M-row table is block-partitioned over the ranks), i.e.
-upload of the replicated latent tables, the HIP sweep (proposal scoring, draws,
-particle weights, final choice), the exchange of the CRP sufficient statistics
-(all-reduce, RCCL for N>1) and of new-row records, and the host commit.
+Pipeline of one run (every rank; rows in random order, experiments.shuffle_rows):
+  1. synthetic table -> model -> pair tables on the GPU (timed: `table_build`, DP cells/s);
+  2. the build's OWN `initialize_trace` from an empty trace (timed: `config.init_s`, F1 after it);
+  3. ONE full `run_inference` iteration over every class (latent classes + observed class; timed:
+     `config.full_iteration_ms`);
+  4. the timed region: W warmup + K "steps".  A step is one batched rejuvenation sweep of the Record class
+     over all rows (strong scaling: the 1M-row table is block-partitioned over the ranks) through the
+     product's own `inference.observed_sweep` with one sub-batch: upload of the replicated latent tables,
+     the HIP sweep (proposal scoring, draws, particle weights, final choice), the exchange of the CRP
+     sufficient statistics (all-reduce, RCCL for N>1) and of new-row records / moved rows, the host commit;
+  5. one extra, untimed sweep with the library's per-phase HIP-event profile on (`phases_ms`).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with
-`roofline` (dominant kernel = block-0 root enumeration, HIP-event timed on the
-library's stream) and `cpu_baseline` (the CPU oracle's sequential-schedule sweep
-on a bounded sample of the same workload, single thread).
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = block 0's
+root scan, HIP-event timed on the library's stream; algorithmic bytes = what THIS algorithm has to move, see
+`roofline_model`) and `cpu_baseline` (the CPU oracle's sequential-schedule sweep on a bounded sample of the
+same workload, single thread).
+
+`python bench.py --gpus N` without a torchrun environment re-launches itself under
+`python -m torch.distributed.run --nproc-per-node N` (one rank per GPU).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,30 +44,16 @@ def build_workload(n_rows, n_hosp, seed):
     from pclean_amd import experiments as ex
     from pclean_amd.model import LoweredModel
     from pclean_amd.synth import synth_hospital
-    from pclean_amd.trace import Trace
     t0 = time.time()
     dirty, clean, latent = synth_hospital(n_rows, n_hosp, seed)
+    (dirty, clean), _ = ex.shuffle_rows([dirty, clean], seed)  # the generator emits a hospital's records consecutively
     poss = ex.possibilities_of(dirty)
     m = ex.hospital_model(poss)
     q = ex.hospital_query(m)
     lw = LoweredModel(m, q, dirty)
     obs = lw.encode_observations(dirty)
-    # initial latent state = the generator's ground-truth entities (initialize_trace at this
-    # scale is SURVEY §8f work); clean values that never occur undamaged fall back to the dirty cell
-    by_path = [{}, {}]
-    ocls = m.classes[q.cls]
-    for col, ref in q.cleanmap.items():
-        if "." not in ref:
-            continue
-        head, rest = ref.split(".", 1)
-        bi = 0 if head == "hosp" else 1
-        cname, attr = m.resolve(ocls.attr(head).target, rest)
-        dom = lw.latent_dom[(cname, attr.name)]
-        by_path[bi][rest] = [c if dom.get(c) >= 0 else d for c, d in zip(clean[col], dirty[col])]
-    tr = Trace.from_clean_values(lw, by_path, n_rows, seed)
-    log(f"[bench] workload built in {time.time() - t0:.1f}s: rows={n_rows} "
-        + " ".join(f"{c}={t.n}" for c, t in tr.tables.items()))
-    return dirty, clean, lw, obs, tr
+    log(f"[bench] workload built in {time.time() - t0:.1f}s: rows={n_rows}")
+    return dirty, clean, lw, obs
 
 
 def oracle_world_for_rows(orc, lw, obs_local, tr, eng, rows):
@@ -95,21 +91,46 @@ def oracle_world_for_rows(orc, lw, obs_local, tr, eng, rows):
 
 
 def hbm_traffic(args, world):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/collect.sh ->
-    profiles/hbm_traffic.json); only valid for the configuration it was measured on."""
+    """HBM bytes per launch of the dominant kernel from this round's committed PMC passes (profiles/collect.sh ->
+    profiles/hbm_traffic.json: rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc runs of
+    this same command); only valid for the configuration it was measured on, otherwise null.  Counters cannot be
+    read from inside the process, so this figure is NOT measured in the run that prints it."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         d = json.load(open(path))
         if d.get("rows") != args.rows or d.get("hospitals") != args.hospitals or d.get("particles") != args.particles \
-                or world != 1:
-            return None
-        return float(d["bytes_per_launch"])
+                or world != 1 or d.get("kernel") != "fk_root_wave_kernel":
+            return None, None
+        return float(d["bytes_per_launch"]), d.get("source")
     except Exception:
+        return None, None
+
+
+def roofline_model(rs, obs_local, particles):
+    """Algorithmic bytes of ONE launch of the root scan as implemented (root_wave.hip), each byte counted once:
+      * the byte rows comp_f[o][.] of the pre-filter terms: one row of kpad bytes per DISTINCT observed value
+        among the swept rows (groups of one referent run back to back and re-read them from L2);
+      * group descriptors: 112 B written by group_desc_kernel and read by the scan, per group;
+      * per group: the representative's observed ids (4 B x terms), grp_off / members (4 B per item + 4 B per
+        group), the current referent (4 B per item);
+      * exact scoring of the survivors: >= 1 candidate per group x terms x (1 B distance + 1 B length) + 8 B prior;
+      * outputs: 4 B per (row, particle) draw, 8 B log-marginal and 4 B overflow flag per row.
+    The §8(d) figure of SURVEY.md (every candidate of every row gathered, 920 296 B/row) is reported beside it
+    as `enumeration_equivalent`: the kernel provably skips almost all of that work."""
+    if not rs.fast:
         return None
+    rows_bytes = 0
+    for p in range(rs.n_pre):
+        col = rs.pre_obs_col[p]
+        if col >= 0:
+            rows_bytes += int(np.unique(obs_local[col]).size) * rs.kpad
+    per_group = 2 * 112 + 4 * rs.n_terms + 4 + rs.n_terms * 2 + 8
+    per_item = 4 + 4 + 4 * rs.n_draws + 8 + 4
+    return float(rows_bytes + rs.n_groups * per_group + rs.n_items * per_item)
 
 
-def cpu_baseline(lw, obs_local, tr, eng, cfg, seed, target_seconds):
-    """Oracle, sequential schedule, single thread, on a prefix sample of the rows."""
+def cpu_baseline(lw, obs, tr, eng, cfg, seed, min_rows, target_seconds):
+    """Oracle, sequential schedule, single thread, on a prefix sample of the (shuffled) rows."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle as orc
@@ -118,7 +139,7 @@ def cpu_baseline(lw, obs_local, tr, eng, cfg, seed, target_seconds):
     eng.upload_trace(tr)  # the tables the oracle copies are the ones currently in the trace
 
     def run(n_sample):
-        w, py = oracle_world_for_rows(orc, lw, obs_local, tr, eng, np.arange(n_sample))
+        w, py = oracle_world_for_rows(orc, lw, obs, tr, eng, np.arange(n_sample))
         cur = np.ascontiguousarray(tr.cur[:, :n_sample].copy())
         c = InferConfig(1, cfg.num_particles, 1, 1, int(cfg.use_mh_instead_of_pg), 50, 100)
         moved, new = C.c_int64(), C.c_int64()
@@ -127,15 +148,25 @@ def cpu_baseline(lw, obs_local, tr, eng, cfg, seed, target_seconds):
                                        orc._p(cur, C.c_int32), orc._p(py, C.c_double), C.byref(moved), C.byref(new))
         return time.perf_counter() - t0
 
-    n_total = obs_local.shape[1]
+    n_total = obs.shape[1]
     probe = min(64, n_total)
     t_probe = run(probe)
-    n_sample = int(min(n_total, max(probe, target_seconds / max(t_probe / probe, 1e-9))))
+    n_sample = int(min(n_total, max(probe, min_rows, target_seconds / max(t_probe / probe, 1e-9))))
     t = run(n_sample) if n_sample > probe else t_probe
     return dict(value=n_sample / t, unit="rows/s/sweep", cores=1, kind="port",
-                sample=f"first {n_sample} rows of the same synthetic table, 1 sequential-schedule sweep of Record, "
-                       f"{t:.1f}s, single thread of {os.cpu_count()} host cores; CPU restatement (oracle/), "
-                       "not the Julia reference")
+                sample=f"first {n_sample} rows of the same (shuffled) synthetic table against the full latent state, "
+                       f"1 sequential-schedule sweep of Record, {t:.1f}s, single thread of {os.cpu_count()} host cores; "
+                       "CPU restatement (oracle/), not the Julia reference")
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torchrun: one rank per GPU through torch.distributed.run."""
+    port = int(os.environ.get("MASTER_PORT", "29533"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("[bench] spawning:", " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -147,22 +178,29 @@ def main():
     ap.add_argument("--hospitals", type=int, default=10_000)
     ap.add_argument("--particles", type=int, default=20)
     ap.add_argument("--seed", type=int, default=20250926)
+    ap.add_argument("--init-batch", type=int, default=32768, help="largest batch of the batched initialize_trace")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-rows", type=int, default=10_000, help="minimum rows of the CPU baseline sample (SURVEY §8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--emulate-shard-of", type=int, default=0,
-                    help="diagnostic, single process: sweep only the first 1/G of the rows (what one rank of a "
-                         "G-GPU job does, without the collectives) and report the step time on stderr; no JSON")
+    ap.add_argument("--no-full-iteration", action="store_true")
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.gpus != world:
+        log(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s), reported as n_gpus={world}")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import torch
     from pclean_amd import _lib
     from pclean_amd.analysis import accuracy_counts, f1_from_counts
     from pclean_amd.engine import Engine, InferenceConfig
-    from pclean_amd.parallel import Comm, exchange_and_commit, shard_bounds
+    from pclean_amd.inference import initialize_trace, observed_sweep, run_inference
+    from pclean_amd.parallel import Comm, shard_bounds
+    from pclean_amd.trace import Trace
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible and pclean_amd has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -173,104 +211,111 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     comm = Comm(device=f"cuda:{local_rank}")
 
-    dirty, clean, lw, obs, tr = build_workload(args.rows, args.hospitals, args.seed)
-    lo, hi = shard_bounds(args.rows, rank, world)
-    if args.emulate_shard_of > 1 and world == 1:
-        lo, hi = shard_bounds(args.rows, 0, args.emulate_shard_of)
-    obs_local = np.ascontiguousarray(obs[:, lo:hi])
-    tr.cur = np.ascontiguousarray(tr.cur[:, lo:hi])
+    dirty, clean, lw, obs = build_workload(args.rows, args.hospitals, args.seed)
     t0 = time.time()
-    eng = Engine(lw, obs_local, device=local_rank, dist_mode=_lib.DIST_OSA, row_offset=lo)
-    log(f"[bench] rank {rank}: pair tables + static upload in {time.time() - t0:.1f}s "
-        f"({len(lw.pair_id)} tables, {sum(len(o) * len(l) for _, o, l in lw.pair_id.values()) / 1e9:.2f} G pairs)")
+    # every rank holds all observation columns (60 MB) and the whole trace: latent-class sweeps and the
+    # initialisation need every referring row; the observed-class sweep is sharded by rows
+    eng = Engine(lw, obs, device=local_rank, dist_mode=_lib.DIST_OSA)
+    static_s = time.time() - t0
+    log(f"[bench] rank {rank}: pair tables {eng.pair_build_s:.1f}s ({len(lw.pair_id)} tables, {eng.pair_count / 1e9:.2f} G pairs, "
+        f"{eng.pair_cells / 1e12:.2f} T DP cells), static upload total {static_s:.1f}s")
+
+    def f1_now(tr):
+        return f1_from_counts(accuracy_counts(lw, tr, dirty, clean))  # replicated trace: same counts on every rank
+
+    # ---- the build's own initialisation + one full iteration ---------------------------------------------------
+    cfg1 = InferenceConfig(1, args.particles)
+    tr = Trace(lw, args.rows, args.seed)
+    t0 = time.time()
+    initialize_trace(eng, tr, cfg1, args.seed, max_batch=args.init_batch, comm=comm)
+    torch.cuda.synchronize()
+    init_s = time.time() - t0
+    acc_init = f1_now(tr)
+    log(f"[bench] initialize_trace {init_s:.1f}s: F1 {acc_init['f1']:.4f} " + " ".join(f"{c}={t.n_live}" for c, t in tr.tables.items()))
+    full_ms = None
+    if not args.no_full_iteration:
+        t0 = time.time()
+        run_inference(eng, tr, cfg1, args.seed, comm=comm)
+        torch.cuda.synchronize()
+        full_ms = 1e3 * (time.time() - t0)
+        log(f"[bench] one full run_inference iteration (every class): {full_ms:.0f} ms "
+            + " ".join(f"{c}={t.n_live}" for c, t in tr.tables.items()))
+
+    # ---- timed region: observed-class sweeps through the product path ------------------------------------------
     cfg = InferenceConfig(args.warmup + args.steps, args.particles)
 
     def step(idx):
-        t_a = time.perf_counter()
-        eng.upload_trace(tr)
-        t_b = time.perf_counter()
-        choice, chosen, logml, new_rows = eng.sweep(tr, cfg, args.seed, idx, reuse_buffers=True)
-        t_c = time.perf_counter()
-        stats = eng.sweep_stats(tr)
-        moved = eng.sweep_moved()
-        tm = eng.hip.get_timing()
-        t_d = time.perf_counter()
-        if os.environ.get("PCLEAN_BENCH_DEBUG"):
-            log("[bench] moved per block", (choice != tr.cur).sum(axis=1), "new per block", (choice < 0).sum(axis=1),
-                "chosen particle hist", np.bincount(chosen, minlength=cfg.num_particles)[:6])
-        if os.environ.get("PCLEAN_BENCH_PROFILE") and idx == args.warmup + args.steps - 1:
-            import cProfile
-            import pstats
-            pr = cProfile.Profile()
-            pr.enable()
-            changed = exchange_and_commit(tr, lw, comm, lo, choice, stats, new_rows, moved_local=moved)
-            pr.disable()
-            pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(12)
-        else:
-            changed = exchange_and_commit(tr, lw, comm, lo, choice, stats, new_rows, moved_local=moved)
-        t_e = time.perf_counter()
-        if os.environ.get("PCLEAN_BENCH_DEBUG"):
-            log(f"[bench] host phases ms: upload {1e3 * (t_b - t_a):.2f} sweep call {1e3 * (t_c - t_b):.2f} "
-                f"(device span {tm.total_ms:.2f}) stats {1e3 * (t_d - t_c):.2f} exchange+commit {1e3 * (t_e - t_d):.2f}")
-        return tm, changed
+        return observed_sweep(eng, tr, cfg, args.seed, 1 + idx, comm, max_sub_batches=1), eng.hip.get_timing()
 
     for i in range(args.warmup):
-        tm, changed = step(i)
-        log(f"[bench] warmup sweep {i}: device {tm.total_ms:.1f} ms, hot kernel {tm.hot_kernel_ms:.1f} ms, "
+        changed, tm = step(i)
+        log(f"[bench] warmup sweep {i}: device {tm.total_ms:.2f} ms, root scan {tm.hot_kernel_ms:.2f} ms, "
             f"{changed} referents changed, {tm.reserved} items re-run by the generic kernel")
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    hot_ms, hot_launches, alg_bytes, dev_ms = 0.0, 0, 0.0, 0.0
+    hot_ms, hot_launches, enum_bytes, dev_ms = 0.0, 0, 0.0, 0.0
     for i in range(args.steps):
-        tm, changed = step(args.warmup + i)
+        changed, tm = step(args.warmup + i)
         hot_ms += tm.hot_kernel_ms
         hot_launches += tm.hot_kernel_launches
-        alg_bytes += tm.hot_kernel_alg_bytes
+        enum_bytes += tm.hot_kernel_alg_bytes
         dev_ms += tm.total_ms
     torch.cuda.synchronize()
     comm.barrier()
     elapsed = comm.max_float(time.perf_counter() - t0)
+    rs = eng.hip.get_root_stats()
+    lo, hi = shard_bounds(args.rows, rank, world)
+    alg_bytes = roofline_model(rs, obs[:, lo:hi], cfg.num_particles)
 
-    if args.emulate_shard_of > 1 and world == 1:
-        log(f"[bench] emulated rank 0 of {args.emulate_shard_of}: {hi - lo} rows, {1e3 * elapsed / args.steps:.2f} ms per step "
-            f"(device span {dev_ms / args.steps:.2f} ms, root kernel {hot_ms / max(hot_launches, 1):.2f} ms), no collectives")
-        eng.close()
-        return
-    cnt = accuracy_counts(lw, tr, {c: v[lo:hi] for c, v in dirty.items()}, {c: v[lo:hi] for c, v in clean.items()})
-    cnt = comm.allreduce_sum_i64(cnt)
-    acc = f1_from_counts(cnt)
+    # ---- per-phase profile of one more (untimed) sweep ----------------------------------------------------------
+    eng.hip.set_profiling(True)
+    step(args.warmup + args.steps)
+    phases = eng.hip.get_profile()
+    eng.hip.set_profiling(False)
+    acc = f1_now(tr)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.rows * args.steps / elapsed
-        K = tr.tables["Hospital"].n
-        per_launch_bytes = alg_bytes / max(hot_launches, 1)
         per_launch_s = 1e-3 * hot_ms / max(hot_launches, 1)
-        achieved = per_launch_bytes / per_launch_s / 1e9 if per_launch_s > 0 else 0.0
+        achieved = (alg_bytes / per_launch_s / 1e9) if (alg_bytes and per_launch_s > 0) else None
+        traffic, traffic_src = hbm_traffic(args, world)
         out = {
             "metric": "rows/sec per Gibbs sweep on 1M-row synthetic hospital; F1 vs ground truth",
             "value": value, "unit": "rows/s/sweep", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic hospital x{args.rows // 1000}: {args.rows} dirty rows, "
-                                   f"{args.hospitals} latent hospitals, Record class, PG n_particles={args.particles}, "
-                                   "2 blocks, batched schedule", "rows": args.rows, "latent_hospitals": int(K),
-                       "particles": args.particles, "parallelism": f"rows sharded over {world} GPU(s)",
-                       "init": "ground-truth entities", "device_ms_per_step": dev_ms / args.steps},
+            "config": {"workload": f"synthetic hospital x{args.rows // 1000}: {args.rows} dirty rows (random order), "
+                                   f"{args.hospitals} true hospitals, Record class, PG n_particles={args.particles}, "
+                                   "2 blocks, batched schedule, one sub-batch per sweep", "rows": args.rows,
+                       "latent_hospitals": int(tr.tables["Hospital"].n_live), "particles": args.particles,
+                       "parallelism": f"rows sharded over {world} GPU(s)",
+                       "init": f"the build's own initialize_trace from an empty trace (batches <= {args.init_batch})"
+                               + ("" if args.no_full_iteration else " + 1 full run_inference iteration"),
+                       "init_s": init_s, "f1_after_init": acc_init["f1"], "full_iteration_ms": full_ms,
+                       "device_ms_per_step": dev_ms / args.steps},
             "f1": acc["f1"], "accuracy": acc,
+            "table_build": {"seconds": eng.pair_build_s, "pairs": eng.pair_count, "dp_cells": eng.pair_cells,
+                            "dp_cells_per_s": eng.pair_cells / max(eng.pair_build_s, 1e-9), "distance": "OSA (restricted DL)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": hbm_traffic(args, world),
-                         "kernel": "fk_root_fast_kernel<12> (block 0 root: rows x candidate hospitals)",
-                         "alg_bytes_per_launch": per_launch_bytes, "avg_launch_ms": 1e3 * per_launch_s,
-                         "note": "achieved = SURVEY §8d algorithmic bytes (full enumeration, 920 296 B/row) / HIP-event "
-                                 "kernel time of this rank. The kernel skips most of that work exactly (integer "
-                                 "pre-filter, one workgroup per distinct row tuple), so frac > 1 is expected; "
-                                 "traffic = measured HBM bytes per launch (rocprofv3 FETCH_SIZE x2 gfx950 correction "
-                                 "+ WRITE_SIZE, profiles/hbm_traffic.json), DESIGN.md §5"},
+                         "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         "kernel": "group_desc_kernel + fk_root_wave_kernel<12> (block 0 root: rows x candidate hospitals)",
+                         "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": 1e3 * per_launch_s,
+                         "groups": rs.n_groups, "items": rs.n_items, "kpad": rs.kpad, "overflow_items": rs.overflow_items,
+                         "enumeration_equivalent": {"bytes_per_launch": enum_bytes / max(hot_launches, 1),
+                                                    "GBps": enum_bytes / max(hot_launches, 1) / max(per_launch_s, 1e-12) / 1e9,
+                                                    "note": "SURVEY §8d full-enumeration bytes (920 296 B/row) / kernel time: "
+                                                            "work the kernel provably skips, not a bandwidth claim"},
+                         "note": "achieved = bytes the implemented algorithm has to move once (bench.roofline_model: distinct "
+                                 "pre-filter byte rows + descriptors + ids + outputs) / HIP-event time of the launch pair on "
+                                 "the library's stream; traffic = HBM bytes per launch from this round's rocprofv3 PMC passes "
+                                 "(profiles/), not measured in this run"},
+            "phases_ms": {k: {"ms": round(v[0], 4), "intervals": v[1]} for k, v in sorted(phases.items(), key=lambda kv: -kv[1][0])},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(lw, obs_local, tr, eng, cfg, args.seed, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(lw, obs, tr, eng, cfg, args.seed, args.cpu_rows, args.cpu_seconds)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         json_line = json.dumps(out)
     eng.close()

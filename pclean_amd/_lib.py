@@ -57,6 +57,12 @@ class Timing(C.Structure):
                 ("reserved", C.c_int32), ("hot_kernel_alg_bytes", C.c_double)]
 
 
+class RootStats(C.Structure):
+    _fields_ = [("fast", C.c_int32), ("n_items", C.c_int32), ("n_groups", C.c_int32), ("n_cand", C.c_int32),
+                ("kpad", C.c_int32), ("n_terms", C.c_int32), ("n_pre", C.c_int32), ("n_draws", C.c_int32),
+                ("pre_obs_col", C.c_int32 * 3), ("overflow_items", C.c_int32)]
+
+
 TERM_DTYPE = np.dtype([("obs_col", "<i4"), ("cand_col", "<i4"), ("pair_table", "<i4"), ("dens_kind", "<i4"),
                        ("max_typos", "<i4"), ("ctx_slot", "<i4"), ("fn_table", "<i4"), ("ctx_mode", "<i4")])
 NODE_DTYPE = np.dtype([("kind", "<i4"), ("table", "<i4"), ("term_begin", "<i4"), ("n_terms", "<i4"),
@@ -372,22 +378,43 @@ class HipContext:
             self._io = {"key": key, "arrays": arrays}
         return self._io["arrays"]
 
-    def sweep(self, cfg, seed, sweep_idx, cur, reuse_buffers=False):
-        """cur [n_blocks][n_rows] -> (choice, chosen particle, log marginal likelihood).  With
-        reuse_buffers the I/O goes through page-locked buffers owned by the context: the returned arrays
-        are then views that the next sweep of the same shape overwrites."""
-        n_blocks, n_rows = np.shape(cur)
-        if reuse_buffers:
-            cur_buf, choice, chosen, logml = self._io_buffers(n_blocks, n_rows)
-            np.copyto(cur_buf, cur)
-            cur = cur_buf
+    def sweep(self, cfg, seed, sweep_idx, cur, reuse_buffers=False, window=None, light=False):
+        """cur [n_blocks][n_rows] -> (choice, chosen particle, log marginal likelihood).
+        window=(lo, hi): cur is the array over ALL rows; rows [lo, hi) are passed in place (no copy) through
+        pclean_set_cur_stride — with reuse_buffers the whole array is page-locked once.
+        reuse_buffers: outputs go through page-locked buffers owned by the context (views that the next sweep
+        of the same shape overwrites).  light: no output copies at all (the caller reads pclean_get_moved /
+        pclean_get_new_rows); returns (None, None, None)."""
+        n_blocks = np.shape(cur)[0]
+        if window is not None:
+            lo, hi = window
+            assert cur.dtype == np.int32 and cur.flags.c_contiguous
+            n_rows = hi - lo
+            if reuse_buffers and self._io.get("cur_pinned") != (cur.ctypes.data, cur.nbytes):
+                old = self._io.get("cur_pinned")
+                if old:
+                    self.lib.pclean_unpin_host(self.h, C.c_void_p(old[0]))
+                check(self.h, self.lib.pclean_pin_host(self.h, C.c_void_p(cur.ctypes.data), C.c_size_t(cur.nbytes)),
+                      "pclean_pin_host")
+                self._io["cur_pinned"] = (cur.ctypes.data, cur.nbytes)
+                self._io["cur_ref"] = cur
+            check(self.h, self.lib.pclean_set_cur_stride(self.h, C.c_int64(cur.shape[1])), "pclean_set_cur_stride")
+            cur_ptr = C.cast(C.c_void_p(cur.ctypes.data + 4 * lo), C.POINTER(C.c_int32))
         else:
+            n_rows = np.shape(cur)[1]
+            check(self.h, self.lib.pclean_set_cur_stride(self.h, C.c_int64(0)), "pclean_set_cur_stride")
             cur = np.ascontiguousarray(cur, dtype=np.int32)
-            choice = np.empty_like(cur)
+            cur_ptr = _p(cur, C.c_int32)
+        if light:
+            choice = chosen = logml = None
+        elif reuse_buffers:
+            _, choice, chosen, logml = self._io_buffers(n_blocks, n_rows)
+        else:
+            choice = np.empty((n_blocks, n_rows), dtype=np.int32)
             chosen = np.empty(n_rows, dtype=np.int32)
             logml = np.empty(n_rows, dtype=np.float64)
         check(self.h, self.lib.pclean_sweep(self.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep_idx),
-                                            C.c_int32(n_blocks), _p(cur, C.c_int32), _p(choice, C.c_int32),
+                                            C.c_int32(n_blocks), cur_ptr, _p(choice, C.c_int32),
                                             _p(chosen, C.c_int32), _p(logml, C.c_double)), "pclean_sweep")
         return choice, chosen, logml
 
@@ -463,6 +490,26 @@ class HipContext:
         check(self.h, self.lib.pclean_stats_device_ptr(self.h, C.c_int32(table_id), C.byref(ptr), C.byref(n)),
               "pclean_stats_device_ptr")
         return ptr.value, n.value
+
+    def get_root_stats(self):
+        r = RootStats()
+        check(self.h, self.lib.pclean_get_root_stats(self.h, C.byref(r)), "pclean_get_root_stats")
+        return r
+
+    def set_profiling(self, on):
+        check(self.h, self.lib.pclean_set_profiling(self.h, C.c_int32(int(on))), "pclean_set_profiling")
+
+    def get_profile(self):
+        """{phase name: (milliseconds, recorded intervals)} accumulated since set_profiling(True)."""
+        n = C.c_int32()
+        check(self.h, self.lib.pclean_get_profile(self.h, C.c_int32(0), None, None, None, C.byref(n)), "pclean_get_profile")
+        names = C.create_string_buffer(32 * max(n.value, 1))
+        ms = np.zeros(max(n.value, 1), dtype=np.float32)
+        cnt = np.zeros(max(n.value, 1), dtype=np.int32)
+        check(self.h, self.lib.pclean_get_profile(self.h, n, names, _p(ms, C.c_float), _p(cnt, C.c_int32), C.byref(n)),
+              "pclean_get_profile")
+        raw = names.raw
+        return {raw[32 * i:32 * i + 32].split(b"\0")[0].decode(): (float(ms[i]), int(cnt[i])) for i in range(n.value)}
 
     def get_timing(self):
         t = Timing()

@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpclean_hip.so")
-SOURCES = ["api.hip", "comm.hip", "dist_kernels.hip", "enum_kernels.hip", "root_fast.hip", "random_kernels.hip", "sweep.hip"]
+SOURCES = ["api.hip", "comm.hip", "dist_kernels.hip", "enum_kernels.hip", "root_wave.hip", "random_kernels.hip", "sweep.hip"]
 HEADERS = ["ctx.h", "../../include/pclean_hip.h", "../../include/pclean_detmath.h", "../../include/pclean_philox.h"]
 # -ffp-contract=off: the parity contract (include/pclean_detmath.h) needs plain
 # IEEE mul/add on device, identical to the gcc-built oracle.
@@ -29,18 +29,32 @@ def _stale():
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+def _obj_stale(src, obj):
+    if not os.path.exists(obj):
+        return True
+    t = os.path.getmtime(obj)
+    deps = [src, os.path.abspath(__file__)] + [os.path.join(CSRC, h) for h in HEADERS]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
 def build(force=False, verbose=True):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objs = []
-    for s in SOURCES:
+    objs, procs = [], []
+    for s in SOURCES:  # one hipcc per stale translation unit, all in parallel
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        objs.append(o)
+        if not force and not _obj_stale(os.path.join(CSRC, s), o):
+            continue
         cmd = [hipcc] + [f for f in FLAGS if f] + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-        objs.append(o)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

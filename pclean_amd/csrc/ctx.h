@@ -64,6 +64,8 @@ struct CandTable {
   std::vector<int64_t> h_counts;
   std::vector<double> h_logc_full, h_logc_m1;
   DevBuf<int64_t> stats;      // delta reference counts of last sweep
+  double h_lse = 0.0;         // options: log-sum of logp (+1e-9), valid for version h_lse_ver (sweep.hip: subtree_ub)
+  uint64_t h_lse_ver = 0;
 };
 
 struct FnTable {
@@ -137,6 +139,8 @@ struct pclean_ctx {
   Block block[PCLEAN_MAX_BLOCKS];
 
   pclean_timing timing = {};
+  pclean_root_stats root_stats = {};
+  int64_t cur_stride = 0;  // pclean_set_cur_stride
   int32_t active_begin = 0, active_count = -1;  // pclean_set_active_rows window (-1 = all rows)
   bool force_generic = false;  // debug: never take the compact-table root kernel
   void* sweep_state = nullptr;  // owned by sweep.hip

@@ -76,6 +76,10 @@ struct ItemsDev {
   // grp_off[g+1]) — each with its own RNG row / particle.  Null: one item per workgroup, n = items.
   const int32_t* grp_off;
   const int32_t* members;
+  // draw j of item t is written to draws_out[t * draw_is + j * draw_ds]; (0, 0) = item-major (n_draws, 1).
+  // The sweep keeps its particle arrays particle-major ([P][N]: draw_is = 1, draw_ds = N) so that the
+  // one-thread-per-row particle kernels read them coalesced.
+  int32_t draw_is, draw_ds;
 };
 
 // Log-marginals of the children of a "new row": either one value per item, or a
@@ -87,7 +91,17 @@ struct ChildrenDev {
   int32_t n_obs[PCLEAN_MAX_CHILDREN];
 };
 
-// Fast path for a block root with many candidates (the dominant kernel): per term a
+// Upper bounds of the children's log-marginals for the gate of the "new row" branch (gate_new_kernel)
+struct GateDev {
+  int32_t n, pad;
+  const double* cache[PCLEAN_MAX_CHILDREN];   // cacheable leaf: exact per-unique-observed-value marginal, else null
+  const int32_t* obs_col[PCLEAN_MAX_CHILDREN];
+  int32_t n_obs[PCLEAN_MAX_CHILDREN];
+  double ub[PCLEAN_MAX_CHILDREN];             // otherwise: a constant upper bound
+};
+int pclean_launch_gate(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const GateDev& gt, int32_t* flag);
+
+// Fast path for a reference slot with many candidates (root_wave.hip, the dominant kernel): per term a
 // candidate-compact byte table comp[o][k] = D[o][value of candidate k] (rebuilt only when
 // the latent table's columns change) so a work item streams F contiguous byte rows instead
 // of gathering, plus the candidates' word lengths clen[k].
@@ -113,15 +127,16 @@ struct FastRootDev {
   // integer pre-filter (root_fast.hip): terms whose byte rows are summed, 1 / (smallest cost of one
   // edit), and the largest prior with / without an excluded reference
   int32_t n_pre, pre[3];
-  int32_t chunk_rounds, pad2;  // rounds (of 16 candidates per lane) per survivor-bitmask chunk (<= 16)
+  int32_t pad1, pad2;
   double inv_c, prior_max_e, prior_max_n;
   FastTermDev terms[PCLEAN_MAX_TERMS];
 };
 
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
-                            int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count);
-size_t pclean_fast_lds_bytes(int lmax, int dstride);
+                            int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
+                            int32_t* desc_scratch);
+size_t pclean_fast_desc_words(int n_groups);  // int32 words of desc_scratch for n_groups groups
 int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_lat, const int32_t* cand_col,
                          const uint16_t* lat_len, int n_cand, int kpad, uint8_t* comp, uint8_t* clen);
 int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* logc_full, int n_cand, int kpad,

@@ -180,6 +180,45 @@ __device__ __forceinline__ double new_score(const NodeDev& nd, const ChildrenDev
   return ((v.deleted ? nd.scal[3] : nd.scal[2]) - v.logden) + snew;
 }
 
+// ---- gate of the "new row" branch ------------------------------------------------------------------
+// The new-row candidate of an FK node needs the log-marginals of the node's sub-plans (its children).  For
+// an item whose current referent e scores well they cannot matter: with
+//     ub = CRP new-table term + sum over children of an upper bound of the child's log-marginal
+// (exact cached value for cacheable leaves; log-sum of the option prior for other leaves; max(0, sum) for
+// nested reference slots — every term density of the sub-tree is a probability mass <= 1), the new row's
+// score is <= ub, and ub < score(e) - 28.5 <= max - 28.5 makes its fixed-point weight exactly 0
+// (pclean_fixw).  Such items skip the evaluation of the children: flag 0.  flag = PCLEAN_CHOICE_NEW (the
+// compaction marker) for items that need them.
+__global__ void gate_new_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it, const GateDev gt,
+                                int32_t* __restrict__ flag) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= it.n) return;
+  const ItemView v = item_view(nd, it, t);
+  bool need = true;
+  if (v.excl >= 0 && !v.deleted) {
+    const double bound = candidate_score(nd, dn, it, v, v.excl);
+    double ub = nd.scal[2] - v.logden;
+    for (int c = 0; c < gt.n; ++c) {
+      if (gt.cache[c] && v.ev_lo < 0) {
+        const int o = gt.obs_col[c][v.row];
+        ub += gt.cache[c][o < 0 ? gt.n_obs[c] : o];
+      } else {
+        ub += gt.ub[c];
+      }
+    }
+    need = !(ub + 1e-6 < bound - 28.5);
+  }
+  flag[t] = need ? PCLEAN_CHOICE_NEW : 0;
+}
+
+int pclean_launch_gate(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const GateDev& gt, int32_t* flag) {
+  if (it.n <= 0) return PCLEAN_OK;
+  DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
+  hipLaunchKernelGGL(gate_new_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, nd, dn, it, gt, flag);
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
+
 // exclusive block scan of one uint64 per lane (256 lanes); returns lane prefix, sets total
 __device__ __forceinline__ uint64_t block_excl_scan(uint64_t part, uint64_t* wsum, uint64_t* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -265,6 +304,7 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   const double lse = pclean_lse_from_fix(m, U);
   const int nd_eff = n_draws > 0 ? n_draws : 1;
   const int n_out = (m_hi - m_lo) * nd_eff;
+  const int draw_is = it.draw_is ? it.draw_is : n_draws, draw_ds = it.draw_ds ? it.draw_ds : 1;
   for (int q = tid; q < n_out; q += 256) {
     const int mi = m_lo + q / nd_eff, j = q % nd_eff;
     const int tm = it.grp_off ? it.members[mi] : t;
@@ -287,7 +327,7 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
       }
       res = (fk && a == n) ? PCLEAN_CHOICE_NEW : a;
     }
-    draws_out[(size_t)tom * n_draws + j] = res;
+    draws_out[(size_t)tom * draw_is + (size_t)j * draw_ds] = res;
   }
 }
 
@@ -343,7 +383,7 @@ __global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, co
     const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[t] : (uint32_t)((int64_t)v.row + it.row_offset);
     for (int j = 0; j < n_draws; ++j) {
       const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)j;
-      int32_t* dst = draws_out + (size_t)to * n_draws + j;
+      int32_t* dst = draws_out + (size_t)to * (it.draw_is ? it.draw_is : n_draws) + (size_t)j * (it.draw_ds ? it.draw_ds : 1);
       if (U == 0) {
         if (tid == 0) *dst = fk ? PCLEAN_CHOICE_NEW : n - 1;
         continue;

@@ -73,20 +73,11 @@ __global__ void derive_excl_kernel(int n, const int32_t* parent_excl, const int6
   out[t] = (e >= 0 && parent_counts[e] <= 1) ? parent_fk_col[e] : -1;
 }
 
-// items of a ctx-dependent block: one per (row, particle)
-__global__ void build_ctx_items_kernel(int n_rows, int P, const int32_t* cur_b, int32_t* it_row, int32_t* it_particle,
-                                       int32_t* it_excl) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)n_rows * P) return;
-  const int i = (int)(t / P);
-  it_row[t] = i;
-  it_particle[t] = (int)(t % P);
-  it_excl[t] = cur_b ? cur_b[i] : -1;
-}
-
+// Particle arrays of a sweep are PARTICLE-MAJOR: slot(p, i) = p * N + i (w, pchoice, pnewpos, draws, ctx), so
+// that one-thread-per-row kernels read them coalesced and per-slot kernels stay coalesced as well.
 struct CtxSrc {
   int32_t n_ctx;
-  const int32_t* pchoice[PCLEAN_MAX_CTX];  // [n_rows*P] of the source block
+  const int32_t* pchoice[PCLEAN_MAX_CTX];  // [P][N] of the source block
   const int32_t* pnewpos[PCLEAN_MAX_CTX];
   const int32_t* vals[PCLEAN_MAX_CTX];     // [n_new][n_nodes] of the source block
   int32_t n_nodes[PCLEAN_MAX_CTX];
@@ -95,9 +86,10 @@ struct CtxSrc {
   PlanDev plan[PCLEAN_MAX_CTX];
 };
 
-__global__ void gather_ctx_kernel(size_t n_items, CtxSrc cs, int32_t* it_ctx) {
+// ctx value c of slot t -> it_ctx[c * NP + t]
+__global__ void gather_ctx_kernel(size_t NP, CtxSrc cs, int32_t* it_ctx) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n_items) return;
+  if (t >= NP) return;
   for (int s = 0; s < PCLEAN_MAX_CTX; ++s) {
     int32_t v = 0;
     if (s < cs.n_ctx) {
@@ -107,46 +99,63 @@ __global__ void gather_ctx_kernel(size_t n_items, CtxSrc cs, int32_t* it_ctx) {
       else
         v = resolve_new_value(cs.plan[s], 0, cs.col[s], cs.vals[s] + (size_t)cs.pnewpos[s][t] * cs.n_nodes[s]);
     }
-    it_ctx[t * PCLEAN_MAX_CTX + s] = v;
+    it_ctx[(size_t)s * NP + t] = v;
   }
 }
 
-// distinct contexts among the particles of a row: rep[s] = first slot of the row with the
-// same ctx tuple; repflag[s] = -1 (compaction marker) for representatives, 0 otherwise
-__global__ void dedup_ctx_kernel(int n_rows, int P, const int32_t* it_ctx, int32_t* repflag, int32_t* rep) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rows) return;
-  const size_t base = (size_t)i * P;
+// distinct contexts among the particles of a row: rep[slot(p,i)] = first particle q <= p of the row with the
+// same ctx tuple; n_distinct[i] = number of representatives.  Typical rows: every particle shares one context.
+__global__ void ctx_count_kernel(int N, int P, const int32_t* __restrict__ it_ctx, int32_t* __restrict__ rep,
+                                 int32_t* __restrict__ n_distinct) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const size_t NP = (size_t)N * P;
+  int nd = 0;
   for (int p = 0; p < P; ++p) {
+    const size_t sp = (size_t)p * N + i;
+    int c[PCLEAN_MAX_CTX];
+    for (int k = 0; k < PCLEAN_MAX_CTX; ++k) c[k] = it_ctx[(size_t)k * NP + sp];
     int q = 0;
     for (; q < p; ++q) {
       bool same = true;
-      for (int c = 0; c < PCLEAN_MAX_CTX; ++c)
-        same &= it_ctx[(base + p) * PCLEAN_MAX_CTX + c] == it_ctx[(base + q) * PCLEAN_MAX_CTX + c];
+      for (int k = 0; k < PCLEAN_MAX_CTX; ++k) same &= it_ctx[(size_t)k * NP + (size_t)q * N + i] == c[k];
       if (same) break;
     }
-    rep[base + p] = (int32_t)(base + q);
-    repflag[base + p] = q == p ? PCLEAN_CHOICE_NEW : 0;
+    rep[sp] = q;
+    nd += q == p ? 1 : 0;
+  }
+  n_distinct[i] = nd;
+}
+// items off[i] .. off[i] + n_distinct[i]) of row i, in particle order of their representatives
+__global__ void ctx_fill_kernel(int N, int P, const int32_t* __restrict__ it_ctx, const int32_t* __restrict__ rep,
+                                const int32_t* __restrict__ off, const int32_t* __restrict__ cur_b,
+                                int32_t* __restrict__ slot_item, int32_t* __restrict__ row, int32_t* __restrict__ ctxv,
+                                int32_t* __restrict__ excl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const size_t NP = (size_t)N * P;
+  int j = off[i];
+  for (int p = 0; p < P; ++p) {
+    const size_t sp = (size_t)p * N + i;
+    const int q = rep[sp];
+    if (q == p) {
+      row[j] = i;
+      excl[j] = cur_b ? cur_b[i] : -1;
+      for (int k = 0; k < PCLEAN_MAX_CTX; ++k) ctxv[(size_t)j * PCLEAN_MAX_CTX + k] = it_ctx[(size_t)k * NP + sp];
+      slot_item[sp] = j++;
+    } else {
+      slot_item[sp] = slot_item[(size_t)q * N + i];  // written above by this very thread
+    }
   }
 }
-__global__ void ctx_items_kernel(int n, int P, const int32_t* list, const int32_t* it_ctx, const int32_t* cur_b,
-                                 int32_t* row, int32_t* ctxv, int32_t* excl) {
-  int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
-  const int slot = list[j];
-  const int i = slot / P;
-  row[j] = i;
-  excl[j] = cur_b ? cur_b[i] : -1;
-  for (int c = 0; c < PCLEAN_MAX_CTX; ++c) ctxv[j * PCLEAN_MAX_CTX + c] = it_ctx[(size_t)slot * PCLEAN_MAX_CTX + c];
-}
-// particle slot s takes the log-marginal of its context's item and its own draw (particle id = s % P)
-__global__ void expand_ctx_kernel(size_t n_slots, int P, const int32_t* rep, const int32_t* pos, const double* lse_item,
+// particle slot t takes the log-marginal of its context's item and its own draw (particle id = t / N)
+__global__ void expand_ctx_kernel(size_t NP, int N, int P, const int32_t* slot_item, const double* lse_item,
                                   const int32_t* draws_item, int32_t* draws, double* w) {
-  size_t s = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_slots) return;
-  const int item = pos[rep[s]];
-  draws[s] = draws_item[(size_t)item * P + (s % P)];
-  w[s] += lse_item[item];
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= NP) return;
+  const int item = slot_item[t];
+  draws[t] = draws_item[(size_t)item * P + (t / N)];
+  w[t] += lse_item[item];
 }
 
 // ---- pure scoring block (flights Obs block 3): p += logdensity(MaybeSwap, ...) ---------------------
@@ -182,7 +191,7 @@ struct ScoreBlockDev {
 __global__ void score_block_kernel(int n_rows, int P, ScoreBlockDev sb, double* w) {
   size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (slot >= (size_t)n_rows * P) return;
-  const int i = (int)(slot / P);
+  const int i = (int)(slot % n_rows);
   const int pidx = sb.prob_fn[(size_t)src_value(sb.pa, slot) * sb.prob_nb + src_value(sb.pb, slot)];
   double acc = 0.0;
   for (int k = 0; k < sb.n_terms; ++k) {
@@ -201,21 +210,20 @@ __global__ void score_block_kernel(int n_rows, int P, ScoreBlockDev sb, double* 
   w[slot] += acc;
 }
 
-// root draws [n_rows][P] (or [n_rows*P][1]) -> particle choices; particle 0 keeps
-// the retained referent under CSMC (row_inference.jl:143-145)
+// root draws (particle-major) -> particle choices; particle 0 keeps the retained referent under CSMC
+// (row_inference.jl:143-145)
 __global__ void set_pchoice_kernel(int n_rows, int P, const int32_t* draws, const int32_t* cur_b, int32_t* pchoice) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)n_rows * P) return;
-  const int i = (int)(t / P), p = (int)(t % P);
   int c = draws[t];
-  if (p == 0 && cur_b && cur_b[i] >= 0) c = cur_b[i];
+  if (t < (size_t)n_rows && cur_b && cur_b[t] >= 0) c = cur_b[t];  // particle 0 occupies slots [0, N)
   pchoice[t] = c;
 }
 
 __global__ void add_weight_shared_kernel(int n_rows, int P, const double* lse, double* w) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (size_t)n_rows * P) return;
-  w[t] += lse[t / P];
+  w[t] += lse[t % n_rows];
 }
 __global__ void add_weight_kernel(size_t n, const double* lse, double* w) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -270,20 +278,19 @@ __global__ void sublist_items_kernel(int n, const int32_t* list, const int32_t* 
   for (int c = 0; c < PCLEAN_MAX_CTX; ++c) ctxv[j * PCLEAN_MAX_CTX + c] = p_ctx ? p_ctx[s * PCLEAN_MAX_CTX + c] : 0;
 }
 
-// first-level new list from (row, particle) slots of a block
-__global__ void rootlist_items_kernel(int n, int P, const int32_t* list, const int32_t* b_ctx, int ctx_per_item,
+// first-level new list from (row, particle) slots of a block (slot = particle * N + row)
+__global__ void rootlist_items_kernel(int n, int N, size_t NP, const int32_t* list, const int32_t* b_ctx,
                                       const int32_t* cur_b, int32_t* row, int32_t* ctxv, int32_t* particle,
                                       int32_t* origin, int32_t* excl) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int slot = list[j];
-  const int i = slot / P;
+  const int i = slot % N;
   row[j] = i;
-  particle[j] = slot % P;
+  particle[j] = slot / N;
   origin[j] = j;
   excl[j] = cur_b ? cur_b[i] : -1;
-  for (int c = 0; c < PCLEAN_MAX_CTX; ++c)
-    ctxv[j * PCLEAN_MAX_CTX + c] = (b_ctx && ctx_per_item) ? b_ctx[(size_t)slot * PCLEAN_MAX_CTX + c] : 0;
+  for (int c = 0; c < PCLEAN_MAX_CTX; ++c) ctxv[j * PCLEAN_MAX_CTX + c] = b_ctx ? b_ctx[(size_t)c * NP + slot] : 0;
 }
 
 __global__ void scatter_vals_kernel(int n, const int32_t* origin, const int32_t* draws, int n_nodes, int node,
@@ -313,117 +320,166 @@ __global__ void gather_i32_kernel(int n, const int32_t* list, const int32_t* src
 }
 
 // ---- particle kernels ----------------------------------------------------------
+// One thread per row; the P particle weights of row i live at logw[i * sr + p * sp] (sweep: particle-major,
+// sr = 1, sp = N -> coalesced; parity entry points: row-major, sr = P, sp = 1).  PMAX (compile-time bound
+// of P) keeps the fixed-point weights in registers.
+#define MAXP 64
+
+template <int PMAX>
 struct FixW {
   double m;
   uint64_t U;
+  uint64_t u[PMAX];
 };
-__device__ FixW fix_weights(const double* w, int P, uint64_t* u) {
-  FixW f{-__builtin_inf(), 0};
-  for (int p = 0; p < P; ++p) f.m = fmax(f.m, w[p]);
-  for (int p = 0; p < P; ++p) {
-    u[p] = f.m == -__builtin_inf() ? 0ull : pclean_fixw(w[p] - f.m);
-    f.U += u[p];
+template <int PMAX>
+__device__ __forceinline__ void fix_weights(const double* w, size_t sp, int P, FixW<PMAX>& f) {
+  f.m = -__builtin_inf();
+  f.U = 0;
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p)
+    if (p < P) f.m = fmax(f.m, w[(size_t)p * sp]);
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p) {
+    f.u[p] = (p < P && f.m != -__builtin_inf()) ? pclean_fixw(w[(size_t)p * sp] - f.m) : 0ull;
+    f.U += f.u[p];
   }
-  return f;
 }
-__device__ int fix_pick(const uint64_t* u, int P, uint64_t U, uint64_t R) {
-  if (U == 0) return P - 1;
-  const uint64_t x = pclean_mulhi64(R, U);
+template <int PMAX>
+__device__ __forceinline__ int fix_pick(const FixW<PMAX>& f, int P, uint64_t R) {
+  if (f.U == 0) return P - 1;
+  const uint64_t x = pclean_mulhi64(R, f.U);
   uint64_t acc = 0;
-  for (int p = 0; p < P; ++p) {
-    acc += u[p];
-    if (acc > x) return p;
+  int res = P - 1;
+  bool found = false;
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p) {
+    acc += f.u[p];
+    if (!found && p < P && acc > x) {
+      res = p;
+      found = true;
+    }
   }
-  return P - 1;
+  return res;
 }
-
-#define MAXP 64
 
 // row_inference.jl:87-105
-__global__ void maybe_resample_kernel(int n_rows, int P, const double* logw, int retain_first, const int32_t* csmc_flag,
-                                      uint64_t seed, uint32_t sweep, uint32_t block, int64_t row_offset,
-                                      int32_t* ancestors, double* logml_inc, double* ess_out, int32_t* did) {
+template <int PMAX>
+__global__ void maybe_resample_kernel(int n_rows, int P, const double* logw, size_t sr, size_t sp, int retain_first,
+                                      const int32_t* csmc_flag, uint64_t seed, uint32_t sweep, uint32_t block,
+                                      int64_t row_offset, int32_t* ancestors, double* logml_inc, double* ess_out,
+                                      int32_t* did) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows) return;
-  uint64_t u[MAXP];
-  const double* w = logw + (size_t)i * P;
-  FixW f = fix_weights(w, P, u);
+  FixW<PMAX> f;
+  fix_weights<PMAX>(logw + (size_t)i * sr, sp, P, f);
   const double Ud = (double)f.U;
   double s2 = 0.0;
-  for (int p = 0; p < P; ++p) s2 += (double)u[p] * (double)u[p];
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p)
+    if (p < P) s2 += (double)f.u[p] * (double)f.u[p];
   const double ess = f.U ? (Ud * Ud) / s2 : 0.0;
   if (ess_out) ess_out[i] = ess;
   const bool retain = csmc_flag ? (csmc_flag[i] >= 0) : (retain_first != 0);
+  int32_t* anc = ancestors + (size_t)i * sr;
   if (ess < (double)P / 2.0) {
     const uint32_t rr = (uint32_t)((int64_t)i + row_offset);
     for (int p = 0; p < P; ++p) {
       if (p == 0 && retain)
-        ancestors[(size_t)i * P] = 0;
+        anc[0] = 0;
       else
-        ancestors[(size_t)i * P + p] =
-            fix_pick(u, P, f.U, pclean_rand64(seed, rr, PCLEAN_SITE_RESAMPLE(block), (uint32_t)p, sweep));
+        anc[(size_t)p * sp] = fix_pick<PMAX>(f, P, pclean_rand64(seed, rr, PCLEAN_SITE_RESAMPLE(block), (uint32_t)p, sweep));
     }
     logml_inc[i] = pclean_lse_from_fix(f.m, f.U) - pclean_log((double)P);
     if (did) did[i] = 1;
   } else {
-    for (int p = 0; p < P; ++p) ancestors[(size_t)i * P + p] = p;
+    for (int p = 0; p < P; ++p) anc[(size_t)p * sp] = p;
     logml_inc[i] = 0.0;
     if (did) did[i] = 0;
   }
 }
 
-// apply ancestors: particle-indexed int32 arrays and weights (clone_with_zero_weight, 17-21)
+// apply ancestors: particle-major int32 arrays and weights (clone_with_zero_weight, 17-21); the log-ML
+// increment of the resampling step is accumulated here as well
 __global__ void apply_ancestors_kernel(int n_rows, int P, const int32_t* ancestors, int n_arrays, int32_t** arrays,
-                                       double* w, const int32_t* did) {
+                                       double* w, const int32_t* did, const double* logml_inc, double* logml_acc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows) return;
+  logml_acc[i] += logml_inc[i];
   if (!did[i]) return;
   int32_t tmp[MAXP];
   for (int a = 0; a < n_arrays; ++a) {
-    int32_t* arr = arrays[a] + (size_t)i * P;
-    for (int p = 0; p < P; ++p) tmp[p] = arr[ancestors[(size_t)i * P + p]];
-    for (int p = 0; p < P; ++p) arr[p] = tmp[p];
+    int32_t* arr = arrays[a] + i;
+    for (int p = 0; p < P; ++p) tmp[p] = arr[(size_t)ancestors[(size_t)p * n_rows + i] * n_rows];
+    for (int p = 0; p < P; ++p) arr[(size_t)p * n_rows] = tmp[p];
   }
-  for (int p = 0; p < P; ++p) w[(size_t)i * P + p] = 0.0;
+  for (int p = 0; p < P; ++p) w[(size_t)p * n_rows + i] = 0.0;
 }
 
-// row_inference.jl:158-165 + return value 186
-__global__ void final_choice_kernel(int n_rows, int P, const double* logw, int use_mh, int is_csmc,
-                                    const int32_t* csmc_flag, uint64_t seed, uint32_t sweep, int64_t row_offset,
-                                    int32_t* chosen, double* log_total) {
+// row_inference.jl:158-165 + return value 186 (logml = accumulated resampling increments + log mean weight)
+template <int PMAX>
+__global__ void final_choice_kernel(int n_rows, int P, const double* logw, size_t sr, size_t sp, int use_mh,
+                                    int is_csmc, const int32_t* csmc_flag, uint64_t seed, uint32_t sweep,
+                                    int64_t row_offset, int32_t* chosen, double* log_total, const double* logml_acc,
+                                    double* logml) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows) return;
-  uint64_t u[MAXP];
-  FixW f = fix_weights(logw + (size_t)i * P, P, u);
+  FixW<PMAX> f;
+  fix_weights<PMAX>(logw + (size_t)i * sr, sp, P, f);
   const uint32_t rr = (uint32_t)((int64_t)i + row_offset);
   const bool csmc = csmc_flag ? (csmc_flag[i] >= 0) : (is_csmc != 0);
   int c;
   if (use_mh && csmc && P >= 2) {
     const double Ud = (double)f.U;
-    const double w0 = (double)u[0] / Ud, w1 = (double)u[1] / Ud;
+    const double w0 = (double)f.u[0] / Ud, w1 = (double)f.u[PMAX > 1 ? 1 : 0] / Ud;
     double ratio = w1 / (1e-10 + w0);
     if (ratio > 1.0) ratio = 1.0;
     const double x = pclean_u01(pclean_rand64(seed, rr, PCLEAN_SITE_MH, 0u, sweep));
     c = (f.U != 0 && x < ratio) ? 1 : 0;
   } else {
-    c = fix_pick(u, P, f.U, pclean_rand64(seed, rr, PCLEAN_SITE_FINAL, 0u, sweep));
+    c = fix_pick<PMAX>(f, P, pclean_rand64(seed, rr, PCLEAN_SITE_FINAL, 0u, sweep));
   }
   chosen[i] = c;
-  if (log_total) log_total[i] = pclean_lse_from_fix(f.m, f.U);
+  const double lt = pclean_lse_from_fix(f.m, f.U);
+  if (log_total) log_total[i] = lt;
+  if (logml) logml[i] = (logml_acc ? logml_acc[i] : 0.0) + lt - pclean_log((double)P);
 }
 
-__global__ void finish_logml_kernel(int n_rows, int P, const double* log_total, const double* inc, double* logml) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_rows) logml[i] = (inc ? inc[i] : 0.0) + log_total[i] - pclean_log((double)P);
-}
+#define DISPATCH_PMAX(P, ...)   \
+  do {                          \
+    if ((P) <= 2) {             \
+      constexpr int PMAX = 2;   \
+      __VA_ARGS__;              \
+    } else if ((P) <= 8) {      \
+      constexpr int PMAX = 8;   \
+      __VA_ARGS__;              \
+    } else if ((P) <= 32) {     \
+      constexpr int PMAX = 32;  \
+      __VA_ARGS__;              \
+    } else {                    \
+      constexpr int PMAX = 64;  \
+      __VA_ARGS__;              \
+    }                           \
+  } while (0)
 
-__global__ void select_choice_kernel(int n_rows, int P, const int32_t* chosen, const int32_t* pchoice,
-                                     const int32_t* pnewpos, int32_t* choice, int32_t* chosen_newpos) {
+// per block after the final choice: the chosen particle's referent, its new-row record, the delta reference
+// counts (the all-reduce payload) and the flags of moved rows / rows with a new referent
+__global__ void finalize_block_kernel(int n_rows, const int32_t* chosen, const int32_t* pchoice, const int32_t* pnewpos,
+                                      const int32_t* cur_b, int32_t* choice, int32_t* chosen_newpos,
+                                      unsigned long long* stats, int32_t* moved_flag, int32_t* new_flag) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows) return;
-  const size_t s = (size_t)i * P + chosen[i];
-  choice[i] = pchoice[s];
-  chosen_newpos[i] = pchoice[s] == PCLEAN_CHOICE_NEW ? pnewpos[s] : -1;
+  const size_t s = (size_t)chosen[i] * n_rows + i;
+  const int c = pchoice[s];
+  const int o = cur_b[i];
+  choice[i] = c;
+  const int np = c == PCLEAN_CHOICE_NEW ? pnewpos[s] : -1;
+  chosen_newpos[i] = np;
+  new_flag[i] = np >= 0 ? 1 : 0;
+  moved_flag[i] = c != o ? 1 : 0;
+  if (o != c) {
+    if (o >= 0) atomicAdd(&stats[o], (unsigned long long)(-1ll));
+    if (c >= 0) atomicAdd(&stats[c], 1ull);
+  }
 }
 
 // own enumerated choices (locals) of the chosen particle, drawn from their conditional given
@@ -434,7 +490,7 @@ __global__ void locals_tail_kernel(int n_rows, int P, GaussDev g, PlanDev plan, 
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows) return;
   const int c = chosen[i];
-  const size_t slot = (size_t)i * P + c;
+  const size_t slot = (size_t)c * n_rows + i;
   const int choice = pchoice[slot];
   const int32_t* v = choice >= 0 ? nullptr : vals + (size_t)pnewpos[slot] * n_nodes;
   locals[2 * i] = locals[2 * i + 1] = -1;
@@ -489,15 +545,6 @@ __global__ void locals_tail_kernel(int n_rows, int P, GaussDev g, PlanDev plan, 
   }
 }
 
-__global__ void stats_kernel(int n_rows, const int32_t* cur_b, const int32_t* choice, unsigned long long* stats) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rows) return;
-  const int o = cur_b ? cur_b[i] : -1, c = choice[i];
-  if (o == c) return;
-  if (o >= 0) atomicAdd(&stats[o], (unsigned long long)(-1ll));
-  if (c >= 0) atomicAdd(&stats[c], 1ull);
-}
-
 __global__ void gather_new_rows_kernel(int n, const int32_t* list, const int32_t* chosen_newpos, const int32_t* vals,
                                        int n_nodes, int32_t* rows_out, int32_t* vals_out) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -507,15 +554,6 @@ __global__ void gather_new_rows_kernel(int n, const int32_t* list, const int32_t
   const int32_t* v = vals + (size_t)chosen_newpos[i] * n_nodes;
   for (int k = 0; k < n_nodes; ++k) vals_out[(size_t)j * n_nodes + k] = v[k];
 }
-__global__ void mark_moved_kernel(int n_rows, const int32_t* cur, const int32_t* choice, int32_t* flag) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_rows) flag[i] = choice[i] != cur[i] ? PCLEAN_CHOICE_NEW : 0;
-}
-__global__ void mark_new_kernel(int n_rows, const int32_t* chosen_newpos, int32_t* flag) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n_rows) flag[i] = chosen_newpos[i] >= 0 ? PCLEAN_CHOICE_NEW : 0;
-}
-
 // ---------------------------------------------------------------------------
 // host side
 static inline dim3 grid1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
@@ -532,10 +570,12 @@ struct ItemList {  // device arrays describing enumeration work items
   const int32_t* ev_rows = nullptr;
   const int32_t* ev_ctx = nullptr;
   const int32_t* rng_row = nullptr;
+  int draw_is = 0, draw_ds = 0;  // ItemsDev::draw_is / draw_ds of the draws this list produces
 };
 
 struct BlockRun {  // per-block device state of one sweep
-  DevBuf<int32_t> pchoice, pnewpos, draws, it_row, it_particle, it_excl, it_ctx, choice, chosen_newpos, vals, locals;
+  DevBuf<int32_t> pchoice, pnewpos, draws, it_ctx, choice, chosen_newpos, vals, locals, moved_flag, new_flag, moved_list,
+      new_list;
   DevBuf<double> lse;
   int n_new = 0;  // rows of vals
   DevBuf<int32_t> plan_kind, plan_nrows, plan_cmb, plan_colmap;
@@ -544,7 +584,7 @@ struct BlockRun {  // per-block device state of one sweep
   bool plan_ready = false;
 };
 
-struct FastRoot {  // candidate-compact tables of a block root (root_fast.hip)
+struct FastRoot {  // candidate-compact tables of a reference slot (root_wave.hip)
   std::vector<DevBuf<uint8_t>> comp, clen;
   std::vector<uint64_t> ver;
   DevBuf<double> prior_e, prior_n;
@@ -566,6 +606,16 @@ struct SweepState {
   std::map<int, uint64_t> leaf_version;
   int64_t row_offset = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evs = nullptr, eve = nullptr;
+  DevBuf<int32_t> tail_counts;      // [2 * PCLEAN_MAX_BLOCKS] number of moved rows / rows with a new referent
+  int32_t* h_counts = nullptr;      // page-locked mirror of tail_counts (+ scratch words)
+  // per-phase HIP-event profile of a sweep (pclean_set_profiling): (phase, start, stop) records
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;
+  std::vector<int> prof_phase;      // phase id of record r (events 2r, 2r+1)
+  size_t prof_used = 0;
+  std::vector<std::string> prof_names;
+  std::vector<float> prof_ms;
+  std::vector<int32_t> prof_launches;
 };
 
 static SweepState* st(pclean_ctx* ctx) {
@@ -578,8 +628,9 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
   SweepState* s = (SweepState*)ctx->sweep_state;
   for (auto& b : s->pool) b.release();
   for (auto& r : s->run) {
-    r.pchoice.release(); r.pnewpos.release(); r.draws.release(); r.it_row.release(); r.it_particle.release();
-    r.locals.release(); r.it_excl.release(); r.it_ctx.release(); r.choice.release(); r.chosen_newpos.release(); r.vals.release();
+    r.pchoice.release(); r.pnewpos.release(); r.draws.release(); r.moved_flag.release(); r.new_flag.release();
+    r.moved_list.release(); r.new_list.release();
+    r.locals.release(); r.it_ctx.release(); r.choice.release(); r.chosen_newpos.release(); r.vals.release();
     r.lse.release(); r.plan_kind.release(); r.plan_nrows.release(); r.plan_cmb.release(); r.plan_colmap.release();
     r.plan_cols.release();
   }
@@ -593,6 +644,9 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
     f.prior_e.release();
     f.prior_n.release();
   }
+  s->tail_counts.release();
+  if (s->h_counts) (void)hipHostFree(s->h_counts);
+  for (auto e : s->prof_ev) (void)hipEventDestroy(e);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
   if (s->evs) (void)hipEventDestroy(s->evs);
@@ -609,6 +663,76 @@ static T* scratch(pclean_ctx* ctx, size_t count) {
   DevBuf<unsigned char>& b = s->pool[s->pool_used++];
   if (b.alloc(std::max<size_t>(count * sizeof(T), 16))) return nullptr;
   return (T*)b.p;
+}
+
+// ---- per-phase profile (pclean_set_profiling): HIP events on the library's stream around groups of launches
+static int prof_phase_id(SweepState* s, const char* name) {
+  for (size_t i = 0; i < s->prof_names.size(); ++i)
+    if (s->prof_names[i] == name) return (int)i;
+  s->prof_names.push_back(name);
+  s->prof_ms.push_back(0.f);
+  s->prof_launches.push_back(0);
+  return (int)s->prof_names.size() - 1;
+}
+struct ProfScope {  // records start at construction, stop at destruction
+  pclean_ctx* ctx;
+  SweepState* s;
+  size_t rec = (size_t)-1;
+  ProfScope(pclean_ctx* c, const char* name) : ctx(c), s(st(c)) {
+    if (!s->prof_on) return;
+    rec = s->prof_used++;
+    while (s->prof_ev.size() < 2 * (rec + 1)) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) {
+        rec = (size_t)-1;
+        --s->prof_used;
+        return;
+      }
+      s->prof_ev.push_back(e);
+    }
+    if (s->prof_phase.size() <= rec) s->prof_phase.resize(rec + 1);
+    s->prof_phase[rec] = prof_phase_id(s, name);
+    (void)hipEventRecord(s->prof_ev[2 * rec], ctx->stream);
+  }
+  ~ProfScope() {
+    if (rec != (size_t)-1) (void)hipEventRecord(s->prof_ev[2 * rec + 1], ctx->stream);
+  }
+};
+static void prof_collect(pclean_ctx* ctx) {  // after the stream has been synchronised
+  SweepState* s = st(ctx);
+  for (size_t r = 0; r < s->prof_used; ++r) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, s->prof_ev[2 * r], s->prof_ev[2 * r + 1]) == hipSuccess) {
+      s->prof_ms[s->prof_phase[r]] += ms;
+      s->prof_launches[s->prof_phase[r]] += 1;
+    }
+  }
+  s->prof_used = 0;
+}
+
+extern "C" int pclean_set_profiling(pclean_ctx* ctx, int32_t on) {
+  if (!ctx) return PCLEAN_ERR_ARG;
+  SweepState* s = st(ctx);
+  s->prof_on = on != 0;
+  s->prof_used = 0;
+  std::fill(s->prof_ms.begin(), s->prof_ms.end(), 0.f);
+  std::fill(s->prof_launches.begin(), s->prof_launches.end(), 0);
+  return PCLEAN_OK;
+}
+extern "C" int pclean_get_profile(pclean_ctx* ctx, int32_t cap, char* names, float* ms, int32_t* launches,
+                                  int32_t* n_out) {
+  if (!ctx || !n_out || cap < 0) return PCLEAN_ERR_ARG;
+  SweepState* s = st(ctx);
+  *n_out = (int32_t)s->prof_names.size();
+  for (int i = 0; i < cap && i < *n_out; ++i) {
+    if (names) {
+      strncpy(names + (size_t)i * 32, s->prof_names[i].c_str(), 31);
+      names[(size_t)i * 32 + 31] = 0;
+    }
+    if (ms) ms[i] = s->prof_ms[i];
+    if (launches) launches[i] = s->prof_launches[i];
+  }
+  return PCLEAN_OK;
 }
 
 static int build_gauss_dev(pclean_ctx* ctx, const pclean_gauss& g, const CandTable* t, GaussDev& d) {
@@ -754,7 +878,7 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
   return PCLEAN_OK;
 }
 
-// Fast path of a block root (root_fast.hip): returns 1 and fills `fr` when the node is an FK
+// Fast path of a reference slot (root_wave.hip): returns 1 and fills `fr` when the node is an FK
 // with many candidates whose terms are all plain AddTypos lookups in byte tables; 0 otherwise.
 static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev& fr) {
   Block& b = ctx->block[block_id];
@@ -774,9 +898,6 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   }
   if (lmax > 255 || dmax > 255) return 0;
   const int kpad = (t.n_rows + 15) & ~15;
-  const size_t lds = (size_t)((t.n_rows + 2) & ~1) * 8 + (size_t)(((lmax + 1) * (dmax + 1) + 1) & ~1) * 8 + 1024;
-  (void)lds;
-  if (pclean_fast_lds_bytes(lmax, dmax + 1) > 160 * 1024) return 0;
   FastRoot& f = st(ctx)->fast[block_id * 64 + node_id];
   if ((int)f.comp.size() != n.n_terms || f.kpad != kpad) {
     for (auto& c : f.comp) c.release();
@@ -856,9 +977,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     } else {
       fr.inv_c = 1.0 / (cmin * (1.0 - 1e-9));
     }
-    fr.chunk_rounds = 16;
-    if (const char* e = getenv("PCLEAN_FAST_CHUNK")) fr.chunk_rounds = std::max(1, std::min(16, atoi(e)));
-    fr.pad2 = 0;
+    fr.pad1 = fr.pad2 = 0;
     fr.prior_max_e = f.logc_max - t.scal[1];
     fr.prior_max_n = f.logc_max - t.scal[0];
   }
@@ -889,6 +1008,50 @@ struct ItemGroups {
 };
 static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
                             ItemGroups& g);
+// Upper bound of the log-marginal of plan sub-tree `node_id` (gate_new_kernel, enum_kernels.hip): every term
+// density of the sub-tree must be a probability mass (<= 1); +inf when it is not (Gaussian terms).
+static double subtree_ub(pclean_ctx* ctx, const Block& b, int node_id) {
+  const pclean_node& n = b.nodes[node_id];
+  if (node_id < (int)b.node_gauss.size() && b.node_gauss[node_id] >= 0) return INFINITY;
+  CandTable& t = ctx->cand[n.table];
+  if (n.kind == PCLEAN_NODE_LEAF) {
+    if (t.h_lse_ver != t.version) {  // log-sum of the option prior, once per upload
+      double m = -INFINITY, acc = 0.0;
+      for (double v : t.h_logc_full) m = std::max(m, v);
+      if (m > -INFINITY)
+        for (double v : t.h_logc_full) acc += std::exp(v - m);
+      t.h_lse = m > -INFINITY ? m + std::log(acc) + 1e-9 : -INFINITY;
+      t.h_lse_ver = t.version;
+    }
+    return t.h_lse;
+  }
+  double sum = 0.0;
+  for (int c = 0; c < n.n_children; ++c) sum += subtree_ub(ctx, b, b.children[n.child_begin + c]);
+  return std::max(0.0, sum);  // log(a + b e^X) <= max(0, X) for a + b <= 1 (CRP prior over rows + new)
+}
+
+__global__ void scatter_f64_kernel(int n, const int32_t* list, const double* src, double* dst) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) dst[list[j]] = src[j];
+}
+// attributes of the items list[j] of a parent list
+__global__ void sub_items_kernel(int n, const int32_t* list, const int32_t* p_row, const int32_t* p_ctx,
+                                 const int32_t* p_excl, const int32_t* p_ev_lo, const int32_t* p_ev_hi,
+                                 const int32_t* p_rng, int32_t* row, int32_t* ctxv, int32_t* excl, int32_t* ev_lo,
+                                 int32_t* ev_hi, int32_t* rng) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int s = list[j];
+  row[j] = p_row ? p_row[s] : s;
+  excl[j] = p_excl ? p_excl[s] : -1;
+  for (int c = 0; c < PCLEAN_MAX_CTX; ++c) ctxv[j * PCLEAN_MAX_CTX + c] = p_ctx ? p_ctx[(size_t)s * PCLEAN_MAX_CTX + c] : 0;
+  if (p_ev_lo) {
+    ev_lo[j] = p_ev_lo[s];
+    ev_hi[j] = p_ev_hi[s];
+  }
+  if (p_rng) rng[j] = p_rng[s];
+}
+
 static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
                      uint64_t seed, uint32_t sweep, int n_draws, double* lse_out, int32_t* draws_out,
                      double* scores_out, const double* snew_override, bool time_it) {
@@ -899,6 +1062,8 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   int rc = build_node_dev(ctx, b, node_id, nd);
   if (rc) return rc;
   ChildrenDev ch{};
+  ItemsDev it{il.n, 0, il.row, il.ctx, excl, n_draws == 1 ? il.particle : nullptr, s->row_offset + ctx->active_begin,
+              nullptr, il.ev_lo, il.ev_hi, il.ev_rows, il.ev_ctx, il.rng_row, nullptr, nullptr, il.draw_is, il.draw_ds};
   if (n.kind == PCLEAN_NODE_FK) {
     if (snew_override) {
       ch.n = 1;
@@ -908,35 +1073,105 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
       if (n.n_children > PCLEAN_MAX_CHILDREN) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "too many children");
       ch.n = n.n_children;
       const CandTable& t = ctx->cand[n.table];
+      // cacheable leaves first: exact marginal per unique observed value (versioned cache)
+      GateDev gt{};
+      gt.n = n.n_children;
+      int n_open = 0;
+      // (short lists — new-row sampling, tests — are not worth the extra launches and the count read-back)
+      const char* gm = getenv("PCLEAN_GATE_MIN");
+      const int gate_min = gm ? atoi(gm) : 2048;
+      bool gate = excl && !scores_out && il.n >= gate_min && !getenv("PCLEAN_NO_GATE");
       for (int c = 0; c < n.n_children; ++c) {
         const int cid = b.children[n.child_begin + c];
         const pclean_node& cn = b.nodes[cid];
         if (cn.kind == PCLEAN_NODE_LEAF && cn.cacheable) {
           rc = ensure_leaf_cache(ctx, block_id, cid, &ch.arr[c], &ch.obs_col[c], &ch.n_obs[c]);
           if (rc) return rc;
+          gt.cache[c] = ch.arr[c];
+          gt.obs_col[c] = ch.obs_col[c];
+          gt.n_obs[c] = ch.n_obs[c];
+          gt.ub[c] = 0.0;
+          if (il.ev_lo) gt.ub[c] = subtree_ub(ctx, b, cid);  // evidence sets: no single observed row to look up
         } else {
-          double* child_lse = scratch<double>(ctx, il.n);
-          if (!child_lse) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-          const int32_t* child_excl = nullptr;
-          if (cn.kind == PCLEAN_NODE_FK && excl) {
-            if (cn.parent_fk_col < 0 || cn.parent_fk_col >= t.n_cols)
-              return pclean_fail(ctx, PCLEAN_ERR_ARG, "node %d: parent_fk_col out of range", cid);
-            int32_t* ce = scratch<int32_t>(ctx, il.n);
-            if (!ce) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-            hipLaunchKernelGGL(derive_excl_kernel, grid1(il.n), dim3(256), 0, ctx->stream, il.n, excl, t.counts.p,
-                               t.cols.p + (size_t)cn.parent_fk_col * t.n_rows, ce);
-            child_excl = ce;
-          }
-          rc = eval_node_lse(ctx, block_id, cid, il, child_excl, seed, sweep, child_lse);
-          if (rc) return rc;
-          ch.arr[c] = child_lse;
-          ch.obs_col[c] = nullptr;
+          ++n_open;
+          gt.cache[c] = nullptr;
+          gt.ub[c] = subtree_ub(ctx, b, cid);
+          if (!(gt.ub[c] < INFINITY)) gate = false;
         }
+        if (il.ev_lo && !(gt.ub[c] < INFINITY)) gate = false;
+      }
+      // Gate of the new-row branch (gate_new_kernel): items whose current referent scores so well that
+      // the new row's fixed-point weight is exactly 0 skip the evaluation of the open children.
+      int32_t* list = nullptr;
+      unsigned int n_need = (unsigned int)il.n;
+      if (gate && n_open > 0) {
+        ProfScope ps(ctx, "gate_new_branch");
+        int32_t* flag = scratch<int32_t>(ctx, il.n);
+        list = scratch<int32_t>(ctx, il.n);
+        if (!flag || !list) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+        if (s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+        rc = pclean_launch_gate(ctx, nd, it, gt, flag);
+        if (rc) return rc;
+        HIPCHK(ctx, hipMemsetAsync(s->counter.p + 2, 0, sizeof(unsigned int), ctx->stream));
+        hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, flag, 1,
+                           s->counter.p + 2, list, nullptr);
+        HIPCHK(ctx, hipMemcpyAsync(&n_need, s->counter.p + 2, sizeof n_need, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      } else {
+        gate = false;
+      }
+      const bool sub = gate && n_need < (unsigned int)il.n;
+      ItemList sil = il;
+      const int32_t* sexcl = excl;
+      if (sub && n_need > 0) {
+        int32_t* row2 = scratch<int32_t>(ctx, n_need);
+        int32_t* ctx2 = scratch<int32_t>(ctx, (size_t)n_need * PCLEAN_MAX_CTX);
+        int32_t* excl2 = scratch<int32_t>(ctx, n_need);
+        int32_t* evl2 = il.ev_lo ? scratch<int32_t>(ctx, n_need) : nullptr;
+        int32_t* evh2 = il.ev_lo ? scratch<int32_t>(ctx, n_need) : nullptr;
+        int32_t* rng2 = il.rng_row ? scratch<int32_t>(ctx, n_need) : nullptr;
+        if (!row2 || !ctx2 || !excl2 || (il.ev_lo && (!evl2 || !evh2)) || (il.rng_row && !rng2))
+          return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+        hipLaunchKernelGGL(sub_items_kernel, grid1(n_need), dim3(256), 0, ctx->stream, (int)n_need, list, il.row, il.ctx,
+                           excl, il.ev_lo, il.ev_hi, il.rng_row, row2, ctx2, excl2, evl2, evh2, rng2);
+        sil = ItemList{(int)n_need, row2, il.ctx ? ctx2 : nullptr, nullptr, nullptr, evl2, evh2, il.ev_rows, il.ev_ctx, rng2};
+        sexcl = excl2;
+      }
+      for (int c = 0; c < n.n_children; ++c) {
+        const int cid = b.children[n.child_begin + c];
+        const pclean_node& cn = b.nodes[cid];
+        if (cn.kind == PCLEAN_NODE_LEAF && cn.cacheable) continue;
+        double* child_lse = scratch<double>(ctx, il.n);
+        if (!child_lse) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+        ch.arr[c] = child_lse;
+        ch.obs_col[c] = nullptr;
+        if (sub) {  // gated items: the child's marginal is never looked at with a non-zero weight
+          hipLaunchKernelGGL(fill_f64_kernel, grid1(il.n), dim3(256), 0, ctx->stream, child_lse, (size_t)il.n,
+                             -__builtin_inf());
+          if (n_need == 0) continue;
+        }
+        const int32_t* child_excl = nullptr;
+        if (cn.kind == PCLEAN_NODE_FK && sexcl) {
+          if (cn.parent_fk_col < 0 || cn.parent_fk_col >= t.n_cols)
+            return pclean_fail(ctx, PCLEAN_ERR_ARG, "node %d: parent_fk_col out of range", cid);
+          int32_t* ce = scratch<int32_t>(ctx, sil.n);
+          if (!ce) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+          hipLaunchKernelGGL(derive_excl_kernel, grid1(sil.n), dim3(256), 0, ctx->stream, sil.n, sexcl, t.counts.p,
+                             t.cols.p + (size_t)cn.parent_fk_col * t.n_rows, ce);
+          child_excl = ce;
+        }
+        double* dst = child_lse;
+        if (sub) {
+          dst = scratch<double>(ctx, sil.n);
+          if (!dst) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+        }
+        rc = eval_node_lse(ctx, block_id, cid, sil, child_excl, seed, sweep, dst);
+        if (rc) return rc;
+        if (sub)
+          hipLaunchKernelGGL(scatter_f64_kernel, grid1(sil.n), dim3(256), 0, ctx->stream, sil.n, list, dst, child_lse);
       }
     }
   }
-  ItemsDev it{il.n, 0, il.row, il.ctx, excl, n_draws == 1 ? il.particle : nullptr, s->row_offset + ctx->active_begin,
-              nullptr, il.ev_lo, il.ev_hi, il.ev_rows, il.ev_ctx, il.rng_row, nullptr, nullptr};
   FastRootDev fr;
   int fast = 0;
   if (!scores_out && !snew_override && !ctx->force_generic && !il.ev_lo && !nd.g.on) {
@@ -944,7 +1179,7 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     if (fast < 0) return fast;
   }
   // Items with identical score vectors (same observed tuple, ctx and excluded row) share one
-  // workgroup: scores once, draws per member item.
+  // wavefront / workgroup: scores once, draws per member item.
   {
     const int nc = nd.n_cand + (n.kind == PCLEAN_NODE_FK ? 1 : 0);
     const bool lds_kernel = (size_t)((nc + 1) & ~1) * 8 + (16 + 64) * 8 <= 160 * 1024;
@@ -960,7 +1195,23 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     }
   }
   const uint32_t site = PCLEAN_SITE_NODE(block_id, node_id);
+  if (time_it) {
+    pclean_root_stats& rs = ctx->root_stats;
+    rs = pclean_root_stats{};
+    rs.fast = fast;
+    rs.n_items = il.n;
+    rs.n_groups = it.n;
+    rs.n_cand = nd.n_cand;
+    rs.n_terms = n.n_terms;
+    rs.n_draws = n_draws;
+    if (fast) {
+      rs.kpad = fr.kpad;
+      rs.n_pre = fr.n_pre;
+      for (int p = 0; p < 3; ++p) rs.pre_obs_col[p] = p < fr.n_pre ? b.terms[n.term_begin + fr.pre[p]].obs_col : -1;
+    }
+  }
   if (!fast) {
+    ProfScope ps(ctx, n.kind == PCLEAN_NODE_FK ? "enum_fk_generic" : "enum_leaf_generic");
     if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
     rc = pclean_launch_enum(ctx, nd, it, ch, seed, sweep, site, n_draws, lse_out, scores_out, draws_out);
     if (time_it) (void)hipEventRecord(s->ev1, ctx->stream);
@@ -968,21 +1219,27 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   }
   // compact-table kernel; items whose survivor list overflows are re-run with the generic kernel
   int32_t* oflag = scratch<int32_t>(ctx, il.n);
-  if (!oflag || s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  int32_t* desc = scratch<int32_t>(ctx, pclean_fast_desc_words(it.n));
+  if (!oflag || !desc || s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   HIPCHK(ctx, hipMemsetAsync(s->counter.p + 1, 0, sizeof(unsigned int), ctx->stream));
-  if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
-  rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag,
-                               s->counter.p + 1);
-  if (time_it) (void)hipEventRecord(s->ev1, ctx->stream);
+  {
+    ProfScope ps(ctx, time_it ? "root_scan_block0" : "slot_scan");
+    if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
+    rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag,
+                                 s->counter.p + 1, desc);
+    if (time_it) (void)hipEventRecord(s->ev1, ctx->stream);
+  }
   if (rc) return rc;
   unsigned int n_over = 0;
   HIPCHK(ctx, hipMemcpyAsync(&n_over, s->counter.p + 1, sizeof n_over, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timing.reserved += (int32_t)n_over;  // items that fell back to the generic kernel
+  if (time_it) ctx->root_stats.overflow_items = (int32_t)n_over;
   if (n_over && getenv("PCLEAN_DEBUG_OVERFLOW"))
     fprintf(stderr, "[pclean] block %d node %d: %u of %d items re-run by the generic kernel\n", block_id, node_id, n_over,
             il.n);
   if (n_over) {
+    ProfScope ps(ctx, "overflow_rerun");
     int32_t* list = scratch<int32_t>(ctx, n_over);
     int32_t* row2 = scratch<int32_t>(ctx, n_over);
     int32_t* excl2 = scratch<int32_t>(ctx, n_over);
@@ -995,7 +1252,8 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     hipLaunchKernelGGL(gather_items_kernel, grid1(n_over), dim3(256), 0, ctx->stream, (int)n_over, list, il.row,
                        il.ctx, excl, it.particle, row2, ctx2, excl2, part2);
     ItemsDev it2{(int)n_over, 0, row2, il.ctx ? ctx2 : nullptr, excl ? excl2 : nullptr, it.particle ? part2 : nullptr,
-                 s->row_offset + ctx->active_begin, list, nullptr, nullptr, nullptr, nullptr, nullptr};
+                 s->row_offset + ctx->active_begin, list, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                 il.draw_is, il.draw_ds};
     rc = pclean_launch_enum(ctx, nd, it2, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out);
   }
   return rc;
@@ -1331,6 +1589,9 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   if (!ctx || !cfg || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid || n_roots <= 0 ||
       !roots || n_items < 0 || !keys || !ev_off || !excl || !chosen || !vals)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: bad arguments");
+  if (!cfg->use_dd_proposals)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: use_dd_proposals = false (prior proposals, "
+                                            "block_proposal.jl:168) is not implemented by the HIP path");
   if (n_items == 0) return PCLEAN_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   Block& b = ctx->block[block_id];
@@ -1498,11 +1759,19 @@ extern "C" int pclean_score_node(pclean_ctx* ctx, int32_t block_id, int32_t node
 }
 
 // ---------------------------------------------------------------------------
+__global__ void gather_moved_kernel(int n, const int32_t* list, const int32_t* choice, int32_t* out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) out[j] = choice[list[j]];
+}
+
 extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
                             int32_t n_blocks, const int32_t* cur, int32_t* choice, int32_t* chosen_particle,
                             double* logml) {
-  if (!ctx || !cfg || n_blocks <= 0 || n_blocks > PCLEAN_MAX_BLOCKS || !cur || !choice)
+  if (!ctx || !cfg || n_blocks <= 0 || n_blocks > PCLEAN_MAX_BLOCKS || !cur)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: bad arguments");
+  if (!cfg->use_dd_proposals)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: use_dd_proposals = false (prior proposals, "
+                                            "block_proposal.jl:168) is not implemented by the HIP path");
   const int N = ctx->active_count >= 0 ? ctx->active_count : ctx->n_rows;
   int P = cfg->num_particles;
   const int use_mh = cfg->use_mh_instead_of_pg != 0;
@@ -1520,15 +1789,24 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     HIPCHK(ctx, hipEventCreate(&s->evs));
     HIPCHK(ctx, hipEventCreate(&s->eve));
   }
+  if (!s->h_counts) HIPCHK(ctx, hipHostMalloc((void**)&s->h_counts, 4 * PCLEAN_MAX_BLOCKS * sizeof(int32_t), hipHostMallocDefault));
   const size_t NP = (size_t)N * P;
   if (s->cur.alloc((size_t)N * n_blocks) || s->chosen.alloc(N) || s->ancestors.alloc(NP) || s->w.alloc(NP) ||
       s->log_total.alloc(N) || s->logml_inc.alloc(N) || s->logml_acc.alloc(N) || s->logml.alloc(N) ||
-      s->counter.alloc(4) || s->arr_ptrs.alloc(2 * PCLEAN_MAX_BLOCKS) || s->did.alloc(N))
+      s->counter.alloc(4) || s->arr_ptrs.alloc(2 * PCLEAN_MAX_BLOCKS) || s->did.alloc(N) ||
+      s->tail_counts.alloc(2 * PCLEAN_MAX_BLOCKS))
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-  HIPCHK(ctx, hipMemcpyAsync(s->cur.p, cur, (size_t)N * n_blocks * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (ctx->cur_stride > 0 && ctx->cur_stride != N) {
+    if (ctx->cur_stride < N) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: cur stride smaller than the active window");
+    for (int b = 0; b < n_blocks; ++b)
+      HIPCHK(ctx, hipMemcpyAsync(s->cur.p + (size_t)b * N, cur + (size_t)b * ctx->cur_stride, (size_t)N * 4,
+                                 hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    HIPCHK(ctx, hipMemcpyAsync(s->cur.p, cur, (size_t)N * n_blocks * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
   (void)hipEventRecord(s->evs, ctx->stream);
-  hipLaunchKernelGGL(fill_f64_kernel, grid1(NP), dim3(256), 0, ctx->stream, s->w.p, NP, 0.0);
-  hipLaunchKernelGGL(fill_f64_kernel, grid1(N), dim3(256), 0, ctx->stream, s->logml_acc.p, (size_t)N, 0.0);
+  HIPCHK(ctx, hipMemsetAsync(s->w.p, 0, NP * sizeof(double), ctx->stream));           // +0.0
+  HIPCHK(ctx, hipMemsetAsync(s->logml_acc.p, 0, (size_t)N * sizeof(double), ctx->stream));
   ctx->timing = pclean_timing{};
   float hot_ms = 0.f;
 
@@ -1538,6 +1816,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     if (b.is_score) {
       // pure scoring block: every particle's weight += sum of its observed choices' log-densities
       if (bi != n_blocks - 1) return pclean_fail(ctx, PCLEAN_ERR_ARG, "a scoring block must be the last block");
+      ProfScope ps(ctx, "score_block");
       ScoreBlockDev sb{};
       auto make_src = [&](int blk, int col, SrcDev& out) -> int {
         if (blk < 0 || blk >= bi || ctx->block[blk].is_score) return pclean_fail(ctx, PCLEAN_ERR_ARG, "score block: bad source block");
@@ -1577,7 +1856,8 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     }
     const int nn = (int)b.nodes.size();
     const int32_t* cur_b = s->cur.p + (size_t)bi * N;
-    if (r.pchoice.alloc(NP) || r.pnewpos.alloc(NP) || r.choice.alloc(N) || r.chosen_newpos.alloc(N))
+    if (r.pchoice.alloc(NP) || r.pnewpos.alloc(NP) || r.choice.alloc(N) || r.chosen_newpos.alloc(N) ||
+        r.moved_flag.alloc(N) || r.new_flag.alloc(N) || r.moved_list.alloc(N) || r.new_list.alloc(N))
       return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
     int rc = ensure_plan_dev(ctx, bi);
     if (rc) return rc;
@@ -1586,6 +1866,8 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     const int32_t* excl;
     if (!has_ctx) {
       il = ItemList{N, nullptr, nullptr, nullptr, nullptr};
+      il.draw_is = 1;   // particle-major draws: slot = particle * N + row
+      il.draw_ds = N;
       excl = cur_b;
       if (r.draws.alloc(NP) || r.lse.alloc(N)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
       rc = eval_node(ctx, bi, 0, il, excl, seed, sweep_idx, P, r.lse.p, r.draws.p, nullptr, nullptr, bi == 0);
@@ -1597,13 +1879,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         hot_ms += ms;
         ctx->timing.hot_kernel_launches += 1;
       }
+      ProfScope ps(ctx, "particle_update");
       hipLaunchKernelGGL(add_weight_shared_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, r.lse.p, s->w.p);
     } else {
-      if (r.it_row.alloc(NP) || r.it_particle.alloc(NP) || r.it_excl.alloc(NP) ||
-          r.it_ctx.alloc(NP * PCLEAN_MAX_CTX) || r.draws.alloc(NP) || r.lse.alloc(NP))
-        return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-      hipLaunchKernelGGL(build_ctx_items_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, cur_b, r.it_row.p,
-                         r.it_particle.p, r.it_excl.p);
+      if (r.it_ctx.alloc(NP * PCLEAN_MAX_CTX) || r.draws.alloc(NP)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
       CtxSrc cs{};
       cs.n_ctx = b.n_ctx;
       for (int c = 0; c < b.n_ctx; ++c) {
@@ -1620,82 +1899,87 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         cs.col[c] = b.ctx_src_col[c];
         cs.plan[c] = s->run[sb].plan;
       }
-      hipLaunchKernelGGL(gather_ctx_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, cs, r.it_ctx.p);
       // One enumeration per distinct (row, context): particles whose earlier choices give the same
       // context share the candidate scores and differ only in their Philox draws.
-      int32_t* repflag = scratch<int32_t>(ctx, NP);
       int32_t* rep = scratch<int32_t>(ctx, NP);
-      int32_t* pos = scratch<int32_t>(ctx, NP);
-      if (!repflag || !rep || !pos) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-      hipLaunchKernelGGL(dedup_ctx_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, r.it_ctx.p, repflag, rep);
-      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-      hipLaunchKernelGGL(compact_new_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, repflag, 0, s->counter.p,
-                         nullptr, nullptr);
+      int32_t* slot_item = scratch<int32_t>(ctx, NP);
+      int32_t* n_distinct = scratch<int32_t>(ctx, (size_t)N + 1);
+      int32_t* off = scratch<int32_t>(ctx, (size_t)N + 1);
+      size_t tmp_scan = 0;
+      HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, n_distinct, off, N + 1, ctx->stream));
+      unsigned char* tmp = scratch<unsigned char>(ctx, tmp_scan);
+      if (!rep || !slot_item || !n_distinct || !off || !tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
       unsigned int n_items = 0;
-      HIPCHK(ctx, hipMemcpyAsync(&n_items, s->counter.p, sizeof n_items, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-      int32_t* list = scratch<int32_t>(ctx, n_items);
+      {
+        ProfScope ps(ctx, "ctx_items");
+        hipLaunchKernelGGL(gather_ctx_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, cs, r.it_ctx.p);
+        HIPCHK(ctx, hipMemsetAsync(n_distinct + N, 0, sizeof(int32_t), ctx->stream));
+        hipLaunchKernelGGL(ctx_count_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, r.it_ctx.p, rep, n_distinct);
+        HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_scan, n_distinct, off, N + 1, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(&n_items, off + N, sizeof n_items, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      }
       int32_t* d_row = scratch<int32_t>(ctx, n_items);
       int32_t* d_ctx = scratch<int32_t>(ctx, (size_t)n_items * PCLEAN_MAX_CTX);
       int32_t* d_excl = scratch<int32_t>(ctx, n_items);
       double* lse_item = scratch<double>(ctx, n_items);
       int32_t* draws_item = scratch<int32_t>(ctx, (size_t)n_items * P);
-      if (!list || !d_row || !d_ctx || !d_excl || !lse_item || !draws_item)
+      if (!d_row || !d_ctx || !d_excl || !lse_item || !draws_item)
         return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-      hipLaunchKernelGGL(compact_new_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, repflag, 1, s->counter.p, list,
-                         pos);
-      hipLaunchKernelGGL(ctx_items_kernel, grid1(n_items), dim3(256), 0, ctx->stream, (int)n_items, P, list,
-                         r.it_ctx.p, cur_b, d_row, d_ctx, d_excl);
+      hipLaunchKernelGGL(ctx_fill_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, r.it_ctx.p, rep, off, cur_b, slot_item,
+                         d_row, d_ctx, d_excl);
       il = ItemList{(int)n_items, d_row, d_ctx, nullptr, nullptr};
       rc = eval_node(ctx, bi, 0, il, d_excl, seed, sweep_idx, P, lse_item, draws_item, nullptr, nullptr, false);
       if (rc) return rc;
-      hipLaunchKernelGGL(expand_ctx_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, P, rep, pos, lse_item,
+      ProfScope ps(ctx, "particle_update");
+      hipLaunchKernelGGL(expand_ctx_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, N, P, slot_item, lse_item,
                          draws_item, r.draws.p, s->w.p);
     }
-    hipLaunchKernelGGL(set_pchoice_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, r.draws.p, cur_b, r.pchoice.p);
-
-    // ---- particles that proposed a NEW referent: sample the new row's contents
-    HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(compact_new_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, r.pchoice.p, 0, s->counter.p,
-                       nullptr, nullptr);
     unsigned int n_new = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&n_new, s->counter.p, sizeof n_new, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    {
+      ProfScope ps(ctx, "particle_update");
+      hipLaunchKernelGGL(set_pchoice_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, r.draws.p, cur_b, r.pchoice.p);
+      // ---- particles that proposed a NEW referent: sample the new row's contents
+      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+      hipLaunchKernelGGL(compact_new_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, r.pchoice.p, 0, s->counter.p,
+                         nullptr, nullptr);
+      HIPCHK(ctx, hipMemcpyAsync(&n_new, s->counter.p, sizeof n_new, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
     r.n_new = (int)n_new;
     if (r.vals.alloc(std::max<size_t>((size_t)n_new * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-    {
-      int32_t* list = scratch<int32_t>(ctx, std::max(n_new, 1u));
+    if (n_new) {
+      ProfScope ps(ctx, "new_row_sampling");
+      int32_t* list = scratch<int32_t>(ctx, n_new);
       if (!list) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
       hipLaunchKernelGGL(compact_new_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, r.pchoice.p, 1, s->counter.p,
                          list, r.pnewpos.p);
-      if (n_new) {
-        hipLaunchKernelGGL(fill_i32_kernel, grid1((size_t)n_new * nn), dim3(256), 0, ctx->stream, r.vals.p,
-                           (size_t)n_new * nn, -2);
-        int32_t* row = scratch<int32_t>(ctx, n_new);
-        int32_t* cx = scratch<int32_t>(ctx, (size_t)n_new * PCLEAN_MAX_CTX);
-        int32_t* part = scratch<int32_t>(ctx, n_new);
-        int32_t* org = scratch<int32_t>(ctx, n_new);
-        int32_t* ex = scratch<int32_t>(ctx, n_new);
-        if (!row || !cx || !part || !org || !ex) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-        hipLaunchKernelGGL(rootlist_items_kernel, grid1(n_new), dim3(256), 0, ctx->stream, (int)n_new, P, list,
-                           has_ctx ? r.it_ctx.p : nullptr, has_ctx ? 1 : 0, cur_b, row, cx, part, org, ex);
-        hipLaunchKernelGGL(set_col_kernel, grid1(n_new), dim3(256), 0, ctx->stream, (int)n_new, nn, 0,
-                           (int32_t)PCLEAN_CHOICE_NEW, r.vals.p);
-        ItemList sub{(int)n_new, row, cx, part, org};
-        rc = sample_children(ctx, bi, 0, sub, ex, seed, sweep_idx, r.vals.p, nn);
-        if (rc) return rc;
-      }
+      hipLaunchKernelGGL(fill_i32_kernel, grid1((size_t)n_new * nn), dim3(256), 0, ctx->stream, r.vals.p,
+                         (size_t)n_new * nn, -2);
+      int32_t* row = scratch<int32_t>(ctx, n_new);
+      int32_t* cx = scratch<int32_t>(ctx, (size_t)n_new * PCLEAN_MAX_CTX);
+      int32_t* part = scratch<int32_t>(ctx, n_new);
+      int32_t* org = scratch<int32_t>(ctx, n_new);
+      int32_t* ex = scratch<int32_t>(ctx, n_new);
+      if (!row || !cx || !part || !org || !ex) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      hipLaunchKernelGGL(rootlist_items_kernel, grid1(n_new), dim3(256), 0, ctx->stream, (int)n_new, N, NP, list,
+                         has_ctx ? r.it_ctx.p : nullptr, cur_b, row, cx, part, org, ex);
+      hipLaunchKernelGGL(set_col_kernel, grid1(n_new), dim3(256), 0, ctx->stream, (int)n_new, nn, 0,
+                         (int32_t)PCLEAN_CHOICE_NEW, r.vals.p);
+      ItemList sub{(int)n_new, row, cx, part, org};
+      rc = sample_children(ctx, bi, 0, sub, ex, seed, sweep_idx, r.vals.p, nn);
+      if (rc) return rc;
     }
+    // (pnewpos is only read where pchoice == NEW, so it needs no initialisation when nobody proposed one)
 
     // ---- resampling between blocks (row_inference.jl:152-155)
     if (!use_mh && bi < n_blocks - 1) {
-      hipLaunchKernelGGL(maybe_resample_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p, 1, cur_b, seed,
-                         sweep_idx, (uint32_t)bi, s->row_offset + ctx->active_begin, s->ancestors.p, s->logml_inc.p, (double*)nullptr,
-                         s->did.p);
-      hipLaunchKernelGGL(add_weight_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, s->logml_inc.p,
-                         s->logml_acc.p);
+      ProfScope ps(ctx, "resample");
+      DISPATCH_PMAX(P, hipLaunchKernelGGL(maybe_resample_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p,
+                                          (size_t)1, (size_t)N, 1, cur_b, seed, sweep_idx, (uint32_t)bi,
+                                          s->row_offset + ctx->active_begin, s->ancestors.p, s->logml_inc.p,
+                                          (double*)nullptr, s->did.p));
       std::vector<int32_t*> ptrs;
       for (int k = 0; k <= bi; ++k) {
         if (ctx->block[k].is_score) continue;
@@ -1704,138 +1988,109 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       }
       HIPCHK(ctx, hipMemcpyAsync(s->arr_ptrs.p, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice,
                                  ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // ptrs goes out of scope
       hipLaunchKernelGGL(apply_ancestors_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->ancestors.p,
-                         (int)ptrs.size(), s->arr_ptrs.p, s->w.p, s->did.p);
+                         (int)ptrs.size(), s->arr_ptrs.p, s->w.p, s->did.p, s->logml_inc.p, s->logml_acc.p);
     }
   }
 
-  // ---- final choice + outputs
-  hipLaunchKernelGGL(final_choice_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p, use_mh, 1, s->cur.p, seed,
-                     sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->log_total.p);
-  hipLaunchKernelGGL(finish_logml_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->log_total.p, s->logml_acc.p,
-                     s->logml.p);
-  for (int bi = 0; bi < n_blocks; ++bi) {
-    BlockRun& r = s->run[bi];
-    const int32_t* cur_b = s->cur.p + (size_t)bi * N;
-    if (ctx->block[bi].is_score) {
-      for (int i = 0; i < N; ++i) choice[(size_t)bi * N + i] = 0;
-      continue;
+  // ---- final choice + per-block outputs: one pass per block, ordered compaction of the rows that moved /
+  // got a new referent (hipcub select keeps ascending row order), ONE read-back of the counts
+  {
+    ProfScope ps(ctx, "final_choice_and_outputs");
+    DISPATCH_PMAX(P, hipLaunchKernelGGL(final_choice_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p,
+                                        (size_t)1, (size_t)N, use_mh, 1, s->cur.p, seed, sweep_idx,
+                                        s->row_offset + ctx->active_begin, s->chosen.p, (double*)nullptr,
+                                        s->logml_acc.p, s->logml.p));
+    size_t tmp_sel = 0;
+    HIPCHK(ctx, hipcub::DeviceSelect::Flagged(nullptr, tmp_sel, hipcub::CountingInputIterator<int32_t>(0),
+                                              (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, N,
+                                              ctx->stream));
+    unsigned char* tmp = scratch<unsigned char>(ctx, std::max<size_t>(tmp_sel, 16));
+    if (!tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    for (int bi = 0; bi < n_blocks; ++bi) {
+      BlockRun& r = s->run[bi];
+      Block& bb = ctx->block[bi];
+      bb.locals_host.clear();
+      if (bb.is_score) continue;
+      const int32_t* cur_b = s->cur.p + (size_t)bi * N;
+      CandTable& rt = ctx->cand[bb.nodes[0].table];
+      HIPCHK(ctx, hipMemsetAsync(rt.stats.p, 0, (size_t)std::max(rt.n_rows, 1) * 8, ctx->stream));
+      hipLaunchKernelGGL(finalize_block_kernel, grid1(N), dim3(256), 0, ctx->stream, N, s->chosen.p, r.pchoice.p,
+                         r.pnewpos.p, cur_b, r.choice.p, r.chosen_newpos.p, (unsigned long long*)rt.stats.p,
+                         r.moved_flag.p, r.new_flag.p);
+      HIPCHK(ctx, hipcub::DeviceSelect::Flagged(tmp, tmp_sel, hipcub::CountingInputIterator<int32_t>(0), r.moved_flag.p,
+                                                r.moved_list.p, s->tail_counts.p + 2 * bi, N, ctx->stream));
+      HIPCHK(ctx, hipcub::DeviceSelect::Flagged(tmp, tmp_sel, hipcub::CountingInputIterator<int32_t>(0), r.new_flag.p,
+                                                r.new_list.p, s->tail_counts.p + 2 * bi + 1, N, ctx->stream));
+      if (choice)
+        HIPCHK(ctx, hipMemcpyAsync(choice + (size_t)bi * N, r.choice.p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+      if (!bb.node_gauss.empty() && bb.node_gauss[0] >= 0 && bb.gauss[bb.node_gauss[0]].n_locals > 0) {
+        GaussDev gd;
+        int rc = build_gauss_dev(ctx, bb.gauss[bb.node_gauss[0]], &rt, gd);
+        if (rc) return rc;
+        if (r.locals.alloc((size_t)N * 2)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+        hipLaunchKernelGGL(locals_tail_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, gd, r.plan, s->chosen.p,
+                           r.pchoice.p, r.pnewpos.p, r.vals.p, (int)bb.nodes.size(), seed, sweep_idx, (uint32_t)bi,
+                           s->row_offset + ctx->active_begin, r.locals.p);
+        bb.locals_host.resize((size_t)N * 2);
+        HIPCHK(ctx, hipMemcpyAsync(bb.locals_host.data(), r.locals.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+      }
     }
-    hipLaunchKernelGGL(select_choice_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->chosen.p, r.pchoice.p,
-                       r.pnewpos.p, r.choice.p, r.chosen_newpos.p);
-    CandTable& rt = ctx->cand[ctx->block[bi].nodes[0].table];
-    HIPCHK(ctx, hipMemsetAsync(rt.stats.p, 0, (size_t)std::max(rt.n_rows, 1) * 8, ctx->stream));
-    hipLaunchKernelGGL(stats_kernel, grid1(N), dim3(256), 0, ctx->stream, N, cur_b, r.choice.p,
-                       (unsigned long long*)rt.stats.p);
-    HIPCHK(ctx, hipMemcpyAsync(choice + (size_t)bi * N, r.choice.p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    Block& bb = ctx->block[bi];
-    bb.locals_host.clear();
-    if (!bb.node_gauss.empty() && bb.node_gauss[0] >= 0 && bb.gauss[bb.node_gauss[0]].n_locals > 0) {
-      GaussDev gd;
-      int rc = build_gauss_dev(ctx, bb.gauss[bb.node_gauss[0]], &rt, gd);
-      if (rc) return rc;
-      if (r.locals.alloc((size_t)N * 2)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-      hipLaunchKernelGGL(locals_tail_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, gd, r.plan, s->chosen.p,
-                         r.pchoice.p, r.pnewpos.p, r.vals.p, (int)bb.nodes.size(), seed, sweep_idx, (uint32_t)bi,
-                         s->row_offset + ctx->active_begin, r.locals.p);
-      bb.locals_host.resize((size_t)N * 2);
-      HIPCHK(ctx, hipMemcpyAsync(bb.locals_host.data(), r.locals.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
-    }
-  }
-  (void)hipEventRecord(s->eve, ctx->stream);
-  if (chosen_particle) HIPCHK(ctx, hipMemcpyAsync(chosen_particle, s->chosen.p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
-  if (logml) HIPCHK(ctx, hipMemcpyAsync(logml, s->logml.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(s->h_counts, s->tail_counts.p, 2 * n_blocks * sizeof(int32_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    (void)hipEventRecord(s->eve, ctx->stream);
+    if (chosen_particle) HIPCHK(ctx, hipMemcpyAsync(chosen_particle, s->chosen.p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (logml) HIPCHK(ctx, hipMemcpyAsync(logml, s->logml.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (choice)
+      for (int bi = 0; bi < n_blocks; ++bi)
+        if (ctx->block[bi].is_score)
+          for (int i = 0; i < N; ++i) choice[(size_t)bi * N + i] = 0;
 
-  // ---- new-row records of the chosen particles -> host
-  for (int bi = 0; bi < n_blocks; ++bi) {
-    BlockRun& r = s->run[bi];
-    Block& b = ctx->block[bi];
-    const int nn = (int)b.nodes.size();
-    b.new_rows_host.clear();
-    b.new_vals_host.clear();
-    if (b.is_score || r.n_new == 0) continue;
-    int32_t* flag = scratch<int32_t>(ctx, N);
-    if (!flag) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-    hipLaunchKernelGGL(mark_new_kernel, grid1(N), dim3(256), 0, ctx->stream, N, r.chosen_newpos.p, flag);
-    HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 0, s->counter.p, nullptr,
-                       nullptr);
-    unsigned int cnt = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&cnt, s->counter.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (!cnt) continue;
-    int32_t* list = scratch<int32_t>(ctx, cnt);
-    int32_t* rows_d = scratch<int32_t>(ctx, cnt);
-    int32_t* vals_d = scratch<int32_t>(ctx, (size_t)cnt * nn);
-    if (!list || !rows_d || !vals_d) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-    HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 1, s->counter.p, list,
-                       nullptr);
-    hipLaunchKernelGGL(gather_new_rows_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, list, r.chosen_newpos.p,
-                       r.vals.p, nn, rows_d, vals_d);
-    b.new_rows_host.resize(cnt);
-    b.new_vals_host.resize((size_t)cnt * nn);
-    HIPCHK(ctx, hipMemcpyAsync(b.new_rows_host.data(), rows_d, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(b.new_vals_host.data(), vals_d, (size_t)cnt * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    // deterministic order (atomic compaction order is not)
-    std::vector<int> order(cnt);
-    for (unsigned i = 0; i < cnt; ++i) order[i] = (int)i;
-    std::sort(order.begin(), order.end(), [&](int a, int c) { return b.new_rows_host[a] < b.new_rows_host[c]; });
-    std::vector<int32_t> rs(cnt), vs((size_t)cnt * nn);
-    for (unsigned i = 0; i < cnt; ++i) {
-      rs[i] = b.new_rows_host[order[i]];
-      memcpy(&vs[(size_t)i * nn], &b.new_vals_host[(size_t)order[i] * nn], nn * 4);
+    // ---- rows whose referent changed and new-row records of the chosen particles -> host (ascending rows)
+    for (int bi = 0; bi < n_blocks; ++bi) {
+      BlockRun& r = s->run[bi];
+      Block& b = ctx->block[bi];
+      const int nn = (int)b.nodes.size();
+      b.new_rows_host.clear();
+      b.new_vals_host.clear();
+      b.moved_rows_host.clear();
+      b.moved_choice_host.clear();
+      if (b.is_score) continue;
+      const int n_moved = s->h_counts[2 * bi], n_newrows = s->h_counts[2 * bi + 1];
+      if (n_moved > 0) {
+        int32_t* ch_d = scratch<int32_t>(ctx, n_moved);
+        if (!ch_d) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+        hipLaunchKernelGGL(gather_moved_kernel, grid1(n_moved), dim3(256), 0, ctx->stream, n_moved, r.moved_list.p,
+                           r.choice.p, ch_d);
+        b.moved_rows_host.resize(n_moved);
+        b.moved_choice_host.resize(n_moved);
+        HIPCHK(ctx, hipMemcpyAsync(b.moved_rows_host.data(), r.moved_list.p, (size_t)n_moved * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(b.moved_choice_host.data(), ch_d, (size_t)n_moved * 4, hipMemcpyDeviceToHost, ctx->stream));
+      }
+      if (n_newrows > 0) {
+        int32_t* rows_d = scratch<int32_t>(ctx, n_newrows);
+        int32_t* vals_d = scratch<int32_t>(ctx, (size_t)n_newrows * nn);
+        if (!rows_d || !vals_d) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+        hipLaunchKernelGGL(gather_new_rows_kernel, grid1(n_newrows), dim3(256), 0, ctx->stream, n_newrows, r.new_list.p,
+                           r.chosen_newpos.p, r.vals.p, nn, rows_d, vals_d);
+        b.new_rows_host.resize(n_newrows);
+        b.new_vals_host.resize((size_t)n_newrows * nn);
+        HIPCHK(ctx, hipMemcpyAsync(b.new_rows_host.data(), rows_d, (size_t)n_newrows * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(b.new_vals_host.data(), vals_d, (size_t)n_newrows * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+      }
     }
-    b.new_rows_host.swap(rs);
-    b.new_vals_host.swap(vs);
-  }
-  // ---- rows whose referent changed (the host commit only has to touch these) -> host, ascending
-  for (int bi = 0; bi < n_blocks; ++bi) {
-    BlockRun& r = s->run[bi];
-    Block& b = ctx->block[bi];
-    b.moved_rows_host.clear();
-    b.moved_choice_host.clear();
-    if (b.is_score) continue;
-    int32_t* flag = scratch<int32_t>(ctx, N);
-    if (!flag) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-    hipLaunchKernelGGL(mark_moved_kernel, grid1(N), dim3(256), 0, ctx->stream, N, s->cur.p + (size_t)bi * N, r.choice.p, flag);
-    HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 0, s->counter.p, nullptr,
-                       nullptr);
-    unsigned int cnt = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&cnt, s->counter.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    if (!cnt) continue;
-    int32_t* list = scratch<int32_t>(ctx, cnt);
-    int32_t* ch_d = scratch<int32_t>(ctx, cnt);
-    if (!list || !ch_d) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-    HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 1, s->counter.p, list,
-                       nullptr);
-    hipLaunchKernelGGL(gather_i32_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, list, r.choice.p, ch_d);
-    std::vector<int32_t> rows_h(cnt), ch_h(cnt);
-    HIPCHK(ctx, hipMemcpyAsync(rows_h.data(), list, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ch_h.data(), ch_d, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    std::vector<int> order(cnt);
-    for (unsigned i = 0; i < cnt; ++i) order[i] = (int)i;
-    std::sort(order.begin(), order.end(), [&](int a, int c) { return rows_h[a] < rows_h[c]; });
-    b.moved_rows_host.resize(cnt);
-    b.moved_choice_host.resize(cnt);
-    for (unsigned i = 0; i < cnt; ++i) {
-      b.moved_rows_host[i] = rows_h[order[i]];
-      b.moved_choice_host[i] = ch_h[order[i]];
-    }
   }
+  if (s->prof_on) prof_collect(ctx);
   float tot = 0;
   HIPCHK(ctx, hipEventElapsedTime(&tot, s->evs, s->eve));
   ctx->timing.total_ms = tot;
   ctx->timing.hot_kernel_ms = hot_ms;
   {
-    // bytes(row) = sum_b [4 F_b + (K_b+1)(8 F_b + 4)] + 8 P; the dominant kernel is block 0's root
+    // bytes(row) = sum_b [4 F_b + (K_b+1)(8 F_b + 4)] + 8 P (full enumeration); reported beside the
+    // byte model of the implemented algorithm (bench.py)
     const Block& b0 = ctx->block[0];
     const double F = b0.nodes[0].n_terms, K = ctx->cand[b0.nodes[0].table].n_rows;
     ctx->timing.hot_kernel_alg_bytes = (double)N * (4.0 * F + (K + 1.0) * (8.0 * F + 4.0) + 8.0 * P);
@@ -1895,6 +2150,18 @@ extern "C" int pclean_get_stats(pclean_ctx* ctx, int32_t table_id, int64_t* out)
   return PCLEAN_OK;
 }
 
+extern "C" int pclean_set_cur_stride(pclean_ctx* ctx, int64_t stride) {
+  if (!ctx || stride < 0) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_cur_stride: bad stride");
+  ctx->cur_stride = stride;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_get_root_stats(pclean_ctx* ctx, pclean_root_stats* out) {
+  if (!ctx || !out) return PCLEAN_ERR_ARG;
+  *out = ctx->root_stats;
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_get_timing(pclean_ctx* ctx, pclean_timing* out) {
   if (!ctx || !out) return PCLEAN_ERR_ARG;
   *out = ctx->timing;
@@ -1917,9 +2184,10 @@ extern "C" int pclean_maybe_resample(pclean_ctx* ctx, int32_t n_rows, int32_t n_
   double* d_ess = scratch<double>(ctx, n_rows);
   if (!d_w || !d_a || !d_inc || !d_ess) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   HIPCHK(ctx, hipMemcpyAsync(d_w, logw, NP * 8, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(maybe_resample_kernel, grid1(n_rows), dim3(256), 0, ctx->stream, n_rows, n_particles, d_w,
-                     retain_first, (const int32_t*)nullptr, seed, sweep, block, s->row_offset, d_a, d_inc, d_ess,
-                     (int32_t*)nullptr);
+  DISPATCH_PMAX(n_particles, hipLaunchKernelGGL(maybe_resample_kernel<PMAX>, grid1(n_rows), dim3(256), 0, ctx->stream,
+                                                n_rows, n_particles, d_w, (size_t)n_particles, (size_t)1, retain_first,
+                                                (const int32_t*)nullptr, seed, sweep, block, s->row_offset, d_a, d_inc,
+                                                d_ess, (int32_t*)nullptr));
   HIPCHK(ctx, hipMemcpyAsync(ancestors, d_a, NP * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(logml_inc, d_inc, (size_t)n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (ess) HIPCHK(ctx, hipMemcpyAsync(ess, d_ess, (size_t)n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -1941,8 +2209,10 @@ extern "C" int pclean_final_choice(pclean_ctx* ctx, int32_t n_rows, int32_t n_pa
   double* d_t = scratch<double>(ctx, n_rows);
   if (!d_w || !d_c || !d_t) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   HIPCHK(ctx, hipMemcpyAsync(d_w, logw, NP * 8, hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(final_choice_kernel, grid1(n_rows), dim3(256), 0, ctx->stream, n_rows, n_particles, d_w, use_mh,
-                     is_csmc, (const int32_t*)nullptr, seed, sweep, s->row_offset, d_c, d_t);
+  DISPATCH_PMAX(n_particles, hipLaunchKernelGGL(final_choice_kernel<PMAX>, grid1(n_rows), dim3(256), 0, ctx->stream,
+                                                n_rows, n_particles, d_w, (size_t)n_particles, (size_t)1, use_mh, is_csmc,
+                                                (const int32_t*)nullptr, seed, sweep, s->row_offset, d_c, d_t,
+                                                (const double*)nullptr, (double*)nullptr));
   HIPCHK(ctx, hipMemcpyAsync(chosen, d_c, (size_t)n_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (log_total) HIPCHK(ctx, hipMemcpyAsync(log_total, d_t, (size_t)n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));

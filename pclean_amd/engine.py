@@ -84,8 +84,16 @@ class Engine:
         sym, off, lm, _ = lw.pool.arrays()
         hip.load_strings(sym, off)
         hip.load_columns(self.obs)
+        import time
+        t0 = time.perf_counter()
+        self.pair_cells = 0  # DP cells of the AddTypos pair tables: sum over tables of (sum of obs lengths) x (sum of latent lengths)
+        self.pair_count = 0
         for key, (pid, odom, ldom) in lw.pair_id.items():
-            hip.build_pair_table(pid, odom.id_array(), ldom.id_array(), self.dist_mode)
+            oi, li = odom.id_array(), ldom.id_array()
+            hip.build_pair_table(pid, oi, li, self.dist_mode)
+            self.pair_cells += int(lw.pool.lens[oi].astype(np.int64).sum()) * int(lw.pool.lens[li].astype(np.int64).sum())
+            self.pair_count += len(oi) * len(li)
+        self.pair_build_s = time.perf_counter() - t0
         for fid, fn in lw.fn_tables.items():
             hip.set_fn_table(fid, fn)
         for key, (pid, n) in lw.eq_pairs.items():  # equality constraints: 0 on the diagonal, 1 elsewhere
@@ -185,11 +193,13 @@ class Engine:
                 self._upload_gauss()
                 self._gauss_pending = False
 
-    def sweep(self, trace, config, seed, sweep_idx, lo=0, hi=None, reuse_buffers=False):
+    def sweep(self, trace, config, seed, sweep_idx, lo=0, hi=None, reuse_buffers=False, light=False):
         """One batched sweep over the observed rows [lo, hi) of the trace (default: all of them).
         Returns (choice, chosen_particle, logml, new_rows), all indexed relative to lo.  reuse_buffers:
-        results are views of page-locked buffers that the next sweep overwrites (callers that commit
-        the result right away: inference.py, bench.py)."""
+        trace.cur is passed in place (page-locked once) and the results are views of page-locked buffers
+        that the next sweep overwrites (callers that commit the result right away: inference.py, bench.py).
+        light: no per-row outputs are copied back (choice / chosen / logml are None); the commit reads the
+        moved rows (sweep_moved) and the new-row records only."""
         cfg = config.as_c() if isinstance(config, InferenceConfig) else config
         hi = trace.cur.shape[1] if hi is None else hi
         if hi <= lo:  # a rank may own no row of a small batch
@@ -197,10 +207,13 @@ class Engine:
                 trace.pending_locals[bi] = np.zeros((0, 2), dtype=np.int32)
             self._empty_sweep = True
             nb = trace.cur.shape[0]
-            return np.zeros((nb, 0), np.int32), np.zeros(0, np.int32), np.zeros(0), {}
+            return (None if light else np.zeros((nb, 0), np.int32)), np.zeros(0, np.int32), np.zeros(0), {}
         self._empty_sweep = False
         self.hip.set_active_rows(lo, hi - lo)
-        choice, chosen, logml = self.hip.sweep(cfg, seed, sweep_idx, trace.cur[:, lo:hi], reuse_buffers)
+        if reuse_buffers and trace.cur.dtype == np.int32 and trace.cur.flags.c_contiguous:
+            choice, chosen, logml = self.hip.sweep(cfg, seed, sweep_idx, trace.cur, True, window=(lo, hi), light=light)
+        else:
+            choice, chosen, logml = self.hip.sweep(cfg, seed, sweep_idx, trace.cur[:, lo:hi], reuse_buffers, light=light)
         new_rows = {}
         for bi, blk in enumerate(self.lw.blocks):
             if blk.get("score"):
@@ -210,7 +223,7 @@ class Engine:
                 new_rows[bi] = (rows, vals)
         if self.lw.locals:
             for bi in self.lw.locals:
-                trace.pending_locals[bi] = self.hip.get_locals(bi, choice.shape[1])
+                trace.pending_locals[bi] = self.hip.get_locals(bi, hi - lo)
         return choice, chosen, logml, new_rows
 
     def sweep_moved(self):

@@ -259,12 +259,14 @@ def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None, max_sub_ba
         lo, hi = shard_bounds(b1 - b0, comm.rank, comm.world)
         lo, hi = lo + b0, hi + b0
         engine.upload_trace(trace)
-        choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi, reuse_buffers=True)
+        light = hasattr(engine, "sweep_moved")  # the HIP engine reports the moved rows: no per-row outputs needed
+        choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi, reuse_buffers=True,
+                                                       **({"light": True} if light else {}))
         stats = engine.sweep_stats(trace)
-        moved = engine.sweep_moved() if hasattr(engine, "sweep_moved") else None
+        moved = engine.sweep_moved() if light else None
         _gather_locals(trace, comm, b0, hi - lo, lo)
         changed += exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True,
-                                       moved_local=moved)
+                                       moved_local=moved, n_local=hi - lo)
     return changed
 
 

@@ -88,7 +88,7 @@ class Comm:
 
 
 def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local, new_rows_local, global_cur=False,
-                        moved_local=None):
+                        moved_local=None, n_local=None):
     """Apply one sweep's result to the replicated trace.
 
     choice_local [n_blocks][n_local]: chosen referents of this rank's rows;
@@ -99,14 +99,15 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
     sweeps, whose evidence sets span all rows): the (row, new referent) pairs of the rows that moved
     are exchanged as well, so the whole trace stays replicated.
     moved_local {block: (local rows ascending, new referent)} (pclean_get_moved): when given, only those rows
-    are touched and choice_local is not scanned.
+    are touched and choice_local is not scanned (it may be None if n_local is given).
 
     Exactly three collectives per sweep, whatever the number of blocks: ONE all-reduce(sum) of the
     concatenated int64 delta-count vectors (+ the moved-row counter) and ONE variable-length
     all-gather (sizes + payload) of the new-row records and moved rows of all blocks.
     Returns the global number of rows whose referent changed."""
     blocks = [bi for bi, blk in enumerate(lowered.blocks) if not blk.get("score")]
-    n_local = np.asarray(choice_local).shape[1]
+    if n_local is None:
+        n_local = np.asarray(choice_local).shape[1]
     # ---- local payloads (tables are still in their pre-sweep state) --------------------------------
     n_before, moved_of, red, msg = {}, {}, [], []
     n_changed = 0

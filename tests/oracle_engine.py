@@ -27,7 +27,7 @@ class OracleEngine:
         logp = helpers.option_logp_cpu(self.oracle, self.lw, trace)
         return helpers.mirror_world(self.oracle, self.lw, np.ascontiguousarray(self.obs[:, lo:hi]), trace, None, 1, logp, row_lo=lo)
 
-    def sweep(self, trace, config, seed, sweep_idx, lo=0, hi=None, reuse_buffers=False):
+    def sweep(self, trace, config, seed, sweep_idx, lo=0, hi=None, reuse_buffers=False, light=False):
         orc, lw = self.oracle, self.lw
         hi = trace.cur.shape[1] if hi is None else hi
         n, nb = hi - lo, trace.cur.shape[0]
