@@ -119,6 +119,8 @@ class HipContext:
         if self.h:
             for a in self._pinned:
                 self.lib.pclean_unpin_host(self.h, C.c_void_p(a.ctypes.data))
+            if self._io.get("cur_pinned"):  # a trace's `cur` registered in place by sweep(window=...)
+                self.lib.pclean_unpin_host(self.h, C.c_void_p(self._io["cur_pinned"][0]))
             self._pinned, self._io = [], {}
             self.lib.pclean_ctx_destroy(self.h)
             self.h = C.c_void_p()
@@ -375,7 +377,7 @@ class HipContext:
                 self._pinned = [p for p in self._pinned if p is not a]
             arrays = (self.pinned_empty((n_blocks, n_rows), np.int32), self.pinned_empty((n_blocks, n_rows), np.int32),
                       self.pinned_empty(n_rows, np.int32), self.pinned_empty(n_rows, np.float64))
-            self._io = {"key": key, "arrays": arrays}
+            self._io.update(key=key, arrays=arrays)
         return self._io["arrays"]
 
     def sweep(self, cfg, seed, sweep_idx, cur, reuse_buffers=False, window=None, light=False):

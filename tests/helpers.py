@@ -146,3 +146,31 @@ def option_logp_cpu(oracle, lw, trace):
             with np.errstate(divide="ignore"):
                 out[(cname, aname)] = np.log(trace.params[(cname, d.param)].value)
     return out
+
+
+def truth_workload(n_rows, n_hosp, seed):
+    """Synthetic hospital-shaped table (pclean_amd.synth) with the latent state set to the generator's
+    ground-truth entities (clean values that never occur undamaged fall back to the dirty cell) — a known,
+    cheap starting state for the full-size property tests.  Returns (dirty, clean, lowered, obs, trace)."""
+    from pclean_amd import experiments as ex
+    from pclean_amd.model import LoweredModel
+    from pclean_amd.synth import synth_hospital
+    from pclean_amd.trace import Trace
+    dirty, clean, latent = synth_hospital(n_rows, n_hosp, seed)
+    poss = ex.possibilities_of(dirty)
+    m = ex.hospital_model(poss)
+    q = ex.hospital_query(m)
+    lw = LoweredModel(m, q, dirty)
+    obs = lw.encode_observations(dirty)
+    by_path = [{}, {}]
+    ocls = m.classes[q.cls]
+    for col, ref in q.cleanmap.items():
+        if "." not in ref:
+            continue
+        head, rest = ref.split(".", 1)
+        bi = 0 if head == "hosp" else 1
+        cname, attr = m.resolve(ocls.attr(head).target, rest)
+        dom = lw.latent_dom[(cname, attr.name)]
+        by_path[bi][rest] = [c if dom.get(c) >= 0 else d for c, d in zip(clean[col], dirty[col])]
+    tr = Trace.from_clean_values(lw, by_path, n_rows, seed)
+    return dirty, clean, lw, obs, tr

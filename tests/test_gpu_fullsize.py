@@ -21,7 +21,8 @@ def test_million_row_sweep_properties(oracle):
     from pclean_amd._lib import InferConfig
     from pclean_amd.engine import Engine, InferenceConfig
     n_rows, n_hosp, P, seed = 1_000_000, 10_000, 20, 20250926
-    dirty, clean, lw, obs, tr = bench.build_workload(n_rows, n_hosp, seed)
+    import helpers
+    dirty, clean, lw, obs, tr = helpers.truth_workload(n_rows, n_hosp, seed)
     eng = Engine(lw, obs, dist_mode=_lib.DIST_OSA)
     try:
         eng.upload_trace(tr)
@@ -82,14 +83,15 @@ def test_million_row_sweep_properties(oracle):
 
 
 def test_fast_root_kernel_equals_generic(oracle):
-    """The compact-table root kernel (root_fast.hip) and the generic enumeration kernel give
+    """The compact-table wave kernel (root_wave.hip) and the generic enumeration kernel give
     bit-identical sweeps; exclusions (incl. sole referrers), new rows and counts-only uploads covered."""
     sys.path.insert(0, ROOT)
     import bench
     from pclean_amd import _lib
     from pclean_amd.engine import Engine, InferenceConfig
     from pclean_amd.parallel import Comm, exchange_and_commit
-    dirty, clean, lw, obs, tr = bench.build_workload(40_000, 1500, 7)
+    import helpers
+    dirty, clean, lw, obs, tr = helpers.truth_workload(40_000, 1500, 7)
     eng = Engine(lw, obs, dist_mode=_lib.DIST_OSA)
     comm = Comm()
     try:
