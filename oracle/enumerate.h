@@ -18,6 +18,7 @@
 #define PCLEAN_ORACLE_ENUMERATE_H
 
 #include <cstdint>
+#include <map>
 #include <vector>
 
 #include "../include/pclean_detmath.h"
@@ -195,20 +196,31 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
   }
   const pclean_gauss* gs = (node_id < (int)b.node_gauss.size() && b.node_gauss[node_id] >= 0)
                                ? &b.gauss[b.node_gauss[node_id]] : nullptr;
-  if (ev) { /* per candidate: evidence rows in list order, terms in plan order per row */
-    for (int k = 0; k < n; ++k) {
-      if (fk && t.counts[k] == 0) continue;
+  if (ev) {
+    /* Evidence sets: terms in plan order; per term the distinct (ctx value, observed value) pairs of the
+     * evidence rows in ascending order (missing observation = -1 first), each adding multiplicity x density;
+     * then the Gaussian terms row by row in list order.  (The reference adds row by row in Dict order,
+     * proposal_compiler.jl:306-350 — the sum is the same up to fp64 rounding.) */
+    for (int ti = 0; ti < nd.n_terms; ++ti) {
+      const pclean_term& tm = b.terms[nd.term_begin + ti];
+      std::map<std::pair<int, int>, int64_t> agg;
+      const bool ev_ctx_term = tm.ctx_slot >= 0 && tm.ctx_mode != 0;
       for (int e = 0; e < ev->n; ++e) {
-        const int er = ev->rows[e];
-        for (int ti = 0; ti < nd.n_terms; ++ti) {
-          const pclean_term& tm = b.terms[nd.term_begin + ti];
-          const int o = w.obs[(size_t)tm.obs_col * w.n_rows + er];
+        const int o = w.obs[(size_t)tm.obs_col * w.n_rows + ev->rows[e]];
+        const int c = ev_ctx_term ? ev->ctx[(size_t)e * PCLEAN_MAX_CTX + tm.ctx_slot] : 0;
+        agg[std::make_pair(c, o)] += 1;
+      }
+      for (const auto& kv : agg) {
+        const int ec = kv.first.first, o = kv.first.second;
+        const double mult = (double)kv.second;
+        for (int k = 0; k < n; ++k) {
+          if (fk && t.counts[k] == 0) continue;
           if (tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP) {
             const OPair& ptm = w.pair[tm.pair_table];
             const int v2 = t.cols[(size_t)tm.cand_col * n + k];
-            const int c = tm.ctx_mode == 0 ? ctxv[tm.ctx_slot] : ev->ctx[(size_t)e * PCLEAN_MAX_CTX + tm.ctx_slot];
+            const int c = tm.ctx_mode == 0 ? ctxv[tm.ctx_slot] : ec;
             const bool same = o >= 0 && ptm.d[(size_t)o * ptm.n_lat + v2] == 0;
-            out[k] += maybe_swap_term(w, o < 0, same, v2 != tm.fn_table, t.cols[(size_t)tm.max_typos * n + k], c);
+            out[k] += mult * maybe_swap_term(w, o < 0, same, v2 != tm.fn_table, t.cols[(size_t)tm.max_typos * n + k], c);
             continue;
           }
           if (o < 0) continue;
@@ -216,12 +228,20 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
           int val = t.cols[(size_t)tm.cand_col * n + k];
           if (tm.ctx_slot >= 0) {
             const OFn& f = w.fn[tm.fn_table];
-            const int c = tm.ctx_mode == 0 ? ctxv[tm.ctx_slot] : ev->ctx[(size_t)e * PCLEAN_MAX_CTX + tm.ctx_slot];
+            const int c = tm.ctx_mode == 0 ? ctxv[tm.ctx_slot] : ec;
             val = tm.ctx_mode == 2 ? f.fn[(size_t)val * f.n_b + c] : f.fn[(size_t)c * f.n_b + val];
           }
-          out[k] += term_density(w, tm, pt, pt.d[(size_t)o * pt.n_lat + val], val);
+          out[k] += mult * term_density(w, tm, pt, pt.d[(size_t)o * pt.n_lat + val], val);
         }
-        if (gs && out[k] > NEG_INF && w.xnum[(size_t)gs->x_col * w.n_rows + er] == w.xnum[(size_t)gs->x_col * w.n_rows + er]) {
+      }
+    }
+    if (gs)
+      for (int k = 0; k < n; ++k) {
+        if (fk && t.counts[k] == 0) continue;
+        for (int e = 0; e < ev->n; ++e) {
+          const int er = ev->rows[e];
+          if (!(out[k] > NEG_INF) || w.xnum[(size_t)gs->x_col * w.n_rows + er] != w.xnum[(size_t)gs->x_col * w.n_rows + er])
+            continue;
           const int32_t* ec = ev->ctx ? ev->ctx + (size_t)e * PCLEAN_MAX_CTX : nullptr;
           out[k] += gauss_lse(gauss_combo_scores(w, *gs, er, ec, [&](int d) -> int {
             switch (gs->src_kind[d]) {
@@ -233,7 +253,6 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
           }));
         }
       }
-    }
     return;
   }
   for (int ti = 0; ti < nd.n_terms; ++ti) {

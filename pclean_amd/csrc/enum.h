@@ -52,6 +52,15 @@ struct DensDev {
   const double* logn;       // log(n)
 };
 
+// Aggregated evidence of one term of a latent-class node (sweep.hip: ensure_agg): for original latent item i the
+// distinct (ctx value, observed value) pairs among its evidence rows, ascending, with multiplicities:
+// entries [off[i], off[i+1]) of key / cnt; key = item << 40 | ctx << 24 | (observed value index + 1) (0 = missing).
+struct AggDev {
+  const uint64_t* key;
+  const int32_t* cnt;
+  const int32_t* off;
+};
+
 // Work items of one enumeration launch. Item t scores evidence row row[t]
 // (identity when null) under ctx[t][.], with candidate excl[t] having lost one
 // reference; draws use particle id particle[t] (n_draws==1) or 0..n_draws-1.
@@ -80,6 +89,10 @@ struct ItemsDev {
   // The sweep keeps its particle arrays particle-major ([P][N]: draw_is = 1, draw_ds = N) so that the
   // one-thread-per-row particle kernels read them coalesced.
   int32_t draw_is, draw_ds;
+  // evidence sets: per term of the node the aggregated evidence (device array [n_terms]) and the original
+  // latent item each list item stands for (identity when null)
+  const AggDev* agg;
+  const int32_t* ev_item;
 };
 
 // Log-marginals of the children of a "new row": either one value per item, or a

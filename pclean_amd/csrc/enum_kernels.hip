@@ -56,7 +56,7 @@ __device__ __forceinline__ double maybe_swap_density(const TermDev& tm, const De
 }
 
 struct ItemView {
-  int row, excl;
+  int row, excl, item;
   const int32_t* ctxv;
   bool deleted;
   double logden;
@@ -65,6 +65,7 @@ struct ItemView {
 
 __device__ __forceinline__ ItemView item_view(const NodeDev& nd, const ItemsDev& it, int t) {
   ItemView v;
+  v.item = t;
   v.row = it.row ? it.row[t] : t;
   v.excl = it.excl ? it.excl[t] : -1;
   v.ctxv = it.ctx ? it.ctx + (size_t)t * PCLEAN_MAX_CTX : nullptr;
@@ -107,34 +108,45 @@ __device__ __forceinline__ double gauss_term(const NodeDev& nd, const ItemView& 
   return gauss_lse(sc, n);
 }
 
+// Evidence sets (latent-class rows scored against every observed row referring to them — the
+// ExternalLikelihoodNodes of proposal_compiler.jl:306-350 / block_proposal.jl:119-155).  Order of the fp64
+// additions (the oracle restates it, oracle/enumerate.h): terms in plan order; per term the DISTINCT (ctx value,
+// observed value) pairs of the evidence rows in ascending order, each adding multiplicity x density — the ~100
+// referring rows of a hospital hold a handful of distinct values per column; then the Gaussian terms row by row.
 __device__ __forceinline__ double candidate_score_ev(const NodeDev& nd, const DensDev& dn, const ItemsDev& it,
                                                      const ItemView& v, int k, double sk) {
-  // evidence order: ascending position in the item's evidence list; terms in plan order per row
-  for (int e = v.ev_lo; e < v.ev_hi; ++e) {
-    const int row = it.ev_rows[e];
-    for (int ti = 0; ti < nd.n_terms; ++ti) {
-      const TermDev& tm = nd.terms[ti];
-      const int o = tm.obs_col[row];
+  const int oi = it.ev_item ? it.ev_item[v.item] : v.item;
+  for (int ti = 0; ti < nd.n_terms; ++ti) {
+    const TermDev& tm = nd.terms[ti];
+    const AggDev ag = it.agg[ti];
+    const int r1 = ag.off[oi + 1];
+    for (int r = ag.off[oi]; r < r1; ++r) {
+      const uint64_t key = ag.key[r];
+      const int o = (int)(key & 0xffffffull) - 1;
+      const int ec = (int)((key >> 24) & 0xffffull);
+      const double mult = (double)ag.cnt[r];
       if (tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP) {
         const int val = tm.cand_col[k];
-        const int c = tm.ctx_mode == 0 ? v.ctxv[tm.ctx_slot] : it.ev_ctx[(size_t)e * PCLEAN_MAX_CTX + tm.ctx_slot];
+        const int c = tm.ctx_mode == 0 ? v.ctxv[tm.ctx_slot] : ec;
         const int d = o < 0 ? 1 : (int)tm.pair[(size_t)o * tm.n_lat + val];
-        sk += maybe_swap_density(tm, dn, o, d, val, k, c);
+        sk += mult * maybe_swap_density(tm, dn, o, d, val, k, c);
         continue;
       }
       if (o < 0) continue;
       int val = tm.cand_col[k];
       if (tm.ctx_slot >= 0) {
-        const int c = tm.ctx_mode == 0 ? v.ctxv[tm.ctx_slot] : it.ev_ctx[(size_t)e * PCLEAN_MAX_CTX + tm.ctx_slot];
+        const int c = tm.ctx_mode == 0 ? v.ctxv[tm.ctx_slot] : ec;
         val = tm.ctx_mode == 2 ? tm.fn[(size_t)val * tm.fn_nb + c] : tm.fn[(size_t)c * tm.fn_nb + val];
       }
       const size_t idx = (size_t)o * tm.n_lat + val;
       const int d = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
-      sk += term_density(tm, dn, d, val);
+      sk += mult * term_density(tm, dn, d, val);
     }
-    if (nd.g.on && sk > -__builtin_inf())
-      sk += gauss_term(nd, v, k, row, it.ev_ctx ? it.ev_ctx + (size_t)e * PCLEAN_MAX_CTX : nullptr);
   }
+  if (nd.g.on)
+    for (int e = v.ev_lo; e < v.ev_hi; ++e)
+      if (sk > -__builtin_inf())
+        sk += gauss_term(nd, v, k, it.ev_rows[e], it.ev_ctx ? it.ev_ctx + (size_t)e * PCLEAN_MAX_CTX : nullptr);
   return sk;
 }
 

@@ -606,6 +606,11 @@ struct SweepState {
   std::map<int, uint64_t> leaf_version;
   int64_t row_offset = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evs = nullptr, eve = nullptr;
+  // evidence of the running pclean_sweep_latent call (ensure_agg)
+  const int32_t* lat_off = nullptr;      // [lat_items + 1] CSR offsets of the original items into the evidence list
+  const int32_t* lat_item_of_pos = nullptr;  // [lat_ev]
+  int lat_items = 0, lat_ev = 0;
+  std::map<int, const AggDev*> lat_agg;  // node -> device array [n_terms]
   DevBuf<int32_t> tail_counts;      // [2 * PCLEAN_MAX_BLOCKS] number of moved rows / rows with a new referent
   int32_t* h_counts = nullptr;      // page-locked mirror of tail_counts (+ scratch words)
   // per-phase HIP-event profile of a sweep (pclean_set_profiling): (phase, start, stop) records
@@ -1008,6 +1013,107 @@ struct ItemGroups {
 };
 static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
                             ItemGroups& g);
+// ---- aggregated evidence of latent-class sweeps -------------------------------------------------------------
+// (contract in enum_kernels.hip: candidate_score_ev)
+__global__ void item_of_pos_kernel(int n_ev, int n_items, const int32_t* __restrict__ off, int32_t* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ev) return;
+  int lo = 0, hi = n_items - 1;  // largest t with off[t] <= e
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (off[mid] <= e)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  out[e] = lo;
+}
+__global__ void agg_key_kernel(int n_ev, const int32_t* __restrict__ item_of_pos, const int32_t* __restrict__ ev_rows,
+                               const int32_t* __restrict__ ev_ctx, int ctx_slot, const int32_t* __restrict__ obs_col,
+                               uint64_t* __restrict__ key) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n_ev) return;
+  const uint64_t o1 = (uint64_t)(uint32_t)(obs_col[ev_rows[e]] + 1) & 0xffffffull;
+  const uint64_t c = ctx_slot >= 0 ? ((uint64_t)(uint32_t)ev_ctx[(size_t)e * PCLEAN_MAX_CTX + ctx_slot] & 0xffffull) : 0ull;
+  key[e] = ((uint64_t)(uint32_t)item_of_pos[e] << 40) | (c << 24) | o1;
+}
+__global__ void agg_off_kernel(int n_items, const uint64_t* __restrict__ uniq, const int32_t* __restrict__ n_runs,
+                               int32_t* __restrict__ off) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t > n_items) return;
+  const uint64_t want = (uint64_t)(uint32_t)t << 40;
+  int lo = 0, hi = *n_runs;  // first run with key >= want
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (uniq[mid] < want)
+      lo = mid + 1;
+    else
+      hi = mid;
+  }
+  off[t] = lo;
+}
+struct AggPack {
+  AggDev a[PCLEAN_MAX_TERMS];
+};
+__global__ void write_agg_kernel(AggPack p, int n, AggDev* dst) {
+  const int i = threadIdx.x;
+  if (i < n) dst[i] = p.a[i];
+}
+
+// Aggregated evidence of every term of node `node_id` over the original items of the running
+// pclean_sweep_latent call; built once per (call, node).
+static int ensure_agg(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const AggDev** out) {
+  SweepState* s = st(ctx);
+  auto itc = s->lat_agg.find(node_id);
+  if (itc != s->lat_agg.end()) {
+    *out = itc->second;
+    return PCLEAN_OK;
+  }
+  ProfScope ps(ctx, "evidence_aggregation");
+  const Block& b = ctx->block[block_id];
+  const pclean_node& n = b.nodes[node_id];
+  const int n_ev = s->lat_ev, n_items = s->lat_items;
+  if (n_items >= (1 << 24)) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "too many latent rows in one latent sweep");
+  AggPack pack{};
+  AggDev* dst = (AggDev*)scratch<unsigned char>(ctx, sizeof(AggDev) * PCLEAN_MAX_TERMS);
+  if (!dst) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  for (int ti = 0; ti < n.n_terms; ++ti) {
+    const pclean_term& tm = b.terms[n.term_begin + ti];
+    const PairTable& pt = ctx->pair[tm.pair_table];
+    if (tm.obs_col < 0 || tm.obs_col >= ctx->n_cols) return pclean_fail(ctx, PCLEAN_ERR_ARG, "term column out of range");
+    if (pt.valid && pt.n_obs + 1 >= (1 << 24)) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "observed domain too large for the evidence keys");
+    const int ctx_slot = (tm.ctx_slot >= 0 && tm.ctx_mode != 0) ? tm.ctx_slot : -1;
+    if (ctx_slot >= 0 && !il.ev_ctx) return pclean_fail(ctx, PCLEAN_ERR_ARG, "term %d needs per-evidence-row ctx", n.term_begin + ti);
+    const size_t ne = (size_t)std::max(n_ev, 1);
+    uint64_t* key = scratch<uint64_t>(ctx, ne);
+    uint64_t* key_s = scratch<uint64_t>(ctx, ne);
+    uint64_t* uniq = scratch<uint64_t>(ctx, ne);
+    int32_t* cnt = scratch<int32_t>(ctx, ne);
+    int32_t* n_runs = scratch<int32_t>(ctx, 4);
+    int32_t* off = scratch<int32_t>(ctx, (size_t)n_items + 2);
+    if (!key || !key_s || !uniq || !cnt || !n_runs || !off) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    HIPCHK(ctx, hipMemsetAsync(n_runs, 0, sizeof(int32_t), ctx->stream));
+    if (n_ev > 0) {
+      hipLaunchKernelGGL(agg_key_kernel, grid1(n_ev), dim3(256), 0, ctx->stream, n_ev, s->lat_item_of_pos, il.ev_rows,
+                         il.ev_ctx, ctx_slot, ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows, key);
+      size_t tmp_sort = 0, tmp_rle = 0;
+      HIPCHK(ctx, hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_sort, key, key_s, n_ev, 0, 64, ctx->stream));
+      HIPCHK(ctx, hipcub::DeviceRunLengthEncode::Encode(nullptr, tmp_rle, key_s, uniq, cnt, n_runs, n_ev, ctx->stream));
+      unsigned char* tmp = scratch<unsigned char>(ctx, std::max(tmp_sort, tmp_rle));
+      if (!tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      HIPCHK(ctx, hipcub::DeviceRadixSort::SortKeys(tmp, tmp_sort, key, key_s, n_ev, 0, 64, ctx->stream));
+      HIPCHK(ctx, hipcub::DeviceRunLengthEncode::Encode(tmp, tmp_rle, key_s, uniq, cnt, n_runs, n_ev, ctx->stream));
+    }
+    hipLaunchKernelGGL(agg_off_kernel, grid1((size_t)n_items + 1), dim3(256), 0, ctx->stream, n_items, uniq, n_runs, off);
+    pack.a[ti] = AggDev{uniq, cnt, off};
+  }
+  hipLaunchKernelGGL(write_agg_kernel, dim3(1), dim3(64), 0, ctx->stream, pack, n.n_terms, dst);
+  HIPCHK(ctx, hipGetLastError());
+  s->lat_agg[node_id] = dst;
+  *out = dst;
+  return PCLEAN_OK;
+}
+
 // Upper bound of the log-marginal of plan sub-tree `node_id` (gate_new_kernel, enum_kernels.hip): every term
 // density of the sub-tree must be a probability mass (<= 1); +inf when it is not (Gaussian terms).
 static double subtree_ub(pclean_ctx* ctx, const Block& b, int node_id) {
@@ -1037,8 +1143,8 @@ __global__ void scatter_f64_kernel(int n, const int32_t* list, const double* src
 // attributes of the items list[j] of a parent list
 __global__ void sub_items_kernel(int n, const int32_t* list, const int32_t* p_row, const int32_t* p_ctx,
                                  const int32_t* p_excl, const int32_t* p_ev_lo, const int32_t* p_ev_hi,
-                                 const int32_t* p_rng, int32_t* row, int32_t* ctxv, int32_t* excl, int32_t* ev_lo,
-                                 int32_t* ev_hi, int32_t* rng) {
+                                 const int32_t* p_rng, const int32_t* p_origin, int32_t* row, int32_t* ctxv,
+                                 int32_t* excl, int32_t* ev_lo, int32_t* ev_hi, int32_t* rng, int32_t* origin) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int s = list[j];
@@ -1050,6 +1156,7 @@ __global__ void sub_items_kernel(int n, const int32_t* list, const int32_t* p_ro
     ev_hi[j] = p_ev_hi[s];
   }
   if (p_rng) rng[j] = p_rng[s];
+  if (origin) origin[j] = p_origin ? p_origin[s] : s;
 }
 
 static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
@@ -1063,7 +1170,13 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   if (rc) return rc;
   ChildrenDev ch{};
   ItemsDev it{il.n, 0, il.row, il.ctx, excl, n_draws == 1 ? il.particle : nullptr, s->row_offset + ctx->active_begin,
-              nullptr, il.ev_lo, il.ev_hi, il.ev_rows, il.ev_ctx, il.rng_row, nullptr, nullptr, il.draw_is, il.draw_ds};
+              nullptr, il.ev_lo, il.ev_hi, il.ev_rows, il.ev_ctx, il.rng_row, nullptr, nullptr, il.draw_is, il.draw_ds,
+              nullptr, nullptr};
+  if (il.ev_lo) {  // evidence sets: aggregated per original latent item (il.origin)
+    rc = ensure_agg(ctx, block_id, node_id, il, &it.agg);
+    if (rc) return rc;
+    it.ev_item = il.origin;
+  }
   if (n.kind == PCLEAN_NODE_FK) {
     if (snew_override) {
       ch.n = 1;
@@ -1130,11 +1243,12 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
         int32_t* evl2 = il.ev_lo ? scratch<int32_t>(ctx, n_need) : nullptr;
         int32_t* evh2 = il.ev_lo ? scratch<int32_t>(ctx, n_need) : nullptr;
         int32_t* rng2 = il.rng_row ? scratch<int32_t>(ctx, n_need) : nullptr;
-        if (!row2 || !ctx2 || !excl2 || (il.ev_lo && (!evl2 || !evh2)) || (il.rng_row && !rng2))
+        int32_t* org2 = il.ev_lo ? scratch<int32_t>(ctx, n_need) : nullptr;
+        if (!row2 || !ctx2 || !excl2 || (il.ev_lo && (!evl2 || !evh2 || !org2)) || (il.rng_row && !rng2))
           return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
         hipLaunchKernelGGL(sub_items_kernel, grid1(n_need), dim3(256), 0, ctx->stream, (int)n_need, list, il.row, il.ctx,
-                           excl, il.ev_lo, il.ev_hi, il.rng_row, row2, ctx2, excl2, evl2, evh2, rng2);
-        sil = ItemList{(int)n_need, row2, il.ctx ? ctx2 : nullptr, nullptr, nullptr, evl2, evh2, il.ev_rows, il.ev_ctx, rng2};
+                           excl, il.ev_lo, il.ev_hi, il.rng_row, il.origin, row2, ctx2, excl2, evl2, evh2, rng2, org2);
+        sil = ItemList{(int)n_need, row2, il.ctx ? ctx2 : nullptr, nullptr, org2, evl2, evh2, il.ev_rows, il.ev_ctx, rng2};
         sexcl = excl2;
       }
       for (int c = 0; c < n.n_children; ++c) {
@@ -1623,6 +1737,14 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   if (ev_ctx && n_ev)
     HIPCHK(ctx, hipMemcpyAsync(d_evc, ev_ctx, (size_t)n_ev * PCLEAN_MAX_CTX * 4, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(d_excl, excl, (size_t)n_roots * n_items * 4, hipMemcpyHostToDevice, ctx->stream));
+  int32_t* d_iop = scratch<int32_t>(ctx, std::max(n_ev, 1));
+  if (!d_iop) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  if (n_ev) hipLaunchKernelGGL(item_of_pos_kernel, grid1(n_ev), dim3(256), 0, ctx->stream, n_ev, n_items, d_off, d_iop);
+  s->lat_off = d_off;
+  s->lat_item_of_pos = d_iop;
+  s->lat_items = n_items;
+  s->lat_ev = n_ev;
+  s->lat_agg.clear();
   hipLaunchKernelGGL(latent_choice_kernel, grid1(n_items), dim3(256), 0, ctx->stream, n_items, P, use_mh, d_keys, seed,
                      sweep_idx, (uint32_t)block_id, d_chosen);
   hipLaunchKernelGGL(fill_i32_kernel, grid1((size_t)n_items * nn), dim3(256), 0, ctx->stream, d_vals,
@@ -1702,6 +1824,8 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   HIPCHK(ctx, hipMemcpyAsync(chosen, d_chosen, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(vals, d_vals, (size_t)n_items * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  s->lat_agg.clear();
+  if (s->prof_on) prof_collect(ctx);
   return PCLEAN_OK;
 }
 
