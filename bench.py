@@ -233,11 +233,18 @@ def main():
     acc_init = f1_now(tr)
     log(f"[bench] initialize_trace {init_s:.1f}s: F1 {acc_init['f1']:.4f} " + " ".join(f"{c}={t.n_live}" for c, t in tr.tables.items()))
     full_ms = None
+    from pclean_amd import inference as inf
     if not args.no_full_iteration:
+        inf.TIMERS.clear()
+        eng.hip.set_profiling(True)
         t0 = time.time()
         run_inference(eng, tr, cfg1, args.seed, comm=comm)
         torch.cuda.synchronize()
         full_ms = 1e3 * (time.time() - t0)
+        full_phases = eng.hip.get_profile()
+        eng.hip.set_profiling(False)
+        log("[bench] full iteration, host phases (ms): " + ", ".join(f"{k} {1e3 * v:.0f}" for k, v in sorted(inf.TIMERS.items(), key=lambda kv: -kv[1]) if v > 2e-3))
+        log("[bench] full iteration, device phases (ms): " + ", ".join(f"{k} {v[0]:.1f}/{v[1]}" for k, v in sorted(full_phases.items(), key=lambda kv: -kv[1][0])))
         log(f"[bench] one full run_inference iteration (every class): {full_ms:.0f} ms "
             + " ".join(f"{c}={t.n_live}" for c, t in tr.tables.items()))
 
@@ -247,6 +254,7 @@ def main():
     def step(idx):
         return observed_sweep(eng, tr, cfg, args.seed, 1 + idx, comm, max_sub_batches=1), eng.hip.get_timing()
 
+    inf.TIMERS.clear()
     for i in range(args.warmup):
         changed, tm = step(i)
         log(f"[bench] warmup sweep {i}: device {tm.total_ms:.2f} ms, root scan {tm.hot_kernel_ms:.2f} ms, "
@@ -264,6 +272,8 @@ def main():
     torch.cuda.synchronize()
     comm.barrier()
     elapsed = comm.max_float(time.perf_counter() - t0)
+    log(f"[bench] timed region, host phases (ms per step over {args.warmup + args.steps} sweeps): "
+        + ", ".join(f"{k} {1e3 * v / (args.warmup + args.steps):.2f}" for k, v in sorted(inf.TIMERS.items(), key=lambda kv: -kv[1])))
     rs = eng.hip.get_root_stats()
     lo, hi = shard_bounds(args.rows, rank, world)
     alg_bytes = roofline_model(rs, obs[:, lo:hi], cfg.num_particles)

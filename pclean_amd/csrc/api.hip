@@ -329,6 +329,7 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
   if (keep_cols && (!t.valid || t.is_options || t.n_rows != n_rows || t.n_cols != n_cols))
     return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_set_table: cols == NULL needs a previous upload of the same shape");
   t.is_options = false;
+  t.is_options_1col = false;
   t.n_rows = n_rows;
   t.n_cols = n_cols;
   const size_t n = (size_t)n_rows * n_cols;
@@ -375,8 +376,14 @@ extern "C" int pclean_set_options(pclean_ctx* ctx, int32_t table_id, int32_t n_o
   t.n_cols = 1;
   if (t.cols.alloc(n_options) || t.logc_full.alloc(n_options))
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  // the candidate-compact byte tables of the wave kernel depend on the option VALUES only: keep their version when
+  // just the log-probabilities changed (ChooseProportionally options are re-uploaded with every parameter move)
+  const bool same_vals = t.valid && t.is_options_1col && (int)t.h_vals.size() == n_options &&
+                         memcmp(t.h_vals.data(), values, (size_t)n_options * sizeof(int32_t)) == 0;
   HIPCHK(ctx, hipMemcpy(t.cols.p, values, n_options * sizeof(int32_t), hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(t.logc_full.p, logp, n_options * sizeof(double), hipMemcpyHostToDevice));
+  t.h_vals.assign(values, values + n_options);
+  t.is_options_1col = true;
   t.h_logc_full.assign(logp, logp + n_options);
   t.h_logc_m1.clear();
   t.h_counts.clear();
@@ -384,6 +391,7 @@ extern "C" int pclean_set_options(pclean_ctx* ctx, int32_t table_id, int32_t n_o
   t.scal[2] = t.scal[3] = kNegInf;
   t.valid = true;
   t.version = ++g_pclean_version;
+  if (!same_vals) t.cols_version = t.version;
   return PCLEAN_OK;
 }
 
@@ -395,6 +403,8 @@ extern "C" int pclean_set_options_cols(pclean_ctx* ctx, int32_t table_id, int32_
   if (rc) return rc;
   CandTable& t = ctx->cand[table_id];
   t.n_cols = n_cols;
+  t.is_options_1col = false;  // value columns beyond the first: always treated as changed
+  t.cols_version = t.version;
   if (t.cols.alloc((size_t)n_options * n_cols)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   HIPCHK(ctx, hipMemcpy(t.cols.p, cols, (size_t)n_options * n_cols * sizeof(int32_t), hipMemcpyHostToDevice));
   return PCLEAN_OK;

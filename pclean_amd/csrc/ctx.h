@@ -61,6 +61,8 @@ struct CandTable {
   DevBuf<double> logc_full;   // FK: log(count-discount); options: logp
   DevBuf<double> logc_m1;     // FK only
   double scal[4] = {0, 0, 0, 0};  // logden_full, logden_m1, lognew_n, lognew_nm1
+  std::vector<int32_t> h_vals;   // option tables: the values as last uploaded (pclean_set_options)
+  bool is_options_1col = false;
   std::vector<int64_t> h_counts;
   std::vector<double> h_logc_full, h_logc_m1;
   DevBuf<int64_t> stats;      // delta reference counts of last sweep

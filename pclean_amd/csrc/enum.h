@@ -131,7 +131,9 @@ struct FastTermDev {
   int32_t n_lat, fn_nb;
 };
 struct FastRootDev {
-  int32_t n_cand, kpad, n_terms, lmax, dstride, pad;
+  int32_t n_cand, kpad, n_terms, lmax, dstride;
+  int32_t is_leaf;        // 1: option list of a LEAF node (no exclusion, no "new row" candidate; prior_e / counts / logc_m1 null)
+  const uint16_t* alive;  // [kpad / 16] bit e of word q: candidate 16 q + e is a live row / an option with a finite prior
   const double* prior_e;  // [kpad] log(count-discount) - logden_m1, -inf for free slots / padding
   const double* prior_n;  // [kpad] same with logden_full (no exclusion)
   const double* logc_m1;
@@ -153,7 +155,7 @@ size_t pclean_fast_desc_words(int n_groups);  // int32 words of desc_scratch for
 int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_lat, const int32_t* cand_col,
                          const uint16_t* lat_len, int n_cand, int kpad, uint8_t* comp, uint8_t* clen);
 int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* logc_full, int n_cand, int kpad,
-                        double logden_e, double logden_n, double* prior_e, double* prior_n);
+                        double logden_e, double logden_n, double* prior_e, double* prior_n, uint16_t* alive);
 
 int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const ChildrenDev& ch, uint64_t seed,
                        uint32_t sweep, uint32_t site, int n_draws, double* lse_out, double* scores_out,

@@ -37,6 +37,7 @@
 #define ADD_TYPOS_IMPOSSIBLE (-1e5)
 #define FIX_CUTOFF 28.5        // pclean_fixw(d) == 0 for d < -28.5
 #define WAVE_SURV_CAP 256      // pre-filter survivors a wave keeps (4 per lane)
+#define WAVE_RB 4              // rounds (16 candidates per lane each) whose loads are in flight together
 #define GD_STRIDE 28           // int32 words per group descriptor
 // descriptor words: 0 m_lo, 1 m_hi, 2 representative item, 3 row, 4 excl, 5 ctx0, 6 ctx1, 7 flags (bit 0: the
 // excluded referent is garbage-collected), 8-9 bound (double), 10.. observed value index of term f
@@ -62,9 +63,18 @@ __global__ void priors_kernel(const int64_t* __restrict__ counts, const double* 
                               double* __restrict__ prior_n) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= kpad) return;
-  const bool live = k < n_cand && counts[k] != 0;
-  prior_e[k] = live ? logc_full[k] - logden_e : -__builtin_inf();
+  // FK table: live rows only; option table (counts == null): every option, prior = its log-probability
+  const bool live = k < n_cand && (counts ? counts[k] != 0 : true);
   prior_n[k] = live ? logc_full[k] - logden_n : -__builtin_inf();
+  if (prior_e) prior_e[k] = live ? logc_full[k] - logden_e : -__builtin_inf();
+}
+// bit e of alive[q] = candidate 16 q + e can carry weight (live row / option with a finite prior)
+__global__ void alive_kernel(const double* __restrict__ prior_n, int kpad, uint16_t* __restrict__ alive) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (kpad >> 4)) return;
+  uint32_t m = 0;
+  for (int e = 0; e < 16; ++e) m |= (prior_n[(q << 4) + e] > -__builtin_inf() ? 1u : 0u) << e;
+  alive[q] = (uint16_t)m;
 }
 
 int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_lat, const int32_t* cand_col,
@@ -80,9 +90,10 @@ int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_
   return PCLEAN_OK;
 }
 int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* logc_full, int n_cand, int kpad,
-                        double logden_e, double logden_n, double* prior_e, double* prior_n) {
+                        double logden_e, double logden_n, double* prior_e, double* prior_n, uint16_t* alive) {
   hipLaunchKernelGGL(priors_kernel, dim3((kpad + 255) / 256), dim3(256), 0, ctx->stream, counts, logc_full, n_cand,
                      kpad, logden_e, logden_n, prior_e, prior_n);
+  hipLaunchKernelGGL(alive_kernel, dim3(((kpad >> 4) + 255) / 256), dim3(256), 0, ctx->stream, prior_n, kpad, alive);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }
@@ -138,9 +149,10 @@ __global__ void group_desc_kernel(const FastRootDev fr, const DensDev dn, const 
   const int ctx1 = it.ctx ? it.ctx[(size_t)t * PCLEAN_MAX_CTX + 1] : 0;
   int o[PCLEAN_MAX_TERMS];
   for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) o[f] = f < fr.n_terms ? fr.terms[f].obs_col[row] : -1;
-  const bool deleted = excl >= 0 && fr.counts[excl] <= 1;
+  const bool deleted = excl >= 0 && fr.counts && fr.counts[excl] <= 1;
   double bound = -__builtin_inf();
-  if (excl >= 0 && !deleted) bound = fast_exact_score(fr, dn, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]) - 1.0;
+  if (excl >= 0 && !deleted && fr.logc_m1)
+    bound = fast_exact_score(fr, dn, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]) - 1.0;
   int32_t* d = gd + (size_t)g * GD_STRIDE;
   d[0] = m_lo;
   d[1] = m_hi;
@@ -194,11 +206,12 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
     }
     const bool excluded = excl >= 0;
     const double logden = excluded ? fr.scal[1] : fr.scal[0];
-    const double* __restrict__ prior = excluded ? fr.prior_e : fr.prior_n;
+    const double* __restrict__ prior = (excluded && fr.prior_e) ? fr.prior_e : fr.prior_n;
     const double pmax = excluded ? fr.prior_max_e : fr.prior_max_n;
-    // the "new row" candidate (index n, last in natural order): wave-uniform loads, in flight during the scan
-    double sn;
-    {
+    // the "new row" candidate (index n, last in natural order): wave-uniform loads, in flight during the scan;
+    // an option list (LEAF node) has none
+    double sn = -__builtin_inf();
+    if (!fr.is_leaf) {
       double snew = 0.0;
       for (int c = 0; c < ch.n; ++c) {
         size_t idx = (size_t)t;
@@ -263,23 +276,28 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
         }
     };
 
-    // ---- phase 0 (groups without a retained referent: nested slots of a new row, initialisation): the
-    // bound is the exact score of the live candidate with the smallest summed distance
+    // ---- phase 0 (groups without a retained referent: nested slots of a new row, option lists,
+    // initialisation): the bound is the exact score of the live candidate with the smallest summed distance
     if (!(bound > -__builtin_inf()) && fr.n_pre > 0) {
       uint64_t best = ~0ull;
-      for (int q0 = 0; q0 < nquads; q0 += 64) {
-        const int q = q0 + lane;
-        if (q >= nquads) break;
-        uint32_t lo[4], hi[4];
-        quad_sums(q, lo, hi);
+      for (int q0 = 0; q0 < nquads; q0 += 64 * WAVE_RB) {
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          const uint32_t D[4] = {lo[w] & 0xffffu, hi[w] & 0xffffu, lo[w] >> 16, hi[w] >> 16};
+        for (int r = 0; r < WAVE_RB; ++r) {
+          const int q = q0 + r * 64 + lane;
+          if (q < nquads) {
+            uint32_t lo[4], hi[4];
+            quad_sums(q, lo, hi);
+            const uint32_t al = fr.alive[q];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int k = (q << 4) + (w << 2) + e;
-            const uint64_t key = ((uint64_t)D[e] << 32) | (uint32_t)k;
-            if (key < best && k < n && k != excl && prior[k] > -__builtin_inf()) best = key;
+            for (int w = 0; w < 4; ++w) {
+              const uint32_t D[4] = {lo[w] & 0xffffu, hi[w] & 0xffffu, lo[w] >> 16, hi[w] >> 16};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int k = (q << 4) + (w << 2) + e;
+                const uint64_t key = ((uint64_t)D[e] << 32) | (uint32_t)k;
+                if (key < best && ((al >> (4 * w + e)) & 1u) && k != excl) best = key;
+              }
+            }
           }
         }
       }
@@ -299,42 +317,50 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
       if (x >= 0.0 && x < 60000.0) dcut = (uint32_t)x + 2u;
     }
 
-    // ---- phase 1: branch-free integer scan, 16 candidates per lane per round; survivors (live candidates
-    // with D <= dcut) go to the wave's LDS list in ascending candidate order
+    // ---- phase 1: branch-free integer scan, 16 candidates per lane per round, WAVE_RB rounds of loads in
+    // flight; survivors (live candidates with D <= dcut) go to the wave's LDS list in ascending candidate order
     int ns = 0;
-    for (int q0 = 0; q0 < nquads; q0 += 64) {
-      const int q = q0 + lane;
-      uint32_t mask16 = 0;
-      if (q < nquads) {
-        uint32_t lo[4], hi[4];
-        quad_sums(q, lo, hi);
+    for (int q0 = 0; q0 < nquads; q0 += 64 * WAVE_RB) {
+      uint32_t m16[WAVE_RB];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-          mask16 |= ((lo[w] & 0xffffu) <= dcut ? 1u : 0u) << (4 * w);
-          mask16 |= ((hi[w] & 0xffffu) <= dcut ? 1u : 0u) << (4 * w + 1);
-          mask16 |= ((lo[w] >> 16) <= dcut ? 1u : 0u) << (4 * w + 2);
-          mask16 |= ((hi[w] >> 16) <= dcut ? 1u : 0u) << (4 * w + 3);
+      for (int r = 0; r < WAVE_RB; ++r) {
+        const int q = q0 + r * 64 + lane;
+        m16[r] = 0;
+        if (q < nquads) {
+          uint32_t lo[4], hi[4];
+          quad_sums(q, lo, hi);
+          uint32_t mk = 0;
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            mk |= ((lo[w] & 0xffffu) <= dcut ? 1u : 0u) << (4 * w);
+            mk |= ((hi[w] & 0xffffu) <= dcut ? 1u : 0u) << (4 * w + 1);
+            mk |= ((lo[w] >> 16) <= dcut ? 1u : 0u) << (4 * w + 2);
+            mk |= ((hi[w] >> 16) <= dcut ? 1u : 0u) << (4 * w + 3);
+          }
+          m16[r] = mk & (uint32_t)fr.alive[q];  // padding and free slots never survive
         }
       }
-      if (__ballot(mask16 != 0) == 0ull) continue;  // wave-uniform: most rounds hold no survivor at all
-      uint32_t keep = 0;
-      for (uint32_t mm = mask16; mm; mm &= mm - 1) {  // drop padding and free slots
-        const int e = __builtin_ctz(mm);
-        const int k = (q << 4) + e;
-        if (k < n && (prior[k] > -__builtin_inf() || k == excl)) keep |= 1u << e;
+      uint32_t any = 0;
+#pragma unroll
+      for (int r = 0; r < WAVE_RB; ++r) any |= m16[r];
+      if (__ballot(any != 0) == 0ull) continue;  // wave-uniform: most rounds hold no survivor at all
+#pragma unroll
+      for (int r = 0; r < WAVE_RB; ++r) {
+        if (__ballot(m16[r] != 0) == 0ull) continue;
+        const int q = q0 + r * 64 + lane;
+        const int cnt = __builtin_popcount(m16[r]);
+        int incl = cnt;
+        for (int sh = 1; sh < 64; sh <<= 1) {
+          const int x = __shfl_up(incl, sh, 64);
+          if (lane >= sh) incl += x;
+        }
+        int pos = ns + incl - cnt;
+        for (uint32_t mm = m16[r]; mm; mm &= mm - 1) {
+          if (pos < WAVE_SURV_CAP) ksv[pos] = (q << 4) + __builtin_ctz(mm);
+          ++pos;
+        }
+        ns += __shfl(incl, 63, 64);
       }
-      const int cnt = __builtin_popcount(keep);
-      int incl = cnt;
-      for (int sh = 1; sh < 64; sh <<= 1) {
-        const int x = __shfl_up(incl, sh, 64);
-        if (lane >= sh) incl += x;
-      }
-      int pos = ns + incl - cnt;
-      for (uint32_t mm = keep; mm; mm &= mm - 1) {
-        if (pos < WAVE_SURV_CAP) ksv[pos] = (q << 4) + __builtin_ctz(mm);
-        ++pos;
-      }
-      ns += __shfl(incl, 63, 64);
     }
     __builtin_amdgcn_wave_barrier();
     if (ns > WAVE_SURV_CAP) {  // flat posterior: the host re-runs these items with the generic kernel
@@ -382,7 +408,7 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
       const int tm = it.grp_off ? it.members[mi] : t;
       if (j == 0 && lse_out) lse_out[tm] = lse;
       if (n_draws > 0) {
-        int32_t res = PCLEAN_CHOICE_NEW;
+        int32_t res = fr.is_leaf ? n - 1 : PCLEAN_CHOICE_NEW;
         if (U != 0) {
           const int row_m = it.row ? it.row[tm] : tm;
           const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[tm] : (uint32_t)((int64_t)row_m + it.row_offset);
@@ -396,7 +422,7 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
             else
               a = mid + 1;
           }
-          res = a == ns ? PCLEAN_CHOICE_NEW : ksv[a];
+          res = a == ns ? (fr.is_leaf ? n - 1 : PCLEAN_CHOICE_NEW) : ksv[a];
         }
         draws_out[(size_t)tm * draw_is + (size_t)j * draw_ds] = res;
       }

@@ -588,6 +588,7 @@ struct FastRoot {  // candidate-compact tables of a reference slot (root_wave.hi
   std::vector<DevBuf<uint8_t>> comp, clen;
   std::vector<uint64_t> ver;
   DevBuf<double> prior_e, prior_n;
+  DevBuf<uint16_t> alive;
   uint64_t prior_ver = 0;
   int kpad = 0;
   double logc_max = 0.0;  // max over candidates of log(count - discount)
@@ -648,6 +649,7 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
     for (auto& c : f.clen) c.release();
     f.prior_e.release();
     f.prior_n.release();
+    f.alive.release();
   }
   s->tail_counts.release();
   if (s->h_counts) (void)hipHostFree(s->h_counts);
@@ -890,8 +892,10 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   if (node_id >= 64) return 0;
   const pclean_node& n = b.nodes[node_id];
   const CandTable& t = ctx->cand[n.table];
-  if (n.kind != PCLEAN_NODE_FK || !t.valid || t.n_rows < 1024 || n.n_terms < 1 || n.n_terms > PCLEAN_MAX_TERMS)
-    return 0;
+  const bool leaf = n.kind == PCLEAN_NODE_LEAF;
+  static const bool no_leaf = getenv("PCLEAN_NO_FAST_LEAF") != nullptr;
+  if (!t.valid || t.n_rows < 1024 || n.n_terms < 1 || n.n_terms > PCLEAN_MAX_TERMS || (leaf && no_leaf)) return 0;
+  if (leaf != t.is_options) return 0;
   int lmax = 0, dmax = 0;
   for (int i = 0; i < n.n_terms; ++i) {
     const pclean_term& tm = b.terms[n.term_begin + i];
@@ -942,10 +946,11 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     fr.terms[i].comp = f.comp[i].p;
     fr.terms[i].clen = f.clen[i].p;
   }
-  if (f.prior_ver != t.version || !f.prior_e.p) {
-    if (f.prior_e.alloc(kpad) || f.prior_n.alloc(kpad)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-    int rc = pclean_build_priors(ctx, t.counts.p, t.logc_full.p, t.n_rows, kpad, t.scal[1], t.scal[0], f.prior_e.p,
-                                 f.prior_n.p);
+  if (f.prior_ver != t.version || !f.prior_n.p) {
+    if ((!leaf && f.prior_e.alloc(kpad)) || f.prior_n.alloc(kpad) || f.alive.alloc(std::max(kpad >> 4, 1)))
+      return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+    int rc = pclean_build_priors(ctx, leaf ? nullptr : t.counts.p, t.logc_full.p, t.n_rows, kpad, t.scal[1], t.scal[0],
+                                 leaf ? nullptr : f.prior_e.p, f.prior_n.p, f.alive.p);
     if (rc) return rc;
     f.prior_ver = t.version;
     f.logc_max = -INFINITY;
@@ -991,10 +996,12 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   fr.n_terms = n.n_terms;
   fr.lmax = lmax;
   fr.dstride = dmax + 1;
-  fr.prior_e = f.prior_e.p;
+  fr.is_leaf = leaf ? 1 : 0;
+  fr.alive = f.alive.p;
+  fr.prior_e = leaf ? nullptr : f.prior_e.p;
   fr.prior_n = f.prior_n.p;
-  fr.logc_m1 = t.logc_m1.p;
-  fr.counts = t.counts.p;
+  fr.logc_m1 = leaf ? nullptr : t.logc_m1.p;
+  fr.counts = leaf ? nullptr : t.counts.p;
   memcpy(fr.scal, t.scal, sizeof fr.scal);
   return 1;
 }

@@ -20,6 +20,24 @@ from .trace import CHOICE_NEW
 
 
 # ---------------------------------------------------------------------------
+# wall-clock accounting of the host phases (bench.py / scripts print it; negligible cost)
+import time as _time
+from collections import defaultdict as _dd
+from contextlib import contextmanager as _cm
+
+TIMERS = _dd(float)
+
+
+@_cm
+def _timed(name):
+    t0 = _time.perf_counter()
+    try:
+        yield
+    finally:
+        TIMERS[name] += _time.perf_counter() - t0
+
+
+# ---------------------------------------------------------------------------
 # evidence sets
 def _follow(lw, trace, start_cls, keys, path):
     """Row ids reached from rows `keys` of start_cls along the reference-slot path."""
@@ -201,7 +219,8 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
     comm = comm or Comm()
     lw = engine.lw
     pl = lw.latent_plans[cname]
-    live, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname)
+    with _timed(f"latent/{cname}/build_evidence"):
+        live, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname)
     if len(live) == 0:
         return 0
     t = trace.tables[cname]
@@ -215,20 +234,24 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
         for r, root in enumerate(pl["roots"]):
             if pl["nodes"][root][0] == 0:
                 excl[r] = t.cols[lw.colidx[cname][pl["root_attr"][r]], live[b0:b1]]
-        engine.upload_trace(trace)
+        with _timed(f"latent/{cname}/upload"):
+            engine.upload_trace(trace)
         lo, hi = shard_bounds(b1 - b0, comm.rank, comm.world)
         lo, hi = lo + b0, hi + b0
         e0, e1 = int(ev_off[lo]), int(ev_off[hi])
         chosen = np.zeros(0, np.int32)
         vals = np.zeros((0, len(pl["nodes"])), np.int32)
         if hi > lo:
-            chosen, vals = engine.sweep_latent(trace, cname, config, seed, sweep_idx, live[lo:hi], ev_off[lo:hi + 1] - e0,
-                                               ev_rows[e0:e1], None if ev_ctx is None else ev_ctx[e0:e1],
-                                               np.ascontiguousarray(excl[:, lo - b0:hi - b0]))
+            with _timed(f"latent/{cname}/gpu_sweep"):
+                chosen, vals = engine.sweep_latent(trace, cname, config, seed, sweep_idx, live[lo:hi],
+                                                   ev_off[lo:hi + 1] - e0, ev_rows[e0:e1],
+                                                   None if ev_ctx is None else ev_ctx[e0:e1],
+                                                   np.ascontiguousarray(excl[:, lo - b0:hi - b0]))
         if comm.world > 1:
             chosen = comm.allgather_varlen_i32(chosen)
             vals = comm.allgather_varlen_i32(vals).reshape(-1, len(pl["nodes"]))
-        changed += commit_latent(lw, trace, cname, live[b0:b1], chosen, vals)
+        with _timed(f"latent/{cname}/commit"):
+            changed += commit_latent(lw, trace, cname, live[b0:b1], chosen, vals)
     return changed
 
 
@@ -258,15 +281,19 @@ def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None, max_sub_ba
                 print(f"{engine.lw.query.cls}: Cleaning row {b0} of {n}", flush=True)
         lo, hi = shard_bounds(b1 - b0, comm.rank, comm.world)
         lo, hi = lo + b0, hi + b0
-        engine.upload_trace(trace)
+        with _timed("observed/upload"):
+            engine.upload_trace(trace)
         light = hasattr(engine, "sweep_moved")  # the HIP engine reports the moved rows: no per-row outputs needed
-        choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi, reuse_buffers=True,
-                                                       **({"light": True} if light else {}))
-        stats = engine.sweep_stats(trace)
-        moved = engine.sweep_moved() if light else None
-        _gather_locals(trace, comm, b0, hi - lo, lo)
-        changed += exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True,
-                                       moved_local=moved, n_local=hi - lo)
+        with _timed("observed/gpu_sweep"):
+            choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi, reuse_buffers=True,
+                                                           **({"light": True} if light else {}))
+        with _timed("observed/stats_moved"):
+            stats = engine.sweep_stats(trace)
+            moved = engine.sweep_moved() if light else None
+            _gather_locals(trace, comm, b0, hi - lo, lo)
+        with _timed("observed/exchange_commit"):
+            changed += exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True,
+                                           moved_local=moved, n_local=hi - lo)
     return changed
 
 
@@ -281,9 +308,10 @@ def resample_parameters(trace):
 def resample_class_parameters(trace, cname):
     """pgibbs_sweep!'s move (inference.jl:72-77): only the swept class's parameters and its table's
     Pitman–Yor hyper-parameters."""
-    trace.resample_parameters(cname)
-    if cname in trace.tables:
-        trace.resample_py_params(trace.tables[cname])
+    with _timed("resample_parameters"):
+        trace.resample_parameters(cname)
+        if cname in trace.tables:
+            trace.resample_py_params(trace.tables[cname])
 
 
 def initialize_trace(engine, trace, config, seed, max_batch=256, comm=None):
