@@ -160,3 +160,7 @@ int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* lo
 int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const ChildrenDev& ch, uint64_t seed,
                        uint32_t sweep, uint32_t site, int n_draws, double* lse_out, double* scores_out,
                        int32_t* draws_out);
+// option list of a LEAF node scored against evidence sets (enum_kernels.hip: ev_leaf_wave_kernel)
+int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const FastRootDev& fr, uint64_t seed,
+                          uint32_t sweep, uint32_t site, int n_draws, double* lse_out, int32_t* draws_out,
+                          int32_t* overflow_flag, unsigned int* overflow_count);

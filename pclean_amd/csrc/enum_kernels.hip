@@ -231,6 +231,185 @@ int pclean_launch_gate(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
   return PCLEAN_OK;
 }
 
+// ---- ev_leaf_wave_kernel: a big option list (LEAF node) scored against an EVIDENCE SET ------------------------
+// Latent-class sweeps re-propose every attribute of a latent row given all observed rows that refer to it
+// (proposal_compiler.jl:306-350).  For an option list of 40k strings that is 40k x (evidence) densities per row
+// in the generic kernels.  Same idea as root_wave.hip, with the aggregated evidence as the "rows":
+//     score(k) <= prior_max - c_min * D(k),   D(k) = sum over entries (o, mult) of the node's plain AddTypos terms
+//                                                     of mult * comp[o][k]      (32-bit integer arithmetic)
+// pass A finds the live option with the smallest D (its exact score - 1 is a lower bound of the maximum), pass B
+// keeps the options with D <= dcut; only those are scored exactly — through candidate_score(), the very
+// function the generic kernels use, so the result is bit-identical.  One wavefront per latent row, persistent
+// grid, no workgroup barrier.  Rows with more than EV_SURV_CAP survivors are flagged for the generic kernel.
+#define EV_SURV_CAP 256
+#define EV_FIX_CUTOFF 28.5
+
+__global__ __launch_bounds__(256) void ev_leaf_wave_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
+                                                           const FastRootDev fr, uint64_t seed, uint32_t sweep,
+                                                           uint32_t site, int n_draws, double* __restrict__ lse_out,
+                                                           int32_t* __restrict__ draws_out,
+                                                           int32_t* __restrict__ overflow_flag,
+                                                           unsigned int* __restrict__ overflow_count) {
+  __shared__ uint64_t s_pref[4][EV_SURV_CAP + 8];
+  __shared__ int32_t s_k[4][EV_SURV_CAP + 8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t* pref = s_pref[wave];
+  int32_t* ksv = s_k[wave];
+  const int n = nd.n_cand;
+  const int nquads = fr.kpad >> 4;
+  const int draw_is = it.draw_is ? it.draw_is : n_draws;
+  for (int t = blockIdx.x * 4 + wave; t < it.n; t += gridDim.x * 4) {
+    const ItemView v = item_view(nd, it, t);
+    const int oi = it.ev_item ? it.ev_item[t] : t;
+    // weighted distance sums of the 16 options of quad q over the entries of the plain (compact-table) terms
+    auto wsum = [&](int q, uint32_t* acc) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0u;
+      for (int f = 0; f < fr.n_terms; ++f) {
+        if (!fr.terms[f].comp) continue;
+        const AggDev ag = it.agg[f];
+        const int r1 = ag.off[oi + 1];
+        for (int r = ag.off[oi]; r < r1; ++r) {
+          const uint64_t key = ag.key[r];
+          const int o = (int)(key & 0xffffffull) - 1;
+          if (o < 0) continue;
+          const uint32_t mult = (uint32_t)ag.cnt[r];
+          const uint4 c = reinterpret_cast<const uint4*>(fr.terms[f].comp + (size_t)o * fr.kpad)[q];
+          const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+          for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[4 * w + e] += mult * ((cw[w] >> (8 * e)) & 0xffu);
+        }
+      }
+    };
+    // ---- pass A: the live option with the smallest weighted distance -> lower bound of the maximum
+    uint64_t best = ~0ull;
+    for (int q0 = 0; q0 < nquads; q0 += 64) {
+      const int q = q0 + lane;
+      if (q < nquads) {
+        uint32_t acc[16];
+        wsum(q, acc);
+        const uint32_t al = fr.alive[q];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const uint64_t key = ((uint64_t)acc[e] << 32) | (uint32_t)((q << 4) + e);
+          if (((al >> e) & 1u) && key < best) best = key;
+        }
+      }
+    }
+    for (int sh = 32; sh > 0; sh >>= 1) {
+      const uint64_t other = __shfl_xor(best, sh, 64);
+      best = other < best ? other : best;
+    }
+    double bound = -__builtin_inf();
+    if (best != ~0ull) bound = candidate_score(nd, dn, it, v, (int)(uint32_t)best) - 1.0;
+    uint32_t dcut = 0xffffffffu;
+    if (fr.inv_c > 0.0 && bound > -__builtin_inf()) {
+      const double x = (fr.prior_max_n - bound + EV_FIX_CUTOFF) * fr.inv_c;
+      if (x >= 0.0 && x < 4.0e9) dcut = (uint32_t)x + 2u;
+    }
+    // ---- pass B: survivors in ascending option order
+    int ns = 0;
+    for (int q0 = 0; q0 < nquads; q0 += 64) {
+      const int q = q0 + lane;
+      uint32_t mask16 = 0;
+      if (q < nquads) {
+        uint32_t acc[16];
+        wsum(q, acc);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mask16 |= (acc[e] <= dcut ? 1u : 0u) << e;
+        mask16 &= (uint32_t)fr.alive[q];
+      }
+      if (__ballot(mask16 != 0) == 0ull) continue;
+      const int cnt = __builtin_popcount(mask16);
+      int incl = cnt;
+      for (int sh = 1; sh < 64; sh <<= 1) {
+        const int x = __shfl_up(incl, sh, 64);
+        if (lane >= sh) incl += x;
+      }
+      int pos = ns + incl - cnt;
+      for (uint32_t mm = mask16; mm; mm &= mm - 1) {
+        if (pos < EV_SURV_CAP) ksv[pos] = (q << 4) + __builtin_ctz(mm);
+        ++pos;
+      }
+      ns += __shfl(incl, 63, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int to = it.out_pos ? it.out_pos[t] : t;
+    if (ns > EV_SURV_CAP) {
+      if (lane == 0) {
+        overflow_flag[to] = PCLEAN_CHOICE_NEW;
+        atomicAdd(overflow_count, 1u);
+      }
+      continue;
+    }
+    if (lane == 0) overflow_flag[to] = 0;
+    // ---- exact scores (the generic kernels' own function), maximum, fixed-point prefix
+    double sc[EV_SURV_CAP / 64];
+    double m = -__builtin_inf();
+#pragma unroll
+    for (int p = 0; p < EV_SURV_CAP / 64; ++p) {
+      sc[p] = -__builtin_inf();
+      const int j = p * 64 + lane;
+      if (j < ns) sc[p] = candidate_score(nd, dn, it, v, ksv[j]);
+      m = fmax(m, sc[p]);
+    }
+    m = wave_max(m);
+    uint64_t carry = 0;
+#pragma unroll
+    for (int p = 0; p < EV_SURV_CAP / 64; ++p) {
+      if (p * 64 >= ns) break;  // wave-uniform
+      const uint64_t u = (m == -__builtin_inf()) ? 0ull : pclean_fixw(sc[p] - m);
+      unsigned long long incl = u;
+      for (int sh = 1; sh < 64; sh <<= 1) {
+        const unsigned long long x = __shfl_up(incl, sh, 64);
+        if (lane >= sh) incl += x;
+      }
+      const int j = p * 64 + lane;
+      if (j < ns) pref[j] = carry + incl;
+      carry += __shfl(incl, 63, 64);
+    }
+    const uint64_t U = carry;
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      if (lse_out) lse_out[to] = pclean_lse_from_fix(m, U);
+      if (n_draws > 0) {
+        int32_t res = n - 1;
+        if (U != 0) {
+          const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[t] : (uint32_t)((int64_t)v.row + it.row_offset);
+          const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : 0u;
+          const uint64_t x = pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U);
+          int a = 0, b = ns - 1;  // smallest index with prefix > x
+          while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (pref[mid] > x)
+              b = mid;
+            else
+              a = mid + 1;
+          }
+          res = ksv[a];
+        }
+        draws_out[(size_t)to * draw_is] = res;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const FastRootDev& fr, uint64_t seed,
+                          uint32_t sweep, uint32_t site, int n_draws, double* lse_out, int32_t* draws_out,
+                          int32_t* overflow_flag, unsigned int* overflow_count) {
+  if (it.n <= 0) return PCLEAN_OK;
+  if (n_draws > 1) return pclean_fail(ctx, PCLEAN_ERR_ARG, "evidence-set option lists draw at most once per item");
+  DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
+  const int wgs = std::min(256 * 8, (it.n + 3) / 4);
+  hipLaunchKernelGGL(ev_leaf_wave_kernel, dim3(wgs), dim3(256), 0, ctx->stream, nd, dn, it, fr, seed, sweep, site, n_draws,
+                     lse_out, draws_out, overflow_flag, overflow_count);
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
+
 // exclusive block scan of one uint64 per lane (256 lanes); returns lane prefix, sets total
 __device__ __forceinline__ uint64_t block_excl_scan(uint64_t part, uint64_t* wsum, uint64_t* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -237,25 +237,45 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
         if (of >= 0) prow[p] = reinterpret_cast<const uint4*>(fr.terms[f].comp + (size_t)of * fr.kpad);
       }
     }
+    // exact score of candidate k.  Three straight-line stages so that the loads of all terms are in flight
+    // together (byte distance + length, then the two density pieces), then the fp64 additions in plan order.
     auto exact = [&](int k) {
       double pr = prior[k];
       if (k == excl) pr = deleted ? -__builtin_inf() : fr.logc_m1[excl] - logden;
+      int dd[NT], LL[NT];
+#pragma unroll
+      for (int f = 0; f < NT; ++f) {
+        dd[f] = 0;
+        LL[f] = 0;
+        if (f < fr.n_terms && o[f] >= 0) {
+          const FastTermDev& tm = fr.terms[f];
+          if (tm.ctx_slot < 0) {
+            dd[f] = tm.comp[(size_t)o[f] * fr.kpad + k];
+            LL[f] = tm.clen[k];
+          } else {
+            const int c = tm.ctx_slot == 0 ? ctx0 : ctx1;
+            const int val = tm.fn[(size_t)c * tm.fn_nb + tm.cand_col[k]];
+            dd[f] = tm.pair[(size_t)o[f] * tm.n_lat + val];
+            LL[f] = tm.lat_len[val];
+          }
+        }
+      }
+      double nbv[NT], lgv[NT];
+#pragma unroll
+      for (int f = 0; f < NT; ++f) {
+        nbv[f] = dn.nb[(size_t)((LL[f] + 4) / 5) * dn.nb_stride + dd[f]];
+        lgv[f] = dn.logl[LL[f]];
+      }
       double b = pr;
 #pragma unroll
       for (int f = 0; f < NT; ++f) {
-        if (f >= fr.n_terms || o[f] < 0) continue;
-        const FastTermDev& tm = fr.terms[f];
-        int d, L;
-        if (tm.ctx_slot < 0) {
-          d = tm.comp[(size_t)o[f] * fr.kpad + k];
-          L = tm.clen[k];
-        } else {
-          const int c = tm.ctx_slot == 0 ? ctx0 : ctx1;
-          const int val = tm.fn[(size_t)c * tm.fn_nb + tm.cand_col[k]];
-          d = tm.pair[(size_t)o[f] * tm.n_lat + val];
-          L = tm.lat_len[val];
+        if (f < fr.n_terms && o[f] >= 0) {  // an explicitly missing observation contributes nothing
+          double l = nbv[f];                // the fp64 operation order of add_typos_dens()
+          l -= lgv[f] * (double)dd[f];
+          l -= HALF_LOG26 * (double)dd[f];
+          const int mt = fr.terms[f].max_typos;
+          b += (mt >= 0 && dd[f] > mt) ? ADD_TYPOS_IMPOSSIBLE : l;
         }
-        b += (tm.max_typos >= 0 && d > tm.max_typos) ? ADD_TYPOS_IMPOSSIBLE : add_typos_dens(dn, L, d);
       }
       return b;
     };

@@ -148,14 +148,48 @@ __global__ void ctx_fill_kernel(int N, int P, const int32_t* __restrict__ it_ctx
     }
   }
 }
-// particle slot t takes the log-marginal of its context's item and its own draw (particle id = t / N)
-__global__ void expand_ctx_kernel(size_t NP, int N, int P, const int32_t* slot_item, const double* lse_item,
-                                  const int32_t* draws_item, int32_t* draws, double* w) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= NP) return;
-  const int item = slot_item[t];
-  draws[t] = draws_item[(size_t)item * P + (t / N)];
-  w[t] += lse_item[item];
+// One thread per row, after a block's root enumeration: particle p of row i takes its draw (row-major from the
+// root kernels: draws_rm[i * P + p], or draw p of its context's item) and the block's log-marginal; particle 0
+// keeps the retained referent under CSMC (row_inference.jl:143-145).  Writes the particle-major arrays
+// coalesced and counts the particles that proposed a NEW referent (block-aggregated atomic).
+__global__ __launch_bounds__(256) void particle_update_kernel(int N, int P, const int32_t* __restrict__ draws_rm,
+                                                              const double* __restrict__ lse,
+                                                              const int32_t* __restrict__ slot_item,
+                                                              const int32_t* __restrict__ draws_item,
+                                                              const double* __restrict__ lse_item,
+                                                              const int32_t* __restrict__ cur_b,
+                                                              int32_t* __restrict__ pchoice, double* __restrict__ w,
+                                                              unsigned int* __restrict__ n_new) {
+  __shared__ unsigned int wcnt[4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned int mine = 0;
+  if (i < N) {
+    const int keep = cur_b ? cur_b[i] : -1;
+    for (int p = 0; p < P; ++p) {
+      const size_t sp = (size_t)p * N + i;
+      int d;
+      double l;
+      if (slot_item) {
+        const int item = slot_item[sp];
+        d = draws_item[(size_t)item * P + p];
+        l = lse_item[item];
+      } else {
+        d = draws_rm[(size_t)i * P + p];
+        l = lse[i];
+      }
+      const int c = (p == 0 && keep >= 0) ? keep : d;
+      pchoice[sp] = c;
+      w[sp] += l;
+      mine += c == PCLEAN_CHOICE_NEW ? 1u : 0u;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
+  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (total) atomicAdd(n_new, total);
+  }
 }
 
 // ---- pure scoring block (flights Obs block 3): p += logdensity(MaybeSwap, ...) ---------------------
@@ -210,21 +244,6 @@ __global__ void score_block_kernel(int n_rows, int P, ScoreBlockDev sb, double* 
   w[slot] += acc;
 }
 
-// root draws (particle-major) -> particle choices; particle 0 keeps the retained referent under CSMC
-// (row_inference.jl:143-145)
-__global__ void set_pchoice_kernel(int n_rows, int P, const int32_t* draws, const int32_t* cur_b, int32_t* pchoice) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)n_rows * P) return;
-  int c = draws[t];
-  if (t < (size_t)n_rows && cur_b && cur_b[t] >= 0) c = cur_b[t];  // particle 0 occupies slots [0, N)
-  pchoice[t] = c;
-}
-
-__global__ void add_weight_shared_kernel(int n_rows, int P, const double* lse, double* w) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= (size_t)n_rows * P) return;
-  w[t] += lse[t % n_rows];
-}
 __global__ void add_weight_kernel(size_t n, const double* lse, double* w) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) w[t] += lse[t];
@@ -589,6 +608,7 @@ struct FastRoot {  // candidate-compact tables of a reference slot (root_wave.hi
   std::vector<uint64_t> ver;
   DevBuf<double> prior_e, prior_n;
   DevBuf<uint16_t> alive;
+  int disabled = 0;  // > 0: the pre-filter does not pay for this node (most items overflowed): that many evaluations use the generic kernel
   uint64_t prior_ver = 0;
   int kpad = 0;
   double logc_max = 0.0;  // max over candidates of log(count - discount)
@@ -887,7 +907,7 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
 
 // Fast path of a reference slot (root_wave.hip): returns 1 and fills `fr` when the node is an FK
 // with many candidates whose terms are all plain AddTypos lookups in byte tables; 0 otherwise.
-static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev& fr) {
+static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev& fr, bool ev_mode = false) {
   Block& b = ctx->block[block_id];
   if (node_id >= 64) return 0;
   const pclean_node& n = b.nodes[node_id];
@@ -901,13 +921,18 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     const pclean_term& tm = b.terms[n.term_begin + i];
     const PairTable& pt = ctx->pair[tm.pair_table];
     if (!pt.valid || tm.dens_kind != PCLEAN_DENS_ADD_TYPOS || pt.elem_bytes != 1) return 0;
-    if (tm.ctx_slot >= 0 && (tm.ctx_mode != 0 || !ctx->fn[tm.fn_table].valid)) return 0;
+    // evidence sets (ev_leaf_wave_kernel): ctx terms are only ever scored exactly (by candidate_score), any mode goes
+    if (tm.ctx_slot >= 0 && ((!ev_mode && tm.ctx_mode != 0) || !ctx->fn[tm.fn_table].valid)) return 0;
     lmax = std::max(lmax, pt.max_lat_len);
     dmax = std::max(dmax, std::max(pt.max_lat_len, pt.max_obs_len));
   }
   if (lmax > 255 || dmax > 255) return 0;
   const int kpad = (t.n_rows + 15) & ~15;
   FastRoot& f = st(ctx)->fast[block_id * 64 + node_id];
+  if (f.disabled > 0) {
+    --f.disabled;
+    return 0;
+  }
   if ((int)f.comp.size() != n.n_terms || f.kpad != kpad) {
     for (auto& c : f.comp) c.release();
     for (auto& c : f.clen) c.release();
@@ -1294,17 +1319,27 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     }
   }
   FastRootDev fr;
-  int fast = 0;
-  if (!scores_out && !snew_override && !ctx->force_generic && !il.ev_lo && !nd.g.on) {
-    fast = try_fast_root(ctx, block_id, node_id, fr);
+  int fast = 0, fast_ev = 0;
+  if (!scores_out && !snew_override && !ctx->force_generic && !nd.g.on) {
+    if (!il.ev_lo)
+      fast = try_fast_root(ctx, block_id, node_id, fr);
+    else if (n.kind == PCLEAN_NODE_LEAF && n_draws <= 1 && !getenv("PCLEAN_NO_FAST_EV"))
+      fast_ev = try_fast_root(ctx, block_id, node_id, fr, true);
     if (fast < 0) return fast;
+    if (fast_ev < 0) return fast_ev;
+    if (fast_ev) {  // needs at least one plain (compact-table) term to filter on
+      bool any = false;
+      for (int i = 0; i < fr.n_terms; ++i) any |= fr.terms[i].comp != nullptr;
+      if (!any) fast_ev = 0;
+    }
   }
   // Items with identical score vectors (same observed tuple, ctx and excluded row) share one
   // wavefront / workgroup: scores once, draws per member item.
   {
     const int nc = nd.n_cand + (n.kind == PCLEAN_NODE_FK ? 1 : 0);
     const bool lds_kernel = (size_t)((nc + 1) & ~1) * 8 + (16 + 64) * 8 <= 160 * 1024;
-    if (n_draws > 0 && !scores_out && !snew_override && !ctx->force_generic && !il.rng_row && (fast || lds_kernel)) {
+    if (n_draws > 0 && !scores_out && !snew_override && !ctx->force_generic && !il.rng_row && !il.ev_lo &&
+        (fast || lds_kernel)) {
       ItemGroups g;
       rc = make_item_groups(ctx, block_id, node_id, il, excl, g);
       if (rc) return rc;
@@ -1331,24 +1366,28 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
       for (int p = 0; p < 3; ++p) rs.pre_obs_col[p] = p < fr.n_pre ? b.terms[n.term_begin + fr.pre[p]].obs_col : -1;
     }
   }
-  if (!fast) {
+  if (!fast && !fast_ev) {
     ProfScope ps(ctx, n.kind == PCLEAN_NODE_FK ? "enum_fk_generic" : "enum_leaf_generic");
     if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
     rc = pclean_launch_enum(ctx, nd, it, ch, seed, sweep, site, n_draws, lse_out, scores_out, draws_out);
     if (time_it) (void)hipEventRecord(s->ev1, ctx->stream);
     return rc;
   }
-  // compact-table kernel; items whose survivor list overflows are re-run with the generic kernel
+  // compact-table kernels; items whose survivor list overflows are re-run with the generic kernel
   int32_t* oflag = scratch<int32_t>(ctx, il.n);
-  int32_t* desc = scratch<int32_t>(ctx, pclean_fast_desc_words(it.n));
-  if (!oflag || !desc || s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  if (!oflag || s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   HIPCHK(ctx, hipMemsetAsync(s->counter.p + 1, 0, sizeof(unsigned int), ctx->stream));
-  {
-    ProfScope ps(ctx, time_it ? "root_scan_block0" : "slot_scan");
+  if (fast) {
+    int32_t* desc = scratch<int32_t>(ctx, pclean_fast_desc_words(it.n));
+    if (!desc) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    ProfScope ps(ctx, time_it ? "root_scan_block0" : (n.kind == PCLEAN_NODE_FK ? "slot_scan" : "option_scan"));
     if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
     rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag,
                                  s->counter.p + 1, desc);
     if (time_it) (void)hipEventRecord(s->ev1, ctx->stream);
+  } else {
+    ProfScope ps(ctx, "evidence_option_scan");
+    rc = pclean_launch_ev_leaf(ctx, nd, it, fr, seed, sweep, site, n_draws, lse_out, draws_out, oflag, s->counter.p + 1);
   }
   if (rc) return rc;
   unsigned int n_over = 0;
@@ -1356,6 +1395,9 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   ctx->timing.reserved += (int32_t)n_over;  // items that fell back to the generic kernel
   if (time_it) ctx->root_stats.overflow_items = (int32_t)n_over;
+  // short strings / flat posteriors: when a quarter of the items overflow the survivor list the integer pre-filter
+  // does not pay for this node -> the next 64 evaluations go straight to the generic kernel, then it is retried
+  if (il.n >= 64 && (size_t)n_over * 4 > (size_t)il.n) s->fast[block_id * 64 + node_id].disabled = 64;
   if (n_over && getenv("PCLEAN_DEBUG_OVERFLOW"))
     fprintf(stderr, "[pclean] block %d node %d: %u of %d items re-run by the generic kernel\n", block_id, node_id, n_over,
             il.n);
@@ -1366,15 +1408,22 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     int32_t* excl2 = scratch<int32_t>(ctx, n_over);
     int32_t* ctx2 = scratch<int32_t>(ctx, (size_t)n_over * PCLEAN_MAX_CTX);
     int32_t* part2 = scratch<int32_t>(ctx, n_over);
-    if (!list || !row2 || !excl2 || !ctx2 || !part2) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    int32_t* evl2 = il.ev_lo ? scratch<int32_t>(ctx, n_over) : nullptr;
+    int32_t* evh2 = il.ev_lo ? scratch<int32_t>(ctx, n_over) : nullptr;
+    int32_t* org2 = il.ev_lo ? scratch<int32_t>(ctx, n_over) : nullptr;
+    int32_t* rng2 = il.rng_row ? scratch<int32_t>(ctx, n_over) : nullptr;
+    if (!list || !row2 || !excl2 || !ctx2 || !part2 || (il.ev_lo && (!evl2 || !evh2 || !org2)) || (il.rng_row && !rng2))
+      return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
     HIPCHK(ctx, hipMemsetAsync(s->counter.p + 1, 0, sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, oflag, 1,
                        s->counter.p + 1, list, nullptr);
-    hipLaunchKernelGGL(gather_items_kernel, grid1(n_over), dim3(256), 0, ctx->stream, (int)n_over, list, il.row,
-                       il.ctx, excl, it.particle, row2, ctx2, excl2, part2);
+    hipLaunchKernelGGL(sub_items_kernel, grid1(n_over), dim3(256), 0, ctx->stream, (int)n_over, list, il.row, il.ctx, excl,
+                       il.ev_lo, il.ev_hi, il.rng_row, il.origin, row2, ctx2, excl2, evl2, evh2, rng2, org2);
+    if (it.particle)
+      hipLaunchKernelGGL(gather_i32_kernel, grid1(n_over), dim3(256), 0, ctx->stream, (int)n_over, list, it.particle, part2);
     ItemsDev it2{(int)n_over, 0, row2, il.ctx ? ctx2 : nullptr, excl ? excl2 : nullptr, it.particle ? part2 : nullptr,
-                 s->row_offset + ctx->active_begin, list, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
-                 il.draw_is, il.draw_ds};
+                 s->row_offset + ctx->active_begin, list, evl2, evh2, il.ev_rows, il.ev_ctx, rng2, nullptr, nullptr,
+                 il.draw_is, il.draw_ds, it.agg, org2};
     rc = pclean_launch_enum(ctx, nd, it2, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out);
   }
   return rc;
@@ -1996,9 +2045,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     ItemList il;
     const int32_t* excl;
     if (!has_ctx) {
-      il = ItemList{N, nullptr, nullptr, nullptr, nullptr};
-      il.draw_is = 1;   // particle-major draws: slot = particle * N + row
-      il.draw_ds = N;
+      il = ItemList{N, nullptr, nullptr, nullptr, nullptr};  // draws row-major [N][P]: one 80-byte store per row
       excl = cur_b;
       if (r.draws.alloc(NP) || r.lse.alloc(N)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
       rc = eval_node(ctx, bi, 0, il, excl, seed, sweep_idx, P, r.lse.p, r.draws.p, nullptr, nullptr, bi == 0);
@@ -2011,9 +2058,12 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         ctx->timing.hot_kernel_launches += 1;
       }
       ProfScope ps(ctx, "particle_update");
-      hipLaunchKernelGGL(add_weight_shared_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, r.lse.p, s->w.p);
+      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+      hipLaunchKernelGGL(particle_update_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
+                         (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
+                         s->w.p, s->counter.p);
     } else {
-      if (r.it_ctx.alloc(NP * PCLEAN_MAX_CTX) || r.draws.alloc(NP)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+      if (r.it_ctx.alloc(NP * PCLEAN_MAX_CTX)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
       CtxSrc cs{};
       cs.n_ctx = b.n_ctx;
       for (int c = 0; c < b.n_ctx; ++c) {
@@ -2063,20 +2113,15 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       rc = eval_node(ctx, bi, 0, il, d_excl, seed, sweep_idx, P, lse_item, draws_item, nullptr, nullptr, false);
       if (rc) return rc;
       ProfScope ps(ctx, "particle_update");
-      hipLaunchKernelGGL(expand_ctx_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, N, P, slot_item, lse_item,
-                         draws_item, r.draws.p, s->w.p);
-    }
-    unsigned int n_new = 0;
-    {
-      ProfScope ps(ctx, "particle_update");
-      hipLaunchKernelGGL(set_pchoice_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, r.draws.p, cur_b, r.pchoice.p);
-      // ---- particles that proposed a NEW referent: sample the new row's contents
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-      hipLaunchKernelGGL(compact_new_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, r.pchoice.p, 0, s->counter.p,
-                         nullptr, nullptr);
-      HIPCHK(ctx, hipMemcpyAsync(&n_new, s->counter.p, sizeof n_new, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      hipLaunchKernelGGL(particle_update_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, (const int32_t*)nullptr,
+                         (const double*)nullptr, slot_item, draws_item, lse_item, cur_b, r.pchoice.p, s->w.p,
+                         s->counter.p);
     }
+    // ---- particles that proposed a NEW referent: sample the new row's contents
+    unsigned int n_new = 0;
+    HIPCHK(ctx, hipMemcpyAsync(&n_new, s->counter.p, sizeof n_new, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     r.n_new = (int)n_new;
     if (r.vals.alloc(std::max<size_t>((size_t)n_new * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
     if (n_new) {

@@ -449,20 +449,20 @@ class Trace:
 
     @staticmethod
     def pitman_yor_score(strength, discount, counts):
-        """trace.jl:65-78, vectorised: counts in table order (cluster j is the j-th object)."""
+        """trace.jl:65-78, vectorised (O(K)): counts in table order (cluster j is the j-th object).  The joins of
+        a cluster of size c that started after `before` customers, sum_{i=1}^{c-1} log(i - d) - log(before + i + s),
+        are written with log-gamma differences."""
+        from scipy.special import gammaln
         counts = np.asarray(counts, dtype=np.float64)
         if counts.size == 0:
             return 0.0
-        from math import lgamma
         n_obj = np.arange(1, counts.size + 1, dtype=np.float64)
         before = np.concatenate([[0.0], np.cumsum(counts)[:-1]])
         lp = np.sum(np.log(n_obj * discount + strength) - np.log(before + strength))
-        # joins of each cluster: sum_{i=1}^{size-1} log(i - d) - log(before + i + s)
-        for c, b in zip(counts, before):
-            c = int(c)
-            if c > 1:
-                lp += lgamma(c - discount) - lgamma(1 - discount)
-                lp -= lgamma(b + c + strength) - lgamma(b + 1 + strength)
+        big = counts > 1
+        c, b = counts[big], before[big]
+        lp += np.sum(gammaln(c - discount) - gammaln(1.0 - discount))
+        lp -= np.sum(gammaln(b + c + strength) - gammaln(b + 1.0 + strength))
         return float(lp)
 
     def resample_py_params(self, t):
