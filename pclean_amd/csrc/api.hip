@@ -162,10 +162,14 @@ extern "C" int pclean_build_pair_table(pclean_ctx* ctx, int32_t table_id, int32_
     if (obs_ids[i] < 0 || obs_ids[i] >= ctx->n_strings) return pclean_fail(ctx, PCLEAN_ERR_ARG, "obs id out of range");
     max_la = std::max(max_la, (int)(ctx->h_off[obs_ids[i] + 1] - ctx->h_off[obs_ids[i]]));
   }
+  int64_t sum_lb = 0;
   for (int i = 0; i < n_lat; ++i) {
     if (lat_ids[i] < 0 || lat_ids[i] >= ctx->n_strings) return pclean_fail(ctx, PCLEAN_ERR_ARG, "lat id out of range");
-    max_lb = std::max(max_lb, (int)(ctx->h_off[lat_ids[i] + 1] - ctx->h_off[lat_ids[i]]));
+    const int len = (int)(ctx->h_off[lat_ids[i] + 1] - ctx->h_off[lat_ids[i]]);
+    max_lb = std::max(max_lb, len);
+    sum_lb += len;
   }
+  pt.mean_lat_len = (double)sum_lb / (double)n_lat;
   pt.n_obs = n_obs;
   pt.n_lat = n_lat;
   pt.max_obs_len = max_la;

@@ -48,6 +48,7 @@ struct PairTable {
   DevBuf<uint8_t> d;          // [n_obs][n_lat] * elem_bytes
   DevBuf<uint16_t> lat_len;   // word length (characters) of each latent value
   int32_t max_lat_len = 0, max_obs_len = 0;
+  double mean_lat_len = 0.0;  // AddTypos tables built on the device: mean length of the latent strings
 };
 
 struct CandTable {

@@ -344,8 +344,7 @@ __global__ __launch_bounds__(256) void ev_leaf_wave_kernel(const NodeDev nd, con
       }
       continue;
     }
-    if (lane == 0) overflow_flag[to] = 0;
-    // ---- exact scores (the generic kernels' own function), maximum, fixed-point prefix
+    // ---- exact scores (the generic kernels' own function), maximum, fixed-point prefix (flags are pre-zeroed)
     double sc[EV_SURV_CAP / 64];
     double m = -__builtin_inf();
 #pragma unroll

@@ -38,9 +38,11 @@
 #define FIX_CUTOFF 28.5        // pclean_fixw(d) == 0 for d < -28.5
 #define WAVE_SURV_CAP 256      // pre-filter survivors a wave keeps (4 per lane)
 #define WAVE_RB 4              // rounds (16 candidates per lane each) whose loads are in flight together
+#define WAVE_TC 6              // terms whose loads are in flight together in the exact scoring
 #define GD_STRIDE 28           // int32 words per group descriptor
 // descriptor words: 0 m_lo, 1 m_hi, 2 representative item, 3 row, 4 excl, 5 ctx0, 6 ctx1, 7 flags (bit 0: the
-// excluded referent is garbage-collected), 8-9 bound (double), 10.. observed value index of term f
+// excluded referent is garbage-collected), 8-9 bound (double), 10..25 observed value index of term f,
+// 26-27 score of the "new row" candidate (double)
 
 __global__ void compact_pair_kernel(const uint8_t* __restrict__ pair, int n_obs, int n_lat,
                                     const int32_t* __restrict__ cand_col, int n_cand, int kpad,
@@ -137,8 +139,8 @@ __device__ __forceinline__ double fast_exact_score(const FastRootDev& fr, const 
 
 // One thread per group: the descriptor the scan kernel consumes, including the lower bound of the maximum
 // from the exact score of the rows' current referent (only ever used as a filter, never as a score).
-__global__ void group_desc_kernel(const FastRootDev fr, const DensDev dn, const ItemsDev it, int n_groups,
-                                  int32_t* __restrict__ gd) {
+__global__ void group_desc_kernel(const FastRootDev fr, const DensDev dn, const ItemsDev it, const ChildrenDev ch,
+                                  int n_groups, int32_t* __restrict__ gd) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_groups) return;
   const int m_lo = it.grp_off ? it.grp_off[g] : g, m_hi = it.grp_off ? it.grp_off[g + 1] : g + 1;
@@ -165,23 +167,40 @@ __global__ void group_desc_kernel(const FastRootDev fr, const DensDev dn, const 
   d[8] = __double2loint(bound);
   d[9] = __double2hiint(bound);
   for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) d[10 + f] = o[f];
-  d[26] = 0;
-  d[27] = 0;
+  // score of the "new row" candidate (proposal_compiler.jl:221-230): CRP new-table term + log-marginals of the
+  // children in plan order — new_score() of enum_kernels.hip; an option list (LEAF node) has none
+  double sn = -__builtin_inf();
+  if (!fr.is_leaf) {
+    const double logden = excl >= 0 ? fr.scal[1] : fr.scal[0];
+    double snew = 0.0;
+    for (int c = 0; c < ch.n; ++c) {
+      size_t idx = (size_t)t;
+      if (ch.obs_col[c]) {
+        const int oc = ch.obs_col[c][row];
+        idx = oc < 0 ? (size_t)ch.n_obs[c] : (size_t)oc;
+      }
+      snew += ch.arr[c][idx];
+    }
+    sn = ((deleted ? fr.scal[3] : fr.scal[2]) - logden) + snew;
+  }
+  d[26] = __double2loint(sn);
+  d[27] = __double2hiint(sn);
 }
 
 template <int NT>
 __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr, const DensDev dn, const ItemsDev it,
-                                                           const ChildrenDev ch, uint64_t seed, uint32_t sweep,
-                                                           uint32_t site, int n_draws, int n_groups,
-                                                           const int32_t* __restrict__ gd,
+                                                           uint64_t seed, uint32_t sweep, uint32_t site, int n_draws,
+                                                           int n_groups, const int32_t* __restrict__ gd,
                                                            double* __restrict__ lse_out,
                                                            int32_t* __restrict__ draws_out,
                                                            int32_t* __restrict__ overflow_flag,
                                                            unsigned int* __restrict__ overflow_count) {
   __shared__ uint64_t s_pref[4][WAVE_SURV_CAP + 8];
+  __shared__ double s_sc[4][WAVE_SURV_CAP + 8];
   __shared__ int32_t s_k[4][WAVE_SURV_CAP + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint64_t* pref = s_pref[wave];
+  double* scv = s_sc[wave];
   int32_t* ksv = s_k[wave];
   const int n = fr.n_cand;
   const int nquads = fr.kpad >> 4;
@@ -192,11 +211,13 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
   for (; g < n_groups; g += wstride) {
     // ---- descriptor -> wave-uniform registers; the next group's descriptor is requested right away -------
     const int m_lo = __builtin_amdgcn_readlane(dv, 0), m_hi = __builtin_amdgcn_readlane(dv, 1);
-    const int t = __builtin_amdgcn_readlane(dv, 2), row = __builtin_amdgcn_readlane(dv, 3);
+    const int t = __builtin_amdgcn_readlane(dv, 2);
     const int excl = __builtin_amdgcn_readlane(dv, 4);
     const int ctx0 = __builtin_amdgcn_readlane(dv, 5), ctx1 = __builtin_amdgcn_readlane(dv, 6);
     const bool deleted = (__builtin_amdgcn_readlane(dv, 7) & 1) != 0;
     double bound = __hiloint2double(__builtin_amdgcn_readlane(dv, 9), __builtin_amdgcn_readlane(dv, 8));
+    // score of the "new row" candidate (index n, last in natural order; -inf for an option list), from the descriptor
+    const double sn = __hiloint2double(__builtin_amdgcn_readlane(dv, 27), __builtin_amdgcn_readlane(dv, 26));
     int o[NT];
 #pragma unroll
     for (int f = 0; f < NT; ++f) o[f] = __builtin_amdgcn_readlane(dv, 10 + f);
@@ -208,21 +229,6 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
     const double logden = excluded ? fr.scal[1] : fr.scal[0];
     const double* __restrict__ prior = (excluded && fr.prior_e) ? fr.prior_e : fr.prior_n;
     const double pmax = excluded ? fr.prior_max_e : fr.prior_max_n;
-    // the "new row" candidate (index n, last in natural order): wave-uniform loads, in flight during the scan;
-    // an option list (LEAF node) has none
-    double sn = -__builtin_inf();
-    if (!fr.is_leaf) {
-      double snew = 0.0;
-      for (int c = 0; c < ch.n; ++c) {
-        size_t idx = (size_t)t;
-        if (ch.obs_col[c]) {
-          const int oc = ch.obs_col[c][row];
-          idx = oc < 0 ? (size_t)ch.n_obs[c] : (size_t)oc;
-        }
-        snew += ch.arr[c][idx];
-      }
-      sn = ((deleted ? fr.scal[3] : fr.scal[2]) - logden) + snew;
-    }
     // byte rows of the (up to 3) most discriminating terms, summed by the integer pre-filter
     const uint4* prow[3];
 #pragma unroll
@@ -237,48 +243,6 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
         if (of >= 0) prow[p] = reinterpret_cast<const uint4*>(fr.terms[f].comp + (size_t)of * fr.kpad);
       }
     }
-    // exact score of candidate k.  Three straight-line stages so that the loads of all terms are in flight
-    // together (byte distance + length, then the two density pieces), then the fp64 additions in plan order.
-    auto exact = [&](int k) {
-      double pr = prior[k];
-      if (k == excl) pr = deleted ? -__builtin_inf() : fr.logc_m1[excl] - logden;
-      int dd[NT], LL[NT];
-#pragma unroll
-      for (int f = 0; f < NT; ++f) {
-        dd[f] = 0;
-        LL[f] = 0;
-        if (f < fr.n_terms && o[f] >= 0) {
-          const FastTermDev& tm = fr.terms[f];
-          if (tm.ctx_slot < 0) {
-            dd[f] = tm.comp[(size_t)o[f] * fr.kpad + k];
-            LL[f] = tm.clen[k];
-          } else {
-            const int c = tm.ctx_slot == 0 ? ctx0 : ctx1;
-            const int val = tm.fn[(size_t)c * tm.fn_nb + tm.cand_col[k]];
-            dd[f] = tm.pair[(size_t)o[f] * tm.n_lat + val];
-            LL[f] = tm.lat_len[val];
-          }
-        }
-      }
-      double nbv[NT], lgv[NT];
-#pragma unroll
-      for (int f = 0; f < NT; ++f) {
-        nbv[f] = dn.nb[(size_t)((LL[f] + 4) / 5) * dn.nb_stride + dd[f]];
-        lgv[f] = dn.logl[LL[f]];
-      }
-      double b = pr;
-#pragma unroll
-      for (int f = 0; f < NT; ++f) {
-        if (f < fr.n_terms && o[f] >= 0) {  // an explicitly missing observation contributes nothing
-          double l = nbv[f];                // the fp64 operation order of add_typos_dens()
-          l -= lgv[f] * (double)dd[f];
-          l -= HALF_LOG26 * (double)dd[f];
-          const int mt = fr.terms[f].max_typos;
-          b += (mt >= 0 && dd[f] > mt) ? ADD_TYPOS_IMPOSSIBLE : l;
-        }
-      }
-      return b;
-    };
     // summed byte distances of the 16 candidates of quad q: D[4w + e], e = byte e of dword w
     auto quad_sums = [&](int q, uint32_t* lo, uint32_t* hi) {
 #pragma unroll
@@ -296,136 +260,198 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
         }
     };
 
-    // ---- phase 0 (groups without a retained referent: nested slots of a new row, option lists,
-    // initialisation): the bound is the exact score of the live candidate with the smallest summed distance
-    if (!(bound > -__builtin_inf()) && fr.n_pre > 0) {
-      uint64_t best = ~0ull;
-      for (int q0 = 0; q0 < nquads; q0 += 64 * WAVE_RB) {
+    // Stage 0 (groups without a retained referent: nested slots of a new row, option lists, initialisation):
+    // the live candidate with the smallest summed distance; its exact score - 1 is the lower bound of the
+    // maximum.  Stage 1: the pre-filter scan.  Both stages share ONE copy of the exact-scoring code below.
+    const bool need_bound = !(bound > -__builtin_inf()) && fr.n_pre > 0;
+    int ns = 0;
+    bool over = false;
+    for (int stage = need_bound ? 0 : 1; stage < 2; ++stage) {
+      ns = 0;
+      if (stage == 0) {
+        uint64_t best = ~0ull;
+        for (int q0 = 0; q0 < nquads; q0 += 64 * WAVE_RB) {
 #pragma unroll
-        for (int r = 0; r < WAVE_RB; ++r) {
-          const int q = q0 + r * 64 + lane;
-          if (q < nquads) {
-            uint32_t lo[4], hi[4];
-            quad_sums(q, lo, hi);
-            const uint32_t al = fr.alive[q];
+          for (int r = 0; r < WAVE_RB; ++r) {
+            const int q = q0 + r * 64 + lane;
+            if (q < nquads) {
+              uint32_t lo[4], hi[4];
+              quad_sums(q, lo, hi);
+              const uint32_t al = fr.alive[q];
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              const uint32_t D[4] = {lo[w] & 0xffffu, hi[w] & 0xffffu, lo[w] >> 16, hi[w] >> 16};
+              for (int w = 0; w < 4; ++w) {
+                const uint32_t D[4] = {lo[w] & 0xffffu, hi[w] & 0xffffu, lo[w] >> 16, hi[w] >> 16};
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int k = (q << 4) + (w << 2) + e;
-                const uint64_t key = ((uint64_t)D[e] << 32) | (uint32_t)k;
-                if (key < best && ((al >> (4 * w + e)) & 1u) && k != excl) best = key;
+                for (int e = 0; e < 4; ++e) {
+                  const int k = (q << 4) + (w << 2) + e;
+                  const uint64_t key = ((uint64_t)D[e] << 32) | (uint32_t)k;
+                  if (key < best && ((al >> (4 * w + e)) & 1u) && k != excl) best = key;
+                }
               }
             }
           }
         }
-      }
-      for (int sh = 32; sh > 0; sh >>= 1) {
-        const uint64_t other = __shfl_xor(best, sh, 64);
-        best = other < best ? other : best;
-      }
-      if (best != ~0ull) bound = exact((int)(uint32_t)best) - 1.0;
-    }
-    // Pre-filter threshold: a candidate whose summed edit distance D over the pre-filter terms exceeds dcut
-    // scores at most pmax - c_min * D < bound - FIX_CUTOFF <= max - FIX_CUTOFF, i.e. its fixed-point weight is
-    // exactly 0 (c_min = smallest cost of one edit, fr.inv_c = 1 / c_min; terms not summed and missing
-    // observations only lower the score further).
-    uint32_t dcut = 0xffffu;
-    if (fr.n_pre > 0 && bound > -__builtin_inf()) {
-      const double x = (pmax - bound + FIX_CUTOFF) * fr.inv_c;
-      if (x >= 0.0 && x < 60000.0) dcut = (uint32_t)x + 2u;
-    }
-
-    // ---- phase 1: branch-free integer scan, 16 candidates per lane per round, WAVE_RB rounds of loads in
-    // flight; survivors (live candidates with D <= dcut) go to the wave's LDS list in ascending candidate order
-    int ns = 0;
-    for (int q0 = 0; q0 < nquads; q0 += 64 * WAVE_RB) {
-      uint32_t m16[WAVE_RB];
+        for (int sh = 32; sh > 0; sh >>= 1) {
+          const uint64_t other = __shfl_xor(best, sh, 64);
+          best = other < best ? other : best;
+        }
+        if (best != ~0ull) {
+          if (lane == 0) ksv[0] = (int)(uint32_t)best;
+          ns = 1;
+        }
+      } else {
+        // Pre-filter threshold: a candidate whose summed edit distance D over the pre-filter terms exceeds dcut
+        // scores at most pmax - c_min * D < bound - FIX_CUTOFF <= max - FIX_CUTOFF, i.e. its fixed-point weight
+        // is exactly 0 (c_min = smallest cost of one edit, fr.inv_c = 1 / c_min; terms not summed and missing
+        // observations only lower the score further).
+        uint32_t dcut = 0xffffu;
+        if (fr.n_pre > 0 && bound > -__builtin_inf()) {
+          const double x = (pmax - bound + FIX_CUTOFF) * fr.inv_c;
+          if (x >= 0.0 && x < 60000.0) dcut = (uint32_t)x + 2u;
+        }
+        // branch-free integer scan, 16 candidates per lane per round, WAVE_RB rounds of loads in flight;
+        // survivors (live candidates with D <= dcut) go to the wave's LDS list in ascending candidate order
+        for (int q0 = 0; q0 < nquads; q0 += 64 * WAVE_RB) {
+          uint32_t m16[WAVE_RB];
 #pragma unroll
-      for (int r = 0; r < WAVE_RB; ++r) {
-        const int q = q0 + r * 64 + lane;
-        m16[r] = 0;
-        if (q < nquads) {
-          uint32_t lo[4], hi[4];
-          quad_sums(q, lo, hi);
-          uint32_t mk = 0;
+          for (int r = 0; r < WAVE_RB; ++r) {
+            const int q = q0 + r * 64 + lane;
+            m16[r] = 0;
+            if (q < nquads) {
+              uint32_t lo[4], hi[4];
+              quad_sums(q, lo, hi);
+              uint32_t mk = 0;
 #pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            mk |= ((lo[w] & 0xffffu) <= dcut ? 1u : 0u) << (4 * w);
-            mk |= ((hi[w] & 0xffffu) <= dcut ? 1u : 0u) << (4 * w + 1);
-            mk |= ((lo[w] >> 16) <= dcut ? 1u : 0u) << (4 * w + 2);
-            mk |= ((hi[w] >> 16) <= dcut ? 1u : 0u) << (4 * w + 3);
+              for (int w = 0; w < 4; ++w) {
+                mk |= ((lo[w] & 0xffffu) <= dcut ? 1u : 0u) << (4 * w);
+                mk |= ((hi[w] & 0xffffu) <= dcut ? 1u : 0u) << (4 * w + 1);
+                mk |= ((lo[w] >> 16) <= dcut ? 1u : 0u) << (4 * w + 2);
+                mk |= ((hi[w] >> 16) <= dcut ? 1u : 0u) << (4 * w + 3);
+              }
+              m16[r] = mk & (uint32_t)fr.alive[q];  // padding and free slots never survive
+            }
           }
-          m16[r] = mk & (uint32_t)fr.alive[q];  // padding and free slots never survive
+          uint32_t any = 0;
+#pragma unroll
+          for (int r = 0; r < WAVE_RB; ++r) any |= m16[r];
+          if (__ballot(any != 0) == 0ull) continue;  // wave-uniform: most rounds hold no survivor at all
+#pragma unroll
+          for (int r = 0; r < WAVE_RB; ++r) {
+            if (__ballot(m16[r] != 0) == 0ull) continue;
+            const int q = q0 + r * 64 + lane;
+            const int cnt = __builtin_popcount(m16[r]);
+            int incl = cnt;
+            for (int sh = 1; sh < 64; sh <<= 1) {
+              const int x = __shfl_up(incl, sh, 64);
+              if (lane >= sh) incl += x;
+            }
+            int pos = ns + incl - cnt;
+            for (uint32_t mm = m16[r]; mm; mm &= mm - 1) {
+              if (pos < WAVE_SURV_CAP) ksv[pos] = (q << 4) + __builtin_ctz(mm);
+              ++pos;
+            }
+            ns += __shfl(incl, 63, 64);
+          }
+        }
+        if (ns > WAVE_SURV_CAP) {
+          over = true;
+          break;
         }
       }
-      uint32_t any = 0;
+      __builtin_amdgcn_wave_barrier();
+      // ---- exact fp64 scores of ksv[0..ns), one candidate per lane per pass -> scv.  The loads of a chunk of
+      // terms are in flight together (byte distance + length, then the two density pieces); the fp64 additions
+      // follow plan order (the operation order of candidate_score(), enum_kernels.hip).
+      for (int base = 0; base < ns; base += 64) {
+        const int j = base + lane;
+        if (j < ns) {
+          const int k = ksv[j];
+          double b = prior[k];
+          if (k == excl) b = deleted ? -__builtin_inf() : fr.logc_m1[excl] - logden;
 #pragma unroll
-      for (int r = 0; r < WAVE_RB; ++r) any |= m16[r];
-      if (__ballot(any != 0) == 0ull) continue;  // wave-uniform: most rounds hold no survivor at all
+          for (int f0 = 0; f0 < NT; f0 += WAVE_TC) {
+            int dd[WAVE_TC], LL[WAVE_TC];
 #pragma unroll
-      for (int r = 0; r < WAVE_RB; ++r) {
-        if (__ballot(m16[r] != 0) == 0ull) continue;
-        const int q = q0 + r * 64 + lane;
-        const int cnt = __builtin_popcount(m16[r]);
-        int incl = cnt;
-        for (int sh = 1; sh < 64; sh <<= 1) {
-          const int x = __shfl_up(incl, sh, 64);
-          if (lane >= sh) incl += x;
+            for (int u = 0; u < WAVE_TC; ++u) {
+              const int f = f0 + u;
+              dd[u] = 0;
+              LL[u] = 0;
+              if (f < NT && f < fr.n_terms && o[f < NT ? f : 0] >= 0) {
+                const FastTermDev& tm = fr.terms[f];
+                if (tm.ctx_slot < 0) {
+                  dd[u] = tm.comp[(size_t)o[f < NT ? f : 0] * fr.kpad + k];
+                  LL[u] = tm.clen[k];
+                } else {
+                  const int c = tm.ctx_slot == 0 ? ctx0 : ctx1;
+                  const int val = tm.fn[(size_t)c * tm.fn_nb + tm.cand_col[k]];
+                  dd[u] = tm.pair[(size_t)o[f < NT ? f : 0] * tm.n_lat + val];
+                  LL[u] = tm.lat_len[val];
+                }
+              }
+            }
+            double nbv[WAVE_TC], lgv[WAVE_TC];
+#pragma unroll
+            for (int u = 0; u < WAVE_TC; ++u) {
+              nbv[u] = dn.nb[(size_t)((LL[u] + 4) / 5) * dn.nb_stride + dd[u]];
+              lgv[u] = dn.logl[LL[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < WAVE_TC; ++u) {
+              const int f = f0 + u;
+              if (f < NT && f < fr.n_terms && o[f < NT ? f : 0] >= 0) {  // a missing observation contributes nothing
+                double l = nbv[u];                                      // operation order of add_typos_dens()
+                l -= lgv[u] * (double)dd[u];
+                l -= HALF_LOG26 * (double)dd[u];
+                const int mt = fr.terms[f].max_typos;
+                b += (mt >= 0 && dd[u] > mt) ? ADD_TYPOS_IMPOSSIBLE : l;
+              }
+            }
+          }
+          scv[j] = b;
         }
-        int pos = ns + incl - cnt;
-        for (uint32_t mm = m16[r]; mm; mm &= mm - 1) {
-          if (pos < WAVE_SURV_CAP) ksv[pos] = (q << 4) + __builtin_ctz(mm);
-          ++pos;
-        }
-        ns += __shfl(incl, 63, 64);
       }
+      __builtin_amdgcn_wave_barrier();
+      if (stage == 0) bound = ns ? scv[0] - 1.0 : -__builtin_inf();
     }
-    __builtin_amdgcn_wave_barrier();
-    if (ns > WAVE_SURV_CAP) {  // flat posterior: the host re-runs these items with the generic kernel
-      for (int mi = m_lo + lane; mi < m_hi; mi += 64)
-        overflow_flag[it.grp_off ? it.members[mi] : t] = PCLEAN_CHOICE_NEW;  // marker understood by compact_new_kernel
+    if (over) {  // flat posterior: the host re-runs these items with the generic kernel (flags are pre-zeroed)
+      if (m_hi - m_lo == 1) {
+        if (lane == 0) overflow_flag[t] = PCLEAN_CHOICE_NEW;  // marker understood by compact_new_kernel
+      } else {
+        for (int mi = m_lo + lane; mi < m_hi; mi += 64) overflow_flag[it.members[mi]] = PCLEAN_CHOICE_NEW;
+      }
       if (lane == 0) atomicAdd(overflow_count, (unsigned int)(m_hi - m_lo));
       continue;
     }
-    for (int mi = m_lo + lane; mi < m_hi; mi += 64) overflow_flag[it.grp_off ? it.members[mi] : t] = 0;
-
-    // ---- phase 2: exact fp64 scores, one survivor per lane per pass; maximum; fixed-point prefix ---------
-    double sc[WAVE_SURV_CAP / 64];
+    // ---- maximum, fixed-point weights, inclusive prefix (survivors in ascending order, then the new row) ---
     double m = sn;
-#pragma unroll
-    for (int p = 0; p < WAVE_SURV_CAP / 64; ++p) {
-      sc[p] = -__builtin_inf();
-      const int j = p * 64 + lane;
-      if (j < ns) sc[p] = exact(ksv[j]);
-      m = fmax(m, sc[p]);
+    for (int base = 0; base < ns; base += 64) {
+      const int j = base + lane;
+      if (j < ns) m = fmax(m, scv[j]);
     }
     m = wave_max64(m);
     uint64_t carry = 0;
-#pragma unroll
-    for (int p = 0; p < WAVE_SURV_CAP / 64; ++p) {
-      if (p * 64 >= ns) break;  // wave-uniform
-      const uint64_t u = (m == -__builtin_inf()) ? 0ull : pclean_fixw(sc[p] - m);
+    for (int base = 0; base < ns; base += 64) {
+      const int j = base + lane;
+      const uint64_t u = (j < ns && m != -__builtin_inf()) ? pclean_fixw(scv[j] - m) : 0ull;
       unsigned long long incl = u;
       for (int sh = 1; sh < 64; sh <<= 1) {
         const unsigned long long x = __shfl_up(incl, sh, 64);
         if (lane >= sh) incl += x;
       }
-      const int j = p * 64 + lane;
       if (j < ns) pref[j] = carry + incl;
       carry += __shfl(incl, 63, 64);
     }
     const uint64_t U = carry + ((m == -__builtin_inf()) ? 0ull : pclean_fixw(sn - m));
     if (lane == 0) pref[ns] = U;
     __builtin_amdgcn_wave_barrier();
-    // ---- phase 3: lse + draws of every (member item, draw) pair of the group --------------------------------
+    // ---- lse + draws of every (member item, draw) pair of the group ------------------------------------------
     const double lse = pclean_lse_from_fix(m, U);
     const int nd_eff = n_draws > 0 ? n_draws : 1;
-    const int n_out = (m_hi - m_lo) * nd_eff;
+    const int n_mem = m_hi - m_lo;
+    const int n_out = n_mem * nd_eff;
     for (int q = lane; q < n_out; q += 64) {
       const int mi = m_lo + q / nd_eff, j = q % nd_eff;
-      const int tm = it.grp_off ? it.members[mi] : t;
+      const int tm = n_mem == 1 ? t : it.members[mi];
       if (j == 0 && lse_out) lse_out[tm] = lse;
       if (n_draws > 0) {
         int32_t res = fr.is_leaf ? n - 1 : PCLEAN_CHOICE_NEW;
@@ -451,8 +477,8 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
   }
 }
 
-typedef void (*wave_kernel_t)(const FastRootDev, const DensDev, const ItemsDev, const ChildrenDev, uint64_t, uint32_t,
-                              uint32_t, int, int, const int32_t*, double*, int32_t*, int32_t*, unsigned int*);
+typedef void (*wave_kernel_t)(const FastRootDev, const DensDev, const ItemsDev, uint64_t, uint32_t, uint32_t, int, int,
+                              const int32_t*, double*, int32_t*, int32_t*, unsigned int*);
 
 static wave_kernel_t pick_kernel(int n_terms) {
   if (n_terms <= 2) return fk_root_wave_kernel<2>;
@@ -470,13 +496,13 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
                             int32_t* desc_scratch) {
   if (it.n <= 0) return PCLEAN_OK;
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(group_desc_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, dn, it, it.n,
+  hipLaunchKernelGGL(group_desc_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, dn, it, ch, it.n,
                      desc_scratch);
   // persistent grid: 4 groups (waves) per workgroup, up to 8 workgroups per CU
   int wgs = 256 * 8;
   if (const char* e = getenv("PCLEAN_WAVE_WGS")) wgs = std::max(1, atoi(e));
   wgs = std::min(wgs, (it.n + 3) / 4);
-  hipLaunchKernelGGL(pick_kernel(fr.n_terms), dim3(wgs), dim3(256), 0, ctx->stream, fr, dn, it, ch, seed, sweep, site,
+  hipLaunchKernelGGL(pick_kernel(fr.n_terms), dim3(wgs), dim3(256), 0, ctx->stream, fr, dn, it, seed, sweep, site,
                      n_draws, it.n, desc_scratch, lse_out, draws_out, overflow_flag, overflow_count);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;

@@ -927,6 +927,17 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     dmax = std::max(dmax, std::max(pt.max_lat_len, pt.max_obs_len));
   }
   if (lmax > 255 || dmax > 255) return 0;
+  if (leaf && !ev_mode) {
+    // An option list scored against ONE observed string: the integer pre-filter keeps every option within
+    // ~10 edits of it (28.5 nats / cost of an edit), i.e. everything when the strings are short (codes, zip
+    // codes, phone numbers) — only long strings (names, addresses) are worth the compact tables.
+    double best = 0.0;
+    for (int i = 0; i < n.n_terms; ++i) {
+      const pclean_term& tm = b.terms[n.term_begin + i];
+      if (tm.ctx_slot < 0) best = std::max(best, ctx->pair[tm.pair_table].mean_lat_len);
+    }
+    if (best < 16.0) return 0;
+  }
   const int kpad = (t.n_rows + 15) & ~15;
   FastRoot& f = st(ctx)->fast[block_id * 64 + node_id];
   if (f.disabled > 0) {
@@ -1377,6 +1388,7 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   int32_t* oflag = scratch<int32_t>(ctx, il.n);
   if (!oflag || s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   HIPCHK(ctx, hipMemsetAsync(s->counter.p + 1, 0, sizeof(unsigned int), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(oflag, 0, (size_t)il.n * sizeof(int32_t), ctx->stream));  // kernels only set overflow markers
   if (fast) {
     int32_t* desc = scratch<int32_t>(ctx, pclean_fast_desc_words(it.n));
     if (!desc) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
@@ -1396,8 +1408,9 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   ctx->timing.reserved += (int32_t)n_over;  // items that fell back to the generic kernel
   if (time_it) ctx->root_stats.overflow_items = (int32_t)n_over;
   // short strings / flat posteriors: when a quarter of the items overflow the survivor list the integer pre-filter
-  // does not pay for this node -> the next 64 evaluations go straight to the generic kernel, then it is retried
-  if (il.n >= 64 && (size_t)n_over * 4 > (size_t)il.n) s->fast[block_id * 64 + node_id].disabled = 64;
+  // does not pay for this option list -> its next 1024 evaluations go straight to the generic kernel, then it is retried
+  if (n.kind == PCLEAN_NODE_LEAF && il.n >= 64 && (size_t)n_over * 4 > (size_t)il.n)
+    s->fast[block_id * 64 + node_id].disabled = 1024;
   if (n_over && getenv("PCLEAN_DEBUG_OVERFLOW"))
     fprintf(stderr, "[pclean] block %d node %d: %u of %d items re-run by the generic kernel\n", block_id, node_id, n_over,
             il.n);
