@@ -39,6 +39,7 @@
 #define WAVE_SURV_CAP 256      // pre-filter survivors a wave keeps (4 per lane)
 #define WAVE_RB 4              // rounds (16 candidates per lane each) whose loads are in flight together
 #define WAVE_TC 6              // terms whose loads are in flight together in the exact scoring
+#define WAVE_DCUT_OK 24        // a cut-off below this many summed edits is considered selective
 #define GD_STRIDE 28           // int32 words per group descriptor
 // descriptor words: 0 m_lo, 1 m_hi, 2 representative item, 3 row, 4 excl, 5 ctx0, 6 ctx1, 7 flags (bit 0: the
 // excluded referent is garbage-collected), 8-9 bound (double), 10..25 observed value index of term f,
@@ -204,11 +205,17 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
   int32_t* ksv = s_k[wave];
   const int n = fr.n_cand;
   const int nquads = fr.kpad >> 4;
-  const int wstride = gridDim.x * 4;
   const int draw_is = it.draw_is ? it.draw_is : n_draws, draw_ds = it.draw_ds ? it.draw_ds : 1;
-  int g = blockIdx.x * 4 + wave;
-  int dv = (g < n_groups && lane < GD_STRIDE) ? gd[(size_t)g * GD_STRIDE + lane] : 0;
-  for (; g < n_groups; g += wstride) {
+  // XCD-aware persistent mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2).  The groups arrive
+  // sorted by referent, so consecutive groups stream the same byte rows: XCD x takes the x-th contiguous eighth
+  // of the groups and its workgroups walk it with a stride — the rows of one referent stay in ONE L2.
+  const int xcd = blockIdx.x & 7, nbx = (gridDim.x + 7 - xcd) >> 3;
+  const int per = (n_groups + 7) >> 3;
+  const int g_hi = min((xcd + 1) * per, n_groups);
+  const int wstride = nbx * 4;
+  int g = xcd * per + (blockIdx.x >> 3) * 4 + wave;
+  int dv = (g < g_hi && lane < GD_STRIDE) ? gd[(size_t)g * GD_STRIDE + lane] : 0;
+  for (; g < g_hi; g += wstride) {
     // ---- descriptor -> wave-uniform registers; the next group's descriptor is requested right away -------
     const int m_lo = __builtin_amdgcn_readlane(dv, 0), m_hi = __builtin_amdgcn_readlane(dv, 1);
     const int t = __builtin_amdgcn_readlane(dv, 2);
@@ -223,7 +230,7 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
     for (int f = 0; f < NT; ++f) o[f] = __builtin_amdgcn_readlane(dv, 10 + f);
     {
       const int gn = g + wstride;
-      dv = (gn < n_groups && lane < GD_STRIDE) ? gd[(size_t)gn * GD_STRIDE + lane] : 0;
+      dv = (gn < g_hi && lane < GD_STRIDE) ? gd[(size_t)gn * GD_STRIDE + lane] : 0;
     }
     const bool excluded = excl >= 0;
     const double logden = excluded ? fr.scal[1] : fr.scal[0];
@@ -263,7 +270,15 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
     // Stage 0 (groups without a retained referent: nested slots of a new row, option lists, initialisation):
     // the live candidate with the smallest summed distance; its exact score - 1 is the lower bound of the
     // maximum.  Stage 1: the pre-filter scan.  Both stages share ONE copy of the exact-scoring code below.
-    const bool need_bound = !(bound > -__builtin_inf()) && fr.n_pre > 0;
+    // A retained referent that explains the row badly (wrong entity, many typos) gives a useless bound: when its
+    // cut-off would let candidates more than WAVE_DCUT_OK edits away through, stage 0 runs as well and the better
+    // of the two bounds is used.
+    bool need_bound = !(bound > -__builtin_inf()) && fr.n_pre > 0;
+    if (!need_bound && fr.n_pre > 0) {
+      const double x = (pmax - bound + FIX_CUTOFF) * fr.inv_c;
+      need_bound = !(x < (double)WAVE_DCUT_OK);
+    }
+    const double bound0 = bound;
     int ns = 0;
     bool over = false;
     for (int stage = need_bound ? 0 : 1; stage < 2; ++stage) {
@@ -411,7 +426,7 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
         }
       }
       __builtin_amdgcn_wave_barrier();
-      if (stage == 0) bound = ns ? scv[0] - 1.0 : -__builtin_inf();
+      if (stage == 0) bound = fmax(bound0, ns ? scv[0] - 1.0 : -__builtin_inf());
     }
     if (over) {  // flat posterior: the host re-runs these items with the generic kernel (flags are pre-zeroed)
       if (m_hi - m_lo == 1) {
@@ -502,6 +517,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   int wgs = 256 * 8;
   if (const char* e = getenv("PCLEAN_WAVE_WGS")) wgs = std::max(1, atoi(e));
   wgs = std::min(wgs, (it.n + 3) / 4);
+  wgs = (wgs + 7) & ~7;  // a multiple of the 8 XCDs (the kernel splits the groups into 8 contiguous ranges)
   hipLaunchKernelGGL(pick_kernel(fr.n_terms), dim3(wgs), dim3(256), 0, ctx->stream, fr, dn, it, seed, sweep, site,
                      n_draws, it.n, desc_scratch, lse_out, draws_out, overflow_flag, overflow_count);
   HIPCHK(ctx, hipGetLastError());

@@ -151,7 +151,9 @@ __global__ void ctx_fill_kernel(int N, int P, const int32_t* __restrict__ it_ctx
 // One thread per row, after a block's root enumeration: particle p of row i takes its draw (row-major from the
 // root kernels: draws_rm[i * P + p], or draw p of its context's item) and the block's log-marginal; particle 0
 // keeps the retained referent under CSMC (row_inference.jl:143-145).  Writes the particle-major arrays
-// coalesced and counts the particles that proposed a NEW referent (block-aggregated atomic).
+// coalesced and emits the list of the particle slots that proposed a NEW referent (new_list[pos] = slot,
+// pnewpos[slot] = pos; positions reserved with one atomic per workgroup, order irrelevant: every use is keyed
+// by (row, particle)).
 __global__ __launch_bounds__(256) void particle_update_kernel(int N, int P, const int32_t* __restrict__ draws_rm,
                                                               const double* __restrict__ lse,
                                                               const int32_t* __restrict__ slot_item,
@@ -159,10 +161,14 @@ __global__ __launch_bounds__(256) void particle_update_kernel(int N, int P, cons
                                                               const double* __restrict__ lse_item,
                                                               const int32_t* __restrict__ cur_b,
                                                               int32_t* __restrict__ pchoice, double* __restrict__ w,
-                                                              unsigned int* __restrict__ n_new) {
-  __shared__ unsigned int wcnt[4];
+                                                              unsigned int* __restrict__ n_new,
+                                                              int32_t* __restrict__ new_list,
+                                                              int32_t* __restrict__ pnewpos) {
+  __shared__ unsigned int wsum[4];
+  __shared__ unsigned int bbase;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned int mine = 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t newmask = 0;
   if (i < N) {
     const int keep = cur_b ? cur_b[i] : -1;
     for (int p = 0; p < P; ++p) {
@@ -180,15 +186,31 @@ __global__ __launch_bounds__(256) void particle_update_kernel(int N, int P, cons
       const int c = (p == 0 && keep >= 0) ? keep : d;
       pchoice[sp] = c;
       w[sp] += l;
-      mine += c == PCLEAN_CHOICE_NEW ? 1u : 0u;
+      if (c == PCLEAN_CHOICE_NEW) newmask |= 1ull << p;
     }
   }
-  for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o, 64);
-  if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = mine;
+  const unsigned int mine = (unsigned int)__popcll(newmask);
+  unsigned int incl = mine;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned int x = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += x;
+  }
+  if (lane == 63) wsum[wave] = incl;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    if (total) atomicAdd(n_new, total);
+    const unsigned int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    bbase = total ? atomicAdd(n_new, total) : 0u;
+  }
+  __syncthreads();
+  if (!mine) return;
+  unsigned int pos = bbase + incl - mine;
+  for (int k = 0; k < wave; ++k) pos += wsum[k];
+  for (uint64_t mm = newmask; mm; mm &= mm - 1) {
+    const int p = __builtin_ctzll(mm);
+    const size_t sp = (size_t)p * N + i;
+    new_list[pos] = (int32_t)sp;
+    pnewpos[sp] = (int32_t)pos;
+    ++pos;
   }
 }
 
@@ -594,7 +616,7 @@ struct ItemList {  // device arrays describing enumeration work items
 
 struct BlockRun {  // per-block device state of one sweep
   DevBuf<int32_t> pchoice, pnewpos, draws, it_ctx, choice, chosen_newpos, vals, locals, moved_flag, new_flag, moved_list,
-      new_list;
+      new_list, new_slots;
   DevBuf<double> lse;
   int n_new = 0;  // rows of vals
   DevBuf<int32_t> plan_kind, plan_nrows, plan_cmb, plan_colmap;
@@ -627,6 +649,15 @@ struct SweepState {
   std::map<int, uint64_t> leaf_version;
   int64_t row_offset = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evs = nullptr, eve = nullptr;
+  // memo tables of option-list marginals (leaf_memo_*): key = block * 64 + node
+  struct LeafMemo {
+    DevBuf<uint64_t> keys;   // [cap][3]
+    DevBuf<double> vals;     // [cap]
+    DevBuf<unsigned int> count;
+    uint64_t ver = 0;
+    int cap = 0;
+  };
+  std::map<int, LeafMemo> memo;
   // evidence of the running pclean_sweep_latent call (ensure_agg)
   const int32_t* lat_off = nullptr;      // [lat_items + 1] CSR offsets of the original items into the evidence list
   const int32_t* lat_item_of_pos = nullptr;  // [lat_ev]
@@ -655,7 +686,7 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
   for (auto& b : s->pool) b.release();
   for (auto& r : s->run) {
     r.pchoice.release(); r.pnewpos.release(); r.draws.release(); r.moved_flag.release(); r.new_flag.release();
-    r.moved_list.release(); r.new_list.release();
+    r.moved_list.release(); r.new_list.release(); r.new_slots.release();
     r.locals.release(); r.it_ctx.release(); r.choice.release(); r.chosen_newpos.release(); r.vals.release();
     r.lse.release(); r.plan_kind.release(); r.plan_nrows.release(); r.plan_cmb.release(); r.plan_colmap.release();
     r.plan_cols.release();
@@ -672,6 +703,11 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
     f.alive.release();
   }
   s->tail_counts.release();
+  for (auto& kv : s->memo) {
+    kv.second.keys.release();
+    kv.second.vals.release();
+    kv.second.count.release();
+  }
   if (s->h_counts) (void)hipHostFree(s->h_counts);
   for (auto e : s->prof_ev) (void)hipEventDestroy(e);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -725,8 +761,9 @@ struct ProfScope {  // records start at construction, stop at destruction
     if (rec != (size_t)-1) (void)hipEventRecord(s->prof_ev[2 * rec + 1], ctx->stream);
   }
 };
-static void prof_collect(pclean_ctx* ctx) {  // after the stream has been synchronised
+static void prof_collect(pclean_ctx* ctx) {
   SweepState* s = st(ctx);
+  (void)hipStreamSynchronize(ctx->stream);  // the last scope's stop event has only just been recorded
   for (size_t r = 0; r < s->prof_used; ++r) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, s->prof_ev[2 * r], s->prof_ev[2 * r + 1]) == hipSuccess) {
@@ -1408,9 +1445,9 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   ctx->timing.reserved += (int32_t)n_over;  // items that fell back to the generic kernel
   if (time_it) ctx->root_stats.overflow_items = (int32_t)n_over;
   // short strings / flat posteriors: when a quarter of the items overflow the survivor list the integer pre-filter
-  // does not pay for this option list -> its next 1024 evaluations go straight to the generic kernel, then it is retried
-  if (n.kind == PCLEAN_NODE_LEAF && il.n >= 64 && (size_t)n_over * 4 > (size_t)il.n)
-    s->fast[block_id * 64 + node_id].disabled = 1024;
+  // does not pay for this option list -> its next 64 evaluations go straight to the generic kernel, then it is retried
+  if (n.kind == PCLEAN_NODE_LEAF && il.n >= 1024 && (size_t)n_over * 4 > (size_t)il.n)
+    s->fast[block_id * 64 + node_id].disabled = 64;
   if (n_over && getenv("PCLEAN_DEBUG_OVERFLOW"))
     fprintf(stderr, "[pclean] block %d node %d: %u of %d items re-run by the generic kernel\n", block_id, node_id, n_over,
             il.n);
@@ -1597,8 +1634,162 @@ static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const It
 }
 
 // log marginal of sub-tree `node_id` for every item (no draws), evaluated once per distinct item tuple
+// ---- memo of option-list marginals ---------------------------------------------------------------------------
+// The log-marginal of an option list (LEAF node) is a pure function of (observed values of its terms, ctx) as long
+// as its option table, pair tables and fn tables stay what they are — the data never changes, so the same tuples
+// come back sweep after sweep (the reference memoises its AddTypos densities the same way, add_typos.jl:47,55).
+// Open-addressing table in HBM: 3 x uint64 key (up to 6 values, each stored +1) + the fp64 marginal.  Lookups
+// and inserts run in different kernels, so a reader never meets a half-written entry; two inserts of one key may
+// land in two slots (harmless: equal values).
+#define MEMO_PROBES 32
+struct MemoDev {
+  uint64_t* keys;
+  double* vals;
+  unsigned int* count;
+  unsigned int cap_mask, max_fill;
+};
+__device__ __forceinline__ void memo_key(const KeyColsDev& kc, int r, const int32_t* ctxv, size_t i, uint64_t* k) {
+  uint32_t v[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+  int nv = 0;
+  for (int c = 0; c < kc.n_cols; ++c) v[nv++] = (uint32_t)(kc.col[c][r] + 1);
+  if (kc.use_ctx && ctxv)
+    for (int q = 0; q < PCLEAN_MAX_CTX; ++q) v[nv++] = (uint32_t)(ctxv[i * PCLEAN_MAX_CTX + q] + 1);
+  k[0] = (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+  k[1] = (uint64_t)v[2] | ((uint64_t)v[3] << 32);
+  k[2] = (uint64_t)v[4] | ((uint64_t)v[5] << 32);
+}
+__device__ __forceinline__ uint32_t memo_hash(const uint64_t* k) {
+  uint64_t h = k[0] * 0x9e3779b97f4a7c15ull;
+  h ^= (h >> 29) + k[1] * 0xbf58476d1ce4e5b9ull;
+  h ^= (h >> 31) + k[2] * 0x94d049bb133111ebull;
+  h *= 0xff51afd7ed558ccdull;
+  return (uint32_t)(h >> 32);
+}
+__global__ void memo_lookup_kernel(int n, KeyColsDev kc, const int32_t* row, const int32_t* ctxv, MemoDev m,
+                                   double* __restrict__ lse_out, int32_t* __restrict__ miss_flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint64_t k[3];
+  memo_key(kc, row ? row[i] : i, ctxv, (size_t)i, k);
+  uint32_t slot = memo_hash(k) & m.cap_mask;
+  int32_t miss = PCLEAN_CHOICE_NEW;
+  for (int p = 0; p < MEMO_PROBES; ++p) {
+    const uint64_t* e = m.keys + (size_t)slot * 3;
+    const uint64_t k0 = e[0];
+    if (k0 == ~0ull) break;
+    if (k0 == k[0] && e[1] == k[1] && e[2] == k[2]) {
+      lse_out[i] = m.vals[slot];
+      miss = 0;
+      break;
+    }
+    slot = (slot + 1) & m.cap_mask;
+  }
+  miss_flag[i] = miss;
+}
+// items list[j] (or all items when list is null) with freshly computed marginals src[j] -> table
+__global__ void memo_insert_kernel(int n, const int32_t* list, KeyColsDev kc, const int32_t* row, const int32_t* ctxv,
+                                   MemoDev m, const double* __restrict__ src) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  if (*m.count >= m.max_fill) return;
+  const int i = list ? list[j] : j;
+  uint64_t k[3];
+  memo_key(kc, row ? row[i] : i, ctxv, (size_t)i, k);
+  uint32_t slot = memo_hash(k) & m.cap_mask;
+  for (int p = 0; p < MEMO_PROBES; ++p) {
+    unsigned long long* e = (unsigned long long*)(m.keys + (size_t)slot * 3);
+    const unsigned long long old = atomicCAS(e, ~0ull, (unsigned long long)k[0]);
+    if (old == ~0ull) {
+      e[1] = k[1];
+      e[2] = k[2];
+      m.vals[slot] = src[j];
+      atomicAdd(m.count, 1u);
+      return;
+    }
+    slot = (slot + 1) & m.cap_mask;
+  }
+}
+
+static int eval_node_lse_core(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
+                              uint64_t seed, uint32_t sweep, double* lse_out);
+
+// log marginal of sub-tree `node_id` for every item (no draws)
 static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
                          uint64_t seed, uint32_t sweep, double* lse_out) {
+  Block& b = ctx->block[block_id];
+  const pclean_node& n = b.nodes[node_id];
+  SweepState* s = st(ctx);
+  std::set<int> cols;
+  bool use_ctx = false;
+  static const bool no_memo = getenv("PCLEAN_NO_MEMO") != nullptr;
+  const bool memo_ok = !no_memo && n.kind == PCLEAN_NODE_LEAF && !il.ev_lo && il.n >= 4096 && node_id < 64 &&
+                       subtree_key(ctx, b, node_id, cols, use_ctx) &&
+                       (int)cols.size() + (use_ctx ? PCLEAN_MAX_CTX : 0) <= 6 && (!use_ctx || il.ctx);
+  if (!memo_ok) return eval_node_lse_core(ctx, block_id, node_id, il, excl, seed, sweep, lse_out);
+  ProfScope ps(ctx, "option_marginal_memo");
+  // version of everything the marginal depends on
+  uint64_t ver = ctx->cand[n.table].version;
+  for (int i = 0; i < n.n_terms; ++i) {
+    const pclean_term& tm = b.terms[n.term_begin + i];
+    ver = ver * 1000003ull + ctx->pair[tm.pair_table].version;
+    if (tm.ctx_slot >= 0) ver = ver * 1000003ull + (uint64_t)(tm.fn_table + 1);
+  }
+  SweepState::LeafMemo& mm = s->memo[block_id * 64 + node_id];
+  const int cap = 1 << 21;
+  if (mm.cap != cap) {
+    if (mm.keys.alloc((size_t)cap * 3) || mm.vals.alloc(cap) || mm.count.alloc(4))
+      return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed (memo)");
+    mm.cap = cap;
+    mm.ver = 0;
+  }
+  if (mm.ver != ver) {
+    HIPCHK(ctx, hipMemsetAsync(mm.keys.p, 0xff, (size_t)cap * 3 * sizeof(uint64_t), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(mm.count.p, 0, sizeof(unsigned int), ctx->stream));
+    mm.ver = ver;
+  }
+  MemoDev md{mm.keys.p, mm.vals.p, mm.count.p, (unsigned int)(cap - 1), (unsigned int)(cap / 2)};
+  KeyColsDev kc{};
+  kc.use_ctx = use_ctx ? 1 : 0;
+  for (int c : cols) kc.col[kc.n_cols++] = ctx->obs.p + (size_t)c * ctx->n_rows + ctx->active_begin;
+  const int N = il.n;
+  int32_t* flag = scratch<int32_t>(ctx, N);
+  int32_t* list = scratch<int32_t>(ctx, N);
+  if (!flag || !list || s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  hipLaunchKernelGGL(memo_lookup_kernel, grid1(N), dim3(256), 0, ctx->stream, N, kc, il.row, il.ctx, md, lse_out, flag);
+  HIPCHK(ctx, hipMemsetAsync(s->counter.p + 3, 0, sizeof(unsigned int), ctx->stream));
+  hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 1, s->counter.p + 3, list,
+                     nullptr);
+  unsigned int n_miss = 0;
+  HIPCHK(ctx, hipMemcpyAsync(&n_miss, s->counter.p + 3, sizeof n_miss, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (n_miss == 0) return PCLEAN_OK;
+  if (n_miss == (unsigned int)N) {
+    int rc = eval_node_lse_core(ctx, block_id, node_id, il, excl, seed, sweep, lse_out);
+    if (rc) return rc;
+    hipLaunchKernelGGL(memo_insert_kernel, grid1(N), dim3(256), 0, ctx->stream, N, (const int32_t*)nullptr, kc, il.row,
+                       il.ctx, md, lse_out);
+    return PCLEAN_OK;
+  }
+  int32_t* row2 = scratch<int32_t>(ctx, n_miss);
+  int32_t* ctx2 = scratch<int32_t>(ctx, (size_t)n_miss * PCLEAN_MAX_CTX);
+  int32_t* excl2 = scratch<int32_t>(ctx, n_miss);
+  double* dst = scratch<double>(ctx, n_miss);
+  if (!row2 || !ctx2 || !excl2 || !dst) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  hipLaunchKernelGGL(sub_items_kernel, grid1(n_miss), dim3(256), 0, ctx->stream, (int)n_miss, list, il.row, il.ctx, excl,
+                     (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, row2,
+                     ctx2, excl2, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr);
+  ItemList sil{(int)n_miss, row2, il.ctx ? ctx2 : nullptr, nullptr, nullptr};
+  int rc = eval_node_lse_core(ctx, block_id, node_id, sil, excl ? excl2 : nullptr, seed, sweep, dst);
+  if (rc) return rc;
+  hipLaunchKernelGGL(scatter_f64_kernel, grid1(n_miss), dim3(256), 0, ctx->stream, (int)n_miss, list, dst, lse_out);
+  hipLaunchKernelGGL(memo_insert_kernel, grid1(n_miss), dim3(256), 0, ctx->stream, (int)n_miss, list, kc, il.row, il.ctx, md,
+                     dst);
+  return PCLEAN_OK;
+}
+
+// evaluated once per distinct item tuple
+static int eval_node_lse_core(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
+                              uint64_t seed, uint32_t sweep, double* lse_out) {
   ItemGroups g;
   int rc0 = make_item_groups(ctx, block_id, node_id, il, excl, g);
   if (rc0) return rc0;
@@ -2049,7 +2240,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     }
     const int nn = (int)b.nodes.size();
     const int32_t* cur_b = s->cur.p + (size_t)bi * N;
-    if (r.pchoice.alloc(NP) || r.pnewpos.alloc(NP) || r.choice.alloc(N) || r.chosen_newpos.alloc(N) ||
+    if (r.pchoice.alloc(NP) || r.pnewpos.alloc(NP) || r.new_slots.alloc(NP) || r.choice.alloc(N) || r.chosen_newpos.alloc(N) ||
         r.moved_flag.alloc(N) || r.new_flag.alloc(N) || r.moved_list.alloc(N) || r.new_list.alloc(N))
       return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
     int rc = ensure_plan_dev(ctx, bi);
@@ -2074,7 +2265,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
       hipLaunchKernelGGL(particle_update_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
-                         s->w.p, s->counter.p);
+                         s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p);
     } else {
       if (r.it_ctx.alloc(NP * PCLEAN_MAX_CTX)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
       CtxSrc cs{};
@@ -2129,7 +2320,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
       hipLaunchKernelGGL(particle_update_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, (const int32_t*)nullptr,
                          (const double*)nullptr, slot_item, draws_item, lse_item, cur_b, r.pchoice.p, s->w.p,
-                         s->counter.p);
+                         s->counter.p, r.new_slots.p, r.pnewpos.p);
     }
     // ---- particles that proposed a NEW referent: sample the new row's contents
     unsigned int n_new = 0;
@@ -2139,11 +2330,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     if (r.vals.alloc(std::max<size_t>((size_t)n_new * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
     if (n_new) {
       ProfScope ps(ctx, "new_row_sampling");
-      int32_t* list = scratch<int32_t>(ctx, n_new);
-      if (!list) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-      hipLaunchKernelGGL(compact_new_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, r.pchoice.p, 1, s->counter.p,
-                         list, r.pnewpos.p);
+      const int32_t* list = r.new_slots.p;
       hipLaunchKernelGGL(fill_i32_kernel, grid1((size_t)n_new * nn), dim3(256), 0, ctx->stream, r.vals.p,
                          (size_t)n_new * nn, -2);
       int32_t* row = scratch<int32_t>(ctx, n_new);
