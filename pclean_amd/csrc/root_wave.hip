@@ -273,6 +273,7 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
     // A retained referent that explains the row badly (wrong entity, many typos) gives a useless bound: when its
     // cut-off would let candidates more than WAVE_DCUT_OK edits away through, stage 0 runs as well and the better
     // of the two bounds is used.
+    bound = fmax(bound, sn);  // the new-row candidate is a candidate too: its exact score bounds the maximum from below
     bool need_bound = !(bound > -__builtin_inf()) && fr.n_pre > 0;
     if (!need_bound && fr.n_pre > 0) {
       const double x = (pmax - bound + FIX_CUTOFF) * fr.inv_c;
@@ -514,11 +515,23 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   hipLaunchKernelGGL(group_desc_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, dn, it, ch, it.n,
                      desc_scratch);
   // persistent grid: 4 groups (waves) per workgroup, up to 8 workgroups per CU
-  int wgs = 256 * 8;
+  // persistent grid = what is resident at once (a workgroup that starts late would still own its full share)
+  wave_kernel_t kern = pick_kernel(fr.n_terms);
+  static int resident[17] = {0};  // per kernel variant (indexed by its term capacity), queried once
+  const int variant = fr.n_terms <= 2 ? 2 : fr.n_terms <= 4 ? 4 : fr.n_terms <= 8 ? 8 : fr.n_terms <= 12 ? 12 : 16;
+  if (!resident[variant]) {
+    int per_cu = 0, n_cu = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    per_cu = std::min(per_cu, 6);  // 256-thread workgroups with ~100 SGPRs: the hardware admits 6 per CU (MI355X_MICROARCH.md)
+    resident[variant] = n_cu * per_cu;
+  }
+  int wgs = resident[variant];
   if (const char* e = getenv("PCLEAN_WAVE_WGS")) wgs = std::max(1, atoi(e));
   wgs = std::min(wgs, (it.n + 3) / 4);
   wgs = (wgs + 7) & ~7;  // a multiple of the 8 XCDs (the kernel splits the groups into 8 contiguous ranges)
-  hipLaunchKernelGGL(pick_kernel(fr.n_terms), dim3(wgs), dim3(256), 0, ctx->stream, fr, dn, it, seed, sweep, site,
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, ctx->stream, fr, dn, it, seed, sweep, site,
                      n_draws, it.n, desc_scratch, lse_out, draws_out, overflow_flag, overflow_count);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
