@@ -12,9 +12,10 @@
 //   ([j][lane]) so every ds_read/ds_write of a wave hits 64 consecutive
 //   16-bit slots (conflict-free).  d[i-2][j-2] for the transposition case is
 //   carried in registers, so only two rows are kept.
-// Kernel dl_pair_kernel (unrestricted DL, Lowrance–Wagner): thread per pair,
-//   full (la+2)x(lb+2) matrix in a lane-interleaved global scratch.  Exact but
-//   slow; used only when PCLEAN_DIST_DL is requested.
+// Kernel osa_bitpar_kernel (restricted DL, bit-parallel, below): the default for observed strings up to 256 symbols;
+//   the DP-tile kernel above remains for longer ones.
+// Kernel dl_lds_kernel (unrestricted DL, Lowrance–Wagner, byte matrix in LDS) and dl_pair_kernel (same recurrence,
+//   full (la+2)x(lb+2) matrix in a lane-interleaved global scratch, for strings whose matrix does not fit in LDS).
 #include "ctx.h"
 
 template <typename OutT>
@@ -133,6 +134,169 @@ __global__ void dl_pair_kernel(const uint16_t* __restrict__ sym, const int64_t* 
 #undef HH
 }
 
+// ---- osa_bitpar_kernel: restricted Damerau-Levenshtein (optimal string alignment), bit-parallel ----------------
+// Hyyro's bit-vector algorithm ("A bit-vector algorithm for computing Levenshtein and Damerau edit distances",
+// Nordic J. Computing 2003 — published algorithm, restated): the column of the DP matrix is kept as vertical /
+// horizontal delta bit-vectors over the PATTERN, one text character per step, ~25 word operations per 64 pattern
+// positions instead of 64 DP cells.  Mapping: pattern = the observed string (wave-uniform: its match masks
+// Peq[symbol] are built once per workgroup in LDS), text = one latent string per lane (staged once per workgroup
+// in LDS, transposed [j][lane] -> conflict-free); a workgroup walks a chunk of observed strings over its 256 latent
+// strings.  W = 64-bit words per pattern (observed strings up to 64 W symbols): the additions and shifts carry
+// across words exactly like big-integer arithmetic.  d = la initially; +1 / -1 per column from bit la-1 of the
+// horizontal deltas.  The 90-character MeasureName column that cost the DP-tile kernel 10 s takes ~0.2 s.
+template <int W, typename SymT, typename OutT>
+__global__ __launch_bounds__(256) void osa_bitpar_kernel(const uint16_t* __restrict__ sym,
+                                                         const int64_t* __restrict__ off,
+                                                         const int32_t* __restrict__ obs_ids,
+                                                         const int32_t* __restrict__ lat_ids, int n_obs, int n_lat,
+                                                         int max_lb, int n_symbols, int u_chunk,
+                                                         OutT* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t* peq = reinterpret_cast<uint64_t*>(smem_raw);                          // [n_symbols][W]
+  SymT* bT = reinterpret_cast<SymT*>(peq + (size_t)n_symbols * W);                // [max_lb][256]
+  const int t = threadIdx.x;
+  const int v = blockIdx.x * 256 + t;
+  int lb = 0;
+  if (v < n_lat) {
+    const int64_t b0 = off[lat_ids[v]];
+    lb = (int)(off[lat_ids[v] + 1] - b0);
+    for (int j = 0; j < lb; ++j) bT[(size_t)j * 256 + t] = (SymT)sym[b0 + j];
+  }
+  const int u0 = blockIdx.y * u_chunk, u1 = min(u0 + u_chunk, n_obs);
+  for (int u = u0; u < u1; ++u) {
+    const int64_t a0 = off[obs_ids[u]];
+    const int la = (int)(off[obs_ids[u] + 1] - a0);
+    __syncthreads();  // previous pattern's masks are no longer read
+    for (int i = t; i < n_symbols * W; i += 256) peq[i] = 0ull;
+    __syncthreads();
+    for (int i = t; i < la; i += 256) {
+      unsigned int* wlo = reinterpret_cast<unsigned int*>(&peq[(size_t)sym[a0 + i] * W + (i >> 6)]);
+      atomicOr(wlo + ((i & 63) >> 5), 1u << (i & 31));
+    }
+    __syncthreads();
+    if (v >= n_lat) continue;
+    int score = la;
+    if (la == 0) {
+      score = lb;
+    } else {
+      uint64_t VP[W], VN[W], D0[W], PMp[W];
+#pragma unroll
+      for (int r = 0; r < W; ++r) {
+        VP[r] = ~0ull;
+        VN[r] = 0ull;
+        D0[r] = 0ull;
+        PMp[r] = 0ull;
+      }
+      const int top_w = (la - 1) >> 6;
+      const uint64_t top_bit = 1ull << ((la - 1) & 63);
+      for (int j = 0; j < lb; ++j) {
+        const uint64_t* pm = peq + (size_t)bT[(size_t)j * 256 + t] * W;
+        uint64_t carry_add = 0, carry_tr = 0, carry_hp = 1ull, carry_hn = 0;
+#pragma unroll
+        for (int r = 0; r < W; ++r) {
+          const uint64_t PM = pm[r];
+          const uint64_t X = (~D0[r]) & PM;                       // transposition (restricted: adjacent pairs)
+          const uint64_t TR = ((X << 1) | carry_tr) & PMp[r];
+          carry_tr = X >> 63;
+          const uint64_t A = PM & VP[r];
+          const uint64_t s1 = A + VP[r];
+          const uint64_t s2 = s1 + carry_add;
+          carry_add = (s1 < A ? 1ull : 0ull) | (s2 < s1 ? 1ull : 0ull);
+          const uint64_t d0 = ((s2 ^ VP[r]) | PM | VN[r]) | TR;
+          const uint64_t HP = VN[r] | ~(d0 | VP[r]);
+          const uint64_t HN = d0 & VP[r];
+          if (r == top_w) {
+            score += (HP & top_bit) ? 1 : 0;
+            score -= (HN & top_bit) ? 1 : 0;
+          }
+          const uint64_t HPs = (HP << 1) | carry_hp;
+          const uint64_t HNs = (HN << 1) | carry_hn;
+          carry_hp = HP >> 63;
+          carry_hn = HN >> 63;
+          VP[r] = HNs | ~(d0 | HPs);
+          VN[r] = d0 & HPs;
+          D0[r] = d0;
+          PMp[r] = PM;
+        }
+      }
+    }
+    if (sizeof(OutT) == 1 && score > 255) score = 255;
+    out[(size_t)u * n_lat + v] = (OutT)score;
+  }
+}
+
+// ---- dl_lds_kernel: unrestricted Damerau-Levenshtein (Lowrance-Wagner), one pair per lane, matrix in LDS -------
+// The full (la+2) x (lb+2) matrix is needed (the transposition term reaches back to an arbitrary earlier row), so
+// it lives in LDS as bytes, transposed [cell][lane] (conflict-free), next to the per-lane "last row of symbol"
+// table; the observed string is wave-uniform.  Strings whose matrix does not fit go to dl_pair_kernel (global
+// scratch).  Distances are exact whenever they are < 255 (a clamped cell can only feed cells that are >= 255 too).
+template <typename OutT>
+__global__ __launch_bounds__(64) void dl_lds_kernel(const uint16_t* __restrict__ sym, const int64_t* __restrict__ off,
+                                                    const int32_t* __restrict__ obs_ids,
+                                                    const int32_t* __restrict__ lat_ids, int n_obs, int n_lat,
+                                                    int max_la, int max_lb, int n_symbols, int u_chunk,
+                                                    OutT* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int t = threadIdx.x;
+  const int Wd = max_lb + 2;
+  unsigned char* H = smem_raw;                                          // [(max_la+2) * Wd][64]
+  unsigned char* da = H + (size_t)(max_la + 2) * Wd * 64;               // [n_symbols][64]
+  unsigned char* bS = da + (size_t)n_symbols * 64;                      // [max_lb][64] latent symbols (low byte)
+  unsigned char* bS2 = bS + (size_t)max_lb * 64;                        // high byte
+#define HH(r, c) H[((size_t)(r) * Wd + (c)) * 64 + t]
+  const int v = blockIdx.x * 64 + t;
+  int lb = 0;
+  if (v < n_lat) {
+    const int64_t b0 = off[lat_ids[v]];
+    lb = (int)(off[lat_ids[v] + 1] - b0);
+    for (int j = 0; j < lb; ++j) {
+      const uint16_t c = sym[b0 + j];
+      bS[(size_t)j * 64 + t] = (unsigned char)(c & 0xff);
+      bS2[(size_t)j * 64 + t] = (unsigned char)(c >> 8);
+    }
+  }
+  const int u0 = blockIdx.y * u_chunk, u1 = min(u0 + u_chunk, n_obs);
+  for (int u = u0; u < u1; ++u) {
+    if (v >= n_lat) continue;
+    const int64_t a0 = off[obs_ids[u]];
+    const int la = (int)(off[obs_ids[u] + 1] - a0);
+    const int maxdist = min(la + lb, 255);
+    for (int s = 0; s < n_symbols; ++s) da[(size_t)s * 64 + t] = 0;
+    HH(0, 0) = (unsigned char)maxdist;
+    for (int i = 0; i <= la; ++i) {
+      HH(i + 1, 0) = (unsigned char)maxdist;
+      HH(i + 1, 1) = (unsigned char)min(i, 255);
+    }
+    for (int j = 0; j <= lb; ++j) {
+      HH(0, j + 1) = (unsigned char)maxdist;
+      HH(1, j + 1) = (unsigned char)min(j, 255);
+    }
+    for (int i = 1; i <= la; ++i) {
+      int db = 0;
+      const uint16_t ai = sym[a0 + i - 1];
+      for (int j = 1; j <= lb; ++j) {
+        const uint16_t bj = (uint16_t)bS[(size_t)(j - 1) * 64 + t] | ((uint16_t)bS2[(size_t)(j - 1) * 64 + t] << 8);
+        const int k = da[(size_t)bj * 64 + t];
+        const int l = db;
+        int cost = 1;
+        if (ai == bj) {
+          cost = 0;
+          db = j;
+        }
+        int vv = HH(i, j) + cost;
+        vv = min(vv, HH(i + 1, j) + 1);
+        vv = min(vv, HH(i, j + 1) + 1);
+        vv = min(vv, HH(k, l) + (i - k - 1) + 1 + (j - l - 1));
+        HH(i + 1, j + 1) = (unsigned char)min(vv, 255);
+      }
+      da[(size_t)ai * 64 + t] = (unsigned char)i;
+    }
+    int d = HH(la + 1, lb + 1);
+    out[(size_t)u * n_lat + v] = (OutT)d;
+  }
+#undef HH
+}
+
 __global__ void lat_len_kernel(const int64_t* __restrict__ off, const int32_t* __restrict__ lat_ids, int n,
                                uint16_t* __restrict__ len) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -147,6 +311,65 @@ int pclean_launch_dist(pclean_ctx* ctx, PairTable& pt, const int32_t* d_obs_ids,
   if (pt.n_obs == 0) {  // empty observed domain (every cell of the column missing): nothing to fill
     HIPCHK(ctx, hipGetLastError());
     return PCLEAN_OK;
+  }
+  static const bool no_bitpar = getenv("PCLEAN_NO_BITPAR") != nullptr;
+  if (dist_mode == PCLEAN_DIST_OSA && max_la <= 256 && !no_bitpar) {
+    // bit-parallel OSA: W words of 64 pattern (observed) positions
+    const int W = std::max(1, (max_la + 63) / 64);
+    const bool sym8 = ctx->n_symbols <= 255;
+    const size_t lds = (size_t)ctx->n_symbols * W * 8 + (size_t)std::max(max_lb, 1) * 256 * (sym8 ? 1 : 2);
+    if (lds <= 160 * 1024) {
+      const int u_chunk = 64;
+      dim3 grid((pt.n_lat + 255) / 256, (pt.n_obs + u_chunk - 1) / u_chunk);
+#define LAUNCH_BITPAR(WW, ST, OT)                                                                                      \
+  do {                                                                                                                 \
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)osa_bitpar_kernel<WW, ST, OT>,                                        \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+    hipLaunchKernelGGL((osa_bitpar_kernel<WW, ST, OT>), grid, dim3(256), lds, ctx->stream, ctx->sym.p, ctx->off.p,     \
+                       d_obs_ids, d_lat_ids, pt.n_obs, pt.n_lat, max_lb, ctx->n_symbols, u_chunk, (OT*)pt.d.p);        \
+  } while (0)
+#define LAUNCH_BITPAR_W(ST, OT)          \
+  do {                                   \
+    if (W == 1)                          \
+      LAUNCH_BITPAR(1, ST, OT);          \
+    else if (W == 2)                     \
+      LAUNCH_BITPAR(2, ST, OT);          \
+    else if (W == 3)                     \
+      LAUNCH_BITPAR(3, ST, OT);          \
+    else                                 \
+      LAUNCH_BITPAR(4, ST, OT);          \
+  } while (0)
+      if (pt.elem_bytes == 1) {
+        if (sym8)
+          LAUNCH_BITPAR_W(uint8_t, uint8_t);
+        else
+          LAUNCH_BITPAR_W(uint16_t, uint8_t);
+      } else {
+        if (sym8)
+          LAUNCH_BITPAR_W(uint8_t, uint16_t);
+        else
+          LAUNCH_BITPAR_W(uint16_t, uint16_t);
+      }
+#undef LAUNCH_BITPAR_W
+#undef LAUNCH_BITPAR
+      HIPCHK(ctx, hipGetLastError());
+      return PCLEAN_OK;
+    }
+  }
+  if (dist_mode == PCLEAN_DIST_DL && pt.elem_bytes == 1 && !getenv("PCLEAN_NO_DL_LDS")) {
+    // unrestricted DL with the matrix in LDS (bytes), when it fits
+    const size_t per_lane = (size_t)(max_la + 2) * (max_lb + 2) + (size_t)ctx->n_symbols + 2 * (size_t)std::max(max_lb, 1);
+    const size_t lds = per_lane * 64;
+    if (lds <= 160 * 1024 && max_la < 255 && ctx->n_symbols <= 65535) {
+      const int u_chunk = 16;
+      dim3 grid((pt.n_lat + 63) / 64, (pt.n_obs + u_chunk - 1) / u_chunk);
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)dl_lds_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)lds));
+      hipLaunchKernelGGL(dl_lds_kernel<uint8_t>, grid, dim3(64), lds, ctx->stream, ctx->sym.p, ctx->off.p, d_obs_ids,
+                         d_lat_ids, pt.n_obs, pt.n_lat, max_la, max_lb, ctx->n_symbols, u_chunk, (uint8_t*)pt.d.p);
+      HIPCHK(ctx, hipGetLastError());
+      return PCLEAN_OK;
+    }
   }
   if (dist_mode == PCLEAN_DIST_OSA) {
     // LDS bytes = ((2*(max_lb+1) + max_lb) * T + max_la) * 2

@@ -104,3 +104,61 @@ def test_detmath_and_philox_bit_exact_on_device(hip, oracle):
     got = hip.debug_rand64(0x1234567890abcdef, rows, 0x10002, 7, 3)
     for r in (0, 1, 77, 4999):
         assert int(got[r]) == L.pco_rand64(0x1234567890abcdef, int(r), 0x10002, 7, 3)
+
+
+def test_pair_table_long_patterns_and_dl_random(hip, oracle):
+    """Multi-word bit-parallel OSA (observed strings of 65..250 symbols incl. transpositions across the 64-bit
+    word boundaries) and the LDS-matrix unrestricted DL kernel on random short strings, against the oracle's DP."""
+    rnd = np.random.default_rng(11)
+    alpha = list("abcdefgh ")
+    long_words = []
+    for n in (63, 64, 65, 66, 100, 127, 128, 129, 130, 184, 192, 193, 250):
+        w = rnd.choice(alpha, size=n)
+        long_words.append("".join(w))
+        sw = w.copy()
+        for pos in (n // 2, min(63, n - 2), min(64, n - 2), min(127, n - 2), n - 2):  # adjacent swaps around word boundaries
+            if 0 <= pos < n - 1:
+                sw[pos], sw[pos + 1] = sw[pos + 1], sw[pos]
+        long_words.append("".join(sw))
+        long_words.append("".join(np.delete(w, rnd.integers(0, n, size=3))))
+    pool, ids = _pool(long_words)
+    sym, off, _, _ = pool.arrays()
+    hip.load_strings(sym, off)
+    ids = np.unique(ids)
+    hip.build_pair_table(31, ids, ids, 0)
+    assert np.array_equal(hip.get_pair_table(31, len(ids), len(ids)), oracle.pair_table(sym, off, ids, ids, 0))
+    short = ["".join(rnd.choice(list("abcx"), size=rnd.integers(0, 30))) for _ in range(400)]
+    pool, ids = _pool(short)
+    sym, off, _, _ = pool.arrays()
+    hip.load_strings(sym, off)
+    ids = np.unique(ids)
+    for mode in (0, 1):
+        hip.build_pair_table(32 + mode, ids[:200], ids, mode)
+        got = hip.get_pair_table(32 + mode, 200, len(ids))
+        assert np.array_equal(got, oracle.pair_table(sym, off, ids[:200], ids, mode)), mode
+
+
+def test_synthetic_table_osa_equals_dl(hip):
+    """The 1M-row bench builds its pair tables with the (bit-parallel) restricted distance while the real datasets
+    use unrestricted Damerau-Levenshtein: on the synthetic generator's strings ('x'-substitution typos) the two
+    flavours agree on EVERY (observed, latent) pair of every column (here at 30k rows / 600 hospitals)."""
+    from pclean_amd import experiments as ex
+    from pclean_amd.model import LoweredModel
+    from pclean_amd.synth import synth_hospital
+    dirty, clean, _ = synth_hospital(30_000, 600, 3)
+    m = ex.hospital_model(ex.possibilities_of(dirty))
+    lw = LoweredModel(m, ex.hospital_query(m), dirty)
+    sym, off, _, _ = lw.pool.arrays()
+    hip.load_strings(sym, off)
+    n_pairs = 0
+    for key, (pid, odom, ldom) in lw.pair_id.items():
+        oi, li = odom.id_array(), ldom.id_array()
+        if lw.pool.lens[oi].max() > 60 or lw.pool.lens[li].max() > 60:
+            oi, li = oi[:400], li[:4000]  # the 90-character measure names: a sample keeps the exact DL kernel quick
+        hip.build_pair_table(40, oi, li, 0)
+        a = hip.get_pair_table(40, len(oi), len(li))
+        hip.build_pair_table(41, oi, li, 1)
+        b = hip.get_pair_table(41, len(oi), len(li))
+        assert np.array_equal(a, b), (key, int(np.sum(a != b)))
+        n_pairs += a.size
+    assert n_pairs > 10_000_000
