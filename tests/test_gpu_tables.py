@@ -138,10 +138,13 @@ def test_pair_table_long_patterns_and_dl_random(hip, oracle):
         assert np.array_equal(got, oracle.pair_table(sym, off, ids[:200], ids, mode)), mode
 
 
-def test_synthetic_table_osa_equals_dl(hip):
-    """The 1M-row bench builds its pair tables with the (bit-parallel) restricted distance while the real datasets
-    use unrestricted Damerau-Levenshtein: on the synthetic generator's strings ('x'-substitution typos) the two
-    flavours agree on EVERY (observed, latent) pair of every column (here at 30k rows / 600 hospitals)."""
+def test_synthetic_table_osa_vs_dl(hip, capsys):
+    """The 1M-row bench builds its pair tables with the (bit-parallel) restricted distance (OSA; the semantics of
+    StringDistances < 0.11) while the real datasets default to unrestricted Damerau-Levenshtein.  The two flavours
+    are NOT identical on the synthetic generator's strings: random digit strings (provider numbers, zip codes,
+    phone numbers) hold gapped transpositions.  Measured here at 30k rows / 600 hospitals: they differ on well
+    under 1 % of the (observed, latent) pairs of a column, never by more than one edit, and only where the
+    distance is >= 2 (an observed value and its own clean value are never affected)."""
     from pclean_amd import experiments as ex
     from pclean_amd.model import LoweredModel
     from pclean_amd.synth import synth_hospital
@@ -150,15 +153,24 @@ def test_synthetic_table_osa_equals_dl(hip):
     lw = LoweredModel(m, ex.hospital_query(m), dirty)
     sym, off, _, _ = lw.pool.arrays()
     hip.load_strings(sym, off)
-    n_pairs = 0
+    n_pairs = n_diff = 0
+    report = []
     for key, (pid, odom, ldom) in lw.pair_id.items():
         oi, li = odom.id_array(), ldom.id_array()
         if lw.pool.lens[oi].max() > 60 or lw.pool.lens[li].max() > 60:
             oi, li = oi[:400], li[:4000]  # the 90-character measure names: a sample keeps the exact DL kernel quick
         hip.build_pair_table(40, oi, li, 0)
-        a = hip.get_pair_table(40, len(oi), len(li))
+        a = hip.get_pair_table(40, len(oi), len(li)).astype(np.int32)
         hip.build_pair_table(41, oi, li, 1)
-        b = hip.get_pair_table(41, len(oi), len(li))
-        assert np.array_equal(a, b), (key, int(np.sum(a != b)))
+        b = hip.get_pair_table(41, len(oi), len(li)).astype(np.int32)
+        diff = a != b
+        assert (b <= a).all(), key                      # unrestricted DL never exceeds the restricted distance
+        assert (b[diff] >= 2).all(), key                # ... and only differs between strings at least 2 edits apart
+        assert diff.mean() < 0.05, (key, float(diff.mean()))
+        report.append((key[0], a.size, int(diff.sum()), int((a - b).max())))
         n_pairs += a.size
+        n_diff += int(diff.sum())
     assert n_pairs > 10_000_000
+    with capsys.disabled():
+        print("\n[osa vs dl] column pairs differing: " + ", ".join(f"{c} {d}/{n} (max {mx})" for c, n, d, mx in report)
+              + f"; total {n_diff}/{n_pairs} = {100.0 * n_diff / n_pairs:.3f} %")
