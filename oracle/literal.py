@@ -1,0 +1,310 @@
+"""oracle/literal.py — TEST INFRASTRUCTURE ONLY (never imported by pclean_amd, bench.py's timed region or the C ABI).
+
+A second, LITERAL restatement of PClean's enumerated block proposal: it walks the MODEL DESCRIPTION (classes,
+attributes, distributions, reference slots — pclean_amd.model's mirror of the `@model` DSL) and a dict-of-rows trace
+holding plain Python strings, the way the reference's generated proposals do:
+
+  * candidates of a reference slot = the rows of the target class + one "new row"     proposal_compiler.jl:131-252
+  * CRP prior  log(count - d) - log(total + s),  new:  log(s + d K) - log(total + s)   proposal_compiler.jl:165-171,
+                                                                                        model/trace.jl:53-61
+  * `prob += logdensity(dist, observed, args...)` for every observed choice below it   proposal_compiler.jl:75
+  * the new row's own choices enumerated over their discrete proposals, sibling
+    sub-plans independently, log-marginals added                                        proposal_compiler.jl:55-129,363-388
+  * StringPrior proposal = atoms + ProposalDummyValue with mass log1p(-exp(lse)); the
+    dummy is scored against the placeholder string "*"^mid                              string_prior.jl:16-26
+  * densities from the strings themselves: Damerau-Levenshtein + NegativeBinomial       add_typos.jl:50-66
+    (scipy's nbinom = Distributions.jl's parametrisation), bigram StringPrior from the
+    lmparams CSVs                                                                        string_prior.jl:43-61
+
+It shares NOTHING with the product's lowering (LoweredModel's nodes / terms / colmap / pair tables / fn tables /
+option tables): plans are derived here from the attribute references, JuliaNodes are evaluated by calling the
+model's Python function on strings.  tests/golden/literal_scores.json holds its per-candidate scores for rows of
+hospital_dirty.csv; the C++ oracle (CPU suite) and the HIP path (-m gpu) must reproduce them to 1e-12 relative.
+Scope: programs built from reference slots, AddTypos, StringPrior, ChooseUniformly, ChooseProportionally and JuliaNodes
+(hospital).  Gaussian / MaybeSwap / TimePrior programs (rents, flights) are covered by the C++ oracle only.
+"""
+import math
+import os
+
+import numpy as np
+from scipy.stats import nbinom
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LM_DIR = os.path.join(os.path.dirname(HERE), "pclean_amd", "lmparams")
+ALPHABET = [chr(c) for c in range(ord("a"), ord("z") + 1)] + [" ", "."]
+IMPOSSIBLE = -1e5  # utils.jl
+
+
+def _lm():
+    init = np.loadtxt(os.path.join(LM_DIR, "letter_probabilities.csv"), delimiter=",").reshape(-1)
+    trans = np.loadtxt(os.path.join(LM_DIR, "letter_transition_matrix.csv"), delimiter=",")
+    return init, trans
+
+
+_INIT, _TRANS = _lm()
+_IDX = {c: i for i, c in enumerate(ALPHABET)}
+
+
+def damerau_levenshtein(a, b, restricted=False):
+    """Unrestricted (Lowrance-Wagner) or restricted (optimal string alignment) Damerau-Levenshtein distance."""
+    la, lb = len(a), len(b)
+    if restricted:
+        d = [[0] * (lb + 1) for _ in range(la + 1)]
+        for i in range(la + 1):
+            d[i][0] = i
+        for j in range(lb + 1):
+            d[0][j] = j
+        for i in range(1, la + 1):
+            for j in range(1, lb + 1):
+                c = 0 if a[i - 1] == b[j - 1] else 1
+                v = min(d[i - 1][j] + 1, d[i][j - 1] + 1, d[i - 1][j - 1] + c)
+                if i > 1 and j > 1 and a[i - 1] == b[j - 2] and a[i - 2] == b[j - 1]:
+                    v = min(v, d[i - 2][j - 2] + 1)
+                d[i][j] = v
+        return d[la][lb]
+    da = {}
+    maxdist = la + lb
+    H = [[0] * (lb + 2) for _ in range(la + 2)]
+    H[0][0] = maxdist
+    for i in range(la + 1):
+        H[i + 1][0] = maxdist
+        H[i + 1][1] = i
+    for j in range(lb + 1):
+        H[0][j + 1] = maxdist
+        H[1][j + 1] = j
+    for i in range(1, la + 1):
+        db = 0
+        for j in range(1, lb + 1):
+            k = da.get(b[j - 1], 0)
+            l = db
+            cost = 1
+            if a[i - 1] == b[j - 1]:
+                cost = 0
+                db = j
+            H[i + 1][j + 1] = min(H[i][j] + cost, H[i + 1][j] + 1, H[i][j + 1] + 1,
+                                  H[k][l] + (i - k - 1) + 1 + (j - l - 1))
+        da[a[i - 1]] = i
+    return H[la + 1][lb + 1]
+
+
+_typo_memo = {}
+
+
+def add_typos_logpdf(observed, word, max_typos=None, restricted=False):
+    """add_typos.jl:50-66."""
+    if observed is None:
+        return 0.0
+    key = (observed, word, max_typos, restricted)
+    v = _typo_memo.get(key)
+    if v is None:
+        d = damerau_levenshtein(observed, word, restricted)
+        if max_typos is not None and d > max_typos:
+            v = IMPOSSIBLE
+        else:
+            v = float(nbinom.logpmf(d, math.ceil(len(word) / 5.0), 0.9))
+            v -= math.log(len(word)) * d
+            v -= math.log(26) * d / 2
+        _typo_memo[key] = v
+    return v
+
+
+def string_prior_logpdf(s, min_len, max_len):
+    """string_prior.jl:43-61."""
+    if len(s) < min_len or len(s) > max_len:
+        return -math.inf
+    score = -math.log(max_len - min_len + 1)
+    prev = None
+    for ch in s:
+        dist = _INIT if prev is None else _TRANS[:, prev]
+        prev = _IDX.get(ch.lower())
+        if prev is None:
+            score += -math.log(28)
+        else:
+            p = dist[prev]
+            score += max(math.log(p), -1000.0) if p > 0 else -1000.0
+    return score
+
+
+def logsumexp(xs):
+    m = max(xs)
+    if m == -math.inf:
+        return m
+    return m + math.log(sum(math.exp(x - m) for x in xs))
+
+
+class LitTrace:
+    """Dict-of-rows database: tables[cls][key] = {attr: string | referenced key}; counts[cls][key]; (strength,
+    discount) per class; params[(cls, param)] = probability vector aligned with the distribution's options."""
+
+    def __init__(self, model):
+        self.model = model
+        self.tables = {c: {} for c in model.classes}
+        self.counts = {c: {} for c in model.classes}
+        self.py = {c: (model.classes[c].py_strength, model.classes[c].py_discount) for c in model.classes}
+        self.params = {}
+
+    def value(self, cls, key, path):
+        """Follow a dotted path from row `key` of class cls; the last step is an own attribute."""
+        row = self.tables[cls][key]
+        c = self.model.classes[cls]
+        parts = path.split(".")
+        for p in parts[:-1]:
+            a = c.attr(p)
+            key = row[p]
+            c = self.model.classes[a.target]
+            row = self.tables[c.name][key]
+        return row[parts[-1]]
+
+    def unrefer(self, cls, key):
+        """unrefer_to_row! (dependency_tracking.jl:162-201): drop one reference; a row nobody refers to any more is
+        deleted and releases its own referents."""
+        self.counts[cls][key] -= 1
+        if self.counts[cls][key] == 0:
+            row = self.tables[cls].pop(key)
+            del self.counts[cls][key]
+            for a in self.model.classes[cls].attrs:
+                if a.kind == "fk":
+                    self.unrefer(a.target, row[a.name])
+
+
+def discrete_proposal(trace, cls, attr):
+    """(options, log-probabilities, dummy string or None) of an own choice (distributions.jl:16)."""
+    from pclean_amd.model import ChooseProportionally, ChooseUniformly, StringPrior
+    d = attr.dist
+    if isinstance(d, StringPrior):
+        lps = [string_prior_logpdf(s, d.min_len, d.max_len) for s in d.atoms]
+        total = logsumexp(lps)
+        return list(d.atoms) + [None], lps + [math.log1p(-math.exp(total))], d.dummy_value()
+    if isinstance(d, ChooseUniformly):
+        return list(d.options), [-math.log(len(d.options))] * len(d.options), None
+    if isinstance(d, ChooseProportionally):
+        probs = trace.params[(cls, d.param)]
+        return list(d.options), [math.log(p) if p > 0 else -math.inf for p in probs], None
+    raise NotImplementedError(type(d))
+
+
+class BlockProposal:
+    """The enumerated proposal of one block of the observed class for one observed row."""
+
+    def __init__(self, trace, query, block_attrs, observed, other_block_values, restricted=False):
+        """observed: {dirty attribute name: string | None}; other_block_values: {path: string} for paths below the
+        reference slots of OTHER blocks (values chosen earlier in the row: the JuliaNode arguments that are not
+        below this block's slot)."""
+        self.trace, self.model, self.query = trace, trace.model, query
+        self.ocls = self.model.classes[query.cls]
+        self.observed, self.ctx, self.restricted = observed, other_block_values, restricted
+        fks = [a for a in block_attrs if self.ocls.attr(a).kind == "fk"]
+        assert len(fks) == 1, "one reference slot per block"
+        self.fk = self.ocls.attr(fks[0])
+        # likelihood terms: (observed string, function of {path below the slot: string} -> latent word, max_typos, paths used)
+        self.terms = []
+        from pclean_amd.model import AddTypos
+        for an in block_attrs:
+            a = self.ocls.attr(an)
+            if a.kind != "choice":
+                continue
+            assert isinstance(a.dist, AddTypos)
+            self.terms.append(self._term(a))
+
+    def _term(self, a):
+        ref = a.dist.ref
+        pre = self.fk.name + "."
+        if ref.startswith(pre):
+            path = ref[len(pre):]
+            return dict(obs=self.observed[a.name], paths=[path], word=lambda vals, p=path: vals[p], max_typos=a.dist.max_typos)
+        j = self.ocls.attr(ref)  # a JuliaNode of the row: its arguments are below this slot or another block's
+        assert j.kind == "julia"
+        mine = [arg[len(pre):] for arg in j.args if arg.startswith(pre)]
+
+        def word(vals, j=j):
+            args = [vals[arg[len(pre):]] if arg.startswith(pre) else self.ctx[arg] for arg in j.args]
+            return j.fn(*args)
+
+        return dict(obs=self.observed[a.name], paths=mine, word=word, max_typos=a.dist.max_typos)
+
+    # -- helpers -------------------------------------------------------------------------------------------------
+    def _crp(self, cls):
+        s, d = self.trace.py[cls]
+        counts = self.trace.counts[cls]
+        total = sum(counts.values())
+        return s, d, counts, total
+
+    def _lik(self, term, vals):
+        return add_typos_logpdf(term["obs"], term["word"](vals), term["max_typos"], self.restricted)
+
+    def _flat(self, cls, key, prefix=""):
+        """{path: string} of every own attribute reachable from row key (the flattened row)."""
+        out = {}
+        for a in self.model.classes[cls].attrs:
+            if a.kind == "choice":
+                out[prefix + a.name] = self.trace.tables[cls][key][a.name]
+            elif a.kind == "fk":
+                out.update(self._flat(a.target, self.trace.tables[cls][key][a.name], prefix + a.name + "."))
+        return out
+
+    def _terms_below(self, prefix):
+        """terms all of whose own paths start with `prefix` (prefix '' = every term)."""
+        return [t for t in self.terms if t["paths"] and all(p.startswith(prefix) for p in t["paths"])]
+
+    def _new_marginal(self, cls, prefix, fixed):
+        """log-marginal of a fresh row of cls reached through `prefix` (path below the slot, '' or 'loc.' ...):
+        its own choices and nested reference slots are independent sub-plans, enumerated one by one.  `fixed` =
+        values of paths outside this row that the terms may need (none in the programs covered)."""
+        total = 0.0
+        for a in self.model.classes[cls].attrs:
+            if a.kind == "choice":
+                path = prefix + a.name
+                terms = [t for t in self.terms if path in t["paths"]]
+                assert all(t["paths"] == [path] for t in terms), "a term below two sub-plans is not enumerable independently"
+                options, lps, dummy = discrete_proposal(self.trace, cls, a)
+                sc = []
+                for o, lp in zip(options, lps):
+                    vals = dict(fixed)
+                    vals[path] = dummy if o is None else o
+                    sc.append(lp + sum(self._lik(t, vals) for t in terms))
+                total += logsumexp(sc)
+            elif a.kind == "fk":
+                sub = prefix + a.name + "."
+                total += logsumexp(list(self._slot_scores(a.target, sub, fixed).values()))
+        return total
+
+    def _slot_scores(self, cls, prefix, fixed):
+        """{key | 'NEW': score} of the candidates of a reference slot to class cls whose row sits at `prefix`."""
+        s, d, counts, total = self._crp(cls)
+        terms = self._terms_below(prefix)
+        out = {}
+        for key, c in counts.items():
+            vals = dict(fixed)
+            vals.update(self._flat(cls, key, prefix))
+            out[key] = (math.log(c - d) - math.log(total + s)) + sum(self._lik(t, vals) for t in terms)
+        out["NEW"] = (math.log(s + d * len(counts)) - math.log(total + s)) + self._new_marginal(cls, prefix, fixed)
+        return out
+
+    def scores(self):
+        """{candidate key of the block's slot | 'NEW': log score}; the block's log-marginal is their logsumexp."""
+        return self._slot_scores(self.fk.target, "", {})
+
+
+def lit_trace_from(lowered, trace):
+    """LitTrace holding the rows of a pclean_amd Trace as strings (decoding only: latent_dom gives the string of a
+    value index, layout names the columns — no plan arrays involved).  Keys are the product's row ids."""
+    lw = lowered
+    lt = LitTrace(lw.model)
+    for cname, t in trace.tables.items():
+        for k in range(t.n):
+            if not t.live[k]:
+                continue
+            row = {}
+            for j, col in enumerate(lw.layout[cname]):
+                if "." in col.name:
+                    continue
+                if col.kind == "fk":
+                    row[col.name] = int(t.cols[j, k])
+                else:
+                    row[col.name] = lw.latent_dom[(cname, col.name)].string(int(t.cols[j, k]))
+            lt.tables[cname][k] = row
+            lt.counts[cname][k] = int(t.counts[k])
+        lt.py[cname] = (float(t.strength), float(t.discount))
+    for (cname, pname), p in trace.params.items():
+        lt.params[(cname, pname)] = np.asarray(p.value, dtype=np.float64)
+    return lt

@@ -313,6 +313,16 @@ class World:
                                 _p(chosen, C.c_int32), _p(vals, C.c_int32))
         return chosen, vals
 
+    def eval_tree(self, block_id, node_id, row, ctxv, excl, n_scores):
+        """(log-marginal, scores of every candidate + the new-row candidate last) of one row; the new-row branch is
+        evaluated recursively."""
+        ctxv = np.ascontiguousarray(ctxv if ctxv is not None else np.zeros(2), np.int32)
+        sc = np.empty(n_scores)
+        self.L.pco_eval_tree.restype = C.c_double
+        lse = self.L.pco_eval_tree(self.h, block_id, node_id, int(row), _p(ctxv, C.c_int32), int(excl), _p(sc, C.c_double),
+                                   n_scores)
+        return lse, sc
+
     def score_node(self, block_id, node_id, rows, ctxv=None, excl=None, snew=None, seed=0, sweep=0, n_draws=0,
                    n_cand=None, want_scores=False):
         rows = np.ascontiguousarray(rows, np.int32)

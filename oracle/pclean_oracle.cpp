@@ -176,6 +176,17 @@ int pco_score_node(const pco::World* w, int block_id, int node_id, int n_items, 
                          draws);
 }
 
+/* Scores of every candidate of `node_id` (+ the new-row candidate, last, for reference slots) for one row, the
+ * new-row branch evaluated recursively (process_plan!, proposal_compiler.jl:363-388).  Returns the log-marginal. */
+double pco_eval_tree(const pco::World* w, int block_id, int node_id, int row, const int32_t* ctxv, int excl,
+                     double* scores, int n_scores) {
+  pco::RowCtx rc{w, block_id, row, ctxv, 0, 0, 0};
+  std::vector<double> s;
+  const double lse = pco::eval_tree(rc, node_id, excl, &s);
+  for (int k = 0; k < n_scores && k < (int)s.size(); ++k) scores[k] = s[k];
+  return lse;
+}
+
 /* ---- particle primitives -------------------------------------------------- */
 void pco_maybe_resample(int n_rows, int P, const double* logw, int retain_first, uint64_t seed, uint32_t sweep,
                         uint32_t block, int64_t row_offset, int32_t* ancestors, double* logml_inc, double* ess) {

@@ -141,7 +141,8 @@ def _materialise_latent(lw, trace, pl, node, vals):
         if nodes[cn][0] == 1:
             values[j] = lw.option_values[(info[cn]["cls"], info[cn]["attr"])][vals[cn]]
         else:
-            values[j] = trace.tables[info[cn]["cls"]].cols[cc, child_row(cn)]
+            r = child_row(cn)  # may create the child row (and grow its table) first
+            values[j] = trace.tables[info[cn]["cls"]].cols[cc, r]
     for j, c in enumerate(layout):
         if c.kind == "fk" and "." not in c.name:
             for k in range(nodes[node][4], nodes[node][4] + nodes[node][5]):
@@ -200,18 +201,29 @@ def commit_latent(lw, trace, cname, live, chosen, vals):
     return changed
 
 
-def sub_batches(n, config, max_sub_batches):
-    """Row ranges of one class sweep between two parameter moves.  The reference resamples the class's
-    parameters and Pitman-Yor hyper-parameters every `rejuv_frequency` rows (inference.jl:72-77); the
-    batched schedule does it between sub-batches of max(rejuv_frequency, ceil(n / max_sub_batches)) rows —
-    exactly the reference's cadence whenever n / rejuv_frequency <= max_sub_batches."""
+def sub_batches(n, config, max_sub_batches, batch_rows=None):
+    """Row ranges of one class sweep, each swept against frozen tables and committed before the next.  The
+    reference resamples the class's parameters and Pitman-Yor hyper-parameters every `rejuv_frequency` rows
+    (inference.jl:72-77); the batched schedule does it between sub-batches of max(rejuv_frequency,
+    ceil(n / max_sub_batches)) rows — exactly the reference's cadence whenever n / rejuv_frequency <=
+    max_sub_batches.  batch_rows overrides the size: batch_rows=1 is the reference's SEQUENTIAL schedule (every
+    row sees the commits of all rows before it; parameters still move every rejuv_frequency rows)."""
     if n <= 0:
         return []
     size = max(int(config.rejuv_frequency), 1, -(-n // max(int(max_sub_batches), 1)))
+    if batch_rows:
+        size = max(int(batch_rows), 1)
     return [(b, min(b + size, n)) for b in range(0, n, size)]
 
 
-def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_sub_batches=32, verbose=False):
+def _crosses_rejuv(b0, b1, config):
+    """True when rows (b0, b1] contain a multiple of rejuv_frequency: time for a parameter move."""
+    rf = max(int(config.rejuv_frequency), 1)
+    return b1 // rf != b0 // rf
+
+
+def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_sub_batches=32, verbose=False,
+                 batch_rows=None):
     """One rejuvenation sweep of latent class cname.  With several ranks the live latent rows are
     block-partitioned: a rank scores its rows against their complete evidence sets (observations and
     trace are replicated), then (chosen particle, sampled values) are all-gathered and every rank
@@ -225,8 +237,10 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
         return 0
     t = trace.tables[cname]
     changed = 0
-    for bn, (b0, b1) in enumerate(sub_batches(len(live), config, max_sub_batches)):
-        if bn:  # inference.jl:72-77: this class's parameters and Pitman-Yor hyper-parameters
+    prev = 0
+    for bn, (b0, b1) in enumerate(sub_batches(len(live), config, max_sub_batches, batch_rows)):
+        if bn and _crosses_rejuv(prev, b0, config):  # inference.jl:72-77: this class's parameters and PY hyper-parameters
+            prev = b0
             resample_class_parameters(trace, cname)
             if verbose and (b0 // max(config.reporting_frequency, 1)) != ((b0 - 1) // max(config.reporting_frequency, 1)):
                 print(f"{cname}: Cleaning row {b0} of {len(live)}", flush=True)
@@ -268,14 +282,17 @@ def _gather_locals(trace, comm, begin, n_local, lo):
     trace.pending_locals = {}
 
 
-def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None, max_sub_batches=32, verbose=False):
+def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None, max_sub_batches=32, verbose=False,
+                   batch_rows=None):
     """One rejuvenation sweep of the observed class; the rows of every sub-batch are block-partitioned over
     the ranks, the class's parameters are resampled between sub-batches (inference.jl:72-77)."""
     comm = comm or Comm()
     n = trace.cur.shape[1]
     changed = 0
-    for bn, (b0, b1) in enumerate(sub_batches(n, config, max_sub_batches)):
-        if bn:
+    prev = 0
+    for bn, (b0, b1) in enumerate(sub_batches(n, config, max_sub_batches, batch_rows)):
+        if bn and _crosses_rejuv(prev, b0, config):
+            prev = b0
             resample_class_parameters(trace, engine.lw.query.cls)
             if verbose and (b0 // max(config.reporting_frequency, 1)) != ((b0 - 1) // max(config.reporting_frequency, 1)):
                 print(f"{engine.lw.query.cls}: Cleaning row {b0} of {n}", flush=True)
@@ -352,12 +369,12 @@ def initialize_trace(engine, trace, config, seed, max_batch=256, comm=None):
     return trace
 
 
-def run_inference(engine, trace, config, seed, verbose=False, comm=None, max_sub_batches=32):
+def run_inference(engine, trace, config, seed, verbose=False, comm=None, max_sub_batches=32, batch_rows=None):
     """run_inference! (inference.jl:83-88): config.num_iters sweeps over all classes.  `comm` shards
     every class sweep over the ranks of a torch.distributed job (one process per GPU).  A class sweep is
     cut into sub-batches between which the class's parameters are resampled (`sub_batches`): at most
     max_sub_batches per class, so tables with n / rejuv_frequency <= max_sub_batches follow the reference's
-    cadence exactly.  use_lo_sweeps is, as in the reference, only read by instrumented_inference.jl (out of
+    cadence exactly; batch_rows=1 is the reference's sequential schedule (sub_batches).  use_lo_sweeps is, as in the reference, only read by instrumented_inference.jl (out of
     scope): pgibbs_sweep! sweeps the latent classes regardless of it."""
     lw = engine.lw
     for it in range(config.num_iters):
@@ -365,9 +382,9 @@ def run_inference(engine, trace, config, seed, verbose=False, comm=None, max_sub
             print(f"Iteration {it + 1}/{config.num_iters}", flush=True)
         for cname in lw.model.class_order:
             if cname in lw.latent_plans:
-                ch = latent_sweep(engine, trace, cname, config, seed, it, comm, max_sub_batches, verbose)
+                ch = latent_sweep(engine, trace, cname, config, seed, it, comm, max_sub_batches, verbose, batch_rows)
             elif cname == lw.query.cls:
-                ch = observed_sweep(engine, trace, config, seed, it, comm, max_sub_batches, verbose)
+                ch = observed_sweep(engine, trace, config, seed, it, comm, max_sub_batches, verbose, batch_rows)
             else:
                 continue
             if verbose:

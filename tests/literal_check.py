@@ -1,0 +1,54 @@
+"""Shared by tests/test_literal_fixtures.py (C++ oracle, CPU) and tests/test_gpu_literal.py (HIP path): compares
+per-candidate scores of pclean_score_node-style scorers with the literal interpreter's fixtures
+(tests/golden/literal_scores.json, generator tests/golden/make_literal_fixtures.py)."""
+import json
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _content_key(lw, trace, cname, k):
+    """flattened values of latent row k as 'path=string|...' (path-sorted) — decoding only."""
+    t = trace.tables[cname]
+    flat = {}
+    for j, col in enumerate(lw.layout[cname]):
+        if col.kind == "val":
+            cls, attr = lw.model.resolve(cname, col.name)
+            flat[col.name] = lw.latent_dom[(cls, attr.name)].string(int(t.cols[j, k]))
+    return "|".join(f"{p}={flat[p]}" for p in sorted(flat))
+
+
+def check(S, score_node, rtol=1e-12):
+    """score_node(block, rows, ctxv, excl) -> (lse [n], scores [n][K+1]) for node 0 of the block."""
+    lw, tr = S["lw"], S["trace"]
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_scores.json")))
+    n_checked = 0
+    for r in fx["rows"]:
+        i = r["row"]
+        for bi, fb in enumerate(r["blocks"]):
+            blk = lw.blocks[bi]
+            cname = blk["root_class"]
+            t = tr.tables[cname]
+            ctxv = np.zeros((1, 2), dtype=np.int32)
+            for c, (sb, col) in enumerate(zip(blk.get("ctx_src_block", []), blk.get("ctx_src_col", []))):
+                src = tr.tables[lw.blocks[sb]["root_class"]]
+                ctxv[0, c] = src.cols[col, tr.cur[sb, i]]
+            lse, scores = score_node(bi, np.array([i], np.int32), ctxv, np.array([tr.cur[bi, i]], np.int32), t.n)
+            scores = np.asarray(scores).reshape(-1)
+            assert len(scores) == t.n + 1
+            seen = 0
+            for k in range(t.n):
+                key = _content_key(lw, tr, cname, k)
+                if key in fb["cands"]:
+                    want = fb["cands"][key]
+                    assert abs(scores[k] - want) <= rtol * max(1.0, abs(want)), (i, bi, key, scores[k], want)
+                    seen += 1
+                else:  # the literal trace deleted it (it lost its last reference) or it is a free slot
+                    assert scores[k] == -np.inf, (i, bi, key, scores[k])
+            assert seen == len(fb["cands"]), (i, bi, seen, len(fb["cands"]))
+            assert abs(scores[t.n] - fb["new"]) <= rtol * max(1.0, abs(fb["new"])), (i, bi, "new", scores[t.n], fb["new"])
+            assert abs(lse[0] - fb["lse"]) <= 1e-9 * max(1.0, abs(fb["lse"])), (i, bi, "lse", lse[0], fb["lse"])
+            n_checked += seen + 1
+    return n_checked

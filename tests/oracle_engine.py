@@ -12,9 +12,12 @@ from pclean_amd._lib import InferConfig
 
 
 class OracleEngine:
-    def __init__(self, oracle, lowered, obs):
+    def __init__(self, oracle, lowered, obs, cached=False):
+        """cached: keep ONE oracle World alive and refresh only what a commit can change (row window, latent tables,
+        parameter-dependent option priors) — what makes row-at-a-time (sequential-schedule) reference runs affordable."""
         self.oracle, self.lw, self.obs = oracle, lowered, np.ascontiguousarray(obs, dtype=np.int32)
         self._choice = None
+        self.cached, self._w, self._logp = cached, None, None
 
     def upload_trace(self, trace):
         pass  # worlds are rebuilt from the trace at every sweep
@@ -24,8 +27,33 @@ class OracleEngine:
                            config.rejuv_frequency, config.reporting_frequency)
 
     def _world(self, trace, lo, hi):
-        logp = helpers.option_logp_cpu(self.oracle, self.lw, trace)
-        return helpers.mirror_world(self.oracle, self.lw, np.ascontiguousarray(self.obs[:, lo:hi]), trace, None, 1, logp, row_lo=lo)
+        orc, lw = self.oracle, self.lw
+        win = np.ascontiguousarray(self.obs[:, lo:hi])
+        if not self.cached or self._w is None:
+            self._logp = helpers.option_logp_cpu(orc, lw, trace)
+            self._w = helpers.mirror_world(orc, lw, win, trace, None, 1, self._logp, row_lo=lo)
+            return self._w
+        from pclean_amd.model import ChooseProportionally
+        w = self._w
+        w.set_obs(win)
+        if getattr(lw, "xnum", None) is not None and lw.xnum.shape[0]:
+            w.set_numeric(lw.xnum[:, lo:hi])
+        for cname, t in trace.tables.items():
+            cols, counts = t.view()
+            full, m1, scal = orc.table_priors(counts, t.strength, t.discount)
+            w.set_table(lw.table_id[cname], np.ascontiguousarray(cols), counts, full, m1, scal)
+        for (cname, aname), dom in lw.latent_dom.items():
+            d = lw.model.classes[cname].attr(aname).dist
+            if isinstance(d, ChooseProportionally):
+                with np.errstate(divide="ignore"):
+                    lp = np.log(trace.params[(cname, d.param)].value)
+                self._logp[(cname, aname)] = lp
+                w.set_options(lw.option_id[(cname, aname)], lw.option_values[(cname, aname)], lp)
+        if lw.prob_spec is not None:
+            w.set_prob(trace.prob_table())
+        if getattr(lw, "gauss", None):
+            w.set_mean(0, trace.mean_param.value)
+        return w
 
     def sweep(self, trace, config, seed, sweep_idx, lo=0, hi=None, reuse_buffers=False, light=False):
         orc, lw = self.oracle, self.lw

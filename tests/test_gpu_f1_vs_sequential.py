@@ -1,0 +1,54 @@
+"""F1 of the batched GPU schedule against the SEQUENTIAL-schedule reference runs (the reference's own schedule:
+one row at a time, creation / garbage collection on the spot) committed in tests/golden/sequential_f1.json
+(generator: scripts/sequential_reference.py, CPU oracle engine).  Same programs, configurations, seeds and row
+shuffles on both sides; the RNG streams necessarily differ (different schedules), so the comparison is between the
+means over the seeds.  north_star: F1 within +-0.5 pt."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _gpu_f1(name, seed, iters, mh, particles, n_rows):
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from pclean_amd import experiments as ex
+    from pclean_amd.analysis import evaluate_accuracy
+    from pclean_amd.engine import Engine, InferenceConfig
+    from pclean_amd.inference import initialize_trace, run_inference
+    from pclean_amd.model import LoweredModel
+    from pclean_amd.trace import Trace
+    import sequential_reference as sr
+    dirty, clean, mk_model, mk_query = sr.program(name, n_rows)
+    (dirty, clean), _ = ex.shuffle_rows([dirty, clean], seed)
+    m = mk_model(ex.possibilities_of(dirty)) if name == "hospital" else mk_model(dirty)
+    lw = LoweredModel(m, mk_query(m), dirty)
+    obs = lw.encode_observations(dirty)
+    eng = Engine(lw, obs, dist_mode=1)
+    try:
+        tr = Trace(lw, obs.shape[1], seed)
+        cfg = InferenceConfig(iters, particles, use_mh_instead_of_pg=mh, rejuv_frequency=50 if name == "hospital" else 500)
+        initialize_trace(eng, tr, cfg, seed, max_batch=256 if name == "hospital" else 1024)
+        run_inference(eng, tr, cfg, seed)
+        tr.check_consistency()
+        return evaluate_accuracy(lw, tr, dirty, clean)["f1"]
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("name", ["hospital", "flights", "rents"])
+def test_batched_gpu_f1_matches_the_sequential_reference(name, capsys):
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "sequential_f1.json")))[name]
+    c = ref["config"]
+    seeds = sorted(int(s) for s in ref["runs"])
+    got = [_gpu_f1(name, sd, c["iters"], c["mh"], c["particles"], c["n_rows"]) for sd in seeds]
+    want = [ref["runs"][str(sd)]["f1"] for sd in seeds]
+    with capsys.disabled():
+        print(f"\n[f1 vs sequential] {name}: batched GPU {np.round(got, 4).tolist()} (mean {np.mean(got):.4f})  "
+              f"sequential reference {np.round(want, 4).tolist()} (mean {np.mean(want):.4f})")
+    assert abs(np.mean(got) - np.mean(want)) <= 0.005, (got, want)       # +-0.5 pt on the means
+    assert min(got) >= np.mean(want) - 0.01                              # and no seed more than 1 pt below the reference

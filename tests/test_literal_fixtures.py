@@ -1,0 +1,35 @@
+"""The C++ oracle (which consumes the product's lowering) against the LITERAL interpreter's fixtures (model
+description + strings only, oracle/literal.py): every candidate score of 14 hospital rows x 2 blocks to 1e-12 —
+a wrong plan, term-to-node assignment, ctx wiring, column map, pair table, fn table or option table in
+LoweredModel would show up here (VERDICT r1 weak #1b)."""
+import numpy as np
+
+import helpers
+import literal_check
+
+
+def test_cpp_oracle_reproduces_literal_scores(oracle):
+    S = helpers.hospital_setup()
+    lw, tr, obs = S["lw"], S["trace"], S["obs"]
+    w = helpers.mirror_world(oracle, lw, obs, tr, None, 1, helpers.option_logp_cpu(oracle, lw, tr))
+
+    def score_node(block, rows, ctxv, excl, n_rows):
+        lse, scores = w.eval_tree(block, 0, rows[0], ctxv[0], excl[0], n_rows + 1)
+        return [lse], scores
+
+    assert literal_check.check(S, score_node) > 1000
+
+
+def test_literal_densities_match_kats():
+    """The literal interpreter's own densities against SURVEY Appendix D's formula-derived values."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import literal as lit
+    assert abs(lit.add_typos_logpdf("abc", "abc") - (-0.105360515658)) < 1e-11
+    assert abs(lit.add_typos_logpdf("birminghxm", "birmingham") - (-5.751792305755)) < 1e-11
+    assert abs(lit.add_typos_logpdf("bxrmxngham", "birmingham") - (-11.580545652645)) < 1e-11
+    assert abs(lit.string_prior_logpdf("birmingham", 3, 30) - (-31.989617526969)) < 1e-10
+    assert lit.string_prior_logpdf("al", 3, 30) == -np.inf
+    assert abs(lit.string_prior_logpdf("2053258100", 10, 10) - (-33.322045101752)) < 1e-10
+    assert lit.damerau_levenshtein("ca", "abc") == 2 and lit.damerau_levenshtein("ca", "abc", restricted=True) == 3
