@@ -631,6 +631,7 @@ struct FastRoot {  // candidate-compact tables of a reference slot (root_wave.hi
   DevBuf<double> prior_e, prior_n;
   DevBuf<uint16_t> alive;
   int disabled = 0;  // > 0: the pre-filter does not pay for this node (most items overflowed): that many evaluations use the generic kernel
+  int backoff = 64;  // length of the next disabled period (doubles every time the retry overflows again)
   uint64_t prior_ver = 0;
   int kpad = 0;
   double logc_max = 0.0;  // max over candidates of log(count - discount)
@@ -1445,9 +1446,13 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   ctx->timing.reserved += (int32_t)n_over;  // items that fell back to the generic kernel
   if (time_it) ctx->root_stats.overflow_items = (int32_t)n_over;
   // short strings / flat posteriors: when a quarter of the items overflow the survivor list the integer pre-filter
-  // does not pay for this option list -> its next 64 evaluations go straight to the generic kernel, then it is retried
-  if (n.kind == PCLEAN_NODE_LEAF && il.n >= 1024 && (size_t)n_over * 4 > (size_t)il.n)
-    s->fast[block_id * 64 + node_id].disabled = 64;
+  // does not pay for this option list -> its next evaluations go straight to the generic kernel (64, then 128, 256, ...
+  // between retries)
+  if (n.kind == PCLEAN_NODE_LEAF && il.n >= 1024 && (size_t)n_over * 4 > (size_t)il.n) {
+    FastRoot& f = s->fast[block_id * 64 + node_id];
+    f.disabled = f.backoff;
+    f.backoff = std::min(f.backoff * 2, 1 << 20);
+  }
   if (n_over && getenv("PCLEAN_DEBUG_OVERFLOW"))
     fprintf(stderr, "[pclean] block %d node %d: %u of %d items re-run by the generic kernel\n", block_id, node_id, n_over,
             il.n);

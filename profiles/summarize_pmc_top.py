@@ -1,0 +1,83 @@
+"""Counter totals per KERNEL (top kernels by time) from rocprofv3 --pmc runs (rocpd sqlite output).
+
+    python profiles/summarize_pmc_top.py <results.db> [<results.db> ...] [--top N] [--json profiles/hbm_traffic.json]
+
+For every database (one --pmc pass each — FETCH_SIZE and WRITE_SIZE cannot share a pass on gfx950) prints, per kernel
+name, the number of dispatches, the average duration and the average value of each counter per dispatch.  FETCH_SIZE /
+WRITE_SIZE are KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half their size
+(/opt/skills/guides/MI355X_MICROARCH.md "HBM"), so HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (x 1024).
+--json merges {kernel, bytes_per_launch, ...} of the dominant sweep kernel (largest fk_root_wave_kernel) into the file
+bench.py echoes as roofline.traffic."""
+import json
+import re
+import sqlite3
+import sys
+
+
+def short(n):
+    n = re.sub(r"void rocprim::ROCPRIM_\d+_NS::detail::", "rp::", n)
+    n = re.sub(r"trampoline_kernel<rocprim::ROCPRIM_\d+_NS::detail::", "", n)
+    n = re.sub(r"\(.*", "", n)
+    return n[:60]
+
+
+def main():
+    args = [a for a in sys.argv[1:]]
+    top = int(args[args.index("--top") + 1]) if "--top" in args else 14
+    out_json = args[args.index("--json") + 1] if "--json" in args else None
+    dbs = [a for a in args if a.endswith(".db")]
+    merged = {}
+    for path in dbs:
+        db = sqlite3.connect(path)
+        cur = db.cursor()
+        tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+        kd = [t for t in tabs if "kernel_dispatch" in t][0]
+        ks = [t for t in tabs if "info_kernel_symbol" in t][0]
+        pe = [t for t in tabs if "pmc_event" in t][0]
+        pi = [t for t in tabs if "info_pmc" in t][0]
+        rows = cur.execute(f"select s.display_name, d.grid_size_x, d.end - d.start, d.event_id from {kd} d join {ks} s "
+                           f"on d.kernel_id = s.id").fetchall()
+        pmc = {}
+        for ev, cname, v in cur.execute(f"select e.event_id, p.name, sum(e.value) from {pe} e join {pi} p on e.pmc_id = p.id "
+                                        f"group by e.event_id, p.name"):
+            pmc.setdefault(ev, {})[cname] = v
+        for name, grid, dur, ev in rows:
+            k = short(name)
+            if "fk_root_wave_kernel" in k or "enum_node" in k:  # split by launch size class: root vs small lists
+                k += " [grid>=1M]" if grid >= 250000 else " [small]"
+            m = merged.setdefault(k, dict(n=0, dur=0.0, counters={}))
+            m["n"] += 1
+            m["dur"] += dur / 1e6
+            for cname, v in pmc.get(ev, {}).items():
+                c = m["counters"].setdefault(cname, [0, 0.0])
+                c[0] += 1
+                c[1] += v
+    names = sorted(merged, key=lambda k: -merged[k]["dur"])[:top]
+    print(f"{'kernel':72s} {'disp':>6s} {'avg_ms':>9s}  counters (average per dispatch)")
+    for k in names:
+        m = merged[k]
+        cs = "  ".join(f"{c}={v[1] / max(v[0], 1):.4g}" for c, v in sorted(m["counters"].items()))
+        print(f"{k:72s} {m['n']:6d} {m['dur'] / m['n']:9.3f}  {cs}")
+        c = m["counters"]
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            b = (2 * c["FETCH_SIZE"][1] / c["FETCH_SIZE"][0] + c["WRITE_SIZE"][1] / c["WRITE_SIZE"][0]) * 1024
+            dur = m["dur"] / m["n"]
+            print(f"{'':72s}        -> HBM bytes per launch {b / 1e9:.3f} GB, {b / 1e9 / (dur / 1e3) / 1e3:.2f} TB/s of 8 TB/s")
+        if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"][1] > 0:
+            wc = c["SQ_WAVE_CYCLES"][1]
+            parts = [f"{n2}/SQ_WAVE_CYCLES={c[n2][1] / wc:.2f}" for n2 in ("SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY") if n2 in c]
+            print(f"{'':72s}        -> " + ", ".join(parts))
+    if out_json:
+        key = next((k for k in names if "fk_root_wave_kernel<12>" in k and "grid>=1M" in k), None)
+        if key and "FETCH_SIZE" in merged[key]["counters"] and "WRITE_SIZE" in merged[key]["counters"]:
+            c = merged[key]["counters"]
+            b = (2 * c["FETCH_SIZE"][1] / c["FETCH_SIZE"][0] + c["WRITE_SIZE"][1] / c["WRITE_SIZE"][0]) * 1024
+            data = dict(kernel="fk_root_wave_kernel", bytes_per_launch=b, rows=1000000, hospitals=10000, particles=20,
+                        fetch_kib=c["FETCH_SIZE"][1] / c["FETCH_SIZE"][0], write_kib=c["WRITE_SIZE"][1] / c["WRITE_SIZE"][0],
+                        source="profiles/r02_pmc_top_kernels.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, "
+                               "2 x FETCH_SIZE + WRITE_SIZE, KiB)")
+            json.dump(data, open(out_json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,6 @@ def test_flights_end_to_end():
         tr.check_consistency()
         acc = evaluate_accuracy(lw, tr, dirty, clean)
         assert acc["errors"] == 2608 and acc["imputed"] == 2312
-        assert acc["f1"] > 0.75
+        assert acc["f1"] > 0.875  # 0.89; sequential reference 0.890 (tests/golden/sequential_f1.json)
     finally:
         eng.close()

@@ -72,7 +72,9 @@ def test_hospital_end_to_end(oracle):
         acc = evaluate_accuracy(lw, tr, S["dirty"], S["clean"])
         assert acc["errors"] == 509
         assert acc["f1"] > f0["f1"]            # rejuvenation repairs what the one-pass initialisation left
-        assert acc["precision"] > 0.95 and acc["f1"] > 0.8
+        # rows in FILE order (sorted by hospital): the worst case of the batched initialisation, F1 0.890;
+        # in random order 0.904 against the sequential reference's 0.905 (tests/test_gpu_f1_vs_sequential.py)
+        assert acc["precision"] > 0.95 and acc["f1"] > 0.88
         # clusters consolidate towards the 45 true hospitals
         assert tr.tables["Hospital"].n_live < 150
         # deterministic given the seeds

@@ -109,7 +109,7 @@ def test_rents_end_to_end():
         tr.check_consistency()
         acc = evaluate_accuracy(lw, tr, dirty, clean)
         assert acc["imputed"] > 1000 and acc["correctly_imputed"] > 0.4 * acc["imputed"]
-        assert acc["f1"] > 0.45
+        assert acc["f1"] > 0.60  # 8000 of the 50 000 rows; the full table (F1 0.689 vs sequential 0.687) is tests/test_gpu_f1_vs_sequential.py
         # the /1000 unit errors get repaired: corrected rents equal the clean rent for most damaged cells
         dn = np.array([float(v) for v in dirty["Monthly Rent"]])
         cn = np.array([float(v) for v in clean["Monthly Rent"]])
