@@ -869,7 +869,7 @@ static int build_node_dev(pclean_ctx* ctx, const Block& b, int node_id, NodeDev&
     if (tm.obs_col < 0 || tm.obs_col >= ctx->n_cols || tm.cand_col < 0 || tm.cand_col >= t.n_cols)
       return pclean_fail(ctx, PCLEAN_ERR_ARG, "term %d: column out of range", n.term_begin + i);
     TermDev& td = nd.terms[i];
-    td.obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
+    td.obs_col = ctx->obs_override ? ctx->obs_override : ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
     td.ctx_mode = tm.ctx_mode;
     td.pad = 0;
     td.cand_col = t.cols.p + (size_t)tm.cand_col * t.n_rows;
@@ -903,6 +903,10 @@ static int build_node_dev(pclean_ctx* ctx, const Block& b, int node_id, NodeDev&
   return PCLEAN_OK;
 }
 
+struct ItemList;
+static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
+                     uint64_t seed, uint32_t sweep, int n_draws, double* lse_out, int32_t* draws_out,
+                     double* scores_out, const double* snew_override, bool time_it);
 // Per-unique-observed-value marginal of a cacheable leaf (one term, no ctx):
 // cache[u] for u < n_obs, cache[n_obs] for a missing observation.
 static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const double** out, const int32_t** obs_col,
@@ -927,13 +931,13 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
   auto itv = s->leaf_version.find(key);
   if (itv == s->leaf_version.end() || itv->second != ver || cache.n < (size_t)U + 1) {
     if (cache.alloc(U + 1)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "alloc");
-    NodeDev nd;
-    int rc = build_node_dev(ctx, b, node_id, nd);
-    if (rc) return rc;
-    nd.terms[0].obs_col = io.p;  // item t observes value t (or missing for t == U)
-    ItemsDev it{U + 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    ChildrenDev ch{};
-    rc = pclean_launch_enum(ctx, nd, it, ch, 0, 0, 0, 0, cache.p, nullptr, nullptr);
+    // item t observes value t (or a missing value for t == U): the usual evaluation path (compact-table wave kernel
+    // for long strings, generic kernel otherwise) with the observed column replaced by the identity column
+    ProfScope ps(ctx, "leaf_cache_rebuild");
+    ItemList il{U + 1, nullptr, nullptr, nullptr, nullptr};
+    ctx->obs_override = io.p;
+    int rc = eval_node(ctx, block_id, node_id, il, nullptr, 0, 0, 0, cache.p, nullptr, nullptr, nullptr, false);
+    ctx->obs_override = nullptr;
     if (rc) return rc;
     s->leaf_version[key] = ver;
   }
@@ -995,7 +999,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     const pclean_term& tm = b.terms[n.term_begin + i];
     const PairTable& pt = ctx->pair[tm.pair_table];
     fr.terms[i] = FastTermDev{};
-    fr.terms[i].obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
+    fr.terms[i].obs_col = ctx->obs_override ? ctx->obs_override : ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
     fr.terms[i].max_typos = tm.max_typos;
     fr.terms[i].ctx_slot = tm.ctx_slot;
     if (tm.ctx_slot >= 0) {  // scored by gathering (few survivors reach it)

@@ -22,4 +22,12 @@ timeout 1200 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAI
   -d "$OUT/pmc_SQ" -- python "$ROOT/bench.py" $ARGS > "$OUT/bench_SQ.json" 2> "$OUT/bench_SQ.log"
 echo "SQ rc=$?"
 cd "$ROOT"
-find "$OUT" -name "*.db" | xargs ls -la
+# summaries on the box (the databases are too large to travel back), then drop the databases
+T=$(find "$OUT/trace" -name "*.db" | head -1)
+python profiles/summarize_rocpd.py "$T" "$OUT/kernel_trace.txt" > /dev/null
+python profiles/timeline.py "$T" 15 1 > "$OUT/sweep_timeline.txt" 2>&1
+python profiles/summarize_pmc_top.py $(find "$OUT"/pmc_* -name "*.db") --top 16 --json "$OUT/hbm_traffic.json" > "$OUT/pmc_top_kernels.txt" 2>&1
+find "$OUT" -name "*.db" -delete
+tail -n 3 "$OUT/bench_trace.log"
+tail -c 600 "$OUT/bench_trace.json"
+ls -la "$OUT"

@@ -41,10 +41,15 @@ def main():
         for ev, cname, v in cur.execute(f"select e.event_id, p.name, sum(e.value) from {pe} e join {pi} p on e.pmc_id = p.id "
                                         f"group by e.event_id, p.name"):
             pmc.setdefault(ev, {})[cname] = v
+        longest = {}
+        for name, grid, dur, ev in rows:
+            longest[short(name)] = max(longest.get(short(name), 0), dur)
         for name, grid, dur, ev in rows:
             k = short(name)
-            if "fk_root_wave_kernel" in k or "enum_node" in k:  # split by launch size class: root vs small lists
-                k += " [grid>=1M]" if grid >= 250000 else " [small]"
+            # the sweep kernels run on lists of every size (initialisation batches, nested slots, ...): the launches
+            # within a factor 2 of the kernel's longest launch are its full-size launches, the rest is "[small]"
+            if any(t in k for t in ("fk_root_wave_kernel", "enum_node", "ev_leaf_wave", "group_desc", "gate_new", "particle_update")):
+                k += " [full-size]" if dur * 2 >= longest[k] else " [small]"
             m = merged.setdefault(k, dict(n=0, dur=0.0, counters={}))
             m["n"] += 1
             m["dur"] += dur / 1e6
@@ -68,7 +73,7 @@ def main():
             parts = [f"{n2}/SQ_WAVE_CYCLES={c[n2][1] / wc:.2f}" for n2 in ("SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY") if n2 in c]
             print(f"{'':72s}        -> " + ", ".join(parts))
     if out_json:
-        key = next((k for k in names if "fk_root_wave_kernel<12>" in k and "grid>=1M" in k), None)
+        key = next((k for k in merged if "fk_root_wave_kernel<12>" in k and "full-size" in k), None)
         if key and "FETCH_SIZE" in merged[key]["counters"] and "WRITE_SIZE" in merged[key]["counters"]:
             c = merged[key]["counters"]
             b = (2 * c["FETCH_SIZE"][1] / c["FETCH_SIZE"][0] + c["WRITE_SIZE"][1] / c["WRITE_SIZE"][0]) * 1024
