@@ -217,6 +217,8 @@ def main():
     # initialisation need every referring row; the observed-class sweep is sharded by rows
     eng = Engine(lw, obs, device=local_rank, dist_mode=_lib.DIST_OSA)
     static_s = time.time() - t0
+    if comm.dist is not None:  # the library's own RCCL communicator: fused device-side all-reduce of the CRP statistics
+        eng.init_device_comm(comm)
     log(f"[bench] rank {rank}: pair tables {eng.pair_build_s:.1f}s ({len(lw.pair_id)} tables, {eng.pair_count / 1e9:.2f} G pairs, "
         f"{eng.pair_cells / 1e12:.2f} T DP cells), static upload total {static_s:.1f}s")
 

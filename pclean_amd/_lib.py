@@ -457,6 +457,15 @@ class HipContext:
               "pclean_allreduce_stats")
         return out
 
+    def allreduce_stats_fused(self, table_ids, n_rows, local_is_zero=False):
+        """One RCCL all-reduce of the concatenated delta counts of `table_ids`; returns the list of summed vectors."""
+        ids = np.ascontiguousarray(table_ids, dtype=np.int32)
+        out = np.zeros(int(sum(n_rows)), dtype=np.int64)
+        check(self.h, self.lib.pclean_allreduce_stats_fused(self.h, C.c_int32(len(ids)), _p(ids, C.c_int32),
+                                                            C.c_int32(int(local_is_zero)), _p(out, C.c_int64)),
+              "pclean_allreduce_stats_fused")
+        return np.split(out, np.cumsum(n_rows)[:-1])
+
     def comm_destroy(self):
         check(self.h, self.lib.pclean_comm_destroy(self.h), "pclean_comm_destroy")
 

@@ -34,6 +34,7 @@ extern "C" int pclean_ctx_destroy(pclean_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   (void)pclean_comm_destroy(ctx);
   pclean_sweep_state_free(ctx);
+  ctx->stats_pack.release();
   ctx->sym.release();
   ctx->off.release();
   ctx->obs.release();

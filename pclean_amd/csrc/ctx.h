@@ -149,6 +149,7 @@ struct pclean_ctx {
   bool force_generic = false;  // debug: never take the compact-table root kernel
   void* sweep_state = nullptr;  // owned by sweep.hip
   void* rccl_comm = nullptr;    // ncclComm_t of pclean_comm_init (comm.hip)
+  DevBuf<int64_t> stats_pack;   // pclean_allreduce_stats_fused: the tables' delta counts as one vector
   int32_t comm_ranks = 0;
 };
 

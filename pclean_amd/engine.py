@@ -242,6 +242,35 @@ class Engine:
         return self.hip.sweep_latent(cfg, seed, sweep_idx, pl["block_id"], pl["roots"], live, ev_off, ev_rows, ev_ctx,
                                      excl, len(pl["nodes"]))
 
+    def init_device_comm(self, comm):
+        """Bind the library's own RCCL communicator to the ranks of `comm` (parallel.Comm over torch.distributed):
+        rank 0's rendezvous id travels through torch's object broadcast.  Afterwards sweep_stats_reduced sums the
+        delta reference counts on the device with ONE all-reduce over xGMI.  Returns False (and the torch path stays
+        in use) when RCCL cannot be bound."""
+        self._dev_comm = False
+        if comm.dist is None:
+            return False
+        try:
+            box = [self.hip.comm_unique_id() if comm.rank == 0 else None]
+            comm.dist.broadcast_object_list(box, src=0)
+            self.hip.comm_init(comm.world, comm.rank, box[0])
+            self._dev_comm = True
+        except Exception as e:  # noqa: BLE001 — any failure: keep the torch.distributed exchange
+            import sys
+            print(f"[pclean] device-side RCCL exchange unavailable ({e}); using torch.distributed", file=sys.stderr)
+        return self._dev_comm
+
+    def sweep_stats_reduced(self, trace):
+        """Delta reference counts of the last sweep summed over ALL ranks, per block root table — one fused RCCL
+        all-reduce of the device-resident buffers (pclean_allreduce_stats_fused); None without init_device_comm."""
+        if not getattr(self, "_dev_comm", False):
+            return None
+        blocks = [bi for bi, blk in enumerate(self.lw.blocks) if not blk.get("score")]
+        tids = [self.lw.table_id[self.lw.blocks[bi]["root_class"]] for bi in blocks]
+        ns = [trace.tables[self.lw.blocks[bi]["root_class"]].n for bi in blocks]
+        # a rank that swept nothing contributes zeros (its device buffers hold stale counts)
+        return dict(zip(blocks, self.hip.allreduce_stats_fused(tids, ns, getattr(self, "_empty_sweep", False))))
+
     def sweep_stats(self, trace):
         """Delta reference counts of the last sweep per block root table (the all-reduce payload)."""
         if getattr(self, "_empty_sweep", False):

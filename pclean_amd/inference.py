@@ -305,12 +305,15 @@ def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None, max_sub_ba
             choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi, reuse_buffers=True,
                                                            **({"light": True} if light else {}))
         with _timed("observed/stats_moved"):
-            stats = engine.sweep_stats(trace)
+            stats = engine.sweep_stats_reduced(trace) if hasattr(engine, "sweep_stats_reduced") else None
+            reduced = stats is not None  # summed over the ranks on the device (one RCCL all-reduce over xGMI)
+            if not reduced:
+                stats = engine.sweep_stats(trace)
             moved = engine.sweep_moved() if light else None
             _gather_locals(trace, comm, b0, hi - lo, lo)
         with _timed("observed/exchange_commit"):
             changed += exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True,
-                                           moved_local=moved, n_local=hi - lo)
+                                           moved_local=moved, n_local=hi - lo, stats_reduced=reduced)
     return changed
 
 

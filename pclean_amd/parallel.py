@@ -88,7 +88,7 @@ class Comm:
 
 
 def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local, new_rows_local, global_cur=False,
-                        moved_local=None, n_local=None):
+                        moved_local=None, n_local=None, stats_reduced=False):
     """Apply one sweep's result to the replicated trace.
 
     choice_local [n_blocks][n_local]: chosen referents of this rank's rows;
@@ -101,6 +101,7 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
     moved_local {block: (local rows ascending, new referent)} (pclean_get_moved): when given, only those rows
     are touched and choice_local is not scanned (it may be None if n_local is given).
 
+    stats_reduced: stats_local is already summed over the ranks on the device (Engine.sweep_stats_reduced).
     Exactly three collectives per sweep, whatever the number of blocks: ONE all-reduce(sum) of the
     concatenated int64 delta-count vectors (+ the moved-row counter) and ONE variable-length
     all-gather (sizes + payload) of the new-row records and moved rows of all blocks.
@@ -133,7 +134,11 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
             msg += [np.array([len(moved)], np.int32), moved + row_lo, ch_m]
     red.append(np.array([n_changed], dtype=np.int64))
     # ---- the exchange ------------------------------------------------------------------------------
-    total = comm.allreduce_sum_i64(np.concatenate(red))
+    if stats_reduced:  # stats_local already holds the sums over all ranks (Engine.sweep_stats_reduced: one RCCL
+        total = np.concatenate(red)  # all-reduce of the device-resident buffers); only the moved-row counter is local
+        total[-1] = int(comm.allreduce_sum_i64(np.array([n_changed], dtype=np.int64))[0]) if comm.world > 1 else n_changed
+    else:
+        total = comm.allreduce_sum_i64(np.concatenate(red))
     parts = comm.allgather_list_i32(np.concatenate(msg))
     # ---- identical commit on every rank ------------------------------------------------------------
     cursor = [0] * len(parts)

@@ -31,6 +31,14 @@ for cname in ("Hospital", "Measure"):
     before = eng.hip.get_stats(tid, n)
     after = eng.hip.allreduce_stats(tid, n)
     assert np.array_equal(before, after) and np.array_equal(eng.hip.get_stats(tid, n), before)
+tids = [lw.table_id["Hospital"], lw.table_id["Measure"]]
+ns = [tr.tables["Hospital"].n, tr.tables["Measure"].n]
+want = [eng.hip.get_stats(t, n) for t, n in zip(tids, ns)]
+got = eng.hip.allreduce_stats_fused(tids, ns)
+assert all(np.array_equal(a, b) for a, b in zip(got, want))
+assert all(np.array_equal(eng.hip.get_stats(t, n), b) for t, n, b in zip(tids, ns, want))
+zero = eng.hip.allreduce_stats_fused(tids, ns, local_is_zero=True)
+assert all(not z.any() for z in zero)
 eng.hip.comm_destroy()
 eng.hip.comm_destroy()
 eng.close()
