@@ -75,6 +75,21 @@ class Comm:
         self.dist.all_gather(outs, buf)
         return [o[:k].cpu().numpy() for o, k in zip(outs, sizes)]
 
+    def allgather_known_i32(self, arr, sizes):
+        """[rank 0's vector, rank 1's vector, ...] when every rank already knows all sizes: ONE collective
+        (all_gather_into_tensor of chunks padded to the largest size) and one device-to-host copy."""
+        arr = np.ascontiguousarray(arr, dtype=np.int32).reshape(-1)
+        if not self.dist:
+            return [arr]
+        m = max(int(max(sizes)), 1)
+        buf = self.torch.zeros(m, dtype=self.torch.int32, device=self.device)
+        if arr.size:
+            buf[:arr.size] = self.torch.from_numpy(arr).to(self.device)
+        out = self.torch.empty(m * self.world, dtype=self.torch.int32, device=self.device)
+        self.dist.all_gather_into_tensor(out, buf)
+        host = out.cpu().numpy().reshape(self.world, m)
+        return [host[r, :int(k)] for r, k in enumerate(sizes)]
+
     def barrier(self):
         if self.dist:
             self.dist.barrier()
@@ -102,9 +117,9 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
     are touched and choice_local is not scanned (it may be None if n_local is given).
 
     stats_reduced: stats_local is already summed over the ranks on the device (Engine.sweep_stats_reduced).
-    Exactly three collectives per sweep, whatever the number of blocks: ONE all-reduce(sum) of the
-    concatenated int64 delta-count vectors (+ the moved-row counter) and ONE variable-length
-    all-gather (sizes + payload) of the new-row records and moved rows of all blocks.
+    Two collectives per sweep, whatever the number of blocks: ONE all-reduce(sum) of the concatenated int64
+    delta-count vectors + the moved-row counter + the per-rank message sizes, and ONE all-gather of the new-row
+    records and moved rows of all blocks.
     Returns the global number of rows whose referent changed."""
     blocks = [bi for bi, blk in enumerate(lowered.blocks) if not blk.get("score")]
     if n_local is None:
@@ -134,12 +149,21 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
             msg += [np.array([len(moved)], np.int32), moved + row_lo, ch_m]
     red.append(np.array([n_changed], dtype=np.int64))
     # ---- the exchange ------------------------------------------------------------------------------
+    # The message sizes ride along in the all-reduce (every rank adds its size at its own index), so the
+    # variable-length all-gather needs no size exchange of its own: TWO collectives per sweep (plus the fused
+    # device-side all-reduce of the statistics when stats_reduced).
+    msg = np.concatenate(msg)
+    sizes = np.zeros(comm.world, dtype=np.int64)
+    sizes[comm.rank] = msg.size
     if stats_reduced:  # stats_local already holds the sums over all ranks (Engine.sweep_stats_reduced: one RCCL
-        total = np.concatenate(red)  # all-reduce of the device-resident buffers); only the moved-row counter is local
-        total[-1] = int(comm.allreduce_sum_i64(np.array([n_changed], dtype=np.int64))[0]) if comm.world > 1 else n_changed
+        total = np.concatenate(red)  # all-reduce of the device-resident buffers); only counter and sizes are local
+        small = comm.allreduce_sum_i64(np.concatenate([[n_changed], sizes]))
+        total[-1] = small[0]
+        sizes = small[1:]
     else:
-        total = comm.allreduce_sum_i64(np.concatenate(red))
-    parts = comm.allgather_list_i32(np.concatenate(msg))
+        both = comm.allreduce_sum_i64(np.concatenate(red + [sizes]))
+        total, sizes = both[:-comm.world], both[-comm.world:]
+    parts = comm.allgather_known_i32(msg, sizes)
     # ---- identical commit on every rank ------------------------------------------------------------
     cursor = [0] * len(parts)
     off = 0
