@@ -214,6 +214,19 @@ __global__ __launch_bounds__(256) void particle_update_kernel(int N, int P, cons
   }
 }
 
+// rows whose CHOSEN particle proposed a NEW referent: slot list + positions (deferred new-row sampling of the last block)
+__global__ void chosen_new_kernel(int N, const int32_t* __restrict__ chosen, const int32_t* __restrict__ pchoice,
+                                  unsigned int* __restrict__ counter, int32_t* __restrict__ list,
+                                  int32_t* __restrict__ pnewpos) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const size_t s = (size_t)chosen[i] * N + i;
+  if (pchoice[s] != PCLEAN_CHOICE_NEW) return;
+  const unsigned int pos = atomicAdd(counter, 1u);
+  list[pos] = (int32_t)s;
+  pnewpos[s] = (int32_t)pos;
+}
+
 // ---- pure scoring block (flights Obs block 3): p += logdensity(MaybeSwap, ...) ---------------------
 struct SrcDev {
   const int32_t* pchoice;
@@ -503,23 +516,43 @@ __global__ void final_choice_kernel(int n_rows, int P, const double* logw, size_
   } while (0)
 
 // per block after the final choice: the chosen particle's referent, its new-row record, the delta reference
-// counts (the all-reduce payload) and the flags of moved rows / rows with a new referent
-__global__ void finalize_block_kernel(int n_rows, const int32_t* chosen, const int32_t* pchoice, const int32_t* pnewpos,
-                                      const int32_t* cur_b, int32_t* choice, int32_t* chosen_newpos,
-                                      unsigned long long* stats, int32_t* moved_flag, int32_t* new_flag) {
+// counts (the all-reduce payload) and the flags of moved rows / rows with a new referent.  Tables with few rows
+// (hist_rows > 0: a handful of very popular referents, e.g. 28 measures for 1M records) accumulate the deltas in an
+// LDS histogram per workgroup first — thousands of global atomics on the same few addresses would serialise.
+__global__ __launch_bounds__(256) void finalize_block_kernel(int n_rows, const int32_t* chosen, const int32_t* pchoice,
+                                                             const int32_t* pnewpos, const int32_t* cur_b,
+                                                             int32_t* choice, int32_t* chosen_newpos,
+                                                             unsigned long long* stats, int hist_rows,
+                                                             int32_t* moved_flag, int32_t* new_flag) {
+  extern __shared__ int32_t hist[];
+  for (int k = threadIdx.x; k < hist_rows; k += 256) hist[k] = 0;
+  if (hist_rows) __syncthreads();
   int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rows) return;
-  const size_t s = (size_t)chosen[i] * n_rows + i;
-  const int c = pchoice[s];
-  const int o = cur_b[i];
-  choice[i] = c;
-  const int np = c == PCLEAN_CHOICE_NEW ? pnewpos[s] : -1;
-  chosen_newpos[i] = np;
-  new_flag[i] = np >= 0 ? 1 : 0;
-  moved_flag[i] = c != o ? 1 : 0;
-  if (o != c) {
-    if (o >= 0) atomicAdd(&stats[o], (unsigned long long)(-1ll));
-    if (c >= 0) atomicAdd(&stats[c], 1ull);
+  if (i < n_rows) {
+    const size_t s = (size_t)chosen[i] * n_rows + i;
+    const int c = pchoice[s];
+    const int o = cur_b[i];
+    choice[i] = c;
+    const int np = c == PCLEAN_CHOICE_NEW ? pnewpos[s] : -1;
+    chosen_newpos[i] = np;
+    new_flag[i] = np >= 0 ? 1 : 0;
+    moved_flag[i] = c != o ? 1 : 0;
+    if (o != c) {
+      if (hist_rows) {
+        if (o >= 0) atomicAdd(&hist[o], -1);
+        if (c >= 0) atomicAdd(&hist[c], 1);
+      } else {
+        if (o >= 0) atomicAdd(&stats[o], (unsigned long long)(-1ll));
+        if (c >= 0) atomicAdd(&stats[c], 1ull);
+      }
+    }
+  }
+  if (hist_rows) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < hist_rows; k += 256) {
+      const int v = hist[k];
+      if (v) atomicAdd(&stats[k], (unsigned long long)(long long)v);
+    }
   }
 }
 
@@ -618,7 +651,8 @@ struct BlockRun {  // per-block device state of one sweep
   DevBuf<int32_t> pchoice, pnewpos, draws, it_ctx, choice, chosen_newpos, vals, locals, moved_flag, new_flag, moved_list,
       new_list, new_slots;
   DevBuf<double> lse;
-  int n_new = 0;  // rows of vals
+  int n_new = 0;  // particles of the block that proposed a NEW referent
+  bool lazy_new = false;  // their contents are sampled after the final choice, for the chosen particles only
   DevBuf<int32_t> plan_kind, plan_nrows, plan_cmb, plan_colmap;
   DevBuf<const int32_t*> plan_cols;
   PlanDev plan{};
@@ -632,6 +666,8 @@ struct FastRoot {  // candidate-compact tables of a reference slot (root_wave.hi
   DevBuf<uint16_t> alive;
   int disabled = 0;  // > 0: the pre-filter does not pay for this node (most items overflowed): that many evaluations use the generic kernel
   int backoff = 64;  // length of the next disabled period (doubles every time the retry overflows again)
+  uint64_t cmin_key = 0;  // (lmax, dmax, density-table stride) the cached c_min belongs to
+  double cmin = 0.0;
   uint64_t prior_ver = 0;
   int kpad = 0;
   double logc_max = 0.0;  // max over candidates of log(count - discount)
@@ -1049,16 +1085,22 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     for (int i = 0; i < n.n_terms; ++i) n_compact += b.terms[n.term_begin + i].ctx_slot < 0 ? 1 : 0;
     fr.n_pre = std::min(3, n_compact);
     for (int p = 0; p < 3; ++p) fr.pre[p] = p < fr.n_pre ? order[p] : 0;
-    double cmin = INFINITY;
     const int stride = ctx->max_d + 1;
-    for (int L = 1; L <= lmax; ++L)
-      for (int d = 1; d <= dmax; ++d) {
-        const int r = (L + 4) / 5;
-        double l = ctx->h_nb[(size_t)r * stride + d];
-        l -= ctx->h_logl[L] * (double)d;
-        l -= 1.629048269010741 * (double)d;
-        if (l == l) cmin = std::min(cmin, -l / (double)d);
-      }
+    const uint64_t ckey = ((uint64_t)lmax << 40) | ((uint64_t)dmax << 20) | (uint64_t)stride;
+    if (f.cmin_key != ckey) {  // ~lmax x dmax host iterations: once per (table shape), not per launch
+      double cm = INFINITY;
+      for (int L = 1; L <= lmax; ++L)
+        for (int d = 1; d <= dmax; ++d) {
+          const int r = (L + 4) / 5;
+          double l = ctx->h_nb[(size_t)r * stride + d];
+          l -= ctx->h_logl[L] * (double)d;
+          l -= 1.629048269010741 * (double)d;
+          if (l == l) cm = std::min(cm, -l / (double)d);
+        }
+      f.cmin = cm;
+      f.cmin_key = ckey;
+    }
+    const double cmin = f.cmin;
     if (!(cmin > 1e-6) || !std::isfinite(cmin)) {
       fr.n_pre = 0;  // no usable bound: evaluate every candidate exactly
       fr.inv_c = 0.0;
@@ -2336,6 +2378,13 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     HIPCHK(ctx, hipMemcpyAsync(&n_new, s->counter.p, sizeof n_new, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     r.n_new = (int)n_new;
+    // The contents of a proposed new row matter (a) as context / scored values of LATER blocks — every particle's —
+    // and (b) for the particle that is finally chosen.  For the last block only (b) is left: its sampling is
+    // deferred until after the final choice and done for the chosen particles alone (same Philox counters, so
+    // the values are the ones eager sampling would have produced; typically 20x fewer items).
+    static const bool eager_all = getenv("PCLEAN_EAGER_NEW") != nullptr;
+    r.lazy_new = bi == n_blocks - 1 && !eager_all;
+    if (r.lazy_new) n_new = 0;  // nothing sampled now
     if (r.vals.alloc(std::max<size_t>((size_t)n_new * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
     if (n_new) {
       ProfScope ps(ctx, "new_row_sampling");
@@ -2387,6 +2436,36 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
                                         (size_t)1, (size_t)N, use_mh, 1, s->cur.p, seed, sweep_idx,
                                         s->row_offset + ctx->active_begin, s->chosen.p, (double*)nullptr,
                                         s->logml_acc.p, s->logml.p));
+    for (int bi = 0; bi < n_blocks; ++bi) {  // deferred new-row contents of the last block (chosen particles only)
+      BlockRun& r = s->run[bi];
+      Block& bb = ctx->block[bi];
+      if (bb.is_score || !r.lazy_new || r.n_new == 0) continue;
+      ProfScope ps2(ctx, "new_row_sampling_chosen");
+      const int nn = (int)bb.nodes.size();
+      const int32_t* cur_b = s->cur.p + (size_t)bi * N;
+      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+      hipLaunchKernelGGL(chosen_new_kernel, grid1(N), dim3(256), 0, ctx->stream, N, s->chosen.p, r.pchoice.p, s->counter.p,
+                         r.new_slots.p, r.pnewpos.p);
+      unsigned int cnt = 0;
+      HIPCHK(ctx, hipMemcpyAsync(&cnt, s->counter.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (r.vals.alloc(std::max<size_t>((size_t)cnt * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+      if (!cnt) continue;
+      hipLaunchKernelGGL(fill_i32_kernel, grid1((size_t)cnt * nn), dim3(256), 0, ctx->stream, r.vals.p, (size_t)cnt * nn, -2);
+      int32_t* row = scratch<int32_t>(ctx, cnt);
+      int32_t* cx = scratch<int32_t>(ctx, (size_t)cnt * PCLEAN_MAX_CTX);
+      int32_t* part = scratch<int32_t>(ctx, cnt);
+      int32_t* org = scratch<int32_t>(ctx, cnt);
+      int32_t* ex = scratch<int32_t>(ctx, cnt);
+      if (!row || !cx || !part || !org || !ex) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      hipLaunchKernelGGL(rootlist_items_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, N, NP, r.new_slots.p,
+                         bb.n_ctx > 0 ? r.it_ctx.p : nullptr, cur_b, row, cx, part, org, ex);
+      hipLaunchKernelGGL(set_col_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, nn, 0, (int32_t)PCLEAN_CHOICE_NEW,
+                         r.vals.p);
+      ItemList sub{(int)cnt, row, cx, part, org};
+      int rc = sample_children(ctx, bi, 0, sub, ex, seed, sweep_idx, r.vals.p, nn);
+      if (rc) return rc;
+    }
     size_t tmp_sel = 0;
     HIPCHK(ctx, hipcub::DeviceSelect::Flagged(nullptr, tmp_sel, hipcub::CountingInputIterator<int32_t>(0),
                                               (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, N,
@@ -2401,9 +2480,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       const int32_t* cur_b = s->cur.p + (size_t)bi * N;
       CandTable& rt = ctx->cand[bb.nodes[0].table];
       HIPCHK(ctx, hipMemsetAsync(rt.stats.p, 0, (size_t)std::max(rt.n_rows, 1) * 8, ctx->stream));
-      hipLaunchKernelGGL(finalize_block_kernel, grid1(N), dim3(256), 0, ctx->stream, N, s->chosen.p, r.pchoice.p,
-                         r.pnewpos.p, cur_b, r.choice.p, r.chosen_newpos.p, (unsigned long long*)rt.stats.p,
-                         r.moved_flag.p, r.new_flag.p);
+      const int hist_rows = rt.n_rows <= 8192 ? rt.n_rows : 0;
+      hipLaunchKernelGGL(finalize_block_kernel, grid1(N), dim3(256), (size_t)hist_rows * sizeof(int32_t), ctx->stream, N,
+                         s->chosen.p, r.pchoice.p, r.pnewpos.p, cur_b, r.choice.p, r.chosen_newpos.p,
+                         (unsigned long long*)rt.stats.p, hist_rows, r.moved_flag.p, r.new_flag.p);
       HIPCHK(ctx, hipcub::DeviceSelect::Flagged(tmp, tmp_sel, hipcub::CountingInputIterator<int32_t>(0), r.moved_flag.p,
                                                 r.moved_list.p, s->tail_counts.p + 2 * bi, N, ctx->stream));
       HIPCHK(ctx, hipcub::DeviceSelect::Flagged(tmp, tmp_sel, hipcub::CountingInputIterator<int32_t>(0), r.new_flag.p,
