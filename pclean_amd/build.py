@@ -15,7 +15,7 @@ HEADERS = ["ctx.h", "../../include/pclean_hip.h", "../../include/pclean_detmath.
 # -ffp-contract=off: the parity contract (include/pclean_detmath.h) needs plain
 # IEEE mul/add on device, identical to the gcc-built oracle.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-         "-Wall", "-Wno-unused-function"]
+         "-Wall", "-Wno-unused-function"] + os.environ.get("PCLEAN_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _stale():

@@ -37,8 +37,12 @@
 #define ADD_TYPOS_IMPOSSIBLE (-1e5)
 #define FIX_CUTOFF 28.5        // pclean_fixw(d) == 0 for d < -28.5
 #define WAVE_SURV_CAP 256      // pre-filter survivors a wave keeps (4 per lane)
+#ifndef WAVE_RB
 #define WAVE_RB 4              // rounds (16 candidates per lane each) whose loads are in flight together
+#endif
+#ifndef WAVE_TC
 #define WAVE_TC 6              // terms whose loads are in flight together in the exact scoring
+#endif
 #define WAVE_DCUT_OK 24        // a cut-off below this many summed edits is considered selective
 #define GD_STRIDE 28           // int32 words per group descriptor
 // descriptor words: 0 m_lo, 1 m_hi, 2 representative item, 3 row, 4 excl, 5 ctx0, 6 ctx1, 7 flags (bit 0: the
