@@ -41,6 +41,7 @@ extern "C" int pclean_ctx_destroy(pclean_ctx* ctx) {
   ctx->iota.release();
   ctx->nb.release();
   ctx->logl.release();
+  ctx->atd.release();
   for (auto& p : ctx->pair) {
     p.d.release();
     p.lat_len.release();
@@ -121,8 +122,19 @@ int pclean_ensure_density(pclean_ctx* ctx, int max_len) {
     }
   logl[0] = 0.0;
   for (int L = 1; L <= ml; ++L) logl[L] = std::log((double)L);
-  if (ctx->nb.alloc(nb.size()) || ctx->logl.alloc(logl.size()))
+  // the full density of (latent length L, distance d): the three fp64 operations of term_density()
+  // (enum_kernels.hip) evaluated here once — same IEEE operations, same order, same bits
+  std::vector<double> atd((size_t)(ml + 1) * (md + 1));
+  for (int L = 0; L <= ml; ++L)
+    for (int d = 0; d <= md; ++d) {
+      double l = nb[(size_t)((L + 4) / 5) * (md + 1) + d];
+      l -= logl[L] * (double)d;
+      l -= 1.629048269010741 * (double)d;
+      atd[(size_t)L * (md + 1) + d] = l;
+    }
+  if (ctx->nb.alloc(nb.size()) || ctx->logl.alloc(logl.size()) || ctx->atd.alloc(atd.size()))
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemcpy(ctx->atd.p, atd.data(), atd.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(ctx->nb.p, nb.data(), nb.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(ctx->logl.p, logl.data(), logl.size() * sizeof(double), hipMemcpyHostToDevice));
   ctx->h_nb.swap(nb);

@@ -135,6 +135,7 @@ struct pclean_ctx {
   int32_t max_r = -1, max_d = -1, max_len = -1;
   std::vector<double> h_nb, h_logl;
   DevBuf<double> nb, logl;
+  DevBuf<double> atd;  // [max_len + 1][max_d + 1]: nb[(L+4)/5][d] - logl[L] d - log(26)/2 d in that fp64 order (add_typos.jl:61-63)
 
   PairTable pair[PCLEAN_MAX_TABLES];
   CandTable cand[PCLEAN_MAX_TABLES];

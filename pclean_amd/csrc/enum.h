@@ -119,15 +119,15 @@ int pclean_launch_gate(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
 // the latent table's columns change) so a work item streams F contiguous byte rows instead
 // of gathering, plus the candidates' word lengths clen[k].
 struct FastTermDev {
-  const uint8_t* comp;     // [n_obs][kpad]   (null for a ctx term)
+  const uint8_t* comp;     // [n_obs][kpad] byte distances saturated at 42 (root_wave.hip: PRE_CLAMP); null for a ctx term
   const uint8_t* clen;     // [kpad]
   const int32_t* obs_col;  // [n_rows]
   int32_t max_typos, ctx_slot;  // ctx_slot >= 0: the latent value goes through fn[ctx][value] first (a
                                 // JuliaNode of an earlier block's choice); scored by gathering, never pre-filtered
-  const uint8_t* pair;       // [n_obs][n_lat] byte distances          (ctx terms only)
+  const uint8_t* pair;       // [n_obs][n_lat] byte distances (ctx terms; true distance behind a saturated byte)
   const uint16_t* lat_len;   // [n_lat]
   const int32_t* cand_col;   // [n_cand]
-  const int32_t* fn;         // [n_ctx][fn_nb]
+  const int32_t* fn;         // [n_ctx][fn_nb]                         (ctx terms only)
   int32_t n_lat, fn_nb;
 };
 struct FastRootDev {
@@ -142,8 +142,10 @@ struct FastRootDev {
   // integer pre-filter (root_fast.hip): terms whose byte rows are summed, 1 / (smallest cost of one
   // edit), and the largest prior with / without an excluded reference
   int32_t n_pre, pre[3];
-  int32_t pad1, pad2;
+  int32_t pad1, atd_stride;
   double inv_c, prior_max_e, prior_max_n;
+  const double* atd;         // [max_len + 1][atd_stride] AddTypos log-density by (latent length, distance) (ctx->atd)
+  const uint8_t* zero_row;   // kpad zero bytes: stands in for the byte row of a missing observation
   FastTermDev terms[PCLEAN_MAX_TERMS];
 };
 

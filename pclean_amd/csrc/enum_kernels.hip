@@ -603,11 +603,11 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
   // a launch may not exceed 2^32 threads: chunk the items (grid = chunk, 256 lanes each)
   const int kMaxBlocks = 4 * 1024 * 1024;
-  // The LDS-resident kernel keeps every score in LDS: beyond ~48 KB only one or two workgroups fit on a CU and the
+  // The LDS-resident kernel keeps every score in LDS: beyond 80 KB only one workgroup fits on a CU and the
   // recompute-per-pass kernel (no LDS, 8 workgroups per CU) wins — unless the launch is grouped (scores shared by
-  // the member items), which only the LDS kernel supports.
-  static const size_t big_from = getenv("PCLEAN_BIG_FROM") ? (size_t)atol(getenv("PCLEAN_BIG_FROM")) : (size_t)48 * 1024;
-  if (lds > 160 * 1024 || (lds > big_from && !it.grp_off && !scores_out)) {
+  // the member items), which only the LDS kernel supports, or draws many times per item (one more pass per draw).
+  static const size_t big_from = getenv("PCLEAN_BIG_FROM") ? (size_t)atol(getenv("PCLEAN_BIG_FROM")) : (size_t)80 * 1024;
+  if (lds > 160 * 1024 || (lds > big_from && !it.grp_off && !scores_out && n_draws <= 1)) {
     for (int base = 0; base < it.n; base += kMaxBlocks)
       hipLaunchKernelGGL(enum_node_big_kernel, dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), 0, ctx->stream, nd,
                          dn, it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out);

@@ -5,27 +5,34 @@
 // Same contract and bit-identical results as enum_node_kernel (enum_kernels.hip) — the code the reference
 // JIT-generates for a ForeignKeyNode (src/inference/proposal_compiler.jl:131-252) plus the CRP prior
 // (165-171) and the AddTypos densities (src/distributions/add_typos.jl:50-66) — restructured for MI355X
-// around four facts:
-//   * candidate-compact byte tables comp_f[o][k] (compact_pair_kernel, rebuilt when the latent table's
-//     columns change) turn the pair-table gather into contiguous byte streams: a lane reads 16 consecutive
-//     candidates with one 16-byte load, a wave 1 KB per row per round -> fully coalesced;
+// (DESIGN.md §2, §5).  Round-2 counters showed the first version of this kernel to be VALU-issue bound
+// (2 800 vector instructions per group, a third of them SGPR-spill traffic), not memory bound; this version
+// is built to issue as few vector instructions per group as possible:
+//   * candidate-compact byte tables comp_f[o][k] = min(D_f[o][value of candidate k], 42) (compact_pair_kernel,
+//     rebuilt when the latent table's columns change): a lane reads 16 consecutive candidates of a row with one
+//     16-byte load, fully coalesced.  Bytes saturate at 42 so that the sum of three rows fits a byte: the
+//     INTEGER PRE-FILTER is three packed 32-bit additions per four candidates and one add + and for the compare;
 //   * a candidate whose score is more than 28.5 nats below the maximum has fixed-point weight
 //     floor(exp(s-m) 2^40) == 0 exactly (pclean_fixw), so it can influence neither the log-sum-exp nor a
-//     draw.  An INTEGER PRE-FILTER proves that for almost every candidate: score <= prior_max -
-//     c_min * (summed byte distances of the three most discriminating terms), compared with a lower bound
-//     of the maximum (the exact score of the rows' current referent, or of the candidate with the smallest
-//     summed distance).  Only the survivors (a handful per group) are scored in fp64, in plan order;
+//     draw.  The pre-filter proves that for almost every candidate: score <= prior_max - c_min * (summed
+//     saturated byte distances of the three most discriminating terms), compared with a lower bound of the
+//     maximum (exact score of the rows' current referent / of the "new row" candidate, computed per group by
+//     group_desc_kernel).  Only the survivors (a handful) are scored in fp64, in plan order (a saturated byte
+//     sends that one term to the pair table for its true distance);
 //   * rows with identical (observed tuple, ctx, referent) share the score vector: ONE WAVEFRONT PER GROUP of
 //     such rows; every (member row, particle) pair draws with its own Philox counter by binary search over
-//     the survivors' fixed-point prefix;
-//   * the per-group dependent chain (group -> member -> row -> observed ids -> byte rows -> bound) is cut
-//     out of the scan: group_desc_kernel (one thread per group, fully parallel) writes a 112-byte descriptor
-//     per group; the persistent scan kernel reads it with one coalesced load and prefetches the next
-//     group's descriptor while it scans.  No workgroup barrier anywhere: a wave owns its group and its
-//     slice of LDS.
-// Survivors are written to the wave's LDS slice in ascending candidate order (ballot + lane prefix), so the
-// inverse CDF needs no sort.  Groups with more than WAVE_SURV_CAP pre-filter survivors (flat posteriors)
-// are flagged and re-run by the host with the LDS-resident generic kernel — results are identical either way.
+//     the survivors' fixed-point prefix.  Groups are sorted by (referent, pre-filter observed values) and a
+//     wave takes WAVE_CHUNK consecutive groups: a group whose pre-filter rows and cut-off are covered by the
+//     previous scan reuses its survivor list (any superset of the required list gives identical results);
+//   * group_desc_kernel (one thread per group) writes a 128-byte descriptor per group; the scan kernel reads it
+//     with one coalesced load and prefetches the next group's.  Chunks are handed out by one atomic counter per
+//     XCD (each XCD walks its own contiguous eighth of the groups: the byte rows of one referent stay in ONE
+//     L2) and stolen from the other XCDs at the tail.  No workgroup barrier anywhere;
+//   * the kernel's table descriptor (FastRootDev, 1.3 KB) is read through the kernarg segment with scalar
+//     loads where it is needed instead of living in (spilled) SGPRs; the per-group log-sum-exp is computed by
+//     group_lse_kernel, one thread per group, instead of redundantly by 64 lanes.
+// Groups with more than WAVE_SURV_CAP pre-filter survivors (flat posteriors) are flagged and re-run by the
+// host with the LDS-resident generic kernel — results are identical either way.
 #include <algorithm>
 #include <cstdlib>
 
@@ -33,21 +40,31 @@
 #include "../../include/pclean_philox.h"
 #include "enum.h"
 
-#define HALF_LOG26 1.629048269010741
 #define ADD_TYPOS_IMPOSSIBLE (-1e5)
 #define FIX_CUTOFF 28.5        // pclean_fixw(d) == 0 for d < -28.5
-#define WAVE_SURV_CAP 256      // pre-filter survivors a wave keeps (4 per lane)
+#define PRE_CLAMP 42           // compact bytes saturate here: three of them sum to <= 126 < 128
+#define CUT_ALL 126u           // cut-off that lets every live candidate through
+#define WAVE_SURV_CAP 256      // pre-filter survivors a wave keeps
 #ifndef WAVE_RB
-#define WAVE_RB 4              // rounds (16 candidates per lane each) whose loads are in flight together
+#define WAVE_RB 2              // rounds (16 candidates per lane each) whose loads are in flight together
 #endif
 #ifndef WAVE_TC
 #define WAVE_TC 6              // terms whose loads are in flight together in the exact scoring
 #endif
-#define WAVE_DCUT_OK 24        // a cut-off below this many summed edits is considered selective
-#define GD_STRIDE 28           // int32 words per group descriptor
+#ifndef WAVE_CHUNK
+#define WAVE_CHUNK 8           // consecutive groups a wave takes at a time
+#endif
+#ifndef WAVE_MIN_WAVES
+#define WAVE_MIN_WAVES 6       // resident workgroups per CU the register allocation aims at
+#endif
+#define WAVE_DCUT_OK 24u       // a cut-off below this many summed edits is considered selective
+#define WAVE_GUESS 4u          // first cut-off tried when the descriptor's bound is useless (widened until something survives)
+#define WAVE_SLACK 3u          // scanned cut-off = required + slack: makes the list reusable by the next groups
+#define GD_STRIDE 32           // int32 words per group descriptor (one 128-byte line)
 // descriptor words: 0 m_lo, 1 m_hi, 2 representative item, 3 row, 4 excl, 5 ctx0, 6 ctx1, 7 flags (bit 0: the
-// excluded referent is garbage-collected), 8-9 bound (double), 10..25 observed value index of term f,
-// 26-27 score of the "new row" candidate (double)
+// excluded referent is garbage-collected, bit 1: the bound is useless -> guess and refine), 8-9 bound (double;
+// already includes the new-row score), 10..25 observed value index of term f, 26-27 score of the "new row"
+// candidate (double), 28 first cut-off, 29 cut-off the bound would require (refine mode: upper limit)
 
 __global__ void compact_pair_kernel(const uint8_t* __restrict__ pair, int n_obs, int n_lat,
                                     const int32_t* __restrict__ cand_col, int n_cand, int kpad,
@@ -57,7 +74,7 @@ __global__ void compact_pair_kernel(const uint8_t* __restrict__ pair, int n_obs,
   if (k >= kpad) return;
   uint8_t v = 0;
   if (k < n_cand) v = pair[(size_t)o * n_lat + cand_col[k]];
-  comp[(size_t)o * kpad + k] = v;
+  comp[(size_t)o * kpad + k] = v < PRE_CLAMP ? v : (uint8_t)PRE_CLAMP;
 }
 __global__ void compact_len_kernel(const uint16_t* __restrict__ lat_len, const int32_t* __restrict__ cand_col,
                                    int n_cand, int kpad, uint8_t* __restrict__ clen) {
@@ -110,43 +127,43 @@ __device__ __forceinline__ double wave_max64(double v) {
   return v;
 }
 
-__device__ __forceinline__ double add_typos_dens(const DensDev& dn, int L, int d) {
-  // the fp64 operation order of term_density() (enum_kernels.hip), add_typos.jl:61-63
-  const int r = (L + 4) / 5;
-  double l = dn.nb[(size_t)r * dn.nb_stride + d];
-  l -= dn.logl[L] * (double)d;
-  l -= HALF_LOG26 * (double)d;
-  return l;
+// AddTypos density of term tm for candidate k against observed value of (>= 0): fr.atd[L][d] holds the three
+// fp64 operations of term_density() (enum_kernels.hip; add_typos.jl:61-63) evaluated once on the host
+__device__ __forceinline__ double wave_term_dens(const FastRootDev& fr, const FastTermDev& tm, int of, int ctx0, int ctx1,
+                                                 int k) {
+  int d, L;
+  if (tm.ctx_slot < 0) {
+    d = tm.comp[(size_t)of * fr.kpad + k];
+    L = tm.clen[k];
+    if (d == PRE_CLAMP) d = tm.pair[(size_t)of * tm.n_lat + tm.cand_col[k]];  // saturated byte: the true distance
+  } else {
+    const int c = tm.ctx_slot == 0 ? ctx0 : ctx1;
+    const int val = tm.fn[(size_t)c * tm.fn_nb + tm.cand_col[k]];
+    d = tm.pair[(size_t)of * tm.n_lat + val];
+    L = tm.lat_len[val];
+  }
+  return (tm.max_typos >= 0 && d > tm.max_typos) ? ADD_TYPOS_IMPOSSIBLE : fr.atd[(size_t)L * fr.atd_stride + d];
 }
 
 // exact score of candidate k for the item described by (o[], ctx): prior first, then the terms in plan
 // order — the operation order of candidate_score() (enum_kernels.hip)
-__device__ __forceinline__ double fast_exact_score(const FastRootDev& fr, const DensDev& dn, const int* o, int ctx0,
-                                                   int ctx1, int k, double pr) {
+__device__ __forceinline__ double fast_exact_score(const FastRootDev& fr, const int* o, int ctx0, int ctx1, int k,
+                                                   double pr) {
   double b = pr;
   for (int f = 0; f < fr.n_terms; ++f) {
-    const FastTermDev& tm = fr.terms[f];
     if (o[f] < 0) continue;  // an explicitly missing observation contributes nothing (add_typos.jl:51-53)
-    int d, L;
-    if (tm.ctx_slot < 0) {
-      d = tm.comp[(size_t)o[f] * fr.kpad + k];
-      L = tm.clen[k];
-    } else {
-      const int c = tm.ctx_slot == 0 ? ctx0 : ctx1;
-      const int val = tm.fn[(size_t)c * tm.fn_nb + tm.cand_col[k]];
-      d = tm.pair[(size_t)o[f] * tm.n_lat + val];
-      L = tm.lat_len[val];
-    }
-    b += (tm.max_typos >= 0 && d > tm.max_typos) ? ADD_TYPOS_IMPOSSIBLE : add_typos_dens(dn, L, d);
+    b += wave_term_dens(fr, fr.terms[f], o[f], ctx0, ctx1, k);
   }
   return b;
 }
 
 // One thread per group: the descriptor the scan kernel consumes, including the lower bound of the maximum
-// from the exact score of the rows' current referent (only ever used as a filter, never as a score).
-__global__ void group_desc_kernel(const FastRootDev fr, const DensDev dn, const ItemsDev it, const ChildrenDev ch,
-                                  int n_groups, int32_t* __restrict__ gd) {
+// from the exact score of the rows' current referent (only ever used as a filter, never as a score) and the
+// pre-filter cut-off that follows from it.
+__global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const ChildrenDev ch, int n_groups,
+                                  int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < 8) chunk_ctr[g] = 0u;
   if (g >= n_groups) return;
   const int m_lo = it.grp_off ? it.grp_off[g] : g, m_hi = it.grp_off ? it.grp_off[g + 1] : g + 1;
   const int t = it.grp_off ? it.members[m_lo] : g;
@@ -159,19 +176,7 @@ __global__ void group_desc_kernel(const FastRootDev fr, const DensDev dn, const 
   const bool deleted = excl >= 0 && fr.counts && fr.counts[excl] <= 1;
   double bound = -__builtin_inf();
   if (excl >= 0 && !deleted && fr.logc_m1)
-    bound = fast_exact_score(fr, dn, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]) - 1.0;
-  int32_t* d = gd + (size_t)g * GD_STRIDE;
-  d[0] = m_lo;
-  d[1] = m_hi;
-  d[2] = t;
-  d[3] = row;
-  d[4] = excl;
-  d[5] = ctx0;
-  d[6] = ctx1;
-  d[7] = deleted ? 1 : 0;
-  d[8] = __double2loint(bound);
-  d[9] = __double2hiint(bound);
-  for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) d[10 + f] = o[f];
+    bound = fast_exact_score(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]) - 1.0;
   // score of the "new row" candidate (proposal_compiler.jl:221-230): CRP new-table term + log-marginals of the
   // children in plan order — new_score() of enum_kernels.hip; an option list (LEAF node) has none
   double sn = -__builtin_inf();
@@ -188,18 +193,96 @@ __global__ void group_desc_kernel(const FastRootDev fr, const DensDev dn, const 
     }
     sn = ((deleted ? fr.scal[3] : fr.scal[2]) - logden) + snew;
   }
+  bound = fmax(bound, sn);  // the new-row candidate is a candidate too: its exact score bounds the maximum from below
+  // Pre-filter cut-off: a candidate whose summed (saturated) edit distance D over the pre-filter terms exceeds the
+  // cut scores at most pmax - c_min * D < bound - FIX_CUTOFF <= max - FIX_CUTOFF, i.e. its fixed-point weight is
+  // exactly 0 (c_min = smallest cost of one edit, fr.inv_c = 1 / c_min; terms not summed and missing observations
+  // only lower the score further).  A bound that would let candidates WAVE_DCUT_OK edits away through (a referent
+  // that explains the row badly, no referent at all) is replaced by guess-and-refine in the scan kernel.
+  uint32_t cut = CUT_ALL, cut_max = CUT_ALL, refine = 0;
+  if (fr.n_pre > 0) {
+    const double pmax = excl >= 0 ? fr.prior_max_e : fr.prior_max_n;
+    if (bound > -__builtin_inf()) {
+      const double x = (pmax - bound + FIX_CUTOFF) * fr.inv_c;
+      if (x >= 0.0 && x < (double)(CUT_ALL - 2u)) cut_max = (uint32_t)x + 2u;
+    }
+    if (cut_max < WAVE_DCUT_OK) {
+      cut = cut_max;
+    } else {
+      cut = WAVE_GUESS;
+      refine = 1;
+    }
+  }
+  int32_t* d = gd + (size_t)g * GD_STRIDE;
+  d[0] = m_lo;
+  d[1] = m_hi;
+  d[2] = t;
+  d[3] = row;
+  d[4] = excl;
+  d[5] = ctx0;
+  d[6] = ctx1;
+  d[7] = (deleted ? 1 : 0) | (refine ? 2 : 0);
+  d[8] = __double2loint(bound);
+  d[9] = __double2hiint(bound);
+  for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) d[10 + f] = o[f];
   d[26] = __double2loint(sn);
   d[27] = __double2hiint(sn);
+  d[28] = (int32_t)cut;
+  d[29] = (int32_t)cut_max;
+  d[30] = 0;
+  d[31] = 0;
+}
+
+// what the scan kernel needs of an item list
+struct WaveItems {
+  const int32_t* members;   // null: group g = item g
+  const int32_t* row;       // identity when null
+  const int32_t* rng_row;   // RNG row of an item (default: row + row_offset)
+  const int32_t* particle;  // RNG particle of an item (n_draws == 1), default: the draw index
+  int64_t row_offset;
+  int32_t draw_is, draw_ds;
+};
+
+// The per-term pointers of FastRootDev (16 terms x 9 fields) must not live in SGPRs: the compiler hoists them out of
+// the group loop and spills them to VGPR lanes (a third of the first version's vector instructions were that spill
+// traffic).  FastRootDev is the kernel's FIRST parameter; its terms[] are only read through the kernarg segment
+// pointer: once at kernel start into lane-resident registers (lane f holds term f), and with scalar loads in the
+// rare ctx-term path.
+typedef const __attribute__((address_space(4))) FastRootDev* fr_karg_t;
+__device__ __forceinline__ fr_karg_t fr_karg() {
+  uint64_t a = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(a));
+  return (fr_karg_t)a;
+}
+// global-memory views of addresses assembled from lane registers (a plain cast would give flat loads)
+typedef const __attribute__((address_space(1))) uint8_t* g_u8_t;
+typedef const __attribute__((address_space(1))) uint16_t* g_u16_t;
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4_t* g_u4_t;
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int l) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+  return ((uint64_t)hi << 32) | lo;
+}
+// exclusive prefix over the wave of a small per-lane count (< 32) + the wave total, from five ballots
+__device__ __forceinline__ int wave_excl_prefix5(int cnt, int& total) {
+  int ex = 0;
+  total = 0;
+#pragma unroll
+  for (int bit = 0; bit < 5; ++bit) {
+    const uint64_t m = __ballot((cnt >> bit) & 1);
+    ex += (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)) << bit;
+    total += __builtin_popcountll(m) << bit;
+  }
+  return ex;
 }
 
 template <int NT>
-__global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr, const DensDev dn, const ItemsDev it,
-                                                           uint64_t seed, uint32_t sweep, uint32_t site, int n_draws,
-                                                           int n_groups, const int32_t* __restrict__ gd,
-                                                           double* __restrict__ lse_out,
-                                                           int32_t* __restrict__ draws_out,
-                                                           int32_t* __restrict__ overflow_flag,
-                                                           unsigned int* __restrict__ overflow_count) {
+__global__ __launch_bounds__(256, WAVE_MIN_WAVES) void fk_root_wave_kernel(
+    const FastRootDev fr, const WaveItems wi, uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, int n_groups,
+    const int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr, double* __restrict__ g_m,
+    uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out, int32_t* __restrict__ overflow_flag,
+    unsigned int* __restrict__ overflow_count) {
   __shared__ uint64_t s_pref[4][WAVE_SURV_CAP + 8];
   __shared__ double s_sc[4][WAVE_SURV_CAP + 8];
   __shared__ int32_t s_k[4][WAVE_SURV_CAP + 8];
@@ -207,187 +290,214 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
   uint64_t* pref = s_pref[wave];
   double* scv = s_sc[wave];
   int32_t* ksv = s_k[wave];
-  const int n = fr.n_cand;
-  const int nquads = fr.kpad >> 4;
-  const int draw_is = it.draw_is ? it.draw_is : n_draws, draw_ds = it.draw_ds ? it.draw_ds : 1;
-  // XCD-aware persistent mapping: workgroup b runs on XCD b % 8 (each XCD has its own L2).  The groups arrive
-  // sorted by referent, so consecutive groups stream the same byte rows: XCD x takes the x-th contiguous eighth
-  // of the groups and its workgroups walk it with a stride — the rows of one referent stay in ONE L2.
-  const int xcd = blockIdx.x & 7, nbx = (gridDim.x + 7 - xcd) >> 3;
-  const int per = (n_groups + 7) >> 3;
-  const int g_hi = min((xcd + 1) * per, n_groups);
-  const int wstride = nbx * 4;
-  int g = xcd * per + (blockIdx.x >> 3) * 4 + wave;
-  int dv = (g < g_hi && lane < GD_STRIDE) ? gd[(size_t)g * GD_STRIDE + lane] : 0;
-  for (; g < g_hi; g += wstride) {
-    // ---- descriptor -> wave-uniform registers; the next group's descriptor is requested right away -------
+  const int kpad = fr.kpad, nquads = kpad >> 4, n_terms = fr.n_terms;
+  const int nd_eff = n_draws > 0 ? n_draws : 1;
+  const int draw_is = wi.draw_is ? wi.draw_is : n_draws, draw_ds = wi.draw_ds ? wi.draw_ds : 1;
+  // lane -> (member slot, draw) of the draw phase, fixed for the launch
+  const int mem_per_pass = nd_eff <= 64 ? 64 / nd_eff : 0;
+  const int slot_l = nd_eff <= 64 ? lane / nd_eff : 0, draw_l = nd_eff <= 64 ? lane - slot_l * nd_eff : 0;
+  // lane f < n_terms: term f's compact rows, candidate lengths and typo limit (ctx terms: the zero row)
+  uint64_t t_comp = (uint64_t)fr.zero_row, t_clen = (uint64_t)fr.zero_row;
+  int t_mt = -1;
+  bool t_ctx = false;
+  if (lane < n_terms) {
+    fr_karg_t F = fr_karg();
+    t_ctx = F->terms[lane].ctx_slot >= 0;
+    t_mt = F->terms[lane].max_typos;
+    if (!t_ctx) {
+      t_comp = (uint64_t)F->terms[lane].comp;
+      t_clen = (uint64_t)F->terms[lane].clen;
+    }
+  }
+  const uint32_t ctx_mask = (uint32_t)__ballot(t_ctx), mt_mask = (uint32_t)__ballot(lane < n_terms && t_mt >= 0);
+  // XCD-aware chunk hand-out: workgroup b runs on XCD b % 8 (each XCD has its own L2).  The groups arrive sorted by
+  // referent, so consecutive groups stream the same byte rows: XCD x owns the x-th contiguous eighth of the groups.
+  const int xcd = blockIdx.x & 7;
+  const int per = (((n_groups + 7) >> 3) + WAVE_CHUNK - 1) / WAVE_CHUNK * WAVE_CHUNK;  // groups per XCD, whole chunks
+  const int chunks_per = per / WAVE_CHUNK;
+  int steal = 0;  // chunks come from the counter of XCD (xcd + steal) & 7; 8 = everything is handed out
+  auto grab = [&]() -> int {  // the returned value is valid in lane 0 and looked at by resolve() only
+    int c = 0;
+    if (lane == 0) c = (int)atomicAdd(&chunk_ctr[(xcd + steal) & 7], 1u);
+    return c;
+  };
+  auto resolve = [&](int raw_lane0, int& g_lo, int& g_hi) {
+    int c = __builtin_amdgcn_readfirstlane(raw_lane0);
+    for (;;) {
+      const int x = (xcd + steal) & 7;
+      if (c < chunks_per) {
+        g_lo = x * per + c * WAVE_CHUNK;
+        g_hi = min(g_lo + WAVE_CHUNK, min((x + 1) * per, n_groups));
+        if (g_lo < g_hi) return;
+      }
+      if (++steal >= 8) {
+        g_lo = g_hi = 0;
+        return;
+      }
+      int r = 0;
+      if (lane == 0) r = (int)atomicAdd(&chunk_ctr[(xcd + steal) & 7], 1u);
+      c = __builtin_amdgcn_readfirstlane(r);
+    }
+  };
+  // cache of the last scan (per wave): pre-filter observed values, scanned cut-off, survivors in ksv
+  int c_o0 = -2, c_o1 = -2, c_o2 = -2, c_ns = 0;
+  uint32_t c_cut = 0;
+  bool c_valid = false;
+  // the previous group of this wave: a group with the same (referent, ctx, observed values, bounds) — the pieces a
+  // large group is split into (make_item_groups) — reuses its survivors, prefix and totals outright
+  int dvp = 0, p_ns = 0;
+  bool p_valid = false, p_over = false;
+  double p_m = 0.0;
+  uint64_t p_U = 0;
+
+  int g = 0, g_end = 0;
+  resolve(grab(), g, g_end);
+  int raw_next = steal < 8 ? grab() : 0;
+  int dv = (g < g_end && lane < GD_STRIDE) ? gd[(size_t)g * GD_STRIDE + lane] : 0;
+  while (g < g_end) {
+    // ---- next group (possibly the first of the next chunk): its descriptor is requested right away ---------------
+    int gn = g + 1, gn_end = g_end;
+    if (gn >= g_end) {
+      if (steal < 8) {
+        resolve(raw_next, gn, gn_end);
+        raw_next = steal < 8 ? grab() : 0;
+      } else {
+        gn = gn_end = 0;
+      }
+    }
+    const int dvn = (gn < gn_end && lane < GD_STRIDE) ? gd[(size_t)gn * GD_STRIDE + lane] : 0;
+    // ---- descriptor -> wave-uniform registers ----------------------------------------------------------------------
     const int m_lo = __builtin_amdgcn_readlane(dv, 0), m_hi = __builtin_amdgcn_readlane(dv, 1);
     const int t = __builtin_amdgcn_readlane(dv, 2);
     const int excl = __builtin_amdgcn_readlane(dv, 4);
-    const int ctx0 = __builtin_amdgcn_readlane(dv, 5), ctx1 = __builtin_amdgcn_readlane(dv, 6);
-    const bool deleted = (__builtin_amdgcn_readlane(dv, 7) & 1) != 0;
-    double bound = __hiloint2double(__builtin_amdgcn_readlane(dv, 9), __builtin_amdgcn_readlane(dv, 8));
-    // score of the "new row" candidate (index n, last in natural order; -inf for an option list), from the descriptor
+    const int flags = __builtin_amdgcn_readlane(dv, 7);
+    const bool deleted = (flags & 1) != 0;
+    bool refine = (flags & 2) != 0;
+    const double bound = __hiloint2double(__builtin_amdgcn_readlane(dv, 9), __builtin_amdgcn_readlane(dv, 8));
+    // score of the "new row" candidate (index n, last in natural order; -inf for an option list)
     const double sn = __hiloint2double(__builtin_amdgcn_readlane(dv, 27), __builtin_amdgcn_readlane(dv, 26));
-    int o[NT];
-#pragma unroll
-    for (int f = 0; f < NT; ++f) o[f] = __builtin_amdgcn_readlane(dv, 10 + f);
-    {
-      const int gn = g + wstride;
-      dv = (gn < g_hi && lane < GD_STRIDE) ? gd[(size_t)gn * GD_STRIDE + lane] : 0;
-    }
+    uint32_t cut = (uint32_t)__builtin_amdgcn_readlane(dv, 28);
+    const uint32_t cut_max = (uint32_t)__builtin_amdgcn_readlane(dv, 29);
     const bool excluded = excl >= 0;
-    const double logden = excluded ? fr.scal[1] : fr.scal[0];
-    const double* __restrict__ prior = (excluded && fr.prior_e) ? fr.prior_e : fr.prior_n;
-    const double pmax = excluded ? fr.prior_max_e : fr.prior_max_n;
-    // byte rows of the (up to 3) most discriminating terms, summed by the integer pre-filter
-    const uint4* prow[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      prow[p] = nullptr;
-      if (p < fr.n_pre) {
-        const int f = fr.pre[p];
-        int of = -1;
-#pragma unroll
-        for (int q = 0; q < NT; ++q)
-          if (q == f) of = o[q];
-        if (of >= 0) prow[p] = reinterpret_cast<const uint4*>(fr.terms[f].comp + (size_t)of * fr.kpad);
-      }
-    }
-    // summed byte distances of the 16 candidates of quad q: D[4w + e], e = byte e of dword w
-    auto quad_sums = [&](int q, uint32_t* lo, uint32_t* hi) {
-#pragma unroll
-      for (int w = 0; w < 4; ++w) lo[w] = hi[w] = 0u;
-#pragma unroll
-      for (int p = 0; p < 3; ++p)
-        if (prow[p]) {
-          const uint4 c = prow[p][q];
-          const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
-#pragma unroll
-          for (int w = 0; w < 4; ++w) {
-            lo[w] += cw[w] & 0x00ff00ffu;
-            hi[w] += (cw[w] >> 8) & 0x00ff00ffu;
-          }
-        }
-    };
+    // lane f: observed value of term f and the address of its byte row; on_mask: terms with an observation
+    const int of_l = __shfl(dv, (lane & 15) + 10, 64);
+    const uint32_t on_mask = (uint32_t)__ballot(lane < n_terms && of_l >= 0);
+    const uint64_t t_row = t_comp + (uint64_t)(uint32_t)(of_l < 0 ? 0 : of_l) * (uint64_t)(uint32_t)kpad;
+    // observed values of the pre-filter terms (-1: missing / fewer than three terms)
+    const int po0 = fr.n_pre > 0 ? __builtin_amdgcn_readlane(dv, 10 + fr.pre[0]) : -1;
+    const int po1 = fr.n_pre > 1 ? __builtin_amdgcn_readlane(dv, 10 + fr.pre[1]) : -1;
+    const int po2 = fr.n_pre > 2 ? __builtin_amdgcn_readlane(dv, 10 + fr.pre[2]) : -1;
 
-    // Stage 0 (groups without a retained referent: nested slots of a new row, option lists, initialisation):
-    // the live candidate with the smallest summed distance; its exact score - 1 is the lower bound of the
-    // maximum.  Stage 1: the pre-filter scan.  Both stages share ONE copy of the exact-scoring code below.
-    // A retained referent that explains the row badly (wrong entity, many typos) gives a useless bound: when its
-    // cut-off would let candidates more than WAVE_DCUT_OK edits away through, stage 0 runs as well and the better
-    // of the two bounds is used.
-    bound = fmax(bound, sn);  // the new-row candidate is a candidate too: its exact score bounds the maximum from below
-    bool need_bound = !(bound > -__builtin_inf()) && fr.n_pre > 0;
-    if (!need_bound && fr.n_pre > 0) {
-      const double x = (pmax - bound + FIX_CUTOFF) * fr.inv_c;
-      need_bound = !(x < (double)WAVE_DCUT_OK);
-    }
-    const double bound0 = bound;
+    // ---- pre-filter scan at cut-off `want` (or the cached list when it covers it): survivors -> ksv, ascending ----
     int ns = 0;
-    bool over = false;
-    for (int stage = need_bound ? 0 : 1; stage < 2; ++stage) {
-      ns = 0;
-      if (stage == 0) {
-        uint64_t best = ~0ull;
+    auto scan = [&](uint32_t want) {
+      if (c_valid && po0 == c_o0 && po1 == c_o1 && po2 == c_o2 && want <= c_cut && c_ns <= WAVE_SURV_CAP) {
+        ns = c_ns;
+        cut = c_cut;
+        return;
+      }
+      const uint64_t zr = (uint64_t)fr.zero_row;
+      const g_u8_t r0 = (g_u8_t)(po0 >= 0 ? readlane64(t_row, fr.pre[0]) : zr);
+      const g_u8_t r1 = (g_u8_t)(po1 >= 0 ? readlane64(t_row, fr.pre[1]) : zr);
+      const g_u8_t r2 = (g_u8_t)(po2 >= 0 ? readlane64(t_row, fr.pre[2]) : zr);
+      const g_u8_t alive = (g_u8_t)(uint64_t)fr.alive;
+      uint32_t cs = min(want + WAVE_SLACK, CUT_ALL);
+      for (;;) {
+        // a byte of (c0 + c1 + c2 + addc) has bit 7 set iff its summed distance exceeds cs (sums <= 126: no carries)
+        const uint32_t addc = 0x01010101u * (127u - cs);
+        ns = 0;
         for (int q0 = 0; q0 < nquads; q0 += 64 * WAVE_RB) {
+          u32x4_t ca[WAVE_RB], cb[WAVE_RB], cc[WAVE_RB], tq[WAVE_RB];
+          uint32_t al[WAVE_RB];
 #pragma unroll
-          for (int r = 0; r < WAVE_RB; ++r) {
-            const int q = q0 + r * 64 + lane;
-            if (q < nquads) {
-              uint32_t lo[4], hi[4];
-              quad_sums(q, lo, hi);
-              const uint32_t al = fr.alive[q];
-#pragma unroll
-              for (int w = 0; w < 4; ++w) {
-                const uint32_t D[4] = {lo[w] & 0xffffu, hi[w] & 0xffffu, lo[w] >> 16, hi[w] >> 16};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                  const int k = (q << 4) + (w << 2) + e;
-                  const uint64_t key = ((uint64_t)D[e] << 32) | (uint32_t)k;
-                  if (key < best && ((al >> (4 * w + e)) & 1u) && k != excl) best = key;
-                }
-              }
-            }
+          for (int r = 0; r < WAVE_RB; ++r) {  // every load of the batch first
+            const uint32_t qq = (uint32_t)min(q0 + r * 64 + lane, nquads - 1);
+            ca[r] = *(g_u4_t)(r0 + (qq << 4));
+            cb[r] = *(g_u4_t)(r1 + (qq << 4));
+            cc[r] = *(g_u4_t)(r2 + (qq << 4));
+            al[r] = *(g_u16_t)(alive + (qq << 1));
           }
-        }
-        for (int sh = 32; sh > 0; sh >>= 1) {
-          const uint64_t other = __shfl_xor(best, sh, 64);
-          best = other < best ? other : best;
-        }
-        if (best != ~0ull) {
-          if (lane == 0) ksv[0] = (int)(uint32_t)best;
-          ns = 1;
-        }
-      } else {
-        // Pre-filter threshold: a candidate whose summed edit distance D over the pre-filter terms exceeds dcut
-        // scores at most pmax - c_min * D < bound - FIX_CUTOFF <= max - FIX_CUTOFF, i.e. its fixed-point weight
-        // is exactly 0 (c_min = smallest cost of one edit, fr.inv_c = 1 / c_min; terms not summed and missing
-        // observations only lower the score further).
-        uint32_t dcut = 0xffffu;
-        if (fr.n_pre > 0 && bound > -__builtin_inf()) {
-          const double x = (pmax - bound + FIX_CUTOFF) * fr.inv_c;
-          if (x >= 0.0 && x < 60000.0) dcut = (uint32_t)x + 2u;
-        }
-        // branch-free integer scan, 16 candidates per lane per round, WAVE_RB rounds of loads in flight;
-        // survivors (live candidates with D <= dcut) go to the wave's LDS list in ascending candidate order
-        for (int q0 = 0; q0 < nquads; q0 += 64 * WAVE_RB) {
-          uint32_t m16[WAVE_RB];
 #pragma unroll
           for (int r = 0; r < WAVE_RB; ++r) {
-            const int q = q0 + r * 64 + lane;
-            m16[r] = 0;
-            if (q < nquads) {
-              uint32_t lo[4], hi[4];
-              quad_sums(q, lo, hi);
-              uint32_t mk = 0;
-#pragma unroll
-              for (int w = 0; w < 4; ++w) {
-                mk |= ((lo[w] & 0xffffu) <= dcut ? 1u : 0u) << (4 * w);
-                mk |= ((hi[w] & 0xffffu) <= dcut ? 1u : 0u) << (4 * w + 1);
-                mk |= ((lo[w] >> 16) <= dcut ? 1u : 0u) << (4 * w + 2);
-                mk |= ((hi[w] >> 16) <= dcut ? 1u : 0u) << (4 * w + 3);
-              }
-              m16[r] = mk & (uint32_t)fr.alive[q];  // padding and free slots never survive
-            }
+            if (q0 + r * 64 + lane >= nquads) al[r] = 0u;
+            tq[r].x = ca[r].x + cb[r].x + cc[r].x + addc;
+            tq[r].y = ca[r].y + cb[r].y + cc[r].y + addc;
+            tq[r].z = ca[r].z + cb[r].z + cc[r].z + addc;
+            tq[r].w = ca[r].w + cb[r].w + cc[r].w + addc;
           }
-          uint32_t any = 0;
+          bool any = false;
 #pragma unroll
-          for (int r = 0; r < WAVE_RB; ++r) any |= m16[r];
-          if (__ballot(any != 0) == 0ull) continue;  // wave-uniform: most rounds hold no survivor at all
+          for (int r = 0; r < WAVE_RB; ++r)
+            any |= ((tq[r].x & tq[r].y & tq[r].z & tq[r].w & 0x80808080u) != 0x80808080u) && al[r] != 0u;
+          if (__ballot(any) == 0ull) continue;  // wave-uniform: most rounds hold no survivor at all
 #pragma unroll
           for (int r = 0; r < WAVE_RB; ++r) {
-            if (__ballot(m16[r] != 0) == 0ull) continue;
-            const int q = q0 + r * 64 + lane;
-            const int cnt = __builtin_popcount(m16[r]);
-            int incl = cnt;
-            for (int sh = 1; sh < 64; sh <<= 1) {
-              const int x = __shfl_up(incl, sh, 64);
-              if (lane >= sh) incl += x;
+            const uint32_t tw[4] = {tq[r].x, tq[r].y, tq[r].z, tq[r].w};
+            uint32_t m16 = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              const uint32_t z = ~tw[w] & 0x80808080u;  // bit 7 of byte e set: candidate 4 w + e passes
+              m16 |= (((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xfu) << (4 * w);
             }
-            int pos = ns + incl - cnt;
-            for (uint32_t mm = m16[r]; mm; mm &= mm - 1) {
+            m16 &= al[r];  // padding and free slots never survive
+            if (__ballot(m16 != 0) == 0ull) continue;
+            const int q = q0 + r * 64 + lane;
+            int total;
+            int pos = ns + wave_excl_prefix5(__builtin_popcount(m16), total);
+            for (uint32_t mm = m16; mm; mm &= mm - 1) {
               if (pos < WAVE_SURV_CAP) ksv[pos] = (q << 4) + __builtin_ctz(mm);
               ++pos;
             }
-            ns += __shfl(incl, 63, 64);
+            ns += total;
           }
         }
-        if (ns > WAVE_SURV_CAP) {
-          over = true;
-          break;
+        if (ns > WAVE_SURV_CAP && cs > want) {  // the slack alone overflowed the list: once more without it
+          cs = want;
+          continue;
         }
+        break;
       }
       __builtin_amdgcn_wave_barrier();
+      c_o0 = po0;
+      c_o1 = po1;
+      c_o2 = po2;
+      c_cut = cs;
+      c_ns = ns;
+      c_valid = true;
+      cut = cs;
+    };
+
+    bool over = false;
+    double m = -__builtin_inf();
+    uint64_t U = 0;
+    const bool same = p_valid && __ballot(lane >= 4 && lane < 30 && dv != dvp) == 0ull;
+    if (same) {
+      ns = p_ns;
+      over = p_over;
+      m = p_m;
+      U = p_U;
+    } else {
+    for (;;) {
+      scan(cut);
+      if (ns > WAVE_SURV_CAP) {
+        over = true;
+        break;
+      }
+      if (refine && ns == 0) {  // nothing within the guessed cut-off: widen it
+        if (cut >= cut_max) break;
+        cut = min(2u * cut + 2u, cut_max);
+        continue;
+      }
       // ---- exact fp64 scores of ksv[0..ns), one candidate per lane per pass -> scv.  The loads of a chunk of
-      // terms are in flight together (byte distance + length, then the two density pieces); the fp64 additions
-      // follow plan order (the operation order of candidate_score(), enum_kernels.hip).
-      for (int base = 0; base < ns; base += 64) {
-        const int j = base + lane;
-        if (j < ns) {
-          const int k = ksv[j];
+      // terms are in flight together (byte distance + length, then the density table); the fp64 additions follow
+      // plan order (the operation order of candidate_score(), enum_kernels.hip).
+      {
+        const double* prior = (excluded && fr.prior_e) ? fr.prior_e : fr.prior_n;
+        for (int base = 0; base < ns; base += 64) {
+          const int j = base + lane;
+          const uint32_t k = (uint32_t)(j < ns ? ksv[j] : ksv[base]);
           double b = prior[k];
-          if (k == excl) b = deleted ? -__builtin_inf() : fr.logc_m1[excl] - logden;
+          if ((int)k == excl) b = deleted ? -__builtin_inf() : fr.logc_m1[excl] - fr.scal[1];
 #pragma unroll
           for (int f0 = 0; f0 < NT; f0 += WAVE_TC) {
             int dd[WAVE_TC], LL[WAVE_TC];
@@ -396,109 +506,174 @@ __global__ __launch_bounds__(256) void fk_root_wave_kernel(const FastRootDev fr,
               const int f = f0 + u;
               dd[u] = 0;
               LL[u] = 0;
-              if (f < NT && f < fr.n_terms && o[f < NT ? f : 0] >= 0) {
-                const FastTermDev& tm = fr.terms[f];
-                if (tm.ctx_slot < 0) {
-                  dd[u] = tm.comp[(size_t)o[f < NT ? f : 0] * fr.kpad + k];
-                  LL[u] = tm.clen[k];
-                } else {
-                  const int c = tm.ctx_slot == 0 ? ctx0 : ctx1;
-                  const int val = tm.fn[(size_t)c * tm.fn_nb + tm.cand_col[k]];
-                  dd[u] = tm.pair[(size_t)o[f < NT ? f : 0] * tm.n_lat + val];
-                  LL[u] = tm.lat_len[val];
+              if (f < NT) {
+                if ((ctx_mask >> f) & 1u) {  // latent value through fn[ctx][.] (a JuliaNode of an earlier block's choice)
+                  if ((on_mask >> f) & 1u) {
+                    fr_karg_t F = fr_karg();
+                    const int of = __builtin_amdgcn_readlane(dv, 10 + f);
+                    const int c = F->terms[f].ctx_slot == 0 ? __builtin_amdgcn_readlane(dv, 5) : __builtin_amdgcn_readlane(dv, 6);
+                    const int val = F->terms[f].fn[(size_t)c * F->terms[f].fn_nb + F->terms[f].cand_col[k]];
+                    dd[u] = F->terms[f].pair[(size_t)of * F->terms[f].n_lat + val];
+                    LL[u] = F->terms[f].lat_len[val];
+                  }
+                } else {  // lanes >= n_terms and missing observations hold the zero row
+                  dd[u] = ((g_u8_t)readlane64(t_row, f))[k];
+                  LL[u] = ((g_u8_t)readlane64(t_clen, f))[k];
                 }
               }
-            }
-            double nbv[WAVE_TC], lgv[WAVE_TC];
-#pragma unroll
-            for (int u = 0; u < WAVE_TC; ++u) {
-              nbv[u] = dn.nb[(size_t)((LL[u] + 4) / 5) * dn.nb_stride + dd[u]];
-              lgv[u] = dn.logl[LL[u]];
             }
 #pragma unroll
             for (int u = 0; u < WAVE_TC; ++u) {
               const int f = f0 + u;
-              if (f < NT && f < fr.n_terms && o[f < NT ? f : 0] >= 0) {  // a missing observation contributes nothing
-                double l = nbv[u];                                      // operation order of add_typos_dens()
-                l -= lgv[u] * (double)dd[u];
-                l -= HALF_LOG26 * (double)dd[u];
-                const int mt = fr.terms[f].max_typos;
-                b += (mt >= 0 && dd[u] > mt) ? ADD_TYPOS_IMPOSSIBLE : l;
+              if (f < NT && dd[u] == PRE_CLAMP && ((on_mask & ~ctx_mask) >> f) & 1u) {  // saturated: the true distance
+                fr_karg_t F = fr_karg();
+                const int of = __builtin_amdgcn_readlane(dv, 10 + f);
+                dd[u] = F->terms[f].pair[(size_t)of * F->terms[f].n_lat + F->terms[f].cand_col[k]];
+              }
+            }
+            double av[WAVE_TC];
+#pragma unroll
+            for (int u = 0; u < WAVE_TC; ++u) av[u] = fr.atd[(uint32_t)(LL[u] * fr.atd_stride + dd[u])];
+#pragma unroll
+            for (int u = 0; u < WAVE_TC; ++u) {
+              const int f = f0 + u;
+              if (f < NT && ((on_mask >> f) & 1u)) {  // a missing observation contributes nothing (add_typos.jl:51-53)
+                double l = av[u];
+                if ((mt_mask >> f) & 1u) l = dd[u] > __builtin_amdgcn_readlane(t_mt, f) ? ADD_TYPOS_IMPOSSIBLE : l;
+                b += l;
               }
             }
           }
-          scv[j] = b;
+          if (j < ns) scv[j] = b;
         }
       }
       __builtin_amdgcn_wave_barrier();
-      if (stage == 0) bound = fmax(bound0, ns ? scv[0] - 1.0 : -__builtin_inf());
+      if (!refine) break;
+      // refine: the best survivor's exact score (and the descriptor's bound) give the cut-off actually required
+      double best = bound;
+      for (int base = 0; base < ns; base += 64) {
+        const int j = base + lane;
+        if (j < ns) best = fmax(best, scv[j]);
+      }
+      best = wave_max64(best);
+      refine = false;
+      uint32_t need = CUT_ALL;
+      {
+        const double x = ((excluded ? fr.prior_max_e : fr.prior_max_n) - best + FIX_CUTOFF) * fr.inv_c;
+        if (x >= 0.0 && x < (double)(CUT_ALL - 2u)) need = (uint32_t)x + 2u;
+      }
+      need = min(need, cut_max);
+      if (need <= cut) break;  // the scanned list is a superset of the required one
+      cut = need;
     }
+    if (!over) {
+      // ---- maximum, fixed-point weights, inclusive prefix: survivors in ascending order, then the new row (entry ns)
+      if (lane == 0) scv[ns] = sn;
+      __builtin_amdgcn_wave_barrier();
+      const int n_e = ns + 1;
+      for (int base = 0; base < n_e; base += 64) {
+        const int j = base + lane;
+        if (j < n_e) m = fmax(m, scv[j]);
+      }
+      m = wave_max64(m);
+      uint64_t carry = 0;
+      for (int base = 0; base < n_e; base += 64) {
+        const int j = base + lane;
+        const uint64_t u = (j < n_e && m != -__builtin_inf()) ? pclean_fixw(scv[j] - m) : 0ull;
+        unsigned long long incl = u;
+        for (int sh = 1; sh < 64; sh <<= 1) {
+          const unsigned long long x = __shfl_up(incl, sh, 64);
+          if (lane >= sh) incl += x;
+        }
+        if (j < n_e) pref[j] = carry + incl;
+        carry += __shfl(incl, 63, 64);
+      }
+      U = carry;
+      __builtin_amdgcn_wave_barrier();
+    }
+    p_ns = ns;
+    p_over = over;
+    p_m = m;
+    p_U = U;
+    }
+    dvp = dv;
+    p_valid = true;
     if (over) {  // flat posterior: the host re-runs these items with the generic kernel (flags are pre-zeroed)
       if (m_hi - m_lo == 1) {
         if (lane == 0) overflow_flag[t] = PCLEAN_CHOICE_NEW;  // marker understood by compact_new_kernel
       } else {
-        for (int mi = m_lo + lane; mi < m_hi; mi += 64) overflow_flag[it.members[mi]] = PCLEAN_CHOICE_NEW;
+        for (int mi = m_lo + lane; mi < m_hi; mi += 64) overflow_flag[wi.members[mi]] = PCLEAN_CHOICE_NEW;
       }
-      if (lane == 0) atomicAdd(overflow_count, (unsigned int)(m_hi - m_lo));
-      continue;
-    }
-    // ---- maximum, fixed-point weights, inclusive prefix (survivors in ascending order, then the new row) ---
-    double m = sn;
-    for (int base = 0; base < ns; base += 64) {
-      const int j = base + lane;
-      if (j < ns) m = fmax(m, scv[j]);
-    }
-    m = wave_max64(m);
-    uint64_t carry = 0;
-    for (int base = 0; base < ns; base += 64) {
-      const int j = base + lane;
-      const uint64_t u = (j < ns && m != -__builtin_inf()) ? pclean_fixw(scv[j] - m) : 0ull;
-      unsigned long long incl = u;
-      for (int sh = 1; sh < 64; sh <<= 1) {
-        const unsigned long long x = __shfl_up(incl, sh, 64);
-        if (lane >= sh) incl += x;
+      if (lane == 0) {
+        atomicAdd(overflow_count, (unsigned int)(m_hi - m_lo));
+        g_m[g] = __builtin_nan("");
       }
-      if (j < ns) pref[j] = carry + incl;
-      carry += __shfl(incl, 63, 64);
-    }
-    const uint64_t U = carry + ((m == -__builtin_inf()) ? 0ull : pclean_fixw(sn - m));
-    if (lane == 0) pref[ns] = U;
-    __builtin_amdgcn_wave_barrier();
-    // ---- lse + draws of every (member item, draw) pair of the group ------------------------------------------
-    const double lse = pclean_lse_from_fix(m, U);
-    const int nd_eff = n_draws > 0 ? n_draws : 1;
-    const int n_mem = m_hi - m_lo;
-    const int n_out = n_mem * nd_eff;
-    for (int q = lane; q < n_out; q += 64) {
-      const int mi = m_lo + q / nd_eff, j = q % nd_eff;
-      const int tm = n_mem == 1 ? t : it.members[mi];
-      if (j == 0 && lse_out) lse_out[tm] = lse;
+    } else {
+      if (lane == 0) {
+        g_m[g] = m;
+        g_U[g] = U;
+      }
+      // ---- draws of every (member item, draw) pair of the group ------------------------------------------------------
       if (n_draws > 0) {
-        int32_t res = fr.is_leaf ? n - 1 : PCLEAN_CHOICE_NEW;
-        if (U != 0) {
-          const int row_m = it.row ? it.row[tm] : tm;
-          const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[tm] : (uint32_t)((int64_t)row_m + it.row_offset);
-          const uint32_t pid = it.particle ? (uint32_t)it.particle[tm] : (uint32_t)j;
-          const uint64_t x = pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U);
-          int a = 0, b = ns;  // smallest index with prefix > x (index ns = the new row)
-          while (a < b) {
-            const int mid = (a + b) >> 1;
-            if (pref[mid] > x)
-              b = mid;
-            else
-              a = mid + 1;
+        const int res_new = fr.is_leaf ? fr.n_cand - 1 : PCLEAN_CHOICE_NEW;
+        const int n_mem = m_hi - m_lo;
+        auto one_draw = [&](int mi, int j) {
+          const int tm = n_mem == 1 ? t : wi.members[mi];
+          int32_t res = res_new;
+          if (U != 0) {
+            const int row_m = wi.row ? wi.row[tm] : tm;
+            const uint32_t rng_row = wi.rng_row ? (uint32_t)wi.rng_row[tm] : (uint32_t)((int64_t)row_m + wi.row_offset);
+            const uint32_t pid = wi.particle ? (uint32_t)wi.particle[tm] : (uint32_t)j;
+            const uint64_t x = pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U);
+            int a = 0, b = ns;  // smallest index with prefix > x (index ns = the new row)
+            while (a < b) {
+              const int mid = (a + b) >> 1;
+              if (pref[mid] > x)
+                b = mid;
+              else
+                a = mid + 1;
+            }
+            if (a < ns) res = ksv[a];
           }
-          res = a == ns ? (fr.is_leaf ? n - 1 : PCLEAN_CHOICE_NEW) : ksv[a];
+          draws_out[(size_t)tm * draw_is + (size_t)j * draw_ds] = res;
+        };
+        if (mem_per_pass > 0) {
+          for (int m0 = 0; m0 < n_mem; m0 += mem_per_pass) {
+            const int ms = m0 + slot_l;
+            if (slot_l < mem_per_pass && ms < n_mem) one_draw(m_lo + ms, draw_l);
+          }
+        } else {
+          const int n_out = n_mem * nd_eff;
+          for (int q = lane; q < n_out; q += 64) one_draw(m_lo + q / nd_eff, q % nd_eff);
         }
-        draws_out[(size_t)tm * draw_is + (size_t)j * draw_ds] = res;
       }
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_wave_barrier();
+    g = gn;
+    g_end = gn_end;
+    dv = dvn;
   }
 }
 
-typedef void (*wave_kernel_t)(const FastRootDev, const DensDev, const ItemsDev, uint64_t, uint32_t, uint32_t, int, int,
-                              const int32_t*, double*, int32_t*, int32_t*, unsigned int*);
+// log-sum-exp of every group from the (maximum, fixed-point total) the scan kernel left, scattered to the member items
+__global__ void group_lse_kernel(int n_groups, const int32_t* __restrict__ grp_off, const int32_t* __restrict__ members,
+                                 const double* __restrict__ g_m, const uint64_t* __restrict__ g_U,
+                                 double* __restrict__ lse_out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const double m = g_m[g];
+  if (m != m) return;  // overflowed group: the generic re-run writes its items
+  const double lse = pclean_lse_from_fix(m, g_U[g]);
+  if (!grp_off) {
+    lse_out[g] = lse;
+    return;
+  }
+  const int hi = grp_off[g + 1];
+  for (int mi = grp_off[g]; mi < hi; ++mi) lse_out[members[mi]] = lse;
+}
+
+typedef void (*wave_kernel_t)(const FastRootDev, const WaveItems, uint64_t, uint32_t, uint32_t, int, int, const int32_t*,
+                              unsigned int*, double*, uint64_t*, int32_t*, int32_t*, unsigned int*);
 
 static wave_kernel_t pick_kernel(int n_terms) {
   if (n_terms <= 2) return fk_root_wave_kernel<2>;
@@ -508,18 +683,24 @@ static wave_kernel_t pick_kernel(int n_terms) {
   return fk_root_wave_kernel<16>;
 }
 
-size_t pclean_fast_desc_words(int n_groups) { return (size_t)std::max(n_groups, 1) * GD_STRIDE; }
+// int32 words of desc_scratch for n_groups groups: descriptors, 8 chunk counters, per-group (maximum, total)
+size_t pclean_fast_desc_words(int n_groups) {
+  const size_t ng = (size_t)std::max(n_groups, 1);
+  return ng * GD_STRIDE + 16 + ng * 4;
+}
 
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
                             int32_t* desc_scratch) {
   if (it.n <= 0) return PCLEAN_OK;
-  DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(group_desc_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, dn, it, ch, it.n,
-                     desc_scratch);
-  // persistent grid: 4 groups (waves) per workgroup, up to 8 workgroups per CU
-  // persistent grid = what is resident at once (a workgroup that starts late would still own its full share)
+  const size_t ng = (size_t)it.n;
+  unsigned int* chunk_ctr = reinterpret_cast<unsigned int*>(desc_scratch + ng * GD_STRIDE);
+  double* g_m = reinterpret_cast<double*>(desc_scratch + ng * GD_STRIDE + 16);
+  uint64_t* g_U = reinterpret_cast<uint64_t*>(g_m + ng);
+  hipLaunchKernelGGL(group_desc_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, it, ch, it.n,
+                     desc_scratch, chunk_ctr);
+  // persistent grid = what is resident at once (a workgroup that starts late would find the counters drained anyway)
   wave_kernel_t kern = pick_kernel(fr.n_terms);
   static int resident[17] = {0};  // per kernel variant (indexed by its term capacity), queried once
   const int variant = fr.n_terms <= 2 ? 2 : fr.n_terms <= 4 ? 4 : fr.n_terms <= 8 ? 8 : fr.n_terms <= 12 ? 12 : 16;
@@ -528,15 +709,19 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
-    per_cu = std::min(per_cu, 6);  // 256-thread workgroups with ~100 SGPRs: the hardware admits 6 per CU (MI355X_MICROARCH.md)
+    per_cu = std::min(per_cu, 8);
     resident[variant] = n_cu * per_cu;
   }
   int wgs = resident[variant];
   if (const char* e = getenv("PCLEAN_WAVE_WGS")) wgs = std::max(1, atoi(e));
-  wgs = std::min(wgs, (it.n + 3) / 4);
-  wgs = (wgs + 7) & ~7;  // a multiple of the 8 XCDs (the kernel splits the groups into 8 contiguous ranges)
-  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, ctx->stream, fr, dn, it, seed, sweep, site,
-                     n_draws, it.n, desc_scratch, lse_out, draws_out, overflow_flag, overflow_count);
+  wgs = std::min(wgs, (it.n + 4 * WAVE_CHUNK - 1) / (4 * WAVE_CHUNK));
+  wgs = (wgs + 7) & ~7;  // a multiple of the 8 XCDs
+  WaveItems wi{it.grp_off ? it.members : nullptr, it.row, it.rng_row, it.particle, it.row_offset, it.draw_is, it.draw_ds};
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, ctx->stream, fr, wi, seed, sweep, site, n_draws, it.n, desc_scratch,
+                     chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count);
+  if (lse_out)
+    hipLaunchKernelGGL(group_lse_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, it.n, it.grp_off, it.members,
+                       g_m, g_U, lse_out);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }

@@ -664,6 +664,7 @@ struct FastRoot {  // candidate-compact tables of a reference slot (root_wave.hi
   std::vector<uint64_t> ver;
   DevBuf<double> prior_e, prior_n;
   DevBuf<uint16_t> alive;
+  DevBuf<uint8_t> zero_row;  // kpad zero bytes (byte row of a missing observation)
   int disabled = 0;  // > 0: the pre-filter does not pay for this node (most items overflowed): that many evaluations use the generic kernel
   int backoff = 64;  // length of the next disabled period (doubles every time the retry overflows again)
   uint64_t cmin_key = 0;  // (lmax, dmax, density-table stride) the cached c_min belongs to
@@ -738,6 +739,7 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
     f.prior_e.release();
     f.prior_n.release();
     f.alive.release();
+    f.zero_row.release();
   }
   s->tail_counts.release();
   for (auto& kv : s->memo) {
@@ -983,6 +985,30 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
   return PCLEAN_OK;
 }
 
+// The (up to three) terms of node n whose byte rows the integer pre-filter of root_wave.hip sums: plain
+// (compact-table) terms, longest latent strings first.  Returns their number; pre[p] = index within the node.
+static int prefilter_terms(pclean_ctx* ctx, const Block& b, const pclean_node& n, int32_t pre[3]) {
+  int order[PCLEAN_MAX_TERMS];
+  const int nt = std::min(n.n_terms, PCLEAN_MAX_TERMS);
+  for (int i = 0; i < nt; ++i) order[i] = i;
+  auto plain = [&](const pclean_term& tm) {
+    return tm.ctx_slot < 0 && tm.dens_kind == PCLEAN_DENS_ADD_TYPOS && tm.pair_table >= 0 && tm.pair_table < PCLEAN_MAX_TABLES &&
+           ctx->pair[tm.pair_table].valid;
+  };
+  std::stable_sort(order, order + nt, [&](int a, int c) {
+    const pclean_term& ta = b.terms[n.term_begin + a];
+    const pclean_term& tc = b.terms[n.term_begin + c];
+    if (plain(ta) != plain(tc)) return plain(ta);  // compact-table terms first
+    if (!plain(ta)) return false;
+    return ctx->pair[ta.pair_table].max_lat_len > ctx->pair[tc.pair_table].max_lat_len;
+  });
+  int n_compact = 0;
+  for (int i = 0; i < nt; ++i) n_compact += plain(b.terms[n.term_begin + i]) ? 1 : 0;
+  const int n_pre = std::min(3, n_compact);
+  for (int p = 0; p < 3; ++p) pre[p] = p < n_pre ? order[p] : 0;
+  return n_pre;
+}
+
 // Fast path of a reference slot (root_wave.hip): returns 1 and fills `fr` when the node is an FK
 // with many candidates whose terms are all plain AddTypos lookups in byte tables; 0 otherwise.
 static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev& fr, bool ev_mode = false) {
@@ -1038,13 +1064,13 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     fr.terms[i].obs_col = ctx->obs_override ? ctx->obs_override : ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
     fr.terms[i].max_typos = tm.max_typos;
     fr.terms[i].ctx_slot = tm.ctx_slot;
+    fr.terms[i].pair = (const uint8_t*)pt.d.p;  // ctx terms gather from it; plain terms look up the true distance
+    fr.terms[i].lat_len = pt.lat_len.p;         // behind a saturated compact byte
+    fr.terms[i].cand_col = t.cols.p + (size_t)tm.cand_col * t.n_rows;
+    fr.terms[i].n_lat = pt.n_lat;
     if (tm.ctx_slot >= 0) {  // scored by gathering (few survivors reach it)
       const FnTable& fnt = ctx->fn[tm.fn_table];
-      fr.terms[i].pair = (const uint8_t*)pt.d.p;
-      fr.terms[i].lat_len = pt.lat_len.p;
-      fr.terms[i].cand_col = t.cols.p + (size_t)tm.cand_col * t.n_rows;
       fr.terms[i].fn = fnt.fn.p;
-      fr.terms[i].n_lat = pt.n_lat;
       fr.terms[i].fn_nb = fnt.n_b;
       continue;
     }
@@ -1060,6 +1086,10 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     fr.terms[i].comp = f.comp[i].p;
     fr.terms[i].clen = f.clen[i].p;
   }
+  if ((int)f.zero_row.n < kpad || !f.zero_row.p) {
+    if (f.zero_row.alloc((size_t)kpad + 4096)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+    HIPCHK(ctx, hipMemsetAsync(f.zero_row.p, 0, f.zero_row.n, ctx->stream));
+  }
   if (f.prior_ver != t.version || !f.prior_n.p) {
     if ((!leaf && f.prior_e.alloc(kpad)) || f.prior_n.alloc(kpad) || f.alive.alloc(std::max(kpad >> 4, 1)))
       return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
@@ -1073,18 +1103,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   // pre-filter: the three terms with the longest latent strings discriminate best; c_min = the
   // smallest density cost of one edit over every (length, distance) the tables hold
   {
-    int order[PCLEAN_MAX_TERMS];
-    for (int i = 0; i < n.n_terms; ++i) order[i] = i;
-    std::stable_sort(order, order + n.n_terms, [&](int a, int c) {
-      const pclean_term& ta = b.terms[n.term_begin + a];
-      const pclean_term& tc = b.terms[n.term_begin + c];
-      if ((ta.ctx_slot >= 0) != (tc.ctx_slot >= 0)) return ta.ctx_slot < 0;  // compact-table terms first
-      return ctx->pair[ta.pair_table].max_lat_len > ctx->pair[tc.pair_table].max_lat_len;
-    });
-    int n_compact = 0;
-    for (int i = 0; i < n.n_terms; ++i) n_compact += b.terms[n.term_begin + i].ctx_slot < 0 ? 1 : 0;
-    fr.n_pre = std::min(3, n_compact);
-    for (int p = 0; p < 3; ++p) fr.pre[p] = p < fr.n_pre ? order[p] : 0;
+    fr.n_pre = prefilter_terms(ctx, b, n, fr.pre);
     const int stride = ctx->max_d + 1;
     const uint64_t ckey = ((uint64_t)lmax << 40) | ((uint64_t)dmax << 20) | (uint64_t)stride;
     if (f.cmin_key != ckey) {  // ~lmax x dmax host iterations: once per (table shape), not per launch
@@ -1107,7 +1126,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     } else {
       fr.inv_c = 1.0 / (cmin * (1.0 - 1e-9));
     }
-    fr.pad1 = fr.pad2 = 0;
+    fr.pad1 = 0;
     fr.prior_max_e = f.logc_max - t.scal[1];
     fr.prior_max_n = f.logc_max - t.scal[0];
   }
@@ -1117,6 +1136,9 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   fr.lmax = lmax;
   fr.dstride = dmax + 1;
   fr.is_leaf = leaf ? 1 : 0;
+  fr.atd = ctx->atd.p;
+  fr.atd_stride = ctx->max_d + 1;
+  fr.zero_row = f.zero_row.p;
   fr.alive = f.alive.p;
   fr.prior_e = leaf ? nullptr : f.prior_e.p;
   fr.prior_n = f.prior_n.p;
@@ -1139,7 +1161,7 @@ struct ItemGroups {
   const int32_t* uid = nullptr;      // [n] inclusive scan of head
 };
 static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
-                            ItemGroups& g);
+                            ItemGroups& g, int split_m = 0);
 // ---- aggregated evidence of latent-class sweeps -------------------------------------------------------------
 // (contract in enum_kernels.hip: candidate_score_ev)
 __global__ void item_of_pos_kernel(int n_ev, int n_items, const int32_t* __restrict__ off, int32_t* __restrict__ out) {
@@ -1436,7 +1458,8 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     if (n_draws > 0 && !scores_out && !snew_override && !ctx->force_generic && !il.rng_row && !il.ev_lo &&
         (fast || lds_kernel)) {
       ItemGroups g;
-      rc = make_item_groups(ctx, block_id, node_id, il, excl, g);
+      // wave kernel: at most ~2 x 256 draws per group (see item_head_kernel)
+      rc = make_item_groups(ctx, block_id, node_id, il, excl, g, fast ? std::max(4, 256 / std::max(n_draws, 1)) : 0);
       if (rc) return rc;
       if (g.n_groups > 0) {
         it.n = g.n_groups;
@@ -1539,6 +1562,8 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
 struct KeyColsDev {
   int32_t n_cols, use_ctx;
   const int32_t* col[32];
+  int32_t n_pre, pad;         // observed columns of the scan kernel's pre-filter terms (prefilter_terms): groups that
+  const int32_t* pre_col[3];  // share them are made adjacent so that a wave can reuse its survivor list
 };
 
 __device__ __forceinline__ uint64_t mix64(uint64_t h, uint32_t v) {
@@ -1555,24 +1580,35 @@ __global__ void item_key_kernel(int n, KeyColsDev kc, const int32_t* row, const 
   for (int c = 0; c < kc.n_cols; ++c) h = mix64(h, (uint32_t)kc.col[c][r]);
   if (kc.use_ctx && ctxv)
     for (int s = 0; s < PCLEAN_MAX_CTX; ++s) h = mix64(h, (uint32_t)ctxv[(size_t)i * PCLEAN_MAX_CTX + s]);
+  // Sort order = (referent, hash of the pre-filter observed values, hash of the whole tuple): groups of one
+  // referent end up adjacent (their waves run back to back and re-read the same byte rows from L2), and within
+  // a referent the groups that share the pre-filter rows are adjacent too (root_wave.hip reuses the scan).
+  // Short keys = few radix passes: 24 hash bits below the referent id, 32 hash bits without one; a
+  // collision of two different tuples can only split a group (item_head_kernel compares exactly).
+  uint64_t hp = 0x9e3779b97f4a7c15ull;
+  for (int c = 0; c < kc.n_pre; ++c) hp = mix64(hp, (uint32_t)kc.pre_col[c][r]);
   if (excl) {
-    // groups of one referent end up adjacent in the sorted order: their workgroups run back to back
-    // and re-read the same byte rows from L2 (the hash only has to separate tuples, order is free).
-    // Short keys = few radix passes: 24 hash bits below the referent id, 32 hash bits without one; a
-    // collision of two different tuples can only split a group (item_head_kernel compares exactly).
     h = mix64(h, (uint32_t)excl[i]);
-    h = ((uint64_t)(uint32_t)(excl[i] + 1) << 24) | (h >> 40);
+    const uint64_t low = kc.n_pre > 0 ? (((hp >> 52) << 12) | (h >> 52)) : (h >> 40);
+    h = ((uint64_t)(uint32_t)(excl[i] + 1) << 24) | low;
   } else {
-    h >>= 32;
+    h = kc.n_pre > 0 ? (((hp >> 48) << 16) | (h >> 48)) : (h >> 32);
   }
   key[i] = h;
   idx[i] = i;
 }
+// split_m > 0: a run of more than split_m items with one key is cut at every multiple of split_m (pieces of
+// split_m .. 2 split_m - 1 items): the scan kernel serialises the draws of a group in ONE wave, and its hand-out
+// of work balances at group granularity (the pieces are adjacent: the wave reuses the previous piece's scores).
 __global__ void item_head_kernel(int n, KeyColsDev kc, const int32_t* row, const int32_t* ctxv, const int32_t* excl,
-                                 const uint64_t* key, const int32_t* idx, int32_t* head) {
+                                 const uint64_t* key, const int32_t* idx, int32_t* head, int split_m) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   int h = 1;
+  if (split_m > 0 && j >= split_m && (j % split_m) == 0 && key[j] == key[j - split_m]) {
+    head[j] = 1;
+    return;
+  }
   if (j > 0 && key[j] == key[j - 1]) {
     const int a = idx[j], b = idx[j - 1];
     const int ra = row ? row[a] : a, rb = row ? row[b] : b;
@@ -1632,7 +1668,7 @@ __global__ void group_offsets_kernel(int n, const int32_t* head, const int32_t* 
 // Groups the items of `il` by (observed values of the sub-tree of node_id, ctx, excl).  g.n_groups == 0
 // when the sub-tree cannot be keyed, the list is small, or fewer than a quarter of the items are duplicates.
 static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
-                            ItemGroups& g) {
+                            ItemGroups& g, int split_m) {
   Block& b = ctx->block[block_id];
   std::set<int> cols;
   bool use_ctx = false;
@@ -1646,6 +1682,15 @@ static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const It
   for (int c : cols) {
     if (c < 0 || c >= ctx->n_cols) return pclean_fail(ctx, PCLEAN_ERR_ARG, "term column out of range");
     kc.col[kc.n_cols++] = ctx->obs.p + (size_t)c * ctx->n_rows + ctx->active_begin;
+  }
+  {
+    const pclean_node& nn = b.nodes[node_id];
+    int32_t pre[3];
+    kc.n_pre = nn.n_terms <= PCLEAN_MAX_TERMS ? prefilter_terms(ctx, b, nn, pre) : 0;
+    for (int q = 0; q < kc.n_pre; ++q) {
+      const int c = b.terms[nn.term_begin + pre[q]].obs_col;
+      kc.pre_col[q] = ctx->obs.p + (size_t)c * ctx->n_rows + ctx->active_begin;
+    }
   }
   uint64_t* key = scratch<uint64_t>(ctx, n);
   uint64_t* key_s = scratch<uint64_t>(ctx, n);
@@ -1667,7 +1712,8 @@ static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const It
   unsigned char* tmp = scratch<unsigned char>(ctx, std::max(tmp_sort, tmp_scan));
   if (!tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_sort, key, key_s, idx, idx_s, n, 0, key_bits, ctx->stream));
-  hipLaunchKernelGGL(item_head_kernel, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, key_s, idx_s, head);
+  hipLaunchKernelGGL(item_head_kernel, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, key_s, idx_s, head,
+                     split_m);
   HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(tmp, tmp_scan, head, uid, n, ctx->stream));
   int32_t n_unique = 0;
   HIPCHK(ctx, hipMemcpyAsync(&n_unique, uid + (n - 1), sizeof n_unique, hipMemcpyDeviceToHost, ctx->stream));
