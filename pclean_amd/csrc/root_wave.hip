@@ -35,6 +35,8 @@
 // host with the LDS-resident generic kernel — results are identical either way.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
+#include <cstdio>
 
 #include "../../include/pclean_detmath.h"
 #include "../../include/pclean_philox.h"
@@ -55,7 +57,7 @@
 #define WAVE_CHUNK 8           // consecutive groups a wave takes at a time
 #endif
 #ifndef WAVE_MIN_WAVES
-#define WAVE_MIN_WAVES 6       // resident workgroups per CU the register allocation aims at
+#define WAVE_MIN_WAVES 5       // resident workgroups per CU the register allocation aims at (measured: 5 beats 6, 7 and 8)
 #endif
 #define WAVE_DCUT_OK 24u       // a cut-off below this many summed edits is considered selective
 #define WAVE_GUESS 4u          // first cut-off tried when the descriptor's bound is useless (widened until something survives)
@@ -184,7 +186,7 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
     const double logden = excl >= 0 ? fr.scal[1] : fr.scal[0];
     double snew = 0.0;
     for (int c = 0; c < ch.n; ++c) {
-      size_t idx = (size_t)t;
+      size_t idx = (size_t)(it.out_pos ? it.out_pos[t] : t);  // per-item marginals are indexed by the output slot
       if (ch.obs_col[c]) {
         const int oc = ch.obs_col[c][row];
         idx = oc < 0 ? (size_t)ch.n_obs[c] : (size_t)oc;
@@ -239,6 +241,7 @@ struct WaveItems {
   const int32_t* row;       // identity when null
   const int32_t* rng_row;   // RNG row of an item (default: row + row_offset)
   const int32_t* particle;  // RNG particle of an item (n_draws == 1), default: the draw index
+  const int32_t* out_pos;   // where item t writes its outputs (identity when null)
   int64_t row_offset;
   int32_t draw_is, draw_ds;
 };
@@ -277,18 +280,34 @@ __device__ __forceinline__ int wave_excl_prefix5(int cnt, int& total) {
   return ex;
 }
 
-template <int NT>
-__global__ __launch_bounds__(256, WAVE_MIN_WAVES) void fk_root_wave_kernel(
+// -DWAVE_PHASE_CLOCK: per-phase cycle totals over all waves (s_memtime), printed by pclean_launch_root_fast for
+// launches of more than 100 000 groups — a measurement build, not the product build.
+#ifdef WAVE_PHASE_CLOCK
+__device__ unsigned long long g_wave_clk[16];
+#define WCLK(i)                                   \
+  {                                               \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    clk_acc[i] += now_ - clk_t;                   \
+    clk_t = now_;                                 \
+  }
+#else
+#define WCLK(i)
+#endif
+
+// CAP = survivors a wave keeps, WPG = waves per workgroup (production shape: <256, 4>; a one-wave 4096-survivor shape
+// was tried as a second chance for overflowed groups and is no faster than the generic kernel on flat posteriors).
+template <int NT, int CAP, int WPG>
+__global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_root_wave_kernel(
     const FastRootDev fr, const WaveItems wi, uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, int n_groups,
     const int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr, double* __restrict__ g_m,
     uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out, int32_t* __restrict__ overflow_flag,
     unsigned int* __restrict__ overflow_count) {
-  __shared__ uint64_t s_pref[4][WAVE_SURV_CAP + 8];
-  __shared__ double s_sc[4][WAVE_SURV_CAP + 8];
-  __shared__ int32_t s_k[4][WAVE_SURV_CAP + 8];
+  // exact scores and, later, the fixed-point prefix share one array: entry j is converted in place by lane j
+  __shared__ uint64_t s_pref[WPG][CAP + 8];
+  __shared__ int32_t s_k[WPG][CAP + 8];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint64_t* pref = s_pref[wave];
-  double* scv = s_sc[wave];
+  double* scv = reinterpret_cast<double*>(s_pref[wave]);
   int32_t* ksv = s_k[wave];
   const int kpad = fr.kpad, nquads = kpad >> 4, n_terms = fr.n_terms;
   const int nd_eff = n_draws > 0 ? n_draws : 1;
@@ -350,6 +369,10 @@ __global__ __launch_bounds__(256, WAVE_MIN_WAVES) void fk_root_wave_kernel(
   double p_m = 0.0;
   uint64_t p_U = 0;
 
+#ifdef WAVE_PHASE_CLOCK
+  unsigned long long clk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long clk_t = __builtin_readcyclecounter();
+#endif
   int g = 0, g_end = 0;
   resolve(grab(), g, g_end);
   int raw_next = steal < 8 ? grab() : 0;
@@ -366,6 +389,7 @@ __global__ __launch_bounds__(256, WAVE_MIN_WAVES) void fk_root_wave_kernel(
       }
     }
     const int dvn = (gn < gn_end && lane < GD_STRIDE) ? gd[(size_t)gn * GD_STRIDE + lane] : 0;
+    WCLK(0)  // chunk hand-out + descriptor request
     // ---- descriptor -> wave-uniform registers ----------------------------------------------------------------------
     const int m_lo = __builtin_amdgcn_readlane(dv, 0), m_hi = __builtin_amdgcn_readlane(dv, 1);
     const int t = __builtin_amdgcn_readlane(dv, 2);
@@ -391,7 +415,7 @@ __global__ __launch_bounds__(256, WAVE_MIN_WAVES) void fk_root_wave_kernel(
     // ---- pre-filter scan at cut-off `want` (or the cached list when it covers it): survivors -> ksv, ascending ----
     int ns = 0;
     auto scan = [&](uint32_t want) {
-      if (c_valid && po0 == c_o0 && po1 == c_o1 && po2 == c_o2 && want <= c_cut && c_ns <= WAVE_SURV_CAP) {
+      if (c_valid && po0 == c_o0 && po1 == c_o1 && po2 == c_o2 && want <= c_cut && c_ns <= CAP) {
         ns = c_ns;
         cut = c_cut;
         return;
@@ -445,13 +469,13 @@ __global__ __launch_bounds__(256, WAVE_MIN_WAVES) void fk_root_wave_kernel(
             int total;
             int pos = ns + wave_excl_prefix5(__builtin_popcount(m16), total);
             for (uint32_t mm = m16; mm; mm &= mm - 1) {
-              if (pos < WAVE_SURV_CAP) ksv[pos] = (q << 4) + __builtin_ctz(mm);
+              if (pos < CAP) ksv[pos] = (q << 4) + __builtin_ctz(mm);
               ++pos;
             }
             ns += total;
           }
         }
-        if (ns > WAVE_SURV_CAP && cs > want) {  // the slack alone overflowed the list: once more without it
+        if (ns > CAP && cs > want) {  // the slack alone overflowed the list: once more without it
           cs = want;
           continue;
         }
@@ -477,9 +501,11 @@ __global__ __launch_bounds__(256, WAVE_MIN_WAVES) void fk_root_wave_kernel(
       m = p_m;
       U = p_U;
     } else {
+    WCLK(1)  // descriptor decode
     for (;;) {
       scan(cut);
-      if (ns > WAVE_SURV_CAP) {
+      WCLK(2)  // scan
+      if (ns > CAP) {
         over = true;
         break;
       }
@@ -548,6 +574,7 @@ __global__ __launch_bounds__(256, WAVE_MIN_WAVES) void fk_root_wave_kernel(
         }
       }
       __builtin_amdgcn_wave_barrier();
+      WCLK(3)  // exact scores
       if (!refine) break;
       // refine: the best survivor's exact score (and the descriptor's bound) give the cut-off actually required
       double best = bound;
@@ -591,6 +618,7 @@ __global__ __launch_bounds__(256, WAVE_MIN_WAVES) void fk_root_wave_kernel(
       U = carry;
       __builtin_amdgcn_wave_barrier();
     }
+    WCLK(4)  // weights
     p_ns = ns;
     p_over = over;
     p_m = m;
@@ -600,9 +628,12 @@ __global__ __launch_bounds__(256, WAVE_MIN_WAVES) void fk_root_wave_kernel(
     p_valid = true;
     if (over) {  // flat posterior: the host re-runs these items with the generic kernel (flags are pre-zeroed)
       if (m_hi - m_lo == 1) {
-        if (lane == 0) overflow_flag[t] = PCLEAN_CHOICE_NEW;  // marker understood by compact_new_kernel
+        if (lane == 0) overflow_flag[wi.out_pos ? wi.out_pos[t] : t] = PCLEAN_CHOICE_NEW;  // marker understood by compact_new_kernel
       } else {
-        for (int mi = m_lo + lane; mi < m_hi; mi += 64) overflow_flag[wi.members[mi]] = PCLEAN_CHOICE_NEW;
+        for (int mi = m_lo + lane; mi < m_hi; mi += 64) {
+          const int tm = wi.members[mi];
+          overflow_flag[wi.out_pos ? wi.out_pos[tm] : tm] = PCLEAN_CHOICE_NEW;
+        }
       }
       if (lane == 0) {
         atomicAdd(overflow_count, (unsigned int)(m_hi - m_lo));
@@ -635,7 +666,7 @@ __global__ __launch_bounds__(256, WAVE_MIN_WAVES) void fk_root_wave_kernel(
             }
             if (a < ns) res = ksv[a];
           }
-          draws_out[(size_t)tm * draw_is + (size_t)j * draw_ds] = res;
+          draws_out[(size_t)(wi.out_pos ? wi.out_pos[tm] : tm) * draw_is + (size_t)j * draw_ds] = res;
         };
         if (mem_per_pass > 0) {
           for (int m0 = 0; m0 < n_mem; m0 += mem_per_pass) {
@@ -649,38 +680,48 @@ __global__ __launch_bounds__(256, WAVE_MIN_WAVES) void fk_root_wave_kernel(
       }
       __builtin_amdgcn_wave_barrier();
     }
+    WCLK(5)  // outputs + draws
     g = gn;
     g_end = gn_end;
     dv = dvn;
+#ifdef WAVE_PHASE_CLOCK
+    clk_acc[7] += 1;
+#endif
   }
+#ifdef WAVE_PHASE_CLOCK
+  clk_acc[6] = __builtin_readcyclecounter() - clk_t;
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_wave_clk[i], clk_acc[i]);
+  if (lane == 0) atomicAdd(&g_wave_clk[8], 1ull);
+#endif
 }
 
 // log-sum-exp of every group from the (maximum, fixed-point total) the scan kernel left, scattered to the member items
 __global__ void group_lse_kernel(int n_groups, const int32_t* __restrict__ grp_off, const int32_t* __restrict__ members,
-                                 const double* __restrict__ g_m, const uint64_t* __restrict__ g_U,
-                                 double* __restrict__ lse_out) {
+                                 const int32_t* __restrict__ out_pos, const double* __restrict__ g_m,
+                                 const uint64_t* __restrict__ g_U, double* __restrict__ lse_out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_groups) return;
   const double m = g_m[g];
-  if (m != m) return;  // overflowed group: the generic re-run writes its items
+  if (m != m) return;  // overflowed group: the re-run writes its items
   const double lse = pclean_lse_from_fix(m, g_U[g]);
   if (!grp_off) {
-    lse_out[g] = lse;
+    lse_out[out_pos ? out_pos[g] : g] = lse;
     return;
   }
   const int hi = grp_off[g + 1];
-  for (int mi = grp_off[g]; mi < hi; ++mi) lse_out[members[mi]] = lse;
+  for (int mi = grp_off[g]; mi < hi; ++mi) lse_out[out_pos ? out_pos[members[mi]] : members[mi]] = lse;
 }
 
 typedef void (*wave_kernel_t)(const FastRootDev, const WaveItems, uint64_t, uint32_t, uint32_t, int, int, const int32_t*,
                               unsigned int*, double*, uint64_t*, int32_t*, int32_t*, unsigned int*);
 
 static wave_kernel_t pick_kernel(int n_terms) {
-  if (n_terms <= 2) return fk_root_wave_kernel<2>;
-  if (n_terms <= 4) return fk_root_wave_kernel<4>;
-  if (n_terms <= 8) return fk_root_wave_kernel<8>;
-  if (n_terms <= 12) return fk_root_wave_kernel<12>;
-  return fk_root_wave_kernel<16>;
+  if (n_terms <= 2) return fk_root_wave_kernel<2, WAVE_SURV_CAP, 4>;
+  if (n_terms <= 4) return fk_root_wave_kernel<4, WAVE_SURV_CAP, 4>;
+  if (n_terms <= 8) return fk_root_wave_kernel<8, WAVE_SURV_CAP, 4>;
+  if (n_terms <= 12) return fk_root_wave_kernel<12, WAVE_SURV_CAP, 4>;
+  return fk_root_wave_kernel<16, WAVE_SURV_CAP, 4>;
 }
 
 // int32 words of desc_scratch for n_groups groups: descriptors, 8 chunk counters, per-group (maximum, total)
@@ -701,27 +742,45 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   hipLaunchKernelGGL(group_desc_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, it, ch, it.n,
                      desc_scratch, chunk_ctr);
   // persistent grid = what is resident at once (a workgroup that starts late would find the counters drained anyway)
+  const int wpg = 4;
   wave_kernel_t kern = pick_kernel(fr.n_terms);
   static int resident[17] = {0};  // per kernel variant (indexed by its term capacity), queried once
   const int variant = fr.n_terms <= 2 ? 2 : fr.n_terms <= 4 ? 4 : fr.n_terms <= 8 ? 8 : fr.n_terms <= 12 ? 12 : 16;
-  if (!resident[variant]) {
+  int& res = resident[variant];
+  if (!res) {
     int per_cu = 0, n_cu = 256;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 256, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)kern, 64 * wpg, 0) != hipSuccess || per_cu <= 0) per_cu = 4;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
     per_cu = std::min(per_cu, 8);
-    resident[variant] = n_cu * per_cu;
+    res = n_cu * per_cu;
   }
-  int wgs = resident[variant];
+  int wgs = res;
   if (const char* e = getenv("PCLEAN_WAVE_WGS")) wgs = std::max(1, atoi(e));
-  wgs = std::min(wgs, (it.n + 4 * WAVE_CHUNK - 1) / (4 * WAVE_CHUNK));
+  wgs = std::min(wgs, (it.n + wpg * WAVE_CHUNK - 1) / (wpg * WAVE_CHUNK));
   wgs = (wgs + 7) & ~7;  // a multiple of the 8 XCDs
-  WaveItems wi{it.grp_off ? it.members : nullptr, it.row, it.rng_row, it.particle, it.row_offset, it.draw_is, it.draw_ds};
-  hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), 0, ctx->stream, fr, wi, seed, sweep, site, n_draws, it.n, desc_scratch,
+  WaveItems wi{it.grp_off ? it.members : nullptr, it.row, it.rng_row, it.particle, it.out_pos, it.row_offset, it.draw_is,
+               it.draw_ds};
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * wpg), 0, ctx->stream, fr, wi, seed, sweep, site, n_draws, it.n, desc_scratch,
                      chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count);
+#ifdef WAVE_PHASE_CLOCK
+  if (it.n > 100000) {
+    unsigned long long h[16];
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_wave_clk), sizeof h);
+    const char* nm[7] = {"handout+desc", "decode", "scan", "exact", "weights", "draws+out", "tail"};
+    double tot = 0;
+    for (int i = 0; i < 6; ++i) tot += (double)h[i];
+    fprintf(stderr, "[wave clk] groups %d terms %d waves %llu (grid %d WGs): ", it.n, fr.n_terms, h[8], wgs);
+    for (int i = 0; i < 6; ++i) fprintf(stderr, "%s %.1f%% ", nm[i], 100.0 * (double)h[i] / tot);
+    fprintf(stderr, "| cycles/group %.0f, groups seen %llu\n", tot / (double)h[7], h[7]);
+    memset(h, 0, sizeof h);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_clk), h, sizeof h);
+  }
+#endif
   if (lse_out)
     hipLaunchKernelGGL(group_lse_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, it.n, it.grp_off, it.members,
-                       g_m, g_U, lse_out);
+                       it.out_pos, g_m, g_U, lse_out);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }
