@@ -58,6 +58,7 @@ def main():
                 c[0] += 1
                 c[1] += v
     names = sorted(merged, key=lambda k: -merged[k]["dur"])[:top]
+    names += [k for k in merged if "fk_root_wave_kernel" in k and "full-size" in k and k not in names]  # the dominant sweep kernels, always
     print(f"{'kernel':72s} {'disp':>6s} {'avg_ms':>9s}  counters (average per dispatch)")
     for k in names:
         m = merged[k]
@@ -73,7 +74,7 @@ def main():
             parts = [f"{n2}/SQ_WAVE_CYCLES={c[n2][1] / wc:.2f}" for n2 in ("SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY") if n2 in c]
             print(f"{'':72s}        -> " + ", ".join(parts))
     if out_json:
-        key = next((k for k in merged if "fk_root_wave_kernel<12>" in k and "full-size" in k), None)
+        key = next((k for k in merged if "fk_root_wave_kernel<12" in k and "full-size" in k), None)
         if key and "FETCH_SIZE" in merged[key]["counters"] and "WRITE_SIZE" in merged[key]["counters"]:
             c = merged[key]["counters"]
             b = (2 * c["FETCH_SIZE"][1] / c["FETCH_SIZE"][0] + c["WRITE_SIZE"][1] / c["WRITE_SIZE"][0]) * 1024
