@@ -408,7 +408,9 @@ class Trace:
     def commit_batch(self, begin, count, choice, new_rows, dedup=False):
         """Commit a batch of observed rows [begin, begin+count) (initialize_trace: rows had no
         referent before).  With dedup, identical new-row proposals of the batch become one row —
-        the sequential reference would have let the second row join the first row's new referent."""
+        the sequential reference would have let the second row join the first row's new referent.
+        Returns the number of latent rows of the blocks' root classes the batch created."""
+        created = 0
         for bi, blk in enumerate(self.lw.blocks):
             if blk.get("score"):
                 self.cur[bi, begin:begin + count] = 0
@@ -424,8 +426,10 @@ class Trace:
                     rank = np.empty(len(order), dtype=np.int64)
                     rank[order] = np.arange(len(order))
                     ch[rows_new] = self.materialise_bulk(bi, u[order])[rank[np.asarray(inv).reshape(-1)]]
+                    created += len(u)
                 else:
                     ch[rows_new] = self.materialise_bulk(bi, vals_new)
+                    created += len(vals_new)
             t = self.tables[cname]
             old = self.cur[bi, begin:begin + count]
             np.add.at(t.counts, ch, 1)
@@ -433,6 +437,7 @@ class Trace:
             self.cur[bi, begin:begin + count] = ch
             cand = np.unique(old[old >= 0])
             self.delete_rows_bulk(cname, cand[(t.counts[cand] == 0) & t.live[cand]])
+        return created
 
     # -- parameter moves (inference.jl:72-77 -> resample_value!) ----------------
     def resample_parameters(self, cname=None):

@@ -26,7 +26,9 @@ def main(particles=2, mh=True, iters=1, seed=0, shuffle=True):
     tr = Trace(lw, obs.shape[1], seed)
     cfg = InferenceConfig(iters, particles, use_mh_instead_of_pg=mh)
     t0 = time.time()
-    initialize_trace(eng, tr, cfg, seed)
+    # the table ships sorted by entity: without the shuffle the in-batch merge pass stands in for the reference's
+    # row-by-row visibility of new rows (inference.initialize_trace)
+    initialize_trace(eng, tr, cfg, seed, merge_rounds=0 if shuffle else 2)
     tr.check_consistency()
     print('after init:', {c: (t.n, t.n_live) for c, t in tr.tables.items()}, flush=True)
     t1 = time.time()
