@@ -20,8 +20,10 @@ It shares NOTHING with the product's lowering (LoweredModel's nodes / terms / co
 option tables): plans are derived here from the attribute references, JuliaNodes are evaluated by calling the
 model's Python function on strings.  tests/golden/literal_scores.json holds its per-candidate scores for rows of
 hospital_dirty.csv; the C++ oracle (CPU suite) and the HIP path (-m gpu) must reproduce them to 1e-12 relative.
-Scope: programs built from reference slots, AddTypos, StringPrior, ChooseUniformly, ChooseProportionally and JuliaNodes
-(hospital).  Gaussian / MaybeSwap / TimePrior programs (rents, flights) are covered by the C++ oracle only.
+Scope: programs built from reference slots, AddTypos, StringPrior (plain and keyed atoms), ChooseUniformly,
+ChooseProportionally, JuliaNodes (hospital) and — GaussBlockProposal below — directly observed latent attributes, own
+ChooseUniformly choices and a TransformedGaussian observation with an IndexedLookup mean (rents).  MaybeSwap /
+TimePrior programs (flights) are covered by the C++ oracle only.
 """
 import math
 import os
@@ -283,6 +285,137 @@ class BlockProposal:
     def scores(self):
         """{candidate key of the block's slot | 'NEW': log score}; the block's log-marginal is their logsumexp."""
         return self._slot_scores(self.fk.target, "", {})
+
+
+# ---- rents-shaped blocks: reference slot + directly observed latent attributes + own uniform choices + Gaussian ----
+def normal_logpdf(x, mean, std):
+    z = (x - mean) / std
+    return -0.5 * z * z - math.log(std) - 0.5 * math.log(2.0 * math.pi)
+
+
+class GaussBlockProposal:
+    """The enumerated proposal of a block `slot ~ Class; noisy ~ AddTypos(slot.attr); own ~ ChooseUniformly(...);
+    x ~ TransformedGaussian(param[f(slot values, own choices)], std, unit)` (experiments/rents/run.jl:13-25) for one
+    observed row.  Dirty columns bound to a latent path (`CountyKey => county.countykey`) are noise-free observations:
+    an existing row must carry exactly that value, a new row takes it (proposal_compiler.jl:277-293).  The own
+    choices that are not observed (the unit, a missing room type) are enumerated INSIDE every candidate branch
+    (proposal_compiler.jl:96-113); each contributes its ChooseUniformly density (choose_uniformly.jl:7-10).
+
+    mean_of(values: {lookup argument: string}) -> the MeanParameter's current value (add_noise.jl:15-21)."""
+
+    def __init__(self, trace, query, block_attrs, row, mean_of):
+        from pclean_amd.model import AddTypos, ChooseUniformly, TransformedGaussian
+        self.trace, self.model, self.query, self.mean_of = trace, trace.model, query, mean_of
+        self.ocls = self.model.classes[query.cls]
+        fks = [a for a in block_attrs if self.ocls.attr(a).kind == "fk"]
+        assert len(fks) == 1
+        self.fk = self.ocls.attr(fks[0])
+        pre = self.fk.name + "."
+        self.typos, self.direct, self.own_obs = [], {}, {}
+        for col, dirty_attr in query.obsmap.items():
+            v = row[col]
+            if dirty_attr.startswith(pre):          # noise-free observation of a value below the slot
+                self.direct[dirty_attr[len(pre):]] = v
+            elif dirty_attr in block_attrs:
+                a = self.ocls.attr(dirty_attr)
+                if isinstance(a.dist, AddTypos):
+                    assert a.dist.ref.startswith(pre)
+                    self.typos.append((a.dist.ref[len(pre):], v, a.dist.max_typos))
+                elif isinstance(a.dist, ChooseUniformly):
+                    self.own_obs[dirty_attr] = v     # observed own choice (None = missing)
+                elif isinstance(a.dist, TransformedGaussian):
+                    self.x = None if v is None else float(v)
+                    self.g = a
+        look = self.ocls.attr(self.g.dist.mean)
+        self.look_args = list(look.args)
+        self.own = [a for a in self.look_args if "." not in a]
+        if self.g.dist.unit not in self.own:
+            self.own.append(self.g.dist.unit)
+
+    def _gauss(self, below):
+        """log-sum over the unobserved own choices of: their uniform densities + the Gaussian density of x
+        (transformed_gaussian.jl:15-16: logpdf(Normal(mean, std), t.backward(x)) - log|t.deriv(t.backward(x))|).
+        `below` = {path below the slot: string} of the candidate."""
+        def rec(i, vals, lp):
+            if i == len(self.own):
+                unit = vals[self.g.dist.unit]
+                args = {a: (below[a.split(".", 1)[1]] if "." in a else vals[a]) for a in self.look_args}
+                xb = unit.backward(self.x)
+                return [lp + normal_logpdf(xb, self.mean_of(args), self.g.dist.std) - math.log(abs(unit.deriv(xb)))]
+            name = self.own[i]
+            opts = self.ocls.attr(name).dist.options
+            seen = self.own_obs.get(name)
+            out = []
+            for o in opts:
+                if seen is not None and o != seen:
+                    continue
+                out += rec(i + 1, dict(vals, **{name: o}), lp - math.log(len(opts)))
+            return out
+        return logsumexp(rec(0, {}, 0.0))
+
+    def _existing(self, cls, key):
+        row = self.trace.tables[cls][key]
+        sc = 0.0
+        for path, v in self.direct.items():
+            if v is not None and row[path] != v:
+                return -math.inf
+        for path, v, mt in self.typos:
+            if v is not None:
+                sc += add_typos_logpdf(v, row[path], mt)
+        return sc + self._gauss(row)
+
+    def _new(self, cls):
+        """fresh row: directly observed attributes take the observed value; every other own choice is enumerated over
+        its discrete proposal — independent sub-plans multiply, the one the Gaussian depends on carries it."""
+        from pclean_amd.model import ChooseProportionally, StringPrior, Unmodeled
+        c = self.model.classes[cls]
+        fixed = {p: v for p, v in self.direct.items() if v is not None}
+        gauss_paths = [a.split(".", 1)[1] for a in self.look_args if "." in a]
+        open_paths = [p for p in gauss_paths if p not in fixed]
+        assert len(open_paths) <= 1
+        total, gauss_done = 0.0, False
+        for a in c.attrs:
+            if a.kind != "choice":
+                continue
+            d = a.dist
+            if isinstance(d, Unmodeled):
+                assert a.name in fixed, "an Unmodeled attribute must be observed"
+                continue
+            if isinstance(d, StringPrior):
+                atoms = d.atoms[fixed[d.keyed_by]] if d.keyed_by else d.atoms
+                lps = [string_prior_logpdf(s_, d.min_len, d.max_len) for s_ in atoms]
+                options = list(atoms) + [d.dummy_value()]
+                lps = lps + [math.log1p(-math.exp(logsumexp(lps)))]
+            elif isinstance(d, ChooseProportionally):
+                probs = self.trace.params[(cls, d.param)]
+                options = list(d.options)
+                lps = [math.log(p) if p > 0 else -math.inf for p in probs]
+            else:
+                raise NotImplementedError(type(d))
+            sc = []
+            for o, lp in zip(options, lps):
+                if a.name in self.direct and self.direct[a.name] is not None and o != self.direct[a.name]:
+                    continue  # observed without noise: the other options are impossible
+                s_ = lp
+                for path, v, mt in self.typos:
+                    if path == a.name and v is not None:
+                        s_ += add_typos_logpdf(v, o, mt)
+                if a.name in open_paths or (not open_paths and a.name == gauss_paths[0]):
+                    s_ += self._gauss(dict(fixed, **{a.name: o}))
+                    gauss_done = True
+                sc.append(s_)
+            total += logsumexp(sc)
+        assert gauss_done
+        return total
+
+    def scores(self):
+        cls = self.fk.target
+        s, d = self.trace.py[cls]
+        counts = self.trace.counts[cls]
+        tot = sum(counts.values())
+        out = {k: (math.log(c - d) - math.log(tot + s)) + self._existing(cls, k) for k, c in counts.items()}
+        out["NEW"] = (math.log(s + d * len(counts)) - math.log(tot + s)) + self._new(cls)
+        return out
 
 
 def lit_trace_from(lowered, trace):

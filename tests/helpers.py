@@ -37,6 +37,28 @@ def hospital_setup(n_rows=None, seed=0):
     return dict(dirty=dirty, clean=clean, model=m, query=q, lw=lw, obs=obs, trace=tr)
 
 
+def rents_setup(n_rows=600, seed=3):
+    """rents (experiments/rents/run.jl) on the first n_rows rows, latent state from the clean values (a clean county
+    name that never occurs undamaged falls back to the dirty cell) — the deterministic state of the literal
+    interpreter's rents fixtures (tests/golden/literal_scores_rents.json)."""
+    dirty, clean = ex.rents_data()
+    dirty = {c: v[:n_rows] for c, v in dirty.items()}
+    clean = {c: v[:n_rows] for c, v in clean.items()}
+    m = ex.rents_model(dirty)
+    q = ex.rents_query(m)
+    lw = LoweredModel(m, q, dirty)
+    obs = lw.encode_observations(dirty)
+    n = obs.shape[1]
+    name_dom, state_dom = lw.latent_dom[("County", "name")], lw.latent_dom[("County", "state")]
+    names = [c if (c is not None and name_dom.get(c) >= 0) else d for c, d in zip(clean["County"], dirty["County"])]
+    states = []
+    for i in range(n):
+        v = clean["State"][i] if clean["State"][i] is not None and state_dom.get(clean["State"][i]) >= 0 else dirty["State"][i]
+        states.append(v if v is not None else state_dom.string(0))
+    tr = Trace.from_clean_values(lw, {0: {"countykey": list(dirty["CountyKey"]), "name": names, "state": states}}, n, seed)
+    return dict(dirty=dirty, clean=clean, model=m, query=q, lw=lw, obs=obs, trace=tr)
+
+
 def density_tables_cpu(oracle, max_len):
     L = oracle.lib()
     ml = max(max_len, 64)

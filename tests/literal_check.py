@@ -52,3 +52,33 @@ def check(S, score_node, rtol=1e-12):
             assert abs(lse[0] - fb["lse"]) <= 1e-9 * max(1.0, abs(fb["lse"])), (i, bi, "lse", lse[0], fb["lse"])
             n_checked += seen + 1
     return n_checked
+
+
+def check_rents(S, score_node, rtol=1e-10):
+    """rents fixtures (tests/golden/literal_scores_rents.json, generator make_literal_fixtures_rents.py): candidates
+    the noise-free observations rule out must score -inf, the others and the new row within rtol (the fixtures use a
+    plain log-sum-exp over the enumerated own choices, the product its fixed-point one: 2^-40 relative per term)."""
+    lw, tr = S["lw"], S["trace"]
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_scores_rents.json")))
+    t = tr.tables["County"]
+    n_checked = 0
+    for r in fx["rows"]:
+        i = r["row"]
+        lse, scores = score_node(0, np.array([i], np.int32), np.zeros((1, 2), np.int32), np.array([tr.cur[0, i]], np.int32), t.n)
+        scores = np.asarray(scores).reshape(-1)
+        assert len(scores) == t.n + 1
+        seen = impossible = 0
+        for k in range(t.n):
+            key = _content_key(lw, tr, "County", k)
+            if key in r["cands"]:
+                want = r["cands"][key]
+                assert abs(scores[k] - want) <= rtol * max(1.0, abs(want)), (i, key, scores[k], want)
+                seen += 1
+            else:
+                assert scores[k] == -np.inf, (i, key, scores[k])
+                impossible += 1
+        assert seen == len(r["cands"]), (i, seen, len(r["cands"]))
+        assert abs(scores[t.n] - r["new"]) <= rtol * max(1.0, abs(r["new"])), (i, "new", scores[t.n], r["new"])
+        assert abs(lse[0] - r["lse"]) <= 1e-9 * max(1.0, abs(r["lse"])), (i, "lse", lse[0], r["lse"])
+        n_checked += seen + 1
+    return n_checked

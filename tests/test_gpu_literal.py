@@ -24,3 +24,20 @@ def test_hip_path_reproduces_literal_scores():
         assert literal_check.check(S, score_node) > 1000
     finally:
         eng.close()
+
+
+def test_hip_path_reproduces_literal_scores_rents():
+    """rents fixtures (tests/golden/literal_scores_rents.json): equality constraints of noise-free observations, keyed
+    StringPrior, ChooseProportionally, own choices enumerated inside the candidate branch, TransformedGaussian."""
+    S = helpers.rents_setup()
+    eng = Engine(S["lw"], S["obs"], dist_mode=1)
+    try:
+        eng.upload_trace(S["trace"])
+
+        def score_node(block, rows, ctxv, excl, n_rows):
+            lse, scores, _ = eng.hip.score_node(block, 0, rows, ctxv=ctxv, excl=excl, n_cand=n_rows + 1, want_scores=True)
+            return lse, scores
+
+        assert literal_check.check_rents(S, score_node) >= 48
+    finally:
+        eng.close()

@@ -20,6 +20,21 @@ def test_cpp_oracle_reproduces_literal_scores(oracle):
     assert literal_check.check(S, score_node) > 1000
 
 
+def test_cpp_oracle_reproduces_literal_scores_rents(oracle):
+    """rents: noise-free observations of latent attributes, keyed StringPrior atoms + dummy, ChooseProportionally with
+    a learned parameter, own uniform choices enumerated inside the candidate branch, TransformedGaussian with an
+    IndexedLookup mean — 24 rows covering every missingness pattern."""
+    S = helpers.rents_setup()
+    lw, tr, obs = S["lw"], S["trace"], S["obs"]
+    w = helpers.mirror_world(oracle, lw, obs, tr, None, 1, helpers.option_logp_cpu(oracle, lw, tr))
+
+    def score_node(block, rows, ctxv, excl, n_rows):
+        lse, scores = w.eval_tree(block, 0, rows[0], ctxv[0], excl[0], n_rows + 1)
+        return [lse], scores
+
+    assert literal_check.check_rents(S, score_node) >= 48
+
+
 def test_literal_densities_match_kats():
     """The literal interpreter's own densities against SURVEY Appendix D's formula-derived values."""
     import os
