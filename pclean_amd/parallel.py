@@ -12,6 +12,8 @@ The exchange step between sweeps is:
 """
 import numpy as np
 
+from .trace import unique_rows
+
 
 def shard_bounds(n_rows, rank, world):
     """Contiguous block partition of the observed rows."""
@@ -195,11 +197,8 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
             # identical new-row proposals of one sweep become ONE latent row (as commit_batch does for the
             # initialisation): in the sequential reference the second row would have joined the first row's
             # new referent instead of creating a duplicate entity.  Rows are created in order of first occurrence.
-            u, first, inv = np.unique(g_vals, axis=0, return_index=True, return_inverse=True)
-            uo = np.argsort(first, kind="stable")
-            rank = np.empty(len(uo), dtype=np.int64)
-            rank[uo] = np.arange(len(uo))
-            new_ids = trace.materialise_bulk(bi, u[uo])[rank[np.asarray(inv).reshape(-1)]]
+            first, grp = unique_rows(g_vals)
+            new_ids = trace.materialise_bulk(bi, g_vals[first])[grp]
         else:
             new_ids = np.empty(0, dtype=np.int64)
         t = trace.tables[cname]

@@ -58,6 +58,29 @@ class ProbTableState:
         self.value = rng.beta(self.a + heads, self.b + tails)
 
 
+def unique_rows(vals):
+    """np.unique(vals, axis=0, return_index=True, return_inverse=True) restricted to what the commits need —
+    (index of the first occurrence of every distinct row, group id of every row), groups numbered in the order
+    np.unique sorts them is NOT needed — through one 64-bit hash per row and a 1-D sort; verified exactly, with
+    the slow path on a hash collision.  Returns (first [g], inv [k]) with groups ordered by first occurrence."""
+    vals = np.ascontiguousarray(vals)
+    k = len(vals)
+    if k == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    mult = (np.arange(1, vals.shape[1] + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
+    h = (vals.astype(np.int64).view(np.uint64) * mult).sum(axis=1, dtype=np.uint64)
+    h ^= h >> np.uint64(29)
+    _, first, inv = np.unique(h, return_index=True, return_inverse=True)
+    inv = np.asarray(inv).reshape(-1)
+    if not np.array_equal(vals[first][inv], vals):  # two different rows share a hash: exact grouping
+        _, first, inv = np.unique(vals, axis=0, return_index=True, return_inverse=True)
+        inv = np.asarray(inv).reshape(-1)
+    order = np.argsort(first, kind="stable")  # groups in order of first occurrence
+    rank = np.empty(len(order), dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    return first[order], rank[inv]
+
+
 class LatentTable:
     def __init__(self, n_cols, strength=1.0, discount=0.0, cap=16):
         self.n_cols = n_cols
@@ -79,6 +102,26 @@ class LatentTable:
             self.live = np.concatenate([self.live, np.zeros(cap - self.n, bool)])
         self.n += 1
         return self.n - 1
+
+    def alloc_many(self, k):
+        """The ids k successive alloc() calls would return, without the Python call per row."""
+        take = min(k, len(self.free))
+        ids = np.empty(k, dtype=np.int64)
+        if take:
+            ids[:take] = self.free[:-take - 1:-1] if take < len(self.free) else self.free[::-1]
+            del self.free[len(self.free) - take:]
+        rest = k - take
+        if rest:
+            need = self.n + rest
+            if need > self.cols.shape[1]:
+                cap = max(16, 2 * self.n, need)
+                grow = cap - self.cols.shape[1]
+                self.cols = np.concatenate([self.cols, np.zeros((self.n_cols, grow), np.int32)], axis=1)
+                self.counts = np.concatenate([self.counts, np.zeros(grow, np.int64)])
+                self.live = np.concatenate([self.live, np.zeros(grow, bool)])
+            ids[take:] = np.arange(self.n, need)
+            self.n = need
+        return ids
 
     def view(self):
         return self.cols[:, :self.n], self.counts[:self.n]
@@ -230,7 +273,7 @@ class Trace:
         """insert_row for the rows of `values` [k][n_cols], in order; returns their row ids."""
         t = self.tables[cname]
         k = len(values)
-        ids = np.fromiter((t.alloc() for _ in range(k)), dtype=np.int64, count=k)
+        ids = t.alloc_many(k)
         t.cols[:, ids] = values.T
         t.cols_dirty = True
         t.counts[ids] = 0
@@ -421,12 +464,9 @@ class Trace:
             if len(rows_new):
                 vals_new = np.asarray(vals_new)
                 if dedup:  # one row per distinct proposal, created in order of first occurrence
-                    u, first, inv = np.unique(vals_new, axis=0, return_index=True, return_inverse=True)
-                    order = np.argsort(first, kind="stable")
-                    rank = np.empty(len(order), dtype=np.int64)
-                    rank[order] = np.arange(len(order))
-                    ch[rows_new] = self.materialise_bulk(bi, u[order])[rank[np.asarray(inv).reshape(-1)]]
-                    created += len(u)
+                    first, grp = unique_rows(vals_new)
+                    ch[rows_new] = self.materialise_bulk(bi, vals_new[first])[grp]
+                    created += len(first)
                 else:
                     ch[rows_new] = self.materialise_bulk(bi, vals_new)
                     created += len(vals_new)

@@ -249,3 +249,29 @@ def test_pitman_yor_score_lgamma_form_matches_oracle_direct_form(oracle):
         got = Trace.pitman_yor_score(s, d, counts)
         want = oracle.pitman_yor_score(s, d, counts)
         assert abs(got - want) <= 1e-9 * max(1.0, abs(want)), (s, d, counts, got, want)
+
+
+def test_bulk_commit_helpers_match_their_row_by_row_definitions():
+    """trace.unique_rows (hashed grouping of new-row proposals) against np.unique(axis=0) + first-occurrence order,
+    LatentTable.alloc_many against repeated alloc() (free list consumed from its end, then fresh ids)."""
+    from pclean_amd.trace import LatentTable, unique_rows
+    rng = np.random.default_rng(1)
+    for k in (0, 1, 5, 1000):
+        v = rng.integers(-2, 4, size=(k, 5)).astype(np.int32)
+        first, grp = unique_rows(v)
+        if k:
+            u, f, inv = np.unique(v, axis=0, return_index=True, return_inverse=True)
+            o = np.argsort(f, kind="stable")
+            rank = np.empty(len(o), np.int64)
+            rank[o] = np.arange(len(o))
+            assert np.array_equal(first, f[o]) and np.array_equal(grp, rank[np.asarray(inv).reshape(-1)])
+    t1, t2 = LatentTable(3), LatentTable(3)
+    for t in (t1, t2):
+        for _ in range(20):
+            t.alloc()
+        t.free = [3, 7, 11, 15]
+    for k in (9, 2, 0):
+        assert [t1.alloc() for _ in range(k)] == list(t2.alloc_many(k))
+        assert t1.n == t2.n and t1.free == t2.free and t2.cols.shape[1] >= t2.n
+    t1.free, t2.free = [1, 2, 3], [1, 2, 3]
+    assert [t1.alloc() for _ in range(2)] == list(t2.alloc_many(2)) and t1.free == t2.free
