@@ -22,8 +22,8 @@ model's Python function on strings.  tests/golden/literal_scores.json holds its 
 hospital_dirty.csv; the C++ oracle (CPU suite) and the HIP path (-m gpu) must reproduce them to 1e-12 relative.
 Scope: programs built from reference slots, AddTypos, StringPrior (plain and keyed atoms), ChooseUniformly,
 ChooseProportionally, JuliaNodes (hospital) and — GaussBlockProposal below — directly observed latent attributes, own
-ChooseUniformly choices and a TransformedGaussian observation with an IndexedLookup mean (rents).  MaybeSwap /
-TimePrior programs (flights) are covered by the C++ oracle only.
+ChooseUniformly choices and a TransformedGaussian observation with an IndexedLookup mean (rents), and — PriorSlotProposal / score_block below — slots with nothing but noise-free
+observations, TimePrior and a block of MaybeSwap observations (flights).
 """
 import math
 import os
@@ -418,6 +418,96 @@ class GaussBlockProposal:
         return out
 
 
+# ---- flights-shaped blocks: slots with noise-free observations only, TimePrior, a block of MaybeSwap observations ----
+import re
+
+_TIME_RE = re.compile(r"^[0-9]?[0-9]:[0-9][0-9] [ap]\.m\.$")  # time_prior.jl:10
+
+
+def maybe_swap_logpdf(observed, val, options, prob):
+    """maybe_swap.jl:13-28 (a missing observation is an observed value)."""
+    if observed is None:
+        return 0.0 if val in options else -1000.0
+    if val == observed:
+        return math.log1p(-prob)
+    return math.log(prob) - math.log(len(options))
+
+
+def own_choice_proposal(trace, cls, attr, row_values):
+    """(options, log-probabilities) of the discrete proposal of an own choice of a NEW row whose already fixed
+    values are row_values (the key of keyed atoms)."""
+    from pclean_amd.model import StringPrior, TimePrior
+    d = attr.dist
+    if isinstance(d, TimePrior):  # time_prior.jl:8-14
+        atoms = d.atoms[row_values[d.keyed_by]]
+        lps = [(-math.log(1440.0) if _TIME_RE.match(a) else -math.inf) for a in atoms]
+        return list(atoms) + [d.dummy_value()], lps + [math.log1p(-math.exp(logsumexp(lps)))]
+    if isinstance(d, StringPrior) and d.keyed_by:
+        atoms = d.atoms[row_values[d.keyed_by]]
+        lps = [string_prior_logpdf(a, d.min_len, d.max_len) for a in atoms]
+        return list(atoms) + [d.dummy_value()], lps + [math.log1p(-math.exp(logsumexp(lps)))]
+    options, lps, dummy = discrete_proposal(trace, cls, attr)
+    return [dummy if o is None else o for o in options], lps
+
+
+class PriorSlotProposal:
+    """Block `slot ~ Class` whose only observations are noise-free ones of the class's attributes
+    (`flight ~ Flight` with `flight => flight.flight_id`, experiments/flights/run.jl:24-26,43): existing rows must
+    carry the observed values (proposal_compiler.jl:277-293), scored by the CRP prior alone; the new row takes the
+    observed values — each at its prior density under its distribution's discrete proposal — and its other choices
+    are enumerated with nothing to score them: their proposals' masses (which sum to 1)."""
+
+    def __init__(self, trace, cls, direct):
+        self.trace, self.model, self.cls, self.direct = trace, trace.model, cls, direct
+
+    def scores(self):
+        s, d = self.trace.py[self.cls]
+        counts = self.trace.counts[self.cls]
+        tot = sum(counts.values())
+        out = {}
+        for k, c in counts.items():
+            row = self.trace.tables[self.cls][k]
+            ok = all(v is None or row[a] == v for a, v in self.direct.items())
+            out[k] = (math.log(c - d) - math.log(tot + s)) if ok else -math.inf
+        new = math.log(s + d * len(counts)) - math.log(tot + s)
+        fixed = {a: v for a, v in self.direct.items() if v is not None}
+        for a in self.model.classes[self.cls].attrs:
+            if a.kind != "choice":
+                continue
+            options, lps = own_choice_proposal(self.trace, self.cls, a, fixed)
+            if a.name in fixed:
+                new += logsumexp([lp for o, lp in zip(options, lps) if o == fixed[a.name]] or [-math.inf])
+            else:
+                new += logsumexp(lps)
+        out["NEW"] = new
+        return out
+
+
+def score_block(trace, query, block_attrs, row, referents):
+    """Block of observed choices without a latent choice (the four MaybeSwap observations of flights,
+    run.jl:29-34): sum of logdensity(MaybeSwap, observed, val, options, prob) with val / options / prob read through
+    the row's CURRENT referents; referents = {slot attribute: key}."""
+    from pclean_amd.model import MaybeSwap
+    model = trace.model
+    ocls = model.classes[query.cls]
+
+    def value(path):
+        head, rest = path.split(".", 1)
+        return trace.value(ocls.attr(head).target, referents[head], rest)
+
+    total = 0.0
+    for col, dirty_attr in query.obsmap.items():
+        if dirty_attr not in block_attrs:
+            continue
+        a = ocls.attr(dirty_attr)
+        assert isinstance(a.dist, MaybeSwap)
+        j = ocls.attr(a.dist.prob)  # ProbLookup JuliaNode
+        r = j.fn.fn(*[value(arg) for arg in j.args])
+        prob = r if isinstance(r, float) else trace.params[(query.cls, j.fn.param)][r]
+        total += maybe_swap_logpdf(row[col], value(a.dist.val), a.dist.options[value(a.dist.key)], prob)
+    return total
+
+
 def lit_trace_from(lowered, trace):
     """LitTrace holding the rows of a pclean_amd Trace as strings (decoding only: latent_dom gives the string of a
     value index, layout names the columns — no plan arrays involved).  Keys are the product's row ids."""
@@ -440,4 +530,7 @@ def lit_trace_from(lowered, trace):
         lt.py[cname] = (float(t.strength), float(t.discount))
     for (cname, pname), p in trace.params.items():
         lt.params[(cname, pname)] = np.asarray(p.value, dtype=np.float64)
+    if getattr(lw, "prob_spec", None) is not None:  # Dict{String, ProbParameter}: key string -> current value
+        pr = lw.prob_spec
+        lt.params[pr["param"]] = {k: float(v) for k, v in zip(pr["keys"], trace.prob_param.value)}
     return lt

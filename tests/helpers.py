@@ -59,6 +59,25 @@ def rents_setup(n_rows=600, seed=3):
     return dict(dirty=dirty, clean=clean, model=m, query=q, lw=lw, obs=obs, trace=tr)
 
 
+def flights_setup(seed=5):
+    """flights (experiments/flights/run.jl), latent state from the clean values: a Flight's time is the clean value
+    when that is one of the flight's observed atoms, else the TimePrior dummy (the states inference can reach) — the
+    deterministic state of the literal interpreter's flights fixtures (tests/golden/literal_scores_flights.json)."""
+    dirty, clean = ex.flights_data()
+    m = ex.flights_model(dirty)
+    q = ex.flights_query(m)
+    lw = LoweredModel(m, q, dirty)
+    obs = lw.encode_observations(dirty)
+    n = obs.shape[1]
+    cols = {"sdt": "sched_dep_time", "sat": "sched_arr_time", "adt": "act_dep_time", "aat": "act_arr_time"}
+    by0 = {"flight_id": list(dirty["flight"])}
+    for f, c in cols.items():
+        d = m.classes["Flight"].attr(f).dist
+        by0[f] = [clean[c][i] if clean[c][i] in d.atoms[dirty["flight"][i]] else d.dummy_value() for i in range(n)]
+    tr = Trace.from_clean_values(lw, {0: by0, 1: {"name": list(dirty["src"])}}, n, seed)
+    return dict(dirty=dirty, clean=clean, model=m, query=q, lw=lw, obs=obs, trace=tr)
+
+
 def density_tables_cpu(oracle, max_len):
     L = oracle.lib()
     ml = max(max_len, 64)

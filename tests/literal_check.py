@@ -82,3 +82,37 @@ def check_rents(S, score_node, rtol=1e-10):
         assert abs(lse[0] - r["lse"]) <= 1e-9 * max(1.0, abs(r["lse"])), (i, "lse", lse[0], r["lse"])
         n_checked += seen + 1
     return n_checked
+
+
+def check_flights(S, score_node, logml, rtol=1e-12):
+    """flights fixtures (tests/golden/literal_scores_flights.json): per-candidate scores of the two reference-slot
+    blocks through score_node, and logml [n_rows] of a ONE-particle conditional SMC sweep (nothing moves: the log
+    marginal likelihood estimate is the sum of the two block marginals and the scoring block's value)."""
+    lw, tr = S["lw"], S["trace"]
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_scores_flights.json")))
+    n_checked = 0
+    for r in fx["rows"]:
+        i = r["row"]
+        for bi, fb in enumerate(r["blocks"]):
+            cname = lw.blocks[bi]["root_class"]
+            assert cname == fb["cls"]
+            t = tr.tables[cname]
+            lse, scores = score_node(bi, np.array([i], np.int32), np.zeros((1, 2), np.int32),
+                                     np.array([tr.cur[bi, i]], np.int32), t.n)
+            scores = np.asarray(scores).reshape(-1)
+            seen = 0
+            for k in range(t.n):
+                key = _content_key(lw, tr, cname, k)
+                if key in fb["cands"]:
+                    want = fb["cands"][key]
+                    assert abs(scores[k] - want) <= rtol * max(1.0, abs(want)), (i, bi, key, scores[k], want)
+                    seen += 1
+                else:
+                    assert scores[k] == -np.inf, (i, bi, key, scores[k])
+            assert seen == len(fb["cands"]), (i, bi, seen, len(fb["cands"]))
+            assert abs(scores[t.n] - fb["new"]) <= 1e-10 * max(1.0, abs(fb["new"])), (i, bi, "new", scores[t.n], fb["new"])
+            assert abs(lse[0] - fb["lse"]) <= 1e-9 * max(1.0, abs(fb["lse"])), (i, bi, "lse", lse[0], fb["lse"])
+            n_checked += seen + 1
+        assert abs(logml[i] - r["logml"]) <= 1e-9 * max(1.0, abs(r["logml"])), (i, "logml", logml[i], r["logml"])
+        n_checked += 1
+    return n_checked

@@ -35,6 +35,30 @@ def test_cpp_oracle_reproduces_literal_scores_rents(oracle):
     assert literal_check.check_rents(S, score_node) >= 48
 
 
+def test_cpp_oracle_reproduces_literal_scores_flights(oracle):
+    """flights: slots whose only observations are noise-free (CRP prior + equality), new rows with StringPrior and
+    keyed TimePrior proposals, the MaybeSwap scoring block (missing observations included) through the learned error
+    probabilities — per-candidate scores and the one-particle log marginal likelihood of 62 rows."""
+    import ctypes as C
+    from pclean_amd._lib import InferConfig
+    S = helpers.flights_setup()
+    lw, tr, obs = S["lw"], S["trace"], S["obs"]
+    w = helpers.mirror_world(oracle, lw, obs, tr, None, 1, helpers.option_logp_cpu(oracle, lw, tr))
+
+    def score_node(block, rows, ctxv, excl, n_rows):
+        lse, scores = w.eval_tree(block, 0, rows[0], ctxv[0], excl[0], n_rows + 1)
+        return [lse], scores
+
+    nb, n = tr.cur.shape
+    choice, chosen, logml = np.empty((nb, n), np.int32), np.empty(n, np.int32), np.empty(n)
+    cfg = InferConfig(1, 1, 1, 1, 0, 50, 100)  # one particle: the retained one
+    oracle.lib().pco_sweep_batched(w.h, C.byref(cfg), C.c_uint64(3), C.c_uint32(0), nb, C.c_int64(0),
+                                   oracle._p(np.ascontiguousarray(tr.cur), C.c_int32), oracle._p(choice, C.c_int32),
+                                   oracle._p(chosen, C.c_int32), oracle._p(logml, C.c_double))
+    assert np.array_equal(choice, tr.cur)
+    assert literal_check.check_flights(S, score_node, logml) > 300
+
+
 def test_literal_densities_match_kats():
     """The literal interpreter's own densities against SURVEY Appendix D's formula-derived values."""
     import os
