@@ -61,6 +61,7 @@ class Engine:
     def __init__(self, lowered, obs, device=0, dist_mode=_lib.DIST_DL, row_offset=0):
         self.lw = lowered
         self.obs = np.ascontiguousarray(obs, dtype=np.int32)
+        self.device, self.row_offset = device, row_offset
         self.hip = HipContext(device)
         self.dist_mode = dist_mode
         self.option_logp = {}
@@ -72,6 +73,29 @@ class Engine:
 
     def close(self):
         self.hip.close()
+
+    def reload(self):
+        """The lowered model grew (LoweredModel.relower: strings drawn for chosen dummy values joined latent
+        domains): a fresh context with the new string pool, pair / fn / option tables and plans.  Rare (a
+        ProposalDummyValue is only ever chosen for unobserved or very short strings), so nothing is patched
+        incrementally.  A device-side RCCL communicator is re-bound by the caller (init_device_comm)."""
+        self.hip.close()
+        self.hip = HipContext(self.device)
+        self.option_logp = {}
+        self._uploaded_shape = {}
+        self._upload_static()
+        if self.row_offset:
+            _lib.check(self.hip.h, self.hip.lib.pclean_set_row_offset(self.hip.h, _lib.C.c_int64(self.row_offset)),
+                       "pclean_set_row_offset")
+        self._dev_comm = False
+
+    def sample_prior_strings(self, dist, n, seed, stream):
+        """n draws of random(StringPrior) (string_prior.jl:28-40: length uniform on [min, max], bigram letters) or
+        random(TimePrior) (time_prior.jl:21-23) by the device samplers, as strings; counter = (seed, stream, i)."""
+        from . import sampling
+        if isinstance(dist, TimePrior):
+            return sampling.random_time_prior(self.hip, n, seed=seed, stream=stream)
+        return sampling.random_string_prior(self.hip, n, dist.min_len, dist.max_len, seed=seed, stream=stream)
 
     # -- static data ----------------------------------------------------------
     def _upload_gauss(self):

@@ -12,6 +12,8 @@ max(rejuv_frequency, n / max_sub_batches) rows and the class's parameters are re
                      pclean_sweep_latent (external likelihood over referring rows),
                      the observed class through pclean_sweep.
 """
+import os
+
 import numpy as np
 
 from .model import ChooseProportionally
@@ -115,6 +117,63 @@ def refresh_flattened(lw, trace):
                         if not np.array_equal(new, t.cols[jj, :t.n]):
                             t.cols[jj, :t.n] = new
                             t.cols_dirty = True
+
+
+def _after_commit(engine, trace, seed):
+    """what follows every commit: chosen dummy values get their prior draw (resample_dummies)"""
+    trace.dummy_stamp = getattr(trace, "dummy_stamp", 0) + 1
+    return resample_dummies(engine, trace, seed, trace.dummy_stamp)
+
+
+def resample_dummies(engine, trace, seed, stamp):
+    """block_proposal.jl:58-60: a RandomChoiceNode whose enumerated proposal chose the ProposalDummyValue gets
+    `random(node.dist, args...)` — a string from the bigram StringPrior / a random TimePrior time — as its value.
+    The sweeps keep the placeholder while they run (its mass and its likelihood are what the enumeration scored);
+    this step, run after every commit, replaces the placeholders of the rows that were just created: the strings
+    are drawn by the device samplers (counter = (seed, class / attribute / stamp, i): identical on every rank),
+    appended to the attribute's latent domain (LoweredModel.relower: pair / fn / equality tables grow a value) and
+    the engine reloads its static data.  Rare: the dummy wins only for unobserved or very short strings.
+    Particle weights: with no observation below the node the reference's weight p - q equals the block marginal up
+    to -log(dummy mass) ~ 1e-40, i.e. bit-identical in fp64; with an observation below it the reference re-scores
+    the sampled string while the sweep's weight used the placeholder's likelihood.
+    Returns the number of values replaced."""
+    from .model import StringPrior, TimePrior
+    lw = engine.lw
+    m = lw.model
+    todo = []
+    for ci, cname in enumerate(m.class_order):
+        t = trace.tables.get(cname)
+        if t is None or t.n == 0:
+            continue
+        for j, col in enumerate(lw.layout[cname]):
+            if col.kind != "val" or "." in col.name:
+                continue
+            d = m.classes[cname].attr(col.name).dist
+            if not isinstance(d, (StringPrior, TimePrior)):
+                continue
+            dummy = lw.latent_dom[(cname, col.name)].get(d.dummy_value())
+            rows = np.flatnonzero((t.cols[j, :t.n] == dummy) & t.live[:t.n])
+            if len(rows):
+                todo.append((cname, j, col.name, d, rows, (ci * 64 + j) * 65536 + (stamp & 0xffff)))
+    if not todo:
+        return 0
+    drawn = [engine.sample_prior_strings(d, len(rows), seed, stream) for cname, j, an, d, rows, stream in todo]
+    lw.relower({(cname, an): strings for (cname, j, an, d, rows, stream), strings in zip(todo, drawn)})
+    engine.reload()
+    trace.on_relower()
+    n = 0
+    for (cname, j, an, d, rows, stream), strings in zip(todo, drawn):
+        dom = lw.latent_dom[(cname, an)]
+        t = trace.tables[cname]
+        t.cols[j, rows] = [dom.index_of(s_) for s_ in strings]
+        t.cols_dirty = True
+        n += len(rows)
+    refresh_flattened(lw, trace)
+    if os.environ.get("PCLEAN_DEBUG_DUMMY"):
+        print(f"[pclean] {n} chosen dummy values resampled: " +
+              ", ".join(f"{cname}.{an} x{len(rows)} (e.g. {strings[0]!r})" for (cname, j, an, d, rows, st), strings in zip(todo, drawn)),
+              flush=True)
+    return n
 
 
 def _materialise_latent(lw, trace, pl, node, vals):
@@ -266,6 +325,8 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
             vals = comm.allgather_varlen_i32(vals).reshape(-1, len(pl["nodes"]))
         with _timed(f"latent/{cname}/commit"):
             changed += commit_latent(lw, trace, cname, live[b0:b1], chosen, vals)
+            if _after_commit(engine, trace, seed):
+                pl = lw.latent_plans[cname]  # (the lowered model was rebuilt in place)
     return changed
 
 
@@ -301,8 +362,10 @@ def _sweep_window(engine, trace, config, seed, sweep_idx, b0, b1, comm):
         moved = engine.sweep_moved() if light else None
         _gather_locals(trace, comm, b0, hi - lo, lo)
     with _timed("observed/exchange_commit"):
-        return exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True,
-                                   moved_local=moved, n_local=hi - lo, stats_reduced=reduced)
+        changed = exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True,
+                                      moved_local=moved, n_local=hi - lo, stats_reduced=reduced)
+        _after_commit(engine, trace, seed)
+        return changed
 
 
 def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None, max_sub_batches=32, verbose=False,
@@ -384,6 +447,7 @@ def initialize_trace(engine, trace, config, seed, max_batch=256, comm=None, merg
                     merged[bi] = (g_rows, g_vals)  # rank order == row order (contiguous shards)
             new_rows = merged
         created = trace.commit_batch(begin, count, choice, new_rows, dedup=True)
+        _after_commit(engine, trace, seed)
         if created >= max(2, count // 64) and count >= 4:  # (identical on every rank: the commit is replicated)
             for r in range(min(merge_rounds, len(cuts))):
                 mid = begin + min(max(int(count * cuts[r]), 1), count - 1)

@@ -245,8 +245,14 @@ class Column:
 class LoweredModel:
     """Domains, flattened table layouts, option tables and per-block plans."""
 
-    def __init__(self, model, query, dirty_columns, pool=None):
+    def __init__(self, model, query, dirty_columns, pool=None, extra_latent=None):
+        """extra_latent {(class, attribute): [strings]}: values a latent attribute holds although they are neither
+        proposal atoms nor the dummy — strings drawn by random(StringPrior / TimePrior) for a chosen
+        ProposalDummyValue (block_proposal.jl:58-60).  They are appended to the attribute's domain (ids of the
+        atoms and the dummy do not move) and are never options of a proposal."""
         self.model, self.query = model, query
+        self._dirty_columns = dirty_columns
+        self.extra_latent = {k: list(v) for k, v in (extra_latent or {}).items()}
         self.pool = pool or StringPool()
         self.latent_dom = {}   # (class, attr) -> Domain of latent values
         self.obs_dom = {}      # dirty attr name -> Domain of observed values
@@ -298,6 +304,8 @@ class LoweredModel:
                     dom = Domain(self.pool, d.options)
                 else:
                     continue
+                for s_ in self.extra_latent.get((cname, a.name), ()):
+                    dom.add(s_)
                 self.latent_dom[(cname, a.name)] = dom
         ocls = m.classes[self.query.cls]
         self.direct_obs = {}   # obs name -> (path or own attr name) observed without noise (clean == dirty)
@@ -333,6 +341,18 @@ class LoweredModel:
         self.query_columns = {dirty: col for col, dirty in self.query.obsmap.items()}
         self._never_missing = {dirty for col, dirty in self.query.obsmap.items()
                                if all(v is not None for v in dirty_columns[col])}
+
+    def relower(self, extra_latent):
+        """Grow latent domains by the strings of extra_latent {(class, attribute): [strings]} and rebuild every
+        derived table IN PLACE (pair / fn / equality tables, plans): value ids held by a trace stay valid, callers
+        keep their reference.  The engine has to reload its static data afterwards (Engine.reload)."""
+        merged = {k: list(v) for k, v in self.extra_latent.items()}
+        for k, v in extra_latent.items():
+            have = merged.setdefault(k, [])
+            have.extend(x for x in dict.fromkeys(v) if x not in have)
+        dirty = self._dirty_columns
+        self.__init__(self.model, self.query, dirty, None, merged)
+        self.encode_observations(dirty)
 
     def encode_observations(self, dirty_columns):
         """[n_cols][n_rows] int32 observed-domain indices, -1 = missing."""

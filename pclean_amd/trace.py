@@ -160,6 +160,17 @@ class Trace:
             prior = m.classes[spec["param"][0]].attr(spec["param"][1]).prior
             self.mean_param = MeanTableState(spec["n_mean"], prior.mean, prior.std, spec["sigma"], self.rng)
 
+    def on_relower(self):
+        """The lowered model was rebuilt in place with larger latent domains (LoweredModel.relower): drop the plans
+        cached from its arrays; a keyed parameter table gains prior draws for the keys that appeared."""
+        self._class_plans, self._node_plans = {}, {}
+        for t in self.tables.values():
+            t.cols_dirty = True
+        pr = self.lw.prob_spec
+        if pr is not None and self.prob_param is not None and len(pr["keys"]) > len(self.prob_param.value):
+            extra = self.rng.beta(self.prob_param.a, self.prob_param.b, size=len(pr["keys"]) - len(self.prob_param.value))
+            self.prob_param.value = np.concatenate([self.prob_param.value, extra])
+
     # -- MaybeSwap error probabilities -------------------------------------------------------------
     def _root_values(self, src):
         bi, col = src

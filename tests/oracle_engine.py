@@ -22,6 +22,19 @@ class OracleEngine:
     def upload_trace(self, trace):
         pass  # worlds are rebuilt from the trace at every sweep
 
+    def reload(self):
+        """the lowered model grew (LoweredModel.relower): drop the cached world, re-read the observations"""
+        self._w, self._logp = None, None
+
+    def sample_prior_strings(self, dist, n, seed, stream):
+        """same draws as Engine.sample_prior_strings (the oracle's samplers are bit-identical to the device's)"""
+        from pclean_amd import sampling
+        from pclean_amd.model import TimePrior
+        ro = self.oracle.RandomOracle()
+        if isinstance(dist, TimePrior):
+            return sampling.random_time_prior(ro, n, seed=seed, stream=stream)
+        return sampling.random_string_prior(ro, n, dist.min_len, dist.max_len, seed=seed, stream=stream)
+
     def _cfg(self, config):
         return InferConfig(config.num_iters, config.num_particles, 1, 1, int(config.use_mh_instead_of_pg),
                            config.rejuv_frequency, config.reporting_frequency)

@@ -1,5 +1,6 @@
 """CPU tests of the host-side mirror: DSL lowering, trace commit / GC, accuracy, config."""
 import ctypes as C
+import re
 
 import numpy as np
 import pytest
@@ -275,3 +276,44 @@ def test_bulk_commit_helpers_match_their_row_by_row_definitions():
         assert t1.n == t2.n and t1.free == t2.free and t2.cols.shape[1] >= t2.n
     t1.free, t2.free = [1, 2, 3], [1, 2, 3]
     assert [t1.alloc() for _ in range(2)] == list(t2.alloc_many(2)) and t1.free == t2.free
+
+
+def test_chosen_dummy_values_get_their_prior_draw(oracle):
+    """block_proposal.jl:58-60 through inference.resample_dummies: every placeholder of a TimePrior attribute is
+    replaced by a random(TimePrior) string that joins the latent domain (ids of the atoms and the dummy keep their
+    place, the lowering is rebuilt in place, the engine reloads); deterministic in (seed, stamp); sweeps go on."""
+    from oracle_engine import OracleEngine
+    from pclean_amd.engine import InferenceConfig
+    from pclean_amd.inference import resample_dummies
+    got = []
+    for rep in range(2):
+        S = helpers.flights_setup()
+        lw, tr, obs = S["lw"], S["trace"], S["obs"]
+        eng = OracleEngine(oracle, lw, obs, cached=True)
+        t = tr.tables["Flight"]
+        before = t.cols[:, :t.n].copy()
+        sizes = {k: len(d) for k, d in lw.latent_dom.items()}
+        atoms = {k: [d.string(i) for i in range(len(d))] for k, d in lw.latent_dom.items()}
+        dummies = {}
+        for a in ("sdt", "sat", "adt", "aat"):
+            j = lw.colidx["Flight"][a]
+            dummies[a] = (j, lw.latent_dom[("Flight", a)].get("**:** p.m."))
+        n_dummy = sum(int(((t.cols[j, :t.n] == dv) & t.live[:t.n]).sum()) for j, dv in dummies.values())
+        assert n_dummy > 5
+        assert resample_dummies(eng, tr, 7, 1) == n_dummy
+        assert resample_dummies(eng, tr, 7, 2) == 0  # nothing left to replace
+        for k, d in lw.latent_dom.items():  # domains only grew at their end
+            assert len(d) >= sizes[k] and [d.string(i) for i in range(sizes[k])] == atoms[k]
+        new_strings = []
+        for a, (j, dv) in dummies.items():
+            col = t.cols[j, :t.n]
+            assert not ((col == dv) & t.live[:t.n]).any()
+            moved = np.flatnonzero(col != before[j])
+            assert (before[j, moved] == dv).all()
+            new_strings += [lw.latent_dom[("Flight", a)].string(int(v)) for v in col[moved]]
+        assert all(re.match(r"^[0-9]?[0-9]:[0-9]?[0-9] [ap]\.m\.$", s_) for s_ in new_strings)
+        tr.check_consistency()
+        choice, chosen, logml, new_rows = eng.sweep(tr, InferenceConfig(1, 2, use_mh_instead_of_pg=True), 1, 0)
+        assert np.isfinite(logml).all()
+        got.append(new_strings)
+    assert got[0] == got[1]
