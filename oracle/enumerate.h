@@ -220,7 +220,7 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
             const int v2 = t.cols[(size_t)tm.cand_col * n + k];
             const int c = tm.ctx_mode == 0 ? ctxv[tm.ctx_slot] : ec;
             const bool same = o >= 0 && ptm.d[(size_t)o * ptm.n_lat + v2] == 0;
-            out[k] += mult * maybe_swap_term(w, o < 0, same, v2 != tm.fn_table, t.cols[(size_t)tm.max_typos * n + k], c);
+            out[k] += mult * maybe_swap_term(w, o < 0, same, v2 < tm.fn_table, t.cols[(size_t)tm.max_typos * n + k], c);
             continue;
           }
           if (o < 0) continue;

@@ -217,7 +217,7 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
           const OPair& pt = w.pair[stt.pair_table];
           const bool same = o >= 0 && pt.d[(size_t)o * pt.n_lat + val] == 0;
           const int nopt = w.fn[stt.nopt_fn].fn[src(stt.key_block, stt.key_col, p)];
-          acc2 += maybe_swap_term(w, o < 0, same, val != stt.other_val, nopt, pidx);
+          acc2 += maybe_swap_term(w, o < 0, same, val < stt.other_val, nopt, pidx);  /* ids from the dummy's on: not an option */
         }
         wts[p] += acc2;
       }

@@ -14,7 +14,7 @@ struct TermDev {
   int32_t n_lat, elem_bytes, dens_kind, max_typos, ctx_slot, fn_nb;
   int32_t ctx_mode, pad;    // 0: ctx of the item; 1: ctx of the evidence row, fn[ctx][cand]; 2: fn[cand][ctx]
   const int32_t* aux_col;   // MAYBE_SWAP: [n_cand] number of options of the candidate's key group
-  int32_t other_val, pad2;  // MAYBE_SWAP: latent value standing for "not one of the options"
+  int32_t other_val, pad2;  // MAYBE_SWAP: first latent value that is "not one of the options" (the dummy; strings drawn for a chosen dummy follow it)
 };
 
 // Gaussian observation with enumerated locals (pclean_gauss resolved to device pointers)

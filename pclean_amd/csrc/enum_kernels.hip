@@ -50,7 +50,7 @@ __device__ __forceinline__ double term_density(const TermDev& tm, const DensDev&
 // MaybeSwap (maybe_swap.jl:13-28): o = observed value index (-1 missing), same = strings equal
 __device__ __forceinline__ double maybe_swap_density(const TermDev& tm, const DensDev& dn, int o, int d, int val, int k,
                                                      int pidx) {
-  if (o < 0) return val == tm.other_val ? -1000.0 : 0.0;
+  if (o < 0) return val >= tm.other_val ? -1000.0 : 0.0;  // dummy and sampled strings (ids after it): not an option
   if (d == 0) return dn.prob_same[pidx];
   return dn.prob_diff[pidx] - dn.logn[tm.aux_col[k]];
 }

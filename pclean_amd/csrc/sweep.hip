@@ -269,7 +269,7 @@ __global__ void score_block_kernel(int n_rows, int P, ScoreBlockDev sb, double* 
     const int o = t.obs_col[i];
     double dens;
     if (o < 0)
-      dens = val == t.other_val ? -1000.0 : 0.0;
+      dens = val >= t.other_val ? -1000.0 : 0.0;  // the dummy, or a string drawn for one (ids after the dummy's)
     else if (t.pair[(size_t)o * t.n_lat + val] == 0)
       dens = sb.prob_same[pidx];
     else

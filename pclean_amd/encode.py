@@ -107,6 +107,21 @@ class Domain:
             self.ids.append(pid)
         return j
 
+    def add_extra(self, s):
+        """A value that is NOT one of the attribute's options even if its string equals one (a string drawn by
+        random(StringPrior / TimePrior) for a chosen dummy): always a new id after the ones added so far; `extra`
+        maps the string to it.  get / index_of keep answering with the first id of a string (the option)."""
+        if not hasattr(self, "extra"):
+            self.extra = {}
+        j = self.extra.get(s)
+        if j is None:
+            pid = self.pool.add(s)
+            j = len(self.ids)
+            self.ids.append(pid)
+            self.local.setdefault(pid, j)
+            self.extra[s] = j
+        return j
+
     def index_of(self, s):
         return self.local[self.pool.index[s]]
 

@@ -178,14 +178,29 @@ def resample_dummies(engine, trace, seed, stamp):
     if not todo:
         return 0
     drawn = [engine.sample_prior_strings(d, len(rows), seed, stream) for cname, j, an, d, rows, stream in todo]
-    lw.relower({(cname, an): strings for (cname, j, an, d, rows, stream), strings in zip(todo, drawn)})
+    # a draw that happens to be one of the row's OWN proposal atoms is that option; anything else is a value outside
+    # the options (MaybeSwap asks `val in options`, maybe_swap.jl:18) and gets an id after the dummy's — even when the
+    # string equals an atom listed under another key
+    own, extras = [], {}
+    for (cname, j, an, d, rows, stream), strings in zip(todo, drawn):
+        t = trace.tables[cname]
+        if getattr(d, "keyed_by", None):
+            kdom = lw.latent_dom[(cname, d.keyed_by)]
+            keys = [kdom.string(int(v)) for v in t.cols[lw.colidx[cname][d.keyed_by], rows]]
+            is_own = [s_ in d.atoms.get(k, ()) for s_, k in zip(strings, keys)]
+        else:
+            atoms = set(d.atoms)
+            is_own = [s_ in atoms for s_ in strings]
+        own.append(is_own)
+        extras[(cname, an)] = [s_ for s_, o in zip(strings, is_own) if not o]
+    lw.relower(extras)
     engine.reload()
     trace.on_relower()
     n = 0
-    for (cname, j, an, d, rows, stream), strings in zip(todo, drawn):
+    for (cname, j, an, d, rows, stream), strings, is_own in zip(todo, drawn, own):
         dom = lw.latent_dom[(cname, an)]
         t = trace.tables[cname]
-        t.cols[j, rows] = [dom.index_of(s_) for s_ in strings]
+        t.cols[j, rows] = [dom.index_of(s_) if o else dom.extra[s_] for s_, o in zip(strings, is_own)]
         t.cols_dirty = True
         n += len(rows)
     refresh_flattened(lw, trace)

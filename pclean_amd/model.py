@@ -305,7 +305,7 @@ class LoweredModel:
                 else:
                     continue
                 for s_ in self.extra_latent.get((cname, a.name), ()):
-                    dom.add(s_)
+                    dom.add_extra(s_)  # ids after the dummy's: never an option (MaybeSwap: "val in options")
                 self.latent_dom[(cname, a.name)] = dom
         ocls = m.classes[self.query.cls]
         self.direct_obs = {}   # obs name -> (path or own attr name) observed without noise (clean == dirty)

@@ -1,6 +1,8 @@
 """CPU tests of the host-side mirror: DSL lowering, trace commit / GC, accuracy, config."""
 import ctypes as C
+import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -316,4 +318,24 @@ def test_chosen_dummy_values_get_their_prior_draw(oracle):
         choice, chosen, logml, new_rows = eng.sweep(tr, InferenceConfig(1, 2, use_mh_instead_of_pg=True), 1, 0)
         assert np.isfinite(logml).all()
         got.append(new_strings)
+        if rep == 0:
+            # the drawn strings are values OUTSIDE the options (maybe_swap.jl:18 `in(val, options)`) — also the ~20 %
+            # of them that spell an atom of some other flight: the literal interpreter (strings) and the oracle (ids)
+            # must agree on the one-particle log marginal likelihood of every row of such a flight
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+            import literal as lit
+            import make_literal_fixtures_flights as mk
+            foreign = sum(s_ in [lw.latent_dom[("Flight", a)].string(i) for i in range(sizes[("Flight", a)])]
+                          for a in dummies for s_ in new_strings)
+            assert foreign > 0  # the interesting case occurs
+            choice, chosen, logml, new_rows = eng.sweep(tr, InferenceConfig(1, 1), 3, 0)
+            assert np.array_equal(choice, tr.cur)
+            lt0 = lit.lit_trace_from(lw, tr)
+            changed = np.flatnonzero((t.cols[:, :t.n] != before).any(axis=0))
+            rows = np.flatnonzero(np.isin(tr.cur[0], changed))[::3]
+            assert len(rows) > 40
+            for i in rows:
+                want = mk.row_fixture(dict(S, trace=tr), lt0, int(i))["logml"]
+                assert abs(logml[i] - want) <= 1e-9 * max(1.0, abs(want)), (i, logml[i], want)
     assert got[0] == got[1]
