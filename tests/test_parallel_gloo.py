@@ -148,7 +148,8 @@ def _run_inference(rank, world, port, out_path, name):
     eng = OracleEngine(orc, lw, obs)  # every rank holds all observations; the work is sharded
     tr = Trace(lw, obs.shape[1], 5)
     cfg = InferenceConfig(2, 3, rejuv_frequency=100)
-    initialize_trace(eng, tr, cfg, 17, max_batch=64, comm=comm)
+    # hospital (file order): with the in-batch merge pass; flights: chosen dummy values get their prior draws
+    initialize_trace(eng, tr, cfg, 17, max_batch=64, comm=comm, merge_rounds=2 if name == "hospital" else 0)
     tr.check_consistency()
     run_inference(eng, tr, cfg, 17, comm=comm)
     tr.check_consistency()
