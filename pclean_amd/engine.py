@@ -66,6 +66,7 @@ class Engine:
         self.dist_mode = dist_mode
         self.option_logp = {}
         self._uploaded_shape = {}
+        self._last_upload = {}
         self._upload_static()
         if row_offset:
             _lib.check(self.hip.h, self.hip.lib.pclean_set_row_offset(self.hip.h, _lib.C.c_int64(row_offset)),
@@ -83,6 +84,7 @@ class Engine:
         self.hip = HipContext(self.device)
         self.option_logp = {}
         self._uploaded_shape = {}
+        self._last_upload = {}
         self._upload_static()
         if self.row_offset:
             _lib.check(self.hip.h, self.hip.lib.pclean_set_row_offset(self.hip.h, _lib.C.c_int64(self.row_offset)),
@@ -191,28 +193,47 @@ class Engine:
 
     # -- dynamic data ---------------------------------------------------------
     def upload_trace(self, trace):
+        """Latent tables, parameter-dependent option priors and parameter tables of `trace` -> device.  Whatever is
+        byte-identical to the last upload is skipped: besides the copies that keeps the device-side versions — and
+        with them the per-value caches of option-list marginals and the compact byte tables — valid (between two
+        observed-class sweeps of one rejuvenation period only the root tables' counts move)."""
         lw, hip = self.lw, self.hip
         m = lw.model
+        last = self._last_upload
         for cname, t in trace.tables.items():
             cols, counts = t.view()
             key = (cname, t.n)
+            prev = last.get(("table", cname))
             if t.cols_dirty or self._uploaded_shape.get(cname) != key:
                 hip.set_table(lw.table_id[cname], np.ascontiguousarray(cols), counts, t.strength, t.discount)
                 t.cols_dirty = False
                 self._uploaded_shape[cname] = key
+            elif prev is not None and prev[1] == (t.strength, t.discount) and np.array_equal(prev[0], counts):
+                continue  # nothing moved in this table
             else:  # only reference counts moved: keep the device columns and their compact byte tables
                 hip.set_table(lw.table_id[cname], None, counts, t.strength, t.discount, n_cols=t.n_cols)
+            last[("table", cname)] = (counts.copy(), (t.strength, t.discount))
         for (cname, aname), dom in lw.latent_dom.items():
             d = m.classes[cname].attr(aname).dist
             if isinstance(d, ChooseProportionally):
                 with np.errstate(divide="ignore"):
                     logp = np.log(trace.params[(cname, d.param)].value)  # logprobs(), utils.jl:33-36
                 self.option_logp[(cname, aname)] = logp
+                prev = last.get(("options", cname, aname))
+                if prev is not None and np.array_equal(prev, logp):
+                    continue
                 hip.set_options(lw.option_id[(cname, aname)], lw.option_values[(cname, aname)], logp)
+                last[("options", cname, aname)] = logp.copy()
         if lw.prob_spec is not None:
-            hip.set_prob_table(trace.prob_table())
+            pt = trace.prob_table()
+            if last.get("prob") is None or not np.array_equal(last["prob"], pt):
+                hip.set_prob_table(pt)
+                last["prob"] = pt.copy()
         if getattr(lw, "gauss", None):
-            hip.set_mean_table(0, trace.mean_param.value)
+            mv = trace.mean_param.value
+            if last.get("mean") is None or not np.array_equal(last["mean"], mv):
+                hip.set_mean_table(0, mv)
+                last["mean"] = mv.copy()
             if self._gauss_pending:  # needs the mean table to exist
                 self._upload_gauss()
                 self._gauss_pending = False
