@@ -22,8 +22,9 @@ model's Python function on strings.  tests/golden/literal_scores.json holds its 
 hospital_dirty.csv; the C++ oracle (CPU suite) and the HIP path (-m gpu) must reproduce them to 1e-12 relative.
 Scope: programs built from reference slots, AddTypos, StringPrior (plain and keyed atoms), ChooseUniformly,
 ChooseProportionally, JuliaNodes (hospital) and — GaussBlockProposal below — directly observed latent attributes, own
-ChooseUniformly choices and a TransformedGaussian observation with an IndexedLookup mean (rents), and — PriorSlotProposal / score_block below — slots with nothing but noise-free
-observations, TimePrior and a block of MaybeSwap observations (flights).
+ChooseUniformly choices and a TransformedGaussian observation with an IndexedLookup mean (rents), — PriorSlotProposal / score_block — slots with nothing but noise-free observations,
+TimePrior and a block of MaybeSwap observations (flights), and — LatentProposal — the rejuvenation of a LATENT row's
+own choices / reference slots against its evidence set (ExternalLikelihoodNodes, hospital).
 """
 import math
 import os
@@ -506,6 +507,64 @@ def score_block(trace, query, block_attrs, row, referents):
         prob = r if isinstance(r, float) else trace.params[(query.cls, j.fn.param)][r]
         total += maybe_swap_logpdf(row[col], value(a.dist.val), a.dist.options[value(a.dist.key)], prob)
     return total
+
+
+# ---- latent-class rows: own choices and reference slots scored against the EVIDENCE SET ---------------------------------
+class LatentProposal(BlockProposal):
+    """Rejuvenation of a row of a latent class (pgibbs_sweep! over the class's own blocks, inference.jl:60-81) whose
+    choices are observed only THROUGH the rows that refer to it: every likelihood term of every referring observed row
+    (ExternalLikelihoodNodes, proposal_compiler.jl:306-350; block_proposal.jl:119-155) is summed.
+
+    top_attrs: the observed class's block the latent class hangs below (`['hosp', 'service', ...]`);
+    sub: the latent class's path below that block's reference slot ('' for the slot's own class, 'loc.', 'loc.county.');
+    evidence: [(observed: {dirty attribute: string | None}, ctx: {path of another block: string})] per referring row."""
+
+    def __init__(self, trace, query, top_attrs, sub, evidence, restricted=False):
+        self.trace, self.model, self.query = trace, trace.model, query
+        self.ocls = self.model.classes[query.cls]
+        self.restricted, self.sub = restricted, sub
+        fks = [a for a in top_attrs if self.ocls.attr(a).kind == "fk"]
+        assert len(fks) == 1
+        self.fk = self.ocls.attr(fks[0])
+        from pclean_amd.model import AddTypos
+        self.terms = []
+        pre = self.fk.name + "."
+        import copy
+        for observed, ctx in evidence:
+            row = copy.copy(self)  # (_term's closures read .observed / .ctx of the object they were made on: one per row)
+            row.observed, row.ctx = observed, ctx
+            for a in self.ocls.attrs:  # EVERY observed choice of the referring row that depends on a value below the slot,
+                if a.kind != "choice" or not isinstance(a.dist, AddTypos):  # whatever block of the observed class it sits in
+                    continue
+                ref = a.dist.ref
+                if "." in ref and not ref.startswith(pre):
+                    continue  # the clean value lives below another slot
+                t = row._term(a)
+                if t["paths"]:
+                    self.terms.append(t)
+
+    def leaf_scores(self, cls, attr_name):
+        """{option string: score} of the discrete proposal of the latent row's own choice (dummy under its string)."""
+        a = self.model.classes[cls].attr(attr_name)
+        path = self.sub + attr_name
+        terms = [t for t in self.terms if path in t["paths"]]
+        assert all(t["paths"] == [path] for t in terms)
+        options, lps, dummy = discrete_proposal(self.trace, cls, a)
+        return {(dummy if o is None else o): lp + sum(self._lik(t, {path: (dummy if o is None else o)}) for t in terms)
+                for o, lp in zip(options, lps)}
+
+    def slot_scores(self, attr_name):
+        """{key | 'NEW': score} of the candidates of the latent row's reference slot (its own reference already
+        removed from the trace by the caller)."""
+        cls = self.sub_class()
+        a = self.model.classes[cls].attr(attr_name)
+        return self._slot_scores(a.target, self.sub + attr_name + ".", {})
+
+    def sub_class(self):
+        c = self.model.classes[self.fk.target]
+        for part in [p for p in self.sub.split(".") if p]:
+            c = self.model.classes[c.attr(part).target]
+        return c.name
 
 
 def lit_trace_from(lowered, trace):

@@ -323,6 +323,16 @@ class World:
                                    n_scores)
         return lse, sc
 
+    def eval_tree_ev(self, block_id, node_id, ev_rows, ev_ctx, excl, n_scores):
+        """eval_tree for a latent-class work item: node of a latent plan scored against an evidence set."""
+        ev_rows = np.ascontiguousarray(ev_rows, np.int32)
+        ev_ctx = None if ev_ctx is None else np.ascontiguousarray(ev_ctx, np.int32)
+        sc = np.empty(n_scores)
+        self.L.pco_eval_tree_ev.restype = C.c_double
+        lse = self.L.pco_eval_tree_ev(self.h, block_id, node_id, len(ev_rows), _p(ev_rows, C.c_int32), _p(ev_ctx, C.c_int32),
+                                      int(excl), _p(sc, C.c_double), n_scores)
+        return lse, sc
+
     def score_node(self, block_id, node_id, rows, ctxv=None, excl=None, snew=None, seed=0, sweep=0, n_draws=0,
                    n_cand=None, want_scores=False):
         rows = np.ascontiguousarray(rows, np.int32)

@@ -187,6 +187,22 @@ double pco_eval_tree(const pco::World* w, int block_id, int node_id, int row, co
   return lse;
 }
 
+/* The same for a latent-class work item: `node_id` of the latent plan `block_id` scored against the EVIDENCE SET
+ * (observed rows ev_rows[0..n_ev), their per-row ctx values ev_ctx[n_ev][PCLEAN_MAX_CTX] or null) — what
+ * sweep_latent() draws from (proposal_compiler.jl:306-350). */
+double pco_eval_tree_ev(const pco::World* w, int block_id, int node_id, int n_ev, const int32_t* ev_rows,
+                        const int32_t* ev_ctx, int excl, double* scores, int n_scores) {
+  pco::Evidence ev;
+  ev.rows = ev_rows;
+  ev.ctx = ev_ctx;
+  ev.n = n_ev;
+  pco::RowCtx rc{w, block_id, 0, nullptr, 0, 0, 0, &ev, 0};
+  std::vector<double> s;
+  const double lse = pco::eval_tree(rc, node_id, excl, &s);
+  for (int k = 0; k < n_scores && k < (int)s.size(); ++k) scores[k] = s[k];
+  return lse;
+}
+
 /* ---- particle primitives -------------------------------------------------- */
 void pco_maybe_resample(int n_rows, int P, const double* logw, int retain_first, uint64_t seed, uint32_t sweep,
                         uint32_t block, int64_t row_offset, int32_t* ancestors, double* logml_inc, double* ess) {

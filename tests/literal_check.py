@@ -116,3 +116,56 @@ def check_flights(S, score_node, logml, rtol=1e-12):
         assert abs(logml[i] - r["logml"]) <= 1e-9 * max(1.0, abs(r["logml"])), (i, "logml", logml[i], r["logml"])
         n_checked += 1
     return n_checked
+
+
+def check_latent(S, eval_ev, rtol=1e-10):
+    """latent-row fixtures (tests/golden/literal_scores_latent.json): eval_ev(block_id, node_id, ev_rows, ev_ctx, excl,
+    n_scores) -> (lse, scores) for a node of a latent plan; evidence sets and ctx from the product's build_evidence."""
+    from pclean_amd.inference import build_evidence
+    lw, tr = S["lw"], S["trace"]
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_scores_latent.json")))
+    ev_cache = {}
+    n_checked = 0
+    for rec in fx["rows"]:
+        cname = rec["cls"]
+        if cname not in ev_cache:
+            ev_cache[cname] = build_evidence(lw, tr, cname)
+        live, ev_off, ev_rows, ev_ctx = ev_cache[cname]
+        t = tr.tables[cname]
+        (pos,) = [j for j, k in enumerate(live) if _content_key(lw, tr, cname, int(k)) == rec["content"]]
+        k = int(live[pos])
+        e0, e1 = int(ev_off[pos]), int(ev_off[pos + 1])
+        assert e1 - e0 == rec["n_evidence"], (cname, rec["content"], e1 - e0, rec["n_evidence"])
+        rows = ev_rows[e0:e1]
+        ctx = None if ev_ctx is None else ev_ctx[e0:e1]
+        pl = lw.latent_plans[cname]
+        for root, attr in zip(pl["roots"], pl["root_attr"]):
+            want = rec["roots"][attr]
+            if want["kind"] == "leaf":
+                opts = lw.option_values[(cname, attr)]
+                dom = lw.latent_dom[(cname, attr)]
+                lse, sc = eval_ev(pl["block_id"], root, rows, ctx, -1, len(opts))
+                assert len(want["scores"]) == len(opts)
+                for j, v in enumerate(opts):
+                    w_ = want["scores"][dom.string(int(v))]
+                    assert (sc[j] == w_) or abs(sc[j] - w_) <= rtol * max(1.0, abs(w_)), (cname, attr, dom.string(int(v)), sc[j], w_)
+                n_checked += len(opts)
+            else:
+                tcls = pl["node_info"][root]["cls"]
+                tt = tr.tables[tcls]
+                excl = int(t.cols[lw.colidx[cname][attr], k])
+                lse, sc = eval_ev(pl["block_id"], root, rows, ctx, excl, tt.n + 1)
+                seen = 0
+                for kk in range(tt.n):
+                    key = _content_key(lw, tr, tcls, kk)
+                    if key in want["cands"] and tt.live[kk] and not (kk == excl and tt.counts[kk] <= 1):
+                        w_ = want["cands"][key]
+                        assert abs(sc[kk] - w_) <= rtol * max(1.0, abs(w_)), (cname, attr, key, sc[kk], w_)
+                        seen += 1
+                    else:
+                        assert sc[kk] == -np.inf, (cname, attr, key, sc[kk])
+                assert seen == len(want["cands"]), (cname, attr, seen, len(want["cands"]))
+                assert abs(sc[tt.n] - want["new"]) <= rtol * max(1.0, abs(want["new"])), (cname, attr, "new", sc[tt.n], want["new"])
+                n_checked += seen + 1
+            assert abs(lse - want["lse"]) <= 1e-9 * max(1.0, abs(want["lse"])), (cname, attr, "lse", lse, want["lse"])
+    return n_checked

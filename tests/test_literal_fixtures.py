@@ -59,6 +59,16 @@ def test_cpp_oracle_reproduces_literal_scores_flights(oracle):
     assert literal_check.check_flights(S, score_node, logml) > 300
 
 
+def test_cpp_oracle_reproduces_literal_scores_of_latent_rows(oracle):
+    """Latent-class rejuvenation: 26 latent rows of the six hospital classes, every root of their latent
+    plans — own choices and reference slots — scored against the evidence set, incl. the cross-block JuliaNode term
+    whose other argument comes from each evidence row's OTHER referent (the per-evidence-row ctx of build_evidence)."""
+    S = helpers.hospital_setup()
+    lw, tr, obs = S["lw"], S["trace"], S["obs"]
+    w = helpers.mirror_world(oracle, lw, obs, tr, None, 1, helpers.option_logp_cpu(oracle, lw, tr))
+    assert literal_check.check_latent(S, w.eval_tree_ev) > 3500
+
+
 def test_literal_densities_match_kats():
     """The literal interpreter's own densities against SURVEY Appendix D's formula-derived values."""
     import os
