@@ -122,6 +122,10 @@ class Domain:
             self.extra[s] = j
         return j
 
+    def n_base(self):
+        """number of values that are not extras (for a StringPrior / TimePrior attribute: atoms + the dummy)"""
+        return len(self.ids) - len(getattr(self, "extra", {}))
+
     def index_of(self, s):
         return self.local[self.pool.index[s]]
 

@@ -171,7 +171,7 @@ class Engine:
                 continue
             elif isinstance(d, StringPrior):
                 # discrete_proposal(::StringPrior): atom scores + dummy mass (string_prior.jl:16-22)
-                ids = dom.id_array()[:-1]
+                ids = dom.id_array()[:dom.n_base() - 1]  # the atoms (the dummy is the last value before any drawn string)
                 offs = np.zeros(len(ids) + 1, dtype=np.int64)
                 lens = lw.pool.lens[ids]
                 np.cumsum(lens, out=offs[1:])

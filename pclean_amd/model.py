@@ -393,7 +393,7 @@ class LoweredModel:
             self._next_table += 1
             # option k of discrete_proposal(dist, ...) is latent-domain value k (atoms are unique,
             # string_prior.jl:15; the dummy value, if any, is last)
-            self.option_values[(cname, aname)] = np.arange(len(dom), dtype=np.int32)
+            self.option_values[(cname, aname)] = np.arange(dom.n_base(), dtype=np.int32)  # (drawn strings are no options)
             if cname in self.model.classes:
                 a = self.model.classes[cname].attr(aname)
                 d = getattr(a, "dist", None)

@@ -176,7 +176,7 @@ def option_logp_cpu(oracle, lw, trace):
                 lp[(keys == k) & (vals == dummy)] = oracle.dummy_logmass(sc[(keys == k) & (vals != dummy)])
             out[(cname, aname)] = lp
         elif isinstance(d, StringPrior):
-            ids = dom.id_array()[:-1]
+            ids = dom.id_array()[:dom.n_base() - 1]
             sc = np.array([oracle.string_prior(lm[off[i]:off[i + 1]], d.min_len, d.max_len, init, trans) for i in ids])
             out[(cname, aname)] = np.concatenate([sc, [oracle.dummy_logmass(sc)]])
         elif isinstance(d, Unmodeled) and cname != lw.query.cls:

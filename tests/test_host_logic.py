@@ -339,3 +339,43 @@ def test_chosen_dummy_values_get_their_prior_draw(oracle):
                 want = mk.row_fixture(dict(S, trace=tr), lt0, int(i))["logml"]
                 assert abs(logml[i] - want) <= 1e-9 * max(1.0, abs(want)), (i, logml[i], want)
     assert got[0] == got[1]
+
+
+def test_unobserved_string_attributes_get_bigram_draws(oracle):
+    """Hospitals whose records lost their name and phone cells: the new Hospital row's StringPrior attributes have no
+    observation, the enumeration chooses the ProposalDummyValue (99.99 % of the prior mass) and random(StringPrior)
+    supplies the value (block_proposal.jl:58-60).  The drawn strings join the latent domain AFTER the dummy and are
+    never options of a later proposal; inference goes on (unkeyed domains: option tables keep their size)."""
+    from oracle_engine import OracleEngine
+    from pclean_amd import experiments as ex
+    from pclean_amd.engine import InferenceConfig
+    from pclean_amd.inference import initialize_trace, run_inference
+    from pclean_amd.model import LoweredModel
+    from pclean_amd.trace import Trace
+    dirty, clean = ex.hospital_data()
+    dirty = {c: list(v[:240]) for c, v in dirty.items()}
+    prov = list(dict.fromkeys(dirty["ProviderNumber"]))[:3]
+    for i in range(240):
+        if dirty["ProviderNumber"][i] in prov:
+            dirty["HospitalName"][i] = None
+            dirty["PhoneNumber"][i] = None
+    (d,), _ = ex.shuffle_rows([dirty], 0)
+    m = ex.hospital_model(ex.possibilities_of(d))
+    lw = LoweredModel(m, ex.hospital_query(m), d)
+    obs = lw.encode_observations(d)
+    n_options = len(lw.option_values[("Hospital", "name")])
+    tr = Trace(lw, obs.shape[1], 0)
+    eng = OracleEngine(oracle, lw, obs, cached=True)
+    cfg = InferenceConfig(2, 2, use_mh_instead_of_pg=True)
+    initialize_trace(eng, tr, cfg, 1, max_batch=64)
+    run_inference(eng, tr, cfg, 1)
+    tr.check_consistency()
+    for attr, lo, hi in (("name", 3, 50), ("phone", 10, 10)):
+        dom = lw.latent_dom[("Hospital", attr)]
+        extras = list(getattr(dom, "extra", {}))
+        assert extras and all(lo <= len(s_) <= hi and set(s_) <= set("abcdefghijklmnopqrstuvwxyz .") for s_ in extras)
+        assert len(lw.option_values[("Hospital", attr)]) == dom.n_base() == len(dom) - len(extras)
+        t = tr.tables["Hospital"]
+        col = t.cols[lw.colidx["Hospital"][attr], :t.n][t.live[:t.n]]
+        assert not (col == dom.get(m.classes["Hospital"].attr(attr).dist.dummy_value())).any()  # no placeholder left
+    assert len(lw.option_values[("Hospital", "name")]) == n_options
