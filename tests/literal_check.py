@@ -169,3 +169,81 @@ def check_latent(S, eval_ev, rtol=1e-10):
                 n_checked += seen + 1
             assert abs(lse - want["lse"]) <= 1e-9 * max(1.0, abs(want["lse"])), (cname, attr, "lse", lse, want["lse"])
     return n_checked
+
+
+def check_latent_flights(S, eval_ev, rtol=1e-10):
+    """flights latent fixtures (tests/golden/literal_scores_latent_flights.json): time attributes of Flight rows; the
+    option table holds every key's atoms + dummies, the row's own key is selected by the equality term on the key
+    column: options of other flights must score -inf."""
+    from pclean_amd.inference import build_evidence
+    lw, tr = S["lw"], S["trace"]
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_scores_latent_flights.json")))
+    live, ev_off, ev_rows, ev_ctx = build_evidence(lw, tr, "Flight")
+    assert ev_ctx is not None  # the per-evidence-row error-probability index
+    pl = lw.latent_plans["Flight"]
+    n_checked = 0
+    for rec in fx["rows"]:
+        (pos,) = [j for j, k in enumerate(live) if _content_key(lw, tr, "Flight", int(k)) == rec["content"]]
+        k = int(live[pos])
+        e0, e1 = int(ev_off[pos]), int(ev_off[pos + 1])
+        assert e1 - e0 == rec["n_evidence"]
+        fid = int(tr.tables["Flight"].cols[lw.colidx["Flight"]["flight_id"], k])
+        for root, attr in zip(pl["roots"], pl["root_attr"]):
+            if attr not in rec["roots"]:
+                continue
+            want = rec["roots"][attr]
+            vals, keys = lw.option_values[("Flight", attr)], lw.option_keycol[("Flight", attr)]
+            dom = lw.latent_dom[("Flight", attr)]
+            lse, sc = eval_ev(pl["block_id"], root, ev_rows[e0:e1], ev_ctx[e0:e1], -1, len(vals))
+            seen = 0
+            for j in range(len(vals)):
+                if int(keys[j]) == fid:
+                    w_ = want["scores"][dom.string(int(vals[j]))]
+                    assert (sc[j] == w_) or abs(sc[j] - w_) <= rtol * max(1.0, abs(w_)), (rec["content"], attr, dom.string(int(vals[j])), sc[j], w_)
+                    seen += 1
+                else:
+                    assert sc[j] == -np.inf
+            assert seen == len(want["scores"])
+            assert abs(lse - want["lse"]) <= 1e-9 * max(1.0, abs(want["lse"])), (rec["content"], attr, lse, want["lse"])
+            n_checked += seen
+    return n_checked
+
+
+def check_latent_rents(S, eval_ev, rtol=1e-10):
+    """rents latent fixtures (tests/golden/literal_scores_latent_rents.json): County.name (keyed options: other keys'
+    options must score -inf) and County.state against the evidence set; S's trace must carry the fixture's own
+    choices (br = row % 5, unit = row % 2)."""
+    from pclean_amd.inference import build_evidence
+    lw, tr = S["lw"], S["trace"]
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_scores_latent_rents.json")))
+    live, ev_off, ev_rows, ev_ctx = build_evidence(lw, tr, "County")
+    assert ev_ctx is not None  # the referring rows' own choices
+    pl = lw.latent_plans["County"]
+    n_checked = 0
+    for rec in fx["rows"]:
+        (pos,) = [j for j, k in enumerate(live) if _content_key(lw, tr, "County", int(k)) == rec["content"]]
+        k = int(live[pos])
+        e0, e1 = int(ev_off[pos]), int(ev_off[pos + 1])
+        assert e1 - e0 == rec["n_evidence"]
+        ck = int(tr.tables["County"].cols[lw.colidx["County"]["countykey"], k])
+        for root, attr in zip(pl["roots"], pl["root_attr"]):
+            if attr not in rec["roots"]:
+                continue
+            want = rec["roots"][attr]
+            vals = lw.option_values[("County", attr)]
+            keys = lw.option_keycol.get(("County", attr))
+            dom = lw.latent_dom[("County", attr)]
+            lse, sc = eval_ev(pl["block_id"], root, ev_rows[e0:e1], ev_ctx[e0:e1], -1, len(vals))
+            seen = 0
+            for j in range(len(vals)):
+                if keys is None or int(keys[j]) == ck:
+                    w_ = want["scores"][dom.string(int(vals[j]))]
+                    assert (sc[j] == w_) or abs(sc[j] - w_) <= rtol * max(1.0, abs(w_)), (rec["content"], attr, dom.string(int(vals[j])), sc[j], w_)
+                    seen += 1
+                else:
+                    assert sc[j] == -np.inf
+            assert seen == len(want["scores"]), (attr, seen, len(want["scores"]))
+            if np.isfinite(want["lse"]):
+                assert abs(lse - want["lse"]) <= 1e-9 * max(1.0, abs(want["lse"])), (rec["content"], attr, lse, want["lse"])
+            n_checked += seen
+    return n_checked

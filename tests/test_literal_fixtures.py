@@ -69,6 +69,26 @@ def test_cpp_oracle_reproduces_literal_scores_of_latent_rows(oracle):
     assert literal_check.check_latent(S, w.eval_tree_ev) > 3500
 
 
+def test_cpp_oracle_reproduces_literal_scores_of_latent_flights(oracle):
+    """Latent Flight rows: keyed TimePrior options scored by the MaybeSwap observations of every referring row with
+    that row's own error probability (the per-evidence-row ctx of build_evidence), missing observations included."""
+    S = helpers.flights_setup()
+    lw, tr, obs = S["lw"], S["trace"], S["obs"]
+    w = helpers.mirror_world(oracle, lw, obs, tr, None, 1, helpers.option_logp_cpu(oracle, lw, tr))
+    assert literal_check.check_latent_flights(S, w.eval_tree_ev) > 150
+
+
+def test_cpp_oracle_reproduces_literal_scores_of_latent_counties(oracle):
+    """Latent County rows of rents: keyed StringPrior options under AddTypos evidence, ChooseProportionally options under
+    equality + TransformedGaussian evidence with every referring row's CURRENT own choices (per-evidence-row locals)."""
+    S = helpers.rents_setup()
+    lw, tr, obs = S["lw"], S["trace"], S["obs"]
+    n = len(tr.locals[0])
+    tr.locals[0][:] = np.stack([np.arange(n) % 5, np.arange(n) % 2], axis=1)  # the fixture's own choices
+    w = helpers.mirror_world(oracle, lw, obs, tr, None, 1, helpers.option_logp_cpu(oracle, lw, tr))
+    assert literal_check.check_latent_rents(S, w.eval_tree_ev) > 700
+
+
 def test_literal_densities_match_kats():
     """The literal interpreter's own densities against SURVEY Appendix D's formula-derived values."""
     import os
