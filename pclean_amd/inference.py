@@ -145,6 +145,43 @@ def _after_commit(engine, trace, seed):
     return resample_dummies(engine, trace, seed, trace.dummy_stamp)
 
 
+def _count_dummy_cases(lw, trace, todo, obs):
+    """Diagnostics of resample_dummies (trace.dummy_cases): how many of the chosen dummies had NO observation of their
+    attribute among the rows referring to the latent row (the sweep's particle weight is the reference's, bit for bit)
+    and how many had one in the block that enumerated them (the sweep's weight used the placeholder's likelihood where
+    the reference re-scores the drawn string — DESIGN.md §11).  Observations scored in a LATER block (flights'
+    MaybeSwap block) count as unobserved: that block re-scores whatever string the row holds."""
+    m, q = lw.model, lw.query
+    ocls = m.classes[q.cls]
+    cases = getattr(trace, "dummy_cases", None)
+    if cases is None:
+        cases = trace.dummy_cases = {"unobserved": 0, "observed": 0}
+    block_of = {a: bi for bi, b in enumerate(ocls.blocks) for a in b}
+    for cname, j, an, d, rows, stream in todo:
+        cols = []
+        for col, ref in q.cleanmap.items():  # dirty columns whose clean value is this attribute, scored in its slot's block
+            if "." not in ref:
+                continue
+            head, rest = ref.split(".", 1)
+            try:
+                cn, la = m.resolve(ocls.attr(head).target, rest)
+            except (KeyError, ValueError):
+                continue
+            if (cn, la.name) == (cname, an) and block_of.get(q.obsmap[col]) == block_of.get(head):
+                cols.append(q.obsmap[col])
+        if not cols or cname not in lw.latent_plans:
+            cases["unobserved"] += len(rows)
+            continue
+        pl = lw.latent_plans[cname]
+        bi = pl["src_block"]
+        assigned = np.flatnonzero(trace.cur[bi] >= 0)  # (during the initialisation later rows have no referent yet)
+        keys = _follow(lw, trace, lw.blocks[bi]["root_class"], trace.cur[bi][assigned], pl["path"])
+        for r in rows:
+            er = assigned[keys == r]
+            seen = any((obs[lw.obs_index[c], er] >= 0).any() for c in cols if c in lw.obs_index)
+            cases["observed" if seen else "unobserved"] += 1
+
+
 def resample_dummies(engine, trace, seed, stamp):
     """block_proposal.jl:58-60: a RandomChoiceNode whose enumerated proposal chose the ProposalDummyValue gets
     `random(node.dist, args...)` — a string from the bigram StringPrior / a random TimePrior time — as its value.
@@ -177,6 +214,7 @@ def resample_dummies(engine, trace, seed, stamp):
                 todo.append((cname, j, col.name, d, rows, (ci * 64 + j) * 65536 + (stamp & 0xffff)))
     if not todo:
         return 0
+    _count_dummy_cases(lw, trace, todo, engine.obs)
     drawn = [engine.sample_prior_strings(d, len(rows), seed, stream) for cname, j, an, d, rows, stream in todo]
     # a draw that happens to be one of the row's OWN proposal atoms is that option; anything else is a value outside
     # the options (MaybeSwap asks `val in options`, maybe_swap.jl:18) and gets an id after the dummy's — even when the
@@ -205,7 +243,7 @@ def resample_dummies(engine, trace, seed, stamp):
         n += len(rows)
     refresh_flattened(lw, trace)
     if os.environ.get("PCLEAN_DEBUG_DUMMY"):
-        print(f"[pclean] {n} chosen dummy values resampled: " +
+        print(f"[pclean] {n} chosen dummy values resampled (so far {trace.dummy_cases}): " +
               ", ".join(f"{cname}.{an} x{len(rows)} (e.g. {strings[0]!r})" for (cname, j, an, d, rows, st), strings in zip(todo, drawn)),
               flush=True)
     return n

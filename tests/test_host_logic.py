@@ -379,3 +379,5 @@ def test_unobserved_string_attributes_get_bigram_draws(oracle):
         col = t.cols[lw.colidx["Hospital"][attr], :t.n][t.live[:t.n]]
         assert not (col == dom.get(m.classes["Hospital"].attr(attr).dist.dummy_value())).any()  # no placeholder left
     assert len(lw.option_values[("Hospital", "name")]) == n_options
+    # every one of these dummies had no observation below it: the sweeps' particle weights were the reference's
+    assert tr.dummy_cases["unobserved"] >= 6 and tr.dummy_cases["observed"] == 0
