@@ -381,3 +381,12 @@ def test_unobserved_string_attributes_get_bigram_draws(oracle):
     assert len(lw.option_values[("Hospital", "name")]) == n_options
     # every one of these dummies had no observation below it: the sweeps' particle weights were the reference's
     assert tr.dummy_cases["unobserved"] >= 6 and tr.dummy_cases["observed"] == 0
+
+
+def test_stable_argsort_ids_equals_numpy_stable_sort():
+    """inference.stable_argsort_ids (16-bit radix digits) against np.argsort(kind="stable") on id-like keys."""
+    from pclean_amd.inference import stable_argsort_ids
+    rng = np.random.default_rng(1)
+    for n, lo, hi in ((0, 0, 1), (10, -1, 5), (100000, -1, 10500), (200000, 0, 300000), (1000, 5, 6), (5000, 70000, 70010)):
+        k = rng.integers(lo, hi, n).astype(np.int32) if n else np.zeros(0, np.int32)
+        assert np.array_equal(stable_argsort_ids(k), np.argsort(k, kind="stable")), (n, lo, hi)
