@@ -200,6 +200,12 @@ class HipContext:
         return out
 
     # -- candidate tables -----------------------------------------------------
+    def root_flags(self, n_rows):
+        """per row of the last sweep's block-0 root scan: bit 0 = re-run by the generic kernel, bit 1 = guess-and-refine"""
+        out = np.empty(n_rows, dtype=np.int32)
+        check(self.h, self.lib.pclean_debug_root_flags(self.h, C.c_int32(n_rows), _p(out, C.c_int32)), "pclean_debug_root_flags")
+        return out
+
     def force_generic(self, on):
         check(self.h, self.lib.pclean_debug_force_generic(self.h, C.c_int32(int(on))), "pclean_debug_force_generic")
 

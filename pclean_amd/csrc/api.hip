@@ -4,6 +4,9 @@
 #include <cmath>
 #include <limits>
 
+#include <map>
+#include <mutex>
+
 #include "ctx.h"
 
 static const double kNegInf = -std::numeric_limits<double>::infinity();
@@ -439,15 +442,38 @@ extern "C" int pclean_load_numeric_columns(pclean_ctx* ctx, int32_t n_rows, int3
   return PCLEAN_OK;
 }
 
+// Page-locked registrations are per process, not per context: two contexts sweeping the same trace (fast vs generic
+// comparisons, two distance flavours) pin the same `cur` array.  Registrations are reference-counted by address.
+static std::mutex g_pin_mu;
+static std::map<void*, std::pair<size_t, int>> g_pins;  // ptr -> (bytes, references)
 extern "C" int pclean_pin_host(pclean_ctx* ctx, void* ptr, size_t bytes) {
   if (!ctx || !ptr || bytes == 0) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_pin_host: bad arguments");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  HIPCHK(ctx, hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  auto it = g_pins.find(ptr);
+  if (it != g_pins.end() && it->second.first >= bytes) {
+    ++it->second.second;
+    return PCLEAN_OK;
+  }
+  if (it != g_pins.end())
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_pin_host: %p is already page-locked with a smaller size", ptr);
+  hipError_t e = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  if (e == hipErrorHostMemoryAlreadyRegistered) {  // registered by someone else (torch, the caller): theirs to release
+    (void)hipGetLastError();
+    return PCLEAN_OK;
+  }
+  if (e != hipSuccess) return pclean_fail(ctx, PCLEAN_ERR_HIP, "hipHostRegister failed: %s", hipGetErrorString(e));
+  g_pins[ptr] = std::make_pair(bytes, 1);
   return PCLEAN_OK;
 }
 extern "C" int pclean_unpin_host(pclean_ctx* ctx, void* ptr) {
   if (!ctx || !ptr) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_unpin_host: bad arguments");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> lk(g_pin_mu);
+  auto it = g_pins.find(ptr);
+  if (it == g_pins.end()) return PCLEAN_OK;  // not ours (see pclean_pin_host)
+  if (--it->second.second > 0) return PCLEAN_OK;
+  g_pins.erase(it);
   HIPCHK(ctx, hipHostUnregister(ptr));
   return PCLEAN_OK;
 }

@@ -713,6 +713,28 @@ __global__ void group_lse_kernel(int n_groups, const int32_t* __restrict__ grp_o
   for (int mi = grp_off[g]; mi < hi; ++mi) lse_out[out_pos ? out_pos[members[mi]] : members[mi]] = lse;
 }
 
+// debug (pclean_debug_root_flags): per item of the last launch, bit 0 = re-run by the generic kernel (survivor list
+// overflowed), bit 1 = its group was scanned in guess-and-refine mode
+__global__ void root_flags_kernel(int n_groups, const int32_t* __restrict__ gd, const int32_t* __restrict__ grp_off,
+                                  const int32_t* __restrict__ members, const int32_t* __restrict__ oflag,
+                                  int32_t* __restrict__ out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const int refine = (gd[(size_t)g * GD_STRIDE + 7] & 2) ? 2 : 0;
+  const int lo = grp_off ? grp_off[g] : g, hi = grp_off ? grp_off[g + 1] : g + 1;
+  for (int mi = lo; mi < hi; ++mi) {
+    const int t = grp_off ? members[mi] : g;
+    out[t] = refine | (oflag[t] != 0 ? 1 : 0);
+  }
+}
+int pclean_launch_root_flags(pclean_ctx* ctx, int n_groups, const int32_t* gd, const int32_t* grp_off,
+                             const int32_t* members, const int32_t* oflag, int32_t* out) {
+  hipLaunchKernelGGL(root_flags_kernel, dim3((n_groups + 255) / 256), dim3(256), 0, ctx->stream, n_groups, gd, grp_off,
+                     members, oflag, out);
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
+
 typedef void (*wave_kernel_t)(const FastRootDev, const WaveItems, uint64_t, uint32_t, uint32_t, int, int, const int32_t*,
                               unsigned int*, double*, uint64_t*, int32_t*, int32_t*, unsigned int*);
 

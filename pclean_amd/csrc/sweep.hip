@@ -711,6 +711,12 @@ struct SweepState {
   std::vector<std::string> prof_names;
   std::vector<float> prof_ms;
   std::vector<int32_t> prof_launches;
+  // block 0's root scan of the last pclean_sweep (pclean_debug_root_flags; the scratch stays valid until the next call)
+  const int32_t* dbg_desc = nullptr;
+  const int32_t* dbg_grp_off = nullptr;
+  const int32_t* dbg_members = nullptr;
+  const int32_t* dbg_oflag = nullptr;
+  int dbg_groups = 0, dbg_items = 0;
 };
 
 static SweepState* st(pclean_ctx* ctx) {
@@ -1503,7 +1509,15 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
     rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag,
                                  s->counter.p + 1, desc);
-    if (time_it) (void)hipEventRecord(s->ev1, ctx->stream);
+    if (time_it) {
+      (void)hipEventRecord(s->ev1, ctx->stream);
+      s->dbg_desc = desc;
+      s->dbg_grp_off = it.grp_off;
+      s->dbg_members = it.members;
+      s->dbg_oflag = oflag;
+      s->dbg_groups = it.n;
+      s->dbg_items = il.n;
+    }
   } else {
     ProfScope ps(ctx, "evidence_option_scan");
     rc = pclean_launch_ev_leaf(ctx, nd, it, fr, seed, sweep, site, n_draws, lse_out, draws_out, oflag, s->counter.p + 1);
@@ -2075,6 +2089,7 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
     if (roots[r] < 0 || roots[r] >= nn) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: bad root");
   SweepState* s = st(ctx);
   s->pool_used = 0;
+  s->dbg_desc = nullptr;
   if (s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   const int n_ev = ev_off[n_items];
   if (n_ev > 0 && !ev_rows) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: evidence rows missing");
@@ -2186,6 +2201,24 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   return PCLEAN_OK;
 }
 
+extern "C" int pclean_debug_root_flags(pclean_ctx* ctx, int32_t n_rows, int32_t* out) {
+  if (!ctx || !out || n_rows <= 0) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_debug_root_flags: bad arguments");
+  SweepState* s = st(ctx);
+  if (!s->dbg_desc || s->dbg_items != n_rows)
+    return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_debug_root_flags: the last call was not a pclean_sweep of %d rows "
+                                              "through the compact-table root kernel", n_rows);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DevBuf<int32_t> d;
+  if (d.alloc(n_rows)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  int rc = pclean_launch_root_flags(ctx, s->dbg_groups, s->dbg_desc, s->dbg_grp_off, s->dbg_members, s->dbg_oflag, d.p);
+  hipError_t e = rc ? hipSuccess : hipMemcpyAsync(out, d.p, (size_t)n_rows * 4, hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  d.release();
+  if (rc) return rc;
+  if (e != hipSuccess) return pclean_fail(ctx, PCLEAN_ERR_HIP, "pclean_debug_root_flags: %s", hipGetErrorString(e));
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_debug_force_generic(pclean_ctx* ctx, int32_t on) {
   if (!ctx) return PCLEAN_ERR_ARG;
   ctx->force_generic = on != 0;
@@ -2210,6 +2243,7 @@ extern "C" int pclean_score_node(pclean_ctx* ctx, int32_t block_id, int32_t node
   HIPCHK(ctx, hipSetDevice(ctx->device));
   SweepState* s = st(ctx);
   s->pool_used = 0;
+  s->dbg_desc = nullptr;
   const pclean_node& n = b.nodes[node_id];
   const CandTable& t = ctx->cand[n.table];
   const int nc = t.n_rows + (n.kind == PCLEAN_NODE_FK ? 1 : 0);
@@ -2264,6 +2298,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   HIPCHK(ctx, hipSetDevice(ctx->device));
   SweepState* s = st(ctx);
   s->pool_used = 0;
+  s->dbg_desc = nullptr;
   if (!s->ev0) {
     HIPCHK(ctx, hipEventCreate(&s->ev0));
     HIPCHK(ctx, hipEventCreate(&s->ev1));
@@ -2688,6 +2723,7 @@ extern "C" int pclean_maybe_resample(pclean_ctx* ctx, int32_t n_rows, int32_t n_
   HIPCHK(ctx, hipSetDevice(ctx->device));
   SweepState* s = st(ctx);
   s->pool_used = 0;
+  s->dbg_desc = nullptr;
   const size_t NP = (size_t)n_rows * n_particles;
   double* d_w = scratch<double>(ctx, NP);
   int32_t* d_a = scratch<int32_t>(ctx, NP);
@@ -2714,6 +2750,7 @@ extern "C" int pclean_final_choice(pclean_ctx* ctx, int32_t n_rows, int32_t n_pa
   HIPCHK(ctx, hipSetDevice(ctx->device));
   SweepState* s = st(ctx);
   s->pool_used = 0;
+  s->dbg_desc = nullptr;
   const size_t NP = (size_t)n_rows * n_particles;
   double* d_w = scratch<double>(ctx, NP);
   int32_t* d_c = scratch<int32_t>(ctx, n_rows);

@@ -79,7 +79,8 @@ class Engine:
         """The lowered model grew (LoweredModel.relower: strings drawn for chosen dummy values joined latent
         domains): a fresh context with the new string pool, pair / fn / option tables and plans.  Rare (a
         ProposalDummyValue is only ever chosen for unobserved or very short strings), so nothing is patched
-        incrementally.  A device-side RCCL communicator is re-bound by the caller (init_device_comm)."""
+        incrementally.  A device-side RCCL communicator bound with init_device_comm is re-bound to the new context —
+        collectively: every rank reloads at the same point (the dummy draws are replicated)."""
         self.hip.close()
         self.hip = HipContext(self.device)
         self.option_logp = {}
@@ -90,6 +91,8 @@ class Engine:
             _lib.check(self.hip.h, self.hip.lib.pclean_set_row_offset(self.hip.h, _lib.C.c_int64(self.row_offset)),
                        "pclean_set_row_offset")
         self._dev_comm = False
+        if getattr(self, "_comm", None) is not None:
+            self.init_device_comm(self._comm)
 
     def sample_prior_strings(self, dist, n, seed, stream):
         """n draws of random(StringPrior) (string_prior.jl:28-40: length uniform on [min, max], bigram letters) or
@@ -293,8 +296,10 @@ class Engine:
         delta reference counts on the device with ONE all-reduce over xGMI.  Returns False (and the torch path stays
         in use) when RCCL cannot be bound."""
         self._dev_comm = False
+        self._comm = None
         if comm.dist is None:
             return False
+        self._comm = comm  # reload() binds the fresh context to the same ranks
         try:
             box = [self.hip.comm_unique_id() if comm.rank == 0 else None]
             comm.dist.broadcast_object_list(box, src=0)

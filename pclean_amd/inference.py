@@ -212,6 +212,9 @@ def resample_dummies(engine, trace, seed, stamp):
             rows = np.flatnonzero((t.cols[j, :t.n] == dummy) & t.live[:t.n])
             if len(rows):
                 todo.append((cname, j, col.name, d, rows, (ci * 64 + j) * 65536 + (stamp & 0xffff)))
+    # the 32-bit Philox stream holds (class, attribute, low 16 bits of the commit number); the commit number's high
+    # bits go into the key, so that runs of more than 65 536 commits (the sequential schedule) never reuse a counter
+    seed = (int(seed) + (int(stamp) >> 16) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
     if not todo:
         return 0
     _count_dummy_cases(lw, trace, todo, engine.obs)
@@ -333,16 +336,20 @@ def commit_latent(lw, trace, cname, live, chosen, vals):
     return changed
 
 
-def sub_batches(n, config, max_sub_batches, batch_rows=None):
+def sub_batches(n, config, max_sub_batches, batch_rows=None, has_parameters=True):
     """Row ranges of one class sweep, each swept against frozen tables and committed before the next.  The
     reference resamples the class's parameters and Pitman-Yor hyper-parameters every `rejuv_frequency` rows
     (inference.jl:72-77); the batched schedule does it between sub-batches of max(rejuv_frequency,
     ceil(n / max_sub_batches)) rows — exactly the reference's cadence whenever n / rejuv_frequency <=
-    max_sub_batches.  batch_rows overrides the size: batch_rows=1 is the reference's SEQUENTIAL schedule (every
+    max_sub_batches.  A class with NOTHING to resample (has_parameters=False: an observed class without learned
+    parameters, e.g. hospital's Record — rejuv_frequency has no effect on it in the reference either) is swept in
+    one batch.  batch_rows overrides the size: batch_rows=1 is the reference's SEQUENTIAL schedule (every
     row sees the commits of all rows before it; parameters still move every rejuv_frequency rows)."""
     if n <= 0:
         return []
     size = max(int(config.rejuv_frequency), 1, -(-n // max(int(max_sub_batches), 1)))
+    if not has_parameters:
+        size = n
     if batch_rows:
         size = max(int(batch_rows), 1)
     return [(b, min(b + size, n)) for b in range(0, n, size)]
@@ -400,6 +407,9 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
             changed += commit_latent(lw, trace, cname, live[b0:b1], chosen, vals)
             if _after_commit(engine, trace, seed):
                 pl = lw.latent_plans[cname]  # (the lowered model was rebuilt in place)
+                # placeholders became drawn strings: per-evidence-row ctx values may have held a dummy's id
+                live2, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname)
+                assert np.array_equal(live2, live)
     return changed
 
 
@@ -444,13 +454,16 @@ def _sweep_window(engine, trace, config, seed, sweep_idx, b0, b1, comm):
 def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None, max_sub_batches=32, verbose=False,
                    batch_rows=None):
     """One rejuvenation sweep of the observed class; the rows of every sub-batch are block-partitioned over
-    the ranks, the class's parameters are resampled between sub-batches (inference.jl:72-77)."""
+    the ranks, the class's parameters are resampled between sub-batches (inference.jl:72-77).  An observed class
+    without learned parameters (hospital's Record) has nothing to resample and is swept in ONE batch
+    (sub_batches); max_sub_batches only bounds the number of parameter moves of a class that has some."""
     comm = comm or Comm()
     n = trace.cur.shape[1]
     changed = 0
     prev = 0
-    for bn, (b0, b1) in enumerate(sub_batches(n, config, max_sub_batches, batch_rows)):
-        if bn and _crosses_rejuv(prev, b0, config):
+    has_par = trace.has_parameters(engine.lw.query.cls)
+    for bn, (b0, b1) in enumerate(sub_batches(n, config, max_sub_batches, batch_rows, has_par)):
+        if bn and has_par and _crosses_rejuv(prev, b0, config):
             prev = b0
             resample_class_parameters(trace, engine.lw.query.cls)
             if verbose and (b0 // max(config.reporting_frequency, 1)) != ((b0 - 1) // max(config.reporting_frequency, 1)):

@@ -491,6 +491,14 @@ class Trace:
         return created
 
     # -- parameter moves (inference.jl:72-77 -> resample_value!) ----------------
+    def has_parameters(self, cname):
+        """True when pgibbs_sweep!'s move every rejuv_frequency rows (inference.jl:72-77) has anything to resample for
+        class cname: a learned parameter declared in it, or Pitman-Yor hyper-parameters of its own table (every
+        latent class; the observed class has no table)."""
+        return (cname in self.tables or any(c == cname for c, _ in self.params)
+                or (self.prob_param is not None and self.lw.prob_spec["param"][0] == cname)
+                or (self.mean_param is not None and self.lw.gauss_spec["param"][0] == cname))
+
     def resample_parameters(self, cname=None):
         """resample_value! of every learned parameter (cname=None: initialize_trace, inference.jl:40-47) or
         of the parameters declared in class cname (pgibbs_sweep!, inference.jl:72-77)."""

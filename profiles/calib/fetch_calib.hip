@@ -1,0 +1,90 @@
+// FETCH_SIZE calibration for the access patterns of fk_root_wave_kernel (profiles/collect_r03.sh runs this under
+// `rocprofv3 --pmc FETCH_SIZE`): kernels with a KNOWN number of bytes / distinct cache lines touched, over a buffer far
+// larger than the 256 MiB Infinity Cache, so that the counter value per known byte can be read off per pattern.
+//   stream16   : every lane loads 16 B, consecutive (the pre-filter scan's pattern)          -> bytes = N
+//   gather_u8  : every lane loads ONE byte at a pseudo-random address (exact scoring's global_load_ubyte of a
+//                survivor's distance / length byte)                                           -> lines = n_gathers
+//   gather_u8x64: the 64 lanes of a wave load one byte each from 64 different 128-byte lines of ONE 16 KB row
+//                (survivors of one byte row)                                                  -> lines = n_gathers
+// Build: hipcc --offload-arch=gfx950 -O3 -o fetch_calib fetch_calib.hip
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#define CHECK(x)                                                                  \
+  do {                                                                            \
+    hipError_t e_ = (x);                                                          \
+    if (e_ != hipSuccess) {                                                       \
+      fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));                     \
+      exit(1);                                                                    \
+    }                                                                             \
+  } while (0)
+
+__global__ void calib_stream16(const uint4* __restrict__ p, size_t n16, uint32_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  uint32_t acc = 0;
+  for (; i < n16; i += stride) {
+    const uint4 v = p[i];
+    acc += v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+__device__ __forceinline__ uint64_t mix(uint64_t x) {
+  x ^= x >> 33;
+  x *= 0xff51afd7ed558ccdull;
+  x ^= x >> 33;
+  x *= 0xc4ceb9fe1a85ec53ull;
+  return x ^ (x >> 33);
+}
+
+// one byte per lane at a random LINE of the buffer (every gather a different 128-byte line with high probability)
+__global__ void calib_gather_u8(const uint8_t* __restrict__ p, size_t n_lines, size_t n_gathers, uint32_t* __restrict__ out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  uint32_t acc = 0;
+  for (; i < n_gathers; i += stride) {
+    const uint64_t h = mix(i * 0x9e3779b97f4a7c15ull + 1);
+    acc += p[(h % n_lines) * 128 + ((h >> 40) & 127)];
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+// a wave gathers 64 bytes from 64 distinct lines of one 16 KB row (row chosen at random per wave iteration)
+__global__ void calib_gather_row(const uint8_t* __restrict__ p, size_t n_rows, size_t n_wave_iters, uint32_t* __restrict__ out) {
+  const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const size_t n_waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  uint32_t acc = 0;
+  for (size_t it = wave; it < n_wave_iters; it += n_waves) {
+    const uint64_t h = mix(it * 0x9e3779b97f4a7c15ull + 7);
+    const size_t row = h % n_rows;
+    acc += p[row * 16384 + (size_t)lane * 256 + ((h >> 40) & 127)];  // lane l -> line 2 l of the row
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
+int main() {
+  const size_t bytes = (size_t)8 << 30;  // 8 GiB >> Infinity Cache
+  uint8_t* buf;
+  uint32_t* out;
+  CHECK(hipMalloc(&buf, bytes));
+  CHECK(hipMalloc(&out, 64));
+  CHECK(hipMemset(buf, 1, bytes));
+  CHECK(hipDeviceSynchronize());
+  const size_t n16 = ((size_t)2 << 30) / 16;                // stream 2 GiB
+  const size_t n_gathers = (size_t)16 << 20;                // 16 Mi single-byte gathers
+  const size_t n_wave_iters = ((size_t)16 << 20) / 64;      // 16 Mi bytes gathered, 64 per wave iteration
+  for (int rep = 0; rep < 3; ++rep) {
+    hipLaunchKernelGGL(calib_stream16, dim3(256 * 16), dim3(256), 0, 0, (const uint4*)buf + ((size_t)rep << 27), n16, out);
+    hipLaunchKernelGGL(calib_gather_u8, dim3(256 * 16), dim3(256), 0, 0, buf, bytes / 128, n_gathers, out);
+    hipLaunchKernelGGL(calib_gather_row, dim3(256 * 16), dim3(256), 0, 0, buf, bytes / 16384, n_wave_iters, out);
+  }
+  CHECK(hipDeviceSynchronize());
+  printf("calib: stream16 bytes %zu; gather_u8 gathers %zu (distinct 128-B lines ~ the same); gather_row gathers %zu\n",
+         n16 * 16, n_gathers, n_wave_iters * 64);
+  return 0;
+}

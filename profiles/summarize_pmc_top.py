@@ -25,6 +25,7 @@ def main():
     args = [a for a in sys.argv[1:]]
     top = int(args[args.index("--top") + 1]) if "--top" in args else 14
     out_json = args[args.index("--json") + 1] if "--json" in args else None
+    source = args[args.index("--source") + 1] if "--source" in args else "profiles/r02_pmc_top_kernels.txt"
     dbs = [a for a in args if a.endswith(".db")]
     merged = {}
     for path in dbs:
@@ -73,6 +74,9 @@ def main():
             wc = c["SQ_WAVE_CYCLES"][1]
             parts = [f"{n2}/SQ_WAVE_CYCLES={c[n2][1] / wc:.2f}" for n2 in ("SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY") if n2 in c]
             print(f"{'':72s}        -> " + ", ".join(parts))
+        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c and c["TCC_HIT_sum"][1] + c["TCC_MISS_sum"][1] > 0:
+            print(f"{'':72s}        -> L2 hit rate TCC_HIT/(TCC_HIT+TCC_MISS) = "
+                  f"{c['TCC_HIT_sum'][1] / (c['TCC_HIT_sum'][1] + c['TCC_MISS_sum'][1]):.3f}")
     if out_json:
         key = next((k for k in merged if "fk_root_wave_kernel<12" in k and "full-size" in k), None)
         if key and "FETCH_SIZE" in merged[key]["counters"] and "WRITE_SIZE" in merged[key]["counters"]:
@@ -80,7 +84,7 @@ def main():
             b = (2 * c["FETCH_SIZE"][1] / c["FETCH_SIZE"][0] + c["WRITE_SIZE"][1] / c["WRITE_SIZE"][0]) * 1024
             data = dict(kernel="fk_root_wave_kernel", bytes_per_launch=b, rows=1000000, hospitals=10000, particles=20,
                         fetch_kib=c["FETCH_SIZE"][1] / c["FETCH_SIZE"][0], write_kib=c["WRITE_SIZE"][1] / c["WRITE_SIZE"][0],
-                        source="profiles/r02_pmc_top_kernels.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, "
+                        source=source + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, "
                                "2 x FETCH_SIZE + WRITE_SIZE, KiB)")
             json.dump(data, open(out_json, "w"), indent=1)
 

@@ -30,6 +30,11 @@ OUT = os.path.join(ROOT, "tests", "golden", "sequential_f1.json")
 
 
 def program(name, n_rows=None):
+    if name.startswith("synth"):  # hospital-shaped synthetic table (pclean_amd.synth), ~100 rows per true hospital
+        from pclean_amd.synth import synth_hospital
+        dirty, clean, _ = synth_hospital(n_rows, max(n_rows // 100, 1), 20250926)
+        return dirty, clean, ex.hospital_model, ex.hospital_query
+    name = name.split("_")[0]
     if name == "hospital":
         dirty, clean = ex.hospital_data()
         mk_model, mk_query = ex.hospital_model, ex.hospital_query
@@ -49,12 +54,12 @@ def run(name, seed, iters, mh, particles, n_rows=None, shuffle=True, batch_rows=
     dirty, clean, mk_model, mk_query = program(name, n_rows)
     if shuffle:
         (dirty, clean), _ = ex.shuffle_rows([dirty, clean], seed)
-    m = mk_model(ex.possibilities_of(dirty)) if name == "hospital" else mk_model(dirty)
+    m = mk_model(ex.possibilities_of(dirty)) if mk_model is ex.hospital_model else mk_model(dirty)
     lw = LoweredModel(m, mk_query(m), dirty)
     obs = lw.encode_observations(dirty)
     eng = OracleEngine(orc, lw, obs, cached=True)
     tr = Trace(lw, obs.shape[1], seed)
-    cfg = InferenceConfig(iters, particles, use_mh_instead_of_pg=mh, rejuv_frequency=50 if name == "hospital" else 500)
+    cfg = InferenceConfig(iters, particles, use_mh_instead_of_pg=mh, rejuv_frequency=rejuv_of(name))
     t0 = time.time()
     initialize_trace(eng, tr, cfg, seed, max_batch=batch_rows)
     t1 = time.time()
@@ -68,10 +73,20 @@ def run(name, seed, iters, mh, particles, n_rows=None, shuffle=True, batch_rows=
                 latent_rows={c: int(t.n_live) for c, t in tr.tables.items()})
 
 
+def rejuv_of(name):
+    """rejuv_frequency of the experiment scripts (hospital: the default 50; flights / rents: 500)"""
+    return 50 if name.split("_")[0] in ("hospital", "synth") else 500
+
+
 CONFIGS = {  # the experiment scripts' configurations (experiments/*/run.jl), rows as the GPU tests use them
     "hospital": dict(iters=3, mh=True, particles=2, n_rows=None),
     "flights": dict(iters=5, mh=True, particles=2, n_rows=None),
     "rents": dict(iters=1, mh=True, particles=2, n_rows=None),
+    # BASELINE.json configs[1], [2]: particle Gibbs with 20 particles (hospital: 2 rejuvenation sweeps)
+    "hospital_pg20": dict(iters=2, mh=False, particles=20, n_rows=None),
+    "rents_pg20": dict(iters=1, mh=False, particles=20, n_rows=None),
+    # the headline workload's shape at a size the sequential schedule can finish: 30 000 rows, 300 true hospitals
+    "synth_pg20": dict(iters=1, mh=False, particles=20, n_rows=30000),
 }
 
 if __name__ == "__main__":

@@ -114,3 +114,93 @@ def test_fast_root_kernel_equals_generic(oracle):
                 assert np.array_equal(np.bincount(tr.cur[bi], minlength=t.n), t.counts[:t.n])
     finally:
         eng.close()
+
+
+def test_million_row_own_init_state_parity(oracle, capsys):
+    """The state bench.py actually times: the build's OWN initialize_trace from an empty trace + one full
+    run_inference iteration at 1M rows (11-12k latent hospitals for 10k true ones, thousands of singleton measures,
+    guess-and-refine groups, groups whose survivor list overflows, thousands of new rows per sweep) — then one
+    observed-class sweep checked (a) bit for bit against the oracle on >= 8 windows that contain rows of every kind
+    (pclean_debug_root_flags picks them), (b) compact-table wave kernels == generic enumeration kernels on all rows."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from pclean_amd import _lib
+    from pclean_amd._lib import InferConfig
+    from pclean_amd.engine import Engine, InferenceConfig
+    from pclean_amd.inference import initialize_trace, run_inference
+    from pclean_amd.trace import Trace
+    n_rows, n_hosp, P, seed = 1_000_000, 10_000, 20, 20250926
+    dirty, clean, lw, obs = bench.build_workload(n_rows, n_hosp, seed)
+    eng = Engine(lw, obs, dist_mode=_lib.DIST_OSA)
+    try:
+        cfg = InferenceConfig(1, P)
+        tr = Trace(lw, n_rows, seed)
+        initialize_trace(eng, tr, cfg, seed, max_batch=32768)
+        run_inference(eng, tr, cfg, seed)
+        tr.check_consistency()
+        n_h, n_m = tr.tables["Hospital"].n_live, tr.tables["Measure"].n_live
+        assert n_h > n_hosp and n_m > 28  # the messy state, not the ground truth
+        eng.upload_trace(tr)
+        choice, chosen, logml, new_rows = eng.sweep(tr, cfg, seed, 1)
+        choice, chosen, logml = choice.copy(), chosen.copy(), logml.copy()
+        new_rows = {k: (v[0].copy(), v[1].copy()) for k, v in new_rows.items()}
+        flags = eng.hip.root_flags(n_rows)
+        rs = eng.hip.get_root_stats()
+        over, refine = np.flatnonzero(flags & 1), np.flatnonzero(flags & 2)
+        moved = np.flatnonzero((choice != tr.cur).any(axis=0))
+        fresh0, fresh1 = np.flatnonzero(choice[0] < 0), np.flatnonzero(choice[1] < 0)
+        with capsys.disabled():
+            print(f"\n[own-init 1M] latent hospitals {n_h}, measures {n_m}; groups {rs.n_groups}, overflowed rows {len(over)}, "
+                  f"guess-and-refine rows {len(refine)}, moved {len(moved)}, new hospital rows {len(fresh0)}, "
+                  f"new measure rows {len(fresh1)}")
+        assert rs.fast == 1 and len(refine) > 0 and len(moved) > 1000 and len(fresh0) + len(fresh1) > 100
+        # (a) oracle parity on windows around rows of every kind
+        W = 96
+        starts = [0, n_rows // 2 - 37, n_rows - W]
+        for special in (over[:1], over[-1:], refine[:1], refine[len(refine) // 2:len(refine) // 2 + 1], refine[-1:],
+                        moved[len(moved) // 2:len(moved) // 2 + 1], fresh0[:1], fresh0[-1:], fresh1[:1], fresh1[-1:]):
+            if len(special):
+                starts.append(int(min(max(special[0] - W // 2, 0), n_rows - W)))
+        assert len(starts) >= 8
+        c = InferConfig(1, P, 1, 1, 0, 50, 100)
+        kinds = np.zeros(4, dtype=np.int64)
+        for start in starts:
+            rows = np.arange(start, start + W)
+            w, _ = bench.oracle_world_for_rows(oracle, lw, obs, tr, eng, rows)
+            cur = np.ascontiguousarray(tr.cur[:, rows])
+            och = np.empty((2, W), dtype=np.int32)
+            ocp = np.empty(W, dtype=np.int32)
+            oml = np.empty(W)
+            oracle.lib().pco_sweep_batched(w.h, C.byref(c), C.c_uint64(seed), C.c_uint32(1), 2, C.c_int64(start),
+                                           oracle._p(cur, C.c_int32), oracle._p(och, C.c_int32),
+                                           oracle._p(ocp, C.c_int32), oracle._p(oml, C.c_double))
+            assert np.array_equal(choice[:, rows], och), start
+            assert np.array_equal(chosen[rows], ocp), start
+            assert np.array_equal(logml[rows], oml), start
+            # the new-row records of the window's rows (sub-choices of every node of the block)
+            for b in range(2):
+                k = oracle.lib().pco_new_rows_count(b)
+                nn = len(lw.blocks[b]["nodes"])
+                orows, ovals = np.empty(k, dtype=np.int32), np.empty((k, nn), dtype=np.int32)
+                if k:
+                    oracle.lib().pco_new_rows_get(b, nn, oracle._p(orows, C.c_int32), oracle._p(ovals, C.c_int32))
+                g_rows, g_vals = new_rows.get(b, (np.zeros(0, np.int32), np.zeros((0, nn), np.int32)))
+                sel = (g_rows >= start) & (g_rows < start + W)
+                assert np.array_equal(g_rows[sel] - start, orows), (start, b)
+                assert np.array_equal(g_vals[sel], ovals), (start, b)
+            kinds += [int((flags[rows] & 1).sum()), int(((flags[rows] & 2) != 0).sum()),
+                      int((choice[:, rows] != tr.cur[:, rows]).any(axis=0).sum()), int((choice[:, rows] < 0).any(axis=0).sum())]
+        with capsys.disabled():
+            print(f"[own-init 1M] {len(starts)} oracle windows of {W} rows: {kinds[0]} overflowed, {kinds[1]} guess-and-refine, "
+                  f"{kinds[2]} moved, {kinds[3]} new-referent rows — all bit-identical")
+        assert kinds[1] > 0 and kinds[2] > 0 and kinds[3] > 0 and (kinds[0] > 0 or len(over) == 0)
+        # (b) wave kernels == generic kernels on this state, every row
+        eng.hip.force_generic(True)
+        b_choice, b_chosen, b_logml, b_new = eng.sweep(tr, cfg, seed, 1)
+        eng.hip.force_generic(False)
+        assert np.array_equal(choice, b_choice) and np.array_equal(chosen, b_chosen) and np.array_equal(logml, b_logml)
+        assert set(new_rows) == set(b_new)
+        for k in new_rows:
+            assert np.array_equal(new_rows[k][0], b_new[k][0]) and np.array_equal(new_rows[k][1], b_new[k][1])
+    finally:
+        eng.close()
