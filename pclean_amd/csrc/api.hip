@@ -60,6 +60,9 @@ extern "C" int pclean_ctx_destroy(pclean_ctx* ctx) {
   for (auto& b : ctx->block) {
     b.d_terms.release();
     for (auto& l : b.leaf_cache) l.release();
+    for (auto& l : b.leaf_m) l.release();
+    for (auto& l : b.leaf_U) l.release();
+    for (auto& l : b.leaf_coarse) l.release();
   }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -621,8 +624,17 @@ extern "C" int pclean_load_block(pclean_ctx* ctx, int32_t block_id, int32_t n_no
   if (b.d_terms.alloc(std::max(n_terms, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   if (n_terms) HIPCHK(ctx, hipMemcpy(b.d_terms.p, terms, n_terms * sizeof(pclean_term), hipMemcpyHostToDevice));
   for (auto& l : b.leaf_cache) l.release();
+  for (auto& l : b.leaf_m) l.release();
+  for (auto& l : b.leaf_U) l.release();
+  for (auto& l : b.leaf_coarse) l.release();
   b.leaf_cache.clear();
   b.leaf_cache.resize(n_nodes);
+  b.leaf_m.clear();
+  b.leaf_m.resize(n_nodes);
+  b.leaf_U.clear();
+  b.leaf_U.resize(n_nodes);
+  b.leaf_coarse.clear();
+  b.leaf_coarse.resize(n_nodes);
   b.gauss.clear();
   b.node_gauss.assign(n_nodes, -1);
   b.valid = true;

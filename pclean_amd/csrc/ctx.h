@@ -104,6 +104,10 @@ struct Block {
   DevBuf<pclean_term> d_terms;
   // per-sweep work buffers live in Sweep state (sweep.hip)
   std::vector<DevBuf<double>> leaf_cache;  // per node: marginal per unique observed value
+  // cacheable option lists (enum_kernels.hip: leaf_coarse_*): per unique observed value the maximum, the fixed-point
+  // total and the inclusive prefix at every 256th option
+  std::vector<DevBuf<double>> leaf_m;
+  std::vector<DevBuf<uint64_t>> leaf_U, leaf_coarse;
   std::vector<int32_t> new_rows_host, new_vals_host, locals_host;
   std::vector<int32_t> moved_rows_host, moved_choice_host;  // rows whose referent changed in the last sweep
 };

@@ -153,6 +153,9 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
                             int32_t* desc_scratch);
+int pclean_launch_overflow_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
+                                uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
+                                int32_t* draws_out);
 int pclean_launch_root_flags(pclean_ctx* ctx, int n_groups, const int32_t* gd, const int32_t* grp_off,
                              const int32_t* members, const int32_t* oflag, int32_t* out);
 size_t pclean_fast_desc_words(int n_groups);  // int32 words of desc_scratch for n_groups groups
@@ -164,6 +167,14 @@ int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* lo
 int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const ChildrenDev& ch, uint64_t seed,
                        uint32_t sweep, uint32_t site, int n_draws, double* lse_out, double* scores_out,
                        int32_t* draws_out);
+// cacheable option lists: per-observed-value (maximum, total, coarse prefix) and draws through them (enum_kernels.hip)
+int pclean_leaf_coarse_blocks(int n_options);
+int pclean_launch_leaf_coarse_build(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, int n_blocks, double* lse_out,
+                                    double* m_out, uint64_t* U_out, uint64_t* coarse);
+int pclean_launch_leaf_coarse_draw(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const int32_t* obs_col, int n_obs,
+                                   int n_blocks, const double* lse_c, const double* m_c, const uint64_t* U_c,
+                                   const uint64_t* coarse, uint64_t seed, uint32_t sweep, uint32_t site, int n_draws,
+                                   double* lse_out, int32_t* draws_out);
 // option list of a LEAF node scored against evidence sets (enum_kernels.hip: ev_leaf_wave_kernel)
 int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const FastRootDev& fr, uint64_t seed,
                           uint32_t sweep, uint32_t site, int n_draws, double* lse_out, int32_t* draws_out,

@@ -594,6 +594,144 @@ __global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, co
   }
 }
 
+// ---- cacheable option lists: per-observed-value (maximum, fixed-point total, coarse prefix) -----------------------
+// A cacheable LEAF (one term on one observed column, no ctx) has a score vector that depends on the evidence row only
+// through that row's observed value o.  leaf_coarse_build_kernel enumerates every o once (item t "observes" value t,
+// the last item a missing value): maximum m[o], total U[o] and the inclusive fixed-point prefix at the end of every
+// block of LEAF_CB consecutive options.  A draw then needs one binary search over the coarse prefix and the exact
+// weights of ONE block of options (leaf_coarse_draw_kernel) instead of three passes over the whole list — the same
+// index "min{k : prefix_k > x}" because integer sums do not depend on how they are bracketed.  The log-marginal
+// m + log(U 2^-40) is what the generic kernels return, bit for bit.
+#define LEAF_CB 256
+
+__global__ __launch_bounds__(256) void leaf_coarse_build_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
+                                                                int n_blocks, double* __restrict__ lse_out,
+                                                                double* __restrict__ m_out, uint64_t* __restrict__ U_out,
+                                                                uint64_t* __restrict__ coarse) {
+  __shared__ double red[4];
+  __shared__ uint64_t wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.x;
+  const int n = nd.n_cand;
+  const ItemView v = item_view(nd, it, t);
+  double lmax = -__builtin_inf();
+  for (int k = tid; k < n; k += 256) lmax = fmax(lmax, candidate_score(nd, dn, it, v, k));
+  lmax = wave_max(lmax);
+  if (lane == 0) red[wave] = lmax;
+  __syncthreads();
+  const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  uint64_t run = 0;
+  for (int b = 0; b < n_blocks; ++b) {
+    const int k = b * LEAF_CB + tid;
+    uint64_t u = 0;
+    if (k < n && m != -__builtin_inf()) u = pclean_fixw(candidate_score(nd, dn, it, v, k) - m);
+    for (int o = 32; o > 0; o >>= 1) u += __shfl_xor((unsigned long long)u, o, 64);
+    __syncthreads();  // wsum of the previous block has been read
+    if (lane == 0) wsum[wave] = u;
+    __syncthreads();
+    run += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (tid == 0) coarse[(size_t)t * n_blocks + b] = run;
+  }
+  if (tid == 0) {
+    m_out[t] = m;
+    U_out[t] = run;
+    lse_out[t] = pclean_lse_from_fix(m, run);
+  }
+}
+
+// one wavefront per (item, draw): coarse search, then the exact weights of the LEAF_CB options of the block found
+__global__ __launch_bounds__(256) void leaf_coarse_draw_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
+                                                               const int32_t* __restrict__ obs_col, int n_obs,
+                                                               int n_blocks, const double* __restrict__ lse_c,
+                                                               const double* __restrict__ m_c,
+                                                               const uint64_t* __restrict__ U_c,
+                                                               const uint64_t* __restrict__ coarse, uint64_t seed,
+                                                               uint32_t sweep, uint32_t site, int n_draws,
+                                                               double* __restrict__ lse_out,
+                                                               int32_t* __restrict__ draws_out) {
+  const int lane = threadIdx.x & 63;
+  const int nd_eff = n_draws > 0 ? n_draws : 1;  // n_draws == 0: log-marginals only
+  const long long n_pairs = (long long)it.n * nd_eff;
+  const int n = nd.n_cand;
+  const int draw_is = it.draw_is ? it.draw_is : n_draws, draw_ds = it.draw_ds ? it.draw_ds : 1;
+  for (long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); q < n_pairs; q += (long long)gridDim.x * 4) {
+    const int t = (int)(q / nd_eff), j = (int)(q - (long long)t * nd_eff);
+    const ItemView v = item_view(nd, it, t);
+    const int to = it.out_pos ? it.out_pos[t] : t;
+    const int ov = obs_col[v.row];
+    const int o = ov < 0 ? n_obs : ov;
+    if (j == 0 && lse_out && lane == 0) lse_out[to] = lse_c[o];
+    if (n_draws <= 0) continue;
+    const uint64_t U = U_c[o];
+    int32_t res = n - 1;
+    if (U != 0) {
+      const double m = m_c[o];
+      const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[t] : (uint32_t)((int64_t)v.row + it.row_offset);
+      const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)j;
+      const uint64_t x = pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U);
+      const uint64_t* cp = coarse + (size_t)o * n_blocks;
+      int a = 0, b = n_blocks - 1;  // smallest block whose inclusive prefix exceeds x
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (cp[mid] > x)
+          b = mid;
+        else
+          a = mid + 1;
+      }
+      const uint64_t base = a > 0 ? cp[a - 1] : 0ull;
+      // lane l: options 4 l .. 4 l + 3 of the block, natural order
+      uint64_t u4[4];
+      uint64_t mine = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = a * LEAF_CB + lane * 4 + e;
+        u4[e] = k < n ? pclean_fixw(candidate_score(nd, dn, it, v, k) - m) : 0ull;
+        mine += u4[e];
+      }
+      unsigned long long incl = mine;
+      for (int sh = 1; sh < 64; sh <<= 1) {
+        const unsigned long long y = __shfl_up(incl, sh, 64);
+        if (lane >= sh) incl += y;
+      }
+      uint64_t acc = base + incl - mine;
+      int found = 0x7fffffff;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc += u4[e];
+        if (found == 0x7fffffff && acc > x) found = a * LEAF_CB + lane * 4 + e;
+      }
+      for (int sh = 32; sh > 0; sh >>= 1) found = min(found, __shfl_xor(found, sh, 64));
+      if (found != 0x7fffffff) res = found;
+    }
+    if (lane == 0) draws_out[(size_t)to * draw_is + (size_t)j * draw_ds] = res;
+  }
+}
+
+int pclean_launch_leaf_coarse_build(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, int n_blocks, double* lse_out,
+                                    double* m_out, uint64_t* U_out, uint64_t* coarse) {
+  if (it.n <= 0) return PCLEAN_OK;
+  DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
+  hipLaunchKernelGGL(leaf_coarse_build_kernel, dim3(it.n), dim3(256), 0, ctx->stream, nd, dn, it, n_blocks, lse_out, m_out,
+                     U_out, coarse);
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
+int pclean_leaf_coarse_blocks(int n_options) { return (n_options + LEAF_CB - 1) / LEAF_CB; }
+
+int pclean_launch_leaf_coarse_draw(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const int32_t* obs_col, int n_obs,
+                                   int n_blocks, const double* lse_c, const double* m_c, const uint64_t* U_c,
+                                   const uint64_t* coarse, uint64_t seed, uint32_t sweep, uint32_t site, int n_draws,
+                                   double* lse_out, int32_t* draws_out) {
+  if (it.n <= 0) return PCLEAN_OK;
+  DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
+  const long long pairs = (long long)it.n * std::max(n_draws, 1);
+  const int wgs = (int)std::min<long long>((pairs + 3) / 4, 256 * 8);
+  hipLaunchKernelGGL(leaf_coarse_draw_kernel, dim3(wgs), dim3(256), 0, ctx->stream, nd, dn, it, obs_col, n_obs, n_blocks,
+                     lse_c, m_c, U_c, coarse, seed, sweep, site, n_draws, lse_out, draws_out);
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
+
 int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const ChildrenDev& ch, uint64_t seed,
                        uint32_t sweep, uint32_t site, int n_draws, double* lse_out, double* scores_out,
                        int32_t* draws_out) {

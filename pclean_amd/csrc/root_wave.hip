@@ -713,6 +713,131 @@ __global__ void group_lse_kernel(int n_groups, const int32_t* __restrict__ grp_o
   for (int mi = grp_off[g]; mi < hi; ++mi) lse_out[out_pos ? out_pos[members[mi]] : members[mi]] = lse;
 }
 
+// ---- overflow_lds_kernel: the items whose pre-filter survivor list overflowed (flat posteriors), re-run over ALL
+// candidates.  Same contract and results as enum_node_kernel (enum_kernels.hip) — scores in LDS, fixed-point
+// weights in place, chunk sums + block scan, binary-search draws — but phase 1 scores through the candidate-compact
+// byte rows (fast_exact_score: coalesced byte loads, one density-table lookup per term) instead of the generic
+// kernel's dependent gather chains (candidate column -> pair byte -> length -> density pieces), which made 27
+// overflowed rows cost 0.56 ms of every 1M-row sweep.  One workgroup per item; items are not grouped.
+__global__ __launch_bounds__(256) void overflow_lds_kernel(const FastRootDev fr, const ItemsDev it, const ChildrenDev ch,
+                                                           uint64_t seed, uint32_t sweep, uint32_t site, int n_draws,
+                                                           double* __restrict__ lse_out,
+                                                           int32_t* __restrict__ draws_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_o[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = blockIdx.x;
+  const int to = it.out_pos ? it.out_pos[t] : t;
+  const int n = fr.n_cand;
+  const bool fk = !fr.is_leaf;
+  const int nc = n + (fk ? 1 : 0);
+  double* s = (double*)smem_o;
+  uint64_t* u = (uint64_t*)smem_o;
+  double* red = (double*)(smem_o + (size_t)((nc + 1) & ~1) * 8);
+  uint64_t* wsum = (uint64_t*)(red + 8);
+  const int row = it.row ? it.row[t] : t;
+  const int excl = it.excl ? it.excl[t] : -1;
+  const int ctx0 = it.ctx ? it.ctx[(size_t)t * PCLEAN_MAX_CTX] : 0;
+  const int ctx1 = it.ctx ? it.ctx[(size_t)t * PCLEAN_MAX_CTX + 1] : 0;
+  int o[PCLEAN_MAX_TERMS];
+  for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) o[f] = f < fr.n_terms ? fr.terms[f].obs_col[row] : -1;
+  const bool deleted = excl >= 0 && fr.counts && fr.counts[excl] <= 1;
+  const double* prior = (excl >= 0 && fr.prior_e) ? fr.prior_e : fr.prior_n;
+  // ---- phase 1: exact scores, prior first, terms in plan order (candidate_score's operation order)
+  double lmax = -__builtin_inf();
+  for (int k = tid; k < n; k += 256) {
+    double pr = prior[k];
+    if (k == excl) pr = deleted ? -__builtin_inf() : fr.logc_m1[excl] - fr.scal[1];
+    const double sk = pr == -__builtin_inf() ? pr : fast_exact_score(fr, o, ctx0, ctx1, k, pr);
+    s[k] = sk;
+    lmax = fmax(lmax, sk);
+  }
+  if (fk && tid == 0) {  // new_score() of enum_kernels.hip
+    const double logden = excl >= 0 ? fr.scal[1] : fr.scal[0];
+    double snew = 0.0;
+    for (int c = 0; c < ch.n; ++c) {
+      size_t idx = (size_t)to;
+      if (ch.obs_col[c]) {
+        const int oc = ch.obs_col[c][row];
+        idx = oc < 0 ? (size_t)ch.n_obs[c] : (size_t)oc;
+      }
+      snew += ch.arr[c][idx];
+    }
+    const double sn = ((deleted ? fr.scal[3] : fr.scal[2]) - logden) + snew;
+    s[n] = sn;
+    lmax = fmax(lmax, sn);
+  }
+  lmax = wave_max64(lmax);
+  if (lane == 0) red[wave] = lmax;
+  __syncthreads();
+  const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  for (int k = tid; k < nc; k += 256) {
+    const double sk = s[k];
+    u[k] = (m == -__builtin_inf()) ? 0ull : pclean_fixw(sk - m);
+  }
+  __syncthreads();
+  const int chunk = (nc + 255) / 256;
+  const int lo = min(tid * chunk, nc), hi = min(lo + chunk, nc);
+  uint64_t part = 0;
+  for (int k = lo; k < hi; ++k) part += u[k];
+  unsigned long long incl = part;
+  for (int sh = 1; sh < 64; sh <<= 1) {
+    const unsigned long long x = __shfl_up(incl, sh, 64);
+    if (lane >= sh) incl += x;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  uint64_t base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  const uint64_t U = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  {
+    uint64_t run = base + incl - part;
+    for (int k = lo; k < hi; ++k) {
+      run += u[k];
+      u[k] = run;
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && lse_out) lse_out[to] = pclean_lse_from_fix(m, U);
+  const int draw_is = it.draw_is ? it.draw_is : n_draws, draw_ds = it.draw_ds ? it.draw_ds : 1;
+  for (int j = tid; j < n_draws; j += 256) {
+    int32_t res = fk ? PCLEAN_CHOICE_NEW : n - 1;
+    if (U != 0) {
+      const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[t] : (uint32_t)((int64_t)row + it.row_offset);
+      const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : (uint32_t)j;
+      const uint64_t x = pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U);
+      int a = 0, b = nc - 1;
+      while (a < b) {
+        const int mid = (a + b) >> 1;
+        if (u[mid] > x)
+          b = mid;
+        else
+          a = mid + 1;
+      }
+      res = (fk && a == n) ? PCLEAN_CHOICE_NEW : a;
+    }
+    draws_out[(size_t)to * draw_is + (size_t)j * draw_ds] = res;
+  }
+}
+
+// returns 1 when the launch was made, 0 when the candidates do not fit the LDS of one workgroup (caller: generic kernel)
+int pclean_launch_overflow_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
+                                uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
+                                int32_t* draws_out) {
+  if (it.n <= 0) return 1;
+  const int nc = fr.n_cand + (fr.is_leaf ? 0 : 1);
+  const size_t lds = (size_t)((nc + 1) & ~1) * 8 + (16 + 64) * 8;
+  if (lds > 160 * 1024 || it.grp_off || it.ev_lo) return 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    HIPCHK(ctx, hipFuncSetAttribute((const void*)overflow_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(overflow_lds_kernel, dim3(it.n), dim3(256), lds, ctx->stream, fr, it, ch, seed, sweep, site, n_draws,
+                     lse_out, draws_out);
+  HIPCHK(ctx, hipGetLastError());
+  return 1;
+}
+
 // debug (pclean_debug_root_flags): per item of the last launch, bit 0 = re-run by the generic kernel (survivor list
 // overflowed), bit 1 = its group was scanned in guess-and-refine mode
 __global__ void root_flags_kernel(int n_groups, const int32_t* __restrict__ gd, const int32_t* __restrict__ grp_off,

@@ -974,14 +974,22 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
   const uint64_t ver = ctx->cand[n.table].version * 1000003ull + pt.version;
   auto itv = s->leaf_version.find(key);
   if (itv == s->leaf_version.end() || itv->second != ver || cache.n < (size_t)U + 1) {
-    if (cache.alloc(U + 1)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "alloc");
-    // item t observes value t (or a missing value for t == U): the usual evaluation path (compact-table wave kernel
-    // for long strings, generic kernel otherwise) with the observed column replaced by the identity column
+    // item t observes value t (or a missing value for t == U): every option of every value once, leaving the
+    // log-marginal, the maximum, the fixed-point total and the coarse prefix (enum_kernels.hip: leaf_coarse_build_kernel)
     ProfScope ps(ctx, "leaf_cache_rebuild");
-    ItemList il{U + 1, nullptr, nullptr, nullptr, nullptr};
+    const int nblk = pclean_leaf_coarse_blocks(ctx->cand[n.table].n_rows);
+    if (cache.alloc(U + 1) || b.leaf_m[node_id].alloc(U + 1) || b.leaf_U[node_id].alloc(U + 1) ||
+        b.leaf_coarse[node_id].alloc((size_t)(U + 1) * nblk))
+      return pclean_fail(ctx, PCLEAN_ERR_HIP, "alloc");
+    NodeDev nd;
     ctx->obs_override = io.p;
-    int rc = eval_node(ctx, block_id, node_id, il, nullptr, 0, 0, 0, cache.p, nullptr, nullptr, nullptr, false);
+    int rc = build_node_dev(ctx, b, node_id, nd);
     ctx->obs_override = nullptr;
+    if (rc) return rc;
+    ItemsDev it{U + 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                nullptr, nullptr, 0, 0, nullptr, nullptr};
+    rc = pclean_launch_leaf_coarse_build(ctx, nd, it, nblk, cache.p, b.leaf_m[node_id].p, b.leaf_U[node_id].p,
+                                         b.leaf_coarse[node_id].p);
     if (rc) return rc;
     s->leaf_version[key] = ver;
   }
@@ -1441,6 +1449,20 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
       }
     }
   }
+  // cacheable option list: log-marginal and draws from the per-observed-value coarse prefix (leaf_coarse_draw_kernel)
+  static const bool no_coarse = getenv("PCLEAN_NO_COARSE_LEAF") != nullptr;
+  if (n.kind == PCLEAN_NODE_LEAF && n.cacheable && !il.ev_lo && !scores_out && !ctx->force_generic && !ctx->obs_override &&
+      !no_coarse && !nd.g.on) {
+    const double* cache = nullptr;
+    const int32_t* ocol = nullptr;
+    int n_obs = 0;
+    rc = ensure_leaf_cache(ctx, block_id, node_id, &cache, &ocol, &n_obs);
+    if (rc) return rc;
+    ProfScope ps(ctx, "option_list_coarse_draw");
+    return pclean_launch_leaf_coarse_draw(ctx, nd, it, ocol, n_obs, pclean_leaf_coarse_blocks(nd.n_cand), cache,
+                                          b.leaf_m[node_id].p, b.leaf_U[node_id].p, b.leaf_coarse[node_id].p, seed, sweep,
+                                          PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out, draws_out);
+  }
   FastRootDev fr;
   int fast = 0, fast_ev = 0;
   if (!scores_out && !snew_override && !ctx->force_generic && !nd.g.on) {
@@ -1562,7 +1584,15 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     ItemsDev it2{(int)n_over, 0, row2, il.ctx ? ctx2 : nullptr, excl ? excl2 : nullptr, it.particle ? part2 : nullptr,
                  s->row_offset + ctx->active_begin, list, evl2, evh2, il.ev_rows, il.ev_ctx, rng2, nullptr, nullptr,
                  il.draw_is, il.draw_ds, it.agg, org2};
-    rc = pclean_launch_enum(ctx, nd, it2, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out);
+    // compact-row exact scoring of every candidate (root_wave.hip: overflow_lds_kernel); evidence sets, groups and
+    // tables beyond one workgroup's LDS go through the generic kernel
+    int done = 0;
+    static const bool no_fast_over = getenv("PCLEAN_NO_FAST_OVERFLOW") != nullptr;
+    if (fast && !no_fast_over) {
+      done = pclean_launch_overflow_fast(ctx, fr, it2, ch, seed, sweep, site, n_draws, lse_out, draws_out);
+      if (done < 0) return done;
+    }
+    if (!done) rc = pclean_launch_enum(ctx, nd, it2, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out);
   }
   return rc;
 }
@@ -1585,8 +1615,9 @@ __device__ __forceinline__ uint64_t mix64(uint64_t h, uint32_t v) {
   h *= 0xff51afd7ed558ccdull;
   return h ^ (h >> 32);
 }
+template <typename KeyT>
 __global__ void item_key_kernel(int n, KeyColsDev kc, const int32_t* row, const int32_t* ctxv, const int32_t* excl,
-                                uint64_t* key, int32_t* idx) {
+                                int low_bits, KeyT* key, int32_t* idx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int r = row ? row[i] : i;
@@ -1597,25 +1628,29 @@ __global__ void item_key_kernel(int n, KeyColsDev kc, const int32_t* row, const 
   // Sort order = (referent, hash of the pre-filter observed values, hash of the whole tuple): groups of one
   // referent end up adjacent (their waves run back to back and re-read the same byte rows from L2), and within
   // a referent the groups that share the pre-filter rows are adjacent too (root_wave.hip reuses the scan).
-  // Short keys = few radix passes: 24 hash bits below the referent id, 32 hash bits without one; a
-  // collision of two different tuples can only split a group (item_head_kernel compares exactly).
+  // Short keys = few radix passes: low_bits hash bits below the referent id (half of them from the pre-filter
+  // values), 32 hash bits without a referent; a collision of two different tuples can only split a group
+  // (item_head_kernel compares exactly).  With a referent the whole key fits 32 bits whenever the table has fewer
+  // than 2^(32 - 16) rows (make_item_groups picks KeyT): half the sort's memory traffic.
   uint64_t hp = 0x9e3779b97f4a7c15ull;
   for (int c = 0; c < kc.n_pre; ++c) hp = mix64(hp, (uint32_t)kc.pre_col[c][r]);
   if (excl) {
     h = mix64(h, (uint32_t)excl[i]);
-    const uint64_t low = kc.n_pre > 0 ? (((hp >> 52) << 12) | (h >> 52)) : (h >> 40);
-    h = ((uint64_t)(uint32_t)(excl[i] + 1) << 24) | low;
+    const int hb = low_bits >> 1, lb = low_bits - hb;  // pre-filter hash bits, tuple hash bits
+    const uint64_t low = kc.n_pre > 0 ? (((hp >> (64 - hb)) << lb) | (h >> (64 - lb))) : (h >> (64 - low_bits));
+    h = ((uint64_t)(uint32_t)(excl[i] + 1) << low_bits) | low;
   } else {
     h = kc.n_pre > 0 ? (((hp >> 48) << 16) | (h >> 48)) : (h >> 32);
   }
-  key[i] = h;
+  key[i] = (KeyT)h;
   idx[i] = i;
 }
 // split_m > 0: a run of more than split_m items with one key is cut at every multiple of split_m (pieces of
 // split_m .. 2 split_m - 1 items): the scan kernel serialises the draws of a group in ONE wave, and its hand-out
 // of work balances at group granularity (the pieces are adjacent: the wave reuses the previous piece's scores).
+template <typename KeyT>
 __global__ void item_head_kernel(int n, KeyColsDev kc, const int32_t* row, const int32_t* ctxv, const int32_t* excl,
-                                 const uint64_t* key, const int32_t* idx, int32_t* head, int split_m) {
+                                 const KeyT* key, const int32_t* idx, int32_t* head, int split_m) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   int h = 1;
@@ -1713,21 +1748,41 @@ static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const It
   int32_t* head = scratch<int32_t>(ctx, n);
   int32_t* uid = scratch<int32_t>(ctx, n);
   if (!key || !key_s || !idx || !idx_s || !head || !uid) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-  hipLaunchKernelGGL(item_key_kernel, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, key, idx);
   size_t tmp_sort = 0, tmp_scan = 0;
-  int key_bits = 32;
+  int key_bits = 32, low_bits = 24;
+  bool k32 = true;  // without a referent the key is 32 hash bits
   if (excl) {  // referent ids are < rows of this node's table (+1 for "none")
     const int kmax = ctx->cand[b.nodes[node_id].table].n_rows + 2;
-    key_bits = 24;
-    while ((1ll << (key_bits - 24)) < kmax) ++key_bits;
+    int rb = 1;
+    while ((1ll << rb) < kmax) ++rb;
+    static const bool force64 = getenv("PCLEAN_SORT_KEY64") != nullptr;
+    k32 = rb <= 16 && !force64;
+    low_bits = k32 ? 32 - rb : 24;
+    key_bits = low_bits + rb;
   }
-  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, key, key_s, idx, idx_s, n, 0, key_bits, ctx->stream));
+  uint32_t* key32 = (uint32_t*)key;
+  uint32_t* key32_s = (uint32_t*)key_s;
+  if (k32) {
+    hipLaunchKernelGGL(item_key_kernel<uint32_t>, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, low_bits,
+                       key32, idx);
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, key32, key32_s, idx, idx_s, n, 0, key_bits, ctx->stream));
+  } else {
+    hipLaunchKernelGGL(item_key_kernel<uint64_t>, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, low_bits,
+                       key, idx);
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_sort, key, key_s, idx, idx_s, n, 0, key_bits, ctx->stream));
+  }
   HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan, head, uid, n, ctx->stream));
   unsigned char* tmp = scratch<unsigned char>(ctx, std::max(tmp_sort, tmp_scan));
   if (!tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_sort, key, key_s, idx, idx_s, n, 0, key_bits, ctx->stream));
-  hipLaunchKernelGGL(item_head_kernel, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, key_s, idx_s, head,
-                     split_m);
+  if (k32) {
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_sort, key32, key32_s, idx, idx_s, n, 0, key_bits, ctx->stream));
+    hipLaunchKernelGGL(item_head_kernel<uint32_t>, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, key32_s,
+                       idx_s, head, split_m);
+  } else {
+    HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_sort, key, key_s, idx, idx_s, n, 0, key_bits, ctx->stream));
+    hipLaunchKernelGGL(item_head_kernel<uint64_t>, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, key_s,
+                       idx_s, head, split_m);
+  }
   HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(tmp, tmp_scan, head, uid, n, ctx->stream));
   int32_t n_unique = 0;
   HIPCHK(ctx, hipMemcpyAsync(&n_unique, uid + (n - 1), sizeof n_unique, hipMemcpyDeviceToHost, ctx->stream));

@@ -193,17 +193,25 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
         order = np.argsort(g_rows, kind="stable")  # identical order on every rank -> identical row ids
         g_rows = g_rows[order]
         g_vals = g_vals[order]
+        t = trace.tables[cname]
+        t.counts[:n_before[bi]] += delta
         if len(g_rows):
             # identical new-row proposals of one sweep become ONE latent row (as commit_batch does for the
             # initialisation): in the sequential reference the second row would have joined the first row's
             # new referent instead of creating a duplicate entity.  Rows are created in order of first occurrence.
             first, grp = unique_rows(g_vals)
-            new_ids = trace.materialise_bulk(bi, g_vals[first])[grp]
+            # a proposing row whose OLD referent has just lost its last reference and holds exactly the proposed
+            # values keeps it (Trace.materialise_bulk): the row re-proposed its own private referent
+            reuse = None
+            if global_cur:
+                old = trace.cur[bi, g_rows[first]].astype(np.int64)
+                ok = old >= 0
+                ok[ok] = (t.counts[old[ok]] == 0) & t.live[old[ok]]
+                reuse = np.where(ok, old, -1)
+            new_ids = trace.materialise_bulk(bi, g_vals[first], reuse)[grp]
         else:
             new_ids = np.empty(0, dtype=np.int64)
-        t = trace.tables[cname]
         np.add.at(t.counts, new_ids, 1)  # each new row is referred to by its creator(s)
-        t.counts[:n_before[bi]] += delta
 
         def resolve(rows_global, ch):
             ch = np.array(ch, dtype=np.int32)

@@ -284,6 +284,8 @@ class Trace:
         """insert_row for the rows of `values` [k][n_cols], in order; returns their row ids."""
         t = self.tables[cname]
         k = len(values)
+        if k == 0:
+            return np.zeros(0, dtype=np.int64)
         ids = t.alloc_many(k)
         t.cols[:, ids] = values.T
         t.cols_dirty = True
@@ -308,18 +310,26 @@ class Trace:
         for j, state in props:
             np.subtract.at(state.counts, t.cols[j, ids], 1)
         t.live[ids] = False
-        t.free.extend(int(r) for r in ids)
+        t.free.extend(ids.tolist())
         for j, target in fks:
             tgt = self.tables[target]
             ref = t.cols[j, ids]
             np.subtract.at(tgt.counts, ref, 1)
-            cand = np.unique(ref)
-            self.delete_rows_bulk(target, cand[(tgt.counts[cand] == 0) & tgt.live[cand]])
+            gone = ref[(tgt.counts[ref] == 0) & tgt.live[ref]]  # (usually none: sort only those)
+            if len(gone):
+                self.delete_rows_bulk(target, np.unique(gone))
 
-    def materialise_bulk(self, bi, vals):
+    def materialise_bulk(self, bi, vals, reuse=None):
         """Rows of block bi's root class for the node choices vals [k][n_nodes] (row_inference.jl:169-185 for
         many rows).  Proposals without a nested NEW referent are built with array operations; the rest
-        go through _materialise.  Returns the row ids, in the order of `vals`."""
+        go through _materialise.  Returns the row ids, in the order of `vals`.
+
+        reuse [k] (optional): per proposal a row of the class that is about to lose its last reference (the
+        proposing row's old referent), -1 for none.  Where the new row's flattened values EQUAL that row's, the row
+        is kept instead of being collected and re-created under another id — in the reference the observed row is
+        unincorporated, its singleton referent garbage-collected and an identical row created under a fresh gensym
+        key (row_inference.jl:115-126, 169-185): the same table up to the row's name.  It keeps the table's columns
+        (and everything the device derives from them) unchanged when rows re-propose their own private referent."""
         k = len(vals)
         out = np.empty(k, dtype=np.int64)
         if k == 0:
@@ -339,7 +349,16 @@ class Trace:
                 values[:, j] = self.tables[ccls].cols[cc, v[:, cn]]
             for j, cid in slots:
                 values[:, j] = v[:, cid]
-            out[idx] = self.insert_rows_bulk(cname, values)
+            if reuse is not None:
+                t = self.tables[cname]
+                old = np.asarray(reuse, dtype=np.int64)[idx]
+                same = old >= 0
+                same[same] = np.all(t.cols[:, old[same]] == values[same].T, axis=0)
+                out[idx[same]] = old[same]
+                fresh = ~same
+                out[idx[fresh]] = self.insert_rows_bulk(cname, values[fresh])
+            else:
+                out[idx] = self.insert_rows_bulk(cname, values)
         for i in np.flatnonzero(~simple):
             out[i] = self._materialise(bi, 0, vals[i])
         return out
