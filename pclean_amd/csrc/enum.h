@@ -152,10 +152,11 @@ struct FastRootDev {
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
-                            int32_t* desc_scratch);
+                            int32_t* desc_scratch, int32_t* overflow_list);
 int pclean_launch_overflow_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                                 uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
-                                int32_t* draws_out);
+                                int32_t* draws_out, const int32_t* over_list, const unsigned int* over_count);
+int pclean_overflow_fast_ok(const FastRootDev& fr, const ItemsDev& it);
 int pclean_launch_root_flags(pclean_ctx* ctx, int n_groups, const int32_t* gd, const int32_t* grp_off,
                              const int32_t* members, const int32_t* oflag, int32_t* out);
 size_t pclean_fast_desc_words(int n_groups);  // int32 words of desc_scratch for n_groups groups

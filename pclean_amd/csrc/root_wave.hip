@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     const FastRootDev fr, const WaveItems wi, uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, int n_groups,
     const int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr, double* __restrict__ g_m,
     uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out, int32_t* __restrict__ overflow_flag,
-    unsigned int* __restrict__ overflow_count) {
+    unsigned int* __restrict__ overflow_count, int32_t* __restrict__ overflow_list) {
   // exact scores and, later, the fixed-point prefix share one array: entry j is converted in place by lane j
   __shared__ uint64_t s_pref[WPG][CAP + 8];
   __shared__ int32_t s_k[WPG][CAP + 8];
@@ -626,18 +626,26 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     }
     dvp = dv;
     p_valid = true;
-    if (over) {  // flat posterior: the host re-runs these items with the generic kernel (flags are pre-zeroed)
-      if (m_hi - m_lo == 1) {
-        if (lane == 0) overflow_flag[wi.out_pos ? wi.out_pos[t] : t] = PCLEAN_CHOICE_NEW;  // marker understood by compact_new_kernel
+    if (over) {  // flat posterior: these items are re-run over all candidates (flags are pre-zeroed); with an
+      // overflow list the re-run kernel consumes it straight from the device (no count read-back)
+      const int n_mem_o = m_hi - m_lo;
+      int base_o = 0;
+      if (lane == 0) {
+        base_o = (int)atomicAdd(overflow_count, (unsigned int)n_mem_o);
+        g_m[g] = __builtin_nan("");
+      }
+      base_o = __builtin_amdgcn_readfirstlane(base_o);
+      if (n_mem_o == 1) {
+        if (lane == 0) {
+          overflow_flag[wi.out_pos ? wi.out_pos[t] : t] = PCLEAN_CHOICE_NEW;  // marker understood by compact_new_kernel
+          if (overflow_list) overflow_list[base_o] = t;
+        }
       } else {
         for (int mi = m_lo + lane; mi < m_hi; mi += 64) {
           const int tm = wi.members[mi];
           overflow_flag[wi.out_pos ? wi.out_pos[tm] : tm] = PCLEAN_CHOICE_NEW;
+          if (overflow_list) overflow_list[base_o + (mi - m_lo)] = tm;
         }
-      }
-      if (lane == 0) {
-        atomicAdd(overflow_count, (unsigned int)(m_hi - m_lo));
-        g_m[g] = __builtin_nan("");
       }
     } else {
       if (lane == 0) {
@@ -719,13 +727,20 @@ __global__ void group_lse_kernel(int n_groups, const int32_t* __restrict__ grp_o
 // byte rows (fast_exact_score: coalesced byte loads, one density-table lookup per term) instead of the generic
 // kernel's dependent gather chains (candidate column -> pair byte -> length -> density pieces), which made 27
 // overflowed rows cost 0.56 ms of every 1M-row sweep.  One workgroup per item; items are not grouped.
-__global__ __launch_bounds__(256) void overflow_lds_kernel(const FastRootDev fr, const ItemsDev it, const ChildrenDev ch,
+#define OVF_T 1024  // threads per workgroup of overflow_lds_kernel (one workgroup per CU: the scores fill its LDS)
+__global__ __launch_bounds__(OVF_T) void overflow_lds_kernel(const FastRootDev fr, const ItemsDev it, const ChildrenDev ch,
                                                            uint64_t seed, uint32_t sweep, uint32_t site, int n_draws,
                                                            double* __restrict__ lse_out,
-                                                           int32_t* __restrict__ draws_out) {
+                                                           int32_t* __restrict__ draws_out,
+                                                           const int32_t* __restrict__ over_list,
+                                                           const unsigned int* __restrict__ over_count) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_o[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int t = blockIdx.x;
+  // list mode: the items the scan kernel appended to over_list (count on the device), fixed grid; else item = workgroup
+  const int n_work = over_list ? (int)*over_count : it.n;
+  for (int wi_ = blockIdx.x; wi_ < n_work; wi_ += gridDim.x) {
+  __syncthreads();  // the previous item's LDS is no longer read
+  const int t = over_list ? over_list[wi_] : wi_;
   const int to = it.out_pos ? it.out_pos[t] : t;
   const int n = fr.n_cand;
   const bool fk = !fr.is_leaf;
@@ -733,7 +748,7 @@ __global__ __launch_bounds__(256) void overflow_lds_kernel(const FastRootDev fr,
   double* s = (double*)smem_o;
   uint64_t* u = (uint64_t*)smem_o;
   double* red = (double*)(smem_o + (size_t)((nc + 1) & ~1) * 8);
-  uint64_t* wsum = (uint64_t*)(red + 8);
+  uint64_t* wsum = (uint64_t*)(red + 16);
   const int row = it.row ? it.row[t] : t;
   const int excl = it.excl ? it.excl[t] : -1;
   const int ctx0 = it.ctx ? it.ctx[(size_t)t * PCLEAN_MAX_CTX] : 0;
@@ -744,7 +759,8 @@ __global__ __launch_bounds__(256) void overflow_lds_kernel(const FastRootDev fr,
   const double* prior = (excl >= 0 && fr.prior_e) ? fr.prior_e : fr.prior_n;
   // ---- phase 1: exact scores, prior first, terms in plan order (candidate_score's operation order)
   double lmax = -__builtin_inf();
-  for (int k = tid; k < n; k += 256) {
+  #pragma unroll 2
+  for (int k = tid; k < n; k += OVF_T) {
     double pr = prior[k];
     if (k == excl) pr = deleted ? -__builtin_inf() : fr.logc_m1[excl] - fr.scal[1];
     const double sk = pr == -__builtin_inf() ? pr : fast_exact_score(fr, o, ctx0, ctx1, k, pr);
@@ -769,13 +785,14 @@ __global__ __launch_bounds__(256) void overflow_lds_kernel(const FastRootDev fr,
   lmax = wave_max64(lmax);
   if (lane == 0) red[wave] = lmax;
   __syncthreads();
-  const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-  for (int k = tid; k < nc; k += 256) {
+  double m = red[0];
+  for (int w = 1; w < OVF_T / 64; ++w) m = fmax(m, red[w]);
+  for (int k = tid; k < nc; k += OVF_T) {
     const double sk = s[k];
     u[k] = (m == -__builtin_inf()) ? 0ull : pclean_fixw(sk - m);
   }
   __syncthreads();
-  const int chunk = (nc + 255) / 256;
+  const int chunk = (nc + OVF_T - 1) / OVF_T;
   const int lo = min(tid * chunk, nc), hi = min(lo + chunk, nc);
   uint64_t part = 0;
   for (int k = lo; k < hi; ++k) part += u[k];
@@ -786,9 +803,11 @@ __global__ __launch_bounds__(256) void overflow_lds_kernel(const FastRootDev fr,
   }
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
-  uint64_t base = 0;
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-  const uint64_t U = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  uint64_t base = 0, U = 0;
+  for (int w = 0; w < OVF_T / 64; ++w) {
+    if (w < wave) base += wsum[w];
+    U += wsum[w];
+  }
   {
     uint64_t run = base + incl - part;
     for (int k = lo; k < hi; ++k) {
@@ -799,7 +818,7 @@ __global__ __launch_bounds__(256) void overflow_lds_kernel(const FastRootDev fr,
   __syncthreads();
   if (tid == 0 && lse_out) lse_out[to] = pclean_lse_from_fix(m, U);
   const int draw_is = it.draw_is ? it.draw_is : n_draws, draw_ds = it.draw_ds ? it.draw_ds : 1;
-  for (int j = tid; j < n_draws; j += 256) {
+  for (int j = tid; j < n_draws; j += OVF_T) {
     int32_t res = fk ? PCLEAN_CHOICE_NEW : n - 1;
     if (U != 0) {
       const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[t] : (uint32_t)((int64_t)row + it.row_offset);
@@ -817,23 +836,34 @@ __global__ __launch_bounds__(256) void overflow_lds_kernel(const FastRootDev fr,
     }
     draws_out[(size_t)to * draw_is + (size_t)j * draw_ds] = res;
   }
+  }
 }
 
 // returns 1 when the launch was made, 0 when the candidates do not fit the LDS of one workgroup (caller: generic kernel)
+static size_t overflow_lds_bytes(const FastRootDev& fr) {
+  const int nc = fr.n_cand + (fr.is_leaf ? 0 : 1);
+  return (size_t)((nc + 1) & ~1) * 8 + (32 + 64) * 8;
+}
+// can the overflowed items of this launch be re-run by overflow_lds_kernel (candidates fit one workgroup's LDS)?
+int pclean_overflow_fast_ok(const FastRootDev& fr, const ItemsDev& it) {
+  return overflow_lds_bytes(fr) <= 160 * 1024 && !it.ev_lo;
+}
+// over_list == null: one workgroup per item of `it` (ungrouped).  Otherwise the items over_list[0 .. *over_count) of
+// `it` (ungrouped view of the scan's items), fixed grid, nothing read back.
 int pclean_launch_overflow_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                                 uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
-                                int32_t* draws_out) {
+                                int32_t* draws_out, const int32_t* over_list, const unsigned int* over_count) {
   if (it.n <= 0) return 1;
-  const int nc = fr.n_cand + (fr.is_leaf ? 0 : 1);
-  const size_t lds = (size_t)((nc + 1) & ~1) * 8 + (16 + 64) * 8;
+  const size_t lds = overflow_lds_bytes(fr);
   if (lds > 160 * 1024 || it.grp_off || it.ev_lo) return 0;
   static bool attr_set = false;
   if (!attr_set) {
     HIPCHK(ctx, hipFuncSetAttribute((const void*)overflow_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(overflow_lds_kernel, dim3(it.n), dim3(256), lds, ctx->stream, fr, it, ch, seed, sweep, site, n_draws,
-                     lse_out, draws_out);
+  const int grid = over_list ? std::min(it.n, 256) : it.n;
+  hipLaunchKernelGGL(overflow_lds_kernel, dim3(grid), dim3(OVF_T), lds, ctx->stream, fr, it, ch, seed, sweep, site, n_draws,
+                     lse_out, draws_out, over_list, over_count);
   HIPCHK(ctx, hipGetLastError());
   return 1;
 }
@@ -861,7 +891,7 @@ int pclean_launch_root_flags(pclean_ctx* ctx, int n_groups, const int32_t* gd, c
 }
 
 typedef void (*wave_kernel_t)(const FastRootDev, const WaveItems, uint64_t, uint32_t, uint32_t, int, int, const int32_t*,
-                              unsigned int*, double*, uint64_t*, int32_t*, int32_t*, unsigned int*);
+                              unsigned int*, double*, uint64_t*, int32_t*, int32_t*, unsigned int*, int32_t*);
 
 static wave_kernel_t pick_kernel(int n_terms) {
   if (n_terms <= 2) return fk_root_wave_kernel<2, WAVE_SURV_CAP, 4>;
@@ -880,7 +910,7 @@ size_t pclean_fast_desc_words(int n_groups) {
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
-                            int32_t* desc_scratch) {
+                            int32_t* desc_scratch, int32_t* overflow_list) {
   if (it.n <= 0) return PCLEAN_OK;
   const size_t ng = (size_t)it.n;
   unsigned int* chunk_ctr = reinterpret_cast<unsigned int*>(desc_scratch + ng * GD_STRIDE);
@@ -909,7 +939,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   WaveItems wi{it.grp_off ? it.members : nullptr, it.row, it.rng_row, it.particle, it.out_pos, it.row_offset, it.draw_is,
                it.draw_ds};
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * wpg), 0, ctx->stream, fr, wi, seed, sweep, site, n_draws, it.n, desc_scratch,
-                     chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count);
+                     chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count, overflow_list);
 #ifdef WAVE_PHASE_CLOCK
   if (it.n > 100000) {
     unsigned long long h[16];

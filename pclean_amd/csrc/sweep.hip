@@ -711,6 +711,12 @@ struct SweepState {
   std::vector<std::string> prof_names;
   std::vector<float> prof_ms;
   std::vector<int32_t> prof_launches;
+  // overflow counters of the compact-table launches of the running call whose re-run needs no read-back
+  // (overflow_lds_kernel in list mode): counted into the statistics / heuristics at the end of the call
+  DevBuf<unsigned int> over_ctr;   // [OVER_SLOTS]
+  struct OverRec { int block, node, n_items; bool time_it, leaf; };
+  std::vector<OverRec> over_rec;
+  unsigned int* h_over = nullptr;  // page-locked copy of over_ctr
   // block 0's root scan of the last pclean_sweep (pclean_debug_root_flags; the scratch stays valid until the next call)
   const int32_t* dbg_desc = nullptr;
   const int32_t* dbg_grp_off = nullptr;
@@ -719,6 +725,7 @@ struct SweepState {
   int dbg_groups = 0, dbg_items = 0;
 };
 
+#define OVER_SLOTS 256
 static SweepState* st(pclean_ctx* ctx) {
   if (!ctx->sweep_state) ctx->sweep_state = new SweepState();
   return (SweepState*)ctx->sweep_state;
@@ -754,6 +761,8 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
     kv.second.count.release();
   }
   if (s->h_counts) (void)hipHostFree(s->h_counts);
+  if (s->h_over) (void)hipHostFree(s->h_over);
+  s->over_ctr.release();
   for (auto e : s->prof_ev) (void)hipEventDestroy(e);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -761,6 +770,52 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
   if (s->eve) (void)hipEventDestroy(s->eve);
   delete s;
   ctx->sweep_state = nullptr;
+}
+
+// Start of an entry point that evaluates plan nodes: scratch pool rewound, overflow counters cleared.
+static int begin_call(pclean_ctx* ctx) {
+  SweepState* s = st(ctx);
+  s->pool_used = 0;
+  s->dbg_desc = nullptr;
+  s->over_rec.clear();
+  if (s->over_ctr.alloc(OVER_SLOTS)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemsetAsync(s->over_ctr.p, 0, OVER_SLOTS * sizeof(unsigned int), ctx->stream));
+  return PCLEAN_OK;
+}
+// End of such a call, after its last stream synchronisation has been queued: the overflow counts of the sync-free
+// launches go into the statistics and the "does the pre-filter pay for this option list" heuristic.
+static int queue_over_copy(pclean_ctx* ctx) {  // before a stream synchronisation of the caller
+  SweepState* s = st(ctx);
+  if (s->over_rec.empty()) return PCLEAN_OK;
+  if (!s->h_over) HIPCHK(ctx, hipHostMalloc((void**)&s->h_over, OVER_SLOTS * sizeof(unsigned int), hipHostMallocDefault));
+  HIPCHK(ctx, hipMemcpyAsync(s->h_over, s->over_ctr.p, s->over_rec.size() * sizeof(unsigned int), hipMemcpyDeviceToHost,
+                             ctx->stream));
+  return PCLEAN_OK;
+}
+static void apply_over_stats(pclean_ctx* ctx) {  // after that synchronisation
+  SweepState* s = st(ctx);
+  for (size_t i = 0; i < s->over_rec.size(); ++i) {
+    const SweepState::OverRec& r = s->over_rec[i];
+    const unsigned int h = s->h_over[i];
+    ctx->timing.reserved += (int32_t)h;
+    if (r.time_it) ctx->root_stats.overflow_items = (int32_t)h;
+    if (r.leaf && r.n_items >= 1024 && (size_t)h * 4 > (size_t)r.n_items) {
+      FastRoot& f = s->fast[r.block * 64 + r.node];
+      f.disabled = f.backoff;
+      f.backoff = std::min(f.backoff * 2, 1 << 20);
+    }
+    if (h && getenv("PCLEAN_DEBUG_OVERFLOW"))
+      fprintf(stderr, "[pclean] block %d node %d: %u of %d items re-run over all candidates\n", r.block, r.node, h, r.n_items);
+  }
+  s->over_rec.clear();
+}
+static int finish_call(pclean_ctx* ctx) {
+  if (st(ctx)->over_rec.empty()) return PCLEAN_OK;
+  int rc = queue_over_copy(ctx);
+  if (rc) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  apply_over_stats(ctx);
+  return PCLEAN_OK;
 }
 
 // bump-style scratch: buffers persist across sweeps, handed out in order
@@ -1519,18 +1574,31 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     if (time_it) (void)hipEventRecord(s->ev1, ctx->stream);
     return rc;
   }
-  // compact-table kernels; items whose survivor list overflows are re-run with the generic kernel
+  // compact-table kernels; items whose survivor list overflows are re-run over all candidates
   int32_t* oflag = scratch<int32_t>(ctx, il.n);
   if (!oflag || s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-  HIPCHK(ctx, hipMemsetAsync(s->counter.p + 1, 0, sizeof(unsigned int), ctx->stream));
+  // Sync-free re-run: the scan kernel appends the overflowed items to a device list that overflow_lds_kernel
+  // (root_wave.hip) consumes with a fixed grid; the count is only read at the end of the call, for the statistics.
+  static const bool no_fast_over = getenv("PCLEAN_NO_FAST_OVERFLOW") != nullptr;
+  const bool list_mode = fast && !no_fast_over && pclean_overflow_fast_ok(fr, it) && s->over_rec.size() < OVER_SLOTS &&
+                         s->over_ctr.p != nullptr;
+  unsigned int* over_count = list_mode ? s->over_ctr.p + s->over_rec.size() : s->counter.p + 1;
+  int32_t* over_list = nullptr;
+  if (list_mode) {
+    over_list = scratch<int32_t>(ctx, il.n);
+    if (!over_list) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    s->over_rec.push_back(SweepState::OverRec{block_id, node_id, il.n, time_it, n.kind == PCLEAN_NODE_LEAF});
+  } else {
+    HIPCHK(ctx, hipMemsetAsync(s->counter.p + 1, 0, sizeof(unsigned int), ctx->stream));
+  }
   HIPCHK(ctx, hipMemsetAsync(oflag, 0, (size_t)il.n * sizeof(int32_t), ctx->stream));  // kernels only set overflow markers
   if (fast) {
     int32_t* desc = scratch<int32_t>(ctx, pclean_fast_desc_words(it.n));
     if (!desc) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
     ProfScope ps(ctx, time_it ? "root_scan_block0" : (n.kind == PCLEAN_NODE_FK ? "slot_scan" : "option_scan"));
     if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
-    rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag,
-                                 s->counter.p + 1, desc);
+    rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag, over_count, desc,
+                                 over_list);
     if (time_it) {
       (void)hipEventRecord(s->ev1, ctx->stream);
       s->dbg_desc = desc;
@@ -1539,6 +1607,16 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
       s->dbg_oflag = oflag;
       s->dbg_groups = it.n;
       s->dbg_items = il.n;
+    }
+    if (!rc && list_mode) {
+      ProfScope ps2(ctx, "overflow_rerun");
+      ItemsDev itf = it;  // the scan's items, ungrouped: list entries index them
+      itf.n = il.n;
+      itf.grp_off = nullptr;
+      itf.members = nullptr;
+      const int done = pclean_launch_overflow_fast(ctx, fr, itf, ch, seed, sweep, site, n_draws, lse_out, draws_out, over_list,
+                                                   over_count);
+      return done < 0 ? done : PCLEAN_OK;
     }
   } else {
     ProfScope ps(ctx, "evidence_option_scan");
@@ -1589,7 +1667,7 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     int done = 0;
     static const bool no_fast_over = getenv("PCLEAN_NO_FAST_OVERFLOW") != nullptr;
     if (fast && !no_fast_over) {
-      done = pclean_launch_overflow_fast(ctx, fr, it2, ch, seed, sweep, site, n_draws, lse_out, draws_out);
+      done = pclean_launch_overflow_fast(ctx, fr, it2, ch, seed, sweep, site, n_draws, lse_out, draws_out, nullptr, nullptr);
       if (done < 0) return done;
     }
     if (!done) rc = pclean_launch_enum(ctx, nd, it2, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out);
@@ -2143,8 +2221,10 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   for (int r = 0; r < n_roots; ++r)
     if (roots[r] < 0 || roots[r] >= nn) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: bad root");
   SweepState* s = st(ctx);
-  s->pool_used = 0;
-  s->dbg_desc = nullptr;
+  {
+    const int rcb = begin_call(ctx);
+    if (rcb) return rcb;
+  }
   if (s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   const int n_ev = ev_off[n_items];
   if (n_ev > 0 && !ev_rows) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: evidence rows missing");
@@ -2253,7 +2333,7 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   s->lat_agg.clear();
   if (s->prof_on) prof_collect(ctx);
-  return PCLEAN_OK;
+  return finish_call(ctx);
 }
 
 extern "C" int pclean_debug_root_flags(pclean_ctx* ctx, int32_t n_rows, int32_t* out) {
@@ -2297,8 +2377,10 @@ extern "C" int pclean_score_node(pclean_ctx* ctx, int32_t block_id, int32_t node
   if (node_id < 0 || node_id >= (int)b.nodes.size()) return pclean_fail(ctx, PCLEAN_ERR_ARG, "bad node id");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   SweepState* s = st(ctx);
-  s->pool_used = 0;
-  s->dbg_desc = nullptr;
+  {
+    const int rcb = begin_call(ctx);
+    if (rcb) return rcb;
+  }
   const pclean_node& n = b.nodes[node_id];
   const CandTable& t = ctx->cand[n.table];
   const int nc = t.n_rows + (n.kind == PCLEAN_NODE_FK ? 1 : 0);
@@ -2325,7 +2407,7 @@ extern "C" int pclean_score_node(pclean_ctx* ctx, int32_t block_id, int32_t node
   if (scores) HIPCHK(ctx, hipMemcpyAsync(scores, d_scores, (size_t)n_items * nc * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (n_draws) HIPCHK(ctx, hipMemcpyAsync(draws, d_draws, (size_t)n_items * n_draws * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  return PCLEAN_OK;
+  return finish_call(ctx);
 }
 
 // ---------------------------------------------------------------------------
@@ -2352,8 +2434,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     if (!ctx->block[b].valid) return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_sweep: block %d not loaded", b);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   SweepState* s = st(ctx);
-  s->pool_used = 0;
-  s->dbg_desc = nullptr;
+  {
+    const int rcb = begin_call(ctx);
+    if (rcb) return rcb;
+  }
   if (!s->ev0) {
     HIPCHK(ctx, hipEventCreate(&s->ev0));
     HIPCHK(ctx, hipEventCreate(&s->ev1));
@@ -2643,7 +2727,12 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     (void)hipEventRecord(s->eve, ctx->stream);
     if (chosen_particle) HIPCHK(ctx, hipMemcpyAsync(chosen_particle, s->chosen.p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logml) HIPCHK(ctx, hipMemcpyAsync(logml, s->logml.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    {
+      const int rco = queue_over_copy(ctx);
+      if (rco) return rco;
+    }
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    apply_over_stats(ctx);
     if (choice)
       for (int bi = 0; bi < n_blocks; ++bi)
         if (ctx->block[bi].is_score)

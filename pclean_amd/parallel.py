@@ -190,9 +190,10 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
             cursor[r] = c
         g_rows = np.concatenate(g_rows)
         g_vals = np.concatenate(g_vals)
-        order = np.argsort(g_rows, kind="stable")  # identical order on every rank -> identical row ids
-        g_rows = g_rows[order]
-        g_vals = g_vals[order]
+        if len(g_rows) > 1 and np.any(g_rows[1:] < g_rows[:-1]):  # (contiguous shards arrive in global row order)
+            order = np.argsort(g_rows, kind="stable")  # identical order on every rank -> identical row ids
+            g_rows = g_rows[order]
+            g_vals = g_vals[order]
         t = trace.tables[cname]
         t.counts[:n_before[bi]] += delta
         if len(g_rows):

@@ -59,26 +59,35 @@ class ProbTableState:
 
 
 def unique_rows(vals):
-    """np.unique(vals, axis=0, return_index=True, return_inverse=True) restricted to what the commits need —
-    (index of the first occurrence of every distinct row, group id of every row), groups numbered in the order
-    np.unique sorts them is NOT needed — through one 64-bit hash per row and a 1-D sort; verified exactly, with
-    the slow path on a hash collision.  Returns (first [g], inv [k]) with groups ordered by first occurrence."""
+    """(index of the first occurrence of every distinct row of vals [k][c], group id of every row), groups numbered in
+    order of first occurrence — what np.unique(vals, axis=0, return_index=True, return_inverse=True) gives after
+    re-ordering its groups, without sorting the rows: one 64-bit hash per row, a 2^16-bucket histogram of its low bits
+    (a row alone in its bucket is distinct from every other row), exact grouping of the few rows that share a bucket.
+    Most proposals of a sweep are distinct, so almost nothing is ever sorted."""
     vals = np.ascontiguousarray(vals)
     k = len(vals)
     if k == 0:
         return np.zeros(0, np.int64), np.zeros(0, np.int64)
-    mult = (np.arange(1, vals.shape[1] + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)
-    h = (vals.astype(np.int64).view(np.uint64) * mult).sum(axis=1, dtype=np.uint64)
+    mult = ((np.arange(1, vals.shape[1] + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) | np.uint64(1)).view(np.int64)
+    h = (vals.astype(np.int64) @ mult).view(np.uint64)  # (integer matmul wraps modulo 2^64)
     h ^= h >> np.uint64(29)
-    _, first, inv = np.unique(h, return_index=True, return_inverse=True)
-    inv = np.asarray(inv).reshape(-1)
-    if not np.array_equal(vals[first][inv], vals):  # two different rows share a hash: exact grouping
-        _, first, inv = np.unique(vals, axis=0, return_index=True, return_inverse=True)
+    bucket = (h & np.uint64(0xFFFF)).astype(np.int64)
+    crowded = np.bincount(bucket, minlength=1 << 16)[bucket] > 1
+    is_first = ~crowded
+    rep = np.arange(k, dtype=np.int64)  # index of the first occurrence of every row's group
+    idx = np.flatnonzero(crowded)
+    if len(idx):  # exact grouping of the rows whose bucket holds more than one row
+        sub = vals[idx]
+        _, f, inv = np.unique(h[idx], return_index=True, return_inverse=True)
         inv = np.asarray(inv).reshape(-1)
-    order = np.argsort(first, kind="stable")  # groups in order of first occurrence
-    rank = np.empty(len(order), dtype=np.int64)
-    rank[order] = np.arange(len(order))
-    return first[order], rank[inv]
+        if not np.array_equal(sub[f][inv], sub):  # two different rows share the 64-bit hash: exact grouping
+            _, f, inv = np.unique(sub, axis=0, return_index=True, return_inverse=True)
+            inv = np.asarray(inv).reshape(-1)
+        rep[idx] = idx[f][inv]
+        is_first[idx[f]] = True
+    first = np.flatnonzero(is_first)
+    rank = np.cumsum(is_first) - 1
+    return first, rank[rep]
 
 
 class LatentTable:
