@@ -72,9 +72,14 @@ def oracle_world_for_rows(orc, lw, obs_local, tr, eng, rows):
     w.set_obs(np.ascontiguousarray(sub_local))
     mr, md, ml, nb, logl = eng.hip.get_density_tables()
     w.set_density(mr, md, ml, nb, logl)
+    from pclean_amd.encode import load_lm_params
+    sym, off, _, _ = lw.pool.arrays()
+    w.set_strings(sym, off)
+    w.set_lm(*load_lm_params(), lw.pool.letter_symbols())
     for key, (pid, odom, ldom) in lw.pair_id.items():
         d = eng.hip.get_pair_rows(pid, remap[key[0]], len(ldom))
         w.set_pair(pid, d, lw.pool.lens[ldom.id_array()].astype(np.uint16))
+        w.set_pair_strings(pid, odom.id_array()[remap[key[0]]], eng.dist_mode)
     for fid, fn in lw.fn_tables.items():
         w.set_fn(fid, fn)
     py = np.zeros((64, 2))

@@ -66,4 +66,16 @@ PCLEAN_RNG_HD uint64_t pclean_rand64(uint64_t seed, uint32_t row, uint32_t site,
   return ((uint64_t)o.v[1] << 32) | (uint64_t)o.v[0];
 }
 
+/* Key of the private draw stream of a value sampled for a chosen ProposalDummyValue (block_proposal.jl:58-60:
+ * `random(node.dist, args...)`): one stream per (draw site of the enumerated node, particle, sweep); the row is the
+ * counter's first word.  The sweep draws the string with this key when it corrects the particle's weight, the host
+ * draws it again with the same key when the particle is chosen and its new row is committed. */
+PCLEAN_RNG_HD uint64_t pclean_dummy_seed(uint64_t seed, uint32_t site, uint32_t particle, uint32_t sweep) {
+  uint64_t x = seed ^ (((uint64_t)site << 32) | (uint64_t)sweep);
+  x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+  x ^= (uint64_t)(particle + 1u) * 0x94d049bb133111ebull;
+  x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+  return x ^ (x >> 31);
+}
+
 #endif /* PCLEAN_PHILOX_H */

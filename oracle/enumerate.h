@@ -32,6 +32,8 @@ struct OPair {
   int n_obs = 0, n_lat = 0;
   std::vector<uint16_t> d;        /* [n_obs][n_lat] */
   std::vector<uint16_t> lat_len;  /* [n_lat] */
+  std::vector<int32_t> obs_ids;   /* pool string of every observed value (AddTypos tables; dummy-value weights) */
+  int dist_mode = PCLEAN_DIST_DL; /* flavour of DamerauLevenshtein() the table was built with */
 };
 struct OTable {
   bool is_options = false;
@@ -78,6 +80,12 @@ struct World {
   std::vector<OTable> table;
   std::vector<OFn> fn;
   std::vector<OBlock> block;
+  /* string pool + letter model of random(StringPrior): what the weight of a particle that chose a
+   * ProposalDummyValue needs (block_proposal.jl:58-60; sweep.h: dummy_correction) */
+  std::vector<uint16_t> sym;
+  std::vector<int64_t> off;
+  std::vector<double> lm_init, lm_trans; /* [28], [28*28] ([prev][next]) */
+  std::vector<uint16_t> letter_sym;      /* [28] pool symbol of every alphabet letter, 0xFFFF = absent */
   World() : mean(64), pair(64), table(64), fn(64), block(16) {}
 };
 

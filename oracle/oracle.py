@@ -49,6 +49,8 @@ def lib():
         L.pco_fixw.restype = C.c_uint64
         L.pco_rand64.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.pco_rand64.restype = C.c_uint64
+        L.pco_dummy_seed.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.pco_dummy_seed.restype = C.c_uint64
         L.pco_world_create.restype = C.c_void_p
         _lib = L
     return _lib
@@ -163,6 +165,19 @@ class RandomOracle:
                                       _p(lens, C.c_int32))
         return out, lens
 
+    def random_string_prior_at(self, seeds, elems, min_len, max_len, init_p, trans_p, stream=0):
+        seeds = np.ascontiguousarray(seeds, np.uint64)
+        elems = np.ascontiguousarray(elems, np.uint32)
+        init_p = np.ascontiguousarray(init_p, np.float64)
+        trans_p = np.ascontiguousarray(trans_p, np.float64)
+        n, stride = len(seeds), max(int(max_len), 1)
+        out = np.zeros((n, stride), np.uint8)
+        lens = np.zeros(n, np.int32)
+        lib().pco_random_string_prior_at(n, _p(seeds, C.c_uint64), _p(elems, C.c_uint32), int(min_len), int(max_len),
+                                         _p(init_p, C.c_double), _p(trans_p, C.c_double), C.c_uint32(stream), stride,
+                                         _p(out, C.c_uint8), _p(lens, C.c_int32))
+        return out, lens
+
     def random_categorical(self, n, logp, seed, stream):
         logp = np.ascontiguousarray(logp, np.float64)
         out = np.zeros(n, np.int32)
@@ -234,6 +249,21 @@ class World:
         d = np.ascontiguousarray(d, np.uint16)
         lat_len = np.ascontiguousarray(lat_len, np.uint16)
         self.L.pco_world_set_pair(self.h, pid, d.shape[0], d.shape[1], _p(d, C.c_uint16), _p(lat_len, C.c_uint16))
+
+    def set_strings(self, sym, off):
+        sym = np.ascontiguousarray(sym, np.uint16)
+        off = np.ascontiguousarray(off, np.int64)
+        self.L.pco_world_set_strings(self.h, len(off) - 1, _p(sym, C.c_uint16), _p(off, C.c_int64))
+
+    def set_pair_strings(self, pid, obs_ids, dist_mode):
+        obs_ids = np.ascontiguousarray(obs_ids, np.int32)
+        self.L.pco_world_set_pair_strings(self.h, pid, len(obs_ids), _p(obs_ids, C.c_int32), int(dist_mode))
+
+    def set_lm(self, init_p, trans_p, letter_sym):
+        init_p = np.ascontiguousarray(init_p, np.float64)
+        trans_p = np.ascontiguousarray(trans_p, np.float64)
+        letter_sym = np.ascontiguousarray(letter_sym, np.uint16)
+        self.L.pco_world_set_lm(self.h, _p(init_p, C.c_double), _p(trans_p, C.c_double), _p(letter_sym, C.c_uint16))
 
     def set_table(self, tid, cols, counts, logc_full, logc_m1, scal):
         cols = np.ascontiguousarray(cols, np.int32)

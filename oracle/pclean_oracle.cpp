@@ -104,6 +104,20 @@ void pco_world_set_pair(pco::World* w, int id, int n_obs, int n_lat, const uint1
   p.d.assign(d, d + (size_t)n_obs * n_lat);
   p.lat_len.assign(lat_len, lat_len + n_lat);
 }
+/* what the weight of a chosen ProposalDummyValue needs (sweep.h: dummy_correction) */
+void pco_world_set_strings(pco::World* w, int n_strings, const uint16_t* sym, const int64_t* off) {
+  w->off.assign(off, off + n_strings + 1);
+  w->sym.assign(sym, sym + off[n_strings]);
+}
+void pco_world_set_pair_strings(pco::World* w, int id, int n_obs, const int32_t* obs_ids, int dist_mode) {
+  w->pair[id].obs_ids.assign(obs_ids, obs_ids + n_obs);
+  w->pair[id].dist_mode = dist_mode;
+}
+void pco_world_set_lm(pco::World* w, const double* init_p, const double* trans_p, const uint16_t* letter_sym) {
+  w->lm_init.assign(init_p, init_p + 28);
+  w->lm_trans.assign(trans_p, trans_p + 28 * 28);
+  w->letter_sym.assign(letter_sym, letter_sym + 28);
+}
 void pco_world_set_table(pco::World* w, int id, int n_rows, int n_cols, const int32_t* cols, const int64_t* counts,
                          const double* logc_full, const double* logc_m1, const double* scal4) {
   pco::OTable& t = w->table[id];
@@ -342,6 +356,18 @@ void pco_random_string_prior(int n, int min_len, int max_len, const double* init
     for (size_t k = 0; k < (size_t)stride; ++k) out[(size_t)i * stride + k] = k < w.size() ? w[k] : 0;
     out_len[i] = (int32_t)w.size();
   }
+}
+void pco_random_string_prior_at(int n, const uint64_t* seeds, const uint32_t* elems, int min_len, int max_len,
+                                const double* init, const double* trans, uint32_t stream, int stride, uint8_t* out,
+                                int32_t* out_len) {
+  for (int i = 0; i < n; ++i) {
+    std::vector<uint8_t> l = pco::random_string_prior(min_len, max_len, init, trans, seeds[i], elems[i], stream);
+    out_len[i] = (int32_t)l.size();
+    for (size_t k = 0; k < l.size() && (int)k < stride; ++k) out[(size_t)i * stride + k] = l[k];
+  }
+}
+uint64_t pco_dummy_seed(uint64_t seed, uint32_t site, uint32_t particle, uint32_t sweep) {
+  return pclean_dummy_seed(seed, site, particle, sweep);
 }
 void pco_random_categorical(int n, int n_options, const double* logp, uint64_t seed, uint32_t stream, int32_t* out) {
   for (int i = 0; i < n; ++i) out[i] = pco::random_categorical(logp, n_options, seed, (uint32_t)i, stream);

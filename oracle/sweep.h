@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "enumerate.h"
+#include "random.h"
 
 namespace pco {
 
@@ -114,6 +115,70 @@ inline int32_t resolve_new_value(const World& w, const OBlock& b, int node, int 
   return -1;
 }
 
+/* Weight correction of a fresh particle whose enumerated proposal chose a ProposalDummyValue somewhere in its new
+ * row (block_proposal.jl:58-60 after proposal_compiler.jl:96-127).  The enumeration scored the dummy option with
+ * its prior mass log(dm) and the PLACEHOLDER string's likelihood, and q_disc holds exactly that; propose_non_enumerable!
+ * then replaces the placeholder by random(node.dist, ...) — no density of its own enters p — and the observations
+ * below the node are scored on the DRAWN string.  So  p - q_disc = block marginal + sum over chosen dummies of
+ *     - log(dm) + sum over the node's AddTypos observations [ logdensity(obs | drawn) - logdensity(obs | placeholder) ].
+ * The string is drawn with the private stream pclean_dummy_seed(seed, site of the node, particle, sweep) at the row's
+ * global id; the host draws it again with the same key when the particle is chosen (inference.resample_dummies).
+ * Supported: StringPrior placeholders under plain AddTypos observations; TimePrior placeholders have no such
+ * observation in their own block, their correction is the -log(dm) term.  Terms through a JuliaNode (ctx) keep the
+ * placeholder's likelihood. */
+inline double dummy_correction(const RowCtx& rc, const int32_t* vals, uint32_t particle) {
+  const World& w = *rc.w;
+  const OBlock& b = w.block[rc.block];
+  const uint32_t rr = rc.rng_row >= 0 ? (uint32_t)rc.rng_row : (uint32_t)((int64_t)rc.row + rc.row_offset);
+  double corr = 0.0;
+  for (size_t node = 0; node < b.nodes.size(); ++node) {
+    const pclean_node& nd = b.nodes[node];
+    if (nd.kind != PCLEAN_NODE_LEAF || nd.dummy_value == 0) continue;
+    const int k = vals[node];
+    if (k < 0) continue; /* -2: not sampled (its slot joined an existing row) */
+    const OTable& t = w.table[nd.table];
+    if (t.cols[k] != nd.dummy_value - 1) continue; /* an atom was chosen */
+    double c = -t.logc_full[k];
+    if ((nd.dummy_spec & 0xff) == PCLEAN_DUMMY_STRING_PRIOR) {
+      std::vector<uint16_t> drawn;
+      bool have = false;
+      for (int ti = 0; ti < nd.n_terms; ++ti) {
+        const pclean_term& tm = b.terms[nd.term_begin + ti];
+        if (tm.dens_kind != PCLEAN_DENS_ADD_TYPOS || tm.ctx_slot >= 0) continue;
+        const int o = w.obs[(size_t)tm.obs_col * w.n_rows + rc.row];
+        if (o < 0) continue;
+        const OPair& pt = w.pair[tm.pair_table];
+        if (!have) {
+          const int mn = (nd.dummy_spec >> 8) & 0xff, mx = (nd.dummy_spec >> 16) & 0xff;
+          const uint64_t key = pclean_dummy_seed(rc.seed, PCLEAN_SITE_NODE(rc.block, (int)node), particle, rc.sweep);
+          std::vector<uint8_t> letters = random_string_prior(mn, mx, w.lm_init.data(), w.lm_trans.data(), key, rr, 0u);
+          for (uint8_t l : letters) drawn.push_back(w.letter_sym[l]);
+          have = true;
+        }
+        const int sid = pt.obs_ids[o];
+        const uint16_t* os = w.sym.data() + w.off[sid];
+        const int ol = (int)(w.off[sid + 1] - w.off[sid]);
+        const int d = pt.dist_mode == PCLEAN_DIST_OSA ? osa_distance(os, ol, drawn.data(), (int)drawn.size())
+                                                      : dl_distance(os, ol, drawn.data(), (int)drawn.size());
+        /* term_density() on (d, word length of the drawn string): add_typos.jl:57-63 */
+        double l;
+        const int L = (int)drawn.size();
+        if (tm.max_typos >= 0 && d > tm.max_typos) {
+          l = IMPOSSIBLE;
+        } else {
+          l = w.nb[(size_t)((L + 4) / 5) * (w.max_d + 1) + d];
+          l -= w.logl[L] * (double)d;
+          l -= HALF_LOG26 * (double)d;
+        }
+        const int ph = nd.dummy_value - 1;
+        c += l - term_density(w, tm, pt, pt.d[(size_t)o * pt.n_lat + ph], ph);
+      }
+    }
+    corr += c;
+  }
+  return corr;
+}
+
 struct NewRow {
   int block, row;
   std::vector<int32_t> vals;
@@ -198,6 +263,9 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
   std::vector<std::vector<int32_t>> pch(n_blocks, std::vector<int32_t>(P));
   std::vector<std::vector<std::vector<int32_t>>> pvals(n_blocks, std::vector<std::vector<int32_t>>(P));
   double acc = 0.0;
+  std::vector<char> has_dummy(n_blocks, 0);
+  for (int bi = 0; bi < n_blocks; ++bi)
+    for (const pclean_node& nd : w.block[bi].nodes) has_dummy[bi] |= nd.kind == PCLEAN_NODE_LEAF && nd.dummy_value != 0;
   for (int bi = 0; bi < n_blocks; ++bi) {
     const OBlock& b = w.block[bi];
     if (b.is_score) { /* p += logdensity(...) of the block's observed choices (block_proposal.jl:62-64) */
@@ -236,7 +304,9 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
         out[s] = ch >= 0 ? rt.cols[(size_t)sc * rt.n_rows + ch] : resolve_new_value(w, src, 0, sc, pvals[sb][p].data());
       }
     };
-    auto finish_particle = [&](int p, const RowCtx& rc, const std::vector<double>& s, const FixSum& f) {
+    /* draws of particle p; returns the weight correction of the ProposalDummyValues its new row chose (0 otherwise) —
+     * added AFTER the block's log marginal (the order of the two fp64 additions is part of the contract) */
+    auto finish_particle = [&](int p, const RowCtx& rc, const std::vector<double>& s, const FixSum& f) -> double {
       int k = fix_draw(s, f, pclean_rand64(seed, rr, PCLEAN_SITE_NODE(bi, 0), (uint32_t)p, sweep));
       int c = k == n_root ? PCLEAN_CHOICE_NEW : k;
       if (p == 0 && cur[bi] >= 0) c = cur[bi]; /* retained particle, row_inference.jl:143-145 */
@@ -245,7 +315,9 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
         pvals[bi][p].assign(b.nodes.size(), -2);
         pvals[bi][p][0] = PCLEAN_CHOICE_NEW;
         sample_new(rc, 0, excl, (uint32_t)p, pvals[bi][p].data());
+        if (has_dummy[bi]) return dummy_correction(rc, pvals[bi][p].data(), (uint32_t)p);
       }
+      return 0.0;
     };
     if (b.n_ctx == 0) {
       RowCtx rc{&w, bi, row, nullptr, seed, sweep, row_offset};
@@ -253,8 +325,9 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
       const double lse = eval_tree(rc, 0, excl, &s);
       FixSum f = fix_sum(s);
       for (int p = 0; p < P; ++p) {
-        finish_particle(p, rc, s, f);
+        const double corr = finish_particle(p, rc, s, f);
         wts[p] += lse;
+        wts[p] += corr;
       }
     } else {
       for (int p = 0; p < P; ++p) {
@@ -264,8 +337,9 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
         std::vector<double> s;
         const double lse = eval_tree(rc, 0, excl, &s);
         FixSum f = fix_sum(s);
-        finish_particle(p, rc, s, f);
+        const double corr = finish_particle(p, rc, s, f);
         wts[p] += lse;
+        wts[p] += corr;
       }
     }
     if (!use_mh && bi < n_blocks - 1) {
@@ -298,7 +372,10 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
       continue;
     }
     choice[bi] = pch[bi][c];
-    if (pch[bi][c] == PCLEAN_CHOICE_NEW) new_rows.push_back(NewRow{bi, row, pvals[bi][c]});
+    if (pch[bi][c] == PCLEAN_CHOICE_NEW) {
+      new_rows.push_back(NewRow{bi, row, pvals[bi][c]});
+      new_rows.back().vals[0] = -1 - c; /* the chosen particle names the draw stream of its dummy values */
+    }
     /* own enumerated choices (locals) of the chosen particle given its referent */
     const OBlock& b = w.block[bi];
     if (locals_out && !b.node_gauss.empty() && b.node_gauss[0] >= 0 && b.gauss[b.node_gauss[0]].n_locals > 0) {

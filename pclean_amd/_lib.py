@@ -16,6 +16,7 @@ CHOICE_NEW = -1
 DIST_OSA, DIST_DL = 0, 1
 DENS_ADD_TYPOS, DENS_EQUAL, DENS_MAYBE_SWAP = 0, 1, 2
 NODE_FK, NODE_LEAF = 0, 1
+DUMMY_STRING_PRIOR, DUMMY_TIME_PRIOR = 1, 2
 
 
 class PCleanHipError(RuntimeError):
@@ -32,7 +33,7 @@ class Node(C.Structure):
     _fields_ = [("kind", C.c_int32), ("table", C.c_int32), ("term_begin", C.c_int32), ("n_terms", C.c_int32),
                 ("child_begin", C.c_int32), ("n_children", C.c_int32), ("parent", C.c_int32),
                 ("parent_fk_col", C.c_int32), ("cacheable", C.c_int32), ("colmap_begin", C.c_int32),
-                ("reserved", C.c_int32 * 2)]
+                ("dummy_value", C.c_int32), ("dummy_spec", C.c_int32)]
 
 
 class Gauss(C.Structure):
@@ -67,7 +68,7 @@ TERM_DTYPE = np.dtype([("obs_col", "<i4"), ("cand_col", "<i4"), ("pair_table", "
                        ("max_typos", "<i4"), ("ctx_slot", "<i4"), ("fn_table", "<i4"), ("ctx_mode", "<i4")])
 NODE_DTYPE = np.dtype([("kind", "<i4"), ("table", "<i4"), ("term_begin", "<i4"), ("n_terms", "<i4"),
                        ("child_begin", "<i4"), ("n_children", "<i4"), ("parent", "<i4"), ("parent_fk_col", "<i4"),
-                       ("cacheable", "<i4"), ("colmap_begin", "<i4"), ("reserved0", "<i4"), ("reserved1", "<i4")])
+                       ("cacheable", "<i4"), ("colmap_begin", "<i4"), ("dummy_value", "<i4"), ("dummy_spec", "<i4")])
 
 _lib = None
 
@@ -221,6 +222,14 @@ class HipContext:
                                                 _p(cols, C.c_int32), _p(counts, C.c_int64), C.c_double(strength),
                                                 C.c_double(discount)), "pclean_set_table")
 
+    def set_lm_tables(self, init_p, trans_p, letter_sym):
+        init_p = np.ascontiguousarray(init_p, dtype=np.float64)
+        trans_p = np.ascontiguousarray(trans_p, dtype=np.float64)
+        letter_sym = np.ascontiguousarray(letter_sym, dtype=np.uint16)
+        assert init_p.size == 28 and trans_p.size == 28 * 28 and letter_sym.size == 28
+        check(self.h, self.lib.pclean_set_lm_tables(self.h, _p(init_p, C.c_double), _p(trans_p, C.c_double),
+                                                    _p(letter_sym, C.c_uint16)), "pclean_set_lm_tables")
+
     def set_options(self, table_id, values, logp):
         values = np.ascontiguousarray(values, dtype=np.int32)
         logp = np.ascontiguousarray(logp, dtype=np.float64)
@@ -294,6 +303,21 @@ class HipContext:
             self.h, C.c_int32(n), C.c_int32(min_len), C.c_int32(max_len), _p(init_p, C.c_double),
             _p(trans_p, C.c_double), C.c_uint64(seed), C.c_uint32(stream), C.c_int32(stride), _p(out, C.c_uint8),
             _p(lens, C.c_int32)), "pclean_random_string_prior")
+        return out, lens
+
+    def random_string_prior_at(self, seeds, elems, min_len, max_len, init_p, trans_p, stream=0):
+        """draw i with the private stream (seeds[i], elems[i]) — the value of a chosen ProposalDummyValue"""
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        elems = np.ascontiguousarray(elems, dtype=np.uint32)
+        init_p = np.ascontiguousarray(init_p, dtype=np.float64)
+        trans_p = np.ascontiguousarray(trans_p, dtype=np.float64)
+        n, stride = len(seeds), max(int(max_len), 1)
+        out = np.zeros((n, stride), dtype=np.uint8)
+        lens = np.zeros(n, dtype=np.int32)
+        check(self.h, self.lib.pclean_random_string_prior_at(
+            self.h, C.c_int32(n), _p(seeds, C.c_uint64), _p(elems, C.c_uint32), C.c_int32(min_len), C.c_int32(max_len),
+            _p(init_p, C.c_double), _p(trans_p, C.c_double), C.c_uint32(stream), C.c_int32(stride), _p(out, C.c_uint8),
+            _p(lens, C.c_int32)), "pclean_random_string_prior_at")
         return out, lens
 
     def random_categorical(self, n, logp, seed, stream):

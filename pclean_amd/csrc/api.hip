@@ -48,7 +48,11 @@ extern "C" int pclean_ctx_destroy(pclean_ctx* ctx) {
   for (auto& p : ctx->pair) {
     p.d.release();
     p.lat_len.release();
+    p.obs_ids.release();
   }
+  ctx->lm_init.release();
+  ctx->lm_trans.release();
+  ctx->letter_sym.release();
   for (auto& c : ctx->cand) {
     c.cols.release();
     c.counts.release();
@@ -63,6 +67,7 @@ extern "C" int pclean_ctx_destroy(pclean_ctx* ctx) {
     for (auto& l : b.leaf_m) l.release();
     for (auto& l : b.leaf_U) l.release();
     for (auto& l : b.leaf_coarse) l.release();
+    for (auto& l : b.leaf_udummy) l.release();
   }
   (void)hipStreamDestroy(ctx->stream);
   delete ctx;
@@ -104,6 +109,13 @@ extern "C" int pclean_load_columns(pclean_ctx* ctx, int32_t n_rows, int32_t n_co
   if (n) HIPCHK(ctx, hipMemcpy(ctx->obs.p, obs, n * sizeof(int32_t), hipMemcpyHostToDevice));
   ctx->n_rows = n_rows;
   ctx->n_cols = n_cols;
+  ctx->col_has_missing.assign(n_cols, 0);
+  for (int c = 0; c < n_cols; ++c)
+    for (int i = 0; i < n_rows; ++i)
+      if (obs[(size_t)c * n_rows + i] < 0) {
+        ctx->col_has_missing[c] = 1;
+        break;
+      }
   return PCLEAN_OK;
 }
 
@@ -198,18 +210,31 @@ extern "C" int pclean_build_pair_table(pclean_ctx* ctx, int32_t table_id, int32_
   if (rc) return rc;
   if (pt.d.alloc(std::max<size_t>((size_t)n_obs * n_lat * pt.elem_bytes, 16)) || pt.lat_len.alloc(n_lat))
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-  DevBuf<int32_t> d_obs, d_lat;
+  DevBuf<int32_t> d_lat;
+  DevBuf<int32_t>& d_obs = pt.obs_ids;  // kept: the weight of a chosen dummy value scores drawn strings against them
+  pt.dist_mode = dist_mode;
   if (d_obs.alloc(std::max(n_obs, 1)) || d_lat.alloc(n_lat)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   if (n_obs) HIPCHK(ctx, hipMemcpy(d_obs.p, obs_ids, n_obs * sizeof(int32_t), hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(d_lat.p, lat_ids, n_lat * sizeof(int32_t), hipMemcpyHostToDevice));
   rc = pclean_launch_dist(ctx, pt, d_obs.p, d_lat.p, dist_mode);
   hipError_t e = hipStreamSynchronize(ctx->stream);
-  d_obs.release();
   d_lat.release();
   if (rc) return rc;
   if (e != hipSuccess) return pclean_fail(ctx, PCLEAN_ERR_HIP, "distance kernel failed: %s", hipGetErrorString(e));
   pt.valid = true;
   pt.version = ++g_pclean_version;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_set_lm_tables(pclean_ctx* ctx, const double* init_p, const double* trans_p, const uint16_t* letter_sym) {
+  if (!ctx || !init_p || !trans_p || !letter_sym) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_lm_tables: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->lm_init.alloc(28) || ctx->lm_trans.alloc(28 * 28) || ctx->letter_sym.alloc(28))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemcpy(ctx->lm_init.p, init_p, 28 * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->lm_trans.p, trans_p, 28 * 28 * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->letter_sym.p, letter_sym, 28 * sizeof(uint16_t), hipMemcpyHostToDevice));
+  ctx->lm_valid = true;
   return PCLEAN_OK;
 }
 
@@ -635,6 +660,16 @@ extern "C" int pclean_load_block(pclean_ctx* ctx, int32_t block_id, int32_t n_no
   b.leaf_U.resize(n_nodes);
   b.leaf_coarse.clear();
   b.leaf_coarse.resize(n_nodes);
+  for (auto& l : b.leaf_udummy) l.release();
+  b.leaf_udummy.clear();
+  b.leaf_udummy.resize(n_nodes);
+  b.leaf_drawable.assign(n_nodes, -1);
+  for (int i = 0; i < n_nodes; ++i)  // the density tables must cover the strings random(StringPrior) can return
+    if (nodes[i].kind == PCLEAN_NODE_LEAF && nodes[i].dummy_value != 0 &&
+        (nodes[i].dummy_spec & 0xff) == PCLEAN_DUMMY_STRING_PRIOR) {
+      const int rcd = pclean_ensure_density(ctx, (nodes[i].dummy_spec >> 16) & 0xff);
+      if (rcd) return rcd;
+    }
   b.gauss.clear();
   b.node_gauss.assign(n_nodes, -1);
   b.valid = true;

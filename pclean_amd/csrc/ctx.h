@@ -47,6 +47,8 @@ struct PairTable {
   int32_t elem_bytes = 1;     // 1: uint8 distances, 2: uint16
   DevBuf<uint8_t> d;          // [n_obs][n_lat] * elem_bytes
   DevBuf<uint16_t> lat_len;   // word length (characters) of each latent value
+  DevBuf<int32_t> obs_ids;    // AddTypos tables built on the device: pool string of every observed value
+  int32_t dist_mode = PCLEAN_DIST_DL;  // flavour the table was built with (dummy_dev.h scores drawn strings with it)
   int32_t max_lat_len = 0, max_obs_len = 0;
   double mean_lat_len = 0.0;  // AddTypos tables built on the device: mean length of the latent strings
 };
@@ -108,6 +110,8 @@ struct Block {
   // total and the inclusive prefix at every 256th option
   std::vector<DevBuf<double>> leaf_m;
   std::vector<DevBuf<uint64_t>> leaf_U, leaf_coarse;
+  std::vector<DevBuf<uint64_t>> leaf_udummy;  // fixed-point weight of the ProposalDummyValue option per observed value
+  std::vector<int> leaf_drawable;  // per node: -1 unknown, 0 the dummy cannot be drawn for any loaded row, 1 it can
   std::vector<int32_t> new_rows_host, new_vals_host, locals_host;
   std::vector<int32_t> moved_rows_host, moved_choice_host;  // rows whose referent changed in the last sweep
 };
@@ -127,6 +131,7 @@ struct pclean_ctx {
   // observed columns
   int32_t n_rows = 0, n_cols = 0;
   DevBuf<int32_t> obs;  // [n_cols][n_rows]
+  std::vector<char> col_has_missing;  // per observed column: some row holds an explicitly missing value (-1)
   DevBuf<int32_t> iota; // identity column for per-unique-value leaf caches
   int32_t n_xcols = 0;
   DevBuf<double> xnum;  // numeric observed columns [n_xcols][n_rows]
@@ -139,6 +144,10 @@ struct pclean_ctx {
   int32_t max_r = -1, max_d = -1, max_len = -1;
   std::vector<double> h_nb, h_logl;
   DevBuf<double> nb, logl;
+  // letter model of random(StringPrior) + pool symbol of every letter (pclean_set_lm_tables)
+  bool lm_valid = false;
+  DevBuf<double> lm_init, lm_trans;
+  DevBuf<uint16_t> letter_sym;
   DevBuf<double> atd;  // [max_len + 1][max_d + 1]: nb[(L+4)/5][d] - logl[L] d - log(26)/2 d in that fp64 order (add_typos.jl:61-63)
 
   PairTable pair[PCLEAN_MAX_TABLES];

@@ -171,7 +171,7 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
 // cacheable option lists: per-observed-value (maximum, total, coarse prefix) and draws through them (enum_kernels.hip)
 int pclean_leaf_coarse_blocks(int n_options);
 int pclean_launch_leaf_coarse_build(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, int n_blocks, double* lse_out,
-                                    double* m_out, uint64_t* U_out, uint64_t* coarse);
+                                    double* m_out, uint64_t* U_out, uint64_t* coarse, int dummy_k, uint64_t* udummy_out);
 int pclean_launch_leaf_coarse_draw(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const int32_t* obs_col, int n_obs,
                                    int n_blocks, const double* lse_c, const double* m_c, const uint64_t* U_c,
                                    const uint64_t* coarse, uint64_t seed, uint32_t sweep, uint32_t site, int n_draws,

@@ -607,7 +607,8 @@ __global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, co
 __global__ __launch_bounds__(256) void leaf_coarse_build_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
                                                                 int n_blocks, double* __restrict__ lse_out,
                                                                 double* __restrict__ m_out, uint64_t* __restrict__ U_out,
-                                                                uint64_t* __restrict__ coarse) {
+                                                                uint64_t* __restrict__ coarse, int dummy_k,
+                                                                uint64_t* __restrict__ udummy_out) {
   __shared__ double red[4];
   __shared__ uint64_t wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -625,6 +626,7 @@ __global__ __launch_bounds__(256) void leaf_coarse_build_kernel(const NodeDev nd
     const int k = b * LEAF_CB + tid;
     uint64_t u = 0;
     if (k < n && m != -__builtin_inf()) u = pclean_fixw(candidate_score(nd, dn, it, v, k) - m);
+    if (k == dummy_k && udummy_out) udummy_out[t] = u;  // weight of the ProposalDummyValue option (0: it cannot be drawn)
     for (int o = 32; o > 0; o >>= 1) u += __shfl_xor((unsigned long long)u, o, 64);
     __syncthreads();  // wsum of the previous block has been read
     if (lane == 0) wsum[wave] = u;
@@ -708,11 +710,11 @@ __global__ __launch_bounds__(256) void leaf_coarse_draw_kernel(const NodeDev nd,
 }
 
 int pclean_launch_leaf_coarse_build(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, int n_blocks, double* lse_out,
-                                    double* m_out, uint64_t* U_out, uint64_t* coarse) {
+                                    double* m_out, uint64_t* U_out, uint64_t* coarse, int dummy_k, uint64_t* udummy_out) {
   if (it.n <= 0) return PCLEAN_OK;
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
   hipLaunchKernelGGL(leaf_coarse_build_kernel, dim3(it.n), dim3(256), 0, ctx->stream, nd, dn, it, n_blocks, lse_out, m_out,
-                     U_out, coarse);
+                     U_out, coarse, dummy_k, udummy_out);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }

@@ -98,6 +98,23 @@ __global__ void random_string_prior_kernel(int n, int min_len, int max_len, cons
   out_len[i] = len;
 }
 
+// the same with a private (key, counter row) per element (values of chosen ProposalDummyValues, pclean_dummy_seed)
+__global__ void random_string_prior_at_kernel(int n, const uint64_t* __restrict__ seeds, const uint32_t* __restrict__ elems,
+                                              int min_len, int max_len, const double* __restrict__ init_p,
+                                              const double* __restrict__ trans_p, uint32_t stream, int stride,
+                                              uint8_t* __restrict__ out, int32_t* __restrict__ out_len) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Draws d{seeds[i], elems[i], PCLEAN_SITE_RANDOM(PCLEAN_RANDOM_STRING_PRIOR), stream, 0};
+  const int len = min_len + (int)d.below((uint32_t)(max_len - min_len + 1));
+  int prev = 0;
+  for (int k = 0; k < len; ++k) {
+    prev = draw28(k == 0 ? init_p : trans_p + (size_t)prev * 28, d.next());
+    out[(size_t)i * stride + k] = (uint8_t)prev;
+  }
+  out_len[i] = len;
+}
+
 // choose_proportionally.jl:3-5 / choose_uniformly.jl:3-5
 __global__ void random_categorical_kernel(int n, int n_options, const double* __restrict__ logp, uint64_t seed,
                                           uint32_t stream, int32_t* __restrict__ out) {
@@ -233,6 +250,33 @@ extern "C" int pclean_random_string_prior(pclean_ctx* ctx, int32_t n, int32_t mi
   TRY(down(ctx, out_letters, d_out, (size_t)n * out_stride));
   TRY(down(ctx, out_len, d_len, (size_t)n));
   d_init.release(); d_trans.release(); d_out.release(); d_len.release();
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_random_string_prior_at(pclean_ctx* ctx, int32_t n, const uint64_t* seeds, const uint32_t* elems,
+                                             int32_t min_len, int32_t max_len, const double* init_p, const double* trans_p,
+                                             uint32_t stream, int32_t out_stride, uint8_t* out_letters, int32_t* out_len) {
+  if (!ctx || n < 0 || min_len < 0 || max_len < min_len || out_stride < max_len || out_stride <= 0 || !init_p || !trans_p ||
+      (n > 0 && (!out_letters || !out_len || !seeds || !elems)))
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_random_string_prior_at: bad arguments");
+  if (n == 0) return PCLEAN_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  DevBuf<double> d_init, d_trans;
+  DevBuf<uint64_t> d_seeds;
+  DevBuf<uint32_t> d_elems;
+  DevBuf<uint8_t> d_out;
+  DevBuf<int32_t> d_len;
+  TRY(up(ctx, d_init, init_p, 28));
+  TRY(up(ctx, d_trans, trans_p, 28 * 28));
+  TRY(up(ctx, d_seeds, seeds, (size_t)n));
+  TRY(up(ctx, d_elems, elems, (size_t)n));
+  if (d_out.alloc((size_t)n * out_stride) || d_len.alloc(n)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemsetAsync(d_out.p, 0, (size_t)n * out_stride, ctx->stream));
+  hipLaunchKernelGGL(random_string_prior_at_kernel, grid_for(n), dim3(256), 0, ctx->stream, n, d_seeds.p, d_elems.p, min_len,
+                     max_len, d_init.p, d_trans.p, stream, out_stride, d_out.p, d_len.p);
+  TRY(down(ctx, out_letters, d_out, (size_t)n * out_stride));
+  TRY(down(ctx, out_len, d_len, (size_t)n));
+  d_init.release(); d_trans.release(); d_seeds.release(); d_elems.release(); d_out.release(); d_len.release();
   return PCLEAN_OK;
 }
 

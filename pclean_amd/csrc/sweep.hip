@@ -19,6 +19,7 @@
 
 #include "../../include/pclean_detmath.h"
 #include "../../include/pclean_philox.h"
+#include "dummy_dev.h"
 #include "enum.h"
 #include "gauss_dev.h"
 
@@ -620,14 +621,117 @@ __global__ void locals_tail_kernel(int n_rows, int P, GaussDev g, PlanDev plan, 
 }
 
 __global__ void gather_new_rows_kernel(int n, const int32_t* list, const int32_t* chosen_newpos, const int32_t* vals,
-                                       int n_nodes, int32_t* rows_out, int32_t* vals_out) {
+                                       int n_nodes, const int32_t* chosen, int32_t* rows_out, int32_t* vals_out) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   const int i = list[j];
   rows_out[j] = i;
   const int32_t* v = vals + (size_t)chosen_newpos[i] * n_nodes;
   for (int k = 0; k < n_nodes; ++k) vals_out[(size_t)j * n_nodes + k] = v[k];
+  vals_out[(size_t)j * n_nodes] = -1 - chosen[i];  // the chosen particle names the draw stream of its dummy values
 }
+// ---- weight of a particle whose new row chose a ProposalDummyValue (block_proposal.jl:58-60) -------------------------
+// The enumeration scored the dummy option with its prior mass and the PLACEHOLDER's likelihood (q_disc holds that);
+// propose_non_enumerable! then replaces the placeholder by random(node.dist, ...) and scores the observations below the
+// node on the drawn string, so  p - q_disc = block marginal + sum over chosen dummies of
+//     - log(dummy mass) + sum over the node's plain AddTypos observations [ logdensity(obs | drawn) - logdensity(obs | placeholder) ]
+// (oracle/sweep.h: dummy_correction restates it; fp64 operation order: per leaf c = -logp, c += (l_drawn - l_placeholder)
+// per term, corr += c in node order; w += corr after the block's log marginal).  One thread per NEW slot.
+#define DUMMY_MAX_LEAVES 8
+#define DUMMY_MAX_TERMS 2
+#define DUMMY_DP_SLOTS 256
+struct DummyTermDev {
+  const int32_t* obs_col;
+  const uint8_t* pair;
+  const uint16_t* lat_len;
+  const int32_t* obs_ids;
+  int32_t n_lat, elem_bytes, max_typos, dist_mode;
+};
+struct DummyLeafDev {
+  int32_t node, dummy_val, kind, min_len, max_len, n_terms;
+  const int32_t* opt_vals;
+  const double* opt_logp;
+  DummyTermDev t[DUMMY_MAX_TERMS];
+};
+struct DummyPackDev {
+  int32_t n_leaves, site_block;
+  DummyLeafDev leaf[DUMMY_MAX_LEAVES];
+  const uint16_t* sym;
+  const int64_t* off;
+  const double* lm_init;
+  const double* lm_trans;
+  const uint16_t* letter_sym;
+  const double* nb;
+  const double* logl;
+  int32_t nb_stride, pad;
+  int16_t* dp;             // [DUMMY_DP_SLOTS][(DUMMY_MAX_LEN + 2)^2]
+  unsigned int* dp_ctr;    // [0] slots handed out, [1] set when they ran out
+};
+__global__ void dummy_correction_kernel(int n_new, int N, const int32_t* __restrict__ new_slots,
+                                        const int32_t* __restrict__ vals, int n_nodes, DummyPackDev dp, uint64_t seed,
+                                        uint32_t sweep, int64_t row_offset, double* __restrict__ w) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_new) return;
+  const int slot = new_slots[j];
+  const int row = slot % N, particle = slot / N;
+  const int32_t* v = vals + (size_t)j * n_nodes;
+  double corr = 0.0;
+  bool any = false;
+  for (int li = 0; li < dp.n_leaves; ++li) {
+    const DummyLeafDev& lf = dp.leaf[li];
+    const int k = v[lf.node];
+    if (k < 0 || lf.opt_vals[k] != lf.dummy_val) continue;
+    any = true;
+    double c = -lf.opt_logp[k];
+    if (lf.kind == PCLEAN_DUMMY_STRING_PRIOR) {
+      uint16_t drawn[DUMMY_MAX_LEN + 1];
+      int L = -1;
+      for (int ti = 0; ti < lf.n_terms; ++ti) {
+        const DummyTermDev& tm = lf.t[ti];
+        const int o = tm.obs_col[row];
+        if (o < 0) continue;
+        if (L < 0) {
+          const uint64_t key = pclean_dummy_seed(seed, PCLEAN_SITE_NODE(dp.site_block, lf.node), (uint32_t)particle, sweep);
+          L = dummy_draw_string(key, (uint32_t)((int64_t)row + row_offset), lf.min_len, lf.max_len, dp.lm_init, dp.lm_trans,
+                                dp.letter_sym, drawn);
+        }
+        const int sid = tm.obs_ids[o];
+        const uint16_t* os = dp.sym + dp.off[sid];
+        const int ol = (int)(dp.off[sid + 1] - dp.off[sid]);
+        const unsigned int ds = atomicAdd(&dp.dp_ctr[0], 1u);
+        if (ds >= DUMMY_DP_SLOTS || ol > DUMMY_MAX_LEN) {
+          dp.dp_ctr[1] = 1u;
+          continue;
+        }
+        int16_t* H = dp.dp + (size_t)ds * (DUMMY_MAX_LEN + 2) * (DUMMY_MAX_LEN + 2);
+        const int d = dummy_distance(tm.dist_mode, os, ol, drawn, L, H);
+        double l;
+        if (tm.max_typos >= 0 && d > tm.max_typos) {
+          l = -1e5;
+        } else {
+          l = dp.nb[(size_t)((L + 4) / 5) * dp.nb_stride + d];
+          l -= dp.logl[L] * (double)d;
+          l -= 1.629048269010741 * (double)d;
+        }
+        const size_t pi = (size_t)o * tm.n_lat + lf.dummy_val;
+        const int dph = tm.elem_bytes == 1 ? (int)tm.pair[pi] : (int)((const uint16_t*)tm.pair)[pi];
+        double lph;
+        if (tm.max_typos >= 0 && dph > tm.max_typos) {
+          lph = -1e5;
+        } else {
+          const int Lp = tm.lat_len[lf.dummy_val];
+          lph = dp.nb[(size_t)((Lp + 4) / 5) * dp.nb_stride + dph];
+          lph -= dp.logl[Lp] * (double)dph;
+          lph -= 1.629048269010741 * (double)dph;
+        }
+        c += l - lph;
+      }
+    }
+    corr += c;
+  }
+  if (any) w[slot] += corr;
+}
+
 // ---------------------------------------------------------------------------
 // host side
 static inline dim3 grid1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
@@ -717,6 +821,10 @@ struct SweepState {
   struct OverRec { int block, node, n_items; bool time_it, leaf; };
   std::vector<OverRec> over_rec;
   unsigned int* h_over = nullptr;  // page-locked copy of over_ctr
+  // dummy_correction_kernel: distance matrices of the strings drawn for chosen ProposalDummyValues
+  DevBuf<int16_t> dummy_dp;
+  DevBuf<unsigned int> dummy_ctr;  // [0] matrices handed out by the running launch, [1] set when they ran out
+  bool dummy_used = false;
   // block 0's root scan of the last pclean_sweep (pclean_debug_root_flags; the scratch stays valid until the next call)
   const int32_t* dbg_desc = nullptr;
   const int32_t* dbg_grp_off = nullptr;
@@ -762,6 +870,8 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
   }
   if (s->h_counts) (void)hipHostFree(s->h_counts);
   if (s->h_over) (void)hipHostFree(s->h_over);
+  s->dummy_dp.release();
+  s->dummy_ctr.release();
   s->over_ctr.release();
   for (auto e : s->prof_ev) (void)hipEventDestroy(e);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
@@ -777,6 +887,7 @@ static int begin_call(pclean_ctx* ctx) {
   SweepState* s = st(ctx);
   s->pool_used = 0;
   s->dbg_desc = nullptr;
+  s->dummy_used = false;
   s->over_rec.clear();
   if (s->over_ctr.alloc(OVER_SLOTS)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   HIPCHK(ctx, hipMemsetAsync(s->over_ctr.p, 0, OVER_SLOTS * sizeof(unsigned int), ctx->stream));
@@ -1043,9 +1154,32 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
     if (rc) return rc;
     ItemsDev it{U + 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
                 nullptr, nullptr, 0, 0, nullptr, nullptr};
+    // the ProposalDummyValue option, if the list has one: its fixed-point weight per observed value tells whether a
+    // particle can draw it at all (block_dummy_drawable)
+    int dummy_k = -1;
+    if (n.dummy_value != 0) {
+      const std::vector<int32_t>& hv = ctx->cand[n.table].h_vals;
+      for (size_t k = 0; k < hv.size(); ++k)
+        if (hv[k] == n.dummy_value - 1) dummy_k = (int)k;
+      if (dummy_k >= 0) {
+        if (b.leaf_udummy[node_id].alloc(U + 1)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "alloc");
+        HIPCHK(ctx, hipMemsetAsync(b.leaf_udummy[node_id].p, 0, (size_t)(U + 1) * sizeof(uint64_t), ctx->stream));
+      }
+    }
     rc = pclean_launch_leaf_coarse_build(ctx, nd, it, nblk, cache.p, b.leaf_m[node_id].p, b.leaf_U[node_id].p,
-                                         b.leaf_coarse[node_id].p);
+                                         b.leaf_coarse[node_id].p, dummy_k, dummy_k >= 0 ? b.leaf_udummy[node_id].p : nullptr);
     if (rc) return rc;
+    b.leaf_drawable[node_id] = 0;
+    if (dummy_k >= 0) {  // (once per rebuild of the cache: a read-back is affordable)
+      std::vector<uint64_t> hu((size_t)U + 1);
+      HIPCHK(ctx, hipMemcpyAsync(hu.data(), b.leaf_udummy[node_id].p, hu.size() * sizeof(uint64_t), hipMemcpyDeviceToHost,
+                                 ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      bool any = tm.obs_col >= 0 && tm.obs_col < (int)ctx->col_has_missing.size() && ctx->col_has_missing[tm.obs_col] &&
+                 hu[U] != 0;
+      for (int o = 0; o < U && !any; ++o) any = hu[o] != 0;
+      b.leaf_drawable[node_id] = any ? 1 : 0;
+    }
     s->leaf_version[key] = ver;
   }
   *out = cache.p;
@@ -2376,7 +2510,6 @@ extern "C" int pclean_score_node(pclean_ctx* ctx, int32_t block_id, int32_t node
   Block& b = ctx->block[block_id];
   if (node_id < 0 || node_id >= (int)b.nodes.size()) return pclean_fail(ctx, PCLEAN_ERR_ARG, "bad node id");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  SweepState* s = st(ctx);
   {
     const int rcb = begin_call(ctx);
     if (rcb) return rcb;
@@ -2408,6 +2541,107 @@ extern "C" int pclean_score_node(pclean_ctx* ctx, int32_t block_id, int32_t node
   if (n_draws) HIPCHK(ctx, hipMemcpyAsync(draws, d_draws, (size_t)n_items * n_draws * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return finish_call(ctx);
+}
+
+// Can a particle of this sweep draw the ProposalDummyValue of some option list of block bi?  Cacheable lists know it
+// per observed value (ensure_leaf_cache: weight of the dummy option); any other list with a dummy is assumed to.
+static int block_dummy_drawable(pclean_ctx* ctx, int bi, bool* out) {
+  Block& b = ctx->block[bi];
+  *out = false;
+  for (int node = 0; node < (int)b.nodes.size(); ++node) {
+    const pclean_node& n = b.nodes[node];
+    if (n.kind != PCLEAN_NODE_LEAF || n.dummy_value == 0) continue;
+    if (!n.cacheable || (node < (int)b.node_gauss.size() && b.node_gauss[node] >= 0)) {
+      *out = true;
+      return PCLEAN_OK;
+    }
+    const double* cache;
+    const int32_t* ocol;
+    int n_obs;
+    int rc = ensure_leaf_cache(ctx, bi, node, &cache, &ocol, &n_obs);
+    if (rc) return rc;
+    if (b.leaf_drawable[node] != 0) {
+      *out = true;
+      return PCLEAN_OK;
+    }
+  }
+  return PCLEAN_OK;
+}
+
+// w[slot] += correction for every NEW slot of block bi whose sampled new row chose a ProposalDummyValue
+static int apply_dummy_corrections(pclean_ctx* ctx, int bi, const int32_t* new_slots, const int32_t* vals, int n_new, int N,
+                                   uint64_t seed, uint32_t sweep, double* w) {
+  if (n_new <= 0) return PCLEAN_OK;
+  Block& b = ctx->block[bi];
+  SweepState* s = st(ctx);
+  const int nn = (int)b.nodes.size();
+  std::vector<DummyLeafDev> leaves;
+  bool need_strings = false;
+  for (int node = 0; node < nn; ++node) {
+    const pclean_node& n = b.nodes[node];
+    if (n.kind != PCLEAN_NODE_LEAF || n.dummy_value == 0) continue;
+    const CandTable& t = ctx->cand[n.table];
+    if (!t.valid || !t.is_options) return pclean_fail(ctx, PCLEAN_ERR_STATE, "node %d: option table not set", node);
+    DummyLeafDev lf{};
+    lf.node = node;
+    lf.dummy_val = n.dummy_value - 1;
+    lf.kind = n.dummy_spec & 0xff;
+    lf.min_len = (n.dummy_spec >> 8) & 0xff;
+    lf.max_len = (n.dummy_spec >> 16) & 0xff;
+    lf.opt_vals = t.cols.p;
+    lf.opt_logp = t.logc_full.p;
+    if (lf.kind == PCLEAN_DUMMY_STRING_PRIOR)
+      for (int ti = 0; ti < n.n_terms; ++ti) {
+        const pclean_term& tm = b.terms[n.term_begin + ti];
+        if (tm.dens_kind != PCLEAN_DENS_ADD_TYPOS || tm.ctx_slot >= 0) continue;  // JuliaNode terms keep the placeholder
+        const PairTable& pt = ctx->pair[tm.pair_table];
+        if (!pt.valid) return pclean_fail(ctx, PCLEAN_ERR_STATE, "pair table %d not built", tm.pair_table);
+        if (!pt.obs_ids.p) continue;  // host-computed table: no strings to compare a drawn value with
+        if (lf.n_terms >= DUMMY_MAX_TERMS)
+          return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "node %d: more than %d observations below a dummy-bearing choice", node,
+                             DUMMY_MAX_TERMS);
+        DummyTermDev& td = lf.t[lf.n_terms++];
+        td.obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
+        td.pair = pt.d.p;
+        td.lat_len = pt.lat_len.p;
+        td.obs_ids = pt.obs_ids.p;
+        td.n_lat = pt.n_lat;
+        td.elem_bytes = pt.elem_bytes;
+        td.max_typos = tm.max_typos;
+        td.dist_mode = pt.dist_mode;
+        need_strings = true;
+      }
+    leaves.push_back(lf);
+  }
+  if (leaves.empty()) return PCLEAN_OK;
+  if (need_strings && !ctx->lm_valid)
+    return pclean_fail(ctx, PCLEAN_ERR_STATE, "a StringPrior dummy value has observations below it: pclean_set_lm_tables first");
+  if (s->dummy_ctr.alloc(2) || (need_strings && s->dummy_dp.alloc((size_t)DUMMY_DP_SLOTS * (DUMMY_MAX_LEN + 2) * (DUMMY_MAX_LEN + 2))))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  if (!s->dummy_used) HIPCHK(ctx, hipMemsetAsync(s->dummy_ctr.p, 0, 2 * sizeof(unsigned int), ctx->stream));
+  s->dummy_used = true;
+  ProfScope ps(ctx, "dummy_value_weights");
+  for (size_t l0 = 0; l0 < leaves.size(); l0 += DUMMY_MAX_LEAVES) {
+    DummyPackDev dp{};
+    dp.n_leaves = (int)std::min<size_t>(DUMMY_MAX_LEAVES, leaves.size() - l0);
+    dp.site_block = bi;
+    for (int i = 0; i < dp.n_leaves; ++i) dp.leaf[i] = leaves[l0 + i];
+    dp.sym = ctx->sym.p;
+    dp.off = ctx->off.p;
+    dp.lm_init = ctx->lm_init.p;
+    dp.lm_trans = ctx->lm_trans.p;
+    dp.letter_sym = ctx->letter_sym.p;
+    dp.nb = ctx->nb.p;
+    dp.logl = ctx->logl.p;
+    dp.nb_stride = ctx->max_d + 1;
+    dp.dp = s->dummy_dp.p;
+    dp.dp_ctr = s->dummy_ctr.p;
+    HIPCHK(ctx, hipMemsetAsync(s->dummy_ctr.p, 0, sizeof(unsigned int), ctx->stream));  // (the overflow flag stays)
+    hipLaunchKernelGGL(dummy_correction_kernel, grid1(n_new), dim3(256), 0, ctx->stream, n_new, N, new_slots, vals, nn, dp,
+                       seed, sweep, s->row_offset + ctx->active_begin, w);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
 }
 
 // ---------------------------------------------------------------------------
@@ -2603,7 +2837,12 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     // deferred until after the final choice and done for the chosen particles alone (same Philox counters, so
     // the values are the ones eager sampling would have produced; typically 20x fewer items).
     static const bool eager_all = getenv("PCLEAN_EAGER_NEW") != nullptr;
-    r.lazy_new = bi == n_blocks - 1 && !eager_all;
+    // A chosen ProposalDummyValue changes its particle's weight (apply_dummy_corrections): where one can be drawn
+    // every NEW slot is sampled before the final choice.
+    bool drawable = false;
+    rc = block_dummy_drawable(ctx, bi, &drawable);
+    if (rc) return rc;
+    r.lazy_new = bi == n_blocks - 1 && !eager_all && !drawable;
     if (r.lazy_new) n_new = 0;  // nothing sampled now
     if (r.vals.alloc(std::max<size_t>((size_t)n_new * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
     if (n_new) {
@@ -2624,6 +2863,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       ItemList sub{(int)n_new, row, cx, part, org};
       rc = sample_children(ctx, bi, 0, sub, ex, seed, sweep_idx, r.vals.p, nn);
       if (rc) return rc;
+      if (drawable) {
+        rc = apply_dummy_corrections(ctx, bi, r.new_slots.p, r.vals.p, (int)n_new, N, seed, sweep_idx, s->w.p);
+        if (rc) return rc;
+      }
     }
     // (pnewpos is only read where pchoice == NEW, so it needs no initialisation when nobody proposed one)
 
@@ -2731,8 +2974,16 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       const int rco = queue_over_copy(ctx);
       if (rco) return rco;
     }
+    s->h_counts[3 * PCLEAN_MAX_BLOCKS] = 0;
+    if (s->dummy_used)
+      HIPCHK(ctx, hipMemcpyAsync(s->h_counts + 3 * PCLEAN_MAX_BLOCKS, s->dummy_ctr.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost,
+                                 ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     apply_over_stats(ctx);
+    if (s->h_counts[3 * PCLEAN_MAX_BLOCKS])
+      return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "pclean_sweep: more than %d chosen dummy values with an observation below "
+                                                   "them in one block (or an observed string longer than %d symbols)",
+                         DUMMY_DP_SLOTS, DUMMY_MAX_LEN);
     if (choice)
       for (int bi = 0; bi < n_blocks; ++bi)
         if (ctx->block[bi].is_score)
@@ -2764,7 +3015,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         int32_t* vals_d = scratch<int32_t>(ctx, (size_t)n_newrows * nn);
         if (!rows_d || !vals_d) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
         hipLaunchKernelGGL(gather_new_rows_kernel, grid1(n_newrows), dim3(256), 0, ctx->stream, n_newrows, r.new_list.p,
-                           r.chosen_newpos.p, r.vals.p, nn, rows_d, vals_d);
+                           r.chosen_newpos.p, r.vals.p, nn, s->chosen.p, rows_d, vals_d);
         b.new_rows_host.resize(n_newrows);
         b.new_vals_host.resize((size_t)n_newrows * nn);
         HIPCHK(ctx, hipMemcpyAsync(b.new_rows_host.data(), rows_d, (size_t)n_newrows * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -86,6 +86,12 @@ class StringPool:
         self._build()
         return self.sym, self.off, self.lm, self.cp
 
+    def letter_symbols(self):
+        """Pool symbol id of each of the 28 letters random(StringPrior) emits (string_prior.jl:28-39), 0xFFFF for a
+        letter that occurs in no pool string (it then equals no observed symbol)."""
+        self._build()
+        return np.array([self._sym_of_cp.get(ord(ch), 0xFFFF) for ch in ALPHABET], dtype=np.uint16)
+
 
 class Domain:
     """Ordered list of pool ids (unique observed values of a column, or the

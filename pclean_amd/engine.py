@@ -102,6 +102,12 @@ class Engine:
             return sampling.random_time_prior(self.hip, n, seed=seed, stream=stream)
         return sampling.random_string_prior(self.hip, n, dist.min_len, dist.max_len, seed=seed, stream=stream)
 
+    def sample_prior_strings_at(self, dist, seeds, elems):
+        """random(StringPrior) with the private streams the sweep used for the weights of the particles that chose the
+        dummy (pclean_dummy_seed keys, global observed rows): the strings those particles' new rows hold."""
+        from . import sampling
+        return sampling.random_string_prior_at(self.hip, seeds, elems, dist.min_len, dist.max_len)
+
     # -- static data ----------------------------------------------------------
     def _upload_gauss(self):
         lw, hip = self.lw, self.hip
@@ -112,6 +118,8 @@ class Engine:
         lw, hip = self.lw, self.hip
         sym, off, lm, _ = lw.pool.arrays()
         hip.load_strings(sym, off)
+        from .encode import load_lm_params
+        hip.set_lm_tables(*load_lm_params(), lw.pool.letter_symbols())
         hip.load_columns(self.obs)
         import time
         t0 = time.perf_counter()

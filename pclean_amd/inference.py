@@ -182,6 +182,14 @@ def _count_dummy_cases(lw, trace, todo, obs):
             cases["observed" if seen else "unobserved"] += 1
 
 
+def _leaf_node_of(lw, bi, cname, aname):
+    """node id of the option list of attribute cname.aname in observed-class block bi (None if it has none)"""
+    for nid, info in enumerate(lw.blocks[bi]["node_info"]):
+        if info["kind"] == "leaf" and info["cls"] == cname and info["attr"] == aname:
+            return nid
+    return None
+
+
 def resample_dummies(engine, trace, seed, stamp):
     """block_proposal.jl:58-60: a RandomChoiceNode whose enumerated proposal chose the ProposalDummyValue gets
     `random(node.dist, args...)` — a string from the bigram StringPrior / a random TimePrior time — as its value.
@@ -195,8 +203,10 @@ def resample_dummies(engine, trace, seed, stamp):
     the sampled string while the sweep's weight used the placeholder's likelihood.
     Returns the number of values replaced."""
     from .model import StringPrior, TimePrior
+    from .sampling import dummy_seed
     lw = engine.lw
     m = lw.model
+    run_seed = int(seed)
     todo = []
     for ci, cname in enumerate(m.class_order):
         t = trace.tables.get(cname)
@@ -218,7 +228,28 @@ def resample_dummies(engine, trace, seed, stamp):
     if not todo:
         return 0
     _count_dummy_cases(lw, trace, todo, engine.obs)
-    drawn = [engine.sample_prior_strings(d, len(rows), seed, stream) for cname, j, an, d, rows, stream in todo]
+    drawn = []
+    for cname, j, an, d, rows, stream in todo:
+        strings = engine.sample_prior_strings(d, len(rows), seed, stream)
+        if isinstance(d, StringPrior) and hasattr(engine, "sample_prior_strings_at"):
+            # rows created by an observed-class sweep: the string the sweep already drew for the creating particle's
+            # weight (private stream pclean_dummy_seed(seed, site of the option list, particle, sweep) at the creating row)
+            seeds, elems, where = [], [], []
+            for i, r in enumerate(rows):
+                org = trace.row_origin.get((cname, int(r)))
+                if org is None:
+                    continue
+                row_o, particle, sweep_idx, bi = org
+                node = _leaf_node_of(lw, bi, cname, an)
+                if node is None:
+                    continue
+                seeds.append(dummy_seed(run_seed, (bi << 16) | node, particle, sweep_idx))
+                elems.append(row_o)
+                where.append(i)
+            if where:
+                for i, s_ in zip(where, engine.sample_prior_strings_at(d, seeds, elems)):
+                    strings[i] = s_
+        drawn.append(strings)
     # a draw that happens to be one of the row's OWN proposal atoms is that option; anything else is a value outside
     # the options (MaybeSwap asks `val in options`, maybe_swap.jl:18) and gets an id after the dummy's — even when the
     # string equals an atom listed under another key
@@ -446,7 +477,7 @@ def _sweep_window(engine, trace, config, seed, sweep_idx, b0, b1, comm):
         _gather_locals(trace, comm, b0, hi - lo, lo)
     with _timed("observed/exchange_commit"):
         changed = exchange_and_commit(trace, engine.lw, comm, lo, choice, stats, new_rows, global_cur=True,
-                                      moved_local=moved, n_local=hi - lo, stats_reduced=reduced)
+                                      moved_local=moved, n_local=hi - lo, stats_reduced=reduced, sweep_idx=sweep_idx)
         _after_commit(engine, trace, seed)
         return changed
 
@@ -532,7 +563,7 @@ def initialize_trace(engine, trace, config, seed, max_batch=256, comm=None, merg
                 if len(g_rows):
                     merged[bi] = (g_rows, g_vals)  # rank order == row order (contiguous shards)
             new_rows = merged
-        created = trace.commit_batch(begin, count, choice, new_rows, dedup=True)
+        created = trace.commit_batch(begin, count, choice, new_rows, dedup=True, sweep_idx=0x7fffffff)
         _after_commit(engine, trace, seed)
         if created >= max(2, count // 64) and count >= 4:  # (identical on every rank: the commit is replicated)
             for r in range(min(merge_rounds, len(cuts))):

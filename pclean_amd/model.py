@@ -568,8 +568,17 @@ class LoweredModel:
                     self._emit_term(blk, kt[0], 1)
                     n_leaf_terms += 1
                 cacheable = int(n_leaf_terms == 1 and len(sub) == 1 and sub[0]["ctx"] is None)
+                # the ProposalDummyValue of the proposal (string_prior.jl:16-26, time_prior.jl:15-19): which latent
+                # value is the placeholder and what random(dist) samples when the dummy is chosen
+                dval, dspec = 0, 0
+                if isinstance(a.dist, (StringPrior, TimePrior)):
+                    dval = self.latent_dom[(cname, a.name)].get(a.dist.dummy_value()) + 1
+                    if isinstance(a.dist, TimePrior):
+                        dspec = _lib.DUMMY_TIME_PRIOR
+                    else:
+                        dspec = _lib.DUMMY_STRING_PRIOR | (int(a.dist.min_len) << 8) | (int(a.dist.max_len) << 16)
                 blk["nodes"].append((_lib.NODE_LEAF, self.option_id[(cname, a.name)], ltb, n_leaf_terms, 0, 0, nid, -1,
-                                     cacheable, 0, 0, 0))
+                                     cacheable, 0, dval, dspec))
                 blk["node_info"].append(dict(kind="leaf", cls=cname, attr=a.name, path=prefix + a.name))
                 kids.append(cid)
                 colsrc[a.name] = (cid, 0)

@@ -105,7 +105,7 @@ class Comm:
 
 
 def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local, new_rows_local, global_cur=False,
-                        moved_local=None, n_local=None, stats_reduced=False):
+                        moved_local=None, n_local=None, stats_reduced=False, sweep_idx=0):
     """Apply one sweep's result to the replicated trace.
 
     choice_local [n_blocks][n_local]: chosen referents of this rank's rows;
@@ -197,6 +197,9 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
         t = trace.tables[cname]
         t.counts[:n_before[bi]] += delta
         if len(g_rows):
+            g_vals = np.array(g_vals)
+            g_part = -1 - g_vals[:, 0]  # entry 0 of a record: -1 - chosen particle (pclean_get_new_rows)
+            g_vals[:, 0] = -1
             # identical new-row proposals of one sweep become ONE latent row (as commit_batch does for the
             # initialisation): in the sequential reference the second row would have joined the first row's
             # new referent instead of creating a duplicate entity.  Rows are created in order of first occurrence.
@@ -209,7 +212,8 @@ def exchange_and_commit(trace, lowered, comm, row_lo, choice_local, stats_local,
                 ok = old >= 0
                 ok[ok] = (t.counts[old[ok]] == 0) & t.live[old[ok]]
                 reuse = np.where(ok, old, -1)
-            new_ids = trace.materialise_bulk(bi, g_vals[first], reuse)[grp]
+            new_ids = trace.materialise_bulk(bi, g_vals[first], reuse,
+                                             origin=(g_rows[first], g_part[first], sweep_idx))[grp]
         else:
             new_ids = np.empty(0, dtype=np.int64)
         np.add.at(t.counts, new_ids, 1)  # each new row is referred to by its creator(s)

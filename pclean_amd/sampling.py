@@ -29,6 +29,24 @@ def random_string_prior(hip, n, min_len, max_len, seed=0, stream=0):
     return ["".join(ALPHABET[k] for k in out[i, :lens[i]]) for i in range(n)]
 
 
+def dummy_seed(seed, site, particle, sweep):
+    """pclean_dummy_seed (include/pclean_philox.h): key of the private draw stream of a value sampled for a chosen
+    ProposalDummyValue at draw site `site` by `particle` in sweep `sweep`."""
+    m = 0xFFFFFFFFFFFFFFFF
+    x = (int(seed) ^ ((int(site) << 32) | (int(sweep) & 0xFFFFFFFF))) & m
+    x = ((x ^ (x >> 30)) * 0xbf58476d1ce4e5b9) & m
+    x ^= ((int(particle) + 1) & 0xFFFFFFFF) * 0x94d049bb133111eb & m
+    x = ((x ^ (x >> 27)) * 0x94d049bb133111eb) & m
+    return x ^ (x >> 31)
+
+
+def random_string_prior_at(hip, seeds, elems, min_len, max_len):
+    """random(StringPrior(min_len, max_len)) with a private stream per element (seeds[i], elems[i])."""
+    init, trans = load_lm_params()
+    out, lens = hip.random_string_prior_at(seeds, elems, min_len, max_len, init, trans)
+    return ["".join(ALPHABET[k] for k in out[i, :lens[i]]) for i in range(len(lens))]
+
+
 def random_choose_proportionally(hip, n, options, probs, seed=0, stream=0):
     with np.errstate(divide="ignore"):
         idx = hip.random_categorical(n, np.log(np.asarray(probs, dtype=np.float64)), seed, stream)

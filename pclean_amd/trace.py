@@ -155,6 +155,11 @@ class Trace:
                     self.params[(cname, a.dist.param)] = ProportionsState(len(a.dist.options), prior.concentration,
                                                                          self.rng)
         self._class_plans, self._node_plans = {}, {}
+        # latent rows created by an observed-class sweep: (class, row) -> (creating observed row, chosen particle,
+        # sweep index, block) — names the draw stream of the values sampled for their chosen ProposalDummyValues
+        # (inference.resample_dummies; include/pclean_philox.h: pclean_dummy_seed)
+        self.row_origin = {}
+        self._origin = None
         self.cur = np.full((len(lowered.blocks), n_rows), -1, dtype=np.int32)
         # own enumerated choices of the observed class (e.g. br, unit) and the Gaussian mean parameter
         self.locals = {bi: np.full((n_rows, 2), -1, dtype=np.int32) for bi in getattr(lowered, "locals", {})}
@@ -271,6 +276,10 @@ class Trace:
         for j, target in self._class_plan(cname)[0]:
             self.tables[target].counts[values[j]] += 1
         self._own_choice_stats(cname, r, +1)
+        if self._origin is not None:
+            self.row_origin[(cname, int(r))] = self._origin
+        else:
+            self.row_origin.pop((cname, int(r)), None)
         return r
 
     def delete_row(self, cname, r):
@@ -305,6 +314,7 @@ class Trace:
             np.add.at(self.tables[target].counts, values[:, j], 1)
         for j, state in props:
             np.add.at(state.counts, values[:, j], 1)
+        self._bulk_ids = ids
         return ids
 
     def delete_rows_bulk(self, cname, ids):
@@ -328,7 +338,7 @@ class Trace:
             if len(gone):
                 self.delete_rows_bulk(target, np.unique(gone))
 
-    def materialise_bulk(self, bi, vals, reuse=None):
+    def materialise_bulk(self, bi, vals, reuse=None, origin=None):
         """Rows of block bi's root class for the node choices vals [k][n_nodes] (row_inference.jl:169-185 for
         many rows).  Proposals without a nested NEW referent are built with array operations; the rest
         go through _materialise.  Returns the row ids, in the order of `vals`.
@@ -338,11 +348,15 @@ class Trace:
         is kept instead of being collected and re-created under another id — in the reference the observed row is
         unincorporated, its singleton referent garbage-collected and an identical row created under a fresh gensym
         key (row_inference.jl:115-126, 169-185): the same table up to the row's name.  It keeps the table's columns
-        (and everything the device derives from them) unchanged when rows re-propose their own private referent."""
+        (and everything the device derives from them) unchanged when rows re-propose their own private referent.
+
+        origin (optional): (creating observed rows [k], chosen particles [k], sweep index) — recorded for the rows
+        created (row_origin) when the block has choices that may hold a ProposalDummyValue."""
         k = len(vals)
         out = np.empty(k, dtype=np.int64)
         if k == 0:
             return out
+        track = origin is not None and self._block_has_dummy(bi)
         cname, n_cols, leaves, copies, slots = self._node_plan(bi, 0)
         nested = [cn for _, cn, _, _ in copies] + [cid for _, cid in slots]
         simple = np.ones(k, dtype=bool)
@@ -366,11 +380,21 @@ class Trace:
                 out[idx[same]] = old[same]
                 fresh = ~same
                 out[idx[fresh]] = self.insert_rows_bulk(cname, values[fresh])
+                made = idx[fresh]
             else:
                 out[idx] = self.insert_rows_bulk(cname, values)
+                made = idx
+            if track:
+                for i in made:
+                    self.row_origin[(cname, int(out[i]))] = (int(origin[0][i]), int(origin[1][i]), int(origin[2]), bi)
         for i in np.flatnonzero(~simple):
+            self._origin = (int(origin[0][i]), int(origin[1][i]), int(origin[2]), bi) if track else None
             out[i] = self._materialise(bi, 0, vals[i])
+            self._origin = None
         return out
+
+    def _block_has_dummy(self, bi):
+        return any(n[0] == 1 and n[10] != 0 for n in self.lw.blocks[bi]["nodes"])
 
     # -- building a new row from the sampled node choices of a block ---------
     def _node_plan(self, bi, node):
@@ -487,7 +511,7 @@ class Trace:
                     got = np.bincount(t.cols[lw.colidx[cname][a.name], live], minlength=len(p.counts))
                     assert np.array_equal(got, p.counts), f"{cname}.{pname}: Dirichlet counts out of sync"
 
-    def commit_batch(self, begin, count, choice, new_rows, dedup=False):
+    def commit_batch(self, begin, count, choice, new_rows, dedup=False, sweep_idx=0):
         """Commit a batch of observed rows [begin, begin+count) (initialize_trace: rows had no
         referent before).  With dedup, identical new-row proposals of the batch become one row —
         the sequential reference would have let the second row join the first row's new referent.
@@ -501,13 +525,16 @@ class Trace:
             ch = np.array(choice[bi], dtype=np.int64)
             rows_new, vals_new = new_rows.get(bi, (np.zeros(0, np.int32), None))
             if len(rows_new):
-                vals_new = np.asarray(vals_new)
+                vals_new = np.array(vals_new)
+                part = -1 - vals_new[:, 0]  # entry 0 of a record: -1 - chosen particle (pclean_get_new_rows)
+                vals_new[:, 0] = CHOICE_NEW
+                rows_g = np.asarray(rows_new, dtype=np.int64) + begin
                 if dedup:  # one row per distinct proposal, created in order of first occurrence
                     first, grp = unique_rows(vals_new)
-                    ch[rows_new] = self.materialise_bulk(bi, vals_new[first])[grp]
+                    ch[rows_new] = self.materialise_bulk(bi, vals_new[first], origin=(rows_g[first], part[first], sweep_idx))[grp]
                     created += len(first)
                 else:
-                    ch[rows_new] = self.materialise_bulk(bi, vals_new)
+                    ch[rows_new] = self.materialise_bulk(bi, vals_new, origin=(rows_g, part, sweep_idx))
                     created += len(vals_new)
             t = self.tables[cname]
             old = self.cur[bi, begin:begin + count]

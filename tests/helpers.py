@@ -105,12 +105,18 @@ def mirror_world(oracle, lw, obs, trace, engine=None, dist_mode=1, option_logp=N
     else:
         mr, md, ml, nb, logl = density_tables_cpu(oracle, max_len)
     w.set_density(mr, md, ml, nb, logl)
+    from pclean_amd.encode import load_lm_params
+    w.set_strings(sym, off)
+    w.set_lm(*load_lm_params(), lw.pool.letter_symbols())
+    if engine is not None:
+        dist_mode = engine.dist_mode
     for key, (pid, odom, ldom) in lw.pair_id.items():
         if engine is not None:
             d = engine.hip.get_pair_table(pid, len(odom), len(ldom))
         else:
             d = oracle.pair_table(sym, off, odom.id_array(), ldom.id_array(), dist_mode)
         w.set_pair(pid, d, lw.pool.lens[ldom.id_array()].astype(np.uint16))
+        w.set_pair_strings(pid, odom.id_array(), dist_mode)
     for fid, fn in lw.fn_tables.items():
         w.set_fn(fid, fn)
     for key, (pid, n) in lw.eq_pairs.items():

@@ -35,6 +35,10 @@ class OracleEngine:
             return sampling.random_time_prior(ro, n, seed=seed, stream=stream)
         return sampling.random_string_prior(ro, n, dist.min_len, dist.max_len, seed=seed, stream=stream)
 
+    def sample_prior_strings_at(self, dist, seeds, elems):
+        from pclean_amd import sampling
+        return sampling.random_string_prior_at(self.oracle.RandomOracle(), seeds, elems, dist.min_len, dist.max_len)
+
     def _cfg(self, config):
         return InferConfig(config.num_iters, config.num_particles, 1, 1, int(config.use_mh_instead_of_pg),
                            config.rejuv_frequency, config.reporting_frequency)
