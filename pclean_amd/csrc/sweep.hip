@@ -1177,8 +1177,17 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
       bool any = tm.obs_col >= 0 && tm.obs_col < (int)ctx->col_has_missing.size() && ctx->col_has_missing[tm.obs_col] &&
                  hu[U] != 0;
-      for (int o = 0; o < U && !any; ++o) any = hu[o] != 0;
+      int first_o = -1;
+      for (int o = 0; o < U && !any; ++o)
+        if (hu[o] != 0) {
+          any = true;
+          first_o = o;
+        }
       b.leaf_drawable[node_id] = any ? 1 : 0;
+      if (getenv("PCLEAN_DEBUG_DUMMY"))
+        fprintf(stderr, "[pclean] block %d node %d: dummy option %d, drawable %d (first observed value %d, weight %llu; missing-value weight %llu)\n",
+                block_id, node_id, dummy_k, any ? 1 : 0, first_o, first_o >= 0 ? (unsigned long long)hu[first_o] : 0ull,
+                (unsigned long long)hu[U]);
     }
     s->leaf_version[key] = ver;
   }
@@ -2561,6 +2570,8 @@ static int block_dummy_drawable(pclean_ctx* ctx, int bi, bool* out) {
     int rc = ensure_leaf_cache(ctx, bi, node, &cache, &ocol, &n_obs);
     if (rc) return rc;
     if (b.leaf_drawable[node] != 0) {
+      static const bool dbg = getenv("PCLEAN_DEBUG_DUMMY") != nullptr;
+      if (dbg) fprintf(stderr, "[pclean] block %d node %d: its ProposalDummyValue can be drawn (flag %d)\n", bi, node, b.leaf_drawable[node]);
       *out = true;
       return PCLEAN_OK;
     }
