@@ -179,8 +179,12 @@ struct Evidence {
 
 /* Scores of all candidates (+ new-row candidate for FK nodes, last) of one
  * node for one work item.  out.size() == n_rows + (FK ? 1 : 0). */
+enum ScoreMode { SCORE_FULL = 0, SCORE_PRIOR = 1, SCORE_TERMS = 2 };
+/* SCORE_PRIOR: the prior part alone (CRP / option prior: what a prior proposal draws from, block_proposal.jl:42-56,
+ * 68-84); SCORE_TERMS: the likelihood terms alone, added in the same order onto 0.0 (what p accumulates for a value
+ * that was NOT enumerated: use_dd_proposals = false). */
 inline void node_scores(const World& w, int block_id, int node_id, int row, const int32_t* ctxv, int excl,
-                        double snew_in, std::vector<double>& out, const Evidence* ev = nullptr) {
+                        double snew_in, std::vector<double>& out, const Evidence* ev = nullptr, int mode = SCORE_FULL) {
   const OBlock& b = w.block[block_id];
   const pclean_node& nd = b.nodes[node_id];
   const OTable& t = w.table[nd.table];
@@ -193,15 +197,18 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
     const double logden = excluded ? t.scal[1] : t.scal[0];
     for (int k = 0; k < n; ++k) {
       if (t.counts[k] == 0) continue;
-      if (k == excl)
+      if (mode == SCORE_TERMS)
+        out[k] = 0.0;
+      else if (k == excl)
         out[k] = deleted ? NEG_INF : t.logc_m1[k] - logden;
       else
         out[k] = t.logc_full[k] - logden;
     }
-    out[n] = ((deleted ? t.scal[3] : t.scal[2]) - logden) + snew_in;
+    out[n] = mode == SCORE_TERMS ? 0.0 : ((deleted ? t.scal[3] : t.scal[2]) - logden) + snew_in;
   } else {
-    for (int k = 0; k < n; ++k) out[k] = t.logc_full[k];
+    for (int k = 0; k < n; ++k) out[k] = mode == SCORE_TERMS ? 0.0 : t.logc_full[k];
   }
+  if (mode == SCORE_PRIOR) return;
   const pclean_gauss* gs = (node_id < (int)b.node_gauss.size() && b.node_gauss[node_id] >= 0)
                                ? &b.gauss[b.node_gauss[node_id]] : nullptr;
   if (ev) {

@@ -247,6 +247,9 @@ static int g_locals_blocks = 0;
 int pco_sweep_batched(const pco::World* w, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep, int n_blocks,
                       int64_t row_offset, const int32_t* cur, int32_t* choice, int32_t* chosen, double* logml) {
   const int N = w->n_rows;
+  if (!cfg->use_dd_proposals)
+    for (int b = 0; b < n_blocks; ++b)
+      if (!pco::prior_mode_supported(w->block[b])) return -1; /* as the product: PCLEAN_ERR_ARG */
   g_new_rows.clear();
   g_locals.assign((size_t)N * n_blocks * 2, -1);
   g_locals_blocks = n_blocks;

@@ -100,6 +100,64 @@ inline void sample_new(const RowCtx& rc, int node, int excl, uint32_t particle, 
   }
 }
 
+/* ---- use_dd_proposals = false (block_proposal.jl:168): nothing is enumerated against the observations.
+ * propose_non_enumerable! (24-157) samples every reference slot from its CRP prior (68-84) and every unobserved
+ * discrete choice of a new row from its prior proposal (42-56: q_cont += lprobs[chosen], p += logdensity of the same
+ * value — they cancel; a chosen ProposalDummyValue leaves -log(dummy mass) and gets random(dist), 58-60), then
+ * p accumulates the log-density of every observed choice given the sampled values (62-64).  The particle's weight
+ * increment is therefore the likelihood of its sampled sub-tree.  Supported for plans whose terms are AddTypos
+ * observations (plain or through a JuliaNode); blocks with equality constraints, MaybeSwap or Gaussian terms are
+ * refused by the callers. ---- */
+inline bool prior_mode_supported(const OBlock& b) {
+  if (b.is_score) return false;
+  for (const pclean_term& tm : b.terms)
+    if (tm.dens_kind != PCLEAN_DENS_ADD_TYPOS) return false;
+  for (int g : b.node_gauss)
+    if (g >= 0) return false;
+  return true;
+}
+
+/* prior draws of the sub-choices of a freshly proposed row of `node`'s table */
+inline void sample_new_prior(const RowCtx& rc, int node, int excl, uint32_t particle, int32_t* vals) {
+  const OBlock& b = rc.w->block[rc.block];
+  const pclean_node& nd = b.nodes[node];
+  const uint32_t rr = rc.rng_row >= 0 ? (uint32_t)rc.rng_row : (uint32_t)((int64_t)rc.row + rc.row_offset);
+  for (int c = 0; c < nd.n_children; ++c) {
+    const int cid = b.children[nd.child_begin + c];
+    const pclean_node& cn = b.nodes[cid];
+    const int cex = child_excl_of(*rc.w, b, node, cid, excl);
+    std::vector<double> s;
+    node_scores(*rc.w, rc.block, cid, rc.row, rc.ctxv, cex, 0.0, s, rc.ev, SCORE_PRIOR);
+    FixSum f = fix_sum(s);
+    const int k = fix_draw(s, f, pclean_rand64(rc.seed, rr, PCLEAN_SITE_NODE(rc.block, cid), particle, rc.sweep));
+    const int n = rc.w->table[cn.table].n_rows;
+    if (cn.kind == PCLEAN_NODE_FK && k == n) {
+      vals[cid] = PCLEAN_CHOICE_NEW;
+      sample_new_prior(rc, cid, cex, particle, vals);
+    } else {
+      vals[cid] = k;
+    }
+  }
+}
+
+/* likelihood of the observations below `node` given its sampled choice (k, or NEW with the sub-choices in vals):
+ * terms of the chosen candidate, or — new row — of its children, added in plan order onto 0.0 */
+inline double subtree_terms(const RowCtx& rc, int node, int choice, int excl, const int32_t* vals) {
+  const OBlock& b = rc.w->block[rc.block];
+  const pclean_node& nd = b.nodes[node];
+  if (choice >= 0) {
+    std::vector<double> s;
+    node_scores(*rc.w, rc.block, node, rc.row, rc.ctxv, excl, 0.0, s, rc.ev, SCORE_TERMS);
+    return s[choice];
+  }
+  double acc = 0.0;
+  for (int c = 0; c < nd.n_children; ++c) {
+    const int cid = b.children[nd.child_begin + c];
+    acc += subtree_terms(rc, cid, vals[cid], child_excl_of(*rc.w, b, node, cid, excl), vals);
+  }
+  return acc;
+}
+
 inline int32_t resolve_new_value(const World& w, const OBlock& b, int node, int col, const int32_t* vals) {
   for (int depth = 0; depth < 16; ++depth) {
     const int cn = b.colmap[2 * (b.nodes[node].colmap_begin + col)];
@@ -319,7 +377,29 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
       }
       return 0.0;
     };
-    if (b.n_ctx == 0) {
+    if (!cfg.use_dd_proposals) { /* prior proposals: every particle draws on its own, weight = likelihood of the draw */
+      for (int p = 0; p < P; ++p) {
+        int32_t cv[PCLEAN_MAX_CTX];
+        ctx_of(p, cv);
+        RowCtx rc{&w, bi, row, b.n_ctx ? cv : nullptr, seed, sweep, row_offset};
+        std::vector<double> s;
+        node_scores(w, bi, 0, row, rc.ctxv, excl, 0.0, s, nullptr, SCORE_PRIOR);
+        FixSum f = fix_sum(s);
+        const int k = fix_draw(s, f, pclean_rand64(seed, rr, PCLEAN_SITE_NODE(bi, 0), (uint32_t)p, sweep));
+        int c = k == n_root ? PCLEAN_CHOICE_NEW : k;
+        if (p == 0 && cur[bi] >= 0) c = cur[bi];
+        pch[bi][p] = c;
+        double corr = 0.0;
+        if (c == PCLEAN_CHOICE_NEW) {
+          pvals[bi][p].assign(b.nodes.size(), -2);
+          pvals[bi][p][0] = PCLEAN_CHOICE_NEW;
+          sample_new_prior(rc, 0, excl, (uint32_t)p, pvals[bi][p].data());
+          if (has_dummy[bi]) corr = dummy_correction(rc, pvals[bi][p].data(), (uint32_t)p);
+        }
+        wts[p] += subtree_terms(rc, 0, c, excl, pvals[bi][p].data());
+        wts[p] += corr;
+      }
+    } else if (b.n_ctx == 0) {
       RowCtx rc{&w, bi, row, nullptr, seed, sweep, row_offset};
       std::vector<double> s;
       const double lse = eval_tree(rc, 0, excl, &s);
@@ -429,6 +509,54 @@ inline void sweep_latent(const World& w, const pclean_infer_config& cfg, uint64_
   const int nn = (int)b.nodes.size();
   const bool use_mh = cfg.use_mh_instead_of_pg != 0;
   const int P = use_mh ? 2 : cfg.num_particles;
+  if (!cfg.use_dd_proposals) {
+    /* prior proposals (block_proposal.jl:168): particle 0 keeps the row's current values (excl[r][t]: current referent
+     * of a reference slot, current OPTION of a choice), every other particle draws each attribute from its prior;
+     * weight = likelihood of the referring rows given the particle's values; then the usual final choice. */
+    for (int t = 0; t < n_items; ++t) {
+      const uint32_t rr = (uint32_t)keys[t];
+      const uint32_t pid = 0x1000u + (uint32_t)block_id;
+      Evidence ev;
+      ev.rows = ev_rows + ev_off[t];
+      ev.ctx = ev_ctx ? ev_ctx + (size_t)ev_off[t] * PCLEAN_MAX_CTX : nullptr;
+      ev.n = ev_off[t + 1] - ev_off[t];
+      RowCtx rc{&w, block_id, 0, nullptr, seed, sweep, 0, &ev, (int64_t)keys[t]};
+      std::vector<double> wts(P, 0.0);
+      std::vector<std::vector<int32_t>> pv(P, std::vector<int32_t>(nn, -2));
+      for (int p = 0; p < P; ++p)
+        for (int r = 0; r < n_roots; ++r) {
+          const int root = roots[r];
+          const pclean_node& rn = b.nodes[root];
+          const int curv = excl[(size_t)r * n_items + t];
+          const int rex = rn.kind == PCLEAN_NODE_FK ? curv : -1;
+          int c = curv;
+          if (p > 0) {
+            std::vector<double> s;
+            node_scores(w, block_id, root, 0, nullptr, rex, 0.0, s, &ev, SCORE_PRIOR);
+            FixSum f = fix_sum(s);
+            const int k = fix_draw(s, f, pclean_rand64(seed, rr, PCLEAN_SITE_NODE(block_id, root), (uint32_t)p, sweep));
+            c = (rn.kind == PCLEAN_NODE_FK && k == w.table[rn.table].n_rows) ? PCLEAN_CHOICE_NEW : k;
+            if (c == PCLEAN_CHOICE_NEW) sample_new_prior(rc, root, rex, (uint32_t)p, pv[p].data());
+          }
+          pv[p][root] = c;
+          wts[p] += subtree_terms(rc, root, c, rex, pv[p].data());
+        }
+      PartW pw = part_weights(wts);
+      int c;
+      if (use_mh && P >= 2) {
+        const double Ud = (double)pw.U;
+        const double w0 = (double)pw.u[0] / Ud, w1 = (double)pw.u[1] / Ud;
+        double ratio = w1 / (1e-10 + w0);
+        if (ratio > 1.0) ratio = 1.0;
+        c = (pw.U != 0 && pclean_u01(pclean_rand64(seed, rr, PCLEAN_SITE_MH, pid, sweep)) < ratio) ? 1 : 0;
+      } else {
+        c = part_pick(pw, pclean_rand64(seed, rr, PCLEAN_SITE_FINAL, pid, sweep));
+      }
+      chosen[t] = c;
+      for (int k = 0; k < nn; ++k) vals[(size_t)t * nn + k] = c > 0 ? pv[c][k] : -2;
+    }
+    return;
+  }
   for (int t = 0; t < n_items; ++t) {
     const uint32_t rr = (uint32_t)keys[t];
     const uint32_t pid = 0x1000u + (uint32_t)block_id;

@@ -160,6 +160,7 @@ struct pclean_ctx {
   int64_t cur_stride = 0;  // pclean_set_cur_stride
   const int32_t* obs_override = nullptr;  // sweep.hip: ensure_leaf_cache scores "item t observes value t"
   int32_t active_begin = 0, active_count = -1;  // pclean_set_active_rows window (-1 = all rows)
+  bool prior_mode = false;     // sweep.hip: the running sweep proposes from the priors (use_dd_proposals = false)
   bool force_generic = false;  // debug: never take the compact-table root kernel
   void* sweep_state = nullptr;  // owned by sweep.hip
   void* rccl_comm = nullptr;    // ncclComm_t of pclean_comm_init (comm.hip)

@@ -176,6 +176,11 @@ int pclean_launch_leaf_coarse_draw(pclean_ctx* ctx, const NodeDev& nd, const Ite
                                    int n_blocks, const double* lse_c, const double* m_c, const uint64_t* U_c,
                                    const uint64_t* coarse, uint64_t seed, uint32_t sweep, uint32_t site, int n_draws,
                                    double* lse_out, int32_t* draws_out);
+// prior proposals (use_dd_proposals = false): w[slot] += likelihood of the slot's sampled sub-tree (enum_kernels.hip)
+int pclean_launch_prior_terms(pclean_ctx* ctx, size_t n_slots, int N, int n_nodes, const NodeDev* nds,
+                              const int32_t* n_children, const int32_t* child_begin, const int32_t* children,
+                              const int32_t* pchoice, const int32_t* pnewpos, const int32_t* vals, const int32_t* it_ctx,
+                              double* w);
 // option list of a LEAF node scored against evidence sets (enum_kernels.hip: ev_leaf_wave_kernel)
 int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const FastRootDev& fr, uint64_t seed,
                           uint32_t sweep, uint32_t site, int n_draws, double* lse_out, int32_t* draws_out,

@@ -177,6 +177,25 @@ __device__ __forceinline__ double candidate_score(const NodeDev& nd, const DensD
   return sk;
 }
 
+// likelihood terms of candidate k alone, added in candidate_score()'s order onto 0.0 — what p accumulates for a value
+// that was sampled from its prior instead of being enumerated (use_dd_proposals = false, block_proposal.jl:62-64)
+__device__ __forceinline__ double candidate_terms(const NodeDev& nd, const DensDev& dn, const ItemsDev& it,
+                                                  const ItemView& v, int k) {
+  if (v.ev_lo >= 0) return candidate_score_ev(nd, dn, it, v, k, 0.0);
+  double sk = 0.0;
+  for (int ti = 0; ti < nd.n_terms; ++ti) {
+    const TermDev& tm = nd.terms[ti];
+    const int o = tm.obs_col[v.row];
+    if (o < 0) continue;
+    int val = tm.cand_col[k];
+    if (tm.ctx_slot >= 0) val = tm.fn[(size_t)v.ctxv[tm.ctx_slot] * tm.fn_nb + val];
+    const size_t idx = (size_t)o * tm.n_lat + val;
+    const int d = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
+    sk += term_density(tm, dn, d, val);
+  }
+  return sk;
+}
+
 // score of the "new row" candidate (proposal_compiler.jl:221-230): CRP new-table
 // term + log-marginals of the children, added in plan order
 __device__ __forceinline__ double new_score(const NodeDev& nd, const ChildrenDev& ch, const ItemView& v, int t) {
@@ -730,6 +749,62 @@ int pclean_launch_leaf_coarse_draw(pclean_ctx* ctx, const NodeDev& nd, const Ite
   const int wgs = (int)std::min<long long>((pairs + 3) / 4, 256 * 8);
   hipLaunchKernelGGL(leaf_coarse_draw_kernel, dim3(wgs), dim3(256), 0, ctx->stream, nd, dn, it, obs_col, n_obs, n_blocks,
                      lse_c, m_c, U_c, coarse, seed, sweep, site, n_draws, lse_out, draws_out);
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
+
+// ---- prior proposals (use_dd_proposals = false): weight of a particle = likelihood of its sampled sub-tree -------
+// One thread per particle slot (slot = particle * N + row).  choice[slot] >= 0: the terms of the block's root at that
+// referent; NEW: the nodes of the sampled new row, children summed in plan order inside their parent (the oracle's
+// recursion, sweep.h: subtree_terms; node ids are in pre-order, so a reverse pass sees the children first).
+#define PRIOR_MAX_NODES 64
+__global__ void prior_terms_kernel(size_t n_slots, int N, int n_nodes, const NodeDev* __restrict__ nds,
+                                   const int32_t* __restrict__ n_children, const int32_t* __restrict__ child_begin,
+                                   const int32_t* __restrict__ children, DensDev dn, const int32_t* __restrict__ pchoice,
+                                   const int32_t* __restrict__ pnewpos, const int32_t* __restrict__ vals,
+                                   const int32_t* __restrict__ it_ctx, double* __restrict__ w) {
+  const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n_slots) return;
+  int32_t cv[PCLEAN_MAX_CTX];
+  for (int c = 0; c < PCLEAN_MAX_CTX; ++c) cv[c] = it_ctx ? it_ctx[(size_t)c * n_slots + slot] : 0;
+  ItemsDev it{};
+  ItemView v{};
+  v.row = (int)(slot % (size_t)N);
+  v.item = v.row;
+  v.excl = -1;
+  v.ctxv = cv;
+  v.ev_lo = v.ev_hi = -1;
+  const int c0 = pchoice[slot];
+  double L;
+  if (c0 >= 0) {
+    L = candidate_terms(nds[0], dn, it, v, c0);
+  } else {
+    const int32_t* vv = vals + (size_t)pnewpos[slot] * n_nodes;
+    double acc[PRIOR_MAX_NODES];
+    for (int node = n_nodes - 1; node >= 0; --node) {
+      const int k = node == 0 ? PCLEAN_CHOICE_NEW : vv[node];
+      double a = 0.0;
+      if (k >= 0) {
+        a = candidate_terms(nds[node], dn, it, v, k);
+      } else if (k == PCLEAN_CHOICE_NEW) {
+        for (int c = 0; c < n_children[node]; ++c) a += acc[children[child_begin[node] + c]];
+      }
+      acc[node] = a;
+    }
+    L = acc[0];
+  }
+  w[slot] += L;
+}
+
+int pclean_launch_prior_terms(pclean_ctx* ctx, size_t n_slots, int N, int n_nodes, const NodeDev* nds,
+                              const int32_t* n_children, const int32_t* child_begin, const int32_t* children,
+                              const int32_t* pchoice, const int32_t* pnewpos, const int32_t* vals, const int32_t* it_ctx,
+                              double* w) {
+  if (n_slots == 0) return PCLEAN_OK;
+  if (n_nodes > PRIOR_MAX_NODES) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "prior proposals: more than %d plan nodes", PRIOR_MAX_NODES);
+  DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
+  hipLaunchKernelGGL(prior_terms_kernel, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, ctx->stream, n_slots, N,
+                     n_nodes, nds, n_children, child_begin, children, dn, pchoice, pnewpos, vals, it_ctx, w);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }

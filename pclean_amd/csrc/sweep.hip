@@ -639,13 +639,14 @@ __global__ void gather_new_rows_kernel(int n, const int32_t* list, const int32_t
 // per term, corr += c in node order; w += corr after the block's log marginal).  One thread per NEW slot.
 #define DUMMY_MAX_LEAVES 8
 #define DUMMY_MAX_TERMS 2
-#define DUMMY_DP_SLOTS 256
+#define DUMMY_DP_ARENA ((size_t)128 << 20)  // int16 cells of distance matrices per launch (256 MB)
 struct DummyTermDev {
   const int32_t* obs_col;
   const uint8_t* pair;
   const uint16_t* lat_len;
   const int32_t* obs_ids;
   int32_t n_lat, elem_bytes, max_typos, dist_mode;
+  int64_t dp_off;  // this term's distance matrix inside a slot's region of the arena (int16 cells)
 };
 struct DummyLeafDev {
   int32_t node, dummy_val, kind, min_len, max_len, n_terms;
@@ -664,14 +665,16 @@ struct DummyPackDev {
   const double* nb;
   const double* logl;
   int32_t nb_stride, pad;
-  int16_t* dp;             // [DUMMY_DP_SLOTS][(DUMMY_MAX_LEN + 2)^2]
-  unsigned int* dp_ctr;    // [0] slots handed out, [1] set when they ran out
+  int16_t* dp;             // arena: one region of slot_cells cells per NEW slot of the launch
+  int64_t slot_cells;
+  unsigned int* dp_ctr;    // [1] set when an observed string is longer than DUMMY_MAX_LEN
 };
-__global__ void dummy_correction_kernel(int n_new, int N, const int32_t* __restrict__ new_slots,
+__global__ void dummy_correction_kernel(int j0, int n_new, int N, const int32_t* __restrict__ new_slots,
                                         const int32_t* __restrict__ vals, int n_nodes, DummyPackDev dp, uint64_t seed,
                                         uint32_t sweep, int64_t row_offset, double* __restrict__ w) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n_new) return;
+  const int jl = blockIdx.x * blockDim.x + threadIdx.x;  // slot of this launch's slice [j0, j0 + n_new)
+  if (jl >= n_new) return;
+  const int j = j0 + jl;
   const int slot = new_slots[j];
   const int row = slot % N, particle = slot / N;
   const int32_t* v = vals + (size_t)j * n_nodes;
@@ -698,12 +701,11 @@ __global__ void dummy_correction_kernel(int n_new, int N, const int32_t* __restr
         const int sid = tm.obs_ids[o];
         const uint16_t* os = dp.sym + dp.off[sid];
         const int ol = (int)(dp.off[sid + 1] - dp.off[sid]);
-        const unsigned int ds = atomicAdd(&dp.dp_ctr[0], 1u);
-        if (ds >= DUMMY_DP_SLOTS || ol > DUMMY_MAX_LEN) {
+        if (ol > DUMMY_MAX_LEN) {
           dp.dp_ctr[1] = 1u;
           continue;
         }
-        int16_t* H = dp.dp + (size_t)ds * (DUMMY_MAX_LEN + 2) * (DUMMY_MAX_LEN + 2);
+        int16_t* H = dp.dp + (size_t)jl * dp.slot_cells + tm.dp_off;
         const int d = dummy_distance(tm.dist_mode, os, ol, drawn, L, H);
         double l;
         if (tm.max_typos >= 0 && d > tm.max_typos) {
@@ -888,6 +890,7 @@ static int begin_call(pclean_ctx* ctx) {
   s->pool_used = 0;
   s->dbg_desc = nullptr;
   s->dummy_used = false;
+  ctx->prior_mode = false;
   s->over_rec.clear();
   if (s->over_ctr.alloc(OVER_SLOTS)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   HIPCHK(ctx, hipMemsetAsync(s->over_ctr.p, 0, OVER_SLOTS * sizeof(unsigned int), ctx->stream));
@@ -1071,6 +1074,11 @@ static int build_node_dev(pclean_ctx* ctx, const Block& b, int node_id, NodeDev&
   if (node_id < (int)b.node_gauss.size() && b.node_gauss[node_id] >= 0) {
     int rc = build_gauss_dev(ctx, b.gauss[b.node_gauss[node_id]], &t, nd.g);
     if (rc) return rc;
+  }
+  if (ctx->prior_mode) {  // prior proposals: candidates are drawn from the prior alone (block_proposal.jl:42-56, 68-84)
+    nd.n_terms = 0;
+    memset(&nd.g, 0, sizeof nd.g);
+    return PCLEAN_OK;
   }
   for (int i = 0; i < n.n_terms; ++i) {
     const pclean_term& tm = b.terms[n.term_begin + i];
@@ -1538,7 +1546,9 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     if (rc) return rc;
     it.ev_item = il.origin;
   }
-  if (n.kind == PCLEAN_NODE_FK) {
+  if (n.kind == PCLEAN_NODE_FK && ctx->prior_mode) {
+    ch.n = 0;  // the new row's choices are sampled from their priors: the branch carries its CRP term alone
+  } else if (n.kind == PCLEAN_NODE_FK) {
     if (snew_override) {
       ch.n = 1;
       ch.arr[0] = snew_override;
@@ -1650,7 +1660,7 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   // cacheable option list: log-marginal and draws from the per-observed-value coarse prefix (leaf_coarse_draw_kernel)
   static const bool no_coarse = getenv("PCLEAN_NO_COARSE_LEAF") != nullptr;
   if (n.kind == PCLEAN_NODE_LEAF && n.cacheable && !il.ev_lo && !scores_out && !ctx->force_generic && !ctx->obs_override &&
-      !no_coarse && !nd.g.on) {
+      !no_coarse && !nd.g.on && !ctx->prior_mode) {
     const double* cache = nullptr;
     const int32_t* ocol = nullptr;
     int n_obs = 0;
@@ -1663,7 +1673,7 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   }
   FastRootDev fr;
   int fast = 0, fast_ev = 0;
-  if (!scores_out && !snew_override && !ctx->force_generic && !nd.g.on) {
+  if (!scores_out && !snew_override && !ctx->force_generic && !nd.g.on && !ctx->prior_mode) {
     if (!il.ev_lo)
       fast = try_fast_root(ctx, block_id, node_id, fr);
     else if (n.kind == PCLEAN_NODE_LEAF && n_draws <= 1 && !getenv("PCLEAN_NO_FAST_EV"))
@@ -1944,8 +1954,11 @@ static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const It
   bool use_ctx = false;
   static const bool disabled = getenv("PCLEAN_NO_DEDUP") != nullptr;
   g = ItemGroups();
-  if (disabled || il.n < 4096 || il.ev_lo || !subtree_key(ctx, b, node_id, cols, use_ctx) || cols.size() > 32)
+  if (ctx->prior_mode) {  // the prior vector of a slot depends on the excluded row alone
+    if (disabled || il.n < 4096 || il.ev_lo) return PCLEAN_OK;
+  } else if (disabled || il.n < 4096 || il.ev_lo || !subtree_key(ctx, b, node_id, cols, use_ctx) || cols.size() > 32) {
     return PCLEAN_OK;
+  }
   const int n = il.n;
   KeyColsDev kc{};
   kc.use_ctx = use_ctx ? 1 : 0;
@@ -1956,7 +1969,7 @@ static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const It
   {
     const pclean_node& nn = b.nodes[node_id];
     int32_t pre[3];
-    kc.n_pre = nn.n_terms <= PCLEAN_MAX_TERMS ? prefilter_terms(ctx, b, nn, pre) : 0;
+    kc.n_pre = (nn.n_terms <= PCLEAN_MAX_TERMS && !ctx->prior_mode) ? prefilter_terms(ctx, b, nn, pre) : 0;
     for (int q = 0; q < kc.n_pre; ++q) {
       const int c = b.terms[nn.term_begin + pre[q]].obs_col;
       kc.pre_col[q] = ctx->obs.p + (size_t)c * ctx->n_rows + ctx->active_begin;
@@ -2588,6 +2601,7 @@ static int apply_dummy_corrections(pclean_ctx* ctx, int bi, const int32_t* new_s
   const int nn = (int)b.nodes.size();
   std::vector<DummyLeafDev> leaves;
   bool need_strings = false;
+  int64_t slot_cells = 0;  // distance-matrix cells one NEW slot can need: every term of every dummy-bearing list
   for (int node = 0; node < nn; ++node) {
     const pclean_node& n = b.nodes[node];
     if (n.kind != PCLEAN_NODE_LEAF || n.dummy_value == 0) continue;
@@ -2611,6 +2625,9 @@ static int apply_dummy_corrections(pclean_ctx* ctx, int bi, const int32_t* new_s
         if (lf.n_terms >= DUMMY_MAX_TERMS)
           return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "node %d: more than %d observations below a dummy-bearing choice", node,
                              DUMMY_MAX_TERMS);
+        if (pt.max_obs_len > DUMMY_MAX_LEN)
+          return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "node %d: observed strings longer than %d symbols below a dummy-bearing "
+                                                       "choice", node, DUMMY_MAX_LEN);
         DummyTermDev& td = lf.t[lf.n_terms++];
         td.obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
         td.pair = pt.d.p;
@@ -2620,6 +2637,8 @@ static int apply_dummy_corrections(pclean_ctx* ctx, int bi, const int32_t* new_s
         td.elem_bytes = pt.elem_bytes;
         td.max_typos = tm.max_typos;
         td.dist_mode = pt.dist_mode;
+        td.dp_off = slot_cells;
+        slot_cells += (int64_t)(pt.max_obs_len + 2) * (lf.max_len + 2);
         need_strings = true;
       }
     leaves.push_back(lf);
@@ -2627,11 +2646,15 @@ static int apply_dummy_corrections(pclean_ctx* ctx, int bi, const int32_t* new_s
   if (leaves.empty()) return PCLEAN_OK;
   if (need_strings && !ctx->lm_valid)
     return pclean_fail(ctx, PCLEAN_ERR_STATE, "a StringPrior dummy value has observations below it: pclean_set_lm_tables first");
-  if (s->dummy_ctr.alloc(2) || (need_strings && s->dummy_dp.alloc((size_t)DUMMY_DP_SLOTS * (DUMMY_MAX_LEN + 2) * (DUMMY_MAX_LEN + 2))))
+  if (leaves.size() > DUMMY_MAX_LEAVES && need_strings)
+    return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "block %d: more than %d dummy-bearing option lists", bi, DUMMY_MAX_LEAVES);
+  if (s->dummy_ctr.alloc(2) || (need_strings && s->dummy_dp.alloc(DUMMY_DP_ARENA)))
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   if (!s->dummy_used) HIPCHK(ctx, hipMemsetAsync(s->dummy_ctr.p, 0, 2 * sizeof(unsigned int), ctx->stream));
   s->dummy_used = true;
   ProfScope ps(ctx, "dummy_value_weights");
+  // slices of NEW slots whose worst-case distance matrices fit the arena
+  const int per_launch = slot_cells > 0 ? (int)std::max<int64_t>(1, (int64_t)DUMMY_DP_ARENA / slot_cells) : n_new;
   for (size_t l0 = 0; l0 < leaves.size(); l0 += DUMMY_MAX_LEAVES) {
     DummyPackDev dp{};
     dp.n_leaves = (int)std::min<size_t>(DUMMY_MAX_LEAVES, leaves.size() - l0);
@@ -2646,10 +2669,13 @@ static int apply_dummy_corrections(pclean_ctx* ctx, int bi, const int32_t* new_s
     dp.logl = ctx->logl.p;
     dp.nb_stride = ctx->max_d + 1;
     dp.dp = s->dummy_dp.p;
+    dp.slot_cells = slot_cells;
     dp.dp_ctr = s->dummy_ctr.p;
-    HIPCHK(ctx, hipMemsetAsync(s->dummy_ctr.p, 0, sizeof(unsigned int), ctx->stream));  // (the overflow flag stays)
-    hipLaunchKernelGGL(dummy_correction_kernel, grid1(n_new), dim3(256), 0, ctx->stream, n_new, N, new_slots, vals, nn, dp,
-                       seed, sweep, s->row_offset + ctx->active_begin, w);
+    for (int j0 = 0; j0 < n_new; j0 += per_launch) {
+      const int cnt = std::min(per_launch, n_new - j0);
+      hipLaunchKernelGGL(dummy_correction_kernel, grid1(cnt), dim3(256), 0, ctx->stream, j0, cnt, N, new_slots, vals, nn, dp,
+                         seed, sweep, s->row_offset + ctx->active_begin, w);
+    }
   }
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
@@ -2661,14 +2687,64 @@ __global__ void gather_moved_kernel(int n, const int32_t* list, const int32_t* c
   if (j < n) out[j] = choice[list[j]];
 }
 
+// use_dd_proposals = false (block_proposal.jl:168): reference slots are sampled from their CRP prior (68-84), the
+// unobserved discrete choices of a new row from their prior proposals (42-56; q_cont and p cancel, a chosen
+// ProposalDummyValue leaves -log(dummy mass) and gets random(dist), 58-60) and p accumulates the log-density of the
+// observed choices given the sampled values (62-64): the particle's weight increment is the likelihood of its sampled
+// sub-tree.  Implemented for plans whose likelihood terms are AddTypos observations (plain or through a JuliaNode).
+static int prior_mode_supported(pclean_ctx* ctx, const Block& b, const char* who) {
+  bool ok = b.valid && !b.is_score;
+  for (const pclean_term& tm : b.terms) ok = ok && tm.dens_kind == PCLEAN_DENS_ADD_TYPOS;
+  for (int g : b.node_gauss) ok = ok && g < 0;
+  if (!ok)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "%s: use_dd_proposals = false (prior proposals, block_proposal.jl:168) is implemented "
+                                            "for plans whose likelihood terms are AddTypos observations; this plan has equality "
+                                            "constraints, MaybeSwap, Gaussian terms or a scoring block", who);
+  return PCLEAN_OK;
+}
+
+// device copies of what prior_terms_kernel needs of block bi: every node with its full terms, the child lists
+static int upload_plan_nodes(pclean_ctx* ctx, int bi, const NodeDev** nds, const int32_t** n_children,
+                             const int32_t** child_begin, const int32_t** children) {
+  Block& b = ctx->block[bi];
+  const int nn = (int)b.nodes.size();
+  std::vector<NodeDev> h(nn);
+  std::vector<int32_t> nc(nn), cb(nn);
+  for (int i = 0; i < nn; ++i) {
+    int rc = build_node_dev(ctx, b, i, h[i]);
+    if (rc) return rc;
+    nc[i] = b.nodes[i].n_children;
+    cb[i] = b.nodes[i].child_begin;
+  }
+  NodeDev* d = (NodeDev*)scratch<unsigned char>(ctx, sizeof(NodeDev) * nn);
+  int32_t* dnc = scratch<int32_t>(ctx, nn);
+  int32_t* dcb = scratch<int32_t>(ctx, nn);
+  int32_t* dch = scratch<int32_t>(ctx, std::max<size_t>(b.children.size(), 1));
+  if (!d || !dnc || !dcb || !dch) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  HIPCHK(ctx, hipMemcpyAsync(d, h.data(), sizeof(NodeDev) * nn, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(dnc, nc.data(), nn * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(dcb, cb.data(), nn * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (!b.children.empty())
+    HIPCHK(ctx, hipMemcpyAsync(dch, b.children.data(), b.children.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope
+  *nds = d;
+  *n_children = dnc;
+  *child_begin = dcb;
+  *children = dch;
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
                             int32_t n_blocks, const int32_t* cur, int32_t* choice, int32_t* chosen_particle,
                             double* logml) {
   if (!ctx || !cfg || n_blocks <= 0 || n_blocks > PCLEAN_MAX_BLOCKS || !cur)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: bad arguments");
-  if (!cfg->use_dd_proposals)
-    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: use_dd_proposals = false (prior proposals, "
-                                            "block_proposal.jl:168) is not implemented by the HIP path");
+  const bool prior_mode = !cfg->use_dd_proposals;
+  if (prior_mode)
+    for (int b = 0; b < n_blocks; ++b) {
+      const int rcp = prior_mode_supported(ctx, ctx->block[b], "pclean_sweep");
+      if (rcp) return rcp;
+    }
   const int N = ctx->active_count >= 0 ? ctx->active_count : ctx->n_rows;
   int P = cfg->num_particles;
   const int use_mh = cfg->use_mh_instead_of_pg != 0;
@@ -2764,7 +2840,43 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     const bool has_ctx = b.n_ctx > 0;
     ItemList il;
     const int32_t* excl;
-    if (!has_ctx) {
+    if (prior_mode) {
+      // every (row, particle) draws its referent from the CRP prior; the block's log marginal plays no part
+      il = ItemList{N, nullptr, nullptr, nullptr, nullptr};
+      excl = cur_b;
+      if (r.draws.alloc(NP) || r.lse.alloc(N)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+      ctx->prior_mode = true;
+      rc = eval_node(ctx, bi, 0, il, excl, seed, sweep_idx, P, nullptr, r.draws.p, nullptr, nullptr, false);
+      if (rc) {
+        ctx->prior_mode = false;
+        return rc;
+      }
+      HIPCHK(ctx, hipMemsetAsync(r.lse.p, 0, (size_t)N * sizeof(double), ctx->stream));
+      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+      hipLaunchKernelGGL(particle_update_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
+                         (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
+                         s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p);
+      if (has_ctx) {  // the particles' contexts: read by the likelihood terms and handed to the new rows' items
+        if (r.it_ctx.alloc(NP * PCLEAN_MAX_CTX)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+        CtxSrc cs{};
+        cs.n_ctx = b.n_ctx;
+        for (int c = 0; c < b.n_ctx; ++c) {
+          const int sb = b.ctx_src_block[c];
+          if (sb < 0 || sb >= bi) return pclean_fail(ctx, PCLEAN_ERR_ARG, "block %d: ctx source must be an earlier block", bi);
+          const Block& src = ctx->block[sb];
+          const CandTable& rt = ctx->cand[src.nodes[0].table];
+          if (b.ctx_src_col[c] < 0 || b.ctx_src_col[c] >= rt.n_cols) return pclean_fail(ctx, PCLEAN_ERR_ARG, "ctx column out of range");
+          cs.pchoice[c] = s->run[sb].pchoice.p;
+          cs.pnewpos[c] = s->run[sb].pnewpos.p;
+          cs.vals[c] = s->run[sb].vals.p;
+          cs.n_nodes[c] = (int)src.nodes.size();
+          cs.root_col[c] = rt.cols.p + (size_t)b.ctx_src_col[c] * rt.n_rows;
+          cs.col[c] = b.ctx_src_col[c];
+          cs.plan[c] = s->run[sb].plan;
+        }
+        hipLaunchKernelGGL(gather_ctx_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, cs, r.it_ctx.p);
+      }
+    } else if (!has_ctx) {
       il = ItemList{N, nullptr, nullptr, nullptr, nullptr};  // draws row-major [N][P]: one 80-byte store per row
       excl = cur_b;
       if (r.draws.alloc(NP) || r.lse.alloc(N)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
@@ -2853,6 +2965,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     bool drawable = false;
     rc = block_dummy_drawable(ctx, bi, &drawable);
     if (rc) return rc;
+    if (prior_mode) drawable = true;  // (prior draws of a StringPrior choice are the dummy almost surely)
     r.lazy_new = bi == n_blocks - 1 && !eager_all && !drawable;
     if (r.lazy_new) n_new = 0;  // nothing sampled now
     if (r.vals.alloc(std::max<size_t>((size_t)n_new * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
@@ -2874,11 +2987,31 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       ItemList sub{(int)n_new, row, cx, part, org};
       rc = sample_children(ctx, bi, 0, sub, ex, seed, sweep_idx, r.vals.p, nn);
       if (rc) return rc;
+      if (prior_mode) {
+        ctx->prior_mode = false;
+        const NodeDev* nds;
+        const int32_t *dnc, *dcb, *dch;
+        rc = upload_plan_nodes(ctx, bi, &nds, &dnc, &dcb, &dch);
+        if (!rc)
+          rc = pclean_launch_prior_terms(ctx, NP, N, nn, nds, dnc, dcb, dch, r.pchoice.p, r.pnewpos.p, r.vals.p,
+                                         has_ctx ? r.it_ctx.p : nullptr, s->w.p);
+        if (rc) return rc;
+      }
       if (drawable) {
         rc = apply_dummy_corrections(ctx, bi, r.new_slots.p, r.vals.p, (int)n_new, N, seed, sweep_idx, s->w.p);
         if (rc) return rc;
       }
+    } else if (prior_mode) {  // nobody proposed a new referent: the likelihood of the chosen referents alone
+      ctx->prior_mode = false;
+      const NodeDev* nds;
+      const int32_t *dnc, *dcb, *dch;
+      rc = upload_plan_nodes(ctx, bi, &nds, &dnc, &dcb, &dch);
+      if (!rc)
+        rc = pclean_launch_prior_terms(ctx, NP, N, nn, nds, dnc, dcb, dch, r.pchoice.p, r.pnewpos.p, r.vals.p,
+                                       has_ctx ? r.it_ctx.p : nullptr, s->w.p);
+      if (rc) return rc;
     }
+    ctx->prior_mode = false;
     // (pnewpos is only read where pchoice == NEW, so it needs no initialisation when nobody proposed one)
 
     // ---- resampling between blocks (row_inference.jl:152-155)
@@ -2992,9 +3125,8 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     apply_over_stats(ctx);
     if (s->h_counts[3 * PCLEAN_MAX_BLOCKS])
-      return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "pclean_sweep: more than %d chosen dummy values with an observation below "
-                                                   "them in one block (or an observed string longer than %d symbols)",
-                         DUMMY_DP_SLOTS, DUMMY_MAX_LEN);
+      return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "pclean_sweep: an observed string longer than %d symbols below a chosen "
+                                                   "dummy value", DUMMY_MAX_LEN);
     if (choice)
       for (int bi = 0; bi < n_blocks; ++bi)
         if (ctx->block[bi].is_score)

@@ -40,7 +40,8 @@ class OracleEngine:
         return sampling.random_string_prior_at(self.oracle.RandomOracle(), seeds, elems, dist.min_len, dist.max_len)
 
     def _cfg(self, config):
-        return InferConfig(config.num_iters, config.num_particles, 1, 1, int(config.use_mh_instead_of_pg),
+        return InferConfig(config.num_iters, config.num_particles, int(getattr(config, "use_dd_proposals", True)), 1,
+                           int(config.use_mh_instead_of_pg),
                            config.rejuv_frequency, config.reporting_frequency)
 
     def _world(self, trace, lo, hi):
@@ -84,9 +85,11 @@ class OracleEngine:
             w = self._world(trace, lo, hi)
             cfg = self._cfg(config)
             cur = np.ascontiguousarray(trace.cur[:, lo:hi])
-            orc.lib().pco_sweep_batched(w.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep_idx), nb, C.c_int64(lo),
-                                        orc._p(cur, C.c_int32), orc._p(choice, C.c_int32), orc._p(chosen, C.c_int32),
-                                        orc._p(logml, C.c_double))
+            rc = orc.lib().pco_sweep_batched(w.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep_idx), nb, C.c_int64(lo),
+                                             orc._p(cur, C.c_int32), orc._p(choice, C.c_int32), orc._p(chosen, C.c_int32),
+                                             orc._p(logml, C.c_double))
+            if rc:
+                raise ValueError("use_dd_proposals = false is implemented for plans whose likelihood terms are AddTypos observations")
             for b, blk in enumerate(lw.blocks):
                 if blk.get("score"):
                     continue

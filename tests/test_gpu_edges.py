@@ -141,15 +141,49 @@ def test_abi_error_paths():
 
 
 
-def test_use_dd_proposals_false_is_refused():
-    """Prior proposals (block_proposal.jl:168) are not implemented: the ABI must say so instead of running the
-    data-driven sweep (VERDICT r1 #9)."""
-    S = helpers.hospital_setup(n_rows=40)
-    eng = Engine(S["lw"], S["obs"], dist_mode=1)
+def test_use_dd_proposals_false_prior_proposals(oracle):
+    """use_dd_proposals = false (block_proposal.jl:168): reference slots from the CRP prior, a new row's choices from
+    their prior proposals, weight = likelihood of the sampled values (propose_non_enumerable!, 24-157).  HIP == oracle
+    bit for bit on hospital (two blocks, the second with a JuliaNode context; PG and MH) and on the `people` program
+    (prior draws of a StringPrior choice are the ProposalDummyValue: random strings weighed against the observation);
+    plans with equality constraints / MaybeSwap / Gaussian terms are refused with a message."""
+    import dummy_program as dp
+    S = helpers.hospital_setup(n_rows=300)
+    cases = [(S["lw"], S["obs"], S["trace"], 2)]
+    m, q, dirty, lw2, obs2 = dp.people_program()
+    from pclean_amd.trace import Trace
+    cases.append((lw2, obs2, Trace(lw2, obs2.shape[1], 0), 1))
+    for lw, obs, tr, nb in cases:
+        eng = Engine(lw, obs, dist_mode=1)
+        try:
+            eng.upload_trace(tr)
+            world = helpers.mirror_world(oracle, lw, obs, tr, eng)
+            for P, mh in ((6, 0), (2, 1)):
+                cfg = InferenceConfig(1, P, use_dd_proposals=False, use_mh_instead_of_pg=bool(mh))
+                choice, chosen, logml, new_rows = eng.sweep(tr, cfg, 77, 3)
+                c = InferConfig(1, P, 0, 1, mh, 50, 100)
+                och, ocp, oml = _oracle_sweep(oracle, world, c, 77, 3, tr.cur)
+                assert np.array_equal(choice, och) and np.array_equal(chosen, ocp), (nb, P, mh)
+                assert np.array_equal(logml, oml), (nb, P, mh, np.abs(logml - oml).max())
+                for b in range(nb):
+                    k = oracle.lib().pco_new_rows_count(b)
+                    nn = len(lw.blocks[b]["nodes"])
+                    orows, ovals = np.empty(k, dtype=np.int32), np.empty((k, nn), dtype=np.int32)
+                    if k:
+                        oracle.lib().pco_new_rows_get(b, nn, oracle._p(orows, C.c_int32), oracle._p(ovals, C.c_int32))
+                    g = new_rows.get(b, (np.zeros(0, np.int32), np.zeros((0, nn), np.int32)))
+                    assert np.array_equal(g[0], orows) and np.array_equal(g[1], ovals), (nb, P, mh, b)
+            # the data-driven sweep gives different draws (same seed): the flag really switches the proposal
+            dd = eng.sweep(tr, InferenceConfig(1, 6), 77, 3)
+            assert not np.array_equal(dd[2], logml)
+        finally:
+            eng.close()
+    R = helpers.rents_setup(n_rows=60)
+    eng = Engine(R["lw"], R["obs"], dist_mode=1)
     try:
-        eng.upload_trace(S["trace"])
-        with pytest.raises(PCleanHipError, match="use_dd_proposals"):
-            eng.sweep(S["trace"], InferenceConfig(1, 4, use_dd_proposals=False), 1, 0)
+        eng.upload_trace(R["trace"])
+        with pytest.raises(PCleanHipError, match="AddTypos"):
+            eng.sweep(R["trace"], InferenceConfig(1, 4, use_dd_proposals=False), 1, 0)
     finally:
         eng.close()
 
