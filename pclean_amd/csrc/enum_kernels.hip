@@ -809,6 +809,56 @@ int pclean_launch_prior_terms(pclean_ctx* ctx, size_t n_slots, int N, int n_node
   return PCLEAN_OK;
 }
 
+// ---- prior proposals for the rows of a LATENT class: likelihood of the referring rows given particle p's values ---
+// slot = item * P + particle; vals[slot][node] = the particle's choices (option / referent / NEW / -2 unused).
+// roots in order; each root's sub-tree as in prior_terms_kernel, every term summed over the item's evidence set
+// (candidate_score_ev onto 0.0).  aggs[node] = aggregated evidence of the node's terms (sweep.hip: ensure_agg).
+__global__ void prior_terms_ev_kernel(int n_items, int P, int n_nodes, const NodeDev* __restrict__ nds,
+                                      const AggDev* const* __restrict__ aggs, const int32_t* __restrict__ n_children,
+                                      const int32_t* __restrict__ child_begin, const int32_t* __restrict__ children,
+                                      int n_roots, const int32_t* __restrict__ roots, DensDev dn, ItemsDev it,
+                                      const int32_t* __restrict__ vals, double* __restrict__ w) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n_items * P) return;
+  const int t = slot / P;
+  ItemView v{};
+  v.item = t;
+  v.row = 0;
+  v.excl = -1;
+  v.ctxv = nullptr;
+  v.ev_lo = it.ev_lo[t];
+  v.ev_hi = it.ev_hi[t];
+  const int32_t* vv = vals + (size_t)slot * n_nodes;
+  double acc[PRIOR_MAX_NODES];
+  for (int node = n_nodes - 1; node >= 0; --node) {
+    const int k = vv[node];
+    double a = 0.0;
+    if (k >= 0) {
+      ItemsDev itn = it;
+      itn.agg = aggs[node];
+      a = candidate_score_ev(nds[node], dn, itn, v, k, 0.0);
+    } else if (k == PCLEAN_CHOICE_NEW) {
+      for (int c = 0; c < n_children[node]; ++c) a += acc[children[child_begin[node] + c]];
+    }
+    acc[node] = a;
+  }
+  double L = 0.0;
+  for (int r = 0; r < n_roots; ++r) L += acc[roots[r]];
+  w[slot] = L;
+}
+
+int pclean_launch_prior_terms_ev(pclean_ctx* ctx, int n_items, int P, int n_nodes, const NodeDev* nds, const AggDev* const* aggs,
+                                 const int32_t* n_children, const int32_t* child_begin, const int32_t* children, int n_roots,
+                                 const int32_t* roots, const ItemsDev& it, const int32_t* vals, double* w) {
+  if (n_items <= 0) return PCLEAN_OK;
+  if (n_nodes > PRIOR_MAX_NODES) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "prior proposals: more than %d plan nodes", PRIOR_MAX_NODES);
+  DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
+  hipLaunchKernelGGL(prior_terms_ev_kernel, dim3((n_items * P + 255) / 256), dim3(256), 0, ctx->stream, n_items, P, n_nodes,
+                     nds, aggs, n_children, child_begin, children, n_roots, roots, dn, it, vals, w);
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
+
 int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const ChildrenDev& ch, uint64_t seed,
                        uint32_t sweep, uint32_t site, int n_draws, double* lse_out, double* scores_out,
                        int32_t* draws_out) {

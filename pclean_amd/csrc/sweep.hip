@@ -2356,6 +2356,65 @@ __global__ void latent_items_kernel(int n, const int32_t* list, const int32_t* k
   origin[j] = t;
 }
 
+// ---- prior proposals for a latent class (use_dd_proposals = false) -----------------------------------------------
+static int prior_mode_supported(pclean_ctx* ctx, const Block& b, const char* who);
+static int upload_plan_nodes(pclean_ctx* ctx, int bi, const NodeDev** nds, const int32_t** n_children,
+                             const int32_t** child_begin, const int32_t** children);
+__global__ void retain_first_kernel(int n_items, int P, const int32_t* __restrict__ cur, int32_t* __restrict__ draws) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_items) draws[(size_t)t * P] = cur[t];  // particle 0 keeps the row's current value
+}
+__global__ void set_node_col_kernel(int n, const int32_t* __restrict__ src, int n_nodes, int node, int32_t* __restrict__ vals) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j < n) vals[(size_t)j * n_nodes + node] = src[j];
+}
+__global__ void latent_prior_items_kernel(int n, int P, int n_items, const int32_t* __restrict__ list,
+                                          const int32_t* __restrict__ keys, const int32_t* __restrict__ cur,
+                                          int32_t* __restrict__ rng, int32_t* __restrict__ particle,
+                                          int32_t* __restrict__ origin, int32_t* __restrict__ excl,
+                                          int32_t* __restrict__ ev_lo, int32_t* __restrict__ ev_hi,
+                                          const int32_t* __restrict__ off) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int idx = list[j], t = idx / P;
+  rng[j] = keys[t];
+  particle[j] = idx - t * P;
+  origin[j] = idx;
+  excl[j] = cur[t];
+  ev_lo[j] = off[t];
+  ev_hi[j] = off[t + 1];
+}
+// final choice among the P particles of every latent row (row_inference.jl:158-165), weights row-major [n_items][P]
+template <int PMAX>
+__global__ void latent_prior_choice_kernel(int n_items, int P, int use_mh, const double* __restrict__ w,
+                                           const int32_t* __restrict__ keys, uint64_t seed, uint32_t sweep, uint32_t block_id,
+                                           int32_t* __restrict__ chosen) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_items) return;
+  FixW<PMAX> f;
+  fix_weights<PMAX>(w + (size_t)t * P, (size_t)1, P, f);
+  const uint32_t rr = (uint32_t)keys[t], pid = 0x1000u + block_id;
+  int c;
+  if (use_mh && P >= 2) {
+    const double Ud = (double)f.U;
+    const double w0 = (double)f.u[0] / Ud, w1 = (double)f.u[PMAX > 1 ? 1 : 0] / Ud;
+    double ratio = w1 / (1e-10 + w0);
+    if (ratio > 1.0) ratio = 1.0;
+    c = (f.U != 0 && pclean_u01(pclean_rand64(seed, rr, PCLEAN_SITE_MH, pid, sweep)) < ratio) ? 1 : 0;
+  } else {
+    c = fix_pick<PMAX>(f, P, pclean_rand64(seed, rr, PCLEAN_SITE_FINAL, pid, sweep));
+  }
+  chosen[t] = c;
+}
+__global__ void gather_chosen_vals_kernel(int n_items, int P, int n_nodes, const int32_t* __restrict__ chosen,
+                                          const int32_t* __restrict__ pv, int32_t* __restrict__ vals) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= (size_t)n_items * n_nodes) return;
+  const int t = (int)(q / n_nodes), k = (int)(q - (size_t)t * n_nodes);
+  const int c = chosen[t];
+  vals[q] = c > 0 ? pv[((size_t)t * P + c) * n_nodes + k] : -2;
+}
+
 extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
                                    int32_t block_id, int32_t n_roots, const int32_t* roots, int32_t n_items,
                                    const int32_t* keys, const int32_t* ev_off, const int32_t* ev_rows,
@@ -2363,9 +2422,10 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   if (!ctx || !cfg || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid || n_roots <= 0 ||
       !roots || n_items < 0 || !keys || !ev_off || !excl || !chosen || !vals)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: bad arguments");
-  if (!cfg->use_dd_proposals)
-    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: use_dd_proposals = false (prior proposals, "
-                                            "block_proposal.jl:168) is not implemented by the HIP path");
+  if (!cfg->use_dd_proposals) {
+    const int rcp = prior_mode_supported(ctx, ctx->block[block_id], "pclean_sweep_latent");
+    if (rcp) return rcp;
+  }
   if (n_items == 0) return PCLEAN_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   Block& b = ctx->block[block_id];
@@ -2408,6 +2468,91 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   s->lat_items = n_items;
   s->lat_ev = n_ev;
   s->lat_agg.clear();
+  if (!cfg->use_dd_proposals) {
+    // Prior proposals (block_proposal.jl:168): particle 0 keeps the row's current values (excl[r][t]: current referent
+    // of a reference slot, current OPTION of a choice), every other particle draws each attribute from its prior;
+    // weight = likelihood of the referring rows given the particle's values; final choice among the particles.
+    const size_t NPi = (size_t)n_items * P;
+    int32_t* pv = scratch<int32_t>(ctx, NPi * nn);
+    int32_t* draws = scratch<int32_t>(ctx, NPi);
+    double* wl = scratch<double>(ctx, NPi);
+    if (!pv || !draws || !wl) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    hipLaunchKernelGGL(fill_i32_kernel, grid1(NPi * nn), dim3(256), 0, ctx->stream, pv, NPi * nn, -2);
+    for (int r = 0; r < n_roots; ++r) {
+      const int root = roots[r];
+      const pclean_node& rn = b.nodes[root];
+      const int32_t* cur_r = d_excl + (size_t)r * n_items;
+      ItemList ilp{n_items, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_keys};
+      ctx->prior_mode = true;
+      int rc = eval_node(ctx, block_id, root, ilp, rn.kind == PCLEAN_NODE_FK ? cur_r : nullptr, seed, sweep_idx, P, nullptr,
+                         draws, nullptr, nullptr, false);
+      if (rc) {
+        ctx->prior_mode = false;
+        return rc;
+      }
+      hipLaunchKernelGGL(retain_first_kernel, grid1(n_items), dim3(256), 0, ctx->stream, n_items, P, cur_r, draws);
+      hipLaunchKernelGGL(set_node_col_kernel, grid1(NPi), dim3(256), 0, ctx->stream, (int)NPi, draws, nn, root, pv);
+      if (rn.kind == PCLEAN_NODE_FK && rn.n_children > 0) {
+        HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+        int32_t* l2 = scratch<int32_t>(ctx, NPi);
+        if (!l2) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+        hipLaunchKernelGGL(compact_new_kernel, grid1(NPi), dim3(256), 0, ctx->stream, NPi, draws, 1, s->counter.p, l2, nullptr);
+        unsigned int c2 = 0;
+        HIPCHK(ctx, hipMemcpyAsync(&c2, s->counter.p, sizeof c2, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (c2) {
+          int32_t* rng2 = scratch<int32_t>(ctx, c2);
+          int32_t* part2 = scratch<int32_t>(ctx, c2);
+          int32_t* org2 = scratch<int32_t>(ctx, c2);
+          int32_t* ex2 = scratch<int32_t>(ctx, c2);
+          int32_t* evl2 = scratch<int32_t>(ctx, c2);
+          int32_t* evh2 = scratch<int32_t>(ctx, c2);
+          if (!rng2 || !part2 || !org2 || !ex2 || !evl2 || !evh2) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+          hipLaunchKernelGGL(latent_prior_items_kernel, grid1(c2), dim3(256), 0, ctx->stream, (int)c2, P, n_items, l2, d_keys,
+                             cur_r, rng2, part2, org2, ex2, evl2, evh2, d_off);
+          ItemList sub{(int)c2, nullptr, nullptr, part2, org2, nullptr, nullptr, nullptr, nullptr, rng2};
+          rc = sample_children(ctx, block_id, root, sub, ex2, seed, sweep_idx, pv, nn);
+          if (rc) {
+            ctx->prior_mode = false;
+            return rc;
+          }
+        }
+      }
+      ctx->prior_mode = false;
+    }
+    // likelihood of every (row, particle)
+    const NodeDev* nds;
+    const int32_t *dnc, *dcb, *dch;
+    int rc = upload_plan_nodes(ctx, block_id, &nds, &dnc, &dcb, &dch);
+    if (rc) return rc;
+    int32_t* d_roots = scratch<int32_t>(ctx, n_roots);
+    const AggDev** d_aggs = (const AggDev**)scratch<unsigned char>(ctx, sizeof(void*) * nn);
+    if (!d_roots || !d_aggs) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    ItemList ilev{n_items, nullptr, nullptr, nullptr, nullptr, d_off, d_off + 1, d_evr, d_evc, d_keys};
+    std::vector<const AggDev*> h_aggs(nn, nullptr);
+    for (int node = 0; node < nn; ++node)
+      if (b.nodes[node].n_terms > 0) {
+        rc = ensure_agg(ctx, block_id, node, ilev, &h_aggs[node]);
+        if (rc) return rc;
+      }
+    HIPCHK(ctx, hipMemcpyAsync(d_aggs, h_aggs.data(), sizeof(void*) * nn, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(d_roots, roots, (size_t)n_roots * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // h_aggs goes out of scope
+    ItemsDev itd{n_items, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, d_off, d_off + 1, d_evr, d_evc, d_keys, nullptr,
+                 nullptr, 0, 0, nullptr, nullptr};
+    rc = pclean_launch_prior_terms_ev(ctx, n_items, P, nn, nds, d_aggs, dnc, dcb, dch, n_roots, d_roots, itd, pv, wl);
+    if (rc) return rc;
+    DISPATCH_PMAX(P, hipLaunchKernelGGL(latent_prior_choice_kernel<PMAX>, grid1(n_items), dim3(256), 0, ctx->stream, n_items, P,
+                                        use_mh, wl, d_keys, seed, sweep_idx, (uint32_t)block_id, d_chosen));
+    hipLaunchKernelGGL(gather_chosen_vals_kernel, grid1((size_t)n_items * nn), dim3(256), 0, ctx->stream, n_items, P, nn,
+                       d_chosen, pv, d_vals);
+    HIPCHK(ctx, hipMemcpyAsync(chosen, d_chosen, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(vals, d_vals, (size_t)n_items * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    s->lat_agg.clear();
+    if (s->prof_on) prof_collect(ctx);
+    return finish_call(ctx);
+  }
   hipLaunchKernelGGL(latent_choice_kernel, grid1(n_items), dim3(256), 0, ctx->stream, n_items, P, use_mh, d_keys, seed,
                      sweep_idx, (uint32_t)block_id, d_chosen);
   hipLaunchKernelGGL(fill_i32_kernel, grid1((size_t)n_items * nn), dim3(256), 0, ctx->stream, d_vals,

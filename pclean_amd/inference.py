@@ -392,6 +392,31 @@ def _crosses_rejuv(b0, b1, config):
     return b1 // rf != b0 // rf
 
 
+def latent_current_choices(lw, trace, cname, rows, config):
+    """excl argument of pclean_sweep_latent for latent rows `rows` of class cname: per sub-plan root the row's current
+    referent (reference slots; -1 for choices).  With use_dd_proposals = false the retained particle must also name the
+    current OPTION of every choice: the index of the row's value in the proposal's options — a value that is no option
+    (a string drawn for a chosen dummy) counts as the ProposalDummyValue, as in block_proposal.jl:49-52."""
+    pl = lw.latent_plans[cname]
+    t = trace.tables[cname]
+    excl = np.full((len(pl["roots"]), len(rows)), -1, dtype=np.int32)
+    for r, root in enumerate(pl["roots"]):
+        col = lw.colidx[cname][pl["root_attr"][r]]
+        if pl["nodes"][root][0] == 0:
+            excl[r] = t.cols[col, rows]
+        elif not getattr(config, "use_dd_proposals", True):
+            opts = lw.option_values[(cname, pl["root_attr"][r])]
+            index = np.full(len(lw.latent_dom[(cname, pl["root_attr"][r])]) + 1, -1, dtype=np.int32)
+            index[opts[::-1]] = np.arange(len(opts) - 1, -1, -1)  # first option holding each value
+            cur = index[t.cols[col, rows]]
+            d = lw.model.classes[cname].attr(pl["root_attr"][r]).dist
+            if (cur < 0).any():
+                dummy = lw.latent_dom[(cname, pl["root_attr"][r])].get(d.dummy_value()) if hasattr(d, "dummy_value") else -1
+                cur = np.where(cur < 0, index[dummy] if dummy >= 0 else 0, cur)
+            excl[r] = cur
+    return excl
+
+
 def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_sub_batches=32, verbose=False,
                  batch_rows=None):
     """One rejuvenation sweep of latent class cname.  With several ranks the live latent rows are
@@ -414,10 +439,7 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
             resample_class_parameters(trace, cname)
             if verbose and (b0 // max(config.reporting_frequency, 1)) != ((b0 - 1) // max(config.reporting_frequency, 1)):
                 print(f"{cname}: Cleaning row {b0} of {len(live)}", flush=True)
-        excl = np.full((len(pl["roots"]), b1 - b0), -1, dtype=np.int32)
-        for r, root in enumerate(pl["roots"]):
-            if pl["nodes"][root][0] == 0:
-                excl[r] = t.cols[lw.colidx[cname][pl["root_attr"][r]], live[b0:b1]]
+        excl = latent_current_choices(lw, trace, cname, live[b0:b1], config)
         with _timed(f"latent/{cname}/upload"):
             engine.upload_trace(trace)
         lo, hi = shard_bounds(b1 - b0, comm.rank, comm.world)

@@ -14,17 +14,20 @@ from pclean_amd.trace import Trace
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("particles,mh", [(2, True), (8, False)])
-def test_latent_sweep_parity(oracle, particles, mh):
+@pytest.mark.parametrize("particles,mh,dd", [(2, True, True), (8, False, True), (2, True, False), (6, False, False)])
+def test_latent_sweep_parity(oracle, particles, mh, dd):
     """Every latent class of the hospital program, on a state with duplicated entities (so that
-    reference slots really move and new referents get proposed), then committed and re-checked."""
+    reference slots really move and new referents get proposed), then committed and re-checked.  dd = False:
+    prior proposals (use_dd_proposals = false, block_proposal.jl:168) — particle 0 retained, the others drawn from
+    the priors, weights = likelihood of the referring rows."""
+    from pclean_amd.inference import latent_current_choices
     S = helpers.hospital_setup(n_rows=600)
     lw, obs = S["lw"], S["obs"]
     eng = Engine(lw, obs, dist_mode=1)
     try:
-        cfg = InferenceConfig(1, particles, use_mh_instead_of_pg=mh)
+        cfg = InferenceConfig(1, particles, use_mh_instead_of_pg=mh, use_dd_proposals=dd)
         tr = Trace(lw, obs.shape[1], 4)
-        initialize_trace(eng, tr, cfg, 4)  # batched init leaves duplicates to merge
+        initialize_trace(eng, tr, InferenceConfig(1, particles, use_mh_instead_of_pg=mh), 4)  # batched init leaves duplicates to merge
         tr.check_consistency()
         moved = 0
         for sweep in range(2):
@@ -34,16 +37,13 @@ def test_latent_sweep_parity(oracle, particles, mh):
                 pl = lw.latent_plans[cname]
                 live, ev_off, ev_rows, ev_ctx = build_evidence(lw, tr, cname)
                 t = tr.tables[cname]
-                excl = np.full((len(pl["roots"]), len(live)), -1, dtype=np.int32)
-                for r, root in enumerate(pl["roots"]):
-                    if pl["nodes"][root][0] == 0:
-                        excl[r] = t.cols[lw.colidx[cname][pl["root_attr"][r]], live]
+                excl = latent_current_choices(lw, tr, cname, live, cfg)
                 eng.upload_trace(tr)
                 eng.hip.set_active_rows(0, -1)
                 world = helpers.mirror_world(oracle, lw, obs, tr, eng)
                 got = eng.hip.sweep_latent(cfg.as_c(), 9, sweep, pl["block_id"], pl["roots"], live, ev_off, ev_rows,
                                            ev_ctx, excl, len(pl["nodes"]))
-                c = InferConfig(1, particles, 1, 1, int(mh), 50, 100)
+                c = InferConfig(1, particles, int(dd), 1, int(mh), 50, 100)
                 want = world.sweep_latent(c, 9, sweep, pl["block_id"], pl["roots"], live, ev_off, ev_rows, ev_ctx, excl,
                                           len(pl["nodes"]))
                 assert np.array_equal(got[0], want[0]), (cname, "chosen particle")
@@ -51,7 +51,7 @@ def test_latent_sweep_parity(oracle, particles, mh):
                 assert ev_off[-1] == obs.shape[1]  # every observed row is evidence of exactly one row of the class
                 moved += commit_latent(lw, tr, cname, live, got[0], got[1])
                 tr.check_consistency()
-        assert moved > 0
+        assert moved > 0 or not dd  # (prior proposals rarely beat the retained particle)
     finally:
         eng.close()
 

@@ -390,3 +390,26 @@ def test_stable_argsort_ids_equals_numpy_stable_sort():
     for n, lo, hi in ((0, 0, 1), (10, -1, 5), (100000, -1, 10500), (200000, 0, 300000), (1000, 5, 6), (5000, 70000, 70010)):
         k = rng.integers(lo, hi, n).astype(np.int32) if n else np.zeros(0, np.int32)
         assert np.array_equal(stable_argsort_ids(k), np.argsort(k, kind="stable")), (n, lo, hi)
+
+
+def test_prior_proposals_end_to_end(oracle):
+    """use_dd_proposals = false through the product's host code (initialize_trace + run_inference over every class) with
+    the oracle engine: the trace stays consistent; the data-driven proposals do better on the same budget."""
+    import helpers
+    from oracle_engine import OracleEngine
+    from pclean_amd.analysis import evaluate_accuracy
+    from pclean_amd.engine import InferenceConfig
+    from pclean_amd.inference import initialize_trace, run_inference
+    from pclean_amd.trace import Trace
+    S = helpers.hospital_setup(n_rows=150)
+    lw, obs = S["lw"], S["obs"]
+    f1 = {}
+    for dd in (False, True):
+        eng = OracleEngine(oracle, lw, obs)
+        tr = Trace(lw, obs.shape[1], 1)
+        cfg = InferenceConfig(1, 4, use_dd_proposals=dd)
+        initialize_trace(eng, tr, cfg, 5, max_batch=32)
+        run_inference(eng, tr, cfg, 5)
+        tr.check_consistency()
+        f1[dd] = evaluate_accuracy(lw, tr, S["dirty"], S["clean"])["f1"]
+    assert 0.0 <= f1[False] <= f1[True]
