@@ -25,14 +25,14 @@ def _gpu_f1(name, seed, iters, mh, particles, n_rows):
     import sequential_reference as sr
     dirty, clean, mk_model, mk_query = sr.program(name, n_rows)
     (dirty, clean), _ = ex.shuffle_rows([dirty, clean], seed)
-    m = mk_model(ex.possibilities_of(dirty)) if name == "hospital" else mk_model(dirty)
+    m = mk_model(ex.possibilities_of(dirty)) if mk_model is ex.hospital_model else mk_model(dirty)
     lw = LoweredModel(m, mk_query(m), dirty)
     obs = lw.encode_observations(dirty)
     eng = Engine(lw, obs, dist_mode=1)
     try:
         tr = Trace(lw, obs.shape[1], seed)
-        cfg = InferenceConfig(iters, particles, use_mh_instead_of_pg=mh, rejuv_frequency=50 if name == "hospital" else 500)
-        initialize_trace(eng, tr, cfg, seed, max_batch=256 if name == "hospital" else 1024)
+        cfg = InferenceConfig(iters, particles, use_mh_instead_of_pg=mh, rejuv_frequency=sr.rejuv_of(name))
+        initialize_trace(eng, tr, cfg, seed, max_batch=256 if name.startswith("hospital") else 1024)
         run_inference(eng, tr, cfg, seed)
         tr.check_consistency()
         return evaluate_accuracy(lw, tr, dirty, clean)["f1"]
@@ -40,7 +40,9 @@ def _gpu_f1(name, seed, iters, mh, particles, n_rows):
         eng.close()
 
 
-@pytest.mark.parametrize("name", ["hospital", "flights", "rents"])
+# the experiment scripts' MH configurations, BASELINE.json configs[1] / [2] (particle Gibbs, 20 particles) and the headline
+# workload's shape at a size the sequential schedule can finish (30 000 synthetic rows, 300 true hospitals)
+@pytest.mark.parametrize("name", ["hospital", "flights", "rents", "hospital_pg20", "rents_pg20", "synth_pg20"])
 def test_batched_gpu_f1_matches_the_sequential_reference(name, capsys):
     ref = json.load(open(os.path.join(ROOT, "tests", "golden", "sequential_f1.json")))[name]
     c = ref["config"]
