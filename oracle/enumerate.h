@@ -55,6 +55,7 @@ struct OBlock {
   int n_ctx = 0;
   int ctx_src_block[PCLEAN_MAX_CTX] = {-1, -1};
   int ctx_src_col[PCLEAN_MAX_CTX] = {-1, -1};
+  int group = -1;                  /* blocks of one model block share a group: no resampling between them */
   bool is_score = false;           /* block without a reference slot (flights Obs block 3) */
   struct ScoreTerm {
     int obs_col, pair_table, val_block, val_col, key_block, key_col, nopt_fn, other_val;

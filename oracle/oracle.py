@@ -60,6 +60,19 @@ def _p(a, t):
     return None if a is None else a.ctypes.data_as(C.POINTER(t))
 
 
+def _ctx_cols(a):
+    """per-item / per-evidence-row context values padded to the PCLEAN_MAX_CTX columns the library indexes"""
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if a.shape[1] < 4:
+        a = np.concatenate([a, np.zeros((a.shape[0], 4 - a.shape[1]), dtype=np.int32)], axis=1)
+    return np.ascontiguousarray(a)
+
+
+
 def _sym(s, symmap=None):
     return np.array([ord(c) for c in s], dtype=np.uint16)
 
@@ -250,6 +263,9 @@ class World:
         lat_len = np.ascontiguousarray(lat_len, np.uint16)
         self.L.pco_world_set_pair(self.h, pid, d.shape[0], d.shape[1], _p(d, C.c_uint16), _p(lat_len, C.c_uint16))
 
+    def set_block_group(self, block_id, group):
+        self.L.pco_world_set_block_group(self.h, int(block_id), int(group))
+
     def set_strings(self, sym, off):
         sym = np.ascontiguousarray(sym, np.uint16)
         off = np.ascontiguousarray(off, np.int64)
@@ -333,7 +349,7 @@ class World:
         keys = np.ascontiguousarray(keys, np.int32)
         ev_off = np.ascontiguousarray(ev_off, np.int32)
         ev_rows = np.ascontiguousarray(ev_rows, np.int32)
-        ev_ctx = None if ev_ctx is None else np.ascontiguousarray(ev_ctx, np.int32)
+        ev_ctx = _ctx_cols(ev_ctx)
         excl = np.ascontiguousarray(excl, np.int32)
         chosen = np.zeros(len(keys), dtype=np.int32)
         vals = np.full((len(keys), n_nodes), -2, dtype=np.int32)
@@ -346,7 +362,7 @@ class World:
     def eval_tree(self, block_id, node_id, row, ctxv, excl, n_scores):
         """(log-marginal, scores of every candidate + the new-row candidate last) of one row; the new-row branch is
         evaluated recursively."""
-        ctxv = np.ascontiguousarray(ctxv if ctxv is not None else np.zeros(2), np.int32)
+        ctxv = _ctx_cols(ctxv if ctxv is not None else np.zeros(2, np.int32)).reshape(-1)
         sc = np.empty(n_scores)
         self.L.pco_eval_tree.restype = C.c_double
         lse = self.L.pco_eval_tree(self.h, block_id, node_id, int(row), _p(ctxv, C.c_int32), int(excl), _p(sc, C.c_double),
@@ -356,7 +372,7 @@ class World:
     def eval_tree_ev(self, block_id, node_id, ev_rows, ev_ctx, excl, n_scores):
         """eval_tree for a latent-class work item: node of a latent plan scored against an evidence set."""
         ev_rows = np.ascontiguousarray(ev_rows, np.int32)
-        ev_ctx = None if ev_ctx is None else np.ascontiguousarray(ev_ctx, np.int32)
+        ev_ctx = _ctx_cols(ev_ctx)
         sc = np.empty(n_scores)
         self.L.pco_eval_tree_ev.restype = C.c_double
         lse = self.L.pco_eval_tree_ev(self.h, block_id, node_id, len(ev_rows), _p(ev_rows, C.c_int32), _p(ev_ctx, C.c_int32),
@@ -367,7 +383,7 @@ class World:
                    n_cand=None, want_scores=False):
         rows = np.ascontiguousarray(rows, np.int32)
         n = len(rows)
-        ctxv = None if ctxv is None else np.ascontiguousarray(ctxv, np.int32)
+        ctxv = _ctx_cols(ctxv)
         excl = None if excl is None else np.ascontiguousarray(excl, np.int32)
         snew = None if snew is None else np.ascontiguousarray(snew, np.float64)
         lse = np.empty(n)

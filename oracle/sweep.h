@@ -422,7 +422,9 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
         wts[p] += corr;
       }
     }
-    if (!use_mh && bi < n_blocks - 1) {
+    const int grp_here = b.group >= 0 ? b.group : bi;
+    const int grp_next = bi + 1 < n_blocks ? (w.block[bi + 1].group >= 0 ? w.block[bi + 1].group : bi + 1) : -2;
+    if (!use_mh && bi < n_blocks - 1 && grp_here != grp_next) { /* row_inference.jl:152-155: between the MODEL's blocks */
       std::vector<int> anc;
       double inc;
       if (maybe_resample(wts, cur[bi] >= 0, seed, rr, sweep, (uint32_t)bi, anc, inc, nullptr)) {

@@ -11,7 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpclean_hip.so")
 
-MAX_CTX = 2
+MAX_CTX = 4
 CHOICE_NEW = -1
 DIST_OSA, DIST_DL = 0, 1
 DENS_ADD_TYPOS, DENS_EQUAL, DENS_MAYBE_SWAP = 0, 1, 2
@@ -77,6 +77,19 @@ def _p(arr, ctype):
     if arr is None:
         return None
     return arr.ctypes.data_as(C.POINTER(ctype))
+
+
+def _ctx_cols(a):
+    """per-item / per-evidence-row context values padded to the PCLEAN_MAX_CTX columns the library indexes"""
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    if a.shape[1] < MAX_CTX:
+        a = np.concatenate([a, np.zeros((a.shape[0], MAX_CTX - a.shape[1]), dtype=np.int32)], axis=1)
+    return np.ascontiguousarray(a)
+
 
 
 def load_library(path=None):
@@ -221,6 +234,9 @@ class HipContext:
         check(self.h, self.lib.pclean_set_table(self.h, C.c_int32(table_id), C.c_int32(n_rows), C.c_int32(n_cols),
                                                 _p(cols, C.c_int32), _p(counts, C.c_int64), C.c_double(strength),
                                                 C.c_double(discount)), "pclean_set_table")
+
+    def set_block_group(self, block_id, group):
+        check(self.h, self.lib.pclean_set_block_group(self.h, C.c_int32(block_id), C.c_int32(group)), "pclean_set_block_group")
 
     def set_lm_tables(self, init_p, trans_p, letter_sym):
         init_p = np.ascontiguousarray(init_p, dtype=np.float64)
@@ -378,7 +394,7 @@ class HipContext:
                    n_cand=None, want_scores=False):
         rows = np.ascontiguousarray(rows, dtype=np.int32)
         n = len(rows)
-        ctxv = None if ctxv is None else np.ascontiguousarray(ctxv, dtype=np.int32)
+        ctxv = _ctx_cols(ctxv)
         excl = None if excl is None else np.ascontiguousarray(excl, dtype=np.int32)
         snew = None if snew is None else np.ascontiguousarray(snew, dtype=np.float64)
         lse = np.empty(n, dtype=np.float64)
@@ -459,7 +475,7 @@ class HipContext:
         keys = np.ascontiguousarray(keys, dtype=np.int32)
         ev_off = np.ascontiguousarray(ev_off, dtype=np.int32)
         ev_rows = np.ascontiguousarray(ev_rows, dtype=np.int32)
-        ev_ctx = None if ev_ctx is None else np.ascontiguousarray(ev_ctx, dtype=np.int32)
+        ev_ctx = _ctx_cols(ev_ctx)
         excl = np.ascontiguousarray(excl, dtype=np.int32)  # [n_roots][n_items]
         n = len(keys)
         chosen = np.zeros(n, dtype=np.int32)

@@ -582,6 +582,13 @@ extern "C" int pclean_load_score_block(pclean_ctx* ctx, int32_t block_id, int32_
   return PCLEAN_OK;
 }
 
+extern "C" int pclean_set_block_group(pclean_ctx* ctx, int32_t block_id, int32_t group) {
+  if (!ctx || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_block_group: bad arguments");
+  ctx->block[block_id].group = group;
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_set_fn_table(pclean_ctx* ctx, int32_t fn_id, int32_t n_a, int32_t n_b, const int32_t* fn) {
   if (!ctx || fn_id < 0 || fn_id >= PCLEAN_MAX_TABLES || n_a <= 0 || n_b <= 0 || !fn)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_fn_table: bad arguments");
@@ -672,6 +679,7 @@ extern "C" int pclean_load_block(pclean_ctx* ctx, int32_t block_id, int32_t n_no
     }
   b.gauss.clear();
   b.node_gauss.assign(n_nodes, -1);
+  b.group = -1;
   b.valid = true;
   return PCLEAN_OK;
 }

@@ -91,6 +91,7 @@ struct ScoreTerm {
 
 struct Block {
   bool valid = false;
+  int32_t group = -1;                // pclean_set_block_group (-1: its own group)
   bool is_score = false;             // no reference slot: only scores observed choices (flights Obs block 3)
   std::vector<ScoreTerm> score_terms;
   int32_t prob_fn = -1, prob_a_block = -1, prob_a_col = -1, prob_b_block = -1, prob_b_col = -1;

@@ -1247,6 +1247,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     if (!pt.valid || tm.dens_kind != PCLEAN_DENS_ADD_TYPOS || pt.elem_bytes != 1) return 0;
     // evidence sets (ev_leaf_wave_kernel): ctx terms are only ever scored exactly (by candidate_score), any mode goes
     if (tm.ctx_slot >= 0 && ((!ev_mode && tm.ctx_mode != 0) || !ctx->fn[tm.fn_table].valid)) return 0;
+    if (tm.ctx_slot >= 2) return 0;  // the wave kernel's group descriptor carries two context values
     lmax = std::max(lmax, pt.max_lat_len);
     dmax = std::max(dmax, std::max(pt.max_lat_len, pt.max_obs_len));
   }
@@ -3160,7 +3161,9 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     // (pnewpos is only read where pchoice == NEW, so it needs no initialisation when nobody proposed one)
 
     // ---- resampling between blocks (row_inference.jl:152-155)
-    if (!use_mh && bi < n_blocks - 1) {
+    const int grp_here = b.group >= 0 ? b.group : bi;
+    const int grp_next = bi + 1 < n_blocks ? (ctx->block[bi + 1].group >= 0 ? ctx->block[bi + 1].group : bi + 1) : -2;
+    if (!use_mh && bi < n_blocks - 1 && grp_here != grp_next) {  // (the slots of one model block: no resampling in between)
       ProfScope ps(ctx, "resample");
       DISPATCH_PMAX(P, hipLaunchKernelGGL(maybe_resample_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p,
                                           (size_t)1, (size_t)N, 1, cur_b, seed, sweep_idx, (uint32_t)bi,

@@ -92,21 +92,16 @@ def build_evidence(lw, trace, cname):
         sk = keys[order]
         ev_rows = order[(sk >= 0) & t.live[np.maximum(sk, 0)]].astype(np.int32)
     ev_ctx = None
-    n_sources = sum(1 for ct in lw.cross_terms if bi in (ct["ctx_block"], ct["local_block"])) \
-        + (cname in lw.latent_ev_prob) + (cname in getattr(lw, "latent_ev_locals", {}))
-    if n_sources > 1:  # each source would need its own ctx slot (PCLEAN_MAX_CTX); none of the three programs does
-        raise NotImplementedError(f"latent class {cname}: more than one per-evidence-row context source")
-    for ct in lw.cross_terms:
-        if ct["ctx_block"] == bi:      # this class sits on the ctx-argument side: ctx = the local argument's value
-            ob, path = ct["local_block"], ct["local_path"]
-        elif ct["local_block"] == bi:  # local side: ctx = the other block's value
-            ob, path = ct["ctx_block"], ct["ctx_path"]
-        else:
-            continue
-        rc = lw.blocks[ob]["root_class"]
-        vals = trace.tables[rc].cols[lw.colidx[rc][path], trace.cur[ob]]
-        ev_ctx = np.zeros((len(ev_rows), 2), dtype=np.int32)
-        ev_ctx[:, 0] = vals[ev_rows]
+    sources = pl.get("ctx_sources", [])
+    if sources and (cname in lw.latent_ev_prob or cname in getattr(lw, "latent_ev_locals", {})):
+        raise NotImplementedError(f"latent class {cname}: JuliaNode contexts together with MaybeSwap / Gaussian evidence contexts")
+    if sources:  # slot s = the evidence row's value of source s (model.py: _build_latent_plans / _copy_subtree)
+        from . import _lib
+        ev_ctx = np.zeros((len(ev_rows), max(2, len(sources))), dtype=np.int32)
+        assert len(sources) <= _lib.MAX_CTX
+        for s_, (ob, col) in enumerate(sources):
+            rc = lw.blocks[ob]["root_class"]
+            ev_ctx[:, s_] = trace.tables[rc].cols[col, trace.cur[ob]][ev_rows]
     if cname in lw.latent_ev_prob:  # MaybeSwap external likelihood: the rows' error-probability index
         ev_ctx = np.zeros((len(ev_rows), 2), dtype=np.int32)
         ev_ctx[:, 0] = trace.prob_index()[ev_rows]

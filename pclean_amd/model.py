@@ -242,6 +242,24 @@ class Column:
         self.name, self.kind, self.cls, self.attr, self.target = name, kind, cls, attr, target
 
 
+class MappedDomain:
+    """Values of a latent domain seen through a single-argument JuliaNode: entry v is the pool string f(value v)
+    (repeats allowed) — what a pair table needs of its latent side (ids, lengths)."""
+
+    def __init__(self, pool, strings):
+        self.pool = pool
+        self.ids = [pool.add(s) for s in strings]
+
+    def __len__(self):
+        return len(self.ids)
+
+    def string(self, j):
+        return self.pool.strings[self.ids[j]]
+
+    def id_array(self):
+        return np.array(self.ids, dtype=np.int32)
+
+
 class LoweredModel:
     """Domains, flattened table layouts, option tables and per-block plans."""
 
@@ -446,14 +464,48 @@ class LoweredModel:
         root_of_block = []
         fk_block = {}
         self.score_blocks = {}
-        for bi, names in enumerate(ocls.blocks):
+        # A block of the observed class with several reference slots (PCleanClass.blocks, model.jl:100-106) is lowered
+        # into one ENGINE block per slot, proposed in declaration order with no resampling in between (block_group:
+        # run_smc! resamples between the class's blocks only, row_inference.jl:152-155).  An observation belongs to the
+        # last slot it mentions; a JuliaNode across two slots of one block reads the earlier slot's value as context.
+        # Independent slots are enumerated independently by the reference as well (process_plan!,
+        # proposal_compiler.jl:363-388); slots tied by a JuliaNode are proposed here one after the other, each given
+        # the earlier ones, instead of jointly.
+        eblocks, self.block_group = [], []
+        for ub, names in enumerate(ocls.blocks):
             fks = [n for n in names if ocls.attr(n).kind == "fk"]
-            if len(fks) > 1:
-                raise NotImplementedError("at most one reference slot per observed-class block (so far)")
+            if len(fks) <= 1:
+                eblocks.append(list(names))
+                self.block_group.append(ub)
+                continue
+            order = {f: i for i, f in enumerate(fks)}
+            groups = [[f] for f in fks]
+
+            def heads(a):
+                if a.kind == "julia":
+                    return [x.split(".", 1)[0] for x in a.args]
+                ref = getattr(a.dist, "ref", None) if a.kind == "choice" else None
+                if ref is None:
+                    return []
+                if "." in ref:
+                    return [ref.split(".", 1)[0]]
+                return heads(ocls.attr(ref))
+            for n in names:
+                a = ocls.attr(n)
+                if a.kind == "fk":
+                    continue
+                hs = [order[h] for h in heads(a) if h in order]
+                groups[max(hs) if hs else len(fks) - 1].append(n)
+            for g in groups:
+                eblocks.append(g)
+                self.block_group.append(ub)
+        self.engine_blocks = eblocks
+        for bi, names in enumerate(eblocks):
+            fks = [n for n in names if ocls.attr(n).kind == "fk"]
             root_of_block.append(fks[0] if fks else None)
             if fks:
                 fk_block[fks[0]] = bi
-        for bi, names in enumerate(ocls.blocks):
+        for bi, names in enumerate(eblocks):
             if root_of_block[bi] is None:
                 self._lower_score_block(bi, ocls, names, fk_block)
                 self.blocks.append(dict(score=True, nodes=[], terms=[], children=[], colmap=[], node_info=[],
@@ -480,8 +532,9 @@ class LoweredModel:
                     local = [x for x in j.args if x.split(".", 1)[0] == root_fk.name]
                     other = [x for x in j.args if x.split(".", 1)[0] != root_fk.name]
                     if len(local) != 1 or len(other) > 1:
-                        raise NotImplementedError("julia nodes must combine one value of this block with at most one "
-                                                  "value of an earlier block (so far)")
+                        raise NotImplementedError(f"{j.name}: a JuliaNode under an AddTypos observation combines ONE value of "
+                                                  "its block's slot with at most one value of an earlier slot; functions of "
+                                                  "several values of one slot, or of three and more slots, are not lowered")
                     lc, la = m.resolve(root_fk.target, local[0].split(".", 1)[1])
                     ldom = self.latent_dom[(lc, la.name)]
                     if other:
@@ -491,9 +544,17 @@ class LoweredModel:
                             raise NotImplementedError("ctx must come from an earlier block")
                         ocn, oa = m.resolve(ocls.attr(ohead).target, orest)
                         odom = self.latent_dom[(ocn, oa.name)]
-                        slot = len(blk["ctx_src_block"])
-                        blk["ctx_src_block"].append(sb)
-                        blk["ctx_src_col"].append(self.colidx[ocls.attr(ohead).target][orest])
+                        src = (sb, self.colidx[ocls.attr(ohead).target][orest])
+                        have = list(zip(blk["ctx_src_block"], blk["ctx_src_col"]))
+                        if src in have:  # two JuliaNodes reading the same earlier value share its ctx slot
+                            slot = have.index(src)
+                        else:
+                            slot = len(have)
+                            if slot >= _lib.MAX_CTX:
+                                raise NotImplementedError(f"a block reads more than {_lib.MAX_CTX} earlier values through JuliaNodes "
+                                                          "(PCLEAN_MAX_CTX)")
+                            blk["ctx_src_block"].append(sb)
+                            blk["ctx_src_col"].append(src[1])
                         order = [j.args.index(other[0]), j.args.index(local[0])]
                         jdom = Domain(self.pool)
                         fn = np.zeros((len(odom), len(ldom)), dtype=np.int32)
@@ -514,7 +575,12 @@ class LoweredModel:
                                                      ctx_block=sb, ctx_path=orest, local_block=bi,
                                                      local_path=local[0].split(".", 1)[1]))
                     else:
-                        raise NotImplementedError("single-argument julia nodes are not lowered yet")
+                        # f(one value of this slot): a pair table whose latent string of value v is f(v) — the
+                        # distances and word lengths AddTypos needs (add_typos.jl:56-63), nothing else changes
+                        mdom = MappedDomain(self.pool, [j.fn(ldom.string(y)) for y in range(len(ldom))])
+                        pid = self._pair_for(a.name, ("julia", j.name), mdom)
+                        terms.append(dict(obs=a.name, path=local[0].split(".", 1)[1], pair=pid,
+                                          max_typos=a.dist.max_typos, ctx=None))
             # direct (noise-free) observations of values below the root slot: equality constraints
             for obsname, key in self.direct_obs.items():
                 if "." in obsname and obsname.split(".", 1)[0] == root_fk.name:
@@ -609,6 +675,9 @@ class LoweredModel:
                 target.load_block(bi, *self.block_arrays(bi))
         for cname, pl in self.latent_plans.items():
             target.load_block(pl["block_id"], *self.latent_block_arrays(cname))
+        if len(set(self.block_group)) < len(self.block_group):  # a model block with several reference slots
+            for bi, g in enumerate(self.block_group):
+                target.set_block_group(bi, g)
 
     def same_pair_table(self, pid):
         odom, vdom = self.same_pairs[pid]
@@ -776,8 +845,12 @@ class LoweredModel:
                 if info["kind"] != "fk" or info["cls"] in self.latent_plans:
                     continue
                 cname = info["cls"]
+                # per-evidence-row context values of the plan's JuliaNode terms: slot s of the observed block keeps its
+                # number (the evidence row's value of that earlier slot); every cross-block JuliaNode whose CONTEXT
+                # argument lives in this class adds a slot holding the evidence row's LOCAL argument (_copy_subtree)
                 plan = dict(block_id=next_block, src_block=bi, src_node=nid, cls=cname, path=info["path"], nodes=[],
-                            terms=[], children=[], colmap=[], node_info=[], roots=[], root_attr=[])
+                            terms=[], children=[], colmap=[], node_info=[], roots=[], root_attr=[],
+                            ctx_sources=list(zip(blk["ctx_src_block"], blk["ctx_src_col"])))
                 node = blk["nodes"][nid]
                 for k in range(node[4], node[4] + node[5]):
                     child = blk["children"][k]
@@ -810,8 +883,16 @@ class LoweredModel:
                 col = self.colidx[info["cls"]][q[len(p) + 1:]]
             else:
                 continue
+            lb = ct["local_block"]
+            src = (lb, self.colidx[self.blocks[lb]["root_class"]][ct["local_path"]])
+            if src not in plan["ctx_sources"]:
+                if len(plan["ctx_sources"]) >= _lib.MAX_CTX:
+                    raise NotImplementedError(f"latent class {plan['cls']}: more than {_lib.MAX_CTX} per-evidence-row context "
+                                              "values (PCLEAN_MAX_CTX)")
+                plan["ctx_sources"].append(src)
             plan["terms"].append((self.obs_index[ct["obs"]], col, ct["pair"], _lib.DENS_ADD_TYPOS,
-                                  -1 if ct["max_typos"] is None else int(ct["max_typos"]), 0, ct["fn"], 2))
+                                  -1 if ct["max_typos"] is None else int(ct["max_typos"]), plan["ctx_sources"].index(src),
+                                  ct["fn"], 2))
         # MaybeSwap observations (scoring blocks) of this value: external likelihood of the referring rows,
         # each with its own error probability (evidence ctx slot 0 = index into the prob table)
         for sbi, sb in getattr(self, "score_blocks", {}).items():
@@ -851,9 +932,10 @@ class LoweredModel:
         pl = self.latent_plans[cname]
         nodes = np.array(pl["nodes"], dtype=_lib.NODE_DTYPE)
         terms = np.array(pl["terms"], dtype=_lib.TERM_DTYPE) if pl["terms"] else np.zeros(0, dtype=_lib.TERM_DTYPE)
-        # every latent-mode ctx term reads slot 0 of the evidence row's ctx
+        # latent-mode ctx terms read the evidence row's ctx slots (ctx_sources; MaybeSwap / Gaussian evidence: slots 0, 1)
+        n_ctx = max(2 if (pl["cls"] in self.latent_ev_locals) else 1, len(pl.get("ctx_sources", [])))
         return (nodes, terms, np.array(pl["children"], dtype=np.int32), np.array(pl["colmap"], dtype=np.int32),
-                np.zeros(1, dtype=np.int32), np.zeros(1, dtype=np.int32))
+                np.zeros(n_ctx, dtype=np.int32), np.zeros(n_ctx, dtype=np.int32))
 
     # -- arrays for the C ABI -------------------------------------------------
     def block_arrays(self, bi):
