@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpclean_hip.so")
+# PCLEAN_HIP_LIB: another build of the same ABI (e.g. the -DWAVE_PHASE_CLOCK measurement build, scripts/build_phase_clock.sh)
+LIB_PATH = os.environ.get("PCLEAN_HIP_LIB") or os.path.join(HERE, "libpclean_hip.so")
 
 MAX_CTX = 4
 CHOICE_NEW = -1

@@ -59,6 +59,9 @@
 #ifndef WAVE_MIN_WAVES
 #define WAVE_MIN_WAVES 5       // resident workgroups per CU the register allocation aims at (measured: 5 beats 6, 7 and 8)
 #endif
+#ifndef WAVE_EXACT_BY_TERM
+#define WAVE_EXACT_BY_TERM 2   // exact scoring: 0 one candidate per lane, 1 one (candidate, term) per lane, 2 the latter for short lists
+#endif
 #define WAVE_DCUT_OK 24u       // a cut-off below this many summed edits is considered selective
 #define WAVE_GUESS 4u          // first cut-off tried when the descriptor's bound is useless (widened until something survives)
 #define WAVE_SLACK 3u          // scanned cut-off = required + slack: makes the list reusable by the next groups
@@ -329,6 +332,13 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     }
   }
   const uint32_t ctx_mask = (uint32_t)__ballot(t_ctx), mt_mask = (uint32_t)__ballot(lane < n_terms && t_mt >= 0);
+  // exact scoring: lane -> (survivor slot j_l of a pass, term f_l); that term's candidate lengths and typo limit
+  constexpr int NTP = NT <= 2 ? 2 : NT <= 4 ? 4 : NT <= 8 ? 8 : 16;
+  constexpr int SPP = 64 / NTP;  // survivors per pass
+  constexpr bool BY_TERM_ONLY = WAVE_EXACT_BY_TERM == 1;  // (measured: taking this path for long lists too is slower)
+  const int f_l = lane & (NTP - 1), j_l = lane / NTP;
+  const g_u8_t clen_f = (g_u8_t)__shfl((unsigned long long)t_clen, f_l, 64);
+  const int mt_f = __shfl(t_mt, f_l, 64);  // -1: no limit (and lanes >= n_terms)
   // XCD-aware chunk hand-out: workgroup b runs on XCD b % 8 (each XCD has its own L2).  The groups arrive sorted by
   // referent, so consecutive groups stream the same byte rows: XCD x owns the x-th contiguous eighth of the groups.
   const int xcd = blockIdx.x & 7;
@@ -372,11 +382,24 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
 #ifdef WAVE_PHASE_CLOCK
   unsigned long long clk_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long clk_t = __builtin_readcyclecounter();
+  unsigned long long cnt_acc[6] = {0, 0, 0, 0, 0, 0};  // full scans, cached scans, survivors, -, -, -
 #endif
   int g = 0, g_end = 0;
   resolve(grab(), g, g_end);
   int raw_next = steal < 8 ? grab() : 0;
-  int dv = (g < g_end && lane < GD_STRIDE) ? gd[(size_t)g * GD_STRIDE + lane] : 0;
+  // descriptor of group x, lane i = its i-th word: scalar base + lane offset (a per-lane 64-bit base would be hoisted out
+  // of the group loop and spilled)
+  auto desc_word = [&](int x) -> int {
+    uint64_t base = (uint64_t)gd + (uint64_t)(uint32_t)x * (uint64_t)(GD_STRIDE * 4);
+    uint32_t off;  // byte offset of this lane's word, formed here (held across the loop it is spilled to scratch)
+    asm volatile(
+        "v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_and_b32 %0, %2, %0\n\tv_lshlrev_b32 %0, 2, %0"
+        : "=v"(off), "+s"(base)
+        : "n"(GD_STRIDE - 1));
+    return *(const __attribute__((address_space(1))) int32_t*)(base + off);
+  };
+  static_assert((GD_STRIDE & (GD_STRIDE - 1)) == 0, "descriptor stride: a power of two");
+  int dv = g < g_end ? desc_word(g) : 0;
   while (g < g_end) {
     // ---- next group (possibly the first of the next chunk): its descriptor is requested right away ---------------
     int gn = g + 1, gn_end = g_end;
@@ -388,7 +411,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
         gn = gn_end = 0;
       }
     }
-    const int dvn = (gn < gn_end && lane < GD_STRIDE) ? gd[(size_t)gn * GD_STRIDE + lane] : 0;
+    const int dvn = gn < gn_end ? desc_word(gn) : 0;
     WCLK(0)  // chunk hand-out + descriptor request
     // ---- descriptor -> wave-uniform registers ----------------------------------------------------------------------
     const int m_lo = __builtin_amdgcn_readlane(dv, 0), m_hi = __builtin_amdgcn_readlane(dv, 1);
@@ -412,18 +435,35 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     const int po1 = fr.n_pre > 1 ? __builtin_amdgcn_readlane(dv, 10 + fr.pre[1]) : -1;
     const int po2 = fr.n_pre > 2 ? __builtin_amdgcn_readlane(dv, 10 + fr.pre[2]) : -1;
 
+    const int n_mem = m_hi - m_lo;
+    // raw attribute words of a member item (row, RNG row, particle, output position): requested together, combined
+    // only where they are used (requesting them ahead of the draw phase was measured: no gain)
+    auto item_attrs = [&](int tm, int& w0, int& w1, int& w2, int& w3) {
+      w0 = w1 = w2 = w3 = tm;
+      if (wi.row) w0 = wi.row[tm];
+      if (wi.rng_row) w1 = wi.rng_row[tm];
+      if (wi.particle) w2 = wi.particle[tm];
+      if (wi.out_pos) w3 = wi.out_pos[tm];
+    };
+
     // ---- pre-filter scan at cut-off `want` (or the cached list when it covers it): survivors -> ksv, ascending ----
     int ns = 0;
     auto scan = [&](uint32_t want) {
       if (c_valid && po0 == c_o0 && po1 == c_o1 && po2 == c_o2 && want <= c_cut && c_ns <= CAP) {
         ns = c_ns;
         cut = c_cut;
+#ifdef WAVE_PHASE_CLOCK
+        cnt_acc[1] += 1;
+#endif
         return;
       }
       const uint64_t zr = (uint64_t)fr.zero_row;
       const g_u8_t r0 = (g_u8_t)(po0 >= 0 ? readlane64(t_row, fr.pre[0]) : zr);
       const g_u8_t r1 = (g_u8_t)(po1 >= 0 ? readlane64(t_row, fr.pre[1]) : zr);
       const g_u8_t r2 = (g_u8_t)(po2 >= 0 ? readlane64(t_row, fr.pre[2]) : zr);
+#ifdef WAVE_PHASE_CLOCK
+      cnt_acc[0] += 1;
+#endif
       const g_u8_t alive = (g_u8_t)(uint64_t)fr.alive;
       uint32_t cs = min(want + WAVE_SLACK, CUT_ALL);
       for (;;) {
@@ -431,7 +471,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
         const uint32_t addc = 0x01010101u * (127u - cs);
         ns = 0;
         for (int q0 = 0; q0 < nquads; q0 += 64 * WAVE_RB) {
-          u32x4_t ca[WAVE_RB], cb[WAVE_RB], cc[WAVE_RB], tq[WAVE_RB];
+          u32x4_t ca[WAVE_RB], cb[WAVE_RB], cc[WAVE_RB];
           uint32_t al[WAVE_RB];
 #pragma unroll
           for (int r = 0; r < WAVE_RB; ++r) {  // every load of the batch first
@@ -441,38 +481,43 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
             cc[r] = *(g_u4_t)(r2 + (qq << 4));
             al[r] = *(g_u16_t)(alive + (qq << 1));
           }
+          // does the batch hold a survivor at all?  Wave-uniform, and mostly not.
+          bool any = false;
 #pragma unroll
           for (int r = 0; r < WAVE_RB; ++r) {
             if (q0 + r * 64 + lane >= nquads) al[r] = 0u;
-            tq[r].x = ca[r].x + cb[r].x + cc[r].x + addc;
-            tq[r].y = ca[r].y + cb[r].y + cc[r].y + addc;
-            tq[r].z = ca[r].z + cb[r].z + cc[r].z + addc;
-            tq[r].w = ca[r].w + cb[r].w + cc[r].w + addc;
+            uint32_t tt = (ca[r].x + cb[r].x + cc[r].x + addc) & (ca[r].y + cb[r].y + cc[r].y + addc) &
+                          (ca[r].z + cb[r].z + cc[r].z + addc) & (ca[r].w + cb[r].w + cc[r].w + addc);
+            any |= ((tt & 0x80808080u) != 0x80808080u) && al[r] != 0u;
           }
-          bool any = false;
-#pragma unroll
-          for (int r = 0; r < WAVE_RB; ++r)
-            any |= ((tq[r].x & tq[r].y & tq[r].z & tq[r].w & 0x80808080u) != 0x80808080u) && al[r] != 0u;
-          if (__ballot(any) == 0ull) continue;  // wave-uniform: most rounds hold no survivor at all
+          if (__ballot(any) == 0ull) continue;
 #pragma unroll
           for (int r = 0; r < WAVE_RB; ++r) {
-            const uint32_t tw[4] = {tq[r].x, tq[r].y, tq[r].z, tq[r].w};
-            uint32_t m16 = 0;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              const uint32_t z = ~tw[w] & 0x80808080u;  // bit 7 of byte e set: candidate 4 w + e passes
-              m16 |= (((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xfu) << (4 * w);
-            }
-            m16 &= al[r];  // padding and free slots never survive
-            if (__ballot(m16 != 0) == 0ull) continue;
             const int q = q0 + r * 64 + lane;
-            int total;
-            int pos = ns + wave_excl_prefix5(__builtin_popcount(m16), total);
-            for (uint32_t mm = m16; mm; mm &= mm - 1) {
-              if (pos < CAP) ksv[pos] = (q << 4) + __builtin_ctz(mm);
-              ++pos;
-            }
-            ns += total;
+            // 16-bit mask of the bytes of (x, y, z, w) whose bit 7 is clear: candidate 4 w + e passes
+            auto pass16 = [&](uint32_t x, uint32_t y, uint32_t z, uint32_t w) -> uint32_t {
+              const uint32_t tw[4] = {x, y, z, w};
+              uint32_t m16 = 0;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                const uint32_t zz = ~tw[i] & 0x80808080u;
+                m16 |= (((zz >> 7) | (zz >> 14) | (zz >> 21) | (zz >> 28)) & 0xfu) << (4 * i);
+              }
+              return m16 & al[r];  // padding and free slots never survive
+            };
+            auto append = [&](uint32_t m16, int32_t* list, int cap, int& n) {
+              if (__ballot(m16 != 0) == 0ull) return;
+              int total;
+              int pos = n + wave_excl_prefix5(__builtin_popcount(m16), total);
+              for (uint32_t mm = m16; mm; mm &= mm - 1) {
+                if (pos < cap) list[pos] = (q << 4) + __builtin_ctz(mm);
+                ++pos;
+              }
+              n += total;
+            };
+            append(pass16(ca[r].x + cb[r].x + cc[r].x + addc, ca[r].y + cb[r].y + cc[r].y + addc,
+                          ca[r].z + cb[r].z + cc[r].z + addc, ca[r].w + cb[r].w + cc[r].w + addc),
+                   ksv, CAP, ns);
           }
         }
         if (ns > CAP && cs > want) {  // the slack alone overflowed the list: once more without it
@@ -505,6 +550,9 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     for (;;) {
       scan(cut);
       WCLK(2)  // scan
+#ifdef WAVE_PHASE_CLOCK
+      cnt_acc[2] += (unsigned long long)min(ns, CAP);
+#endif
       if (ns > CAP) {
         over = true;
         break;
@@ -514,10 +562,55 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
         cut = min(2u * cut + 2u, cut_max);
         continue;
       }
+#if WAVE_EXACT_BY_TERM != 0
+      // ---- exact fp64 scores of ksv[0..ns) -> scv: lane (j, f) = (survivor j of the pass, term f).  Every lane
+      // issues ITS byte-distance and length loads at once and then its density load — two memory round trips per
+      // pass whatever the number of terms (a per-candidate loop over the terms serialises them: the kernel is bound
+      // by dependent round trips, not by bytes).  The fp64 additions then follow plan order through lane shuffles
+      // (the operation order of candidate_score(), enum_kernels.hip).
+      if (BY_TERM_ONLY || ns <= SPP) {
+        const double* prior = (excluded && fr.prior_e) ? fr.prior_e : fr.prior_n;
+        const bool f_on = ((on_mask >> f_l) & 1u) != 0u, f_ctx = ((ctx_mask >> f_l) & 1u) != 0u;
+        const g_u8_t row_f = (g_u8_t)__shfl((unsigned long long)t_row, f_l, 64);
+        const int of_f = __shfl(dv, 10 + f_l, 64);
+        for (int base = 0; base < ns; base += SPP) {
+          const int j = base + j_l;
+          const uint32_t k = (uint32_t)ksv[j < ns ? j : base];
+          double b = 0.0;
+          if (f_l == 0) b = prior[k];
+          int dd = 0, LL = 0;
+          if (!f_ctx) {  // lanes >= n_terms and missing observations hold the zero row
+            dd = row_f[k];
+            LL = clen_f[k];
+          } else if (f_on) {  // latent value through fn[ctx][.] (a JuliaNode of an earlier block's choice)
+            fr_karg_t F = fr_karg();
+            const int c = F->terms[f_l].ctx_slot == 0 ? __builtin_amdgcn_readlane(dv, 5) : __builtin_amdgcn_readlane(dv, 6);
+            const int val = F->terms[f_l].fn[(size_t)c * F->terms[f_l].fn_nb + F->terms[f_l].cand_col[k]];
+            dd = F->terms[f_l].pair[(size_t)of_f * F->terms[f_l].n_lat + val];
+            LL = F->terms[f_l].lat_len[val];
+          }
+          if (dd == PRE_CLAMP && f_on && !f_ctx) {  // saturated: the true distance
+            fr_karg_t F = fr_karg();
+            dd = F->terms[f_l].pair[(size_t)of_f * F->terms[f_l].n_lat + F->terms[f_l].cand_col[k]];
+          }
+          double l = fr.atd[(uint32_t)(LL * fr.atd_stride + dd)];
+          if (mt_f >= 0 && dd > mt_f) l = ADD_TYPOS_IMPOSSIBLE;
+          if ((int)k == excl) b = deleted ? -__builtin_inf() : fr.logc_m1[excl] - fr.scal[1];
+          const int l0 = lane & ~(NTP - 1);
+#pragma unroll
+          for (int f = 0; f < NT; ++f) {
+            const double lf = __shfl(l, l0 + f, 64);
+            if ((on_mask >> f) & 1u) b += lf;  // a missing observation contributes nothing (add_typos.jl:51-53)
+          }
+          if (f_l == 0 && j < ns) scv[j] = b;
+        }
+      }
+#endif
+#if WAVE_EXACT_BY_TERM != 1
       // ---- exact fp64 scores of ksv[0..ns), one candidate per lane per pass -> scv.  The loads of a chunk of
       // terms are in flight together (byte distance + length, then the density table); the fp64 additions follow
       // plan order (the operation order of candidate_score(), enum_kernels.hip).
-      {
+      if (!BY_TERM_ONLY && (WAVE_EXACT_BY_TERM == 0 || ns > SPP)) {
         const double* prior = (excluded && fr.prior_e) ? fr.prior_e : fr.prior_n;
         for (int base = 0; base < ns; base += 64) {
           const int j = base + lane;
@@ -573,6 +666,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
           if (j < ns) scv[j] = b;
         }
       }
+#endif
       __builtin_amdgcn_wave_barrier();
       WCLK(3)  // exact scores
       if (!refine) break;
@@ -608,12 +702,13 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
         const int j = base + lane;
         const uint64_t u = (j < n_e && m != -__builtin_inf()) ? pclean_fixw(scv[j] - m) : 0ull;
         unsigned long long incl = u;
-        for (int sh = 1; sh < 64; sh <<= 1) {
+        const int n_here = min(64, n_e - base);  // entries of this pass: the usual list is two or three long
+        for (int sh = 1; sh < n_here; sh <<= 1) {
           const unsigned long long x = __shfl_up(incl, sh, 64);
           if (lane >= sh) incl += x;
         }
         if (j < n_e) pref[j] = carry + incl;
-        carry += __shfl(incl, 63, 64);
+        carry += __shfl(incl, n_here - 1, 64);
       }
       U = carry;
       __builtin_amdgcn_wave_barrier();
@@ -655,14 +750,11 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
       // ---- draws of every (member item, draw) pair of the group ------------------------------------------------------
       if (n_draws > 0) {
         const int res_new = fr.is_leaf ? fr.n_cand - 1 : PCLEAN_CHOICE_NEW;
-        const int n_mem = m_hi - m_lo;
-        auto one_draw = [&](int mi, int j) {
-          const int tm = n_mem == 1 ? t : wi.members[mi];
+        auto finish_draw = [&](int w0, int w1, int w2, int w3, int j) {
           int32_t res = res_new;
           if (U != 0) {
-            const int row_m = wi.row ? wi.row[tm] : tm;
-            const uint32_t rng_row = wi.rng_row ? (uint32_t)wi.rng_row[tm] : (uint32_t)((int64_t)row_m + wi.row_offset);
-            const uint32_t pid = wi.particle ? (uint32_t)wi.particle[tm] : (uint32_t)j;
+            const uint32_t rng_row = wi.rng_row ? (uint32_t)w1 : (uint32_t)((int64_t)w0 + wi.row_offset);
+            const uint32_t pid = wi.particle ? (uint32_t)w2 : (uint32_t)j;
             const uint64_t x = pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U);
             int a = 0, b = ns;  // smallest index with prefix > x (index ns = the new row)
             while (a < b) {
@@ -674,16 +766,24 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
             }
             if (a < ns) res = ksv[a];
           }
-          draws_out[(size_t)(wi.out_pos ? wi.out_pos[tm] : tm) * draw_is + (size_t)j * draw_ds] = res;
+          draws_out[(size_t)w3 * draw_is + (size_t)j * draw_ds] = res;
         };
         if (mem_per_pass > 0) {
           for (int m0 = 0; m0 < n_mem; m0 += mem_per_pass) {
             const int ms = m0 + slot_l;
-            if (slot_l < mem_per_pass && ms < n_mem) one_draw(m_lo + ms, draw_l);
+            if (slot_l < mem_per_pass && ms < n_mem) {
+              int w0, w1, w2, w3;
+              item_attrs(n_mem == 1 ? t : wi.members[m_lo + ms], w0, w1, w2, w3);
+              finish_draw(w0, w1, w2, w3, draw_l);
+            }
           }
         } else {
           const int n_out = n_mem * nd_eff;
-          for (int q = lane; q < n_out; q += 64) one_draw(m_lo + q / nd_eff, q % nd_eff);
+          for (int q = lane; q < n_out; q += 64) {
+            int w0, w1, w2, w3;
+            item_attrs(n_mem == 1 ? t : wi.members[m_lo + q / nd_eff], w0, w1, w2, w3);
+            finish_draw(w0, w1, w2, w3, q % nd_eff);
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -701,6 +801,8 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
   if (lane == 0)
     for (int i = 0; i < 8; ++i) atomicAdd(&g_wave_clk[i], clk_acc[i]);
   if (lane == 0) atomicAdd(&g_wave_clk[8], 1ull);
+  if (lane == 0)
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_wave_clk[9 + i], cnt_acc[i]);
 #endif
 }
 
@@ -950,7 +1052,8 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
     for (int i = 0; i < 6; ++i) tot += (double)h[i];
     fprintf(stderr, "[wave clk] groups %d terms %d waves %llu (grid %d WGs): ", it.n, fr.n_terms, h[8], wgs);
     for (int i = 0; i < 6; ++i) fprintf(stderr, "%s %.1f%% ", nm[i], 100.0 * (double)h[i] / tot);
-    fprintf(stderr, "| cycles/group %.0f, groups seen %llu\n", tot / (double)h[7], h[7]);
+    fprintf(stderr, "| cycles/group %.0f, groups seen %llu; full scans %llu, cached scans %llu (unused %llu), survivors scored %llu\n",
+            tot / (double)h[7], h[7], h[9], h[10], h[14], h[11]);
     memset(h, 0, sizeof h);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_clk), h, sizeof h);
   }
