@@ -58,7 +58,8 @@ struct DensDev {
 struct AggDev {
   const uint64_t* key;
   const int32_t* cnt;
-  const int32_t* off;
+  const int32_t* off;  // runs of original item oi: [off[oi], end ? end[oi] : off[oi + 1])
+  const int32_t* end;  // null: the runs of consecutive items are contiguous
 };
 
 // Work items of one enumeration launch. Item t scores evidence row row[t]
@@ -184,7 +185,7 @@ int pclean_launch_prior_terms(pclean_ctx* ctx, size_t n_slots, int N, int n_node
 int pclean_launch_prior_terms_ev(pclean_ctx* ctx, int n_items, int P, int n_nodes, const NodeDev* nds, const AggDev* const* aggs,
                                  const int32_t* n_children, const int32_t* child_begin, const int32_t* children, int n_roots,
                                  const int32_t* roots, const ItemsDev& it, const int32_t* vals, double* w);
-// option list of a LEAF node scored against evidence sets (enum_kernels.hip: ev_leaf_wave_kernel)
+// option list of a LEAF node scored against evidence sets (enum_kernels.hip: ev_leaf_block_kernel)
 int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const FastRootDev& fr, uint64_t seed,
                           uint32_t sweep, uint32_t site, int n_draws, double* lse_out, int32_t* draws_out,
                           int32_t* overflow_flag, unsigned int* overflow_count);

@@ -119,7 +119,7 @@ __device__ __forceinline__ double candidate_score_ev(const NodeDev& nd, const De
   for (int ti = 0; ti < nd.n_terms; ++ti) {
     const TermDev& tm = nd.terms[ti];
     const AggDev ag = it.agg[ti];
-    const int r1 = ag.off[oi + 1];
+    const int r1 = ag.end ? ag.end[oi] : ag.off[oi + 1];
     for (int r = ag.off[oi]; r < r1; ++r) {
       const uint64_t key = ag.key[r];
       const int o = (int)(key & 0xffffffull) - 1;
@@ -250,7 +250,7 @@ int pclean_launch_gate(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
   return PCLEAN_OK;
 }
 
-// ---- ev_leaf_wave_kernel: a big option list (LEAF node) scored against an EVIDENCE SET ------------------------
+// ---- ev_leaf_block_kernel: a big option list (LEAF node) scored against an EVIDENCE SET -----------------------
 // Latent-class sweeps re-propose every attribute of a latent row given all observed rows that refer to it
 // (proposal_compiler.jl:306-350).  For an option list of 40k strings that is 40k x (evidence) densities per row
 // in the generic kernels.  Same idea as root_wave.hip, with the aggregated evidence as the "rows":
@@ -258,26 +258,34 @@ int pclean_launch_gate(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
 //                                                     of mult * comp[o][k]      (32-bit integer arithmetic)
 // pass A finds the live option with the smallest D (its exact score - 1 is a lower bound of the maximum), pass B
 // keeps the options with D <= dcut; only those are scored exactly — through candidate_score(), the very
-// function the generic kernels use, so the result is bit-identical.  One wavefront per latent row, persistent
-// grid, no workgroup barrier.  Rows with more than EV_SURV_CAP survivors are flagged for the generic kernel.
-#define EV_SURV_CAP 256
+// function the generic kernels use, so the result is bit-identical.  ONE WORKGROUP of EV_T threads per latent row:
+// a sub-batch of a latent sweep holds a few hundred rows (a handful for the small classes, each with the evidence
+// of 10^5 observed rows), so one wavefront per row (the first version) left most of the chip idle behind a few
+// stragglers.  The integer sums, the maximum and the fixed-point prefix do not depend on how the options are split
+// over threads.  Rows with more than EV_SURV_CAP survivors are flagged for the generic kernel.
+#define EV_T 512
+#define EV_W (EV_T / 64)
+#define EV_SURV_CAP 2048
 #define EV_FIX_CUTOFF 28.5
 
-__global__ __launch_bounds__(256) void ev_leaf_wave_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
-                                                           const FastRootDev fr, uint64_t seed, uint32_t sweep,
-                                                           uint32_t site, int n_draws, double* __restrict__ lse_out,
-                                                           int32_t* __restrict__ draws_out,
-                                                           int32_t* __restrict__ overflow_flag,
-                                                           unsigned int* __restrict__ overflow_count) {
-  __shared__ uint64_t s_pref[4][EV_SURV_CAP + 8];
-  __shared__ int32_t s_k[4][EV_SURV_CAP + 8];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint64_t* pref = s_pref[wave];
-  int32_t* ksv = s_k[wave];
+__global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
+                                                             const FastRootDev fr, uint64_t seed, uint32_t sweep,
+                                                             uint32_t site, int n_draws, double* __restrict__ lse_out,
+                                                             int32_t* __restrict__ draws_out,
+                                                             int32_t* __restrict__ overflow_flag,
+                                                             unsigned int* __restrict__ overflow_count) {
+  __shared__ uint64_t s_pref[EV_SURV_CAP];  // exact scores (as doubles), then the fixed-point inclusive prefix
+  __shared__ int32_t s_k[EV_SURV_CAP];
+  __shared__ uint64_t s_w64[EV_W];
+  __shared__ double s_wd[EV_W];
+  __shared__ int s_wi[EV_W];
+  __shared__ double s_bound;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* scv = reinterpret_cast<double*>(s_pref);
   const int n = nd.n_cand;
   const int nquads = fr.kpad >> 4;
   const int draw_is = it.draw_is ? it.draw_is : n_draws;
-  for (int t = blockIdx.x * 4 + wave; t < it.n; t += gridDim.x * 4) {
+  for (int t = blockIdx.x; t < it.n; t += gridDim.x) {
     const ItemView v = item_view(nd, it, t);
     const int oi = it.ev_item ? it.ev_item[t] : t;
     // weighted distance sums of the 16 options of quad q over the entries of the plain (compact-table) terms
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(256) void ev_leaf_wave_kernel(const NodeDev nd, con
       for (int f = 0; f < fr.n_terms; ++f) {
         if (!fr.terms[f].comp) continue;
         const AggDev ag = it.agg[f];
-        const int r1 = ag.off[oi + 1];
+        const int r1 = ag.end ? ag.end[oi] : ag.off[oi + 1];
         for (int r = ag.off[oi]; r < r1; ++r) {
           const uint64_t key = ag.key[r];
           const int o = (int)(key & 0xffffffull) - 1;
@@ -304,25 +312,28 @@ __global__ __launch_bounds__(256) void ev_leaf_wave_kernel(const NodeDev nd, con
     };
     // ---- pass A: the live option with the smallest weighted distance -> lower bound of the maximum
     uint64_t best = ~0ull;
-    for (int q0 = 0; q0 < nquads; q0 += 64) {
-      const int q = q0 + lane;
-      if (q < nquads) {
-        uint32_t acc[16];
-        wsum(q, acc);
-        const uint32_t al = fr.alive[q];
+    for (int q = tid; q < nquads; q += EV_T) {
+      uint32_t acc[16];
+      wsum(q, acc);
+      const uint32_t al = fr.alive[q];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const uint64_t key = ((uint64_t)acc[e] << 32) | (uint32_t)((q << 4) + e);
-          if (((al >> e) & 1u) && key < best) best = key;
-        }
+      for (int e = 0; e < 16; ++e) {
+        const uint64_t key = ((uint64_t)acc[e] << 32) | (uint32_t)((q << 4) + e);
+        if (((al >> e) & 1u) && key < best) best = key;
       }
     }
     for (int sh = 32; sh > 0; sh >>= 1) {
       const uint64_t other = __shfl_xor(best, sh, 64);
       best = other < best ? other : best;
     }
-    double bound = -__builtin_inf();
-    if (best != ~0ull) bound = candidate_score(nd, dn, it, v, (int)(uint32_t)best) - 1.0;
+    if (lane == 0) s_w64[wave] = best;
+    __syncthreads();
+    if (tid == 0) {
+      for (int w = 1; w < EV_W; ++w) best = s_w64[w] < best ? s_w64[w] : best;
+      s_bound = best != ~0ull ? candidate_score(nd, dn, it, v, (int)(uint32_t)best) - 1.0 : -__builtin_inf();
+    }
+    __syncthreads();
+    const double bound = s_bound;
     uint32_t dcut = 0xffffffffu;
     if (fr.inv_c > 0.0 && bound > -__builtin_inf()) {
       const double x = (fr.prior_max_n - bound + EV_FIX_CUTOFF) * fr.inv_c;
@@ -330,8 +341,8 @@ __global__ __launch_bounds__(256) void ev_leaf_wave_kernel(const NodeDev nd, con
     }
     // ---- pass B: survivors in ascending option order
     int ns = 0;
-    for (int q0 = 0; q0 < nquads; q0 += 64) {
-      const int q = q0 + lane;
+    for (int q0 = 0; q0 < nquads; q0 += EV_T) {
+      const int q = q0 + tid;
       uint32_t mask16 = 0;
       if (q < nquads) {
         uint32_t acc[16];
@@ -340,57 +351,69 @@ __global__ __launch_bounds__(256) void ev_leaf_wave_kernel(const NodeDev nd, con
         for (int e = 0; e < 16; ++e) mask16 |= (acc[e] <= dcut ? 1u : 0u) << e;
         mask16 &= (uint32_t)fr.alive[q];
       }
-      if (__ballot(mask16 != 0) == 0ull) continue;
       const int cnt = __builtin_popcount(mask16);
       int incl = cnt;
       for (int sh = 1; sh < 64; sh <<= 1) {
         const int x = __shfl_up(incl, sh, 64);
         if (lane >= sh) incl += x;
       }
-      int pos = ns + incl - cnt;
+      if (lane == 63) s_wi[wave] = incl;
+      __syncthreads();
+      int pos = ns + incl - cnt, round_total = 0;
+      for (int w = 0; w < EV_W; ++w) {
+        if (w < wave) pos += s_wi[w];
+        round_total += s_wi[w];
+      }
       for (uint32_t mm = mask16; mm; mm &= mm - 1) {
-        if (pos < EV_SURV_CAP) ksv[pos] = (q << 4) + __builtin_ctz(mm);
+        if (pos < EV_SURV_CAP) s_k[pos] = (q << 4) + __builtin_ctz(mm);
         ++pos;
       }
-      ns += __shfl(incl, 63, 64);
+      ns += round_total;
+      __syncthreads();  // s_wi is rewritten by the next round
     }
-    __builtin_amdgcn_wave_barrier();
     const int to = it.out_pos ? it.out_pos[t] : t;
     if (ns > EV_SURV_CAP) {
-      if (lane == 0) {
+      if (tid == 0) {
         overflow_flag[to] = PCLEAN_CHOICE_NEW;
         atomicAdd(overflow_count, 1u);
       }
-      continue;
+      continue;  // (every thread: ns is uniform; the loop's first barrier follows writes to other arrays only)
     }
     // ---- exact scores (the generic kernels' own function), maximum, fixed-point prefix (flags are pre-zeroed)
-    double sc[EV_SURV_CAP / 64];
     double m = -__builtin_inf();
-#pragma unroll
-    for (int p = 0; p < EV_SURV_CAP / 64; ++p) {
-      sc[p] = -__builtin_inf();
-      const int j = p * 64 + lane;
-      if (j < ns) sc[p] = candidate_score(nd, dn, it, v, ksv[j]);
-      m = fmax(m, sc[p]);
+    for (int j = tid; j < ns; j += EV_T) {
+      const double sc = candidate_score(nd, dn, it, v, s_k[j]);
+      scv[j] = sc;
+      m = fmax(m, sc);
     }
     m = wave_max(m);
+    if (lane == 0) s_wd[wave] = m;
+    __syncthreads();
+    m = s_wd[0];
+    for (int w = 1; w < EV_W; ++w) m = fmax(m, s_wd[w]);
     uint64_t carry = 0;
-#pragma unroll
-    for (int p = 0; p < EV_SURV_CAP / 64; ++p) {
-      if (p * 64 >= ns) break;  // wave-uniform
-      const uint64_t u = (m == -__builtin_inf()) ? 0ull : pclean_fixw(sc[p] - m);
+    for (int j0 = 0; j0 < ns; j0 += EV_T) {
+      const int j = j0 + tid;
+      const uint64_t u = (j < ns && m != -__builtin_inf()) ? pclean_fixw(scv[j] - m) : 0ull;
       unsigned long long incl = u;
       for (int sh = 1; sh < 64; sh <<= 1) {
         const unsigned long long x = __shfl_up(incl, sh, 64);
         if (lane >= sh) incl += x;
       }
-      const int j = p * 64 + lane;
-      if (j < ns) pref[j] = carry + incl;
-      carry += __shfl(incl, 63, 64);
+      __syncthreads();  // the previous chunk's readers of s_w64 are done
+      if (lane == 63) s_w64[wave] = incl;
+      __syncthreads();
+      uint64_t base = carry, chunk_total = 0;
+      for (int w = 0; w < EV_W; ++w) {
+        if (w < wave) base += s_w64[w];
+        chunk_total += s_w64[w];
+      }
+      if (j < ns) s_pref[j] = base + incl;  // entry j: read as a score by this thread only, above
+      carry += chunk_total;
     }
     const uint64_t U = carry;
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
+    __syncthreads();
+    if (tid == 0) {
       if (lse_out) lse_out[to] = pclean_lse_from_fix(m, U);
       if (n_draws > 0) {
         int32_t res = n - 1;
@@ -401,17 +424,17 @@ __global__ __launch_bounds__(256) void ev_leaf_wave_kernel(const NodeDev nd, con
           int a = 0, b = ns - 1;  // smallest index with prefix > x
           while (a < b) {
             const int mid = (a + b) >> 1;
-            if (pref[mid] > x)
+            if (s_pref[mid] > x)
               b = mid;
             else
               a = mid + 1;
           }
-          res = ksv[a];
+          res = s_k[a];
         }
         draws_out[(size_t)to * draw_is] = res;
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();  // the next row overwrites s_k / s_pref
   }
 }
 
@@ -421,14 +444,15 @@ int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it
   if (it.n <= 0) return PCLEAN_OK;
   if (n_draws > 1) return pclean_fail(ctx, PCLEAN_ERR_ARG, "evidence-set option lists draw at most once per item");
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
-  const int wgs = std::min(256 * 8, (it.n + 3) / 4);
-  hipLaunchKernelGGL(ev_leaf_wave_kernel, dim3(wgs), dim3(256), 0, ctx->stream, nd, dn, it, fr, seed, sweep, site, n_draws,
+  const int wgs = std::min(256 * 8, it.n);
+  hipLaunchKernelGGL(ev_leaf_block_kernel, dim3(wgs), dim3(EV_T), 0, ctx->stream, nd, dn, it, fr, seed, sweep, site, n_draws,
                      lse_out, draws_out, overflow_flag, overflow_count);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }
 
-// exclusive block scan of one uint64 per lane (256 lanes); returns lane prefix, sets total
+// exclusive block scan of one uint64 per lane (NW waves); returns lane prefix, sets total
+template <int NW = 4>
 __device__ __forceinline__ uint64_t block_excl_scan(uint64_t part, uint64_t* wsum, uint64_t* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned long long incl = part;
@@ -439,12 +463,17 @@ __device__ __forceinline__ uint64_t block_excl_scan(uint64_t part, uint64_t* wsu
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
   uint64_t base = 0;
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-  *total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  uint64_t tot = 0;
+  for (int w = 0; w < NW; ++w) {
+    if (w < wave) base += wsum[w];
+    tot += wsum[w];
+  }
+  *total = tot;
   return base + incl - part;
 }
 
-__global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
+template <int BT>
+__global__ __launch_bounds__(BT) void enum_node_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
                                                         const ChildrenDev ch, uint64_t seed, uint32_t sweep,
                                                         uint32_t site, int n_draws, int item_base,
                                                         double* __restrict__ lse_out,
@@ -462,13 +491,13 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   const int nc = n + (fk ? 1 : 0);
   double* s = (double*)smem;                                    // [nc]
   uint64_t* u = (uint64_t*)smem;                                // same storage, after phase 3
-  double* red = (double*)(smem + (size_t)((nc + 1) & ~1) * 8);  // [8]
-  uint64_t* wsum = (uint64_t*)(red + 8);                        // [8]
+  double* red = (double*)(smem + (size_t)((nc + 1) & ~1) * 8);  // [16]
+  uint64_t* wsum = (uint64_t*)(red + 16);                       // [16]
   const ItemView v = item_view(nd, it, t);
 
   // ---- phase 1: scores ----------------------------------------------------
   double lmax = -__builtin_inf();
-  for (int k = tid; k < n; k += 256) {
+  for (int k = tid; k < n; k += BT) {
     const double sk = candidate_score(nd, dn, it, v, k);
     s[k] = sk;
     if (scores_out) scores_out[(size_t)to * nc + k] = sk;
@@ -484,20 +513,21 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   lmax = wave_max(lmax);
   if (lane == 0) red[wave] = lmax;
   __syncthreads();
-  const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  double m = red[0];
+  for (int w = 1; w < BT / 64; ++w) m = fmax(m, red[w]);
   // ---- phase 3: fixed-point weights in place ----------------------------------
-  for (int k = tid; k < nc; k += 256) {
+  for (int k = tid; k < nc; k += BT) {
     const double sk = s[k];
     u[k] = (m == -__builtin_inf()) ? 0ull : pclean_fixw(sk - m);
   }
   __syncthreads();
   // ---- phase 4: chunk sums + block scan ---------------------------------------
-  const int chunk = (nc + 255) / 256;
+  const int chunk = (nc + BT - 1) / BT;
   const int lo = min(tid * chunk, nc), hi = min(lo + chunk, nc);
   uint64_t part = 0;
   for (int k = lo; k < hi; ++k) part += u[k];
   uint64_t U;
-  const uint64_t pre = block_excl_scan(part, wsum, &U);
+  const uint64_t pre = block_excl_scan<BT / 64>(part, wsum, &U);
   // ---- phase 5: lse + draws of every member item of the group -------------------------------------
   // The lane's chunk becomes an inclusive prefix in place; every (member item, draw) pair then locates
   // its threshold by binary search (smallest k with prefix[k] > x — a zero-weight candidate is never hit,
@@ -514,7 +544,7 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   const int nd_eff = n_draws > 0 ? n_draws : 1;
   const int n_out = (m_hi - m_lo) * nd_eff;
   const int draw_is = it.draw_is ? it.draw_is : n_draws, draw_ds = it.draw_ds ? it.draw_ds : 1;
-  for (int q = tid; q < n_out; q += 256) {
+  for (int q = tid; q < n_out; q += BT) {
     const int mi = m_lo + q / nd_eff, j = q % nd_eff;
     const int tm = it.grp_off ? it.members[mi] : t;
     const int tom = it.out_pos ? it.out_pos[tm] : tm;
@@ -540,14 +570,17 @@ __global__ __launch_bounds__(256) void enum_node_kernel(const NodeDev nd, const 
   }
 }
 
-__global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
+// BT threads per item: 256 for launches that fill the chip, 1024 for the few-item launches of the latent sweeps (the
+// re-run of a sub-batch's overflowed rows: a dozen workgroups, each walking the whole option list three times)
+template <int BT>
+__global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
                                                             const ChildrenDev ch, uint64_t seed, uint32_t sweep,
                                                             uint32_t site, int n_draws, int item_base,
                                                             double* __restrict__ lse_out,
                                                             double* __restrict__ scores_out,
                                                             int32_t* __restrict__ draws_out) {
-  __shared__ double red[8];
-  __shared__ uint64_t wsum[8];
+  __shared__ double red[BT / 64];
+  __shared__ uint64_t wsum[BT / 64];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int t = blockIdx.x + item_base;
@@ -560,7 +593,7 @@ __global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, co
 
   // pass A: max (lane-strided, coalesced)
   double lmax = -__builtin_inf();
-  for (int k = tid; k < n; k += 256) {
+  for (int k = tid; k < n; k += BT) {
     const double sk = candidate_score(nd, dn, it, v, k);
     if (scores_out) scores_out[(size_t)to * nc + k] = sk;
     lmax = fmax(lmax, sk);
@@ -572,10 +605,11 @@ __global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, co
   lmax = wave_max(lmax);
   if (lane == 0) red[wave] = lmax;
   __syncthreads();
-  const double m = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+  double m = red[0];
+  for (int w = 1; w < BT / 64; ++w) m = fmax(m, red[w]);
 
   // pass B: fixed-point weights over contiguous per-lane chunks (natural order prefix)
-  const int chunk = (nc + 255) / 256;
+  const int chunk = (nc + BT - 1) / BT;
   const int lo = min(tid * chunk, nc), hi = min(lo + chunk, nc);
   uint64_t part = 0;
   if (m != -__builtin_inf())
@@ -584,7 +618,7 @@ __global__ __launch_bounds__(256) void enum_node_big_kernel(const NodeDev nd, co
       part += pclean_fixw(sk - m);
     }
   uint64_t U;
-  const uint64_t pre = block_excl_scan(part, wsum, &U);
+  const uint64_t pre = block_excl_scan<BT / 64>(part, wsum, &U);
   if (tid == 0 && lse_out) lse_out[to] = pclean_lse_from_fix(m, U);
 
   // pass C: draws, located by recomputing the owning lane's chunk
@@ -873,19 +907,31 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
   // the member items), which only the LDS kernel supports, or draws many times per item (one more pass per draw).
   static const size_t big_from = getenv("PCLEAN_BIG_FROM") ? (size_t)atol(getenv("PCLEAN_BIG_FROM")) : (size_t)80 * 1024;
   if (lds > 160 * 1024 || (lds > big_from && !it.grp_off && !scores_out && n_draws <= 1)) {
-    for (int base = 0; base < it.n; base += kMaxBlocks)
-      hipLaunchKernelGGL(enum_node_big_kernel, dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), 0, ctx->stream, nd,
-                         dn, it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out);
+    if (it.n <= 1024) {  // too few workgroups to fill the chip: more threads per item
+      hipLaunchKernelGGL(enum_node_big_kernel<1024>, dim3(it.n), dim3(1024), 0, ctx->stream, nd, dn, it, ch, seed, sweep, site,
+                         n_draws, 0, lse_out, scores_out, draws_out);
+    } else {
+      for (int base = 0; base < it.n; base += kMaxBlocks)
+        hipLaunchKernelGGL(enum_node_big_kernel<256>, dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), 0, ctx->stream, nd,
+                           dn, it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out);
+    }
   } else {
     static bool attr_set = false;
     if (!attr_set) {
-      HIPCHK(ctx, hipFuncSetAttribute((const void*)enum_node_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)enum_node_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024));
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)enum_node_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                       160 * 1024));
       attr_set = true;
     }
-    for (int base = 0; base < it.n; base += kMaxBlocks)
-      hipLaunchKernelGGL(enum_node_kernel, dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), lds, ctx->stream, nd, dn,
-                         it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out);
+    if (it.n <= 1024) {  // (groups or items) too few workgroups to fill the chip: more threads per item
+      hipLaunchKernelGGL(enum_node_kernel<1024>, dim3(it.n), dim3(1024), lds, ctx->stream, nd, dn, it, ch, seed, sweep, site,
+                         n_draws, 0, lse_out, scores_out, draws_out);
+    } else {
+      for (int base = 0; base < it.n; base += kMaxBlocks)
+        hipLaunchKernelGGL(enum_node_kernel<256>, dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), lds, ctx->stream, nd, dn,
+                           it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out);
+    }
   }
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;

@@ -812,7 +812,7 @@ struct SweepState {
   // evidence of the running pclean_sweep_latent call (ensure_agg)
   const int32_t* lat_off = nullptr;      // [lat_items + 1] CSR offsets of the original items into the evidence list
   const int32_t* lat_item_of_pos = nullptr;  // [lat_ev]
-  int lat_items = 0, lat_ev = 0;
+  int lat_items = 0, lat_ev = 0, lat_max_ev = 0;  // (largest evidence set of the call)
   std::map<int, const AggDev*> lat_agg;  // node -> device array [n_terms]
   DevBuf<int32_t> tail_counts;      // [2 * PCLEAN_MAX_BLOCKS] number of moved rows / rows with a new referent
   int32_t* h_counts = nullptr;      // page-locked mirror of tail_counts (+ scratch words)
@@ -1256,7 +1256,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     const pclean_term& tm = b.terms[n.term_begin + i];
     const PairTable& pt = ctx->pair[tm.pair_table];
     if (!pt.valid || tm.dens_kind != PCLEAN_DENS_ADD_TYPOS || pt.elem_bytes != 1) return 0;
-    // evidence sets (ev_leaf_wave_kernel): ctx terms are only ever scored exactly (by candidate_score), any mode goes
+    // evidence sets (ev_leaf_block_kernel): ctx terms are only ever scored exactly (by candidate_score), any mode goes
     if (tm.ctx_slot >= 0 && ((!ev_mode && tm.ctx_mode != 0) || !ctx->fn[tm.fn_table].valid)) return 0;
     if (tm.ctx_slot >= 2) return 0;  // the wave kernel's group descriptor carries two context values
     lmax = std::max(lmax, pt.max_lat_len);
@@ -1436,6 +1436,95 @@ __global__ void agg_off_kernel(int n_items, const uint64_t* __restrict__ uniq, c
 struct AggPack {
   AggDev a[PCLEAN_MAX_TERMS];
 };
+// The same aggregation with one workgroup per (original item, term) when no item has more than AGG_LDS_CAP evidence
+// rows — the sub-batches of a large latent class (a few hundred rows with ~100 referring rows each): the keys of the
+// item's rows are sorted in LDS (bitonic), run-length encoded and written at the item's own offset of the evidence
+// list.  Same runs in the same order as the global sort + run-length encoding below (which costs ~18 launches per
+// term); the scores that walk them are unchanged.
+#define AGG_LDS_CAP 2048
+struct AggTermArgs {
+  const int32_t* obs_col[PCLEAN_MAX_TERMS];
+  int32_t ctx_slot[PCLEAN_MAX_TERMS];
+  uint64_t* uniq[PCLEAN_MAX_TERMS];
+  int32_t* cnt[PCLEAN_MAX_TERMS];
+  int32_t* end[PCLEAN_MAX_TERMS];
+};
+__global__ __launch_bounds__(256) void agg_item_kernel(int n_items, const int32_t* __restrict__ ev_off,
+                                                       const int32_t* __restrict__ ev_rows, const int32_t* __restrict__ ev_ctx,
+                                                       AggTermArgs a) {
+  __shared__ uint64_t s_key[AGG_LDS_CAP];
+  __shared__ int32_t s_run[AGG_LDS_CAP];  // run id of sorted position i, then the run lengths
+  __shared__ int s_w[4];
+  const int t = blockIdx.x, ti = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lo = ev_off[t], L = ev_off[t + 1] - lo;
+  if (L <= 0) {
+    if (tid == 0) a.end[ti][t] = lo;
+    return;
+  }
+  int np2 = 1;
+  while (np2 < L) np2 <<= 1;
+  const int32_t* oc = a.obs_col[ti];
+  const int cs = a.ctx_slot[ti];
+  for (int i = tid; i < np2; i += 256) {
+    uint64_t key = ~0ull;  // padding sorts last
+    if (i < L) {
+      const int e = lo + i;
+      const uint64_t o1 = (uint64_t)(uint32_t)(oc[ev_rows[e]] + 1) & 0xffffffull;
+      const uint64_t c = cs >= 0 ? ((uint64_t)(uint32_t)ev_ctx[(size_t)e * PCLEAN_MAX_CTX + cs] & 0xffffull) : 0ull;
+      key = ((uint64_t)(uint32_t)t << 40) | (c << 24) | o1;
+    }
+    s_key[i] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < np2; i += 256) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const uint64_t x = s_key[i], y = s_key[ixj];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            s_key[i] = y;
+            s_key[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  // run ids: inclusive count of heads over the sorted keys, in chunks of 256 positions
+  int base = 0;
+  for (int i0 = 0; i0 < L; i0 += 256) {
+    const int i = i0 + tid;
+    const int head = (i < L && (i == 0 || s_key[i] != s_key[i - 1])) ? 1 : 0;
+    int incl = head;
+    for (int sh = 1; sh < 64; sh <<= 1) {
+      const int x = __shfl_up(incl, sh, 64);
+      if (lane >= sh) incl += x;
+    }
+    if (lane == 63) s_w[wave] = incl;
+    __syncthreads();
+    int before = base, total = 0;
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) before += s_w[w];
+      total += s_w[w];
+    }
+    if (i < L) s_run[i] = before + incl - 1;
+    base += total;
+    __syncthreads();
+  }
+  const int n_runs = base;
+  // heads write their key; lengths = distance to the next head
+  for (int i = tid; i < L; i += 256) {
+    if (i == 0 || s_key[i] != s_key[i - 1]) {
+      const int r = s_run[i];
+      int j = i + 1;
+      while (j < L && s_key[j] == s_key[i]) ++j;
+      a.uniq[ti][lo + r] = s_key[i];
+      a.cnt[ti][lo + r] = j - i;
+    }
+  }
+  if (tid == 0) a.end[ti][t] = lo + n_runs;
+}
 __global__ void write_agg_kernel(AggPack p, int n, AggDev* dst) {
   const int i = threadIdx.x;
   if (i < n) dst[i] = p.a[i];
@@ -1458,6 +1547,32 @@ static int ensure_agg(pclean_ctx* ctx, int block_id, int node_id, const ItemList
   AggPack pack{};
   AggDev* dst = (AggDev*)scratch<unsigned char>(ctx, sizeof(AggDev) * PCLEAN_MAX_TERMS);
   if (!dst) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  static const bool no_item_agg = getenv("PCLEAN_NO_ITEM_AGG") != nullptr;
+  if (n_ev > 0 && s->lat_max_ev <= AGG_LDS_CAP && n.n_terms <= PCLEAN_MAX_TERMS && !no_item_agg) {
+    AggTermArgs at{};
+    for (int ti = 0; ti < n.n_terms; ++ti) {
+      const pclean_term& tm = b.terms[n.term_begin + ti];
+      const PairTable& pt = ctx->pair[tm.pair_table];
+      if (tm.obs_col < 0 || tm.obs_col >= ctx->n_cols) return pclean_fail(ctx, PCLEAN_ERR_ARG, "term column out of range");
+      if (pt.valid && pt.n_obs + 1 >= (1 << 24)) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "observed domain too large for the evidence keys");
+      const int ctx_slot = (tm.ctx_slot >= 0 && tm.ctx_mode != 0) ? tm.ctx_slot : -1;
+      if (ctx_slot >= 0 && !il.ev_ctx) return pclean_fail(ctx, PCLEAN_ERR_ARG, "term %d needs per-evidence-row ctx", n.term_begin + ti);
+      at.obs_col[ti] = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows;
+      at.ctx_slot[ti] = ctx_slot;
+      at.uniq[ti] = scratch<uint64_t>(ctx, (size_t)n_ev);
+      at.cnt[ti] = scratch<int32_t>(ctx, (size_t)n_ev);
+      at.end[ti] = scratch<int32_t>(ctx, (size_t)n_items);
+      if (!at.uniq[ti] || !at.cnt[ti] || !at.end[ti]) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      pack.a[ti] = AggDev{at.uniq[ti], at.cnt[ti], s->lat_off, at.end[ti]};
+    }
+    hipLaunchKernelGGL(agg_item_kernel, dim3(n_items, n.n_terms), dim3(256), 0, ctx->stream, n_items, s->lat_off, il.ev_rows,
+                       il.ev_ctx, at);
+    hipLaunchKernelGGL(write_agg_kernel, dim3(1), dim3(64), 0, ctx->stream, pack, n.n_terms, dst);
+    HIPCHK(ctx, hipGetLastError());
+    s->lat_agg[node_id] = dst;
+    *out = dst;
+    return PCLEAN_OK;
+  }
   for (int ti = 0; ti < n.n_terms; ++ti) {
     const pclean_term& tm = b.terms[n.term_begin + ti];
     const PairTable& pt = ctx->pair[tm.pair_table];
@@ -1486,7 +1601,7 @@ static int ensure_agg(pclean_ctx* ctx, int block_id, int node_id, const ItemList
       HIPCHK(ctx, hipcub::DeviceRunLengthEncode::Encode(tmp, tmp_rle, key_s, uniq, cnt, n_runs, n_ev, ctx->stream));
     }
     hipLaunchKernelGGL(agg_off_kernel, grid1((size_t)n_items + 1), dim3(256), 0, ctx->stream, n_items, uniq, n_runs, off);
-    pack.a[ti] = AggDev{uniq, cnt, off};
+    pack.a[ti] = AggDev{uniq, cnt, off, nullptr};
   }
   hipLaunchKernelGGL(write_agg_kernel, dim3(1), dim3(64), 0, ctx->stream, pack, n.n_terms, dst);
   HIPCHK(ctx, hipGetLastError());
@@ -2575,6 +2690,8 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   s->lat_item_of_pos = d_iop;
   s->lat_items = n_items;
   s->lat_ev = n_ev;
+  s->lat_max_ev = 0;
+  for (int t = 0; t < n_items; ++t) s->lat_max_ev = std::max(s->lat_max_ev, ev_off[t + 1] - ev_off[t]);
   s->lat_agg.clear();
   if (!cfg->use_dd_proposals) {
     // Prior proposals (block_proposal.jl:168): particle 0 keeps the row's current values (excl[r][t]: current referent

@@ -428,7 +428,16 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
     t = trace.tables[cname]
     changed = 0
     prev = 0
-    for bn, (b0, b1) in enumerate(sub_batches(len(live), config, max_sub_batches, batch_rows)):
+    # A latent class WITHOUT learned parameters is swept in one batch: the only thing the reference resamples every
+    # rejuv_frequency rows of it are its table's Pitman-Yor hyper-parameters, whose conditional (reference counts of
+    # the table, number of rows) no update of the class's own rows touches — those moves commute with the row
+    # updates and are made, as many as the cut schedule would make, after the batch.
+    learned = trace.has_learned_parameters(cname)
+    deferred_moves = 0
+    if not learned and not batch_rows:
+        cut = sub_batches(len(live), config, max_sub_batches)
+        deferred_moves = sum(1 for i in range(1, len(cut)) if _crosses_rejuv(cut[i - 1][0], cut[i][0], config))
+    for bn, (b0, b1) in enumerate(sub_batches(len(live), config, max_sub_batches, batch_rows, has_parameters=learned)):
         if bn and _crosses_rejuv(prev, b0, config):  # inference.jl:72-77: this class's parameters and PY hyper-parameters
             prev = b0
             resample_class_parameters(trace, cname)
@@ -458,6 +467,8 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
                 # placeholders became drawn strings: per-evidence-row ctx values may have held a dummy's id
                 live2, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname)
                 assert np.array_equal(live2, live)
+    for _ in range(deferred_moves):
+        resample_class_parameters(trace, cname)
     return changed
 
 

@@ -554,6 +554,15 @@ class Trace:
                 or (self.prob_param is not None and self.lw.prob_spec["param"][0] == cname)
                 or (self.mean_param is not None and self.lw.gauss_spec["param"][0] == cname))
 
+    def has_learned_parameters(self, cname):
+        """True when class cname declares a learned parameter (its value depends on the rows of the class, so the move
+        of inference.jl:72-77 has to interleave with the row updates).  A class whose only "parameters" are its table's
+        Pitman-Yor hyper-parameters is different: their conditional depends on the table's reference counts alone, and
+        a sweep of the class's OWN rows changes neither those counts nor the set of rows."""
+        return (any(c == cname for c, _ in self.params)
+                or (self.prob_param is not None and self.lw.prob_spec["param"][0] == cname)
+                or (self.mean_param is not None and self.lw.gauss_spec["param"][0] == cname))
+
     def resample_parameters(self, cname=None):
         """resample_value! of every learned parameter (cname=None: initialize_trace, inference.jl:40-47) or
         of the parameters declared in class cname (pgibbs_sweep!, inference.jl:72-77)."""
@@ -567,22 +576,32 @@ class Trace:
             self.mean_param.resample(self.rng, idx, x)
 
     @staticmethod
+    def _py_prepare(counts):
+        """The count-only pieces of pitman_yor_score (shared by the three evaluations of one hyper-parameter move)."""
+        counts = np.asarray(counts, dtype=np.float64)
+        n_obj = np.arange(1, counts.size + 1, dtype=np.float64)
+        before = np.concatenate([[0.0], np.cumsum(counts)[:-1]])
+        big = counts > 1
+        c, b = counts[big], before[big]
+        return counts.size, n_obj, before, c, b
+
+    @staticmethod
+    def _py_score_prepared(strength, discount, prep):
+        from scipy.special import gammaln
+        size, n_obj, before, c, b = prep
+        if size == 0:
+            return 0.0
+        lp = np.sum(np.log(n_obj * discount + strength) - np.log(before + strength))
+        lp += np.sum(gammaln(c - discount) - gammaln(1.0 - discount))
+        lp -= np.sum(gammaln(b + c + strength) - gammaln(b + 1.0 + strength))
+        return float(lp)
+
+    @staticmethod
     def pitman_yor_score(strength, discount, counts):
         """trace.jl:65-78, vectorised (O(K)): counts in table order (cluster j is the j-th object).  The joins of
         a cluster of size c that started after `before` customers, sum_{i=1}^{c-1} log(i - d) - log(before + i + s),
         are written with log-gamma differences."""
-        from scipy.special import gammaln
-        counts = np.asarray(counts, dtype=np.float64)
-        if counts.size == 0:
-            return 0.0
-        n_obj = np.arange(1, counts.size + 1, dtype=np.float64)
-        before = np.concatenate([[0.0], np.cumsum(counts)[:-1]])
-        lp = np.sum(np.log(n_obj * discount + strength) - np.log(before + strength))
-        big = counts > 1
-        c, b = counts[big], before[big]
-        lp += np.sum(gammaln(c - discount) - gammaln(1.0 - discount))
-        lp -= np.sum(gammaln(b + c + strength) - gammaln(b + 1.0 + strength))
-        return float(lp)
+        return Trace._py_score_prepared(strength, discount, Trace._py_prepare(counts))
 
     def resample_py_params(self, t):
         """resample_py_params! (trace.jl:80-108): independence MH on strength ~ Gamma(1,1) and
@@ -590,15 +609,16 @@ class Trace:
         counts = t.counts[:t.n][t.counts[:t.n] > 0]
         if counts.size == 0:
             return
-        old = self.pitman_yor_score(t.strength, t.discount, counts)
+        prep = self._py_prepare(counts)
+        old = self._py_score_prepared(t.strength, t.discount, prep)
         s_new = self.rng.gamma(1.0, 1.0)
-        new = self.pitman_yor_score(s_new, t.discount, counts)
+        new = self._py_score_prepared(s_new, t.discount, prep)
         # logpdf(Gamma(1,1), x) = -x
         alpha = new + (-t.strength) - old - (-s_new)
         if np.log(self.rng.random()) < alpha:
             t.strength, old = s_new, new
         d_new = self.rng.random()
-        new = self.pitman_yor_score(t.strength, d_new, counts)
+        new = self._py_score_prepared(t.strength, d_new, prep)
         if np.log(self.rng.random()) < new - old:
             t.discount = d_new
 
