@@ -407,6 +407,24 @@ class HipContext:
             _p(lse, C.c_double), _p(scores, C.c_double), _p(draws, C.c_int32)), "pclean_score_node")
         return lse, scores, draws
 
+    def score_node_ev(self, block_id, node_id, keys, ev_off, ev_rows, ev_ctx=None, excl=None, seed=0, sweep=0, n_draws=0,
+                      n_cand=None, want_scores=False):
+        """pclean_score_node_ev: one node of a latent plan for latent rows `keys` against their evidence sets."""
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        n = len(keys)
+        ev_off = np.ascontiguousarray(ev_off, dtype=np.int32)
+        ev_rows = np.ascontiguousarray(ev_rows, dtype=np.int32)
+        ev_ctx = _ctx_cols(ev_ctx)
+        excl = None if excl is None else np.ascontiguousarray(excl, dtype=np.int32)
+        lse = np.empty(n, dtype=np.float64)
+        scores = np.empty((n, n_cand), dtype=np.float64) if want_scores else None
+        draws = np.empty(n, dtype=np.int32) if n_draws else None
+        check(self.h, self.lib.pclean_score_node_ev(
+            self.h, C.c_int32(block_id), C.c_int32(node_id), C.c_int32(n), _p(keys, C.c_int32), _p(ev_off, C.c_int32),
+            _p(ev_rows, C.c_int32), _p(ev_ctx, C.c_int32), _p(excl, C.c_int32), C.c_uint64(seed), C.c_uint32(sweep),
+            C.c_int32(n_draws), _p(lse, C.c_double), _p(scores, C.c_double), _p(draws, C.c_int32)), "pclean_score_node_ev")
+        return lse, scores, draws
+
     def pinned_empty(self, shape, dtype):
         """numpy array whose buffer is page-locked for this context (released with the context)."""
         a = np.empty(shape, dtype=dtype)

@@ -2935,6 +2935,66 @@ extern "C" int pclean_score_node(pclean_ctx* ctx, int32_t block_id, int32_t node
   return finish_call(ctx);
 }
 
+// pclean_score_node for EVIDENCE SETS: item t is a latent row scored against the observed rows
+// ev_rows[ev_off[t] .. ev_off[t + 1]) (with their per-row ctx) — one plan node of a latent class's plan, as
+// pclean_sweep_latent evaluates it (same aggregation, same kernels), with the per-candidate scores returned.
+extern "C" int pclean_score_node_ev(pclean_ctx* ctx, int32_t block_id, int32_t node_id, int32_t n_items,
+                                    const int32_t* keys, const int32_t* ev_off, const int32_t* ev_rows,
+                                    const int32_t* ev_ctx, const int32_t* excl, uint64_t seed, uint32_t sweep,
+                                    int32_t n_draws, double* lse, double* scores, int32_t* draws) {
+  if (!ctx || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid || n_items <= 0 || !keys ||
+      !ev_off || n_draws < 0 || n_draws > 1 || (n_draws > 0 && !draws))
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_score_node_ev: bad arguments");
+  Block& b = ctx->block[block_id];
+  if (node_id < 0 || node_id >= (int)b.nodes.size()) return pclean_fail(ctx, PCLEAN_ERR_ARG, "bad node id");
+  const int n_ev = ev_off[n_items];
+  if (n_ev < 0 || (n_ev > 0 && !ev_rows)) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_score_node_ev: evidence rows missing");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  {
+    const int rcb = begin_call(ctx);
+    if (rcb) return rcb;
+  }
+  SweepState* s = st(ctx);
+  const pclean_node& n = b.nodes[node_id];
+  const CandTable& t = ctx->cand[n.table];
+  const int nc = t.n_rows + (n.kind == PCLEAN_NODE_FK ? 1 : 0);
+  int32_t* d_keys = scratch<int32_t>(ctx, n_items);
+  int32_t* d_off = scratch<int32_t>(ctx, (size_t)n_items + 1);
+  int32_t* d_evr = scratch<int32_t>(ctx, std::max(n_ev, 1));
+  int32_t* d_evc = ev_ctx ? scratch<int32_t>(ctx, (size_t)std::max(n_ev, 1) * PCLEAN_MAX_CTX) : nullptr;
+  int32_t* d_iop = scratch<int32_t>(ctx, std::max(n_ev, 1));
+  int32_t* d_excl = excl ? scratch<int32_t>(ctx, n_items) : nullptr;
+  double* d_lse = scratch<double>(ctx, n_items);
+  double* d_scores = scores ? scratch<double>(ctx, (size_t)n_items * nc) : nullptr;
+  int32_t* d_draws = n_draws ? scratch<int32_t>(ctx, n_items) : nullptr;
+  if (!d_keys || !d_off || !d_evr || (ev_ctx && !d_evc) || !d_iop || (excl && !d_excl) || !d_lse || (scores && !d_scores) ||
+      (n_draws && !d_draws))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  HIPCHK(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n_items * 4, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(d_off, ev_off, ((size_t)n_items + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n_ev) HIPCHK(ctx, hipMemcpyAsync(d_evr, ev_rows, (size_t)n_ev * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (ev_ctx && n_ev)
+    HIPCHK(ctx, hipMemcpyAsync(d_evc, ev_ctx, (size_t)n_ev * PCLEAN_MAX_CTX * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (excl) HIPCHK(ctx, hipMemcpyAsync(d_excl, excl, (size_t)n_items * 4, hipMemcpyHostToDevice, ctx->stream));
+  if (n_ev) hipLaunchKernelGGL(item_of_pos_kernel, grid1(n_ev), dim3(256), 0, ctx->stream, n_ev, n_items, d_off, d_iop);
+  s->lat_off = d_off;
+  s->lat_item_of_pos = d_iop;
+  s->lat_items = n_items;
+  s->lat_ev = n_ev;
+  s->lat_max_ev = 0;
+  for (int i = 0; i < n_items; ++i) s->lat_max_ev = std::max(s->lat_max_ev, ev_off[i + 1] - ev_off[i]);
+  s->lat_agg.clear();
+  ItemList il{n_items, nullptr, nullptr, nullptr, nullptr, d_off, d_off + 1, d_evr, d_evc, d_keys};
+  int rc = eval_node(ctx, block_id, node_id, il, d_excl, seed, sweep, n_draws, d_lse, d_draws, d_scores, nullptr, false);
+  s->lat_agg.clear();
+  if (rc) return rc;
+  if (lse) HIPCHK(ctx, hipMemcpyAsync(lse, d_lse, (size_t)n_items * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (scores) HIPCHK(ctx, hipMemcpyAsync(scores, d_scores, (size_t)n_items * nc * 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (n_draws) HIPCHK(ctx, hipMemcpyAsync(draws, d_draws, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return finish_call(ctx);
+}
+
 // Can a particle of this sweep draw the ProposalDummyValue of some option list of block bi?  Cacheable lists know it
 // per observed value (ensure_leaf_cache: weight of the dummy option); any other list with a dummy is assumed to.
 static int block_dummy_drawable(pclean_ctx* ctx, int bi, bool* out) {
