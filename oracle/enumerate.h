@@ -87,6 +87,11 @@ struct World {
   std::vector<int64_t> off;
   std::vector<double> lm_init, lm_trans; /* [28], [28*28] ([prev][next]) */
   std::vector<uint16_t> letter_sym;      /* [28] pool symbol of every alphabet letter, 0xFFFF = absent */
+  /* evidence sets added ROW BY ROW (every term of an evidence row, then the next row): the reference's own order of
+   * operations (one ExternalLikelihoodNode per referring row, proposal_compiler.jl:306-350).  Off: the aggregated
+   * order the HIP path uses (per term, distinct (ctx, observed value) pairs x multiplicity).  A CPU test holds the
+   * two within 1e-9 of each other (tests/test_literal_fixtures.py). */
+  bool ev_row_by_row = false;
   World() : mean(64), pair(64), table(64), fn(64), block(16) {}
 };
 
@@ -212,6 +217,51 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
   if (mode == SCORE_PRIOR) return;
   const pclean_gauss* gs = (node_id < (int)b.node_gauss.size() && b.node_gauss[node_id] >= 0)
                                ? &b.gauss[b.node_gauss[node_id]] : nullptr;
+  if (ev && w.ev_row_by_row) {
+    for (int e = 0; e < ev->n; ++e) {
+      const int er = ev->rows[e];
+      const int32_t* ecx = ev->ctx ? ev->ctx + (size_t)e * PCLEAN_MAX_CTX : nullptr;
+      for (int ti = 0; ti < nd.n_terms; ++ti) {
+        const pclean_term& tm = b.terms[nd.term_begin + ti];
+        const int o = w.obs[(size_t)tm.obs_col * w.n_rows + er];
+        const bool ev_ctx_term = tm.ctx_slot >= 0 && tm.ctx_mode != 0;
+        const int ec = ev_ctx_term ? ecx[tm.ctx_slot] : 0;
+        for (int k = 0; k < n; ++k) {
+          if (fk && t.counts[k] == 0) continue;
+          if (tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP) {
+            const OPair& ptm = w.pair[tm.pair_table];
+            const int v2 = t.cols[(size_t)tm.cand_col * n + k];
+            const int c = tm.ctx_mode == 0 ? ctxv[tm.ctx_slot] : ec;
+            const bool same = o >= 0 && ptm.d[(size_t)o * ptm.n_lat + v2] == 0;
+            out[k] += maybe_swap_term(w, o < 0, same, v2 < tm.fn_table, t.cols[(size_t)tm.max_typos * n + k], c);
+            continue;
+          }
+          if (o < 0) continue;
+          const OPair& pt = w.pair[tm.pair_table];
+          int val = t.cols[(size_t)tm.cand_col * n + k];
+          if (tm.ctx_slot >= 0) {
+            const OFn& f = w.fn[tm.fn_table];
+            const int c = tm.ctx_mode == 0 ? ctxv[tm.ctx_slot] : ec;
+            val = tm.ctx_mode == 2 ? f.fn[(size_t)val * f.n_b + c] : f.fn[(size_t)c * f.n_b + val];
+          }
+          out[k] += term_density(w, tm, pt, pt.d[(size_t)o * pt.n_lat + val], val);
+        }
+      }
+      if (gs && w.xnum[(size_t)gs->x_col * w.n_rows + er] == w.xnum[(size_t)gs->x_col * w.n_rows + er])
+        for (int k = 0; k < n; ++k) {
+          if ((fk && t.counts[k] == 0) || !(out[k] > NEG_INF)) continue;
+          out[k] += gauss_lse(gauss_combo_scores(w, *gs, er, ecx, [&](int d) -> int {
+            switch (gs->src_kind[d]) {
+              case PCLEAN_GSRC_CAND: return t.cols[(size_t)gs->src[d] * n + k];
+              case PCLEAN_GSRC_OBS: return w.obs[(size_t)gs->src[d] * w.n_rows + er];
+              case PCLEAN_GSRC_ITEMCTX: return ctxv[gs->src[d]];
+              default: return ecx[gs->src[d]];
+            }
+          }));
+        }
+    }
+    return;
+  }
   if (ev) {
     /* Evidence sets: terms in plan order; per term the distinct (ctx value, observed value) pairs of the
      * evidence rows in ascending order (missing observation = -1 first), each adding multiplicity x density;

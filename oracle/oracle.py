@@ -263,6 +263,10 @@ class World:
         lat_len = np.ascontiguousarray(lat_len, np.uint16)
         self.L.pco_world_set_pair(self.h, pid, d.shape[0], d.shape[1], _p(d, C.c_uint16), _p(lat_len, C.c_uint16))
 
+    def set_ev_row_by_row(self, on):
+        """evidence sets summed row by row (the reference's order) instead of aggregated per term"""
+        self.L.pco_world_set_ev_row_by_row(self.h, int(bool(on)))
+
     def set_block_group(self, block_id, group):
         self.L.pco_world_set_block_group(self.h, int(block_id), int(group))
 

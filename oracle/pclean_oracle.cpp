@@ -141,6 +141,7 @@ void pco_world_set_options(pco::World* w, int id, int n, const int32_t* values, 
   t.logc_m1.clear();
 }
 void pco_world_set_block_group(pco::World* w, int id, int group) { w->block[id].group = group; }
+void pco_world_set_ev_row_by_row(pco::World* w, int on) { w->ev_row_by_row = on != 0; }
 void pco_world_set_fn(pco::World* w, int id, int n_a, int n_b, const int32_t* fn) {
   pco::OFn& f = w->fn[id];
   f.n_a = n_a;
