@@ -111,6 +111,19 @@ def hbm_traffic(args, world):
         return None, None
 
 
+def step_traffic(args, world):
+    """HBM bytes of one WHOLE sweep (every kernel of the step) from the committed all-kernel PMC passes
+    (profiles/step_traffic.py -> profiles/hbm_traffic.json "step"); null off the measured configuration."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get("step")
+        if not d or d.get("rows") != args.rows or d.get("hospitals") != args.hospitals or d.get("particles") != args.particles \
+                or world != 1:
+            return None
+        return d
+    except Exception:
+        return None
+
+
 def roofline_model(rs, obs_local, particles):
     """Algorithmic bytes of ONE launch of the root scan as implemented (root_wave.hip), each byte counted once:
       * the byte rows comp_f[o][.] of the pre-filter terms: one row of kpad bytes per DISTINCT observed value
@@ -319,6 +332,13 @@ def main():
         per_launch_s = 1e-3 * hot_ms / max(hot_launches, 1)
         achieved = (alg_bytes / per_launch_s / 1e9) if (alg_bytes and per_launch_s > 0) else None
         traffic, traffic_src = hbm_traffic(args, world)
+        st = step_traffic(args, world)
+        step_model = None
+        if st:  # the whole step against the HBM roof: counter bytes of every kernel of a sweep / this run's device time
+            dev_s = 1e-3 * dev_ms / args.steps
+            step_model = {"hbm_bytes_per_step": st["hbm_bytes_per_step"], "device_ms_per_step": 1e3 * dev_s,
+                          "GBps": st["hbm_bytes_per_step"] / dev_s / 1e9, "frac_of_hbm_peak": st["hbm_bytes_per_step"] / dev_s / 8e12,
+                          "dispatches_per_step": st.get("dispatches"), "source": st.get("source")}
         out = {
             "metric": "rows/sec per Gibbs sweep on 1M-row synthetic hospital; F1 vs ground truth",
             "value": value, "unit": "rows/s/sweep", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -344,6 +364,7 @@ def main():
                          "kernel": "group_desc_kernel + fk_root_wave_kernel<12> (block 0 root: rows x candidate hospitals)",
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": 1e3 * per_launch_s,
                          "groups": rs.n_groups, "items": rs.n_items, "kpad": rs.kpad, "overflow_items": rs.overflow_items,
+                         "step": step_model,
                          "enumeration_equivalent": {"bytes_per_launch": enum_bytes / max(hot_launches, 1),
                                                     "GBps": enum_bytes / max(hot_launches, 1) / max(per_launch_s, 1e-12) / 1e9,
                                                     "note": "SURVEY §8d full-enumeration bytes (920 296 B/row) / kernel time: "

@@ -28,6 +28,12 @@ pass WRITE WRITE_SIZE
 pass SQ SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_WAIT_INST_ANY
 pass SQ2 SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS
 pass TCC TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum
+# whole-step traffic: the same two counters over EVERY kernel (no include filter), fewer sweeps
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_all_$C" -- python "$ROOT/bench.py" --steps 2 --warmup 1 \
+    --no-cpu-baseline > "$OUT/bench_all_$C.json" 2> "$OUT/bench_all_$C.log"
+  echo "all $C rc=$?"
+done
 if [ -x "$ROOT/profiles/calib/fetch_calib" ]; then
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_calib" -- "$ROOT/profiles/calib/fetch_calib" \
     > "$OUT/calib.log" 2>&1
@@ -39,6 +45,8 @@ python profiles/summarize_rocpd.py "$T" "$OUT/kernel_trace.txt" > /dev/null
 python profiles/timeline.py "$T" 15 1 > "$OUT/sweep_timeline.txt" 2>&1
 python profiles/summarize_pmc_top.py $(find "$OUT"/pmc_FETCH "$OUT"/pmc_WRITE "$OUT"/pmc_SQ "$OUT"/pmc_SQ2 "$OUT"/pmc_TCC -name "*.db") \
   --top 12 --source "profiles/${TAG}_pmc_root_kernels.txt" --json "$OUT/hbm_traffic.json" > "$OUT/pmc_root_kernels.txt" 2>&1
+python profiles/step_traffic.py $(find "$OUT"/pmc_all_FETCH_SIZE -name "*.db" | head -1) $(find "$OUT"/pmc_all_WRITE_SIZE -name "*.db" | head -1) \
+  --json "$OUT/hbm_traffic.json" > "$OUT/step_traffic.txt" 2>&1
 [ -d "$OUT/pmc_calib" ] && python profiles/summarize_pmc_top.py $(find "$OUT"/pmc_calib -name "*.db") --top 8 > "$OUT/fetch_calibration.txt" 2>&1
 find "$OUT" -name "*.db" -delete
 tail -n 3 "$OUT/bench_trace.log"
