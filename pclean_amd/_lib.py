@@ -221,6 +221,9 @@ class HipContext:
         check(self.h, self.lib.pclean_debug_root_flags(self.h, C.c_int32(n_rows), _p(out, C.c_int32)), "pclean_debug_root_flags")
         return out
 
+    def global_evidence_sort(self, on):
+        check(self.h, self.lib.pclean_debug_global_evidence_sort(self.h, C.c_int32(int(on))), "pclean_debug_global_evidence_sort")
+
     def force_generic(self, on):
         check(self.h, self.lib.pclean_debug_force_generic(self.h, C.c_int32(int(on))), "pclean_debug_force_generic")
 

@@ -163,6 +163,7 @@ struct pclean_ctx {
   int32_t active_begin = 0, active_count = -1;  // pclean_set_active_rows window (-1 = all rows)
   bool prior_mode = false;     // sweep.hip: the running sweep proposes from the priors (use_dd_proposals = false)
   bool force_generic = false;  // debug: never take the compact-table root kernel
+  bool no_item_agg = false;    // debug: aggregate evidence with the global sort + run-length encoding only
   void* sweep_state = nullptr;  // owned by sweep.hip
   void* rccl_comm = nullptr;    // ncclComm_t of pclean_comm_init (comm.hip)
   DevBuf<int64_t> stats_pack;   // pclean_allreduce_stats_fused: the tables' delta counts as one vector

@@ -1547,8 +1547,7 @@ static int ensure_agg(pclean_ctx* ctx, int block_id, int node_id, const ItemList
   AggPack pack{};
   AggDev* dst = (AggDev*)scratch<unsigned char>(ctx, sizeof(AggDev) * PCLEAN_MAX_TERMS);
   if (!dst) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-  static const bool no_item_agg = getenv("PCLEAN_NO_ITEM_AGG") != nullptr;
-  if (n_ev > 0 && s->lat_max_ev <= AGG_LDS_CAP && n.n_terms <= PCLEAN_MAX_TERMS && !no_item_agg) {
+  if (n_ev > 0 && s->lat_max_ev <= AGG_LDS_CAP && n.n_terms <= PCLEAN_MAX_TERMS && !ctx->no_item_agg) {
     AggTermArgs at{};
     for (int ti = 0; ti < n.n_terms; ++ti) {
       const pclean_term& tm = b.terms[n.term_begin + ti];
@@ -2877,6 +2876,12 @@ extern "C" int pclean_debug_root_flags(pclean_ctx* ctx, int32_t n_rows, int32_t*
   d.release();
   if (rc) return rc;
   if (e != hipSuccess) return pclean_fail(ctx, PCLEAN_ERR_HIP, "pclean_debug_root_flags: %s", hipGetErrorString(e));
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_debug_global_evidence_sort(pclean_ctx* ctx, int32_t on) {
+  if (!ctx) return PCLEAN_ERR_ARG;
+  ctx->no_item_agg = on != 0;
   return PCLEAN_OK;
 }
 

@@ -232,3 +232,45 @@ def test_new_branch_gate_light_outputs_and_profile(oracle):
         assert np.array_equal(ch, a[0][bi][rows])
         assert np.array_equal(rows, moved_l[bi][0]) and np.array_equal(ch, moved_l[bi][1])
     assert prof and sum(v[0] for v in prof.values()) > 0 and "final_choice_and_outputs" in prof
+
+
+def test_evidence_aggregation_paths_at_the_lds_capacity(oracle):
+    """Latent sweeps of a 1 800-row synthetic table: HospitalType's single row is referred to by every observed row
+    (1 800 evidence rows: the per-row LDS aggregation pads them to its 2 048-key capacity), Condition's rows by
+    hundreds.  The LDS aggregation and the global radix sort + run-length encoding must give the same sweep, and
+    both the oracle's."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from pclean_amd.inference import build_evidence, initialize_trace, latent_current_choices
+    dirty, clean, lw, obs = bench.build_workload(1800, 20, 5)
+    eng = Engine(lw, obs, dist_mode=0)
+    try:
+        cfg = InferenceConfig(1, 4)
+        tr = Trace(lw, obs.shape[1], 5)
+        initialize_trace(eng, tr, cfg, 5)
+        seen_big = False
+        for cname in lw.model.class_order:
+            if cname not in lw.latent_plans:
+                continue
+            pl = lw.latent_plans[cname]
+            live, ev_off, ev_rows, ev_ctx = build_evidence(lw, tr, cname)
+            longest = int(np.max(np.diff(ev_off)))
+            excl = latent_current_choices(lw, tr, cname, live, cfg)
+            eng.upload_trace(tr)
+            eng.hip.set_active_rows(0, -1)
+            args = (cfg.as_c(), 11, 0, pl["block_id"], pl["roots"], live, ev_off, ev_rows, ev_ctx, excl, len(pl["nodes"]))
+            a = eng.hip.sweep_latent(*args)
+            eng.hip.global_evidence_sort(True)
+            b = eng.hip.sweep_latent(*args)
+            eng.hip.global_evidence_sort(False)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), cname
+            if 1024 < longest <= 2048:
+                seen_big = True
+                world = helpers.mirror_world(oracle, lw, obs, tr, eng)
+                want = world.sweep_latent(InferConfig(1, 4, 1, 1, 0, 50, 100), 11, 0, pl["block_id"], pl["roots"], live, ev_off,
+                                          ev_rows, ev_ctx, excl, len(pl["nodes"]))
+                assert np.array_equal(a[0], want[0]) and np.array_equal(a[1], want[1]), cname
+        assert seen_big  # some class had an evidence set between 1 025 and 2 048 rows
+    finally:
+        eng.close()

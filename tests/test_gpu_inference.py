@@ -43,6 +43,13 @@ def test_latent_sweep_parity(oracle, particles, mh, dd):
                 world = helpers.mirror_world(oracle, lw, obs, tr, eng)
                 got = eng.hip.sweep_latent(cfg.as_c(), 9, sweep, pl["block_id"], pl["roots"], live, ev_off, ev_rows,
                                            ev_ctx, excl, len(pl["nodes"]))
+                # the other evidence aggregation (global radix sort + run-length encoding: what evidence sets of more
+                # than 2048 rows take) gives the same runs, hence the same result
+                eng.hip.global_evidence_sort(True)
+                got2 = eng.hip.sweep_latent(cfg.as_c(), 9, sweep, pl["block_id"], pl["roots"], live, ev_off, ev_rows,
+                                            ev_ctx, excl, len(pl["nodes"]))
+                eng.hip.global_evidence_sort(False)
+                assert np.array_equal(got[0], got2[0]) and np.array_equal(got[1], got2[1]), (cname, "aggregation paths")
                 c = InferConfig(1, particles, int(dd), 1, int(mh), 50, 100)
                 want = world.sweep_latent(c, 9, sweep, pl["block_id"], pl["roots"], live, ev_off, ev_rows, ev_ctx, excl,
                                           len(pl["nodes"]))
