@@ -456,7 +456,10 @@ __global__ void maybe_resample_kernel(int n_rows, int P, const double* logw, siz
 
 // apply ancestors: particle-major int32 arrays and weights (clone_with_zero_weight, 17-21); the log-ML
 // increment of the resampling step is accumulated here as well
-__global__ void apply_ancestors_kernel(int n_rows, int P, const int32_t* ancestors, int n_arrays, int32_t** arrays,
+struct AncestorArrays {  // the particle-major arrays a resampling step permutes, by value (no upload, no synchronisation)
+  int32_t* p[2 * PCLEAN_MAX_BLOCKS];
+};
+__global__ void apply_ancestors_kernel(int n_rows, int P, const int32_t* ancestors, int n_arrays, AncestorArrays arrays,
                                        double* w, const int32_t* did, const double* logml_inc, double* logml_acc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows) return;
@@ -464,7 +467,7 @@ __global__ void apply_ancestors_kernel(int n_rows, int P, const int32_t* ancesto
   if (!did[i]) return;
   int32_t tmp[MAXP];
   for (int a = 0; a < n_arrays; ++a) {
-    int32_t* arr = arrays[a] + i;
+    int32_t* arr = arrays.p[a] + i;
     for (int p = 0; p < P; ++p) tmp[p] = arr[(size_t)ancestors[(size_t)p * n_rows + i] * n_rows];
     for (int p = 0; p < P; ++p) arr[(size_t)p * n_rows] = tmp[p];
   }
@@ -3458,17 +3461,15 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
                                           (size_t)1, (size_t)N, 1, cur_b, seed, sweep_idx, (uint32_t)bi,
                                           s->row_offset + ctx->active_begin, s->ancestors.p, s->logml_inc.p,
                                           (double*)nullptr, s->did.p));
-      std::vector<int32_t*> ptrs;
+      AncestorArrays arrs{};
+      int n_arr = 0;
       for (int k = 0; k <= bi; ++k) {
         if (ctx->block[k].is_score) continue;
-        ptrs.push_back(s->run[k].pchoice.p);
-        ptrs.push_back(s->run[k].pnewpos.p);
+        arrs.p[n_arr++] = s->run[k].pchoice.p;
+        arrs.p[n_arr++] = s->run[k].pnewpos.p;
       }
-      HIPCHK(ctx, hipMemcpyAsync(s->arr_ptrs.p, ptrs.data(), ptrs.size() * sizeof(void*), hipMemcpyHostToDevice,
-                                 ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // ptrs goes out of scope
-      hipLaunchKernelGGL(apply_ancestors_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->ancestors.p,
-                         (int)ptrs.size(), s->arr_ptrs.p, s->w.p, s->did.p, s->logml_inc.p, s->logml_acc.p);
+      hipLaunchKernelGGL(apply_ancestors_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->ancestors.p, n_arr, arrs, s->w.p,
+                         s->did.p, s->logml_inc.p, s->logml_acc.p);
     }
   }
 
