@@ -750,6 +750,26 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
       // ---- draws of every (member item, draw) pair of the group ------------------------------------------------------
       if (n_draws > 0) {
         const int res_new = fr.is_leaf ? fr.n_cand - 1 : PCLEAN_CHOICE_NEW;
+        // A DECIDED group: the total is exactly one unit (PCLEAN_FIX_ONE) — the maximum's own weight — so every other
+        // entry has fixed-point weight 0 and every draw, whatever its random number (x < U), returns the first entry
+        // with a non-zero prefix.  No Philox, no multiply-high, no per-lane search, no RNG attributes: most groups
+        // (the rows whose referent explains them 28.5 nats better than anything else) are of this kind.
+        const bool decided = U == PCLEAN_FIX_ONE;
+#ifdef WAVE_PHASE_CLOCK
+        cnt_acc[3] += decided ? 1 : 0;
+#endif
+        int dec_res = res_new;
+        if (decided) {
+          int a = 0, b = ns;  // wave-uniform: smallest index with a non-zero prefix
+          while (a < b) {
+            const int mid = (a + b) >> 1;
+            if (pref[mid] > 0ull)
+              b = mid;
+            else
+              a = mid + 1;
+          }
+          if (a < ns) dec_res = ksv[a];
+        }
         auto finish_draw = [&](int w0, int w1, int w2, int w3, int j) {
           int32_t res = res_new;
           if (U != 0) {
@@ -768,22 +788,24 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
           }
           draws_out[(size_t)w3 * draw_is + (size_t)j * draw_ds] = res;
         };
+        auto one_output = [&](int tm, int j) {
+          if (decided) {
+            const int op = wi.out_pos ? wi.out_pos[tm] : tm;
+            draws_out[(size_t)op * draw_is + (size_t)j * draw_ds] = dec_res;
+          } else {
+            int w0, w1, w2, w3;
+            item_attrs(tm, w0, w1, w2, w3);
+            finish_draw(w0, w1, w2, w3, j);
+          }
+        };
         if (mem_per_pass > 0) {
           for (int m0 = 0; m0 < n_mem; m0 += mem_per_pass) {
             const int ms = m0 + slot_l;
-            if (slot_l < mem_per_pass && ms < n_mem) {
-              int w0, w1, w2, w3;
-              item_attrs(n_mem == 1 ? t : wi.members[m_lo + ms], w0, w1, w2, w3);
-              finish_draw(w0, w1, w2, w3, draw_l);
-            }
+            if (slot_l < mem_per_pass && ms < n_mem) one_output(n_mem == 1 ? t : wi.members[m_lo + ms], draw_l);
           }
         } else {
           const int n_out = n_mem * nd_eff;
-          for (int q = lane; q < n_out; q += 64) {
-            int w0, w1, w2, w3;
-            item_attrs(n_mem == 1 ? t : wi.members[m_lo + q / nd_eff], w0, w1, w2, w3);
-            finish_draw(w0, w1, w2, w3, q % nd_eff);
-          }
+          for (int q = lane; q < n_out; q += 64) one_output(n_mem == 1 ? t : wi.members[m_lo + q / nd_eff], q % nd_eff);
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -1052,8 +1074,8 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
     for (int i = 0; i < 6; ++i) tot += (double)h[i];
     fprintf(stderr, "[wave clk] groups %d terms %d waves %llu (grid %d WGs): ", it.n, fr.n_terms, h[8], wgs);
     for (int i = 0; i < 6; ++i) fprintf(stderr, "%s %.1f%% ", nm[i], 100.0 * (double)h[i] / tot);
-    fprintf(stderr, "| cycles/group %.0f, groups seen %llu; full scans %llu, cached scans %llu (unused %llu), survivors scored %llu\n",
-            tot / (double)h[7], h[7], h[9], h[10], h[14], h[11]);
+    fprintf(stderr, "| cycles/group %.0f, groups seen %llu; full scans %llu, cached scans %llu, decided groups %llu, survivors scored %llu\n",
+            tot / (double)h[7], h[7], h[9], h[10], h[12], h[11]);
     memset(h, 0, sizeof h);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_clk), h, sizeof h);
   }
