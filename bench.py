@@ -125,26 +125,33 @@ def step_traffic(args, world):
 
 
 def roofline_model(rs, obs_local, particles):
-    """Algorithmic bytes of ONE launch of the root scan as implemented (root_wave.hip), each byte counted once:
-      * the byte rows comp_f[o][.] of the pre-filter terms: one row of kpad bytes per DISTINCT observed value
-        among the swept rows (groups of one referent run back to back and re-read them from L2);
-      * group descriptors: 112 B written by group_desc_kernel and read by the scan, per group;
-      * per group: the representative's observed ids (4 B x terms), grp_off / members (4 B per item + 4 B per
-        group), the current referent (4 B per item);
-      * exact scoring of the survivors: >= 1 candidate per group x terms x (1 B distance + 1 B length) + 8 B prior;
+    """Algorithmic bytes of ONE launch pair (group_desc_kernel + the root scan, root_wave.hip) as implemented, each
+    byte counted once, random gathers at the 64-byte sector the memory system moves for them:
+      * coarse level of the scan: one block-minimum row (cstride bytes, one byte per 64 candidates) per DISTINCT
+        observed value of the pre-filter columns among the swept rows;
+      * fine level: the 64-candidate blocks the launch's scans actually read (rs.fine_blocks, counted by the kernel):
+        3 x 64 B of byte rows + 8 B of the alive bitmap each;
+      * exact scores: group_desc_kernel gathers every term of the current referent once per group (one sector each);
+        the scan kernel gathers the (survivor, term) pairs it could not take from the descriptor (rs.scored_terms);
+      * group descriptors: 128 B written and read per group; per group the representative's observed ids, grp_off /
+        members (4 B per item + 4 B per group), the current referent (4 B per item);
       * outputs: 4 B per (row, particle) draw, 8 B log-marginal and 4 B overflow flag per row.
-    The §8(d) figure of SURVEY.md (every candidate of every row gathered, 920 296 B/row) is reported beside it
-    as `enumeration_equivalent`: the kernel provably skips almost all of that work."""
+    Returns (bytes, bytes of round 2's model: every distinct pre-filter byte row streamed once — what the kernel read
+    before the two-level scan).  The §8(d) figure of SURVEY.md (every candidate of every row gathered, 920 296 B/row)
+    is reported beside both as `enumeration_equivalent`: work the kernel provably skips."""
     if not rs.fast:
-        return None
-    rows_bytes = 0
+        return None, None
+    distinct = 0
     for p in range(rs.n_pre):
         col = rs.pre_obs_col[p]
         if col >= 0:
-            rows_bytes += int(np.unique(obs_local[col]).size) * rs.kpad
-    per_group = 2 * 112 + 4 * rs.n_terms + 4 + rs.n_terms * 2 + 8
+            distinct += int(np.unique(obs_local[col]).size)
+    per_group = 2 * 128 + 4 * rs.n_terms + 4 + 64 * rs.n_terms
     per_item = 4 + 4 + 4 * rs.n_draws + 8 + 4
-    return float(rows_bytes + rs.n_groups * per_group + rs.n_items * per_item)
+    common = rs.n_groups * per_group + rs.n_items * per_item
+    two_level = distinct * rs.cstride + rs.fine_blocks * (3 * 64 + 8) + rs.scored_terms * 64
+    rows_once = distinct * rs.kpad
+    return float(common + two_level), float(common + rows_once)
 
 
 def cpu_baseline(lw, obs, tr, eng, cfg, seed, min_rows, target_seconds):
@@ -305,7 +312,7 @@ def main():
         + ", ".join(f"{k} {1e3 * v / (args.warmup + args.steps):.2f}" for k, v in sorted(inf.TIMERS.items(), key=lambda kv: -kv[1])))
     rs = eng.hip.get_root_stats()
     lo, hi = shard_bounds(args.rows, rank, world)
-    alg_bytes = roofline_model(rs, obs[:, lo:hi], cfg.num_particles)
+    alg_bytes, alg_bytes_rows_once = roofline_model(rs, obs[:, lo:hi], cfg.num_particles)
 
     # ---- the same sweep cut into 32 sub-batches (upload / sweep / exchange / commit per sub-batch): what a class WITH
     # learned parameters costs under the default max_sub_batches (reported beside the headline, not as it) --------------
@@ -364,13 +371,20 @@ def main():
                          "kernel": "group_desc_kernel + fk_root_wave_kernel<12> (block 0 root: rows x candidate hospitals)",
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": 1e3 * per_launch_s,
                          "groups": rs.n_groups, "items": rs.n_items, "kpad": rs.kpad, "overflow_items": rs.overflow_items,
+                         "full_scans": rs.full_scans, "fine_blocks": rs.fine_blocks, "scored_terms": rs.scored_terms,
+                         "rows_streamed_once_model": {"bytes_per_launch": alg_bytes_rows_once,
+                                                      "GBps": (alg_bytes_rows_once / per_launch_s / 1e9) if (alg_bytes_rows_once and per_launch_s > 0) else None,
+                                                      "note": "round 2's byte model (every distinct pre-filter byte row "
+                                                              "streamed once): what the scan read before its block-minimum "
+                                                              "level; kept for comparison across rounds"},
                          "step": step_model,
                          "enumeration_equivalent": {"bytes_per_launch": enum_bytes / max(hot_launches, 1),
                                                     "GBps": enum_bytes / max(hot_launches, 1) / max(per_launch_s, 1e-12) / 1e9,
                                                     "note": "SURVEY §8d full-enumeration bytes (920 296 B/row) / kernel time: "
                                                             "work the kernel provably skips, not a bandwidth claim"},
-                         "note": "achieved = bytes the implemented algorithm has to move once (bench.roofline_model: distinct "
-                                 "pre-filter byte rows + descriptors + ids + outputs) / HIP-event time of the launch pair on "
+                         "note": "achieved = bytes the implemented algorithm has to move once (bench.roofline_model: block-minimum "
+                                 "rows + the fine blocks and sector gathers the kernel counted + descriptors + ids + outputs) "
+                                 "/ HIP-event time of the launch pair on "
                                  "the library's stream; traffic = HBM bytes per launch from this round's rocprofv3 PMC passes "
                                  "(profiles/), not measured in this run"},
             "phases_ms": {k: {"ms": round(v[0], 4), "intervals": v[1]} for k, v in sorted(phases.items(), key=lambda kv: -kv[1][0])},

@@ -122,6 +122,7 @@ int pclean_launch_gate(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
 struct FastTermDev {
   const uint8_t* comp;     // [n_obs][kpad] byte distances saturated at 42 (root_wave.hip: PRE_CLAMP); null for a ctx term
   const uint8_t* clen;     // [kpad]
+  const uint8_t* cmin;     // [n_obs][cstride] smallest byte of comp[o] within each block of 64 candidates (255 padding)
   const int32_t* obs_col;  // [n_rows]
   int32_t max_typos, ctx_slot;  // ctx_slot >= 0: the latent value goes through fn[ctx][value] first (a
                                 // JuliaNode of an earlier block's choice); scored by gathering, never pre-filtered
@@ -143,7 +144,7 @@ struct FastRootDev {
   // integer pre-filter (root_fast.hip): terms whose byte rows are summed, 1 / (smallest cost of one
   // edit), and the largest prior with / without an excluded reference
   int32_t n_pre, pre[3];
-  int32_t pad1, atd_stride;
+  int32_t cstride, atd_stride;  // cstride: bytes per row of the block-minimum tables (0: none)
   double inv_c, prior_max_e, prior_max_n;
   const double* atd;         // [max_len + 1][atd_stride] AddTypos log-density by (latent length, distance) (ctx->atd)
   const uint8_t* zero_row;   // kpad zero bytes: stands in for the byte row of a missing observation
@@ -153,7 +154,8 @@ struct FastRootDev {
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
-                            int32_t* desc_scratch, int32_t* overflow_list);
+                            int32_t* desc_scratch, int32_t* overflow_list,
+                            unsigned int* scan_stats = nullptr);
 int pclean_launch_overflow_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                                 uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                                 int32_t* draws_out, const int32_t* over_list, const unsigned int* over_count);
@@ -163,6 +165,9 @@ int pclean_launch_root_flags(pclean_ctx* ctx, int n_groups, const int32_t* gd, c
 size_t pclean_fast_desc_words(int n_groups);  // int32 words of desc_scratch for n_groups groups
 int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_lat, const int32_t* cand_col,
                          const uint16_t* lat_len, int n_cand, int kpad, uint8_t* comp, uint8_t* clen);
+// block minima of a compact table: cmin[o][kb] = min of comp[o][64 kb .. 64 kb + 63] (root_wave.hip: the coarse level
+// of the pre-filter scan)
+int pclean_build_compact_min(pclean_ctx* ctx, const uint8_t* comp, int n_obs, int kpad, int cstride, uint8_t* cmin);
 int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* logc_full, int n_cand, int kpad,
                         double logden_e, double logden_n, double* prior_e, double* prior_n, uint16_t* alive);
 

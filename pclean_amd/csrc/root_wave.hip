@@ -48,7 +48,7 @@
 #define CUT_ALL 126u           // cut-off that lets every live candidate through
 #define WAVE_SURV_CAP 256      // pre-filter survivors a wave keeps
 #ifndef WAVE_RB
-#define WAVE_RB 2              // rounds (16 candidates per lane each) whose loads are in flight together
+#define WAVE_RB 1              // rounds (16 candidates per lane each) in flight together in the whole-row fallback of the scan
 #endif
 #ifndef WAVE_TC
 #define WAVE_TC 6              // terms whose loads are in flight together in the exact scoring
@@ -59,6 +59,9 @@
 #ifndef WAVE_MIN_WAVES
 #define WAVE_MIN_WAVES 5       // resident workgroups per CU the register allocation aims at (measured: 5 beats 6, 7 and 8)
 #endif
+#ifndef WAVE_BLK_CAP
+#define WAVE_BLK_CAP 128       // passing 64-candidate blocks a scan's fine level takes (more: the rows are streamed whole)
+#endif
 #ifndef WAVE_EXACT_BY_TERM
 #define WAVE_EXACT_BY_TERM 2   // exact scoring: 0 one candidate per lane, 1 one (candidate, term) per lane, 2 the latter for short lists
 #endif
@@ -67,9 +70,11 @@
 #define WAVE_SLACK 3u          // scanned cut-off = required + slack: makes the list reusable by the next groups
 #define GD_STRIDE 32           // int32 words per group descriptor (one 128-byte line)
 // descriptor words: 0 m_lo, 1 m_hi, 2 representative item, 3 row, 4 excl, 5 ctx0, 6 ctx1, 7 flags (bit 0: the
-// excluded referent is garbage-collected, bit 1: the bound is useless -> guess and refine), 8-9 bound (double;
+// excluded referent is garbage-collected, bit 1: the bound is useless -> guess and refine, bit 2: words 30-31 hold
+// the exact score of the current referent), 8-9 bound (double;
 // already includes the new-row score), 10..25 observed value index of term f, 26-27 score of the "new row"
-// candidate (double), 28 first cut-off, 29 cut-off the bound would require (refine mode: upper limit)
+// candidate (double), 28 first cut-off, 29 cut-off the bound would require (refine mode: upper limit), 30-31 exact
+// score of the current referent (double)
 
 __global__ void compact_pair_kernel(const uint8_t* __restrict__ pair, int n_obs, int n_lat,
                                     const int32_t* __restrict__ cand_col, int n_cand, int kpad,
@@ -80,6 +85,24 @@ __global__ void compact_pair_kernel(const uint8_t* __restrict__ pair, int n_obs,
   uint8_t v = 0;
   if (k < n_cand) v = pair[(size_t)o * n_lat + cand_col[k]];
   comp[(size_t)o * kpad + k] = v < PRE_CLAMP ? v : (uint8_t)PRE_CLAMP;
+}
+// cmin[o][kb] = smallest byte of comp[o][64 kb .. 64 kb + 63] (padding blocks: 255).  One thread per (row, block).
+__global__ void compact_min_kernel(const uint8_t* __restrict__ comp, int n_obs, int kpad, int cstride,
+                                   uint8_t* __restrict__ cmin) {
+  const int kb = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = blockIdx.y;
+  if (kb >= cstride) return;
+  uint32_t m = 255u;
+  const int q0 = kb * 4, nq = kpad >> 4;
+  for (int q = q0; q < q0 + 4 && q < nq; ++q) {
+    const uint4 c = reinterpret_cast<const uint4*>(comp + (size_t)o * kpad)[q];
+    const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m = min(m, (cw[w] >> (8 * e)) & 0xffu);
+  }
+  cmin[(size_t)o * cstride + kb] = (uint8_t)m;
 }
 __global__ void compact_len_kernel(const uint16_t* __restrict__ lat_len, const int32_t* __restrict__ cand_col,
                                    int n_cand, int kpad, uint8_t* __restrict__ clen) {
@@ -115,6 +138,15 @@ int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_
   }
   hipLaunchKernelGGL(compact_len_kernel, dim3((kpad + 255) / 256), dim3(256), 0, ctx->stream, lat_len, cand_col, n_cand,
                      kpad, clen);
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
+int pclean_build_compact_min(pclean_ctx* ctx, const uint8_t* comp, int n_obs, int kpad, int cstride, uint8_t* cmin) {
+  for (int o0 = 0; o0 < n_obs; o0 += 65535) {  // gridDim.y limit
+    const int no = std::min(65535, n_obs - o0);
+    hipLaunchKernelGGL(compact_min_kernel, dim3((cstride + 63) / 64, no), dim3(64), 0, ctx->stream,
+                       comp + (size_t)o0 * kpad, no, kpad, cstride, cmin + (size_t)o0 * cstride);
+  }
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }
@@ -179,9 +211,15 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
   int o[PCLEAN_MAX_TERMS];
   for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) o[f] = f < fr.n_terms ? fr.terms[f].obs_col[row] : -1;
   const bool deleted = excl >= 0 && fr.counts && fr.counts[excl] <= 1;
-  double bound = -__builtin_inf();
-  if (excl >= 0 && !deleted && fr.logc_m1)
-    bound = fast_exact_score(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]) - 1.0;
+  double bound = -__builtin_inf(), score_cur = 0.0;
+  bool have_cur = false;
+  if (excl >= 0 && !deleted && fr.logc_m1) {
+    // the current referent's exact score: the same operations in the same order as the scan kernel's own scoring of
+    // candidate excl, so the scan kernel takes it from the descriptor when that candidate is its only survivor
+    score_cur = fast_exact_score(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]);
+    have_cur = true;
+    bound = score_cur - 1.0;
+  }
   // score of the "new row" candidate (proposal_compiler.jl:221-230): CRP new-table term + log-marginals of the
   // children in plan order — new_score() of enum_kernels.hip; an option list (LEAF node) has none
   double sn = -__builtin_inf();
@@ -226,7 +264,7 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
   d[4] = excl;
   d[5] = ctx0;
   d[6] = ctx1;
-  d[7] = (deleted ? 1 : 0) | (refine ? 2 : 0);
+  d[7] = (deleted ? 1 : 0) | (refine ? 2 : 0) | (have_cur ? 4 : 0);
   d[8] = __double2loint(bound);
   d[9] = __double2hiint(bound);
   for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) d[10 + f] = o[f];
@@ -234,8 +272,8 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
   d[27] = __double2hiint(sn);
   d[28] = (int32_t)cut;
   d[29] = (int32_t)cut_max;
-  d[30] = 0;
-  d[31] = 0;
+  d[30] = __double2loint(score_cur);
+  d[31] = __double2hiint(score_cur);
 }
 
 // what the scan kernel needs of an item list
@@ -304,14 +342,17 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     const FastRootDev fr, const WaveItems wi, uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, int n_groups,
     const int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr, double* __restrict__ g_m,
     uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out, int32_t* __restrict__ overflow_flag,
-    unsigned int* __restrict__ overflow_count, int32_t* __restrict__ overflow_list) {
+    unsigned int* __restrict__ overflow_count, int32_t* __restrict__ overflow_list,
+    unsigned int* __restrict__ scan_stats) {
   // exact scores and, later, the fixed-point prefix share one array: entry j is converted in place by lane j
   __shared__ uint64_t s_pref[WPG][CAP + 8];
   __shared__ int32_t s_k[WPG][CAP + 8];
+  __shared__ int32_t s_blk[WPG][WAVE_BLK_CAP];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint64_t* pref = s_pref[wave];
   double* scv = reinterpret_cast<double*>(s_pref[wave]);
   int32_t* ksv = s_k[wave];
+  int32_t* blk = s_blk[wave];
   const int kpad = fr.kpad, nquads = kpad >> 4, n_terms = fr.n_terms;
   const int nd_eff = n_draws > 0 ? n_draws : 1;
   const int draw_is = wi.draw_is ? wi.draw_is : n_draws, draw_ds = wi.draw_ds ? wi.draw_ds : 1;
@@ -384,6 +425,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
   unsigned long long clk_t = __builtin_readcyclecounter();
   unsigned long long cnt_acc[6] = {0, 0, 0, 0, 0, 0};  // full scans, cached scans, survivors, -, -, -
 #endif
+  unsigned int st_scans = 0, st_blocks = 0, st_terms = 0;  // bench.py's byte model: what the launch really read
   int g = 0, g_end = 0;
   resolve(grab(), g, g_end);
   int raw_next = steal < 8 ? grab() : 0;
@@ -465,11 +507,72 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
       cnt_acc[0] += 1;
 #endif
       const g_u8_t alive = (g_u8_t)(uint64_t)fr.alive;
+      st_scans += 1u;
       uint32_t cs = min(want + WAVE_SLACK, CUT_ALL);
+      // coarse level: the block-minimum rows (one byte per 64 candidates).  sum of the three minima > cut-off: no
+      // candidate of the block can pass (the minima bound every candidate's bytes from below) — the block's 3 x 64
+      // bytes are never read.  A scan reads ~3 x kpad / 64 bytes + the few blocks that hold a near candidate.
+      const uint32_t cst = (uint32_t)fr.cstride;
+      fr_karg_t FK = fr_karg();  // (the block-minimum bases: scalar loads from the kernarg segment, once per scan)
+      const g_u8_t m0 = (g_u8_t)(po0 >= 0 ? (uint64_t)FK->terms[fr.pre[0]].cmin + (uint64_t)((uint32_t)po0 * cst) : zr);
+      const g_u8_t m1 = (g_u8_t)(po1 >= 0 ? (uint64_t)FK->terms[fr.pre[1]].cmin + (uint64_t)((uint32_t)po1 * cst) : zr);
+      const g_u8_t m2 = (g_u8_t)(po2 >= 0 ? (uint64_t)FK->terms[fr.pre[2]].cmin + (uint64_t)((uint32_t)po2 * cst) : zr);
+      const int kblk = (kpad + 63) >> 6;
       for (;;) {
         // a byte of (c0 + c1 + c2 + addc) has bit 7 set iff its summed distance exceeds cs (sums <= 126: no carries)
         const uint32_t addc = 0x01010101u * (127u - cs);
         ns = 0;
+        bool fine_done = false;
+        if (cst != 0u) {
+          int nb = 0;  // passing blocks -> blk[], ascending
+          for (int kb0 = 0; kb0 < kblk; kb0 += 64) {
+            const int kb = kb0 + lane;
+            const bool pass = kb < kblk && (uint32_t)m0[kb] + (uint32_t)m1[kb] + (uint32_t)m2[kb] <= cs;
+            const uint64_t mk = __ballot(pass);
+            if (pass) {
+              const int pos = nb + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+              if (pos < WAVE_BLK_CAP) blk[pos] = kb;
+            }
+            nb += __builtin_popcountll(mk);
+          }
+          __builtin_amdgcn_wave_barrier();
+#ifdef WAVE_PHASE_CLOCK
+          cnt_acc[4] += nb <= WAVE_BLK_CAP ? 1 : 0;
+          cnt_acc[5] += (unsigned long long)min(nb, 100000);
+#endif
+          if (nb <= WAVE_BLK_CAP) {
+            fine_done = true;
+            st_blocks += (unsigned int)nb;
+            for (int i0 = 0; i0 < nb; i0 += 16) {  // 16 blocks x 4 quads per pass, in ascending candidate order
+              const int bi = i0 + (lane >> 2);
+              const int q = bi < nb ? blk[bi] * 4 + (lane & 3) : nquads;
+              uint32_t m16 = 0;
+              if (q < nquads) {
+                const u32x4_t ca = *(g_u4_t)(r0 + ((uint32_t)q << 4)), cb = *(g_u4_t)(r1 + ((uint32_t)q << 4)),
+                              cc = *(g_u4_t)(r2 + ((uint32_t)q << 4));
+                const uint32_t al = *(g_u16_t)(alive + ((uint32_t)q << 1));
+                const uint32_t tw[4] = {ca.x + cb.x + cc.x + addc, ca.y + cb.y + cc.y + addc, ca.z + cb.z + cc.z + addc,
+                                        ca.w + cb.w + cc.w + addc};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                  const uint32_t zz = ~tw[i] & 0x80808080u;
+                  m16 |= (((zz >> 7) | (zz >> 14) | (zz >> 21) | (zz >> 28)) & 0xfu) << (4 * i);
+                }
+                m16 &= al;
+              }
+              if (__ballot(m16 != 0) == 0ull) continue;
+              int total;
+              int pos = ns + wave_excl_prefix5(__builtin_popcount(m16), total);
+              for (uint32_t mm = m16; mm; mm &= mm - 1) {
+                if (pos < CAP) ksv[pos] = (q << 4) + __builtin_ctz(mm);
+                ++pos;
+              }
+              ns += total;
+            }
+          }
+        }
+        if (!fine_done) st_blocks += (unsigned int)kblk;
+        if (!fine_done)
         for (int q0 = 0; q0 < nquads; q0 += 64 * WAVE_RB) {
           u32x4_t ca[WAVE_RB], cb[WAVE_RB], cc[WAVE_RB];
           uint32_t al[WAVE_RB];
@@ -562,13 +665,24 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
         cut = min(2u * cut + 2u, cut_max);
         continue;
       }
+      // ---- the only survivor is the rows' current referent (nine groups in ten): its exact score is in the descriptor
+      // (group_desc_kernel computed it for the bound, bit for bit what the code below would compute) — no gather at all
+      bool scored = false;
+      if (ns == 1 && (flags & 4) != 0) {
+        const int k0 = __builtin_amdgcn_readfirstlane(ksv[0]);
+        if (k0 == excl) {
+          if (lane == 0) scv[0] = __hiloint2double(__builtin_amdgcn_readlane(dv, 31), __builtin_amdgcn_readlane(dv, 30));
+          scored = true;
+        }
+      }
+      if (!scored) st_terms += (unsigned int)(ns * n_terms);
 #if WAVE_EXACT_BY_TERM != 0
       // ---- exact fp64 scores of ksv[0..ns) -> scv: lane (j, f) = (survivor j of the pass, term f).  Every lane
       // issues ITS byte-distance and length loads at once and then its density load — two memory round trips per
       // pass whatever the number of terms (a per-candidate loop over the terms serialises them: the kernel is bound
       // by dependent round trips, not by bytes).  The fp64 additions then follow plan order through lane shuffles
       // (the operation order of candidate_score(), enum_kernels.hip).
-      if (BY_TERM_ONLY || ns <= SPP) {
+      if (!scored && (BY_TERM_ONLY || ns <= SPP)) {
         const double* prior = (excluded && fr.prior_e) ? fr.prior_e : fr.prior_n;
         const bool f_on = ((on_mask >> f_l) & 1u) != 0u, f_ctx = ((ctx_mask >> f_l) & 1u) != 0u;
         const g_u8_t row_f = (g_u8_t)__shfl((unsigned long long)t_row, f_l, 64);
@@ -610,7 +724,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
       // ---- exact fp64 scores of ksv[0..ns), one candidate per lane per pass -> scv.  The loads of a chunk of
       // terms are in flight together (byte distance + length, then the density table); the fp64 additions follow
       // plan order (the operation order of candidate_score(), enum_kernels.hip).
-      if (!BY_TERM_ONLY && (WAVE_EXACT_BY_TERM == 0 || ns > SPP)) {
+      if (!scored && !BY_TERM_ONLY && (WAVE_EXACT_BY_TERM == 0 || ns > SPP)) {
         const double* prior = (excluded && fr.prior_e) ? fr.prior_e : fr.prior_n;
         for (int base = 0; base < ns; base += 64) {
           const int j = base + lane;
@@ -818,6 +932,11 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     clk_acc[7] += 1;
 #endif
   }
+  if (scan_stats && lane == 0) {
+    atomicAdd(&scan_stats[0], st_scans);
+    atomicAdd(&scan_stats[1], st_blocks);
+    atomicAdd(&scan_stats[2], st_terms);
+  }
 #ifdef WAVE_PHASE_CLOCK
   clk_acc[6] = __builtin_readcyclecounter() - clk_t;
   if (lane == 0)
@@ -1015,7 +1134,7 @@ int pclean_launch_root_flags(pclean_ctx* ctx, int n_groups, const int32_t* gd, c
 }
 
 typedef void (*wave_kernel_t)(const FastRootDev, const WaveItems, uint64_t, uint32_t, uint32_t, int, int, const int32_t*,
-                              unsigned int*, double*, uint64_t*, int32_t*, int32_t*, unsigned int*, int32_t*);
+                              unsigned int*, double*, uint64_t*, int32_t*, int32_t*, unsigned int*, int32_t*, unsigned int*);
 
 static wave_kernel_t pick_kernel(int n_terms) {
   if (n_terms <= 2) return fk_root_wave_kernel<2, WAVE_SURV_CAP, 4>;
@@ -1034,7 +1153,7 @@ size_t pclean_fast_desc_words(int n_groups) {
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
-                            int32_t* desc_scratch, int32_t* overflow_list) {
+                            int32_t* desc_scratch, int32_t* overflow_list, unsigned int* scan_stats) {
   if (it.n <= 0) return PCLEAN_OK;
   const size_t ng = (size_t)it.n;
   unsigned int* chunk_ctr = reinterpret_cast<unsigned int*>(desc_scratch + ng * GD_STRIDE);
@@ -1063,7 +1182,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   WaveItems wi{it.grp_off ? it.members : nullptr, it.row, it.rng_row, it.particle, it.out_pos, it.row_offset, it.draw_is,
                it.draw_ds};
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * wpg), 0, ctx->stream, fr, wi, seed, sweep, site, n_draws, it.n, desc_scratch,
-                     chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count, overflow_list);
+                     chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count, overflow_list, scan_stats);
 #ifdef WAVE_PHASE_CLOCK
   if (it.n > 100000) {
     unsigned long long h[16];
@@ -1074,8 +1193,8 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
     for (int i = 0; i < 6; ++i) tot += (double)h[i];
     fprintf(stderr, "[wave clk] groups %d terms %d waves %llu (grid %d WGs): ", it.n, fr.n_terms, h[8], wgs);
     for (int i = 0; i < 6; ++i) fprintf(stderr, "%s %.1f%% ", nm[i], 100.0 * (double)h[i] / tot);
-    fprintf(stderr, "| cycles/group %.0f, groups seen %llu; full scans %llu, cached scans %llu, decided groups %llu, survivors scored %llu\n",
-            tot / (double)h[7], h[7], h[9], h[10], h[12], h[11]);
+    fprintf(stderr, "| cycles/group %.0f, groups seen %llu; full scans %llu, cached scans %llu, decided groups %llu, survivors scored %llu; two-level scans %llu, passing blocks %llu\n",
+            tot / (double)h[7], h[7], h[9], h[10], h[12], h[11], h[13], h[14]);
     memset(h, 0, sizeof h);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_clk), h, sizeof h);
   }

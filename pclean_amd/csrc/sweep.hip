@@ -770,7 +770,7 @@ struct BlockRun {  // per-block device state of one sweep
 };
 
 struct FastRoot {  // candidate-compact tables of a reference slot (root_wave.hip)
-  std::vector<DevBuf<uint8_t>> comp, clen;
+  std::vector<DevBuf<uint8_t>> comp, clen, cblk;  // cblk: block minima of comp (one byte per 64 candidates)
   std::vector<uint64_t> ver;
   DevBuf<double> prior_e, prior_n;
   DevBuf<uint16_t> alive;
@@ -829,7 +829,8 @@ struct SweepState {
   std::vector<int32_t> prof_launches;
   // overflow counters of the compact-table launches of the running call whose re-run needs no read-back
   // (overflow_lds_kernel in list mode): counted into the statistics / heuristics at the end of the call
-  DevBuf<unsigned int> over_ctr;   // [OVER_SLOTS]
+  bool scan_stats_used = false;
+  DevBuf<unsigned int> over_ctr;   // [OVER_SLOTS + 4]: the last four = scan statistics of the timed root launch
   struct OverRec { int block, node, n_items; bool time_it, leaf; };
   std::vector<OverRec> over_rec;
   unsigned int* h_over = nullptr;  // page-locked copy of over_ctr
@@ -869,6 +870,7 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
   for (auto& f : s->fast) {
     for (auto& c : f.comp) c.release();
     for (auto& c : f.clen) c.release();
+    for (auto& c : f.cblk) c.release();
     f.prior_e.release();
     f.prior_n.release();
     f.alive.release();
@@ -906,18 +908,23 @@ static int begin_call(pclean_ctx* ctx) {
   s->dummy_used = false;
   ctx->prior_mode = false;
   s->over_rec.clear();
-  if (s->over_ctr.alloc(OVER_SLOTS)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-  HIPCHK(ctx, hipMemsetAsync(s->over_ctr.p, 0, OVER_SLOTS * sizeof(unsigned int), ctx->stream));
+  if (s->over_ctr.alloc(OVER_SLOTS + 4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemsetAsync(s->over_ctr.p, 0, (OVER_SLOTS + 4) * sizeof(unsigned int), ctx->stream));
+  s->scan_stats_used = false;
   return PCLEAN_OK;
 }
 // End of such a call, after its last stream synchronisation has been queued: the overflow counts of the sync-free
 // launches go into the statistics and the "does the pre-filter pay for this option list" heuristic.
 static int queue_over_copy(pclean_ctx* ctx) {  // before a stream synchronisation of the caller
   SweepState* s = st(ctx);
-  if (s->over_rec.empty()) return PCLEAN_OK;
-  if (!s->h_over) HIPCHK(ctx, hipHostMalloc((void**)&s->h_over, OVER_SLOTS * sizeof(unsigned int), hipHostMallocDefault));
-  HIPCHK(ctx, hipMemcpyAsync(s->h_over, s->over_ctr.p, s->over_rec.size() * sizeof(unsigned int), hipMemcpyDeviceToHost,
-                             ctx->stream));
+  if (s->over_rec.empty() && !s->scan_stats_used) return PCLEAN_OK;
+  if (!s->h_over) HIPCHK(ctx, hipHostMalloc((void**)&s->h_over, (OVER_SLOTS + 4) * sizeof(unsigned int), hipHostMallocDefault));
+  if (!s->over_rec.empty())
+    HIPCHK(ctx, hipMemcpyAsync(s->h_over, s->over_ctr.p, s->over_rec.size() * sizeof(unsigned int), hipMemcpyDeviceToHost,
+                               ctx->stream));
+  if (s->scan_stats_used)
+    HIPCHK(ctx, hipMemcpyAsync(s->h_over + OVER_SLOTS, s->over_ctr.p + OVER_SLOTS, 4 * sizeof(unsigned int),
+                               hipMemcpyDeviceToHost, ctx->stream));
   return PCLEAN_OK;
 }
 static void apply_over_stats(pclean_ctx* ctx) {  // after that synchronisation
@@ -936,9 +943,15 @@ static void apply_over_stats(pclean_ctx* ctx) {  // after that synchronisation
       fprintf(stderr, "[pclean] block %d node %d: %u of %d items re-run over all candidates\n", r.block, r.node, h, r.n_items);
   }
   s->over_rec.clear();
+  if (s->scan_stats_used) {
+    ctx->root_stats.full_scans = (int32_t)s->h_over[OVER_SLOTS];
+    ctx->root_stats.fine_blocks = (int32_t)s->h_over[OVER_SLOTS + 1];
+    ctx->root_stats.scored_terms = (int32_t)s->h_over[OVER_SLOTS + 2];
+    s->scan_stats_used = false;
+  }
 }
 static int finish_call(pclean_ctx* ctx) {
-  if (st(ctx)->over_rec.empty()) return PCLEAN_OK;
+  if (st(ctx)->over_rec.empty() && !st(ctx)->scan_stats_used) return PCLEAN_OK;
   int rc = queue_over_copy(ctx);
   if (rc) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1286,12 +1299,16 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   if ((int)f.comp.size() != n.n_terms || f.kpad != kpad) {
     for (auto& c : f.comp) c.release();
     for (auto& c : f.clen) c.release();
+    for (auto& c : f.cblk) c.release();
+    f.cblk.assign(n.n_terms, DevBuf<uint8_t>());
     f.comp.assign(n.n_terms, DevBuf<uint8_t>());
     f.clen.assign(n.n_terms, DevBuf<uint8_t>());
     f.ver.assign(n.n_terms, 0);
     f.kpad = kpad;
     f.prior_ver = 0;
   }
+  // block minima of the compact rows (one byte per 64 candidates): the coarse level of the pre-filter scan
+  const int cstride = ((((kpad + 63) >> 6) + 15) & ~15);
   for (int i = 0; i < n.n_terms; ++i) {
     const pclean_term& tm = b.terms[n.term_begin + i];
     const PairTable& pt = ctx->pair[tm.pair_table];
@@ -1316,10 +1333,15 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
       int rc = pclean_build_compact(ctx, pt.d.p, pt.n_obs, pt.n_lat, t.cols.p + (size_t)tm.cand_col * t.n_rows,
                                     pt.lat_len.p, t.n_rows, kpad, f.comp[i].p, f.clen[i].p);
       if (rc) return rc;
+      if (f.cblk[i].alloc(std::max<size_t>((size_t)pt.n_obs * cstride, 16)))
+        return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed (compact tables)");
+      rc = pclean_build_compact_min(ctx, f.comp[i].p, pt.n_obs, kpad, cstride, f.cblk[i].p);
+      if (rc) return rc;
       f.ver[i] = ver;
     }
     fr.terms[i].comp = f.comp[i].p;
     fr.terms[i].clen = f.clen[i].p;
+    fr.terms[i].cmin = f.cblk[i].p;
   }
   if ((int)f.zero_row.n < kpad || !f.zero_row.p) {
     if (f.zero_row.alloc((size_t)kpad + 4096)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
@@ -1361,7 +1383,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     } else {
       fr.inv_c = 1.0 / (cmin * (1.0 - 1e-9));
     }
-    fr.pad1 = 0;
+    fr.cstride = cstride;
     fr.prior_max_e = f.logc_max - t.scal[1];
     fr.prior_max_n = f.logc_max - t.scal[0];
   }
@@ -1845,6 +1867,7 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     rs.n_draws = n_draws;
     if (fast) {
       rs.kpad = fr.kpad;
+      rs.cstride = fr.cstride;
       rs.n_pre = fr.n_pre;
       for (int p = 0; p < 3; ++p) rs.pre_obs_col[p] = p < fr.n_pre ? b.terms[n.term_begin + fr.pre[p]].obs_col : -1;
     }
@@ -1879,8 +1902,13 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
     if (!desc) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
     ProfScope ps(ctx, time_it ? "root_scan_block0" : (n.kind == PCLEAN_NODE_FK ? "slot_scan" : "option_scan"));
     if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
+    unsigned int* scan_stats = nullptr;
+    if (time_it && s->over_ctr.p) {  // the timed launch (block 0's root): what it read, for bench.py's byte model
+      scan_stats = s->over_ctr.p + OVER_SLOTS;
+      s->scan_stats_used = true;
+    }
     rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag, over_count, desc,
-                                 over_list);
+                                 over_list, scan_stats);
     if (time_it) {
       (void)hipEventRecord(s->ev1, ctx->stream);
       s->dbg_desc = desc;
