@@ -63,7 +63,8 @@ class RootStats(C.Structure):
     _fields_ = [("fast", C.c_int32), ("n_items", C.c_int32), ("n_groups", C.c_int32), ("n_cand", C.c_int32),
                 ("kpad", C.c_int32), ("n_terms", C.c_int32), ("n_pre", C.c_int32), ("n_draws", C.c_int32),
                 ("pre_obs_col", C.c_int32 * 3), ("overflow_items", C.c_int32), ("cstride", C.c_int32),
-                ("full_scans", C.c_int32), ("fine_blocks", C.c_int32), ("scored_terms", C.c_int32)]
+                ("full_scans", C.c_int32), ("fine_blocks", C.c_int32), ("scored_terms", C.c_int32),
+                ("resolved_groups", C.c_int32)]
 
 
 TERM_DTYPE = np.dtype([("obs_col", "<i4"), ("cand_col", "<i4"), ("pair_table", "<i4"), ("dens_kind", "<i4"),

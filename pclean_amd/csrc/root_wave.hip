@@ -65,13 +65,14 @@
 #ifndef WAVE_EXACT_BY_TERM
 #define WAVE_EXACT_BY_TERM 2   // exact scoring: 0 one candidate per lane, 1 one (candidate, term) per lane, 2 the latter for short lists
 #endif
+#define WAVE_RES_UNRESOLVED (-2147483647 - 1)  // g_res of a group the scan kernel has to walk
 #define WAVE_DCUT_OK 24u       // a cut-off below this many summed edits is considered selective
 #define WAVE_GUESS 4u          // first cut-off tried when the descriptor's bound is useless (widened until something survives)
 #define WAVE_SLACK 3u          // scanned cut-off = required + slack: makes the list reusable by the next groups
 #define GD_STRIDE 32           // int32 words per group descriptor (one 128-byte line)
 // descriptor words: 0 m_lo, 1 m_hi, 2 representative item, 3 row, 4 excl, 5 ctx0, 6 ctx1, 7 flags (bit 0: the
 // excluded referent is garbage-collected, bit 1: the bound is useless -> guess and refine, bit 2: words 30-31 hold
-// the exact score of the current referent), 8-9 bound (double;
+// the exact score of the current referent, bit 3: resolved by group_desc_kernel, the scan kernel skips it), 8-9 bound (double;
 // already includes the new-row score), 10..25 observed value index of term f, 26-27 score of the "new row"
 // candidate (double), 28 first cut-off, 29 cut-off the bound would require (refine mode: upper limit), 30-31 exact
 // score of the current referent (double)
@@ -198,10 +199,13 @@ __device__ __forceinline__ double fast_exact_score(const FastRootDev& fr, const 
 // from the exact score of the rows' current referent (only ever used as a filter, never as a score) and the
 // pre-filter cut-off that follows from it.
 __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const ChildrenDev ch, int n_groups,
-                                  int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr) {
+                                  int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr, double* __restrict__ g_m,
+                                  uint64_t* __restrict__ g_U, int32_t* __restrict__ g_res,
+                                  unsigned int* __restrict__ scan_stats) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < 8) chunk_ctr[g] = 0u;
-  if (g >= n_groups) return;
+  unsigned int st_blocks = 0, st_resolved = 0;  // (summed over the wavefront at the end: one atomic per wave)
+  if (g < n_groups) {
   const int m_lo = it.grp_off ? it.grp_off[g] : g, m_hi = it.grp_off ? it.grp_off[g + 1] : g + 1;
   const int t = it.grp_off ? it.members[m_lo] : g;
   const int row = it.row ? it.row[t] : t;
@@ -256,6 +260,62 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
       refine = 1;
     }
   }
+  // ---- RESOLVED groups.  Nine groups in ten end the same way: the rows' current referent is the only candidate within
+  // the cut-off, and it (or the new row) outweighs the other by more than 28.5 nats, i.e. the fixed-point total is
+  // exactly one unit and every draw returns the same entry.  One THREAD settles such a group here — the two-level
+  // pre-filter scan of its three byte rows with the required cut-off, looking for any candidate other than the
+  // referent — instead of one WAVEFRONT walking it through the scan kernel's serial phases (~20 us per group per
+  // wave whatever the phases contain).  The scan kernel skips the groups flagged here; their rows'
+  // draws are written by resolved_draws_kernel, their log-marginals by group_lse_kernel as for every group.
+  bool resolved = false;
+  int res_val = 0;
+  double res_m = 0.0;
+  if (g_res && have_cur && !refine && fr.n_pre == 3 && fr.cstride > 0 && !fr.is_leaf) {
+    const double hi = fmax(score_cur, sn), lo = fmin(score_cur, sn);
+    if (hi > -__builtin_inf() && score_cur != sn && !(lo - hi >= -28.5)) {  // pclean_fixw: the smaller one weighs 0
+      const uint8_t *r[3], *mn[3];
+      for (int p = 0; p < 3; ++p) {
+        const int op = o[fr.pre[p]];
+        r[p] = op >= 0 ? fr.terms[fr.pre[p]].comp + (size_t)op * fr.kpad : fr.zero_row;
+        mn[p] = op >= 0 ? fr.terms[fr.pre[p]].cmin + (size_t)op * fr.cstride : fr.zero_row;
+      }
+      const int nquads = fr.kpad >> 4, kblk = (fr.kpad + 63) >> 6;
+      bool has_excl = false, other = false;
+      for (int kb0 = 0; kb0 < kblk && !other; kb0 += 16) {
+        const uint4 a = *reinterpret_cast<const uint4*>(mn[0] + kb0), b = *reinterpret_cast<const uint4*>(mn[1] + kb0),
+                    c = *reinterpret_cast<const uint4*>(mn[2] + kb0);
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w}, cw[4] = {c.x, c.y, c.z, c.w};
+        for (int e = 0; e < 16 && !other; ++e) {
+          const int kb = kb0 + e;
+          if (kb >= kblk) break;
+          const uint32_t sh = 8u * (e & 3);
+          if (((aw[e >> 2] >> sh) & 0xffu) + ((bw[e >> 2] >> sh) & 0xffu) + ((cw[e >> 2] >> sh) & 0xffu) > cut) continue;
+          ++st_blocks;
+          for (int q = kb * 4; q < kb * 4 + 4 && q < nquads && !other; ++q) {
+            const uint4 fa = reinterpret_cast<const uint4*>(r[0])[q], fb = reinterpret_cast<const uint4*>(r[1])[q],
+                        fc = reinterpret_cast<const uint4*>(r[2])[q];
+            const uint32_t al = fr.alive[q];
+            const uint32_t xa[4] = {fa.x, fa.y, fa.z, fa.w}, xb[4] = {fb.x, fb.y, fb.z, fb.w}, xc[4] = {fc.x, fc.y, fc.z, fc.w};
+            for (int i = 0; i < 16; ++i) {
+              const uint32_t s2 = 8u * (i & 3);
+              const uint32_t dsum = ((xa[i >> 2] >> s2) & 0xffu) + ((xb[i >> 2] >> s2) & 0xffu) + ((xc[i >> 2] >> s2) & 0xffu);
+              if (dsum <= cut && ((al >> i) & 1u)) {
+                if (q * 16 + i == excl)
+                  has_excl = true;
+                else
+                  other = true;
+              }
+            }
+          }
+        }
+      }
+      if (has_excl && !other) {
+        resolved = true;
+        res_m = hi;
+        res_val = sn > score_cur ? PCLEAN_CHOICE_NEW : excl;
+      }
+    }
+  }
   int32_t* d = gd + (size_t)g * GD_STRIDE;
   d[0] = m_lo;
   d[1] = m_hi;
@@ -264,7 +324,7 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
   d[4] = excl;
   d[5] = ctx0;
   d[6] = ctx1;
-  d[7] = (deleted ? 1 : 0) | (refine ? 2 : 0) | (have_cur ? 4 : 0);
+  d[7] = (deleted ? 1 : 0) | (refine ? 2 : 0) | (have_cur ? 4 : 0) | (resolved ? 8 : 0);
   d[8] = __double2loint(bound);
   d[9] = __double2hiint(bound);
   for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) d[10 + f] = o[f];
@@ -274,6 +334,49 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
   d[29] = (int32_t)cut_max;
   d[30] = __double2loint(score_cur);
   d[31] = __double2hiint(score_cur);
+  if (g_res) g_res[g] = resolved ? res_val : WAVE_RES_UNRESOLVED;
+  if (resolved) {
+    g_m[g] = res_m;
+    g_U[g] = PCLEAN_FIX_ONE;
+    st_resolved = 1u;
+  }
+  }
+  if (scan_stats) {  // the byte model's counters: the blocks these scans read, the groups settled here
+    for (int sh = 32; sh > 0; sh >>= 1) {
+      st_blocks += __shfl_xor(st_blocks, sh, 64);
+      st_resolved += __shfl_xor(st_resolved, sh, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && (st_blocks | st_resolved)) {
+      atomicAdd(&scan_stats[1], st_blocks);
+      atomicAdd(&scan_stats[3], st_resolved);
+    }
+  }
+}
+
+// draws of the RESOLVED groups (group_desc_kernel): one thread per member position; its group by bisection of grp_off
+__global__ void resolved_draws_kernel(int n_items, int n_groups, const int32_t* __restrict__ grp_off,
+                                      const int32_t* __restrict__ members, const int32_t* __restrict__ out_pos,
+                                      const int32_t* __restrict__ g_res, int n_draws, int draw_is, int draw_ds,
+                                      int32_t* __restrict__ draws_out) {
+  const int mi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mi >= n_items) return;
+  int g = mi, tm = mi;
+  if (grp_off) {
+    int lo = 0, hi = n_groups - 1;  // largest g with grp_off[g] <= mi
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (grp_off[mid] <= mi)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    g = lo;
+    tm = members[mi];
+  }
+  const int r = g_res[g];
+  if (r == WAVE_RES_UNRESOLVED) return;
+  int32_t* dst = draws_out + (size_t)(out_pos ? out_pos[tm] : tm) * draw_is;
+  for (int j = 0; j < n_draws; ++j) dst[(size_t)j * draw_ds] = r;
 }
 
 // what the scan kernel needs of an item list
@@ -460,6 +563,12 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     const int t = __builtin_amdgcn_readlane(dv, 2);
     const int excl = __builtin_amdgcn_readlane(dv, 4);
     const int flags = __builtin_amdgcn_readlane(dv, 7);
+    if (flags & 8) {  // settled by group_desc_kernel (its rows' draws: resolved_draws_kernel): nothing to do here
+      g = gn;
+      g_end = gn_end;
+      dv = dvn;
+      continue;
+    }
     const bool deleted = (flags & 1) != 0;
     bool refine = (flags & 2) != 0;
     const double bound = __hiloint2double(__builtin_amdgcn_readlane(dv, 9), __builtin_amdgcn_readlane(dv, 8));
@@ -1147,20 +1256,29 @@ static wave_kernel_t pick_kernel(int n_terms) {
 // int32 words of desc_scratch for n_groups groups: descriptors, 8 chunk counters, per-group (maximum, total)
 size_t pclean_fast_desc_words(int n_groups) {
   const size_t ng = (size_t)std::max(n_groups, 1);
-  return ng * GD_STRIDE + 16 + ng * 4;
+  return ng * GD_STRIDE + 16 + ng * 4 + ng;
 }
 
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
-                            int32_t* desc_scratch, int32_t* overflow_list, unsigned int* scan_stats) {
+                            int32_t* desc_scratch, int32_t* overflow_list, unsigned int* scan_stats, int n_items) {
   if (it.n <= 0) return PCLEAN_OK;
   const size_t ng = (size_t)it.n;
   unsigned int* chunk_ctr = reinterpret_cast<unsigned int*>(desc_scratch + ng * GD_STRIDE);
   double* g_m = reinterpret_cast<double*>(desc_scratch + ng * GD_STRIDE + 16);
   uint64_t* g_U = reinterpret_cast<uint64_t*>(g_m + ng);
+  int32_t* g_res = reinterpret_cast<int32_t*>(g_U + ng);
+  // groups are settled by group_desc_kernel only when their rows' draws can be written afterwards (the member count is
+  // known) and the launch draws at all
+  // OFF by default (PCLEAN_RESOLVE_GROUPS=1 turns it on): bit-identical on every parity test, and it takes the scan
+  // kernel's full scans from 138k to 5.6k on the 1M-row table — but as written (one thread walking its group's block
+  // minima with uncoalesced 16-byte loads and early exits) group_desc_kernel becomes the slower part: 1.25 -> 1.87 ms
+  // for the launch pair.  Kept for the next round: the settling belongs in a kernel with a few lanes per group.
+  static const bool want_resolve = getenv("PCLEAN_RESOLVE_GROUPS") != nullptr;
+  const bool resolve = n_draws > 0 && want_resolve && (!it.grp_off || n_items > 0);
   hipLaunchKernelGGL(group_desc_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, it, ch, it.n,
-                     desc_scratch, chunk_ctr);
+                     desc_scratch, chunk_ctr, g_m, g_U, resolve ? g_res : nullptr, scan_stats);
   // persistent grid = what is resident at once (a workgroup that starts late would find the counters drained anyway)
   const int wpg = 4;
   wave_kernel_t kern = pick_kernel(fr.n_terms);
@@ -1199,6 +1317,12 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_clk), h, sizeof h);
   }
 #endif
+  if (resolve) {
+    const int n_mem_all = it.grp_off ? n_items : it.n;
+    hipLaunchKernelGGL(resolved_draws_kernel, dim3((n_mem_all + 255) / 256), dim3(256), 0, ctx->stream, n_mem_all, it.n,
+                       it.grp_off, it.members, it.out_pos, g_res, n_draws, it.draw_is ? it.draw_is : n_draws,
+                       it.draw_ds ? it.draw_ds : 1, draws_out);
+  }
   if (lse_out)
     hipLaunchKernelGGL(group_lse_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, it.n, it.grp_off, it.members,
                        it.out_pos, g_m, g_U, lse_out);

@@ -947,6 +947,7 @@ static void apply_over_stats(pclean_ctx* ctx) {  // after that synchronisation
     ctx->root_stats.full_scans = (int32_t)s->h_over[OVER_SLOTS];
     ctx->root_stats.fine_blocks = (int32_t)s->h_over[OVER_SLOTS + 1];
     ctx->root_stats.scored_terms = (int32_t)s->h_over[OVER_SLOTS + 2];
+    ctx->root_stats.resolved_groups = (int32_t)s->h_over[OVER_SLOTS + 3];
     s->scan_stats_used = false;
   }
 }
@@ -1908,7 +1909,7 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
       s->scan_stats_used = true;
     }
     rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag, over_count, desc,
-                                 over_list, scan_stats);
+                                 over_list, scan_stats, il.n);
     if (time_it) {
       (void)hipEventRecord(s->ev1, ctx->stream);
       s->dbg_desc = desc;
