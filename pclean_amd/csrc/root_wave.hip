@@ -350,8 +350,9 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
       st_resolved += __shfl_xor(st_resolved, sh, 64);
     }
     if ((threadIdx.x & 63) == 0 && (st_blocks | st_resolved)) {
-      atomicAdd(&scan_stats[1], st_blocks);
-      atomicAdd(&scan_stats[3], st_resolved);
+      unsigned int* sl = scan_stats + (size_t)(((blockIdx.x * blockDim.x + threadIdx.x) >> 6) & 63) * 32;
+      atomicAdd(&sl[1], st_blocks);
+      atomicAdd(&sl[3], st_resolved);
     }
   }
 }
@@ -1044,10 +1045,11 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     clk_acc[7] += 1;
 #endif
   }
-  if (scan_stats && lane == 0) {
-    atomicAdd(&scan_stats[0], st_scans);
-    atomicAdd(&scan_stats[1], st_blocks);
-    atomicAdd(&scan_stats[2], st_terms);
+  if (scan_stats && lane == 0) {  // 64 slots a cache line apart: same-line atomics are served one after the other
+    unsigned int* sl = scan_stats + (size_t)((blockIdx.x * WPG + wave) & 63) * 32;
+    atomicAdd(&sl[0], st_scans);
+    atomicAdd(&sl[1], st_blocks);
+    atomicAdd(&sl[2], st_terms);
   }
 #ifdef WAVE_PHASE_CLOCK
   clk_acc[6] = __builtin_readcyclecounter() - clk_t;

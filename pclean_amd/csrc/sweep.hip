@@ -150,13 +150,16 @@ __global__ void ctx_fill_kernel(int N, int P, const int32_t* __restrict__ it_ctx
     }
   }
 }
+// (PU_T = 1024 threads per workgroup: the ONE returning atomic per workgroup on the same counter is served at ~30 ns
+// apiece at the memory side — 3 900 workgroups of 256 were a 0.12 ms floor of a 0.17 ms kernel)
+#define PU_T 1024
 // One thread per row, after a block's root enumeration: particle p of row i takes its draw (row-major from the
 // root kernels: draws_rm[i * P + p], or draw p of its context's item) and the block's log-marginal; particle 0
 // keeps the retained referent under CSMC (row_inference.jl:143-145).  Writes the particle-major arrays
 // coalesced and emits the list of the particle slots that proposed a NEW referent (new_list[pos] = slot,
 // pnewpos[slot] = pos; positions reserved with one atomic per workgroup, order irrelevant: every use is keyed
 // by (row, particle)).
-__global__ __launch_bounds__(256) void particle_update_kernel(int N, int P, const int32_t* __restrict__ draws_rm,
+__global__ __launch_bounds__(PU_T) void particle_update_kernel(int N, int P, const int32_t* __restrict__ draws_rm,
                                                               const double* __restrict__ lse,
                                                               const int32_t* __restrict__ slot_item,
                                                               const int32_t* __restrict__ draws_item,
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256) void particle_update_kernel(int N, int P, cons
                                                               unsigned int* __restrict__ n_new,
                                                               int32_t* __restrict__ new_list,
                                                               int32_t* __restrict__ pnewpos) {
-  __shared__ unsigned int wsum[4];
+  __shared__ unsigned int wsum[PU_T / 64];
   __shared__ unsigned int bbase;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -200,7 +203,8 @@ __global__ __launch_bounds__(256) void particle_update_kernel(int N, int P, cons
   if (lane == 63) wsum[wave] = incl;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    unsigned int total = 0;
+    for (int k = 0; k < PU_T / 64; ++k) total += wsum[k];
     bbase = total ? atomicAdd(n_new, total) : 0u;
   }
   __syncthreads();
@@ -830,7 +834,7 @@ struct SweepState {
   // overflow counters of the compact-table launches of the running call whose re-run needs no read-back
   // (overflow_lds_kernel in list mode): counted into the statistics / heuristics at the end of the call
   bool scan_stats_used = false;
-  DevBuf<unsigned int> over_ctr;   // [OVER_SLOTS + 4]: the last four = scan statistics of the timed root launch
+  DevBuf<unsigned int> over_ctr;   // [OVER_SLOTS + STAT_WORDS]: the tail = scan statistics of the timed root launch
   struct OverRec { int block, node, n_items; bool time_it, leaf; };
   std::vector<OverRec> over_rec;
   unsigned int* h_over = nullptr;  // page-locked copy of over_ctr
@@ -847,6 +851,7 @@ struct SweepState {
 };
 
 #define OVER_SLOTS 256
+#define STAT_WORDS (64 * 32)  // scan statistics of the timed root launch: 64 slots, 128 bytes apart
 static SweepState* st(pclean_ctx* ctx) {
   if (!ctx->sweep_state) ctx->sweep_state = new SweepState();
   return (SweepState*)ctx->sweep_state;
@@ -908,8 +913,8 @@ static int begin_call(pclean_ctx* ctx) {
   s->dummy_used = false;
   ctx->prior_mode = false;
   s->over_rec.clear();
-  if (s->over_ctr.alloc(OVER_SLOTS + 4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-  HIPCHK(ctx, hipMemsetAsync(s->over_ctr.p, 0, (OVER_SLOTS + 4) * sizeof(unsigned int), ctx->stream));
+  if (s->over_ctr.alloc(OVER_SLOTS + STAT_WORDS)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemsetAsync(s->over_ctr.p, 0, (OVER_SLOTS + STAT_WORDS) * sizeof(unsigned int), ctx->stream));
   s->scan_stats_used = false;
   return PCLEAN_OK;
 }
@@ -918,12 +923,12 @@ static int begin_call(pclean_ctx* ctx) {
 static int queue_over_copy(pclean_ctx* ctx) {  // before a stream synchronisation of the caller
   SweepState* s = st(ctx);
   if (s->over_rec.empty() && !s->scan_stats_used) return PCLEAN_OK;
-  if (!s->h_over) HIPCHK(ctx, hipHostMalloc((void**)&s->h_over, (OVER_SLOTS + 4) * sizeof(unsigned int), hipHostMallocDefault));
+  if (!s->h_over) HIPCHK(ctx, hipHostMalloc((void**)&s->h_over, (OVER_SLOTS + STAT_WORDS) * sizeof(unsigned int), hipHostMallocDefault));
   if (!s->over_rec.empty())
     HIPCHK(ctx, hipMemcpyAsync(s->h_over, s->over_ctr.p, s->over_rec.size() * sizeof(unsigned int), hipMemcpyDeviceToHost,
                                ctx->stream));
   if (s->scan_stats_used)
-    HIPCHK(ctx, hipMemcpyAsync(s->h_over + OVER_SLOTS, s->over_ctr.p + OVER_SLOTS, 4 * sizeof(unsigned int),
+    HIPCHK(ctx, hipMemcpyAsync(s->h_over + OVER_SLOTS, s->over_ctr.p + OVER_SLOTS, STAT_WORDS * sizeof(unsigned int),
                                hipMemcpyDeviceToHost, ctx->stream));
   return PCLEAN_OK;
 }
@@ -944,10 +949,13 @@ static void apply_over_stats(pclean_ctx* ctx) {  // after that synchronisation
   }
   s->over_rec.clear();
   if (s->scan_stats_used) {
-    ctx->root_stats.full_scans = (int32_t)s->h_over[OVER_SLOTS];
-    ctx->root_stats.fine_blocks = (int32_t)s->h_over[OVER_SLOTS + 1];
-    ctx->root_stats.scored_terms = (int32_t)s->h_over[OVER_SLOTS + 2];
-    ctx->root_stats.resolved_groups = (int32_t)s->h_over[OVER_SLOTS + 3];
+    unsigned long long tot[4] = {0, 0, 0, 0};  // 64 slots a cache line apart (root_wave.hip: WAVE_STAT_SLOTS)
+    for (int sl = 0; sl < 64; ++sl)
+      for (int i = 0; i < 4; ++i) tot[i] += s->h_over[OVER_SLOTS + sl * 32 + i];
+    ctx->root_stats.full_scans = (int32_t)tot[0];
+    ctx->root_stats.fine_blocks = (int32_t)tot[1];
+    ctx->root_stats.scored_terms = (int32_t)tot[2];
+    ctx->root_stats.resolved_groups = (int32_t)tot[3];
     s->scan_stats_used = false;
   }
 }
@@ -3320,7 +3328,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       }
       HIPCHK(ctx, hipMemsetAsync(r.lse.p, 0, (size_t)N * sizeof(double), ctx->stream));
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-      hipLaunchKernelGGL(particle_update_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
+      hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
                          s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p);
       if (has_ctx) {  // the particles' contexts: read by the likelihood terms and handed to the new rows' items
@@ -3358,7 +3366,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       }
       ProfScope ps(ctx, "particle_update");
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-      hipLaunchKernelGGL(particle_update_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
+      hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
                          s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p);
     } else {
@@ -3413,7 +3421,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       if (rc) return rc;
       ProfScope ps(ctx, "particle_update");
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-      hipLaunchKernelGGL(particle_update_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, (const int32_t*)nullptr,
+      hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, (const int32_t*)nullptr,
                          (const double*)nullptr, slot_item, draws_item, lse_item, cur_b, r.pchoice.p, s->w.p,
                          s->counter.p, r.new_slots.p, r.pnewpos.p);
     }
