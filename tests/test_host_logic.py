@@ -413,3 +413,33 @@ def test_prior_proposals_end_to_end(oracle):
         tr.check_consistency()
         f1[dd] = evaluate_accuracy(lw, tr, S["dirty"], S["clean"])["f1"]
     assert 0.0 <= f1[False] <= f1[True]
+
+
+def test_py_moves_commute_with_the_sweep_of_the_class_own_rows(oracle):
+    """A latent class without learned parameters is swept in ONE batch and its table's Pitman-Yor moves are made after
+    the batch (inference.latent_sweep).  The claim behind it: those moves' conditional (the table's reference counts,
+    its rows) is untouched by updates of the class's own rows, and the row updates do not consume the trace's RNG — so
+    the hyper-parameters after the sweep are THE SAME NUMBERS as under the cut schedule with interleaved moves (what
+    differs between the two schedules is only how stale the frozen tables are for the later rows)."""
+    from oracle_engine import OracleEngine
+    from pclean_amd.engine import InferenceConfig
+    from pclean_amd.inference import initialize_trace, latent_sweep
+    from pclean_amd.trace import Trace
+    S = helpers.hospital_setup(n_rows=400)
+    lw, obs = S["lw"], S["obs"]
+    cfg = InferenceConfig(1, 2, use_mh_instead_of_pg=True, rejuv_frequency=10)
+    out = {}
+    for mode in ("one_batch", "cut"):
+        tr = Trace(lw, obs.shape[1], 7)
+        eng = OracleEngine(oracle, lw, obs)
+        initialize_trace(eng, tr, cfg, 7)
+        cname = next(c for c in lw.model.class_order if c in lw.latent_plans and not tr.has_learned_parameters(c)
+                     and tr.tables[c].n_live > 40)
+        if mode == "cut":  # the round-2 schedule: sub-batches with the moves in between
+            tr.has_learned_parameters = lambda c: True
+        t = tr.tables[cname]
+        counts_before = t.counts[:t.n].copy()
+        latent_sweep(eng, tr, cname, cfg, 7, 0)
+        assert np.array_equal(tr.tables[cname].counts[:len(counts_before)], counts_before)  # own sweep: counts untouched
+        out[mode] = (cname, tr.tables[cname].strength, tr.tables[cname].discount)
+    assert out["one_batch"] == out["cut"], out
