@@ -80,3 +80,56 @@ def test_prefilter_never_drops_a_candidate_that_carries_weight(oracle):
         # and the log-sum-exp / prefix of the survivors alone are those of the full enumeration
         assert w[surv].sum() == w.sum()
     assert n_dropped > 0.9 * n_checked  # with a tight bound the filter removes almost everything
+
+
+def test_block_minimum_level_keeps_every_candidate_within_the_cut(oracle):
+    """The coarse level of the scan (root_wave.hip: compact_min_kernel + the block list): a block of 64 candidates is
+    read only if the sum of its three per-row minima is within the cut-off.  Every candidate within the cut-off lies in
+    such a block (its own bytes bound the minima from above), so the two-level scan finds exactly the survivors of the
+    streamed rows — for any tables, any cut-off, padding and dead rows included."""
+    rng = np.random.default_rng(11)
+    for trial in range(200):
+        n = int(rng.integers(1, 700))
+        kpad = (n + 15) & ~15
+        rows = np.minimum(rng.integers(0, 60, size=(3, kpad)), PRE_CLAMP).astype(np.int64)
+        rows[:, n:] = 0                                   # padding bytes are 0 (compact_pair_kernel)
+        near = rng.integers(0, n, size=rng.integers(0, 4))
+        rows[:, near] = rng.integers(0, 4, size=(3, len(near)))  # a few genuinely close candidates
+        alive = np.zeros(kpad, dtype=bool)
+        alive[:n] = rng.random(n) < 0.9
+        cut = int(rng.integers(0, CUT_ALL + 1))
+        want = np.nonzero((rows.sum(0) <= cut) & alive)[0]
+        kblk = (kpad + 63) >> 6
+        got = []
+        for kb in range(kblk):
+            blk = rows[:, 64 * kb:64 * kb + 64]
+            if blk.min(1).sum() > cut:                     # the three minima of the block
+                continue
+            k = np.arange(64 * kb, min(64 * kb + 64, kpad))
+            got.extend(k[(blk.sum(0) <= cut) & alive[k]].tolist())
+        assert np.array_equal(np.array(got, dtype=want.dtype), want)  # same set, ascending order
+
+
+def test_a_total_of_one_unit_decides_every_draw(oracle):
+    """The decided-group shortcut (root_wave.hip): when the fixed-point total of a list is exactly one unit, all entries
+    but one have weight 0 (the maximum alone weighs one unit), so min{k : prefix_k > x} is the same k for every
+    x in [0, U) — whatever Philox would have produced."""
+    rng = np.random.default_rng(3)
+    one = 1 << 40
+    hits = 0
+    for trial in range(2000):
+        n = int(rng.integers(1, 6))
+        s = rng.normal(0, 25, size=n)
+        if rng.random() < 0.5:
+            s[rng.integers(0, n)] += 60.0
+        w = _fixw(oracle, s - s.max())
+        U = int(w.sum())
+        if U != one:
+            continue
+        hits += 1
+        assert (w > 0).sum() == 1 and int(w.max()) == one
+        prefix = np.cumsum(w.astype(object))
+        first = int(np.argmax(w > 0))
+        for x in (0, 1, one // 2, one - 1):
+            assert int(np.argmax(prefix > x)) == first
+    assert hits > 500
