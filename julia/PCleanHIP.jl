@@ -105,6 +105,19 @@ function sweep_latent!(c, cfg, seed, sweep_idx, block, roots::Vector{Int32}, key
         c.h, cc, seed, sweep_idx, block, length(roots), roots, n, keys, ev_off, ev_rows, ctxp, excl, chosen, vals))
     chosen, vals
 end
+# per-candidate scores of ONE plan node of a latent plan against evidence sets (parity checks: what the generated proposal
+# of proposal_compiler.jl:306-350 accumulates for every candidate); scores[:, i] over the node's candidates (+ new row)
+function score_node_ev(c, block, node, keys::Vector{Int32}, ev_off::Vector{Int32}, ev_rows::Vector{Int32},
+                       ev_ctx::Union{Nothing,Matrix{Int32}}, excl::Union{Nothing,Vector{Int32}}, n_cand)
+    n = length(keys); lse = zeros(Float64, n); scores = zeros(Float64, n_cand, n)
+    ctxp = ev_ctx === nothing ? Ptr{Int32}(C_NULL) : pointer(ev_ctx)
+    exp_ = excl === nothing ? Ptr{Int32}(C_NULL) : pointer(excl)
+    GC.@preserve keys ev_off ev_rows ev_ctx excl lse scores check(c, ccall((:pclean_score_node_ev, lib), Cint,
+        (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, UInt64, UInt32, Int32,
+         Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+        c.h, block, node, n, keys, ev_off, ev_rows, ctxp, exp_, 0, 0, 0, lse, scores, C_NULL))
+    lse, scores
+end
 function random_string_prior_at(c, seeds::Vector{UInt64}, elems::Vector{UInt32}, lo, hi, init_p, trans_p)
     n = length(seeds); out = zeros(UInt8, hi, n); len = Vector{Int32}(undef, n)
     GC.@preserve seeds elems init_p trans_p out len check(c, ccall((:pclean_random_string_prior_at, lib), Cint,
