@@ -135,3 +135,49 @@ def test_literal_densities_match_kats():
     assert lit.string_prior_logpdf("al", 3, 30) == -np.inf
     assert abs(lit.string_prior_logpdf("2053258100", 10, 10) - (-33.322045101752)) < 1e-10
     assert lit.damerau_levenshtein("ca", "abc") == 2 and lit.damerau_levenshtein("ca", "abc", restricted=True) == 3
+
+
+def test_prior_proposal_weights_equal_the_literal_likelihood(oracle):
+    """use_dd_proposals = false (block_proposal.jl:42-56,68-84,168): a particle draws its referents from the CRP prior and
+    its weight is the likelihood of the row's observations given the drawn values.  One particle, no current referents
+    (initialisation mode): the sweep's log marginal likelihood estimate of a row is that particle's weight — the sum,
+    over the blocks, of the AddTypos densities of the observed strings given the CHOSEN referents' strings, which the
+    literal interpreter evaluates from the model description and the strings alone (its own Damerau-Levenshtein and
+    negative-binomial).  Checked for every row whose particle chose existing referents in both blocks (a drawn NEW
+    referent's sampled values are covered by the bit-exact HIP-vs-oracle tests)."""
+    import literal as lit
+    from oracle_engine import OracleEngine
+    from pclean_amd.engine import InferenceConfig
+    S = helpers.hospital_setup()
+    lw, tr, dirty, m, q = S["lw"], S["trace"], S["dirty"], S["model"], S["query"]
+    ocls = m.classes[q.cls]
+    lt = lit.lit_trace_from(lw, tr)
+    eng = OracleEngine(oracle, lw, S["obs"])
+    cur = tr.cur.copy()
+    tr.cur[:] = -1  # no retained particle: every particle is a prior draw
+    try:
+        choice, chosen, logml, new_rows = eng.sweep(tr, InferenceConfig(1, 1, use_dd_proposals=False), 21, 0, 0, 300)
+    finally:
+        tr.cur[:] = cur
+    blocks = [b for b in ocls.blocks]
+    checked = 0
+    for i in range(300):
+        if (choice[:, i] < 0).any():
+            continue
+        obs = {q.obsmap[c]: dirty[c][i] for c in q.obsmap}
+        vals_of = {}
+        for bi, battrs in enumerate(blocks):
+            fk = [a for a in battrs if ocls.attr(a).kind == "fk"][0]
+            bp0 = lit.BlockProposal.__new__(lit.BlockProposal)
+            bp0.trace, bp0.model = lt, m
+            for p, v in bp0._flat(ocls.attr(fk).target, int(choice[bi, i])).items():
+                vals_of[fk + "." + p] = v
+        want = 0.0
+        for bi, battrs in enumerate(blocks):
+            fk = [a for a in battrs if ocls.attr(a).kind == "fk"][0]
+            bp = lit.BlockProposal(lt, q, battrs, obs, vals_of, restricted=False)
+            own = {p[len(fk) + 1:]: v for p, v in vals_of.items() if p.startswith(fk + ".")}
+            want += sum(bp._lik(t, own) for t in bp.terms if t["obs"] is not None)
+        assert abs(logml[i] - want) <= 1e-10 * max(1.0, abs(want)), (i, logml[i], want)
+        checked += 1
+    assert checked > 200
