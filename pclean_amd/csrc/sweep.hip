@@ -1581,7 +1581,7 @@ static int ensure_agg(pclean_ctx* ctx, int block_id, int node_id, const ItemList
   AggPack pack{};
   AggDev* dst = (AggDev*)scratch<unsigned char>(ctx, sizeof(AggDev) * PCLEAN_MAX_TERMS);
   if (!dst) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-  if (n_ev > 0 && s->lat_max_ev <= AGG_LDS_CAP && n.n_terms <= PCLEAN_MAX_TERMS && !ctx->no_item_agg) {
+  if (n_ev > 0 && s->lat_max_ev <= AGG_LDS_CAP && n.n_terms > 0 && n.n_terms <= PCLEAN_MAX_TERMS && !ctx->no_item_agg) {
     AggTermArgs at{};
     for (int ti = 0; ti < n.n_terms; ++ti) {
       const pclean_term& tm = b.terms[n.term_begin + ti];
