@@ -109,6 +109,7 @@ extern "C" int pclean_load_columns(pclean_ctx* ctx, int32_t n_rows, int32_t n_co
   if (n) HIPCHK(ctx, hipMemcpy(ctx->obs.p, obs, n * sizeof(int32_t), hipMemcpyHostToDevice));
   ctx->n_rows = n_rows;
   ctx->n_cols = n_cols;
+  ++ctx->obs_version;
   ctx->col_has_missing.assign(n_cols, 0);
   for (int c = 0; c < n_cols; ++c)
     for (int i = 0; i < n_rows; ++i)

@@ -132,6 +132,7 @@ struct pclean_ctx {
   // observed columns
   int32_t n_rows = 0, n_cols = 0;
   DevBuf<int32_t> obs;  // [n_cols][n_rows]
+  uint64_t obs_version = 0;  // bumped by every pclean_load_columns (keys the static per-row tuple ids, sweep.hip)
   std::vector<char> col_has_missing;  // per observed column: some row holds an explicitly missing value (-1)
   DevBuf<int32_t> iota; // identity column for per-unique-value leaf caches
   int32_t n_xcols = 0;

@@ -1193,7 +1193,12 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
       return pclean_fail(ctx, PCLEAN_ERR_HIP, "alloc");
     NodeDev nd;
     ctx->obs_override = io.p;
+    // the cache holds the DATA-DRIVEN marginal whatever the running sweep proposes from: build_node_dev drops a node's
+    // terms in prior mode (use_dd_proposals = false), which must never reach a cache keyed by table versions alone
+    const bool prior_saved = ctx->prior_mode;
+    ctx->prior_mode = false;
     int rc = build_node_dev(ctx, b, node_id, nd);
+    ctx->prior_mode = prior_saved;
     ctx->obs_override = nullptr;
     if (rc) return rc;
     ItemsDev it{U + 1, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
@@ -1564,6 +1569,22 @@ __global__ void write_agg_kernel(AggPack p, int n, AggDev* dst) {
   if (i < n) dst[i] = p.a[i];
 }
 
+// A per-evidence-row ctx value occupies 16 bits of an aggregation key (agg_key_kernel / agg_item_kernel): its domain
+// (the ctx side of the term's fn table, or the error-probability table of a MaybeSwap term) must stay below 2^16 or runs
+// of different values would alias.
+static int agg_ctx_fits(pclean_ctx* ctx, const pclean_term& tm, int ctx_slot) {
+  if (ctx_slot < 0) return PCLEAN_OK;
+  int64_t dom = 0;
+  if (tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP)
+    dom = ctx->n_prob;
+  else if (tm.fn_table >= 0 && tm.fn_table < PCLEAN_MAX_TABLES && ctx->fn[tm.fn_table].valid)
+    dom = tm.ctx_mode == 2 ? ctx->fn[tm.fn_table].n_b : ctx->fn[tm.fn_table].n_a;
+  if (dom >= (1 << 16))
+    return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "evidence aggregation: a per-evidence-row ctx domain of %lld values does not "
+                                                 "fit the 16 key bits", (long long)dom);
+  return PCLEAN_OK;
+}
+
 // Aggregated evidence of every term of node `node_id` over the original items of the running
 // pclean_sweep_latent call; built once per (call, node).
 static int ensure_agg(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const AggDev** out) {
@@ -1590,6 +1611,7 @@ static int ensure_agg(pclean_ctx* ctx, int block_id, int node_id, const ItemList
       if (pt.valid && pt.n_obs + 1 >= (1 << 24)) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "observed domain too large for the evidence keys");
       const int ctx_slot = (tm.ctx_slot >= 0 && tm.ctx_mode != 0) ? tm.ctx_slot : -1;
       if (ctx_slot >= 0 && !il.ev_ctx) return pclean_fail(ctx, PCLEAN_ERR_ARG, "term %d needs per-evidence-row ctx", n.term_begin + ti);
+      { const int rck = agg_ctx_fits(ctx, tm, ctx_slot); if (rck) return rck; }  // (16 key bits per ctx value)
       at.obs_col[ti] = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows;
       at.ctx_slot[ti] = ctx_slot;
       at.uniq[ti] = scratch<uint64_t>(ctx, (size_t)n_ev);
@@ -1613,6 +1635,7 @@ static int ensure_agg(pclean_ctx* ctx, int block_id, int node_id, const ItemList
     if (pt.valid && pt.n_obs + 1 >= (1 << 24)) return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "observed domain too large for the evidence keys");
     const int ctx_slot = (tm.ctx_slot >= 0 && tm.ctx_mode != 0) ? tm.ctx_slot : -1;
     if (ctx_slot >= 0 && !il.ev_ctx) return pclean_fail(ctx, PCLEAN_ERR_ARG, "term %d needs per-evidence-row ctx", n.term_begin + ti);
+      { const int rck = agg_ctx_fits(ctx, tm, ctx_slot); if (rck) return rck; }  // (16 key bits per ctx value)
     const size_t ne = (size_t)std::max(n_ev, 1);
     uint64_t* key = scratch<uint64_t>(ctx, ne);
     uint64_t* key_s = scratch<uint64_t>(ctx, ne);
@@ -2159,7 +2182,7 @@ static int ensure_tuple_ids(pclean_ctx* ctx, int block_id, int node_id, const st
                             int n_pre, const int32_t** tuple_id, const uint32_t** pre_hash) {
   SweepState* s = st(ctx);
   SweepState::TupleIds& t = s->tuple_ids[block_id * 64 + node_id];
-  uint64_t sig = (uint64_t)ctx->n_rows * 0x9e3779b97f4a7c15ull + (uint64_t)(uintptr_t)ctx->obs.p;
+  uint64_t sig = (uint64_t)ctx->n_rows * 0x9e3779b97f4a7c15ull + (uint64_t)(uintptr_t)ctx->obs.p + ctx->obs_version * 0xd6e8feb86659fd93ull;
   for (int c : cols) sig = sig * 1000003ull + (uint64_t)(c + 1);
   for (int q = 0; q < n_pre; ++q) sig = sig * 1000003ull + (uint64_t)(pre_cols[q] + 7);
   if (t.sig != sig || !t.id.p) {
@@ -3234,6 +3257,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     const int rcb = begin_call(ctx);
     if (rcb) return rcb;
   }
+  struct PriorModeGuard {  // no exit of this call (error returns included) leaves the context in prior mode
+    pclean_ctx* c;
+    ~PriorModeGuard() { c->prior_mode = false; }
+  } prior_guard{ctx};
   if (!s->ev0) {
     HIPCHK(ctx, hipEventCreate(&s->ev0));
     HIPCHK(ctx, hipEventCreate(&s->ev1));
@@ -3437,10 +3464,11 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     static const bool eager_all = getenv("PCLEAN_EAGER_NEW") != nullptr;
     // A chosen ProposalDummyValue changes its particle's weight (apply_dummy_corrections): where one can be drawn
     // every NEW slot is sampled before the final choice.
-    bool drawable = false;
-    rc = block_dummy_drawable(ctx, bi, &drawable);
-    if (rc) return rc;
-    if (prior_mode) drawable = true;  // (prior draws of a StringPrior choice are the dummy almost surely)
+    bool drawable = prior_mode;  // (prior draws of a StringPrior choice are the dummy almost surely)
+    if (!prior_mode) {
+      rc = block_dummy_drawable(ctx, bi, &drawable);
+      if (rc) return rc;
+    }
     r.lazy_new = bi == n_blocks - 1 && !eager_all && !drawable;
     if (r.lazy_new) n_new = 0;  // nothing sampled now
     if (r.vals.alloc(std::max<size_t>((size_t)n_new * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");

@@ -642,6 +642,9 @@ class LoweredModel:
                     if isinstance(a.dist, TimePrior):
                         dspec = _lib.DUMMY_TIME_PRIOR
                     else:
+                        if not (0 <= int(a.dist.min_len) <= 255 and 0 <= int(a.dist.max_len) <= 255):
+                            raise NotImplementedError(f"{cname}.{a.name}: StringPrior lengths beyond 255 do not fit the "
+                                                      "dummy specification (device draws use DUMMY_MAX_LEN = 255)")
                         dspec = _lib.DUMMY_STRING_PRIOR | (int(a.dist.min_len) << 8) | (int(a.dist.max_len) << 16)
                 blk["nodes"].append((_lib.NODE_LEAF, self.option_id[(cname, a.name)], ltb, n_leaf_terms, 0, 0, nid, -1,
                                      cacheable, 0, dval, dspec))

@@ -173,9 +173,13 @@ def test_use_dd_proposals_false_prior_proposals(oracle):
                         oracle.lib().pco_new_rows_get(b, nn, oracle._p(orows, C.c_int32), oracle._p(ovals, C.c_int32))
                     g = new_rows.get(b, (np.zeros(0, np.int32), np.zeros((0, nn), np.int32)))
                     assert np.array_equal(g[0], orows) and np.array_equal(g[1], ovals), (nb, P, mh, b)
-            # the data-driven sweep gives different draws (same seed): the flag really switches the proposal
+            # the data-driven sweep gives different draws (same seed): the flag really switches the proposal — and it
+            # equals the oracle's data-driven sweep: nothing the prior-proposal sweeps built (option-list caches keyed
+            # by table versions) leaks into it (advisor r3)
             dd = eng.sweep(tr, InferenceConfig(1, 6), 77, 3)
             assert not np.array_equal(dd[2], logml)
+            och, ocp, oml = _oracle_sweep(oracle, world, InferConfig(1, 6, 1, 1, 0, 50, 100), 77, 3, tr.cur)
+            assert np.array_equal(dd[0], och) and np.array_equal(dd[1], ocp) and np.array_equal(dd[2], oml), nb
         finally:
             eng.close()
     R = helpers.rents_setup(n_rows=60)
