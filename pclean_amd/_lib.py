@@ -67,6 +67,19 @@ class RootStats(C.Structure):
                 ("resolved_groups", C.c_int32)]
 
 
+class CommitSlot(C.Structure):
+    _fields_ = [("table_id", C.c_int32), ("n_hw", C.c_int32), ("n_free", C.c_int32), ("cols_changed", C.c_int32),
+                ("created", C.c_int32), ("deleted", C.c_int32), ("total", C.c_int64), ("live", C.c_int64),
+                ("max_count", C.c_int64)]
+
+
+class CommitSummary(C.Structure):
+    _fields_ = [("fallback", C.c_int32), ("n_changed", C.c_int32), ("n_slots", C.c_int32), ("pad", C.c_int32),
+                ("n_records", C.c_int32 * 16), ("n_distinct", C.c_int32 * 16), ("slot", CommitSlot * 16)]
+
+
+COMMIT_FB_RECORDS, COMMIT_FB_DUMMY, COMMIT_FB_CAPACITY = 1, 2, 4
+
 TERM_DTYPE = np.dtype([("obs_col", "<i4"), ("cand_col", "<i4"), ("pair_table", "<i4"), ("dens_kind", "<i4"),
                        ("max_typos", "<i4"), ("ctx_slot", "<i4"), ("fn_table", "<i4"), ("ctx_mode", "<i4")])
 NODE_DTYPE = np.dtype([("kind", "<i4"), ("table", "<i4"), ("term_begin", "<i4"), ("n_terms", "<i4"),
@@ -373,14 +386,22 @@ class HipContext:
                                                         _p(out, C.c_int32)), "pclean_random_time_prior")
         return out
 
+    def table_shape(self, table_id):
+        """(rows, columns) of a candidate table as the library holds it (a latent table uploaded with spare capacity
+        for the device-resident commit has more rows than the trace's table)"""
+        nr, nc = C.c_int32(), C.c_int32()
+        check(self.h, self.lib.pclean_table_shape(self.h, C.c_int32(table_id), C.byref(nr), C.byref(nc)), "pclean_table_shape")
+        return nr.value, nc.value
+
     def get_table_priors(self, table_id, n_rows, is_options=False):
-        full = np.empty(n_rows, dtype=np.float64)
-        m1 = np.empty(n_rows, dtype=np.float64)
+        cap = max(self.table_shape(table_id)[0], n_rows)
+        full = np.empty(cap, dtype=np.float64)
+        m1 = np.empty(cap, dtype=np.float64)
         scal = np.empty(4, dtype=np.float64)
         check(self.h, self.lib.pclean_get_table_priors(self.h, C.c_int32(table_id), _p(full, C.c_double),
                                                        None if is_options else _p(m1, C.c_double),
                                                        _p(scal, C.c_double)), "pclean_get_table_priors")
-        return full, m1, scal
+        return full[:n_rows], m1[:n_rows], scal
 
     def load_block(self, block_id, nodes, terms, children, colmap, ctx_src_block=(), ctx_src_col=()):
         nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
@@ -530,11 +551,12 @@ class HipContext:
     def allreduce_stats_fused(self, table_ids, n_rows, local_is_zero=False):
         """One RCCL all-reduce of the concatenated delta counts of `table_ids`; returns the list of summed vectors."""
         ids = np.ascontiguousarray(table_ids, dtype=np.int32)
-        out = np.zeros(int(sum(n_rows)), dtype=np.int64)
+        caps = [self.table_shape(int(t))[0] for t in ids]  # (the library's tables may hold spare capacity)
+        out = np.zeros(int(sum(caps)), dtype=np.int64)
         check(self.h, self.lib.pclean_allreduce_stats_fused(self.h, C.c_int32(len(ids)), _p(ids, C.c_int32),
                                                             C.c_int32(int(local_is_zero)), _p(out, C.c_int64)),
               "pclean_allreduce_stats_fused")
-        return np.split(out, np.cumsum(n_rows)[:-1])
+        return [part[:n] for part, n in zip(np.split(out, np.cumsum(caps)[:-1]), n_rows)]
 
     def comm_destroy(self):
         check(self.h, self.lib.pclean_comm_destroy(self.h), "pclean_comm_destroy")
@@ -561,9 +583,73 @@ class HipContext:
         return rows, vals
 
     def get_stats(self, table_id, n_rows):
-        out = np.zeros(n_rows, dtype=np.int64)
+        out = np.zeros(max(self.table_shape(table_id)[0], n_rows), dtype=np.int64)
         check(self.h, self.lib.pclean_get_stats(self.h, C.c_int32(table_id), _p(out, C.c_int64)), "pclean_get_stats")
+        return out[:n_rows]
+
+    # -- device-resident commit (include/pclean_hip.h) -------------------------------------------------------------
+    def commit_enable(self, n_blocks):
+        """(supported, reason)"""
+        ok = C.c_int32()
+        check(self.h, self.lib.pclean_commit_enable(self.h, C.c_int32(n_blocks), C.byref(ok)), "pclean_commit_enable")
+        return bool(ok.value), ("" if ok.value else self.lib.pclean_last_error(self.h).decode())
+
+    def commit_tables(self):
+        n = C.c_int32()
+        ids = np.zeros(16, dtype=np.int32)
+        check(self.h, self.lib.pclean_commit_n_slots(self.h, C.byref(n), _p(ids, C.c_int32)), "pclean_commit_n_slots")
+        return [int(t) for t in ids[:n.value]]
+
+    def commit_set_table_state(self, table_id, n_hw, free):
+        free = np.ascontiguousarray(free, dtype=np.int32)
+        check(self.h, self.lib.pclean_commit_set_table_state(self.h, C.c_int32(table_id), C.c_int32(n_hw), C.c_int32(len(free)),
+                                                             _p(free, C.c_int32) if len(free) else None),
+              "pclean_commit_set_table_state")
+
+    def commit_device(self, n_blocks, sweep_idx):
+        out = CommitSummary()
+        check(self.h, self.lib.pclean_commit_device(self.h, C.c_int32(n_blocks), C.c_uint32(sweep_idx), C.byref(out)),
+              "pclean_commit_device")
         return out
+
+    def commit_pull_table(self, table_id):
+        """(state words, cols [n_cols][cap], counts, live, free stack, origin [cap][4]) of a latent table's device state"""
+        cap, nc = self.table_shape(table_id)
+        state = np.zeros(8, dtype=np.int32)
+        cols = np.zeros((nc, cap), dtype=np.int32)
+        counts = np.zeros(cap, dtype=np.int64)
+        live = np.zeros(cap, dtype=np.uint8)
+        free = np.zeros(cap, dtype=np.int32)
+        origin = np.zeros((cap, 4), dtype=np.int32)
+        check(self.h, self.lib.pclean_commit_pull_table(self.h, C.c_int32(table_id), _p(state, C.c_int32), _p(cols, C.c_int32),
+                                                        _p(counts, C.c_int64), _p(live, C.c_uint8), _p(free, C.c_int32),
+                                                        _p(origin, C.c_int32)), "pclean_commit_pull_table")
+        return state, cols, counts, live.astype(bool), free[:state[1]], origin
+
+    def set_cur(self, cur):
+        cur = np.ascontiguousarray(cur, dtype=np.int32)
+        check(self.h, self.lib.pclean_set_cur(self.h, C.c_int32(cur.shape[0]), _p(cur, C.c_int32)), "pclean_set_cur")
+
+    def get_cur(self, n_blocks, n_rows, out=None):
+        out = np.empty((n_blocks, n_rows), dtype=np.int32) if out is None else out
+        assert out.dtype == np.int32 and out.flags.c_contiguous and out.shape == (n_blocks, n_rows)
+        check(self.h, self.lib.pclean_get_cur(self.h, C.c_int32(n_blocks), _p(out, C.c_int32)), "pclean_get_cur")
+        return out
+
+    def drop_cur(self):
+        check(self.h, self.lib.pclean_drop_cur(self.h), "pclean_drop_cur")
+
+    def set_sweep_mode(self, deferred):
+        check(self.h, self.lib.pclean_set_sweep_mode(self.h, C.c_int32(1 if deferred else 0)), "pclean_set_sweep_mode")
+
+    def sweep_fetch(self):
+        check(self.h, self.lib.pclean_sweep_fetch(self.h), "pclean_sweep_fetch")
+
+    def sweep_device_cur(self, cfg, seed, sweep_idx, n_blocks):
+        """pclean_sweep on the device-resident referents (cur == NULL), no output buffers"""
+        check(self.h, self.lib.pclean_set_cur_stride(self.h, C.c_int64(0)), "pclean_set_cur_stride")
+        check(self.h, self.lib.pclean_sweep(self.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep_idx), C.c_int32(n_blocks),
+                                            None, None, None, None), "pclean_sweep")
 
     def stats_device_ptr(self, table_id):
         ptr = C.c_void_p()

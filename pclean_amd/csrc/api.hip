@@ -36,6 +36,7 @@ extern "C" int pclean_ctx_destroy(pclean_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   (void)pclean_comm_destroy(ctx);
+  pclean_commit_state_free(ctx);
   pclean_sweep_state_free(ctx);
   ctx->stats_pack.release();
   ctx->sym.release();
@@ -408,6 +409,11 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
     HIPCHK(ctx, hipMemcpy(t.logc_full.p, t.h_logc_full.data(), n_rows * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(ctx, hipMemcpy(t.logc_m1.p, t.h_logc_m1.data(), n_rows * sizeof(double), hipMemcpyHostToDevice));
   }
+  t.strength = strength;
+  t.discount = discount;
+  t.logc_max = kNegInf;
+  for (double v : t.h_logc_full) t.logc_max = std::max(t.logc_max, v);
+  t.h_mirror_stale = false;
   t.valid = true;
   t.version = ++g_pclean_version;
   if (!keep_cols) t.cols_version = t.version;
@@ -434,6 +440,9 @@ extern "C" int pclean_set_options(pclean_ctx* ctx, int32_t table_id, int32_t n_o
   t.h_vals.assign(values, values + n_options);
   t.is_options_1col = true;
   t.h_logc_full.assign(logp, logp + n_options);
+  t.logc_max = kNegInf;
+  for (int k = 0; k < n_options; ++k) t.logc_max = std::max(t.logc_max, logp[k]);
+  t.h_mirror_stale = false;
   t.h_logc_m1.clear();
   t.h_counts.clear();
   t.scal[0] = t.scal[1] = 0.0;
@@ -608,9 +617,26 @@ extern "C" int pclean_get_table_priors(pclean_ctx* ctx, int32_t table_id, double
   if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || !ctx->cand[table_id].valid)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_get_table_priors: bad arguments");
   CandTable& t = ctx->cand[table_id];
-  if (logc_full) memcpy(logc_full, t.h_logc_full.data(), t.h_logc_full.size() * sizeof(double));
-  if (logc_m1 && !t.is_options) memcpy(logc_m1, t.h_logc_m1.data(), t.h_logc_m1.size() * sizeof(double));
+  if (t.h_mirror_stale && !t.is_options) {  // a device-resident commit moved the counts: read the device arrays
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (logc_full && t.n_rows) HIPCHK(ctx, hipMemcpy(logc_full, t.logc_full.p, (size_t)t.n_rows * sizeof(double), hipMemcpyDeviceToHost));
+    if (logc_m1 && t.n_rows) HIPCHK(ctx, hipMemcpy(logc_m1, t.logc_m1.p, (size_t)t.n_rows * sizeof(double), hipMemcpyDeviceToHost));
+  } else {
+    if (logc_full) memcpy(logc_full, t.h_logc_full.data(), t.h_logc_full.size() * sizeof(double));
+    if (logc_m1 && !t.is_options) memcpy(logc_m1, t.h_logc_m1.data(), t.h_logc_m1.size() * sizeof(double));
+  }
   if (scal4) memcpy(scal4, t.scal, 4 * sizeof(double));
+  return PCLEAN_OK;
+}
+
+/* rows / columns of candidate table `table_id` as the library holds it (a table uploaded with spare capacity for the
+ * device-resident commit has more rows than the trace's table) */
+extern "C" int pclean_table_shape(pclean_ctx* ctx, int32_t table_id, int32_t* n_rows, int32_t* n_cols) {
+  if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || !ctx->cand[table_id].valid)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_table_shape: bad arguments");
+  if (n_rows) *n_rows = ctx->cand[table_id].n_rows;
+  if (n_cols) *n_cols = ctx->cand[table_id].n_cols;
   return PCLEAN_OK;
 }
 

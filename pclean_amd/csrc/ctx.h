@@ -69,6 +69,9 @@ struct CandTable {
   std::vector<int64_t> h_counts;
   std::vector<double> h_logc_full, h_logc_m1;
   DevBuf<int64_t> stats;      // delta reference counts of last sweep
+  double strength = 1.0, discount = 0.0;  // Pitman-Yor parameters of the last upload
+  double logc_max = 0.0;      // FK tables: max over rows of log(count - discount) (-inf for an empty table)
+  bool h_mirror_stale = false;  // the device arrays moved on without the host mirrors (pclean_commit_device)
   double h_lse = 0.0;         // options: log-sum of logp (+1e-9), valid for version h_lse_ver (sweep.hip: subtree_ub)
   uint64_t h_lse_ver = 0;
 };
@@ -160,6 +163,12 @@ struct pclean_ctx {
   pclean_timing timing = {};
   pclean_root_stats root_stats = {};
   int64_t cur_stride = 0;  // pclean_set_cur_stride
+  // device-resident current referents [n_blocks][n_rows] (pclean_set_cur; kept up to date by pclean_commit_device)
+  DevBuf<int32_t> dev_cur;
+  int32_t dev_cur_blocks = 0;
+  bool dev_cur_valid = false;
+  bool defer_outputs = false;   // pclean_set_sweep_mode bit 0
+  void* commit_state = nullptr;  // owned by commit.hip
   const int32_t* obs_override = nullptr;  // sweep.hip: ensure_leaf_cache scores "item t observes value t"
   int32_t active_begin = 0, active_count = -1;  // pclean_set_active_rows window (-1 = all rows)
   bool prior_mode = false;     // sweep.hip: the running sweep proposes from the priors (use_dd_proposals = false)
@@ -198,3 +207,5 @@ int pclean_launch_dist(pclean_ctx* ctx, PairTable& pt, const int32_t* d_obs_ids,
 int pclean_ensure_density(pclean_ctx* ctx, int max_len);
 // sweep.hip
 void pclean_sweep_state_free(pclean_ctx* ctx);
+// commit.hip
+void pclean_commit_state_free(pclean_ctx* ctx);

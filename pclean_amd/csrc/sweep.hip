@@ -23,17 +23,7 @@
 #include "dummy_dev.h"
 #include "enum.h"
 #include "gauss_dev.h"
-
-// ---------------------------------------------------------------------------
-// device-side plan description for resolving values of freshly sampled rows
-struct PlanDev {
-  int32_t n_nodes;
-  const int32_t* kind;          // [n_nodes]
-  const int32_t* const* cols;   // [n_nodes] base pointer of the node's table columns
-  const int32_t* n_rows;        // [n_nodes] column stride
-  const int32_t* colmap_begin;  // [n_nodes]
-  const int32_t* colmap;        // pairs
-};
+#include "sweep_state.h"
 
 __device__ int32_t resolve_new_value(const PlanDev& pl, int node, int col, const int32_t* vals) {
   for (int depth = 0; depth < 16; ++depth) {
@@ -761,102 +751,6 @@ struct ItemList {  // device arrays describing enumeration work items
   int draw_is = 0, draw_ds = 0;  // ItemsDev::draw_is / draw_ds of the draws this list produces
 };
 
-struct BlockRun {  // per-block device state of one sweep
-  DevBuf<int32_t> pchoice, pnewpos, draws, it_ctx, choice, chosen_newpos, vals, locals, moved_flag, new_flag, moved_list,
-      new_list, new_slots;
-  DevBuf<double> lse;
-  int n_new = 0;  // particles of the block that proposed a NEW referent
-  bool lazy_new = false;  // their contents are sampled after the final choice, for the chosen particles only
-  DevBuf<int32_t> plan_kind, plan_nrows, plan_cmb, plan_colmap;
-  DevBuf<const int32_t*> plan_cols;
-  PlanDev plan{};
-  bool plan_ready = false;
-};
-
-struct FastRoot {  // candidate-compact tables of a reference slot (root_wave.hip)
-  std::vector<DevBuf<uint8_t>> comp, clen, cblk;  // cblk: block minima of comp (one byte per 64 candidates)
-  std::vector<uint64_t> ver;
-  DevBuf<double> prior_e, prior_n;
-  DevBuf<uint16_t> alive;
-  DevBuf<uint8_t> zero_row;  // kpad zero bytes (byte row of a missing observation)
-  int disabled = 0;  // > 0: the pre-filter does not pay for this node (most items overflowed): that many evaluations use the generic kernel
-  int backoff = 64;  // length of the next disabled period (doubles every time the retry overflows again)
-  uint64_t cmin_key = 0;  // (lmax, dmax, density-table stride) the cached c_min belongs to
-  double cmin = 0.0;
-  uint64_t prior_ver = 0;
-  int kpad = 0;
-  double logc_max = 0.0;  // max over candidates of log(count - discount)
-};
-
-struct SweepState {
-  FastRoot fast[PCLEAN_MAX_BLOCKS * 64];  // [block * 64 + node]
-  std::vector<DevBuf<unsigned char>> pool;  // scratch buffers, recycled per sweep
-  size_t pool_used = 0;
-  BlockRun run[PCLEAN_MAX_BLOCKS];
-  DevBuf<int32_t> cur, chosen, ancestors, csmc_flag, did;
-  DevBuf<double> w, log_total, logml_inc, logml_acc, logml;
-  DevBuf<unsigned int> counter;
-  DevBuf<int32_t*> arr_ptrs;
-  std::map<int, DevBuf<int32_t>> leaf_iota;  // key = block*256+node
-  std::map<int, uint64_t> leaf_version;
-  int64_t row_offset = 0;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, evs = nullptr, eve = nullptr;
-  // memo tables of option-list marginals (leaf_memo_*): key = block * 64 + node
-  struct LeafMemo {
-    DevBuf<uint64_t> keys;   // [cap][3]
-    DevBuf<double> vals;     // [cap]
-    DevBuf<unsigned int> count;
-    uint64_t ver = 0;
-    int cap = 0;
-  };
-  std::map<int, LeafMemo> memo;
-  struct TupleIds {  // ensure_tuple_ids: key = block * 64 + node
-    DevBuf<int32_t> id;
-    DevBuf<uint32_t> pre;
-    uint64_t sig = 0;
-  };
-  std::map<int, TupleIds> tuple_ids;
-  // evidence of the running pclean_sweep_latent call (ensure_agg)
-  const int32_t* lat_off = nullptr;      // [lat_items + 1] CSR offsets of the original items into the evidence list
-  const int32_t* lat_item_of_pos = nullptr;  // [lat_ev]
-  int lat_items = 0, lat_ev = 0, lat_max_ev = 0;  // (largest evidence set of the call)
-  std::map<int, const AggDev*> lat_agg;  // node -> device array [n_terms]
-  DevBuf<int32_t> tail_counts;      // [2 * PCLEAN_MAX_BLOCKS] number of moved rows / rows with a new referent
-  int32_t* h_counts = nullptr;      // page-locked mirror of tail_counts (+ scratch words)
-  // per-phase HIP-event profile of a sweep (pclean_set_profiling): (phase, start, stop) records
-  bool prof_on = false;
-  std::vector<hipEvent_t> prof_ev;
-  std::vector<int> prof_phase;      // phase id of record r (events 2r, 2r+1)
-  size_t prof_used = 0;
-  std::vector<std::string> prof_names;
-  std::vector<float> prof_ms;
-  std::vector<int32_t> prof_launches;
-  // overflow counters of the compact-table launches of the running call whose re-run needs no read-back
-  // (overflow_lds_kernel in list mode): counted into the statistics / heuristics at the end of the call
-  bool scan_stats_used = false;
-  DevBuf<unsigned int> over_ctr;   // [OVER_SLOTS + STAT_WORDS]: the tail = scan statistics of the timed root launch
-  struct OverRec { int block, node, n_items; bool time_it, leaf; };
-  std::vector<OverRec> over_rec;
-  unsigned int* h_over = nullptr;  // page-locked copy of over_ctr
-  // dummy_correction_kernel: distance matrices of the strings drawn for chosen ProposalDummyValues
-  DevBuf<int16_t> dummy_dp;
-  DevBuf<unsigned int> dummy_ctr;  // [0] matrices handed out by the running launch, [1] set when they ran out
-  bool dummy_used = false;
-  // block 0's root scan of the last pclean_sweep (pclean_debug_root_flags; the scratch stays valid until the next call)
-  const int32_t* dbg_desc = nullptr;
-  const int32_t* dbg_grp_off = nullptr;
-  const int32_t* dbg_members = nullptr;
-  const int32_t* dbg_oflag = nullptr;
-  int dbg_groups = 0, dbg_items = 0;
-};
-
-#define OVER_SLOTS 256
-#define STAT_WORDS (64 * 32)  // scan statistics of the timed root launch: 64 slots, 128 bytes apart
-static SweepState* st(pclean_ctx* ctx) {
-  if (!ctx->sweep_state) ctx->sweep_state = new SweepState();
-  return (SweepState*)ctx->sweep_state;
-}
-
 void pclean_sweep_state_free(pclean_ctx* ctx) {
   if (!ctx->sweep_state) return;
   SweepState* s = (SweepState*)ctx->sweep_state;
@@ -1368,8 +1262,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
                                  leaf ? nullptr : f.prior_e.p, f.prior_n.p, f.alive.p);
     if (rc) return rc;
     f.prior_ver = t.version;
-    f.logc_max = -INFINITY;
-    for (double v : t.h_logc_full) f.logc_max = std::max(f.logc_max, v);
+    f.logc_max = t.logc_max;  // (maintained with the table: pclean_set_table / pclean_set_options / pclean_commit_device)
   }
   // pre-filter: the three terms with the longest latent strings discriminate best; c_min = the
   // smallest density cost of one edit over every (length, distance) the tables hold
@@ -3235,8 +3128,15 @@ static int upload_plan_nodes(pclean_ctx* ctx, int bi, const NodeDev** nds, const
 extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
                             int32_t n_blocks, const int32_t* cur, int32_t* choice, int32_t* chosen_particle,
                             double* logml) {
-  if (!ctx || !cfg || n_blocks <= 0 || n_blocks > PCLEAN_MAX_BLOCKS || !cur)
+  if (!ctx || !cfg || n_blocks <= 0 || n_blocks > PCLEAN_MAX_BLOCKS)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: bad arguments");
+  // cur == NULL: the current referents are the device-resident array of pclean_set_cur / the last pclean_commit_device
+  const bool dev_cur = cur == nullptr;
+  if (dev_cur && (!ctx->dev_cur_valid || ctx->dev_cur_blocks != n_blocks || !ctx->dev_cur.p))
+    return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_sweep: cur == NULL needs pclean_set_cur (device-resident referents)");
+  const bool defer = ctx->defer_outputs;
+  if (defer && (choice || chosen_particle || logml))
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: deferred outputs (pclean_set_sweep_mode) take no per-row output buffers");
   const bool prior_mode = !cfg->use_dd_proposals;
   if (prior_mode)
     for (int b = 0; b < n_blocks; ++b) {
@@ -3274,7 +3174,13 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       s->counter.alloc(4) || s->arr_ptrs.alloc(2 * PCLEAN_MAX_BLOCKS) || s->did.alloc(N) ||
       s->tail_counts.alloc(2 * PCLEAN_MAX_BLOCKS))
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-  if (ctx->cur_stride > 0 && ctx->cur_stride != N) {
+  // cur_base + bi * cur_ld = current referents of block bi over the active window
+  const int32_t* cur_base = s->cur.p;
+  size_t cur_ld = (size_t)N;
+  if (dev_cur) {
+    cur_base = ctx->dev_cur.p + ctx->active_begin;
+    cur_ld = (size_t)ctx->n_rows;
+  } else if (ctx->cur_stride > 0 && ctx->cur_stride != N) {
     if (ctx->cur_stride < N) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: cur stride smaller than the active window");
     for (int b = 0; b < n_blocks; ++b)
       HIPCHK(ctx, hipMemcpyAsync(s->cur.p + (size_t)b * N, cur + (size_t)b * ctx->cur_stride, (size_t)N * 4,
@@ -3282,11 +3188,16 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   } else {
     HIPCHK(ctx, hipMemcpyAsync(s->cur.p, cur, (size_t)N * n_blocks * 4, hipMemcpyHostToDevice, ctx->stream));
   }
+  s->last_cur_base = cur_base;
+  s->last_cur_ld = cur_ld;
+  s->last_N = N;
+  s->last_blocks = n_blocks;
+  s->last_dev_cur = dev_cur;
   (void)hipEventRecord(s->evs, ctx->stream);
   HIPCHK(ctx, hipMemsetAsync(s->w.p, 0, NP * sizeof(double), ctx->stream));           // +0.0
   HIPCHK(ctx, hipMemsetAsync(s->logml_acc.p, 0, (size_t)N * sizeof(double), ctx->stream));
   ctx->timing = pclean_timing{};
-  float hot_ms = 0.f;
+  bool hot_timed = false;
 
   for (int bi = 0; bi < n_blocks; ++bi) {
     Block& b = ctx->block[bi];
@@ -3333,7 +3244,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       continue;
     }
     const int nn = (int)b.nodes.size();
-    const int32_t* cur_b = s->cur.p + (size_t)bi * N;
+    const int32_t* cur_b = cur_base + (size_t)bi * cur_ld;
     if (r.pchoice.alloc(NP) || r.pnewpos.alloc(NP) || r.new_slots.alloc(NP) || r.choice.alloc(N) || r.chosen_newpos.alloc(N) ||
         r.moved_flag.alloc(N) || r.new_flag.alloc(N) || r.moved_list.alloc(N) || r.new_list.alloc(N))
       return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
@@ -3384,11 +3295,8 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       if (r.draws.alloc(NP) || r.lse.alloc(N)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
       rc = eval_node(ctx, bi, 0, il, excl, seed, sweep_idx, P, r.lse.p, r.draws.p, nullptr, nullptr, bi == 0);
       if (rc) return rc;
-      if (bi == 0) {
-        HIPCHK(ctx, hipEventSynchronize(s->ev1));
-        float ms = 0;
-        HIPCHK(ctx, hipEventElapsedTime(&ms, s->ev0, s->ev1));
-        hot_ms += ms;
+      if (bi == 0) {  // (the elapsed time of the launch is read at the end of the call: no synchronisation here)
+        hot_timed = true;
         ctx->timing.hot_kernel_launches += 1;
       }
       ProfScope ps(ctx, "particle_update");
@@ -3543,7 +3451,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   {
     ProfScope ps(ctx, "final_choice_and_outputs");
     DISPATCH_PMAX(P, hipLaunchKernelGGL(final_choice_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p,
-                                        (size_t)1, (size_t)N, use_mh, 1, s->cur.p, seed, sweep_idx,
+                                        (size_t)1, (size_t)N, use_mh, 1, cur_base, seed, sweep_idx,
                                         s->row_offset + ctx->active_begin, s->chosen.p, (double*)nullptr,
                                         s->logml_acc.p, s->logml.p));
     for (int bi = 0; bi < n_blocks; ++bi) {  // deferred new-row contents of the last block (chosen particles only)
@@ -3552,7 +3460,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       if (bb.is_score || !r.lazy_new || r.n_new == 0) continue;
       ProfScope ps2(ctx, "new_row_sampling_chosen");
       const int nn = (int)bb.nodes.size();
-      const int32_t* cur_b = s->cur.p + (size_t)bi * N;
+      const int32_t* cur_b = cur_base + (size_t)bi * cur_ld;
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
       hipLaunchKernelGGL(chosen_new_kernel, grid1(N), dim3(256), 0, ctx->stream, N, s->chosen.p, r.pchoice.p, s->counter.p,
                          r.new_slots.p, r.pnewpos.p);
@@ -3586,8 +3494,9 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       BlockRun& r = s->run[bi];
       Block& bb = ctx->block[bi];
       bb.locals_host.clear();
+      r.locals_rows = 0;
       if (bb.is_score) continue;
-      const int32_t* cur_b = s->cur.p + (size_t)bi * N;
+      const int32_t* cur_b = cur_base + (size_t)bi * cur_ld;
       CandTable& rt = ctx->cand[bb.nodes[0].table];
       HIPCHK(ctx, hipMemsetAsync(rt.stats.p, 0, (size_t)std::max(rt.n_rows, 1) * 8, ctx->stream));
       const int hist_rows = rt.n_rows <= 8192 ? rt.n_rows : 0;
@@ -3608,73 +3517,20 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         hipLaunchKernelGGL(locals_tail_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, gd, r.plan, s->chosen.p,
                            r.pchoice.p, r.pnewpos.p, r.vals.p, (int)bb.nodes.size(), seed, sweep_idx, (uint32_t)bi,
                            s->row_offset + ctx->active_begin, r.locals.p);
-        bb.locals_host.resize((size_t)N * 2);
-        HIPCHK(ctx, hipMemcpyAsync(bb.locals_host.data(), r.locals.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        r.locals_rows = N;
+        if (!defer) {  // (deferred outputs: pclean_get_locals copies them when asked)
+          bb.locals_host.resize((size_t)N * 2);
+          HIPCHK(ctx, hipMemcpyAsync(bb.locals_host.data(), r.locals.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+        }
       }
     }
-    HIPCHK(ctx, hipMemcpyAsync(s->h_counts, s->tail_counts.p, 2 * n_blocks * sizeof(int32_t), hipMemcpyDeviceToHost,
-                               ctx->stream));
     (void)hipEventRecord(s->eve, ctx->stream);
     if (chosen_particle) HIPCHK(ctx, hipMemcpyAsync(chosen_particle, s->chosen.p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (logml) HIPCHK(ctx, hipMemcpyAsync(logml, s->logml.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
-    {
-      const int rco = queue_over_copy(ctx);
-      if (rco) return rco;
-    }
-    s->h_counts[3 * PCLEAN_MAX_BLOCKS] = 0;
-    if (s->dummy_used)
-      HIPCHK(ctx, hipMemcpyAsync(s->h_counts + 3 * PCLEAN_MAX_BLOCKS, s->dummy_ctr.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost,
-                                 ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    apply_over_stats(ctx);
-    if (s->h_counts[3 * PCLEAN_MAX_BLOCKS])
-      return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "pclean_sweep: an observed string longer than %d symbols below a chosen "
-                                                   "dummy value", DUMMY_MAX_LEN);
-    if (choice)
-      for (int bi = 0; bi < n_blocks; ++bi)
-        if (ctx->block[bi].is_score)
-          for (int i = 0; i < N; ++i) choice[(size_t)bi * N + i] = 0;
-
-    // ---- rows whose referent changed and new-row records of the chosen particles -> host (ascending rows)
-    for (int bi = 0; bi < n_blocks; ++bi) {
-      BlockRun& r = s->run[bi];
-      Block& b = ctx->block[bi];
-      const int nn = (int)b.nodes.size();
-      b.new_rows_host.clear();
-      b.new_vals_host.clear();
-      b.moved_rows_host.clear();
-      b.moved_choice_host.clear();
-      if (b.is_score) continue;
-      const int n_moved = s->h_counts[2 * bi], n_newrows = s->h_counts[2 * bi + 1];
-      if (n_moved > 0) {
-        int32_t* ch_d = scratch<int32_t>(ctx, n_moved);
-        if (!ch_d) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-        hipLaunchKernelGGL(gather_moved_kernel, grid1(n_moved), dim3(256), 0, ctx->stream, n_moved, r.moved_list.p,
-                           r.choice.p, ch_d);
-        b.moved_rows_host.resize(n_moved);
-        b.moved_choice_host.resize(n_moved);
-        HIPCHK(ctx, hipMemcpyAsync(b.moved_rows_host.data(), r.moved_list.p, (size_t)n_moved * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(b.moved_choice_host.data(), ch_d, (size_t)n_moved * 4, hipMemcpyDeviceToHost, ctx->stream));
-      }
-      if (n_newrows > 0) {
-        int32_t* rows_d = scratch<int32_t>(ctx, n_newrows);
-        int32_t* vals_d = scratch<int32_t>(ctx, (size_t)n_newrows * nn);
-        if (!rows_d || !vals_d) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-        hipLaunchKernelGGL(gather_new_rows_kernel, grid1(n_newrows), dim3(256), 0, ctx->stream, n_newrows, r.new_list.p,
-                           r.chosen_newpos.p, r.vals.p, nn, s->chosen.p, rows_d, vals_d);
-        b.new_rows_host.resize(n_newrows);
-        b.new_vals_host.resize((size_t)n_newrows * nn);
-        HIPCHK(ctx, hipMemcpyAsync(b.new_rows_host.data(), rows_d, (size_t)n_newrows * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(b.new_vals_host.data(), vals_d, (size_t)n_newrows * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
-      }
-    }
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
-  if (s->prof_on) prof_collect(ctx);
-  float tot = 0;
-  HIPCHK(ctx, hipEventElapsedTime(&tot, s->evs, s->eve));
-  ctx->timing.total_ms = tot;
-  ctx->timing.hot_kernel_ms = hot_ms;
+  s->last_hot_timed = hot_timed;
+  s->outputs_pending = true;
+  s->lists_on_host = false;
   {
     // bytes(row) = sum_b [4 F_b + (K_b+1)(8 F_b + 4)] + 8 P (full enumeration); reported beside the
     // byte model of the implemented algorithm (bench.py)
@@ -3682,6 +3538,116 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     const double F = b0.nodes[0].n_terms, K = ctx->cand[b0.nodes[0].table].n_rows;
     ctx->timing.hot_kernel_alg_bytes = (double)N * (4.0 * F + (K + 1.0) * (8.0 * F + 4.0) + 8.0 * P);
   }
+  if (defer) return PCLEAN_OK;  // nothing read back, no synchronisation: pclean_commit_device / pclean_sweep_fetch finish the call
+  int rcf = pclean_sweep_finish_queue(ctx);
+  if (rcf) return rcf;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  rcf = pclean_sweep_finish_synced(ctx);
+  if (rcf) return rcf;
+  if (choice)
+    for (int bi = 0; bi < n_blocks; ++bi)
+      if (ctx->block[bi].is_score)
+        for (int i = 0; i < N; ++i) choice[(size_t)bi * N + i] = 0;
+  return pclean_sweep_fetch_lists(ctx);
+}
+
+// ---- end of a sweep, in three steps so that a caller with more work for the stream (pclean_commit_device) pays ONE
+// synchronisation for everything -----------------------------------------------------------------------------------
+// 1. queue the small read-backs: moved / new-row counts, overflow statistics, the dummy-arena flag
+int pclean_sweep_finish_queue(pclean_ctx* ctx) {
+  SweepState* s = st(ctx);
+  if (!s->outputs_pending) return PCLEAN_OK;
+  HIPCHK(ctx, hipMemcpyAsync(s->h_counts, s->tail_counts.p, 2 * s->last_blocks * sizeof(int32_t), hipMemcpyDeviceToHost,
+                             ctx->stream));
+  const int rco = queue_over_copy(ctx);
+  if (rco) return rco;
+  s->h_counts[3 * PCLEAN_MAX_BLOCKS] = 0;
+  if (s->dummy_used)
+    HIPCHK(ctx, hipMemcpyAsync(s->h_counts + 3 * PCLEAN_MAX_BLOCKS, s->dummy_ctr.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost,
+                               ctx->stream));
+  return PCLEAN_OK;
+}
+// 2. after the caller's stream synchronisation: statistics, timing, error flags
+int pclean_sweep_finish_synced(pclean_ctx* ctx) {
+  SweepState* s = st(ctx);
+  if (!s->outputs_pending) return PCLEAN_OK;
+  s->outputs_pending = false;
+  apply_over_stats(ctx);
+  if (s->prof_on) prof_collect(ctx);
+  float tot = 0;
+  HIPCHK(ctx, hipEventElapsedTime(&tot, s->evs, s->eve));
+  ctx->timing.total_ms = tot;
+  ctx->timing.hot_kernel_ms = 0.f;
+  if (s->last_hot_timed) {
+    float ms = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    ctx->timing.hot_kernel_ms = ms;
+  }
+  if (s->h_counts[3 * PCLEAN_MAX_BLOCKS])
+    return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "pclean_sweep: an observed string longer than %d symbols below a chosen "
+                                                 "dummy value", DUMMY_MAX_LEN);
+  return PCLEAN_OK;
+}
+// 3. rows whose referent changed and new-row records of the chosen particles -> host (ascending rows); one more
+// synchronisation.  The host commit's input; the device-resident commit never needs it.
+int pclean_sweep_fetch_lists(pclean_ctx* ctx) {
+  SweepState* s = st(ctx);
+  if (s->lists_on_host) return PCLEAN_OK;
+  for (int bi = 0; bi < s->last_blocks; ++bi) {
+    BlockRun& r = s->run[bi];
+    Block& b = ctx->block[bi];
+    const int nn = (int)b.nodes.size();
+    b.new_rows_host.clear();
+    b.new_vals_host.clear();
+    b.moved_rows_host.clear();
+    b.moved_choice_host.clear();
+    if (b.is_score) continue;
+    const int n_moved = s->h_counts[2 * bi], n_newrows = s->h_counts[2 * bi + 1];
+    if (n_moved > 0) {
+      int32_t* ch_d = scratch<int32_t>(ctx, n_moved);
+      if (!ch_d) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      hipLaunchKernelGGL(gather_moved_kernel, grid1(n_moved), dim3(256), 0, ctx->stream, n_moved, r.moved_list.p,
+                         r.choice.p, ch_d);
+      b.moved_rows_host.resize(n_moved);
+      b.moved_choice_host.resize(n_moved);
+      HIPCHK(ctx, hipMemcpyAsync(b.moved_rows_host.data(), r.moved_list.p, (size_t)n_moved * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(b.moved_choice_host.data(), ch_d, (size_t)n_moved * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (n_newrows > 0) {
+      int32_t* rows_d = scratch<int32_t>(ctx, n_newrows);
+      int32_t* vals_d = scratch<int32_t>(ctx, (size_t)n_newrows * nn);
+      if (!rows_d || !vals_d) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      hipLaunchKernelGGL(gather_new_rows_kernel, grid1(n_newrows), dim3(256), 0, ctx->stream, n_newrows, r.new_list.p,
+                         r.chosen_newpos.p, r.vals.p, nn, s->chosen.p, rows_d, vals_d);
+      b.new_rows_host.resize(n_newrows);
+      b.new_vals_host.resize((size_t)n_newrows * nn);
+      HIPCHK(ctx, hipMemcpyAsync(b.new_rows_host.data(), rows_d, (size_t)n_newrows * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(b.new_vals_host.data(), vals_d, (size_t)n_newrows * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  s->lists_on_host = true;
+  return PCLEAN_OK;
+}
+
+// Finish a sweep run with deferred outputs (pclean_set_sweep_mode) the way a plain pclean_sweep call ends: counts,
+// statistics and the moved-row / new-row lists on the host (pclean_get_moved / pclean_get_new_rows / pclean_get_stats).
+extern "C" int pclean_sweep_fetch(pclean_ctx* ctx) {
+  if (!ctx) return PCLEAN_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  int rc = pclean_sweep_finish_queue(ctx);
+  if (rc) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  rc = pclean_sweep_finish_synced(ctx);
+  if (rc) return rc;
+  return pclean_sweep_fetch_lists(ctx);
+}
+
+// bit 0: deferred outputs — pclean_sweep reads nothing back and does not synchronise; pclean_commit_device (or
+// pclean_sweep_fetch) finishes the call.
+extern "C" int pclean_set_sweep_mode(pclean_ctx* ctx, int32_t flags) {
+  if (!ctx || flags < 0 || flags > 1) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_sweep_mode: bad flags");
+  ctx->defer_outputs = (flags & 1) != 0;
   return PCLEAN_OK;
 }
 
@@ -3711,8 +3677,17 @@ extern "C" int pclean_get_moved(pclean_ctx* ctx, int32_t block_id, int32_t* n_ou
 extern "C" int pclean_get_locals(pclean_ctx* ctx, int32_t block_id, int32_t* out) {
   if (!ctx || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid || !out)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_get_locals: bad arguments");
-  const Block& b = ctx->block[block_id];
+  Block& b = ctx->block[block_id];
   const int N = ctx->active_count >= 0 ? ctx->active_count : ctx->n_rows;
+  {
+    BlockRun& r = st(ctx)->run[block_id];
+    if (b.locals_host.empty() && r.locals_rows == N && r.locals.p) {  // a sweep with deferred outputs left them on the device
+      HIPCHK(ctx, hipSetDevice(ctx->device));
+      b.locals_host.resize((size_t)N * 2);
+      HIPCHK(ctx, hipMemcpyAsync(b.locals_host.data(), r.locals.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    }
+  }
   if (b.locals_host.size() == (size_t)N * 2)
     memcpy(out, b.locals_host.data(), (size_t)N * 8);
   else

@@ -1,0 +1,131 @@
+// Per-context state of the sweep entry points (sweep.hip) that other translation units of the library read
+// (commit.hip: the device-resident commit consumes a sweep's device-side outputs).  Not part of the ABI.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "ctx.h"
+#include "enum.h"
+
+// ---------------------------------------------------------------------------
+// device-side plan description for resolving values of freshly sampled rows
+struct PlanDev {
+  int32_t n_nodes;
+  const int32_t* kind;          // [n_nodes]
+  const int32_t* const* cols;   // [n_nodes] base pointer of the node's table columns
+  const int32_t* n_rows;        // [n_nodes] column stride
+  const int32_t* colmap_begin;  // [n_nodes]
+  const int32_t* colmap;        // pairs
+};
+
+
+struct BlockRun {  // per-block device state of one sweep
+  DevBuf<int32_t> pchoice, pnewpos, draws, it_ctx, choice, chosen_newpos, vals, locals, moved_flag, new_flag, moved_list,
+      new_list, new_slots;
+  DevBuf<double> lse;
+  int n_new = 0;  // particles of the block that proposed a NEW referent
+  int locals_rows = 0;  // rows of `locals` the last sweep filled (0: none)
+  bool lazy_new = false;  // their contents are sampled after the final choice, for the chosen particles only
+  DevBuf<int32_t> plan_kind, plan_nrows, plan_cmb, plan_colmap;
+  DevBuf<const int32_t*> plan_cols;
+  PlanDev plan{};
+  bool plan_ready = false;
+};
+
+struct FastRoot {  // candidate-compact tables of a reference slot (root_wave.hip)
+  std::vector<DevBuf<uint8_t>> comp, clen, cblk;  // cblk: block minima of comp (one byte per 64 candidates)
+  std::vector<uint64_t> ver;
+  DevBuf<double> prior_e, prior_n;
+  DevBuf<uint16_t> alive;
+  DevBuf<uint8_t> zero_row;  // kpad zero bytes (byte row of a missing observation)
+  int disabled = 0;  // > 0: the pre-filter does not pay for this node (most items overflowed): that many evaluations use the generic kernel
+  int backoff = 64;  // length of the next disabled period (doubles every time the retry overflows again)
+  uint64_t cmin_key = 0;  // (lmax, dmax, density-table stride) the cached c_min belongs to
+  double cmin = 0.0;
+  uint64_t prior_ver = 0;
+  int kpad = 0;
+  double logc_max = 0.0;  // max over candidates of log(count - discount)
+};
+
+struct SweepState {
+  FastRoot fast[PCLEAN_MAX_BLOCKS * 64];  // [block * 64 + node]
+  std::vector<DevBuf<unsigned char>> pool;  // scratch buffers, recycled per sweep
+  size_t pool_used = 0;
+  BlockRun run[PCLEAN_MAX_BLOCKS];
+  DevBuf<int32_t> cur, chosen, ancestors, csmc_flag, did;
+  // the last pclean_sweep call, for the calls that finish it (pclean_sweep_finish_*, pclean_commit_device)
+  const int32_t* last_cur_base = nullptr;  // current referents of block bi: last_cur_base + bi * last_cur_ld
+  size_t last_cur_ld = 0;
+  int last_N = 0, last_blocks = 0;
+  bool last_dev_cur = false, last_hot_timed = false;
+  bool outputs_pending = false;  // counts / statistics of the last sweep not yet read back
+  bool lists_on_host = false;    // moved-row / new-row lists of the last sweep already copied
+  DevBuf<double> w, log_total, logml_inc, logml_acc, logml;
+  DevBuf<unsigned int> counter;
+  DevBuf<int32_t*> arr_ptrs;
+  std::map<int, DevBuf<int32_t>> leaf_iota;  // key = block*256+node
+  std::map<int, uint64_t> leaf_version;
+  int64_t row_offset = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evs = nullptr, eve = nullptr;
+  // memo tables of option-list marginals (leaf_memo_*): key = block * 64 + node
+  struct LeafMemo {
+    DevBuf<uint64_t> keys;   // [cap][3]
+    DevBuf<double> vals;     // [cap]
+    DevBuf<unsigned int> count;
+    uint64_t ver = 0;
+    int cap = 0;
+  };
+  std::map<int, LeafMemo> memo;
+  struct TupleIds {  // ensure_tuple_ids: key = block * 64 + node
+    DevBuf<int32_t> id;
+    DevBuf<uint32_t> pre;
+    uint64_t sig = 0;
+  };
+  std::map<int, TupleIds> tuple_ids;
+  // evidence of the running pclean_sweep_latent call (ensure_agg)
+  const int32_t* lat_off = nullptr;      // [lat_items + 1] CSR offsets of the original items into the evidence list
+  const int32_t* lat_item_of_pos = nullptr;  // [lat_ev]
+  int lat_items = 0, lat_ev = 0, lat_max_ev = 0;  // (largest evidence set of the call)
+  std::map<int, const AggDev*> lat_agg;  // node -> device array [n_terms]
+  DevBuf<int32_t> tail_counts;      // [2 * PCLEAN_MAX_BLOCKS] number of moved rows / rows with a new referent
+  int32_t* h_counts = nullptr;      // page-locked mirror of tail_counts (+ scratch words)
+  // per-phase HIP-event profile of a sweep (pclean_set_profiling): (phase, start, stop) records
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;
+  std::vector<int> prof_phase;      // phase id of record r (events 2r, 2r+1)
+  size_t prof_used = 0;
+  std::vector<std::string> prof_names;
+  std::vector<float> prof_ms;
+  std::vector<int32_t> prof_launches;
+  // overflow counters of the compact-table launches of the running call whose re-run needs no read-back
+  // (overflow_lds_kernel in list mode): counted into the statistics / heuristics at the end of the call
+  bool scan_stats_used = false;
+  DevBuf<unsigned int> over_ctr;   // [OVER_SLOTS + STAT_WORDS]: the tail = scan statistics of the timed root launch
+  struct OverRec { int block, node, n_items; bool time_it, leaf; };
+  std::vector<OverRec> over_rec;
+  unsigned int* h_over = nullptr;  // page-locked copy of over_ctr
+  // dummy_correction_kernel: distance matrices of the strings drawn for chosen ProposalDummyValues
+  DevBuf<int16_t> dummy_dp;
+  DevBuf<unsigned int> dummy_ctr;  // [0] matrices handed out by the running launch, [1] set when they ran out
+  bool dummy_used = false;
+  // block 0's root scan of the last pclean_sweep (pclean_debug_root_flags; the scratch stays valid until the next call)
+  const int32_t* dbg_desc = nullptr;
+  const int32_t* dbg_grp_off = nullptr;
+  const int32_t* dbg_members = nullptr;
+  const int32_t* dbg_oflag = nullptr;
+  int dbg_groups = 0, dbg_items = 0;
+};
+
+#define OVER_SLOTS 256
+#define STAT_WORDS (64 * 32)  // scan statistics of the timed root launch: 64 slots, 128 bytes apart
+static SweepState* st(pclean_ctx* ctx) {
+  if (!ctx->sweep_state) ctx->sweep_state = new SweepState();
+  return (SweepState*)ctx->sweep_state;
+}
+
+
+// sweep.hip: the three steps that end a sweep (see there)
+int pclean_sweep_finish_queue(pclean_ctx* ctx);
+int pclean_sweep_finish_synced(pclean_ctx* ctx);
+int pclean_sweep_fetch_lists(pclean_ctx* ctx);

@@ -33,6 +33,10 @@ def make_gauss(spec, mean_table_id=0):
     return g
 
 
+def lw_locals(lw):
+    return getattr(lw, "locals", {})
+
+
 def _logsumexp(x):
     m = np.max(x)
     if not np.isfinite(m):
@@ -67,6 +71,7 @@ class Engine:
         self.option_logp = {}
         self._uploaded_shape = {}
         self._last_upload = {}
+        self._dc = None  # state of the device-resident commit (enable_device_commit)
         self._upload_static()
         if row_offset:
             _lib.check(self.hip.h, self.hip.lib.pclean_set_row_offset(self.hip.h, _lib.C.c_int64(row_offset)),
@@ -93,6 +98,7 @@ class Engine:
         self._dev_comm = False
         if getattr(self, "_comm", None) is not None:
             self.init_device_comm(self._comm)
+        self._dc = None  # (a fresh context: the device-resident commit is set up again on demand)
 
     def sample_prior_strings(self, dist, n, seed, stream):
         """n draws of random(StringPrior) (string_prior.jl:28-40: length uniform on [min, max], bigram letters) or
@@ -211,19 +217,38 @@ class Engine:
         lw, hip = self.lw, self.hip
         m = lw.model
         last = self._last_upload
+        dc = getattr(self, "_dc", None)
         for cname, t in trace.tables.items():
             cols, counts = t.view()
-            key = (cname, t.n)
+            cap = t.n
+            if dc is not None and cname in dc["tables"]:
+                # device-resident commit: the table is uploaded with spare rows (count 0: dead candidates, weight exactly 0)
+                # so that the device can create rows without changing any array's shape
+                cap = dc["cap"].get(cname, 0)
+                if t.n + self._slack_min(cname, t) > cap:
+                    cap = dc["cap"][cname] = self._capacity(cname, t)
+                if cap > t.n:
+                    pc = np.zeros((t.n_cols, cap), dtype=np.int32)
+                    pc[:, :t.n] = cols
+                    pk = np.zeros(cap, dtype=np.int64)
+                    pk[:t.n] = counts
+                    cols, counts = pc, pk
+            key = (cname, cap)
             prev = last.get(("table", cname))
+            alloc = (t.n, len(t.free))
             if t.cols_dirty or self._uploaded_shape.get(cname) != key:
                 hip.set_table(lw.table_id[cname], np.ascontiguousarray(cols), counts, t.strength, t.discount)
                 t.cols_dirty = False
                 self._uploaded_shape[cname] = key
-            elif prev is not None and prev[1] == (t.strength, t.discount) and np.array_equal(prev[0], counts):
+            elif prev is not None and prev[1] == (t.strength, t.discount) and np.array_equal(prev[0], counts) \
+                    and (dc is None or cname not in dc["tables"] or dc["alloc"].get(cname) == alloc):
                 continue  # nothing moved in this table
             else:  # only reference counts moved: keep the device columns and their compact byte tables
                 hip.set_table(lw.table_id[cname], None, counts, t.strength, t.discount, n_cols=t.n_cols)
             last[("table", cname)] = (counts.copy(), (t.strength, t.discount))
+            if dc is not None and cname in dc["tables"]:
+                hip.commit_set_table_state(lw.table_id[cname], t.n, t.free)
+                dc["alloc"][cname] = alloc
         for (cname, aname), dom in lw.latent_dom.items():
             d = m.classes[cname].attr(aname).dist
             if isinstance(d, ChooseProportionally):
@@ -281,6 +306,152 @@ class Engine:
             for bi in self.lw.locals:
                 trace.pending_locals[bi] = self.hip.get_locals(bi, hi - lo)
         return choice, chosen, logml, new_rows
+
+    # -- device-resident commit (csrc/commit.hip) ------------------------------------------------------------------
+    def _slack_min(self, cname, t):
+        """spare rows a table needs before the next device commit: twice what the last commits created"""
+        dc = self._dc
+        return max(64, 2 * dc["created"].get(cname, 0) + 16)
+
+    def _capacity(self, cname, t):
+        slack = max(256, t.n // 8, 2 * self._slack_min(cname, t))
+        return -(-(t.n + slack) // 64) * 64
+
+    def enable_device_commit(self, trace, comm=None):
+        """Switch the engine to the device-resident commit of observed-class sweeps (pclean_commit_*): latent tables
+        are uploaded with spare capacity, their allocation state and the observed rows' referents live in HBM and
+        sweep_commit_device() commits a sweep without any per-row read-back.  Returns False (and changes nothing) when
+        the plan / the run is one the device commit does not take: several ranks (the new-row records of the other
+        ranks are exchanged through the host), or a plan shape pclean_commit_enable refuses."""
+        if getattr(self, "_dc", None) is not None:
+            return True
+        if getattr(self, "_dc_refused", False):
+            return False
+        if (comm is not None and comm.world > 1) or self.row_offset:
+            self._dc_refused = True
+            return False
+        lw = self.lw
+        self.upload_trace(trace)  # (the library checks the blocks' tables exist)
+        ok, why = self.hip.commit_enable(len(lw.blocks))
+        if not ok:
+            self._dc_refused, self._dc_why = True, why
+            return False
+        by_id = {tid: c for c, tid in lw.table_id.items()}
+        self._dc = dict(tables=[by_id[t] for t in self.hip.commit_tables()], cap={}, alloc={}, created={}, cur_version=None,
+                        commits=0, fallbacks=0)
+        for cname in self._dc["tables"]:  # re-upload with capacity
+            self._uploaded_shape.pop(cname, None)
+        self.upload_trace(trace)
+        return True
+
+    def _sync_cur(self, trace):
+        dc = self._dc
+        if dc["cur_version"] != (id(trace), trace._cur_version):
+            self.hip.set_cur(trace._cur)
+            dc["cur_version"] = (id(trace), trace._cur_version)
+
+    def sweep_commit_device(self, trace, config, seed, sweep_idx, lo=0, hi=None):
+        """One batched sweep of the observed rows [lo, hi) against the device-resident tables AND its commit on the
+        device: ONE stream synchronisation, a summary comes back.  Returns the number of rows whose referent changed,
+        or None when the device refused the commit (nothing was modified; the sweep's outputs are on the host as after
+        a plain sweep(..., light=True): the caller commits on the host).  The host arrays of `trace` are left alone:
+        the trace is marked as behind the device and pulls the state when something reads it (Trace._sync)."""
+        dc = self._dc
+        cfg = config.as_c() if isinstance(config, InferenceConfig) else config
+        hi = trace._cur.shape[1] if hi is None else hi
+        if trace._dev is None:  # the host arrays are current: the device gets whatever moved since the last upload
+            self.upload_trace(trace)
+            self._sync_cur(trace)
+        elif trace._dev is not self:
+            raise _lib.PCleanHipError("the trace is ahead on another engine")
+        self._empty_sweep = False
+        self.hip.set_active_rows(lo, hi - lo)
+        self.hip.set_sweep_mode(True)
+        try:
+            self.hip.sweep_device_cur(cfg, seed, sweep_idx, len(self.lw.blocks))
+            summ = self.hip.commit_device(len(self.lw.blocks), sweep_idx)
+        finally:
+            self.hip.set_sweep_mode(False)
+        dc["commits"] += 1
+        by_id = {tid: c for c, tid in self.lw.table_id.items()}
+        if summ.fallback:
+            dc["fallbacks"] += 1
+            dc["last_fallback"] = int(summ.fallback)
+            self.hip.sweep_fetch()
+            # tables about to outgrow their capacity get more room at the next upload
+            for bi, blk in enumerate(self.lw.blocks):
+                if not blk.get("score"):
+                    c = blk["root_class"]
+                    dc["created"][c] = max(dc["created"].get(c, 0), int(summ.n_records[bi]))
+            return None
+        for si in range(summ.n_slots):
+            sl = summ.slot[si]
+            c = by_id[sl.table_id]
+            dc["created"][c] = max(int(sl.created), dc["created"].get(c, 0) // 2)
+            dc["alloc"][c] = (int(sl.n_hw), int(sl.n_free))
+        for bi in lw_locals(self.lw):  # own enumerated choices of the chosen particles: host-owned (parameter moves read them)
+            trace._locals[bi][lo:hi] = self.hip.get_locals(bi, hi - lo)
+        trace._dev = self
+        return int(summ.n_changed)
+
+    def fetched_new_rows(self, trace, lo, hi):
+        """new-row records of the last sweep once its outputs are on the host (a refused device commit: pclean_sweep_fetch
+        ran) — what sweep(..., light=True) returns as new_rows; own enumerated choices go to trace.pending_locals"""
+        new_rows = {}
+        for bi, blk in enumerate(self.lw.blocks):
+            if blk.get("score"):
+                continue
+            rows, vals = self.hip.get_new_rows(bi, len(blk["nodes"]))
+            if len(rows):
+                new_rows[bi] = (rows, vals)
+        for bi in lw_locals(self.lw):
+            trace.pending_locals[bi] = self.hip.get_locals(bi, hi - lo)
+        return new_rows
+
+    def pull(self, trace):
+        """Device-resident state -> host arrays of `trace` (called through Trace._sync when something reads a trace that
+        device commits left behind): latent tables with their allocation state, the observed rows' referents, the
+        Dirichlet counts of own choices (recomputed from the tables), the origins of created rows."""
+        lw, dc = self.lw, self._dc
+        for cname in dc["tables"]:
+            t = trace._tables[cname]
+            state, cols, counts, live, free, origin = self.hip.commit_pull_table(lw.table_id[cname])
+            n = int(state[0])
+            if t.cols.shape[1] < n:
+                grow = max(n, 2 * t.cols.shape[1]) - t.cols.shape[1]
+                t.cols = np.concatenate([t.cols, np.zeros((t.n_cols, grow), np.int32)], axis=1)
+                t.counts = np.concatenate([t.counts, np.zeros(grow, np.int64)])
+                t.live = np.concatenate([t.live, np.zeros(grow, bool)])
+            t.cols[:, :n] = cols[:, :n]
+            t.counts[:n] = counts[:n]
+            t.counts[n:] = 0
+            t.live[:n] = live[:n]
+            t.live[n:] = False
+            t.n = n
+            t.free = [int(r) for r in free]
+            t.cols_dirty = False
+            for r in np.flatnonzero(origin[:, 0]):
+                mark = int(origin[r, 0])
+                if mark > 0:
+                    trace._row_origin[(cname, int(r))] = (int(origin[r, 1]), int(origin[r, 2]), int(origin[r, 3]), mark - 1)
+                else:
+                    trace._row_origin.pop((cname, int(r)), None)
+            cap = dc["cap"].get(cname, n)
+            pk = np.zeros(max(cap, n), dtype=np.int64)
+            pk[:n] = counts[:n]
+            self._last_upload[("table", cname)] = (pk if cap > n else pk[:n].copy(), (t.strength, t.discount))
+            dc["alloc"][cname] = (n, len(t.free))
+        if trace._cur.flags.c_contiguous and trace._cur.dtype == np.int32:
+            self.hip.get_cur(trace._cur.shape[0], trace._cur.shape[1], out=trace._cur)  # in place (the array may be page-locked)
+        else:
+            trace._cur[...] = self.hip.get_cur(*trace._cur.shape)
+        dc["cur_version"] = (id(trace), trace._cur_version)
+        for (cname, pname), state in trace._params.items():  # own-choice sufficient statistics (check_consistency's identity)
+            t = trace._tables[cname]
+            rows = np.flatnonzero(t.live[:t.n])
+            for a in lw.model.classes[cname].attrs:
+                if a.kind == "choice" and isinstance(a.dist, ChooseProportionally) and a.dist.param == pname:
+                    state.counts = np.bincount(t.cols[lw.colidx[cname][a.name], rows], minlength=len(state.counts)).astype(np.int64)
 
     def sweep_moved(self):
         """{block: (rows relative to the swept window, new referent)} of the last sweep, rows ascending."""

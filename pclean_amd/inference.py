@@ -28,6 +28,8 @@ from collections import defaultdict as _dd
 from contextlib import contextmanager as _cm
 
 TIMERS = _dd(float)
+# PCLEAN_HOST_COMMIT=1: commit every observed-class sweep on the host (the path of several ranks, of refused device commits)
+DEVICE_COMMIT = not os.environ.get("PCLEAN_HOST_COMMIT")
 
 
 @_cm
@@ -490,12 +492,28 @@ def _sweep_window(engine, trace, config, seed, sweep_idx, b0, b1, comm):
     the rows are block-partitioned over the ranks.  Returns the global number of rows whose referent changed."""
     lo, hi = shard_bounds(b1 - b0, comm.rank, comm.world)
     lo, hi = lo + b0, hi + b0
-    with _timed("observed/upload"):
-        engine.upload_trace(trace)
     light = hasattr(engine, "sweep_moved")  # the HIP engine reports the moved rows: no per-row outputs needed
+    fetched = False
+    if hi > lo and DEVICE_COMMIT and hasattr(engine, "enable_device_commit") and engine.enable_device_commit(trace, comm):
+        # the sweep AND its commit on the device (csrc/commit.hip): tables, counts and referents stay in HBM, the host
+        # arrays of the trace fall behind until something reads them (Trace._sync)
+        with _timed("observed/device_sweep_commit"):
+            changed = engine.sweep_commit_device(trace, config, seed, sweep_idx, lo, hi)
+        if changed is not None:
+            # (no created row holds a ProposalDummyValue — the device refuses such commits — so resample_dummies has
+            # nothing to draw; the commit still counts for the draw streams of later ones)
+            trace.dummy_stamp = getattr(trace, "dummy_stamp", 0) + 1
+            return changed
+        fetched = True  # refused, nothing modified: the sweep's outputs are on the host, the commit runs there
+    if not fetched:
+        with _timed("observed/upload"):
+            engine.upload_trace(trace)
     with _timed("observed/gpu_sweep"):
-        choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi, reuse_buffers=True,
-                                                       **({"light": True} if light else {}))
+        if fetched:
+            choice, chosen, logml, new_rows = None, None, None, engine.fetched_new_rows(trace, lo, hi)
+        else:
+            choice, chosen, logml, new_rows = engine.sweep(trace, config, seed, sweep_idx, lo, hi, reuse_buffers=True,
+                                                           **({"light": True} if light else {}))
     with _timed("observed/stats_moved"):
         stats = engine.sweep_stats_reduced(trace) if hasattr(engine, "sweep_stats_reduced") else None
         reduced = stats is not None  # summed over the ranks on the device (one RCCL all-reduce over xGMI)
@@ -517,7 +535,7 @@ def observed_sweep(engine, trace, config, seed, sweep_idx, comm=None, max_sub_ba
     without learned parameters (hospital's Record) has nothing to resample and is swept in ONE batch
     (sub_batches); max_sub_batches only bounds the number of parameter moves of a class that has some."""
     comm = comm or Comm()
-    n = trace.cur.shape[1]
+    n = trace._cur.shape[1]  # (the shape only: no pull of a trace the device is ahead of)
     changed = 0
     prev = 0
     has_par = trace.has_parameters(engine.lw.query.cls)

@@ -140,8 +140,56 @@ class LatentTable:
         return int(np.sum(self.counts[:self.n] > 0))
 
 
+def _device_synced(name):
+    """Attribute `name` of a Trace whose arrays may be BEHIND the device (Engine.sweep_commit_device commits sweeps in
+    HBM and leaves the host arrays alone): any access first pulls the device state (Engine.pull)."""
+    private = "_" + name
+
+    def get(self):
+        if self._dev is not None:
+            self._sync()
+        if name == "cur":
+            self._cur_version += 1  # (conservative: a reader may write through the array it gets)
+        return getattr(self, private)
+
+    def put(self, value):
+        if self._dev is not None:
+            self._sync()
+        if name == "cur":
+            self._cur_version += 1
+        setattr(self, private, value)
+
+    return property(get, put)
+
+
 class Trace:
+    tables = _device_synced("tables")
+    params = _device_synced("params")
+    row_origin = _device_synced("row_origin")
+    locals = _device_synced("locals")
+    cur = _device_synced("cur")
+
+    def _sync(self):
+        """Bring the host arrays up to date with the device-resident state (no-op when nothing is ahead)."""
+        dev = self._dev
+        if dev is not None:
+            self._dev = None  # (first: the pull itself goes through these attributes)
+            dev.pull(self)
+
+    def __deepcopy__(self, memo):
+        import copy
+        self._sync()
+        new = object.__new__(type(self))
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            # (the lowered model is the program, not trace state: shared, as every engine of the trace shares it)
+            new.__dict__[k] = None if k == "_dev" else (v if k == "lw" else copy.deepcopy(v, memo))
+        return new
+
     def __init__(self, lowered, n_rows, seed=0):
+        self._dev = None       # the Engine whose device state is ahead of the host arrays (None: the host is current)
+        self._cur_version = 0  # bumped by every host access to `cur` (the engine re-uploads the referents when it moved)
+        self.n_rows = n_rows
         self.lw = lowered
         self.rng = np.random.default_rng(seed)
         m = lowered.model
@@ -550,7 +598,7 @@ class Trace:
         """True when pgibbs_sweep!'s move every rejuv_frequency rows (inference.jl:72-77) has anything to resample for
         class cname: a learned parameter declared in it, or Pitman-Yor hyper-parameters of its own table (every
         latent class; the observed class has no table)."""
-        return (cname in self.tables or any(c == cname for c, _ in self.params)
+        return (cname in self._tables or any(c == cname for c, _ in self._params)  # (static keys: no device pull)
                 or (self.prob_param is not None and self.lw.prob_spec["param"][0] == cname)
                 or (self.mean_param is not None and self.lw.gauss_spec["param"][0] == cname))
 
@@ -559,7 +607,7 @@ class Trace:
         of inference.jl:72-77 has to interleave with the row updates).  A class whose only "parameters" are its table's
         Pitman-Yor hyper-parameters is different: their conditional depends on the table's reference counts alone, and
         a sweep of the class's OWN rows changes neither those counts nor the set of rows."""
-        return (any(c == cname for c, _ in self.params)
+        return (any(c == cname for c, _ in self._params)
                 or (self.prob_param is not None and self.lw.prob_spec["param"][0] == cname)
                 or (self.mean_param is not None and self.lw.gauss_spec["param"][0] == cname))
 
