@@ -59,7 +59,10 @@ def test_device_commit_equals_host_commit(program):
         done = refused = 0
         for sweep in range(n_sweeps):
             host = copy.deepcopy(tr)  # (synchronises tr with the device first)
-            # reference sweep: a plain engine, the host trace uploaded without capacity padding
+            # reference sweep: a plain engine, the host trace uploaded afresh without capacity padding (cols_dirty: the
+            # flag is the trace's note to ITS engine; the copy goes to another one)
+            for t in host.tables.values():
+                t.cols_dirty = True
             ref_eng.upload_trace(host)
             _, _, _, ref_new = ref_eng.sweep(host, cfg, 42, sweep, light=True)
             ref_moved = ref_eng.sweep_moved()
