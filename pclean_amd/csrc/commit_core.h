@@ -78,6 +78,7 @@ struct PccTable {
 
 struct PccPlan {  // static description of one block's enumeration plan (include/pclean_hip.h: pclean_node)
   int32_t n_nodes, n_fk_nodes, n_used, track;  // track: the block has option lists with a ProposalDummyValue
+  int32_t exclusive, pad1;               // no other block of the commit can touch the tables of this plan
   int32_t kind[PCC_MAX_NODES];
   int32_t slot[PCC_MAX_NODES];           // FK nodes: table slot; leaves: -1
   int32_t parent[PCC_MAX_NODES];
@@ -117,12 +118,52 @@ struct PccResult {
   int32_t n_changed;             // rows whose referent changed (all blocks)
   int32_t n_records[PCC_MAX_BLOCKS];
   int32_t n_distinct[PCC_MAX_BLOCKS];
+  int32_t n_nested[PCC_MAX_BLOCKS];   // distinct proposals with a nested NEW referent
   int32_t alloc_upper[PCC_MAX_SLOTS];  // rows the commit may create per table (before reuse)
 };
 
 #define PCC_F_FIRST 1
 #define PCC_F_SIMPLE 2
 #define PCC_F_REUSE 4
+
+// part[0..nt) -> exclusive prefix sums, part[nt] = total
+#ifdef PCC_DEVICE
+__device__ void pcc_scan_partials(int32_t* part, int nt, int tid) {  // nt: a multiple of 64, at most 1024
+  __shared__ int32_t wave_total[16];
+  const int lane = tid & 63, w = tid >> 6;
+  const int32_t x = part[tid];
+  int32_t incl = x;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int32_t y = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += y;
+  }
+  if (lane == 63) wave_total[w] = incl;
+  __syncthreads();
+  if (w == 0) {
+    const int nw = nt >> 6;
+    const int32_t v = lane < nw ? wave_total[lane] : 0;
+    int32_t inc = v;
+    for (int o = 1; o < 16; o <<= 1) {
+      const int32_t y = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += y;
+    }
+    if (lane < nw) wave_total[lane] = inc - v;
+    if (lane == nw - 1) part[nt] = inc;
+  }
+  __syncthreads();
+  part[tid] = wave_total[w] + incl - x;
+}
+#else
+static inline void pcc_scan_partials(int32_t* part, int nt, int tid) {
+  int32_t run = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int32_t x = part[t];
+    part[t] = run;
+    run += x;
+  }
+  part[nt] = run;
+}
+#endif
 
 // ---- workgroup-wide exclusive scan of a[0..n) in place; returns the total (uniform) ------------------------------
 // part: nt + 1 words shared by the workgroup.  Each thread owns a contiguous chunk (n is a few thousand).
@@ -135,15 +176,7 @@ PCC_FN int32_t pcc_excl_scan(int32_t* a, int n, int32_t* part, int tid, int nt) 
   PCC_BARRIER();  // (part may still be read by the previous scan's callers)
   part[tid] = s;
   PCC_BARRIER();
-  if (tid == 0) {
-    int32_t run = 0;
-    for (int t = 0; t < nt; ++t) {
-      const int32_t x = part[t];
-      part[t] = run;
-      run += x;
-    }
-    part[nt] = run;
-  }
+  pcc_scan_partials(part, nt, tid);
   PCC_BARRIER();
   int32_t run = part[tid];
   for (int i = lo; i < hi; ++i) {
@@ -282,23 +315,57 @@ PCC_FN void pcc_collect(PccTable* tb, int s0, int32_t* part, int tid, int nt) {
   }
 }
 
+// Proposals without a nested NEW referent: the proposing row keeps its old referent where that row just lost its last
+// reference and holds exactly the proposed values (Trace.materialise_bulk: reuse).  pending_delta: the sweep's delta
+// counts are not applied yet (phase A of a plan whose tables no other block touches: what it sees is what its own
+// apply step will see).  Sets PCC_F_REUSE + newid; scan[j] = 1 for the simple first records that need a fresh row.
+PCC_FN void pcc_mark_reuse(const PccTable* tb, const PccPlan& pl, const PccBlock& b, int k, bool pending_delta, int tid, int nt) {
+  const PccTable& root = tb[pl.used_slot[0]];
+  for (int j = tid; j < k; j += nt) {
+    int32_t fl = b.flags[j];
+    int32_t fresh = 0;
+    if ((fl & PCC_F_FIRST) && (fl & PCC_F_SIMPLE)) {
+      const int32_t* v = pcc_record(b, j);
+      int32_t row[PCC_MAX_NODES];
+      (void)pcc_new_nodes(pl, v, row);
+      const int old = b.cur[b.new_list[j]];
+      bool same = old >= 0 && root.live[old] && root.counts[old] + (pending_delta ? b.delta[old] : 0) == 0;
+      for (int c = 0; c < root.n_cols && same; ++c)
+        same = root.cols[(size_t)c * root.stride + old] == pcc_col_value(tb, pl, v, row, 0, c);
+      if (same) {
+        b.newid[j] = old;
+        b.flags[j] = fl | PCC_F_REUSE;
+      } else {
+        fresh = 1;
+      }
+    }
+    b.scan[j] = fresh;
+  }
+  PCC_BARRIER();
+}
+
 // ---- phase A of one block: group identical records, check what the commit would need; modifies scratch only -------
 PCC_FN void pcc_prepare_block(const PccTable* tb, const PccPlan& pl, const PccBlock& b, int bi, PccResult* res, int tid, int nt) {
   const int k = b.counts2[1];
   if (tid == 0) {
     res->n_records[bi] = k;
     res->n_distinct[bi] = 0;
+    res->n_nested[bi] = 0;
   }
   if (k > b.kcap) {
     if (tid == 0) PCC_OR32(&res->fallback, PCC_FB_RECORDS);
     return;
   }
-  for (int i = tid; i <= b.hmask; i += nt) b.ht[i] = -1;
+  if (k == 0) return;
+  int hm = b.hmask < 63 ? b.hmask : 63;  // hash table of this sweep: the smallest power of two >= 4 k (at most the scratch's)
+  while (hm + 1 < 4 * k && hm < b.hmask) hm = 2 * hm + 1;
+  const uint32_t hmask = (uint32_t)hm;
+  for (int i = tid; i <= hm; i += nt) b.ht[i] = -1;
   PCC_BARRIER();
   // insert: the slot of a class of identical records ends up holding its smallest record index
   for (int j = tid; j < k; j += nt) {
     const int32_t* v = pcc_record(b, j);
-    uint32_t s = pcc_hash(b, v) & (uint32_t)b.hmask;
+    uint32_t s = pcc_hash(b, v) & hmask;
     for (;;) {
       int32_t c = b.ht[s];
       if (c < 0) {
@@ -309,30 +376,33 @@ PCC_FN void pcc_prepare_block(const PccTable* tb, const PccPlan& pl, const PccBl
         PCC_MIN32(&b.ht[s], j);
         break;
       }
-      s = (s + 1) & (uint32_t)b.hmask;
+      s = (s + 1) & hmask;
     }
   }
   PCC_BARRIER();
   for (int j = tid; j < k; j += nt) {
     const int32_t* v = pcc_record(b, j);
-    uint32_t s = pcc_hash(b, v) & (uint32_t)b.hmask;
+    uint32_t s = pcc_hash(b, v) & hmask;
     for (;;) {
       const int32_t c = b.ht[s];
       if (pcc_same(b, pcc_record(b, c), v)) {
         b.rep[j] = c;
         break;
       }
-      s = (s + 1) & (uint32_t)b.hmask;
+      s = (s + 1) & hmask;
     }
     int32_t fl = 0;
     if (b.rep[j] == j) {
       fl = PCC_F_FIRST | PCC_F_SIMPLE;
       int32_t row[PCC_MAX_NODES];
       const uint64_t mask = pcc_new_nodes(pl, v, row);
-      if (mask != 1ull) fl &= ~PCC_F_SIMPLE;  // a nested reference slot proposes a NEW row as well
+      if (mask != 1ull) {  // a nested reference slot proposes a NEW row as well
+        fl &= ~PCC_F_SIMPLE;
+        PCC_ADD32(&res->n_nested[bi], 1);
+      }
       for (int p = 0; p < pl.n_fk_nodes; ++p) {
         const int f = pl.fk_post[p];
-        if ((mask >> f) & 1ull) PCC_ADD32(&res->alloc_upper[pl.slot[f]], 1);
+        if (((mask >> f) & 1ull) && !(f == 0 && pl.exclusive)) PCC_ADD32(&res->alloc_upper[pl.slot[f]], 1);
       }
       for (int l = 0; l < pl.n_nodes; ++l)  // would a created row hold a ProposalDummyValue?
         if (pl.kind[l] == 1 && pl.dummy_val[l] != 0 && ((mask >> pl.parent[l]) & 1ull) && v[l] >= 0 &&
@@ -343,10 +413,17 @@ PCC_FN void pcc_prepare_block(const PccTable* tb, const PccPlan& pl, const PccBl
     b.flags[j] = fl;
   }
   PCC_BARRIER();
+  if (pl.exclusive) {  // the root rows this block really creates: first records that do not keep their old referent
+    pcc_mark_reuse(tb, pl, b, k, true, tid, nt);
+    for (int j = tid; j < k; j += nt)
+      if ((b.flags[j] & PCC_F_FIRST) && !(b.flags[j] & PCC_F_REUSE)) PCC_ADD32(&res->alloc_upper[pl.used_slot[0]], 1);
+    PCC_BARRIER();
+  }
 }
 
 // ---- phase B of one block: apply ------------------------------------------------------------------------------------
-PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, PccResult* res, int32_t* part, int tid, int nt) {
+PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, int bi, PccResult* res, int32_t* part, int tid,
+                            int nt) {
   const int k = b.counts2[1], n_moved = b.counts2[0];
   const int U = pl.n_used;
   PccTable& root = tb[pl.used_slot[0]];
@@ -356,36 +433,18 @@ PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, 
     for (int r = tid; r < n0; r += nt) root.counts[r] += b.delta[r];
     PCC_BARRIER();
   }
-  // 2. proposals without a nested NEW referent: keep the proposing row's old referent where it just lost its last
-  //    reference and holds exactly the proposed values (Trace.materialise_bulk: reuse)
-  for (int j = tid; j < k; j += nt) {
-    int32_t fl = b.flags[j];
-    int32_t fresh = 0;
-    if ((fl & PCC_F_FIRST) && (fl & PCC_F_SIMPLE)) {
-      const int32_t* v = pcc_record(b, j);
-      int32_t row[PCC_MAX_NODES];
-      (void)pcc_new_nodes(pl, v, row);
-      const int old = b.cur[b.new_list[j]];
-      bool same = old >= 0 && root.counts[old] == 0 && root.live[old];
-      for (int c = 0; c < root.n_cols && same; ++c)
-        same = root.cols[(size_t)c * root.stride + old] == pcc_col_value(tb, pl, v, row, 0, c);
-      if (same) {
-        fl |= PCC_F_REUSE;
-        b.newid[j] = old;
-        b.flags[j] = fl;
-      } else {
-        fresh = 1;
-      }
-    }
-    b.scan[j] = fresh;
-  }
-  PCC_BARRIER();
+  if (k > 0) {
+  // 2. proposals without a nested NEW referent that keep the proposing row's old referent (pcc_mark_reuse; a plan with
+  //    tables of its own decided in phase A, which also left scan[j] = needs a fresh root row)
+  if (!pl.exclusive) pcc_mark_reuse(tb, pl, b, k, false, tid, nt);
   const int32_t n_simple = pcc_excl_scan(b.scan, k, part, tid, nt);
   for (int j = tid; j < k; j += nt) b.base[(size_t)j * U] = b.scan[j];
   PCC_BARRIER();
   // 3. proposals with nested NEW referents are created one after the other, after all the others: allocation index
   //    of every record in every table = exclusive scan of the rows it creates there
   int32_t total[PCC_MAX_SLOTS];
+  for (int u = 0; u < U; ++u) total[u] = u == 0 ? n_simple : 0;
+  if (res->n_nested[bi] > 0)
   for (int u = 0; u < U; ++u) {
     for (int j = tid; j < k; j += nt) {
       int32_t c = 0;
@@ -467,6 +526,7 @@ PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, 
     PCC_ADD64(&root.counts[id], 1);
   }
   PCC_BARRIER();
+  }  // k > 0
   // 6. current referents
   for (int m = tid; m < n_moved; m += nt) {
     const int r = b.moved_list[m];
@@ -501,7 +561,7 @@ PCC_FN void pcc_commit(PccTable* tb, int n_slots, const PccPlan* plans, const Pc
     }
   PCC_BARRIER();
   if (res->fallback) return;
-  for (int bi = 0; bi < n_blocks; ++bi) pcc_apply_block(tb, plans[bi], blocks[bi], res, part, tid, nt);
+  for (int bi = 0; bi < n_blocks; ++bi) pcc_apply_block(tb, plans[bi], blocks[bi], bi, res, part, tid, nt);
 }
 
 // ---- host-side construction of a PccPlan from a block's plan arrays (shared by commit.hip and the test harness) ---
@@ -659,6 +719,9 @@ static inline const char* pcc_build_schema(const PccBlockIn* blocks, int n_block
     pl = PccPlan();
     if (pcc_build_plan(b.nodes, b.n_nodes, b.children, sc.slot_of_table, pl)) return "plan shape";
     if (root_seen[pl.used_slot[0]]++) return "two blocks with the same root class";
+    pl.exclusive = 1;
+    for (int u = 0; u < pl.n_used; ++u)
+      if (sc.tables[pl.used_slot[u]].n_blocks_using > 1) pl.exclusive = 0;
   }
   if (sc.n_plans == 0) return "no block with a reference slot";
   return nullptr;

@@ -3499,7 +3499,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       const int32_t* cur_b = cur_base + (size_t)bi * cur_ld;
       CandTable& rt = ctx->cand[bb.nodes[0].table];
       HIPCHK(ctx, hipMemsetAsync(rt.stats.p, 0, (size_t)std::max(rt.n_rows, 1) * 8, ctx->stream));
-      const int hist_rows = rt.n_rows <= 8192 ? rt.n_rows : 0;
+      const int hist_rows = rt.n_rows <= 12288 ? rt.n_rows : 0;  // (48 KB of LDS per workgroup at most)
       hipLaunchKernelGGL(finalize_block_kernel, grid1(N), dim3(256), (size_t)hist_rows * sizeof(int32_t), ctx->stream, N,
                          s->chosen.p, r.pchoice.p, r.pnewpos.p, cur_b, r.choice.p, r.chosen_newpos.p,
                          (unsigned long long*)rt.stats.p, hist_rows, r.moved_flag.p, r.new_flag.p);

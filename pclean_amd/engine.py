@@ -225,6 +225,8 @@ class Engine:
                 # device-resident commit: the table is uploaded with spare rows (count 0: dead candidates, weight exactly 0)
                 # so that the device can create rows without changing any array's shape
                 cap = dc["cap"].get(cname, 0)
+                grown = max(0, t.n - dc["alloc"].get(cname, (t.n, 0))[0])  # what the host added to the high-water mark
+                dc["created"][cname] = max(grown, dc["created"].get(cname, 0))
                 if t.n + self._slack_min(cname, t) > cap:
                     cap = dc["cap"][cname] = self._capacity(cname, t)
                 if cap > t.n:
@@ -309,12 +311,14 @@ class Engine:
 
     # -- device-resident commit (csrc/commit.hip) ------------------------------------------------------------------
     def _slack_min(self, cname, t):
-        """spare rows a table needs before the next device commit: twice what the last commits created"""
+        """spare rows a table needs before the next device commit: a few times what the last commits added to its
+        high-water mark (rows re-created from the free list need no room) — dead candidates cost every scan, so the
+        margin stays small"""
         dc = self._dc
-        return max(64, 2 * dc["created"].get(cname, 0) + 16)
+        return max(64, 4 * dc["created"].get(cname, 0) + 16)
 
     def _capacity(self, cname, t):
-        slack = max(256, t.n // 8, 2 * self._slack_min(cname, t))
+        slack = max(256, t.n // 16, 2 * self._slack_min(cname, t))
         return -(-(t.n + slack) // 64) * 64
 
     def enable_device_commit(self, trace, comm=None):
@@ -378,16 +382,12 @@ class Engine:
             dc["fallbacks"] += 1
             dc["last_fallback"] = int(summ.fallback)
             self.hip.sweep_fetch()
-            # tables about to outgrow their capacity get more room at the next upload
-            for bi, blk in enumerate(self.lw.blocks):
-                if not blk.get("score"):
-                    c = blk["root_class"]
-                    dc["created"][c] = max(dc["created"].get(c, 0), int(summ.n_records[bi]))
-            return None
+            return None  # (a table about to outgrow its capacity gets more room at the next upload: upload_trace)
         for si in range(summ.n_slots):
             sl = summ.slot[si]
             c = by_id[sl.table_id]
-            dc["created"][c] = max(int(sl.created), dc["created"].get(c, 0) // 2)
+            grown = max(0, int(sl.n_hw) - dc["alloc"].get(c, (int(sl.n_hw), 0))[0])  # rows the high-water mark moved
+            dc["created"][c] = max(grown, dc["created"].get(c, 0) // 2)
             dc["alloc"][c] = (int(sl.n_hw), int(sl.n_free))
         for bi in lw_locals(self.lw):  # own enumerated choices of the chosen particles: host-owned (parameter moves read them)
             trace._locals[bi][lo:hi] = self.hip.get_locals(bi, hi - lo)

@@ -11,16 +11,19 @@ def main():
     which = int(sys.argv[3]) if len(sys.argv) > 3 else 1
     rows = list(db.execute("select name, grid_x, workgroup_x, lds_size, vgpr_count, start, end from kernels order by start"))
     idx = [i for i, r in enumerate(rows) if "final_choice_kernel" in r[0]]
+    TAIL = ("finalize_block", "select", "Select", "gather_moved", "gather_new_rows", "locals_tail", "partition", "pcc_commit_kernel",
+            "pcc_refresh_kernel", "init_lookback_scan_state", "chosen_new_kernel", "fillBufferAligned", "copyBuffer")
+
+    def tail_end(i):  # last dispatch of the sweep whose final choice is dispatch i (outputs, device commit)
+        e = i
+        while e + 1 < len(rows) and any(k in rows[e + 1][0] for k in TAIL) and rows[e + 1][5] - rows[e][6] < 400_000:
+            e += 1
+        return e
+
     b = idx[-which]
     a = idx[-which - 1] if len(idx) > which else 0
-    s = a + 1
-    while s < b and "finalize_block_kernel" not in rows[s][0] and "DeviceSelect" not in rows[s][0] and "gather_" not in rows[s][0] \
-            and "select" not in rows[s][0].lower():
-        break
-    # the sweep starts after the previous sweep's tail: first kernel after the last gather/select following final_choice a
-    s = a + 1
-    while s < b and any(k in rows[s][0] for k in ("finalize_block", "select", "Select", "gather_moved", "gather_new_rows", "locals_tail", "partition")):
-        s += 1
+    s = tail_end(a) + 1 if len(idx) > which else 0
+    e = tail_end(b)
     t0 = rows[s][5]
 
     def short(n):
@@ -31,7 +34,7 @@ def main():
     prev_end = None
     tot = 0.0
     agg = {}
-    for r in rows[s:b + 12]:
+    for r in rows[s:e + 1]:
         d = (r[6] - r[5]) / 1e3
         gap = (r[5] - prev_end) / 1e3 if prev_end else 0.0
         prev_end = r[6]
@@ -42,7 +45,7 @@ def main():
         agg[key][1] += d
         if d >= min_us or gap >= min_us:
             print(f"{(r[5] - t0) / 1e3:9.1f}us dur {d:8.1f} gap {gap:7.1f} grid={r[1]:>9} wg={r[2]:>4} lds={r[3]:>6} v={r[4]:>3} {short(r[0])}")
-    print(f"span {(rows[b + 11][6] - t0) / 1e3:.1f} us, kernels {b + 12 - s}, busy {tot:.1f} us")
+    print(f"span {(rows[e][6] - t0) / 1e3:.1f} us, kernels {e + 1 - s}, busy {tot:.1f} us")
     print("-- by kernel:")
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
         print(f"  {v[1]:9.1f} us  x{v[0]:4d}  {k}")
