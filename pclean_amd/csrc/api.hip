@@ -707,6 +707,7 @@ extern "C" int pclean_load_block(pclean_ctx* ctx, int32_t block_id, int32_t n_no
   b.gauss.clear();
   b.node_gauss.assign(n_nodes, -1);
   b.group = -1;
+  b.version = ++g_pclean_version;
   b.valid = true;
   return PCLEAN_OK;
 }

@@ -11,6 +11,14 @@
 #include <cmath>
 
 #define PCC_DEVICE
+// phase clock of the commit kernel (PCLEAN_COMMIT_PROF=1 prints it): thread 0 stamps the constant-rate counter
+__device__ long long pcc_prof_t[64];
+__device__ int pcc_prof_n;
+#define PCC_STAMP(name)                                                   \
+  do {                                                                    \
+    if (tid == 0 && pcc_prof_n < 64) pcc_prof_t[pcc_prof_n++] = (long long)wall_clock64(); \
+  } while (0)
+#define PCC_CUR_SEPARATE
 #include "commit_core.h"
 #include "sweep_state.h"
 
@@ -59,7 +67,7 @@ struct CommitState {
   // per plan scratch
   int kcap[PCC_MAX_BLOCKS];
   DevBuf<int32_t> ht[PCC_MAX_BLOCKS], rep[PCC_MAX_BLOCKS], flags[PCC_MAX_BLOCKS], scan[PCC_MAX_BLOCKS], base[PCC_MAX_BLOCKS],
-      newid[PCC_MAX_BLOCKS];
+      newid[PCC_MAX_BLOCKS], recpos[PCC_MAX_BLOCKS];
   DevBuf<PccResult> d_res;
   DevBuf<PccSums> d_sums;
   // page-locked mirrors
@@ -85,7 +93,7 @@ void pclean_commit_state_free(pclean_ctx* ctx) {
   c->d_sums.release();
   for (int b = 0; b < PCC_MAX_BLOCKS; ++b) {
     c->d_colmap[b].release(); c->ht[b].release(); c->rep[b].release(); c->flags[b].release(); c->scan[b].release();
-    c->base[b].release(); c->newid[b].release();
+    c->base[b].release(); c->newid[b].release(); c->recpos[b].release();
   }
   if (c->h_blocks) (void)hipHostFree(c->h_blocks);
   if (c->h_res) (void)hipHostFree(c->h_res);
@@ -100,6 +108,7 @@ void pclean_commit_state_free(pclean_ctx* ctx) {
 __global__ __launch_bounds__(1024) void pcc_commit_kernel(PccTable* tb, int n_slots, const PccPlan* plans, const PccBlock* blocks,
                                                           int n_blocks, PccResult* res) {
   __shared__ int32_t part[1025];
+  if (threadIdx.x == 0) pcc_prof_n = 0;
   if (threadIdx.x == 0)
     for (int s = 0; s < n_slots; ++s) {
       tb[s].state[PCC_ST_COLS_CHANGED] = 0;
@@ -107,6 +116,12 @@ __global__ __launch_bounds__(1024) void pcc_commit_kernel(PccTable* tb, int n_sl
       tb[s].state[PCC_ST_DELETED] = 0;
     }
   pcc_commit(tb, n_slots, plans, blocks, n_blocks, res, part, (int)threadIdx.x, (int)blockDim.x);
+}
+
+// the moved rows' current referents, after the commit kernel decided the created rows' ids (grid.y = plan)
+__global__ __launch_bounds__(256) void pcc_cur_kernel(const PccBlock* blocks, const PccResult* res) {
+  if (res->fallback) return;
+  pcc_update_cur(blocks[blockIdx.y], (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
 }
 
 __global__ void pcc_live_kernel(int n, const int64_t* counts, uint8_t* live) {
@@ -448,7 +463,7 @@ extern "C" int pclean_commit_device(pclean_ctx* ctx, int32_t n_blocks, uint32_t 
     int hsz = 1;
     while (hsz < 4 * kcap) hsz <<= 1;
     if (c->ht[p].alloc(hsz) || c->rep[p].alloc(kcap) || c->flags[p].alloc(kcap) || c->scan[p].alloc(kcap) ||
-        c->base[p].alloc((size_t)kcap * pl.n_used) || c->newid[p].alloc(kcap))
+        c->base[p].alloc((size_t)kcap * pl.n_used) || c->newid[p].alloc(kcap) || c->recpos[p].alloc(kcap))
       return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
     PccBlock& pb = c->h_blocks[p];
     pb.N = N;
@@ -474,10 +489,13 @@ extern "C" int pclean_commit_device(pclean_ctx* ctx, int32_t n_blocks, uint32_t 
     pb.scan = c->scan[p].p;
     pb.base = c->base[p].p;
     pb.newid = c->newid[p].p;
+    pb.recpos = c->recpos[p].p;
   }
   HIPCHK(ctx, hipMemcpyAsync(c->d_blocks.p, c->h_blocks, sizeof(PccBlock) * c->n_plans, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(pcc_commit_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_tables.p, c->n_slots, c->d_plans.p,
                      c->d_blocks.p, c->n_plans, c->d_res.p);
+  hipLaunchKernelGGL(pcc_cur_kernel, dim3(std::min(1024, (N + 255) / 256), c->n_plans), dim3(256), 0, ctx->stream, c->d_blocks.p,
+                     c->d_res.p);
   int rc = launch_refresh(ctx, c);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(PccResult), hipMemcpyDeviceToHost, ctx->stream));
@@ -489,6 +507,16 @@ extern "C" int pclean_commit_device(pclean_ctx* ctx, int32_t n_blocks, uint32_t 
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the ONE synchronisation of sweep + commit
   rc = pclean_sweep_finish_synced(ctx);
   if (rc) return rc;
+  static const bool prof = getenv("PCLEAN_COMMIT_PROF") != nullptr;
+  if (prof) {
+    long long t[64];
+    int n = 0;
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(pcc_prof_n), sizeof n);
+    (void)hipMemcpyFromSymbol(t, HIP_SYMBOL(pcc_prof_t), sizeof t);
+    fprintf(stderr, "[pclean] commit kernel phases (us since start; 100 MHz clock):");
+    for (int i = 1; i < n && i < 64; ++i) fprintf(stderr, " %.1f", (double)(t[i] - t[0]) / 100.0);
+    fprintf(stderr, "  (records %d %d, moved %d %d)\n", c->h_res->n_records[0], c->h_res->n_records[1], s->h_counts[0], s->h_counts[2]);
+  }
   out->fallback = c->h_res->fallback;
   out->n_changed = c->h_res->n_changed;
   out->n_slots = c->n_slots;

@@ -40,6 +40,10 @@ static inline int32_t pcc_cas32_host(int32_t* p, int32_t cmp, int32_t v) {
 #define PCC_CAS32(p, cmp, v) pcc_cas32_host((p), (cmp), (v))
 #endif
 
+#ifndef PCC_STAMP
+#define PCC_STAMP(name) ((void)0)
+#endif
+
 #define PCC_MAX_SLOTS 16   // latent tables one commit can touch (the classes reachable from the blocks' roots)
 #define PCC_MAX_NODES 64   // nodes of one block's plan
 #define PCC_MAX_FK 8       // direct reference slots of one class
@@ -111,6 +115,7 @@ struct PccBlock {  // one block of one sweep: the sweep's outputs (device-reside
   int32_t* scan;                 // [kcap]
   int32_t* base;                 // [kcap][n_used] first allocation index of the record in every used table
   int32_t* newid;                // [kcap] id of the record's root row
+  int32_t* recpos;               // [kcap] chosen_newpos[new_list[j]] (filled by phase A)
 };
 
 struct PccResult {
@@ -189,9 +194,7 @@ PCC_FN int32_t pcc_excl_scan(int32_t* a, int n, int32_t* part, int tid, int nt) 
   return total;
 }
 
-PCC_FN const int32_t* pcc_record(const PccBlock& b, int j) {
-  return b.vals + (size_t)b.chosen_newpos[b.new_list[j]] * b.nn;
-}
+PCC_FN const int32_t* pcc_record(const PccBlock& b, int j) { return b.vals + (size_t)b.recpos[j] * b.nn; }
 // node choice k of a record; entry 0 (the root) is NEW by definition (the library stores other things there)
 PCC_FN int32_t pcc_val(const int32_t* v, int k) { return k == 0 ? -1 : v[k]; }
 
@@ -357,6 +360,7 @@ PCC_FN void pcc_prepare_block(const PccTable* tb, const PccPlan& pl, const PccBl
     return;
   }
   if (k == 0) return;
+  for (int j = tid; j < k; j += nt) b.recpos[j] = b.chosen_newpos[b.new_list[j]];
   int hm = b.hmask < 63 ? b.hmask : 63;  // hash table of this sweep: the smallest power of two >= 4 k (at most the scratch's)
   while (hm + 1 < 4 * k && hm < b.hmask) hm = 2 * hm + 1;
   const uint32_t hmask = (uint32_t)hm;
@@ -421,6 +425,17 @@ PCC_FN void pcc_prepare_block(const PccTable* tb, const PccPlan& pl, const PccBl
   }
 }
 
+// current referents of the rows that moved: the chosen existing referent, or the row created for the chosen proposal
+PCC_FN void pcc_update_cur(const PccBlock& b, int tid, int nt) {
+  const int k = b.counts2[1], n_moved = b.counts2[0];
+  for (int m = tid; m < n_moved; m += nt) {
+    const int r = b.moved_list[m];
+    const int c = b.choice[r];
+    if (c >= 0) b.cur[r] = c;
+  }
+  for (int j = tid; j < k; j += nt) b.cur[b.new_list[j]] = b.newid[j];
+}
+
 // ---- phase B of one block: apply ------------------------------------------------------------------------------------
 PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, int bi, PccResult* res, int32_t* part, int tid,
                             int nt) {
@@ -433,6 +448,7 @@ PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, 
     for (int r = tid; r < n0; r += nt) root.counts[r] += b.delta[r];
     PCC_BARRIER();
   }
+  PCC_STAMP("delta");
   if (k > 0) {
   // 2. proposals without a nested NEW referent that keep the proposing row's old referent (pcc_mark_reuse; a plan with
   //    tables of its own decided in phase A, which also left scan[j] = needs a fresh root row)
@@ -440,6 +456,7 @@ PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, 
   const int32_t n_simple = pcc_excl_scan(b.scan, k, part, tid, nt);
   for (int j = tid; j < k; j += nt) b.base[(size_t)j * U] = b.scan[j];
   PCC_BARRIER();
+  PCC_STAMP("reuse+scan");
   // 3. proposals with nested NEW referents are created one after the other, after all the others: allocation index
   //    of every record in every table = exclusive scan of the rows it creates there
   int32_t total[PCC_MAX_SLOTS];
@@ -468,6 +485,7 @@ PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, 
     total[u] = tot + (u == 0 ? n_simple : 0);
     PCC_BARRIER();
   }
+  PCC_STAMP("nested scans");
   // 4. create the rows: ids from the free stack (last freed first), then from the high-water mark
   int32_t top0[PCC_MAX_SLOTS], hw0[PCC_MAX_SLOTS];
   for (int u = 0; u < U; ++u) {
@@ -519,6 +537,7 @@ PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, 
       t.state[PCC_ST_CREATED] += a;
     }
   PCC_BARRIER();
+  PCC_STAMP("create");
   // 5. every proposing row refers to its (group's) new row
   for (int j = tid; j < k; j += nt) {
     const int id = b.newid[b.rep[j]];
@@ -527,17 +546,18 @@ PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, 
   }
   PCC_BARRIER();
   }  // k > 0
-  // 6. current referents
-  for (int m = tid; m < n_moved; m += nt) {
-    const int r = b.moved_list[m];
-    const int c = b.choice[r];
-    if (c >= 0) b.cur[r] = c;
-  }
-  for (int j = tid; j < k; j += nt) b.cur[b.new_list[j]] = b.newid[j];
+  PCC_STAMP("refer");
+  // 6. current referents (the GPU build runs pcc_update_cur as a wide kernel of its own after this one: nothing below
+  //    reads them)
+#ifndef PCC_CUR_SEPARATE
+  pcc_update_cur(b, tid, nt);
+#endif
   if (tid == 0) res->n_changed += n_moved;
   PCC_BARRIER();
+  PCC_STAMP("cur");
   // 7. garbage collection
   pcc_collect(tb, pl.used_slot[0], part, tid, nt);
+  PCC_STAMP("collect");
 }
 
 // ---- the whole commit ------------------------------------------------------------------------------------------------
@@ -549,7 +569,11 @@ PCC_FN void pcc_commit(PccTable* tb, int n_slots, const PccPlan* plans, const Pc
     for (int s = 0; s < PCC_MAX_SLOTS; ++s) res->alloc_upper[s] = 0;
   }
   PCC_BARRIER();
-  for (int bi = 0; bi < n_blocks; ++bi) pcc_prepare_block(tb, plans[bi], blocks[bi], bi, res, tid, nt);
+  PCC_STAMP("start");
+  for (int bi = 0; bi < n_blocks; ++bi) {
+    pcc_prepare_block(tb, plans[bi], blocks[bi], bi, res, tid, nt);
+    PCC_STAMP("prepare");
+  }
   PCC_BARRIER();
   if (tid == 0)
     for (int s = 0; s < n_slots; ++s) {

@@ -94,6 +94,7 @@ struct ScoreTerm {
 
 struct Block {
   bool valid = false;
+  uint64_t version = 0;              // bumped by every pclean_load_block of this block
   int32_t group = -1;                // pclean_set_block_group (-1: its own group)
   bool is_score = false;             // no reference slot: only scores observed choices (flights Obs block 3)
   std::vector<ScoreTerm> score_terms;

@@ -82,22 +82,20 @@ struct CtxSrc {
 __global__ void gather_ctx_kernel(size_t NP, CtxSrc cs, int32_t* it_ctx) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= NP) return;
-  for (int s = 0; s < PCLEAN_MAX_CTX; ++s) {
-    int32_t v = 0;
-    if (s < cs.n_ctx) {
-      const int choice = cs.pchoice[s][t];
-      if (choice >= 0)
-        v = cs.root_col[s][choice];
-      else
-        v = resolve_new_value(cs.plan[s], 0, cs.col[s], cs.vals[s] + (size_t)cs.pnewpos[s][t] * cs.n_nodes[s]);
-    }
+  for (int s = 0; s < cs.n_ctx; ++s) {  // (slots >= n_ctx of the buffer were zeroed once, when it was sized)
+    int32_t v;
+    const int choice = cs.pchoice[s][t];
+    if (choice >= 0)
+      v = cs.root_col[s][choice];
+    else
+      v = resolve_new_value(cs.plan[s], 0, cs.col[s], cs.vals[s] + (size_t)cs.pnewpos[s][t] * cs.n_nodes[s]);
     it_ctx[(size_t)s * NP + t] = v;
   }
 }
 
 // distinct contexts among the particles of a row: rep[slot(p,i)] = first particle q <= p of the row with the
 // same ctx tuple; n_distinct[i] = number of representatives.  Typical rows: every particle shares one context.
-__global__ void ctx_count_kernel(int N, int P, const int32_t* __restrict__ it_ctx, int32_t* __restrict__ rep,
+__global__ void ctx_count_kernel(int N, int P, int n_ctx, const int32_t* __restrict__ it_ctx, int32_t* __restrict__ rep,
                                  int32_t* __restrict__ n_distinct) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -106,11 +104,12 @@ __global__ void ctx_count_kernel(int N, int P, const int32_t* __restrict__ it_ct
   for (int p = 0; p < P; ++p) {
     const size_t sp = (size_t)p * N + i;
     int c[PCLEAN_MAX_CTX];
-    for (int k = 0; k < PCLEAN_MAX_CTX; ++k) c[k] = it_ctx[(size_t)k * NP + sp];
+    for (int k = 0; k < PCLEAN_MAX_CTX; ++k) c[k] = k < n_ctx ? it_ctx[(size_t)k * NP + sp] : 0;
     int q = 0;
     for (; q < p; ++q) {
       bool same = true;
-      for (int k = 0; k < PCLEAN_MAX_CTX; ++k) same &= it_ctx[(size_t)k * NP + (size_t)q * N + i] == c[k];
+      for (int k = 0; k < PCLEAN_MAX_CTX; ++k)
+        if (k < n_ctx) same &= it_ctx[(size_t)k * NP + (size_t)q * N + i] == c[k];
       if (same) break;
     }
     rep[sp] = q;
@@ -119,7 +118,7 @@ __global__ void ctx_count_kernel(int N, int P, const int32_t* __restrict__ it_ct
   n_distinct[i] = nd;
 }
 // items off[i] .. off[i] + n_distinct[i]) of row i, in particle order of their representatives
-__global__ void ctx_fill_kernel(int N, int P, const int32_t* __restrict__ it_ctx, const int32_t* __restrict__ rep,
+__global__ void ctx_fill_kernel(int N, int P, int n_ctx, const int32_t* __restrict__ it_ctx, const int32_t* __restrict__ rep,
                                 const int32_t* __restrict__ off, const int32_t* __restrict__ cur_b,
                                 int32_t* __restrict__ slot_item, int32_t* __restrict__ row, int32_t* __restrict__ ctxv,
                                 int32_t* __restrict__ excl) {
@@ -133,7 +132,7 @@ __global__ void ctx_fill_kernel(int N, int P, const int32_t* __restrict__ it_ctx
     if (q == p) {
       row[j] = i;
       excl[j] = cur_b ? cur_b[i] : -1;
-      for (int k = 0; k < PCLEAN_MAX_CTX; ++k) ctxv[(size_t)j * PCLEAN_MAX_CTX + k] = it_ctx[(size_t)k * NP + sp];
+      for (int k = 0; k < PCLEAN_MAX_CTX; ++k) ctxv[(size_t)j * PCLEAN_MAX_CTX + k] = k < n_ctx ? it_ctx[(size_t)k * NP + sp] : 0;
       slot_item[sp] = j++;
     } else {
       slot_item[sp] = slot_item[(size_t)q * N + i];  // written above by this very thread
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(PU_T) void particle_update_kernel(int N, int P, con
                                                               int32_t* __restrict__ pchoice, double* __restrict__ w,
                                                               unsigned int* __restrict__ n_new,
                                                               int32_t* __restrict__ new_list,
-                                                              int32_t* __restrict__ pnewpos) {
+                                                              int32_t* __restrict__ pnewpos, int first) {
   __shared__ unsigned int wsum[PU_T / 64];
   __shared__ unsigned int bbase;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -180,7 +179,7 @@ __global__ __launch_bounds__(PU_T) void particle_update_kernel(int N, int P, con
       }
       const int c = (p == 0 && keep >= 0) ? keep : d;
       pchoice[sp] = c;
-      w[sp] += l;
+      w[sp] = first ? 0.0 + l : w[sp] + l;  // (first block of the sweep: the weights start at +0.0)
       if (c == PCLEAN_CHOICE_NEW) newmask |= 1ull << p;
     }
   }
@@ -2476,6 +2475,11 @@ static int ensure_plan_dev(pclean_ctx* ctx, int block_id) {
     cmb[i] = b.nodes[i].colmap_begin;
     cols[i] = t.cols.p;
   }
+  // unchanged since the last upload (same tables at the same addresses with the same shapes): nothing to do — the
+  // arrays are tiny, but five copies and a synchronisation per block and sweep are not
+  if (r.plan_ready && r.plan_sig_block == b.version && r.plan_sig_nrows == nrows && r.plan_sig_cols == cols && r.plan_sig_colmap == b.colmap.size() &&
+      r.plan_sig_kind == kind && r.plan_sig_cmb == cmb)
+    return PCLEAN_OK;
   if (r.plan_kind.alloc(nn) || r.plan_nrows.alloc(nn) || r.plan_cmb.alloc(nn) || r.plan_cols.alloc(nn) ||
       r.plan_colmap.alloc(std::max<size_t>(b.colmap.size(), 2)))
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "alloc");
@@ -2488,6 +2492,13 @@ static int ensure_plan_dev(pclean_ctx* ctx, int block_id) {
                                ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
   r.plan = PlanDev{nn, r.plan_kind.p, r.plan_cols.p, r.plan_nrows.p, r.plan_cmb.p, r.plan_colmap.p};
+  r.plan_sig_nrows = nrows;
+  r.plan_sig_cols = cols;
+  r.plan_sig_kind = kind;
+  r.plan_sig_cmb = cmb;
+  r.plan_sig_colmap = b.colmap.size();
+  r.plan_sig_block = b.version;
+  r.plan_ready = true;
   return PCLEAN_OK;
 }
 
@@ -3125,6 +3136,18 @@ static int upload_plan_nodes(pclean_ctx* ctx, int bi, const NodeDev** nds, const
   return PCLEAN_OK;
 }
 
+// per-(row, particle) context values [PCLEAN_MAX_CTX][NP]: the kernels that produce and group them touch the n_ctx
+// slots the block uses; the others are zeroed here, once per shape (the few readers of whole tuples see zeros)
+static int ensure_it_ctx(pclean_ctx* ctx, BlockRun& r, size_t NP, int n_ctx) {
+  if (r.it_ctx.alloc(NP * PCLEAN_MAX_CTX)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  if (r.it_ctx_np != NP || r.it_ctx_used != n_ctx) {
+    HIPCHK(ctx, hipMemsetAsync(r.it_ctx.p, 0, NP * PCLEAN_MAX_CTX * sizeof(int32_t), ctx->stream));
+    r.it_ctx_np = NP;
+    r.it_ctx_used = n_ctx;
+  }
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
                             int32_t n_blocks, const int32_t* cur, int32_t* choice, int32_t* chosen_particle,
                             double* logml) {
@@ -3194,7 +3217,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   s->last_blocks = n_blocks;
   s->last_dev_cur = dev_cur;
   (void)hipEventRecord(s->evs, ctx->stream);
-  HIPCHK(ctx, hipMemsetAsync(s->w.p, 0, NP * sizeof(double), ctx->stream));           // +0.0
+  // particle weights start at +0.0: the first block's particle_update_kernel stores instead of accumulating (a sweep that
+  // begins with a scoring block accumulates onto zeros)
+  const bool w_by_first_block = !ctx->block[0].is_score;
+  if (!w_by_first_block) HIPCHK(ctx, hipMemsetAsync(s->w.p, 0, NP * sizeof(double), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(s->logml_acc.p, 0, (size_t)N * sizeof(double), ctx->stream));
   ctx->timing = pclean_timing{};
   bool hot_timed = false;
@@ -3268,9 +3294,9 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
-                         s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p);
+                         s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0);
       if (has_ctx) {  // the particles' contexts: read by the likelihood terms and handed to the new rows' items
-        if (r.it_ctx.alloc(NP * PCLEAN_MAX_CTX)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+        { const int rci = ensure_it_ctx(ctx, r, NP, b.n_ctx); if (rci) return rci; }
         CtxSrc cs{};
         cs.n_ctx = b.n_ctx;
         for (int c = 0; c < b.n_ctx; ++c) {
@@ -3303,9 +3329,9 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
-                         s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p);
+                         s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0);
     } else {
-      if (r.it_ctx.alloc(NP * PCLEAN_MAX_CTX)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+      { const int rci = ensure_it_ctx(ctx, r, NP, b.n_ctx); if (rci) return rci; }
       CtxSrc cs{};
       cs.n_ctx = b.n_ctx;
       for (int c = 0; c < b.n_ctx; ++c) {
@@ -3337,7 +3363,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         ProfScope ps(ctx, "ctx_items");
         hipLaunchKernelGGL(gather_ctx_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, cs, r.it_ctx.p);
         HIPCHK(ctx, hipMemsetAsync(n_distinct + N, 0, sizeof(int32_t), ctx->stream));
-        hipLaunchKernelGGL(ctx_count_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, r.it_ctx.p, rep, n_distinct);
+        hipLaunchKernelGGL(ctx_count_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, (int)b.n_ctx, r.it_ctx.p, rep, n_distinct);
         HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_scan, n_distinct, off, N + 1, ctx->stream));
         HIPCHK(ctx, hipMemcpyAsync(&n_items, off + N, sizeof n_items, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -3349,7 +3375,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       int32_t* draws_item = scratch<int32_t>(ctx, (size_t)n_items * P);
       if (!d_row || !d_ctx || !d_excl || !lse_item || !draws_item)
         return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-      hipLaunchKernelGGL(ctx_fill_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, r.it_ctx.p, rep, off, cur_b, slot_item,
+      hipLaunchKernelGGL(ctx_fill_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, (int)b.n_ctx, r.it_ctx.p, rep, off, cur_b, slot_item,
                          d_row, d_ctx, d_excl);
       il = ItemList{(int)n_items, d_row, d_ctx, nullptr, nullptr};
       rc = eval_node(ctx, bi, 0, il, d_excl, seed, sweep_idx, P, lse_item, draws_item, nullptr, nullptr, false);
@@ -3358,7 +3384,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, (const int32_t*)nullptr,
                          (const double*)nullptr, slot_item, draws_item, lse_item, cur_b, r.pchoice.p, s->w.p,
-                         s->counter.p, r.new_slots.p, r.pnewpos.p);
+                         s->counter.p, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0);
     }
     // ---- particles that proposed a NEW referent: sample the new row's contents
     unsigned int n_new = 0;

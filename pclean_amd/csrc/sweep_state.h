@@ -26,11 +26,17 @@ struct BlockRun {  // per-block device state of one sweep
   DevBuf<double> lse;
   int n_new = 0;  // particles of the block that proposed a NEW referent
   int locals_rows = 0;  // rows of `locals` the last sweep filled (0: none)
+  size_t it_ctx_np = 0;  // shape it_ctx was last zeroed for (sweep.hip: ensure_it_ctx)
+  int it_ctx_used = -1;
   bool lazy_new = false;  // their contents are sampled after the final choice, for the chosen particles only
   DevBuf<int32_t> plan_kind, plan_nrows, plan_cmb, plan_colmap;
   DevBuf<const int32_t*> plan_cols;
   PlanDev plan{};
   bool plan_ready = false;
+  std::vector<int32_t> plan_sig_nrows, plan_sig_kind, plan_sig_cmb;  // what the device arrays were built from
+  std::vector<const int32_t*> plan_sig_cols;
+  size_t plan_sig_colmap = 0;
+  uint64_t plan_sig_block = 0;
 };
 
 struct FastRoot {  // candidate-compact tables of a reference slot (root_wave.hip)

@@ -98,7 +98,7 @@ int pcch_commit(void* hv, int N, int sweep_idx, int row_lo, int kcap, const int3
   if (!h->built) return -1;
   const int P = h->sc.n_plans;
   std::vector<PccBlock> blocks(P);
-  std::vector<std::vector<int32_t>> ht(P), rep(P), flags(P), scan(P), base(P), newid(P);
+  std::vector<std::vector<int32_t>> ht(P), rep(P), flags(P), scan(P), base(P), newid(P), recpos(P);
   int hsz = 1;
   while (hsz < 4 * kcap) hsz <<= 1;
   for (int p = 0; p < P; ++p) {
@@ -126,12 +126,14 @@ int pcch_commit(void* hv, int N, int sweep_idx, int row_lo, int kcap, const int3
     scan[p].assign(kcap, 0);
     base[p].assign((size_t)kcap * h->sc.plans[p].n_used, 0);
     newid[p].assign(kcap, 0);
+    recpos[p].assign(kcap, 0);
     b.ht = ht[p].data();
     b.rep = rep[p].data();
     b.flags = flags[p].data();
     b.scan = scan[p].data();
     b.base = base[p].data();
     b.newid = newid[p].data();
+    b.recpos = recpos[p].data();
   }
   for (int s = 0; s < h->sc.n_slots; ++s) {
     h->sc.tables[s].state[PCC_ST_COLS_CHANGED] = 0;
