@@ -25,6 +25,62 @@
 #include "gauss_dev.h"
 #include "sweep_state.h"
 
+// every blocking point of the orchestration goes through here: PCLEAN_TRACE_SYNC=1 lists them per call
+static int g_sync_count = 0;
+
+// One 32-bit count from the device to the host in the middle of a call (how many items need the next step): instead of a
+// copy + stream synchronisation (~25 us until the host thread is woken) a one-thread kernel publishes the value in
+// page-locked memory and the host spins on a sequence number — the remaining host round trips of a sweep cost a few
+// microseconds each.  PCLEAN_NO_POLL=1: the plain copy + synchronisation.
+__global__ void publish_count_kernel(const unsigned int* __restrict__ src, volatile unsigned int* __restrict__ dst, unsigned int seq) {
+  dst[0] = *src;
+  __threadfence_system();
+  dst[1] = seq;
+}
+static int read_count(pclean_ctx* ctx, const void* dev, void* out, const char* func, int line) {
+  SweepState* s = st(ctx);
+  static const bool no_poll = getenv("PCLEAN_NO_POLL") != nullptr;
+  static const bool trace = getenv("PCLEAN_TRACE_SYNC") != nullptr;
+  if (trace) fprintf(stderr, "[pclean sync %d] %s:%d (count)\n", ++g_sync_count, func, line);
+  if (!no_poll && !s->h_poll) {
+    if (hipHostMalloc((void**)&s->h_poll, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) s->h_poll = nullptr;
+    if (s->h_poll) {
+      s->h_poll[0] = s->h_poll[1] = 0;
+      if (hipHostGetDevicePointer((void**)&s->d_poll, (void*)s->h_poll, 0) != hipSuccess) {
+        (void)hipHostFree((void*)s->h_poll);
+        s->h_poll = nullptr;
+      }
+    }
+  }
+  if (no_poll || !s->h_poll) {
+    HIPCHK(ctx, hipMemcpyAsync(out, dev, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return PCLEAN_OK;
+  }
+  const unsigned int seq = ++s->poll_seq;
+  hipLaunchKernelGGL(publish_count_kernel, dim3(1), dim3(1), 0, ctx->stream, (const unsigned int*)dev, s->d_poll, seq);
+  volatile unsigned int* h = s->h_poll;
+  for (long spins = 0; h[1] != seq; ++spins)
+    if (spins > 2000000) {  // (a failed launch would spin for ever: let the runtime report it)
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      if (h[1] != seq) return pclean_fail(ctx, PCLEAN_ERR_HIP, "count read-back: the publishing kernel did not run");
+    }
+  *(unsigned int*)out = h[0];
+  return PCLEAN_OK;
+}
+#define PCLEAN_READ_COUNT(ctx, dev, out)                                  \
+  do {                                                                    \
+    const int rc_ = read_count(ctx, (dev), (out), __func__, __LINE__);    \
+    if (rc_) return rc_;                                                  \
+  } while (0)
+
+#define PCLEAN_SYNC(ctx)                                                                                   \
+  do {                                                                                                     \
+    static const bool trace_ = getenv("PCLEAN_TRACE_SYNC") != nullptr;                                     \
+    if (trace_) fprintf(stderr, "[pclean sync %d] %s:%d\n", ++g_sync_count, __func__, __LINE__);          \
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));                                                        \
+  } while (0)
+
 __device__ int32_t resolve_new_value(const PlanDev& pl, int node, int col, const int32_t* vals) {
   for (int depth = 0; depth < 16; ++depth) {
     const int cn = pl.colmap[2 * (pl.colmap_begin[node] + col)];
@@ -786,6 +842,7 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
   }
   if (s->h_counts) (void)hipHostFree(s->h_counts);
   if (s->h_over) (void)hipHostFree(s->h_over);
+  if (s->h_poll) (void)hipHostFree((void*)s->h_poll);
   s->dummy_dp.release();
   s->dummy_ctr.release();
   s->over_ctr.release();
@@ -856,7 +913,7 @@ static int finish_call(pclean_ctx* ctx) {
   if (st(ctx)->over_rec.empty() && !st(ctx)->scan_stats_used) return PCLEAN_OK;
   int rc = queue_over_copy(ctx);
   if (rc) return rc;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_SYNC(ctx);
   apply_over_stats(ctx);
   return PCLEAN_OK;
 }
@@ -867,7 +924,12 @@ static T* scratch(pclean_ctx* ctx, size_t count) {
   SweepState* s = st(ctx);
   if (s->pool_used == s->pool.size()) s->pool.emplace_back();
   DevBuf<unsigned char>& b = s->pool[s->pool_used++];
-  if (b.alloc(std::max<size_t>(count * sizeof(T), 16))) return nullptr;
+  // a slot that has to grow takes half as much again: the sizes of a sweep's lists (groups, items that need a step)
+  // drift from sweep to sweep, and a hipFree + hipMalloc in the middle of a sweep stalls the stream for ~0.3 ms
+  const size_t need = std::max<size_t>(count * sizeof(T), 16);
+  if (need > b.n && b.alloc(std::max(need, b.n + b.n / 2))) {
+    if (b.alloc(need)) return nullptr;
+  }
   return (T*)b.p;
 }
 
@@ -1116,7 +1178,7 @@ static int ensure_leaf_cache(pclean_ctx* ctx, int block_id, int node_id, const d
       std::vector<uint64_t> hu((size_t)U + 1);
       HIPCHK(ctx, hipMemcpyAsync(hu.data(), b.leaf_udummy[node_id].p, hu.size() * sizeof(uint64_t), hipMemcpyDeviceToHost,
                                  ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      PCLEAN_SYNC(ctx);
       bool any = tm.obs_col >= 0 && tm.obs_col < (int)ctx->col_has_missing.size() && ctx->col_has_missing[tm.obs_col] &&
                  hu[U] != 0;
       int first_o = -1;
@@ -1674,8 +1736,7 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
         HIPCHK(ctx, hipMemsetAsync(s->counter.p + 2, 0, sizeof(unsigned int), ctx->stream));
         hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, flag, 1,
                            s->counter.p + 2, list, nullptr);
-        HIPCHK(ctx, hipMemcpyAsync(&n_need, s->counter.p + 2, sizeof n_need, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        PCLEAN_READ_COUNT(ctx, s->counter.p + 2, &n_need);
       } else {
         gate = false;
       }
@@ -1858,8 +1919,7 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   }
   if (rc) return rc;
   unsigned int n_over = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&n_over, s->counter.p + 1, sizeof n_over, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_READ_COUNT(ctx, s->counter.p + 1, &n_over);
   ctx->timing.reserved += (int32_t)n_over;  // items that fell back to the generic kernel
   if (time_it) ctx->root_stats.overflow_items = (int32_t)n_over;
   // short strings / flat posteriors: when a quarter of the items overflow the survivor list the integer pre-filter
@@ -2099,7 +2159,7 @@ static int ensure_tuple_ids(pclean_ctx* ctx, int block_id, int node_id, const st
                        (const int32_t*)nullptr, (const int32_t*)nullptr, key_s.p, idx_s.p, head.p, 0);
     HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(tmp.p, tmp_scan, head.p, uid.p, n, ctx->stream));
     hipLaunchKernelGGL(tuple_id_scatter_kernel, grid1(n), dim3(256), 0, ctx->stream, n, idx_s.p, uid.p, t.id.p);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    PCLEAN_SYNC(ctx);
     key.release(); key_s.release(); idx.release(); idx_s.release(); head.release(); uid.release(); tmp.release();
     t.sig = sig;
   }
@@ -2196,8 +2256,7 @@ static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const It
   }
   HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(tmp, tmp_scan, head, uid, n, ctx->stream));
   int32_t n_unique = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&n_unique, uid + (n - 1), sizeof n_unique, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_READ_COUNT(ctx, uid + (n - 1), &n_unique);
   if (n_unique <= 0 || (double)n_unique > 0.75 * n) return PCLEAN_OK;  // not worth the indirection
   int32_t* grp_off = scratch<int32_t>(ctx, (size_t)n_unique + 1);
   if (!grp_off) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
@@ -2337,8 +2396,7 @@ static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemL
   hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 1, s->counter.p + 3, list,
                      nullptr);
   unsigned int n_miss = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&n_miss, s->counter.p + 3, sizeof n_miss, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_READ_COUNT(ctx, s->counter.p + 3, &n_miss);
   if (n_miss == 0) return PCLEAN_OK;
   if (n_miss == (unsigned int)N) {
     int rc = eval_node_lse_core(ctx, block_id, node_id, il, excl, seed, sweep, lse_out);
@@ -2429,8 +2487,7 @@ static int sample_children(pclean_ctx* ctx, int block_id, int node_id, const Ite
       hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, draws, 0,
                          s->counter.p, nullptr, nullptr);
       unsigned int cnt = 0;
-      HIPCHK(ctx, hipMemcpyAsync(&cnt, s->counter.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      PCLEAN_READ_COUNT(ctx, s->counter.p, &cnt);
       if (cnt) {
         int32_t* list = scratch<int32_t>(ctx, cnt);
         int32_t* row = scratch<int32_t>(ctx, cnt);
@@ -2490,7 +2547,7 @@ static int ensure_plan_dev(pclean_ctx* ctx, int block_id) {
   if (!b.colmap.empty())
     HIPCHK(ctx, hipMemcpyAsync(r.plan_colmap.p, b.colmap.data(), b.colmap.size() * 4, hipMemcpyHostToDevice,
                                ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+  PCLEAN_SYNC(ctx);  // host vectors go out of scope
   r.plan = PlanDev{nn, r.plan_kind.p, r.plan_cols.p, r.plan_nrows.p, r.plan_cmb.p, r.plan_colmap.p};
   r.plan_sig_nrows = nrows;
   r.plan_sig_cols = cols;
@@ -2689,8 +2746,7 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
         if (!l2) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
         hipLaunchKernelGGL(compact_new_kernel, grid1(NPi), dim3(256), 0, ctx->stream, NPi, draws, 1, s->counter.p, l2, nullptr);
         unsigned int c2 = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&c2, s->counter.p, sizeof c2, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        PCLEAN_READ_COUNT(ctx, s->counter.p, &c2);
         if (c2) {
           int32_t* rng2 = scratch<int32_t>(ctx, c2);
           int32_t* part2 = scratch<int32_t>(ctx, c2);
@@ -2728,7 +2784,7 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
       }
     HIPCHK(ctx, hipMemcpyAsync(d_aggs, h_aggs.data(), sizeof(void*) * nn, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(d_roots, roots, (size_t)n_roots * 4, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // h_aggs goes out of scope
+    PCLEAN_SYNC(ctx);  // h_aggs goes out of scope
     ItemsDev itd{n_items, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, d_off, d_off + 1, d_evr, d_evc, d_keys, nullptr,
                  nullptr, 0, 0, nullptr, nullptr};
     rc = pclean_launch_prior_terms_ev(ctx, n_items, P, nn, nds, d_aggs, dnc, dcb, dch, n_roots, d_roots, itd, pv, wl);
@@ -2739,7 +2795,7 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
                        d_chosen, pv, d_vals);
     HIPCHK(ctx, hipMemcpyAsync(chosen, d_chosen, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipMemcpyAsync(vals, d_vals, (size_t)n_items * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    PCLEAN_SYNC(ctx);
     s->lat_agg.clear();
     if (s->prof_on) prof_collect(ctx);
     return finish_call(ctx);
@@ -2754,8 +2810,7 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   hipLaunchKernelGGL(compact_new_kernel, grid1(n_items), dim3(256), 0, ctx->stream, (size_t)n_items, d_flag, 0,
                      s->counter.p, nullptr, nullptr);
   unsigned int cnt = 0;
-  HIPCHK(ctx, hipMemcpyAsync(&cnt, s->counter.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_READ_COUNT(ctx, s->counter.p, &cnt);
   if (cnt) {
     int32_t* list = scratch<int32_t>(ctx, cnt);
     int32_t* rng = scratch<int32_t>(ctx, cnt);
@@ -2792,8 +2847,7 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
         hipLaunchKernelGGL(compact_new_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (size_t)cnt, draws, 0,
                            s->counter.p, nullptr, nullptr);
         unsigned int c2 = 0;
-        HIPCHK(ctx, hipMemcpyAsync(&c2, s->counter.p, sizeof c2, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        PCLEAN_READ_COUNT(ctx, s->counter.p, &c2);
         if (c2) {
           int32_t* l2 = scratch<int32_t>(ctx, c2);
           int32_t* row2 = scratch<int32_t>(ctx, c2);
@@ -2822,7 +2876,7 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   }
   HIPCHK(ctx, hipMemcpyAsync(chosen, d_chosen, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(vals, d_vals, (size_t)n_items * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_SYNC(ctx);
   s->lat_agg.clear();
   if (s->prof_on) prof_collect(ctx);
   return finish_call(ctx);
@@ -2903,7 +2957,7 @@ extern "C" int pclean_score_node(pclean_ctx* ctx, int32_t block_id, int32_t node
   if (lse) HIPCHK(ctx, hipMemcpyAsync(lse, d_lse, n_items * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (scores) HIPCHK(ctx, hipMemcpyAsync(scores, d_scores, (size_t)n_items * nc * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (n_draws) HIPCHK(ctx, hipMemcpyAsync(draws, d_draws, (size_t)n_items * n_draws * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_SYNC(ctx);
   return finish_call(ctx);
 }
 
@@ -2963,7 +3017,7 @@ extern "C" int pclean_score_node_ev(pclean_ctx* ctx, int32_t block_id, int32_t n
   if (lse) HIPCHK(ctx, hipMemcpyAsync(lse, d_lse, (size_t)n_items * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (scores) HIPCHK(ctx, hipMemcpyAsync(scores, d_scores, (size_t)n_items * nc * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (n_draws) HIPCHK(ctx, hipMemcpyAsync(draws, d_draws, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_SYNC(ctx);
   return finish_call(ctx);
 }
 
@@ -3128,7 +3182,7 @@ static int upload_plan_nodes(pclean_ctx* ctx, int bi, const NodeDev** nds, const
   HIPCHK(ctx, hipMemcpyAsync(dcb, cb.data(), nn * 4, hipMemcpyHostToDevice, ctx->stream));
   if (!b.children.empty())
     HIPCHK(ctx, hipMemcpyAsync(dch, b.children.data(), b.children.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the host vectors go out of scope
+  PCLEAN_SYNC(ctx);  // the host vectors go out of scope
   *nds = d;
   *n_children = dnc;
   *child_begin = dcb;
@@ -3365,8 +3419,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         HIPCHK(ctx, hipMemsetAsync(n_distinct + N, 0, sizeof(int32_t), ctx->stream));
         hipLaunchKernelGGL(ctx_count_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, (int)b.n_ctx, r.it_ctx.p, rep, n_distinct);
         HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_scan, n_distinct, off, N + 1, ctx->stream));
-        HIPCHK(ctx, hipMemcpyAsync(&n_items, off + N, sizeof n_items, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        PCLEAN_READ_COUNT(ctx, off + N, &n_items);
       }
       int32_t* d_row = scratch<int32_t>(ctx, n_items);
       int32_t* d_ctx = scratch<int32_t>(ctx, (size_t)n_items * PCLEAN_MAX_CTX);
@@ -3388,8 +3441,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     }
     // ---- particles that proposed a NEW referent: sample the new row's contents
     unsigned int n_new = 0;
-    HIPCHK(ctx, hipMemcpyAsync(&n_new, s->counter.p, sizeof n_new, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    PCLEAN_READ_COUNT(ctx, s->counter.p, &n_new);
     r.n_new = (int)n_new;
     // The contents of a proposed new row matter (a) as context / scored values of LATER blocks — every particle's —
     // and (b) for the particle that is finally chosen.  For the last block only (b) is left: its sampling is
@@ -3491,8 +3543,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       hipLaunchKernelGGL(chosen_new_kernel, grid1(N), dim3(256), 0, ctx->stream, N, s->chosen.p, r.pchoice.p, s->counter.p,
                          r.new_slots.p, r.pnewpos.p);
       unsigned int cnt = 0;
-      HIPCHK(ctx, hipMemcpyAsync(&cnt, s->counter.p, sizeof cnt, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      PCLEAN_READ_COUNT(ctx, s->counter.p, &cnt);
       if (r.vals.alloc(std::max<size_t>((size_t)cnt * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
       if (!cnt) continue;
       hipLaunchKernelGGL(fill_i32_kernel, grid1((size_t)cnt * nn), dim3(256), 0, ctx->stream, r.vals.p, (size_t)cnt * nn, -2);
@@ -3567,7 +3618,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   if (defer) return PCLEAN_OK;  // nothing read back, no synchronisation: pclean_commit_device / pclean_sweep_fetch finish the call
   int rcf = pclean_sweep_finish_queue(ctx);
   if (rcf) return rcf;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_SYNC(ctx);
   rcf = pclean_sweep_finish_synced(ctx);
   if (rcf) return rcf;
   if (choice)
@@ -3651,7 +3702,7 @@ int pclean_sweep_fetch_lists(pclean_ctx* ctx) {
       HIPCHK(ctx, hipMemcpyAsync(b.new_vals_host.data(), vals_d, (size_t)n_newrows * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
   }
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_SYNC(ctx);
   s->lists_on_host = true;
   return PCLEAN_OK;
 }
@@ -3663,7 +3714,7 @@ extern "C" int pclean_sweep_fetch(pclean_ctx* ctx) {
   HIPCHK(ctx, hipSetDevice(ctx->device));
   int rc = pclean_sweep_finish_queue(ctx);
   if (rc) return rc;
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_SYNC(ctx);
   rc = pclean_sweep_finish_synced(ctx);
   if (rc) return rc;
   return pclean_sweep_fetch_lists(ctx);
@@ -3711,7 +3762,7 @@ extern "C" int pclean_get_locals(pclean_ctx* ctx, int32_t block_id, int32_t* out
       HIPCHK(ctx, hipSetDevice(ctx->device));
       b.locals_host.resize((size_t)N * 2);
       HIPCHK(ctx, hipMemcpyAsync(b.locals_host.data(), r.locals.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+      PCLEAN_SYNC(ctx);
     }
   }
   if (b.locals_host.size() == (size_t)N * 2)
@@ -3780,7 +3831,7 @@ extern "C" int pclean_maybe_resample(pclean_ctx* ctx, int32_t n_rows, int32_t n_
   HIPCHK(ctx, hipMemcpyAsync(ancestors, d_a, NP * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(logml_inc, d_inc, (size_t)n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
   if (ess) HIPCHK(ctx, hipMemcpyAsync(ess, d_ess, (size_t)n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_SYNC(ctx);
   return PCLEAN_OK;
 }
 
@@ -3805,7 +3856,7 @@ extern "C" int pclean_final_choice(pclean_ctx* ctx, int32_t n_rows, int32_t n_pa
                                                 (const double*)nullptr, (double*)nullptr));
   HIPCHK(ctx, hipMemcpyAsync(chosen, d_c, (size_t)n_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (log_total) HIPCHK(ctx, hipMemcpyAsync(log_total, d_t, (size_t)n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  PCLEAN_SYNC(ctx);
   return PCLEAN_OK;
 }
 

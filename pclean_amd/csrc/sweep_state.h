@@ -65,6 +65,9 @@ struct SweepState {
   size_t last_cur_ld = 0;
   int last_N = 0, last_blocks = 0;
   bool last_dev_cur = false, last_hot_timed = false;
+  volatile unsigned int* h_poll = nullptr;  // page-locked (value, sequence number) of read_count (sweep.hip)
+  unsigned int* d_poll = nullptr;
+  unsigned int poll_seq = 0;
   bool outputs_pending = false;  // counts / statistics of the last sweep not yet read back
   bool lists_on_host = false;    // moved-row / new-row lists of the last sweep already copied
   DevBuf<double> w, log_total, logml_inc, logml_acc, logml;

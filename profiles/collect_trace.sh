@@ -16,5 +16,6 @@ cd "$ROOT"
 T=$(find "$OUT/trace" -name "*.db" | head -1)
 python profiles/summarize_rocpd.py "$T" "$OUT/kernel_trace.txt" > /dev/null
 python profiles/timeline.py "$T" 12 1 > "$OUT/sweep_timeline.txt" 2>&1
+python profiles/timeline.py "$T" 0 1 > "$OUT/sweep_timeline_all.txt" 2>&1
 find "$OUT" -name "*.db" -delete
 tail -n 3 "$OUT/bench_trace.log"
