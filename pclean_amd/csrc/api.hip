@@ -416,7 +416,10 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
   t.h_mirror_stale = false;
   t.valid = true;
   t.version = ++g_pclean_version;
-  if (!keep_cols) t.cols_version = t.version;
+  if (!keep_cols) {
+    t.cols_version = t.version;
+    t.cols_delta_n = -1;
+  }
   return PCLEAN_OK;
 }
 

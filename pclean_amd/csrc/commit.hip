@@ -42,7 +42,7 @@ struct CommitSlot {
   int stride = 0;
   bool state_set = false;
   DevBuf<uint8_t> live;
-  DevBuf<int32_t> free_stack, gflag, gscan, glist, origin;
+  DevBuf<int32_t> free_stack, gflag, gscan, glist, origin, chg;
   DevBuf<double> lut;
   int lut_n = 0;
   double lut_discount = 0.0;
@@ -86,7 +86,7 @@ void pclean_commit_state_free(pclean_ctx* ctx) {
   if (!ctx->commit_state) return;
   CommitState* c = (CommitState*)ctx->commit_state;
   for (auto& s : c->slot) {
-    s.live.release(); s.free_stack.release(); s.gflag.release(); s.gscan.release(); s.glist.release(); s.origin.release();
+    s.live.release(); s.free_stack.release(); s.gflag.release(); s.gscan.release(); s.glist.release(); s.origin.release(); s.chg.release();
     s.lut.release();
   }
   c->d_tables.release(); c->d_plans.release(); c->d_blocks.release(); c->d_states.release(); c->d_res.release();
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(1024) void pcc_commit_kernel(PccTable* tb, int n_sl
       tb[s].state[PCC_ST_COLS_CHANGED] = 0;
       tb[s].state[PCC_ST_CREATED] = 0;
       tb[s].state[PCC_ST_DELETED] = 0;
+      tb[s].state[PCC_ST_NCHG] = 0;
     }
   pcc_commit(tb, n_slots, plans, blocks, n_blocks, res, part, (int)threadIdx.x, (int)blockDim.x);
 }
@@ -281,7 +282,7 @@ extern "C" int pclean_commit_set_table_state(pclean_ctx* ctx, int32_t table_id, 
                        t.n_rows);
   const size_t st = std::max(t.n_rows, 1);
   if (s.live.alloc(st) || s.free_stack.alloc(st) || s.gflag.alloc(st) || s.gscan.alloc(st) || s.glist.alloc(st) ||
-      s.origin.alloc(4 * st))
+      s.origin.alloc(4 * st) || s.chg.alloc(st))
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   s.stride = t.n_rows;
   HIPCHK(ctx, hipMemsetAsync(s.gflag.p, 0, st * 4, ctx->stream));
@@ -303,6 +304,7 @@ extern "C" int pclean_commit_set_table_state(pclean_ctx* ctx, int32_t table_id, 
   pt.gscan = s.gscan.p;
   pt.glist = s.glist.p;
   pt.origin = s.origin.p;
+  pt.chg = s.chg.p;
   pt.stride = t.n_rows;
   pt.n_cols = t.n_cols;
   s.state_set = true;
@@ -550,7 +552,14 @@ extern "C" int pclean_commit_device(pclean_ctx* ctx, int32_t n_blocks, uint32_t 
     t.logc_max = cs.max_count > 0 ? std::log((double)cs.max_count - t.discount) : -INFINITY;
     t.h_mirror_stale = true;
     t.version = ++g_pclean_version;
-    if (w[PCC_ST_COLS_CHANGED]) t.cols_version = t.version;
+    if (w[PCC_ST_COLS_CHANGED]) {
+      // the rows whose columns were written: tables derived from the columns (root_wave.hip's candidate-compact byte
+      // tables) refresh those rows alone when they were built from the version this commit started from
+      t.cols_delta_base = t.cols_version;
+      t.cols_delta_n = w[PCC_ST_NCHG];
+      t.cols_delta_rows = cs.chg.p;
+      t.cols_version = t.version;
+    }
     pclean_commit_slot& o = out->slot[si];
     o.table_id = cs.table_id;
     o.n_hw = w[PCC_ST_NHW];

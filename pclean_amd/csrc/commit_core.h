@@ -22,6 +22,7 @@
 #define PCC_BARRIER() __syncthreads()
 #define PCC_ADD64(p, v) atomicAdd((unsigned long long*)(p), (unsigned long long)(long long)(v))
 #define PCC_ADD32(p, v) atomicAdd((int*)(p), (int)(v))
+#define PCC_FETCH_ADD32(p, v) atomicAdd((int*)(p), (int)(v))
 #define PCC_OR32(p, v) atomicOr((int*)(p), (int)(v))
 #define PCC_MIN32(p, v) atomicMin((int*)(p), (int)(v))
 #define PCC_CAS32(p, cmp, v) atomicCAS((int*)(p), (int)(cmp), (int)(v))
@@ -30,6 +31,12 @@
 #define PCC_BARRIER() ((void)0)
 #define PCC_ADD64(p, v) (*(p) += (int64_t)(v))
 #define PCC_ADD32(p, v) (*(p) += (int32_t)(v))
+static inline int32_t pcc_fetch_add32_host(int32_t* p, int32_t v) {
+  const int32_t old = *p;
+  *p += v;
+  return old;
+}
+#define PCC_FETCH_ADD32(p, v) pcc_fetch_add32_host((p), (v))
 #define PCC_OR32(p, v) (*(p) |= (int32_t)(v))
 #define PCC_MIN32(p, v) (*(p) = (*(p) < (int32_t)(v) ? *(p) : (int32_t)(v)))
 static inline int32_t pcc_cas32_host(int32_t* p, int32_t cmp, int32_t v) {
@@ -57,6 +64,7 @@ static inline int32_t pcc_cas32_host(int32_t* p, int32_t cmp, int32_t v) {
 #define PCC_ST_COLS_CHANGED 2  // a row was written since the flag was last cleared
 #define PCC_ST_CREATED 3       // rows created / deleted since the counters were last cleared
 #define PCC_ST_DELETED 4
+#define PCC_ST_NCHG 5           // entries of PccTable::chg: the rows written since the counter was last cleared
 #define PCC_ST_WORDS 8
 
 // reasons a commit is refused (PccResult::fallback): nothing has been modified, the caller commits on the host
@@ -73,6 +81,7 @@ struct PccTable {
   int32_t* gflag;       // [stride] scratch, all zero between uses
   int32_t* gscan;       // [stride] scratch
   int32_t* glist;       // [stride] scratch: the rows being deleted
+  int32_t* chg;         // [stride] ids of the rows this commit wrote (any order): what derived tables have to refresh
   int32_t* origin;      // [stride][4]: (mark, creating observed row, chosen particle, sweep index); mark: 0 untouched since
                         //   the last pull, 1 + block = recorded, -1 = cleared (Trace.row_origin)
   int32_t stride, n_cols, n_fk, n_blocks_using;  // n_blocks_using: blocks of the commit whose plan can create rows here
@@ -523,6 +532,7 @@ PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, 
         t.origin[4 * (size_t)id] = -1;
       }
       t.state[PCC_ST_COLS_CHANGED] = 1;
+      t.chg[PCC_FETCH_ADD32(&t.state[PCC_ST_NCHG], 1)] = id;
       row[f] = id;
     }
     b.newid[j] = row[0];

@@ -71,6 +71,11 @@ struct CandTable {
   DevBuf<int64_t> stats;      // delta reference counts of last sweep
   double strength = 1.0, discount = 0.0;  // Pitman-Yor parameters of the last upload
   double logc_max = 0.0;      // FK tables: max over rows of log(count - discount) (-inf for an empty table)
+  // the last change of the value columns, when a device commit made it: rows [cols_delta_rows[0 .. cols_delta_n)) are what
+  // differs between cols_version and cols_delta_base (-1: unknown, e.g. a re-upload)
+  uint64_t cols_delta_base = 0;
+  int32_t cols_delta_n = -1;
+  const int32_t* cols_delta_rows = nullptr;
   bool h_mirror_stale = false;  // the device arrays moved on without the host mirrors (pclean_commit_device)
   double h_lse = 0.0;         // options: log-sum of logp (+1e-9), valid for version h_lse_ver (sweep.hip: subtree_ub)
   uint64_t h_lse_ver = 0;

@@ -168,6 +168,8 @@ int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_
 // block minima of a compact table: cmin[o][kb] = min of comp[o][64 kb .. 64 kb + 63] (root_wave.hip: the coarse level
 // of the pre-filter scan)
 int pclean_build_compact_min(pclean_ctx* ctx, const uint8_t* comp, int n_obs, int kpad, int cstride, uint8_t* cmin);
+int pclean_update_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_lat, const int32_t* cand_col,
+                          const uint16_t* lat_len, const int32_t* rows, int n_rows, int kpad, uint8_t* comp, uint8_t* clen);
 int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* logc_full, int n_cand, int kpad,
                         double logden_e, double logden_n, double* prior_e, double* prior_n, uint16_t* alive);
 

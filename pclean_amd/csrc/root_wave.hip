@@ -145,6 +145,30 @@ int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }
+// the same for the candidates rows[0 .. n_rows) alone (a device commit wrote those rows of the table)
+__global__ void compact_update_kernel(const uint8_t* __restrict__ pair, int n_lat, const int32_t* __restrict__ cand_col,
+                                      const uint16_t* __restrict__ lat_len, const int32_t* __restrict__ rows, int n_rows, int kpad,
+                                      uint8_t* __restrict__ comp, uint8_t* __restrict__ clen) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = blockIdx.y;
+  if (j >= n_rows) return;
+  const int k = rows[j];
+  const int val = cand_col[k];
+  const uint8_t v = pair[(size_t)o * n_lat + val];
+  comp[(size_t)o * kpad + k] = v < PRE_CLAMP ? v : (uint8_t)PRE_CLAMP;
+  if (o == 0) clen[k] = (uint8_t)lat_len[val];
+}
+int pclean_update_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_lat, const int32_t* cand_col,
+                          const uint16_t* lat_len, const int32_t* rows, int n_rows, int kpad, uint8_t* comp, uint8_t* clen) {
+  if (n_rows <= 0) return PCLEAN_OK;
+  for (int o0 = 0; o0 < n_obs; o0 += 65535) {
+    const int no = std::min(65535, n_obs - o0);
+    hipLaunchKernelGGL(compact_update_kernel, dim3((n_rows + 63) / 64, no), dim3(64), 0, ctx->stream, pair + (size_t)o0 * n_lat,
+                       n_lat, cand_col, lat_len, rows, n_rows, kpad, comp + (size_t)o0 * kpad, clen);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
 int pclean_build_compact_min(pclean_ctx* ctx, const uint8_t* comp, int n_obs, int kpad, int cstride, uint8_t* cmin) {
   for (int o0 = 0; o0 < n_obs; o0 += 65535) {  // gridDim.y limit
     const int no = std::min(65535, n_obs - o0);

@@ -1296,7 +1296,21 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
       continue;
     }
     const uint64_t ver = t.cols_version * 1000003ull + pt.version;
+    static const bool no_delta = getenv("PCLEAN_NO_COMPACT_DELTA") != nullptr;
+    if (f.ver[i] != ver && f.comp[i].p && f.cblk[i].p && !no_delta && t.cols_delta_n >= 0 && t.cols_delta_n * 8 <= t.n_rows &&
+        f.ver[i] == t.cols_delta_base * 1000003ull + pt.version) {
+      // built from the columns as they were before the last device commit, which wrote a few rows: refresh those rows
+      // (and the block minima), not the whole table
+      ProfScope psd(ctx, "compact_table_update");
+      int rc = pclean_update_compact(ctx, pt.d.p, pt.n_obs, pt.n_lat, t.cols.p + (size_t)tm.cand_col * t.n_rows, pt.lat_len.p,
+                                     t.cols_delta_rows, t.cols_delta_n, kpad, f.comp[i].p, f.clen[i].p);
+      if (rc) return rc;
+      rc = pclean_build_compact_min(ctx, f.comp[i].p, pt.n_obs, kpad, cstride, f.cblk[i].p);
+      if (rc) return rc;
+      f.ver[i] = ver;
+    }
     if (f.ver[i] != ver || !f.comp[i].p) {
+      ProfScope psd(ctx, "compact_table_rebuild");
       if (f.comp[i].alloc(std::max<size_t>((size_t)pt.n_obs * kpad, 16)) || f.clen[i].alloc(kpad))
         return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed (compact tables)");
       int rc = pclean_build_compact(ctx, pt.d.p, pt.n_obs, pt.n_lat, t.cols.p + (size_t)tm.cand_col * t.n_rows,

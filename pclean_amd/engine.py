@@ -2,6 +2,7 @@
 rejuvenation sweeps of the observed class (pgibbs_sweep!'s loop over the rows of
 the observed class, src/inference/inference.jl:60-81 + row_inference.jl:108-187).
 """
+import os
 import re
 
 import numpy as np
@@ -383,6 +384,11 @@ class Engine:
             dc["last_fallback"] = int(summ.fallback)
             self.hip.sweep_fetch()
             return None  # (a table about to outgrow its capacity gets more room at the next upload: upload_trace)
+        if os.environ.get("PCLEAN_DEBUG_COMMIT"):
+            print("[pclean] device commit: changed", summ.n_changed, "records", list(summ.n_records[:len(self.lw.blocks)]),
+                  "distinct", list(summ.n_distinct[:len(self.lw.blocks)]),
+                  {by_id[summ.slot[i].table_id]: (summ.slot[i].n_hw, summ.slot[i].n_free, summ.slot[i].created, summ.slot[i].deleted,
+                                                  summ.slot[i].cols_changed) for i in range(summ.n_slots)}, flush=True)
         for si in range(summ.n_slots):
             sl = summ.slot[si]
             c = by_id[sl.table_id]

@@ -15,7 +15,7 @@ struct Harness {
   std::vector<int> is_score;
   PccSchema sc;
   bool built = false;
-  std::vector<int32_t> gflag[PCC_MAX_SLOTS], gscan[PCC_MAX_SLOTS], glist[PCC_MAX_SLOTS];
+  std::vector<int32_t> gflag[PCC_MAX_SLOTS], gscan[PCC_MAX_SLOTS], glist[PCC_MAX_SLOTS], chg[PCC_MAX_SLOTS];
   const char* why = nullptr;
 };
 
@@ -86,6 +86,8 @@ int pcch_set_table(void* hv, int s, int stride, int n_cols, int32_t* cols, int64
   t.gflag = h->gflag[s].data();
   t.gscan = h->gscan[s].data();
   t.glist = h->glist[s].data();
+  h->chg[s].assign(stride > 0 ? stride : 1, 0);
+  t.chg = h->chg[s].data();
   return 0;
 }
 
@@ -139,6 +141,7 @@ int pcch_commit(void* hv, int N, int sweep_idx, int row_lo, int kcap, const int3
     h->sc.tables[s].state[PCC_ST_COLS_CHANGED] = 0;
     h->sc.tables[s].state[PCC_ST_CREATED] = 0;
     h->sc.tables[s].state[PCC_ST_DELETED] = 0;
+    h->sc.tables[s].state[PCC_ST_NCHG] = 0;
   }
   PccResult res;
   memset(&res, 0, sizeof res);

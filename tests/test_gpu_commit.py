@@ -36,16 +36,31 @@ def _same_state(a, b, what):
         assert np.array_equal(a.locals[bi], b.locals[bi]), (what, "own enumerated choices", bi)
 
 
+def _synthetic(n_rows, n_hosp):
+    from pclean_amd import experiments as ex
+    from pclean_amd.model import LoweredModel
+    from pclean_amd.synth import synth_hospital
+    dirty, clean, latent = synth_hospital(n_rows, n_hosp, 7)
+    (dirty, clean), _ = ex.shuffle_rows([dirty, clean], 7)
+    m = ex.hospital_model(ex.possibilities_of(dirty))
+    lw = LoweredModel(m, ex.hospital_query(m), dirty)
+    return lw, lw.encode_observations(dirty)
+
+
 def _programs():
     S = helpers.hospital_setup(n_rows=500)
     yield "hospital", S["lw"], S["obs"], None, InferenceConfig(1, 8), 5
+    # a table large enough for the compact-table root scan (>= 1024 candidates): the device commit refreshes the byte
+    # rows of the candidates it wrote instead of rebuilding the tables (root_wave.hip: compact_update_kernel)
+    lw, obs = _synthetic(40000, 2500)
+    yield "synthetic", lw, obs, None, InferenceConfig(1, 6), 4
     S = helpers.flights_setup()
     yield "flights", S["lw"], S["obs"], S["trace"], InferenceConfig(1, 4), 4
     R = helpers.rents_setup(n_rows=2000)
     yield "rents", R["lw"], R["obs"], R["trace"], InferenceConfig(1, 4), 4
 
 
-@pytest.mark.parametrize("program", ["hospital", "flights", "rents"])
+@pytest.mark.parametrize("program", ["hospital", "synthetic", "flights", "rents"])
 def test_device_commit_equals_host_commit(program):
     name, lw, obs, tr, cfg, n_sweeps = next(p for p in _programs() if p[0] == program)
     eng = Engine(lw, obs, dist_mode=_lib.DIST_DL)
@@ -53,7 +68,7 @@ def test_device_commit_equals_host_commit(program):
     try:
         if tr is None:  # the build's own batched initialisation: duplicate entities everywhere, lots to merge and collect
             tr = Trace(lw, obs.shape[1], 1)
-            inf.initialize_trace(eng, tr, cfg, 11, max_batch=64)
+            inf.initialize_trace(eng, tr, cfg, 11, max_batch=64 if name == "hospital" else 4096)
         assert eng.enable_device_commit(tr), getattr(eng, "_dc_why", "")
         n = obs.shape[1]
         done = refused = 0
