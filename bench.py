@@ -96,19 +96,20 @@ def oracle_world_for_rows(orc, lw, obs_local, tr, eng, rows):
 
 
 def hbm_traffic(args, world):
-    """HBM bytes per launch of the dominant kernel from this round's committed PMC passes (profiles/collect.sh ->
-    profiles/hbm_traffic.json: rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc runs of
-    this same command); only valid for the configuration it was measured on, otherwise null.  Counters cannot be
-    read from inside the process, so this figure is NOT measured in the run that prints it."""
+    """HBM bytes per launch of the dominant kernel GROUP (group_desc_kernel + fk_root_wave_kernel<12> + group_lse_kernel of
+    block 0's root: the launches `alg_bytes_per_launch` models) from this round's committed PMC passes (profiles/collect_r04.sh
+    -> profiles/hbm_traffic.json: rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc runs of this same
+    command); only valid for the configuration it was measured on, otherwise null.  Counters cannot be read from inside
+    the process, so this figure is NOT measured in the run that prints it."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         d = json.load(open(path))
         if d.get("rows") != args.rows or d.get("hospitals") != args.hospitals or d.get("particles") != args.particles \
-                or world != 1 or d.get("kernel") != "fk_root_wave_kernel":
-            return None, None
-        return float(d["bytes_per_launch"]), d.get("source")
+                or world != 1 or "pair_bytes_per_launch" not in d:
+            return None, None, None
+        return float(d["pair_bytes_per_launch"]), d.get("source"), d.get("pair_components")
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def step_traffic(args, world):
@@ -124,14 +125,20 @@ def step_traffic(args, world):
         return None
 
 
+LINE = 128  # bytes the memory system moves for one random gather: the L2 line.  The FETCH_SIZE calibration
+# (profiles/calib/fetch_calib.hip, profiles/r03_fetch_calibration.txt) counts a single-byte gather at 64 B and the guide's
+# gfx950 correction doubles FETCH_SIZE: 128 B per gather, the same rule the counter traffic is corrected with.
+
+
 def roofline_model(rs, obs_local, particles):
-    """Algorithmic bytes of ONE launch pair (group_desc_kernel + the root scan, root_wave.hip) as implemented, each
-    byte counted once, random gathers at the 64-byte sector the memory system moves for them:
+    """Algorithmic bytes of ONE launch of the dominant kernel group — group_desc_kernel + fk_root_wave_kernel<12> +
+    group_lse_kernel of block 0's root (root_wave.hip) — as implemented, each byte counted once, every random gather at
+    the 128-byte line the memory system moves for it (LINE):
       * coarse level of the scan: one block-minimum row (cstride bytes, one byte per 64 candidates) per DISTINCT
         observed value of the pre-filter columns among the swept rows;
       * fine level: the 64-candidate blocks the launch's scans actually read (rs.fine_blocks, counted by the kernel):
-        3 x 64 B of byte rows + 8 B of the alive bitmap each;
-      * exact scores: group_desc_kernel gathers every term of the current referent once per group (one sector each);
+        three byte rows (one line each) + 8 B of the alive bitmap;
+      * exact scores: group_desc_kernel gathers every term of the current referent once per group (one line each);
         the scan kernel gathers the (survivor, term) pairs it could not take from the descriptor (rs.scored_terms);
       * group descriptors: 128 B written and read per group; per group the representative's observed ids, grp_off /
         members (4 B per item + 4 B per group), the current referent (4 B per item);
@@ -146,12 +153,32 @@ def roofline_model(rs, obs_local, particles):
         col = rs.pre_obs_col[p]
         if col >= 0:
             distinct += int(np.unique(obs_local[col]).size)
-    per_group = 2 * 128 + 4 * rs.n_terms + 4 + 64 * rs.n_terms
+    per_group = 2 * 128 + 4 * rs.n_terms + 4 + LINE * rs.n_terms
     per_item = 4 + 4 + 4 * rs.n_draws + 8 + 4
     common = rs.n_groups * per_group + rs.n_items * per_item
-    two_level = distinct * rs.cstride + rs.fine_blocks * (3 * 64 + 8) + rs.scored_terms * 64
+    two_level = distinct * rs.cstride + rs.fine_blocks * (3 * LINE + 8) + rs.scored_terms * LINE
     rows_once = distinct * rs.kpad
     return float(common + two_level), float(common + rows_once)
+
+
+def step_byte_model(n, p, rs, n_groups_block1, n_obs_compact, kpad_compact, delta_rows):
+    """Algorithmic bytes of the five largest movers of one sweep besides the root scan (profiles/r04_step_traffic.txt names
+    them), per kernel: what each has to read and write once, in bytes.  n rows, p particles."""
+    np_ = n * p
+    m = {}
+    # block 0: draws [N][P] + lse + cur in, pchoice + weights out (the first block stores the weights); block 1: the
+    # particle's item (4), its draw (4), its item's lse (8, mostly shared), weights read + written, pchoice out
+    m["particle_update_kernel"] = np_ * (4 + 4 + 8) + n * 12 + np_ * (4 + 4 + 8 + 16 + 4)
+    # grouping: three 1M-item sorts of (32-bit key, 32-bit index) pairs: histogram pass + 4 onesweep passes (read + write)
+    m["radix_sort_onesweep (3 groupings)"] = 3 * (n * 4 + 4 * n * 16)
+    m["item_key + item_head + scans + group_offsets (3 groupings)"] = 3 * n * (8 + 4 + 4 + 12 + 8 + 8)
+    m["maybe_resample_kernel + apply_ancestors"] = np_ * 8 + n * (8 + 4 + 4) + np_ * 4
+    m["gather_ctx + ctx_count + ctx_fill"] = np_ * (4 + 4) + np_ * 4 + n * 8 + np_ * 4 + n * (4 + 16 + 4) + np_ * 4
+    m["final_choice + finalize_block x2 + selects"] = np_ * 8 + n * 12 + 2 * n * (4 + 4 + 16) + 4 * n * 4
+    m["gate_new_kernel x2"] = 2 * n * (rs.n_terms * LINE // 2 + 16)
+    m["compact table refresh (Measure)"] = sum(delta_rows * no * (LINE // 2) + no * kp * 1 for no, kp in zip(n_obs_compact, kpad_compact))
+    m["root scans of the Measure slot + nested slots (group descriptors + draws)"] = n_groups_block1 * (2 * 128 + 4 * LINE) + n * (8 + 4 * p)
+    return {k: float(v) for k, v in m.items()}
 
 
 def cpu_baseline(lw, obs, tr, eng, cfg, seed, min_rows, target_seconds):
@@ -208,6 +235,8 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=10_000, help="minimum rows of the CPU baseline sample (SURVEY §8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-iteration", action="store_true")
+    ap.add_argument("--no-dl-sample", action="store_true", help="skip timing the unrestricted-DL kernel on one table")
+    ap.add_argument("--dl-sample-cells", type=float, default=6e10, help="largest table (in DP cells) the DL sample may pick")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong (default, the BASELINE metric): --rows rows in total, sharded over the ranks; weak: --rows "
                          "rows PER RANK (the table grows with the ranks, the number of true hospitals stays: the pair "
@@ -253,6 +282,33 @@ def main():
     log(f"[bench] rank {rank}: pair tables {eng.pair_build_s:.1f}s ({len(lw.pair_id)} tables, {eng.pair_count / 1e9:.2f} G pairs, "
         f"{eng.pair_cells / 1e12:.2f} T DP cells), static upload total {static_s:.1f}s")
 
+    # the unrestricted-DL kernel (what the three real programs build their tables with) on one table of the workload
+    dl_sample = None
+    if rank == 0 and not args.no_dl_sample:
+        def cells_of(v):
+            return int(lw.pool.lens[v[1].id_array()].astype(np.int64).sum()) * int(lw.pool.lens[v[2].id_array()].astype(np.int64).sum())
+
+        # (bounded by DP cells: the sample must stay a few seconds whatever the kernel's speed on long strings)
+        key, (pid, odom, ldom) = max(((k, v) for k, v in lw.pair_id.items() if cells_of(v) <= args.dl_sample_cells),
+                                     key=lambda kv: cells_of(kv[1]))
+        oi, li = odom.id_array(), ldom.id_array()
+        spare = lw._next_pair  # (an unused pair-table id)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.hip.build_pair_table(spare, oi, li, _lib.DIST_DL)
+        torch.cuda.synchronize()
+        dl_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        eng.hip.build_pair_table(spare, oi, li, _lib.DIST_OSA)
+        torch.cuda.synchronize()
+        osa_s = time.perf_counter() - t0
+        cells = int(lw.pool.lens[oi].astype(np.int64).sum()) * int(lw.pool.lens[li].astype(np.int64).sum())
+        dl_sample = {"table": f"{key[0]} x {key[1]}", "pairs": len(oi) * len(li), "dp_cells": cells,
+                     "dl_seconds": dl_s, "dl_pairs_per_s": len(oi) * len(li) / dl_s, "dl_dp_cells_per_s": cells / dl_s,
+                     "osa_seconds": osa_s, "osa_pairs_per_s": len(oi) * len(li) / osa_s}
+        log(f"[bench] distance kernels on {dl_sample['table']} ({dl_sample['pairs'] / 1e9:.2f} G pairs): unrestricted DL "
+            f"{dl_s:.2f}s = {dl_sample['dl_pairs_per_s'] / 1e9:.2f} G pairs/s, OSA {osa_s:.3f}s = {dl_sample['osa_pairs_per_s'] / 1e9:.1f} G pairs/s")
+
     def f1_now(tr):
         return f1_from_counts(accuracy_counts(lw, tr, dirty, clean))  # replicated trace: same counts on every rank
 
@@ -267,6 +323,13 @@ def main():
     log(f"[bench] initialize_trace {init_s:.1f}s: F1 {acc_init['f1']:.4f} " + " ".join(f"{c}={t.n_live}" for c, t in tr.tables.items()))
     full_ms = None
     from pclean_amd import inference as inf
+    # one-time set-up of the device-resident commit (tables re-uploaded with spare capacity, scratch, log tables):
+    # inference would do it at its first observed-class sweep
+    t0 = time.time()
+    dc_on = inf.DEVICE_COMMIT and eng.enable_device_commit(tr, comm)
+    torch.cuda.synchronize()
+    dc_enable_ms = 1e3 * (time.time() - t0)
+    log(f"[bench] device-resident commit: {'on' if dc_on else 'off (' + getattr(eng, '_dc_why', 'several ranks') + ')'}, set-up {dc_enable_ms:.0f} ms")
     if not args.no_full_iteration:
         inf.TIMERS.clear()
         eng.hip.set_profiling(True)
@@ -338,14 +401,32 @@ def main():
         value = args.rows * args.steps / elapsed
         per_launch_s = 1e-3 * hot_ms / max(hot_launches, 1)
         achieved = (alg_bytes / per_launch_s / 1e9) if (alg_bytes and per_launch_s > 0) else None
-        traffic, traffic_src = hbm_traffic(args, world)
+        traffic, traffic_src, traffic_parts = hbm_traffic(args, world)
         st = step_traffic(args, world)
         step_model = None
+        # per-kernel byte model of the step's largest movers besides the root scans (an algorithmic denominator for the
+        # whole step, beside the counters)
+        blk1 = lw.blocks[1]
+        n_obs_c, kpad_c = [], []
+        for t_ in blk1["terms"][blk1["nodes"][0][2]:blk1["nodes"][0][2] + blk1["nodes"][0][3]]:
+            if t_[5] < 0:  # plain (compact-table) terms of the Measure slot
+                pid = t_[2]
+                n_obs_c.append(next(len(v[1]) for v in lw.pair_id.values() if v[0] == pid))
+                kpad_c.append(((eng._dc["cap"].get(blk1["root_class"], 0) if eng._dc else tr.tables[blk1["root_class"]].n) + 15) // 16 * 16)
+        created = (eng._dc or {}).get("created", {}).get(blk1["root_class"], 0)
+        per_kernel = step_byte_model(hi - lo, cfg.num_particles, rs, 0, n_obs_c, kpad_c, max(created, 1))
+        per_kernel.pop("root scans of the Measure slot + nested slots (group descriptors + draws)", None)
+        if alg_bytes:
+            per_kernel["block-0 root scan (roofline.alg_bytes_per_launch)"] = alg_bytes
         if st:  # the whole step against the HBM roof: counter bytes of every kernel of a sweep / this run's device time
             dev_s = 1e-3 * dev_ms / args.steps
             step_model = {"hbm_bytes_per_step": st["hbm_bytes_per_step"], "device_ms_per_step": 1e3 * dev_s,
                           "GBps": st["hbm_bytes_per_step"] / dev_s / 1e9, "frac_of_hbm_peak": st["hbm_bytes_per_step"] / dev_s / 8e12,
-                          "dispatches_per_step": st.get("dispatches"), "source": st.get("source")}
+                          "dispatches_per_step": st.get("dispatches"), "source": st.get("source"),
+                          "by_kernel_counters": st.get("by_kernel")}
+        step_model = dict(step_model or {}, alg_bytes_model=per_kernel, alg_bytes_modelled=sum(per_kernel.values()),
+                          note="alg_bytes_model: what each kernel group has to read and write once (bench.step_byte_model); the Measure "
+                               "slot's root scan and the nested slots are covered by counters only")
         out = {
             "metric": "rows/sec per Gibbs sweep on 1M-row synthetic hospital; F1 vs ground truth",
             "value": value, "unit": "rows/s/sweep", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -354,21 +435,30 @@ def main():
             "config": {"workload": f"synthetic hospital x{args.rows // 1000}: {args.rows} dirty rows (random order), "
                                    f"{args.hospitals} true hospitals, Record class, PG n_particles={args.particles}, "
                                    "2 blocks, batched schedule, the product's default observed_sweep (Record has no "
-                                   "learned parameter: one batch per sweep)", "rows": args.rows,
+                                   "learned parameter: one batch per sweep), AddTypos pair tables of the OSA flavour", "rows": args.rows,
                        "latent_hospitals": int(tr.tables["Hospital"].n_live), "particles": args.particles,
                        "parallelism": f"rows sharded over {world} GPU(s)",
                        "init": f"the build's own initialize_trace from an empty trace (batches <= {args.init_batch})"
                                + ("" if args.no_full_iteration else " + 1 full run_inference iteration"),
                        "init_s": init_s, "f1_after_init": acc_init["f1"], "full_iteration_ms": full_ms,
                        "device_ms_per_step": dev_ms / args.steps,
+                       "commit": ("device-resident (pclean_commit_device): tables, counts, free lists and referents stay in HBM, one "
+                                  "synchronisation per step" if dc_on else "host (parallel.exchange_and_commit)"),
+                       "device_commit_setup_ms": dc_enable_ms,
+                       "device_commits": (eng._dc or {}).get("commits"), "device_commit_refusals": (eng._dc or {}).get("fallbacks"),
                        "ms_per_step_32_sub_batches": ms_32},
             "f1": acc["f1"], "accuracy": acc,
             "table_build": {"seconds": eng.pair_build_s, "pairs": eng.pair_count, "dp_cells": eng.pair_cells,
-                            "dp_cells_per_s": eng.pair_cells / max(eng.pair_build_s, 1e-9), "distance": "OSA (restricted DL)"},
+                            "dp_cells_per_s": eng.pair_cells / max(eng.pair_build_s, 1e-9),
+                            "distance": "OSA (restricted DL): the tables the headline sweep and its F1 run on; the three real programs "
+                                        "use unrestricted DL, 0.48 % of the synthetic pairs differ (DESIGN.md §3)",
+                            "unrestricted_dl_sample": dl_sample},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
-                         "traffic_source": traffic_src,
-                         "kernel": "group_desc_kernel + fk_root_wave_kernel<12> (block 0 root: rows x candidate hospitals)",
+                         "traffic_source": traffic_src, "traffic_components": traffic_parts,
+                         "traffic_over_alg": (traffic / alg_bytes) if (traffic and alg_bytes) else None,
+                         "kernel": "group_desc_kernel + fk_root_wave_kernel<12> + group_lse_kernel (block 0 root: rows x candidate "
+                                   "hospitals); alg bytes, launch time and counter traffic all cover these three launches",
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": 1e3 * per_launch_s,
                          "groups": rs.n_groups, "items": rs.n_items, "kpad": rs.kpad, "overflow_items": rs.overflow_items,
                          "full_scans": rs.full_scans, "fine_blocks": rs.fine_blocks, "scored_terms": rs.scored_terms,
@@ -383,8 +473,8 @@ def main():
                                                     "note": "SURVEY §8d full-enumeration bytes (920 296 B/row) / kernel time: "
                                                             "work the kernel provably skips, not a bandwidth claim"},
                          "note": "achieved = bytes the implemented algorithm has to move once (bench.roofline_model: block-minimum "
-                                 "rows + the fine blocks and sector gathers the kernel counted + descriptors + ids + outputs) "
-                                 "/ HIP-event time of the launch pair on "
+                                 "rows + the fine blocks and gathers the kernel counted, every random gather at the 128-byte line "
+                                 "+ descriptors + ids + outputs) / HIP-event time of the launch group on "
                                  "the library's stream; traffic = HBM bytes per launch from this round's rocprofv3 PMC passes "
                                  "(profiles/), not measured in this run"},
             "phases_ms": {k: {"ms": round(v[0], 4), "intervals": v[1]} for k, v in sorted(phases.items(), key=lambda kv: -kv[1][0])},

@@ -313,14 +313,15 @@ class Engine:
     # -- device-resident commit (csrc/commit.hip) ------------------------------------------------------------------
     def _slack_min(self, cname, t):
         """spare rows a table needs before the next device commit: a few times what the last commits added to its
-        high-water mark (rows re-created from the free list need no room) — dead candidates cost every scan, so the
-        margin stays small"""
+        high-water mark (rows re-created from the free list need no room).  Dead candidates cost every enumeration —
+        a one-row table padded to hundreds of rows would make its reference slots hundreds of times dearer — so the
+        margin stays proportional to the table"""
         dc = self._dc
-        return max(64, 4 * dc["created"].get(cname, 0) + 16)
+        return max(8, 4 * dc["created"].get(cname, 0) + 8)
 
     def _capacity(self, cname, t):
-        slack = max(256, t.n // 16, 2 * self._slack_min(cname, t))
-        return -(-(t.n + slack) // 64) * 64
+        slack = max(16, t.n // 16, 2 * self._slack_min(cname, t))
+        return -(-(t.n + slack) // 16) * 16
 
     def enable_device_commit(self, trace, comm=None):
         """Switch the engine to the device-resident commit of observed-class sweeps (pclean_commit_*): latent tables

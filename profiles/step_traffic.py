@@ -68,7 +68,8 @@ def main():
             data = json.load(open(out_json))
         except Exception:
             data = {}
-        data["step"] = dict(hbm_bytes_per_step=tot, dispatches=n_f, rows=1000000, hospitals=10000, particles=20,
+        by_kernel = {k: (2 * f.get(k, [0, 0.0, 0.0])[1] + w.get(k, [0, 0.0, 0.0])[1]) * 1024 for k in names[:12]}
+        data["step"] = dict(hbm_bytes_per_step=tot, dispatches=n_f, rows=1000000, hospitals=10000, particles=20, by_kernel=by_kernel,
                             source="profiles/step_traffic.py over two rocprofv3 --pmc passes of bench.py over all kernels "
                                    "(FETCH_SIZE; WRITE_SIZE), one sweep = the dispatches between the last two final_choice_kernel")
         json.dump(data, open(out_json, "w"), indent=1)
