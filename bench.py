@@ -389,6 +389,17 @@ def main():
     comm.barrier()
     ms_32 = 1e3 * comm.max_float(time.perf_counter() - t0) / n_sub
 
+    # ---- fixed / proportional split of the step: the same sweep as TWO half windows costs 2 x fixed + proportional ---
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_half = 3
+    for i in range(n_half):
+        observed_sweep(eng, tr, cfg, args.seed, 2000 + i, comm, batch_rows=-(-args.rows // 2))
+    torch.cuda.synchronize()
+    comm.barrier()
+    ms_2 = 1e3 * comm.max_float(time.perf_counter() - t0) / n_half
+
     # ---- per-phase profile of one more (untimed) sweep ----------------------------------------------------------
     eng.hip.set_profiling(True)
     step(args.warmup + args.steps)
@@ -446,7 +457,11 @@ def main():
                                   "synchronisation per step" if dc_on else "host (parallel.exchange_and_commit)"),
                        "device_commit_setup_ms": dc_enable_ms,
                        "device_commits": (eng._dc or {}).get("commits"), "device_commit_refusals": (eng._dc or {}).get("fallbacks"),
-                       "ms_per_step_32_sub_batches": ms_32},
+                       "ms_per_step_32_sub_batches": ms_32,
+                       # what does not shrink with the rows a rank sweeps (launches, count read-backs, the commit kernel, table
+                       # refreshes) vs what does: from the same sweep run as two half windows (2 x fixed + proportional)
+                       "step_fixed_ms": max(ms_2 - ms_per_step, 0.0), "step_proportional_ms": max(2 * ms_per_step - ms_2, 0.0),
+                       "ms_per_step_2_windows": ms_2},
             "f1": acc["f1"], "accuracy": acc,
             "table_build": {"seconds": eng.pair_build_s, "pairs": eng.pair_count, "dp_cells": eng.pair_cells,
                             "dp_cells_per_s": eng.pair_cells / max(eng.pair_build_s, 1e-9),

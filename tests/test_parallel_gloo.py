@@ -108,12 +108,12 @@ def test_two_rank_sweep_equals_single_process(tmp_path, oracle, use_moved):
 
 # ---------------------------------------------------------------------------
 # whole inference (initialize_trace + run_inference over every class) on 2 ranks
-def _program(name):
+def _program(name, cap=None):
     from pclean_amd import experiments as ex
     from pclean_amd.model import LoweredModel
     if name == "flights":
         dirty, clean = ex.flights_data()
-        dirty = {c: v[:600] for c, v in dirty.items()}
+        dirty = {c: v[:cap or 600] for c, v in dirty.items()}
         m = ex.flights_model(dirty)
         q = ex.flights_query(m)
     elif name == "rents":
@@ -123,7 +123,7 @@ def _program(name):
         q = ex.rents_query(m)
     else:
         dirty, clean = ex.hospital_data()
-        dirty = {c: v[:200] for c, v in dirty.items()}
+        dirty = {c: v[:cap or 200] for c, v in dirty.items()}
         m = ex.hospital_model(ex.possibilities_of(dirty))
         q = ex.hospital_query(m)
     lw = LoweredModel(m, q, dirty)
@@ -186,3 +186,85 @@ def test_two_rank_inference_equals_single_process(tmp_path, oracle, name):
     for k in a.files:
         assert np.array_equal(a[k], b[k]), k
     assert (a["cur"] >= 0).all()
+
+
+# ---------------------------------------------------------------------------
+# the fused statistics path (exchange_and_commit(..., stats_reduced=True)): what Engine.sweep_stats_reduced feeds it on a
+# multi-GPU run — the delta reference counts already summed over the ranks by ONE device-side all-reduce
+# (pclean_allreduce_stats_fused) — driven here through a stand-in engine whose "device-side" all-reduce is a gloo one
+def _run_fused(rank, world, port, out_path, name):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import oracle as orc
+    from oracle_engine import OracleEngine
+    from pclean_amd.engine import InferenceConfig
+    from pclean_amd.inference import initialize_trace, observed_sweep, run_inference
+    from pclean_amd.parallel import Comm
+    from pclean_amd.trace import Trace
+    if world > 1:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    comm = Comm()
+
+    class FusedStatsEngine(OracleEngine):
+        """sweep_stats_reduced as the HIP engine provides it after init_device_comm: per block root table the delta counts
+        summed over ALL ranks (a rank that swept nothing contributes zeros), in one collective for all tables; reload()
+        re-binds the communicator (counted)."""
+        reloads = 0
+        fused_calls = 0
+
+        def sweep_stats_reduced(self, trace):
+            local = self.sweep_stats(trace)
+            blocks = sorted(local)
+            flat = np.concatenate([np.asarray(local[b], dtype=np.int64) for b in blocks]) if blocks else np.zeros(0, np.int64)
+            total = comm.allreduce_sum_i64(flat)
+            type(self).fused_calls += 1
+            out, off = {}, 0
+            for b in blocks:
+                n = len(local[b])
+                out[b] = total[off:off + n]
+                off += n
+            return out
+
+        def reload(self):
+            type(self).reloads += 1
+            super().reload()
+
+    lw, obs = _program(name, 60 if name == "hospital" else 120)
+    eng = (FusedStatsEngine if world > 1 else OracleEngine)(orc, lw, obs)
+    tr = Trace(lw, obs.shape[1], 5)
+    cfg = InferenceConfig(1, 3, rejuv_frequency=100)
+    initialize_trace(eng, tr, cfg, 17, max_batch=32, comm=comm)
+    run_inference(eng, tr, cfg, 17, comm=comm, batch_rows=7)   # windows of 7 rows: shards of 4 + 3
+    observed_sweep(eng, tr, cfg, 17, 5, comm, batch_rows=1)    # windows of ONE row: rank 1's shard is always empty
+    tr.check_consistency()
+    if world > 1:
+        assert FusedStatsEngine.fused_calls > obs.shape[1], FusedStatsEngine.fused_calls
+    if rank == world - 1:
+        np.savez(out_path, cur=tr.cur, reloads=np.array([getattr(type(eng), "reloads", 0)]),
+                 **{f"cols_{c}": t.cols[:, :t.n] for c, t in tr.tables.items()},
+                 **{f"counts_{c}": t.counts[:t.n] for c, t in tr.tables.items()})
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("name", ["hospital", "flights"])
+def test_fused_statistics_path_two_ranks(tmp_path, oracle, name):
+    """exchange_and_commit with stats_reduced=True (the multi-GPU default once the device communicator is bound) on
+    gloo world-size 2 == the single-process run, including windows where one rank owns no row and — flights: chosen
+    dummy values — engine reloads in the middle of the run."""
+    import torch.multiprocessing as mp
+    single = str(tmp_path / "single.npz")
+    _run_fused(0, 1, 0, single, name)
+    multi = str(tmp_path / "multi.npz")
+    port = 33500 + (os.getpid() % 2000) + (53 if name == "flights" else 0)
+    mp.spawn(_run_fused, args=(2, port, multi, name), nprocs=2, join=True)
+    a, b = np.load(single), np.load(multi)
+    for k in a.files:
+        if k != "reloads":
+            assert np.array_equal(a[k], b[k]), k
+    if name == "flights":
+        assert b["reloads"][0] > 0, "flights chooses dummy values: the engine must have been reloaded mid-run"
