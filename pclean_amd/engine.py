@@ -317,9 +317,13 @@ class Engine:
         a one-row table padded to hundreds of rows would make its reference slots hundreds of times dearer — so the
         margin stays proportional to the table"""
         dc = self._dc
+        if os.environ.get("PCLEAN_DC_NOPAD"):
+            return 0
         return max(8, 4 * dc["created"].get(cname, 0) + 8)
 
     def _capacity(self, cname, t):
+        if os.environ.get("PCLEAN_DC_NOPAD"):  # diagnostic: no spare rows (every growth is a refused commit)
+            return t.n
         slack = max(16, t.n // 16, 2 * self._slack_min(cname, t))
         return -(-(t.n + slack) // 16) * 16
 
