@@ -26,13 +26,15 @@ from pclean_amd.inference import initialize_trace, run_inference
 from pclean_amd.model import LoweredModel
 from pclean_amd.trace import Trace
 
-OUT = os.path.join(ROOT, "tests", "golden", "sequential_f1.json")
+OUT = os.environ.get("PCLEAN_SEQ_OUT") or os.path.join(ROOT, "tests", "golden", "sequential_f1.json")  # (PCLEAN_SEQ_OUT: runs in
+# parallel write their own file; merge the entries into the golden afterwards)
 
 
 def program(name, n_rows=None):
     if name.startswith("synth"):  # hospital-shaped synthetic table (pclean_amd.synth), ~100 rows per true hospital
         from pclean_amd.synth import synth_hospital
-        dirty, clean, _ = synth_hospital(n_rows, max(n_rows // 100, 1), 20250926)
+        n_hosp = 3000 if "k3000" in name else max(n_rows // 100, 1)  # (k3000: many entities, ~10 rows each)
+        dirty, clean, _ = synth_hospital(n_rows, n_hosp, 20250926)
         return dirty, clean, ex.hospital_model, ex.hospital_query
     name = name.split("_")[0]
     if name == "hospital":
@@ -87,6 +89,8 @@ CONFIGS = {  # the experiment scripts' configurations (experiments/*/run.jl), ro
     "rents_pg20": dict(iters=1, mh=False, particles=20, n_rows=None),
     # the headline workload's shape at a size the sequential schedule can finish: 30 000 rows, 300 true hospitals
     "synth_pg20": dict(iters=1, mh=False, particles=20, n_rows=30000),
+    # ... and with MANY entities (3 000 true hospitals, ~10 rows each): the table a batched sweep freezes is large
+    "synth_k3000_pg20": dict(iters=1, mh=False, particles=20, n_rows=30000),
 }
 
 if __name__ == "__main__":
@@ -98,8 +102,16 @@ if __name__ == "__main__":
             seeds = [int(x) for x in sys.argv[sys.argv.index(a) + 1].split(",")]
     res = json.load(open(OUT)) if os.path.exists(OUT) else {}
     for name in names:
+        runs = dict(res.get(name, {}).get("runs", {})) if res.get(name, {}).get("config") == CONFIGS[name] else {}
+        for sd in seeds:  # (seeds already recorded for this configuration are kept)
+            if str(sd) not in runs:
+                runs[str(sd)] = run(name, sd, **CONFIGS[name])
+                res[name] = dict(config=CONFIGS[name], schedule="sequential (batch_rows=1), CPU oracle engine, rows shuffled with the seed",
+                                 runs=runs)
+                res[name]["f1_mean"] = float(np.mean([r["f1"] for r in runs.values()]))
+                json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
         res[name] = dict(config=CONFIGS[name], schedule="sequential (batch_rows=1), CPU oracle engine, rows shuffled with the seed",
-                         runs={str(sd): run(name, sd, **CONFIGS[name]) for sd in seeds})
+                         runs=runs)
         res[name]["f1_mean"] = float(np.mean([r["f1"] for r in res[name]["runs"].values()]))
         json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
     print(json.dumps({k: v["f1_mean"] for k, v in res.items()}))

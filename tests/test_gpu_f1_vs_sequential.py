@@ -53,4 +53,9 @@ def test_batched_gpu_f1_matches_the_sequential_reference(name, capsys):
         print(f"\n[f1 vs sequential] {name}: batched GPU {np.round(got, 4).tolist()} (mean {np.mean(got):.4f})  "
               f"sequential reference {np.round(want, 4).tolist()} (mean {np.mean(want):.4f})")
     assert abs(np.mean(got) - np.mean(want)) <= 0.005, (got, want)       # +-0.5 pt on the means
+    lit = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_sequential.json")))
+    if name in lit:  # ... and of the INDEPENDENT literal sequential reference (oracle/literal_inference.py)
+        with capsys.disabled():
+            print(f"[f1 vs literal sequential] {name}: literal reference mean {lit[name]['f1_mean']:.4f}")
+        assert abs(np.mean(got) - lit[name]["f1_mean"]) <= 0.005, (got, lit[name]["f1_mean"])
     assert min(got) >= np.mean(want) - 0.01                              # and no seed more than 1 pt below the reference

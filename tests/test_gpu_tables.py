@@ -127,6 +127,19 @@ def test_pair_table_long_patterns_and_dl_random(hip, oracle):
     ids = np.unique(ids)
     hip.build_pair_table(31, ids, ids, 0)
     assert np.array_equal(hip.get_pair_table(31, len(ids), len(ids)), oracle.pair_table(sym, off, ids, ids, 0))
+    # the same long strings through the unrestricted-DL kernel (dl_wave_kernel: 64 lanes per pair, up to 4 column chunks
+    # per lane; the 9-letter alphabet makes gapped transpositions common)
+    hip.build_pair_table(31, ids, ids, 1)
+    assert np.array_equal(hip.get_pair_table(31, len(ids), len(ids)), oracle.pair_table(sym, off, ids, ids, 1))
+    # every lane-group shape of that kernel: strings of at most 16 / 32 / 64 / 128 / 192 symbols, empty strings included
+    for top in (16, 32, 33, 64, 100, 160):
+        words = ["".join(rnd.choice(list("abcx"), size=int(rnd.integers(0, top + 1)))) for _ in range(90)] + ["", "a" * top]
+        pool2, ids2 = _pool(words)
+        sym2, off2, _, _ = pool2.arrays()
+        hip.load_strings(sym2, off2)
+        ids2 = np.unique(ids2)
+        hip.build_pair_table(31, ids2, ids2, 1)
+        assert np.array_equal(hip.get_pair_table(31, len(ids2), len(ids2)), oracle.pair_table(sym2, off2, ids2, ids2, 1)), top
     short = ["".join(rnd.choice(list("abcx"), size=rnd.integers(0, 30))) for _ in range(400)]
     pool, ids = _pool(short)
     sym, off, _, _ = pool.arrays()

@@ -1,0 +1,56 @@
+"""The INDEPENDENT end-to-end reference (oracle/literal_inference.py: the reference's sequential schedule on a
+dict-of-rows trace of strings, scored by oracle/literal.py — none of the product's lowering, trace, inference or analysis
+code) against the product's own sequential-schedule runs: tests/golden/literal_sequential.json (generator:
+scripts/literal_sequential_reference.py) vs tests/golden/sequential_f1.json (scripts/sequential_reference.py: the
+product's host code with batch_rows=1 on the CPU oracle engine).  Same program, configurations, seeds and row shuffles;
+the random numbers differ, so F1 is compared on the means (north_star: +-0.5 pt) and the number of latent rows per class
+must agree to within a few rows.  A bug in the product's commit, garbage collection, parameter moves or evaluate_accuracy
+would show here: it is no longer common to both sides."""
+import functools
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+def test_literal_sampler_runs_and_keeps_its_database_consistent():
+    import literal_sequential_reference as lsr
+    import literal_inference as LI
+    from pclean_amd import experiments as ex
+    dirty, clean = ex.hospital_data()
+    dirty = {c: v[:160] for c, v in dirty.items()}
+    clean = {c: v[:160] for c, v in clean.items()}
+    (dirty, clean), _ = ex.shuffle_rows([dirty, clean], 4)
+    m = ex.hospital_model(ex.possibilities_of(dirty))
+    q = ex.hospital_query(m)
+    for mh, particles in ((True, 2), (False, 5)):
+        s = LI.LiteralSampler(m, q, dirty, lsr.Cfg(1, particles, mh), 4)
+        s.initialize()
+        s.check()
+        f0 = s.accuracy(dirty, clean)["f1"]
+        s.sweep()
+        s.check()
+        acc = s.accuracy(dirty, clean)
+        assert acc["f1"] > f0 and acc["f1"] > 0.8 and acc["precision"] > 0.95, (f0, acc)
+        rows = s.latent_rows()
+        assert rows["HospitalType"] == 1 and 4 <= rows["Hospital"] <= 12, rows
+
+
+@pytest.mark.parametrize("name", ["hospital", "hospital_pg20"])
+def test_product_sequential_runs_match_the_literal_reference(name):
+    lit = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_sequential.json")))[name]
+    prod = json.load(open(os.path.join(ROOT, "tests", "golden", "sequential_f1.json")))[name]
+    assert {k: lit["config"][k] for k in ("iters", "mh", "particles")} == {k: prod["config"][k] for k in ("iters", "mh", "particles")}
+    assert sorted(lit["runs"]) == sorted(prod["runs"])
+    assert abs(lit["f1_mean"] - prod["f1_mean"]) <= 0.005, (lit["f1_mean"], prod["f1_mean"])
+    for sd in lit["runs"]:
+        a, b = lit["runs"][sd]["latent_rows"], prod["runs"][sd]["latent_rows"]
+        for cls in b:
+            assert abs(a[cls] - b[cls]) <= max(3, b[cls] // 10), (sd, cls, a, b)
+        assert abs(lit["runs"][sd]["f1"] - prod["runs"][sd]["f1"]) <= 0.01, sd
