@@ -235,6 +235,9 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=10_000, help="minimum rows of the CPU baseline sample (SURVEY §8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-iteration", action="store_true")
+    ap.add_argument("--distance", choices=("osa", "dl"), default="osa",
+                    help="flavour of the AddTypos pair tables the workload runs on: restricted (OSA, bit-parallel; the default "
+                         "of the headline since round 1) or unrestricted Damerau-Levenshtein (what the three real programs use)")
     ap.add_argument("--no-dl-sample", action="store_true", help="skip timing the unrestricted-DL kernel on one table")
     ap.add_argument("--dl-sample-cells", type=float, default=6e10, help="largest table (in DP cells) the DL sample may pick")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
@@ -275,7 +278,7 @@ def main():
     t0 = time.time()
     # every rank holds all observation columns (60 MB) and the whole trace: latent-class sweeps and the
     # initialisation need every referring row; the observed-class sweep is sharded by rows
-    eng = Engine(lw, obs, device=local_rank, dist_mode=_lib.DIST_OSA)
+    eng = Engine(lw, obs, device=local_rank, dist_mode=_lib.DIST_OSA if args.distance == "osa" else _lib.DIST_DL)
     static_s = time.time() - t0
     if comm.dist is not None:  # the library's own RCCL communicator: fused device-side all-reduce of the CRP statistics
         eng.init_device_comm(comm)
@@ -446,7 +449,8 @@ def main():
             "config": {"workload": f"synthetic hospital x{args.rows // 1000}: {args.rows} dirty rows (random order), "
                                    f"{args.hospitals} true hospitals, Record class, PG n_particles={args.particles}, "
                                    "2 blocks, batched schedule, the product's default observed_sweep (Record has no "
-                                   "learned parameter: one batch per sweep), AddTypos pair tables of the OSA flavour", "rows": args.rows,
+                                   "learned parameter: one batch per sweep), AddTypos pair tables of the "
+                                   + ("OSA" if args.distance == "osa" else "unrestricted-DL") + " flavour", "rows": args.rows,
                        "latent_hospitals": int(tr.tables["Hospital"].n_live), "particles": args.particles,
                        "parallelism": f"rows sharded over {world} GPU(s)",
                        "init": f"the build's own initialize_trace from an empty trace (batches <= {args.init_batch})"
@@ -465,8 +469,10 @@ def main():
             "f1": acc["f1"], "accuracy": acc,
             "table_build": {"seconds": eng.pair_build_s, "pairs": eng.pair_count, "dp_cells": eng.pair_cells,
                             "dp_cells_per_s": eng.pair_cells / max(eng.pair_build_s, 1e-9),
-                            "distance": "OSA (restricted DL): the tables the headline sweep and its F1 run on; the three real programs "
-                                        "use unrestricted DL, 0.48 % of the synthetic pairs differ (DESIGN.md §3)",
+                            "distance": ("OSA (restricted DL): the tables the headline sweep and its F1 run on; the three real programs "
+                                         "use unrestricted DL, 0.48 % of the synthetic pairs differ (DESIGN.md §3); bench.py "
+                                         "--distance dl runs the same workload on unrestricted-DL tables") if args.distance == "osa"
+                            else "unrestricted Damerau-Levenshtein (dl_wave_kernel)",
                             "unrestricted_dl_sample": dl_sample},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,

@@ -906,7 +906,11 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
   // recompute-per-pass kernel (no LDS, 8 workgroups per CU) wins — unless the launch is grouped (scores shared by
   // the member items), which only the LDS kernel supports, or draws many times per item (one more pass per draw).
   static const size_t big_from = getenv("PCLEAN_BIG_FROM") ? (size_t)atol(getenv("PCLEAN_BIG_FROM")) : (size_t)80 * 1024;
-  if (lds > 160 * 1024 || (lds > big_from && !it.grp_off && !scores_out && n_draws <= 1)) {
+  // (a launch of at most 1024 items — the sub-batches of the latent sweeps — cannot fill the chip with workgroups whatever
+  // their LDS footprint: the LDS-resident kernel's single pass beats three recomputing passes there, measured 0.22 vs
+  // 0.40 ms per launch on the Hospital sub-batches)
+  static const bool big_few = getenv("PCLEAN_BIG_FEW_ITEMS") != nullptr;
+  if (lds > 160 * 1024 || (lds > big_from && !it.grp_off && !scores_out && n_draws <= 1 && (it.n > 1024 || big_few))) {
     if (it.n <= 1024) {  // too few workgroups to fill the chip: more threads per item
       hipLaunchKernelGGL(enum_node_big_kernel<1024>, dim3(it.n), dim3(1024), 0, ctx->stream, nd, dn, it, ch, seed, sweep, site,
                          n_draws, 0, lse_out, scores_out, draws_out);

@@ -1939,7 +1939,9 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   // short strings / flat posteriors: when a quarter of the items overflow the survivor list the integer pre-filter
   // does not pay for this option list -> its next evaluations go straight to the generic kernel (64, then 128, 256, ...
   // between retries)
-  if (n.kind == PCLEAN_NODE_LEAF && il.n >= 1024 && (size_t)n_over * 4 > (size_t)il.n) {
+  // (latent sub-batches hold a few hundred rows: the same rule from 64 items on — an option list of short strings, where
+  // the pre-filter keeps everything, otherwise pays a scan AND a full re-run in every sub-batch)
+  if (n.kind == PCLEAN_NODE_LEAF && il.n >= (il.ev_lo ? 64 : 1024) && (size_t)n_over * 4 > (size_t)il.n) {
     FastRoot& f = s->fast[block_id * 64 + node_id];
     f.disabled = f.backoff;
     f.backoff = std::min(f.backoff * 2, 1 << 20);
