@@ -94,6 +94,10 @@ struct ItemsDev {
   // latent item each list item stands for (identity when null)
   const AggDev* agg;
   const int32_t* ev_item;
+  // Indirect launch (the sync-free re-run of the items an evidence-set scan flagged): workgroup b of the generic kernels
+  // takes item sel[b] and retires when b >= *sel_n — the list and its length never leave the device.  Null: item b.
+  const int32_t* sel;
+  const unsigned int* sel_n;
 };
 
 // Log-marginals of the children of a "new row": either one value per item, or a
@@ -195,4 +199,4 @@ int pclean_launch_prior_terms_ev(pclean_ctx* ctx, int n_items, int P, int n_node
 // option list of a LEAF node scored against evidence sets (enum_kernels.hip: ev_leaf_block_kernel)
 int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const FastRootDev& fr, uint64_t seed,
                           uint32_t sweep, uint32_t site, int n_draws, double* lse_out, int32_t* draws_out,
-                          int32_t* overflow_flag, unsigned int* overflow_count);
+                          int32_t* overflow_flag, unsigned int* overflow_count, int32_t* overflow_list = nullptr);

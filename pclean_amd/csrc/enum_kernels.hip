@@ -273,7 +273,8 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
                                                              uint32_t site, int n_draws, double* __restrict__ lse_out,
                                                              int32_t* __restrict__ draws_out,
                                                              int32_t* __restrict__ overflow_flag,
-                                                             unsigned int* __restrict__ overflow_count) {
+                                                             unsigned int* __restrict__ overflow_count,
+                                                             int32_t* __restrict__ overflow_list) {
   __shared__ uint64_t s_pref[EV_SURV_CAP];  // exact scores (as doubles), then the fixed-point inclusive prefix
   __shared__ int32_t s_k[EV_SURV_CAP];
   __shared__ uint64_t s_w64[EV_W];
@@ -375,7 +376,8 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
     if (ns > EV_SURV_CAP) {
       if (tid == 0) {
         overflow_flag[to] = PCLEAN_CHOICE_NEW;
-        atomicAdd(overflow_count, 1u);
+        const unsigned int at = atomicAdd(overflow_count, 1u);
+        if (overflow_list) overflow_list[at] = t;  // (item index: the re-run reads the same item arrays)
       }
       continue;  // (every thread: ns is uniform; the loop's first barrier follows writes to other arrays only)
     }
@@ -440,13 +442,13 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
 
 int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const FastRootDev& fr, uint64_t seed,
                           uint32_t sweep, uint32_t site, int n_draws, double* lse_out, int32_t* draws_out,
-                          int32_t* overflow_flag, unsigned int* overflow_count) {
+                          int32_t* overflow_flag, unsigned int* overflow_count, int32_t* overflow_list) {
   if (it.n <= 0) return PCLEAN_OK;
   if (n_draws > 1) return pclean_fail(ctx, PCLEAN_ERR_ARG, "evidence-set option lists draw at most once per item");
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
   const int wgs = std::min(256 * 8, it.n);
   hipLaunchKernelGGL(ev_leaf_block_kernel, dim3(wgs), dim3(EV_T), 0, ctx->stream, nd, dn, it, fr, seed, sweep, site, n_draws,
-                     lse_out, draws_out, overflow_flag, overflow_count);
+                     lse_out, draws_out, overflow_flag, overflow_count, overflow_list);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }
@@ -482,7 +484,11 @@ __global__ __launch_bounds__(BT) void enum_node_kernel(const NodeDev nd, const D
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int g = blockIdx.x + item_base;
+  int g = blockIdx.x + item_base;
+  if (it.sel) {  // (never together with groups)
+    if ((unsigned int)g >= *it.sel_n) return;
+    g = it.sel[g];
+  }
   const int m_lo = it.grp_off ? it.grp_off[g] : g, m_hi = it.grp_off ? it.grp_off[g + 1] : g + 1;
   const int t = it.grp_off ? it.members[m_lo] : g;  // the item whose scores stand for the whole group
   const int to = it.out_pos ? it.out_pos[t] : t;    // output slot of this item
@@ -583,7 +589,11 @@ __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, con
   __shared__ uint64_t wsum[BT / 64];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int t = blockIdx.x + item_base;
+  int t = blockIdx.x + item_base;
+  if (it.sel) {
+    if ((unsigned int)t >= *it.sel_n) return;
+    t = it.sel[t];
+  }
   const int to = it.out_pos ? it.out_pos[t] : t;  // output slot of this item
   const int n = nd.n_cand;
   const bool fk = nd.kind == PCLEAN_NODE_FK;
@@ -910,8 +920,11 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
   // their LDS footprint: the LDS-resident kernel's single pass beats three recomputing passes there, measured 0.22 vs
   // 0.40 ms per launch on the Hospital sub-batches)
   static const bool big_few = getenv("PCLEAN_BIG_FEW_ITEMS") != nullptr;
-  if (lds > 160 * 1024 || (lds > big_from && !it.grp_off && !scores_out && n_draws <= 1 && (it.n > 1024 || big_few))) {
-    if (it.n <= 1024) {  // too few workgroups to fill the chip: more threads per item
+  // (an indirect launch runs as many workgroups as its device-side list holds — the items a scan could not settle, few)
+  const bool few = it.n <= 1024 || (it.sel && it.n <= 16384);
+  if (it.sel && it.grp_off) return pclean_fail(ctx, PCLEAN_ERR_ARG, "indirect launches are not grouped");
+  if (lds > 160 * 1024 || (lds > big_from && !it.grp_off && !scores_out && n_draws <= 1 && (!few || big_few))) {
+    if (few) {  // too few workgroups to fill the chip: more threads per item
       hipLaunchKernelGGL(enum_node_big_kernel<1024>, dim3(it.n), dim3(1024), 0, ctx->stream, nd, dn, it, ch, seed, sweep, site,
                          n_draws, 0, lse_out, scores_out, draws_out);
     } else {
@@ -928,7 +941,7 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
                                       160 * 1024));
       attr_set = true;
     }
-    if (it.n <= 1024) {  // (groups or items) too few workgroups to fill the chip: more threads per item
+    if (few) {  // (groups or items) too few workgroups to fill the chip: more threads per item
       hipLaunchKernelGGL(enum_node_kernel<1024>, dim3(it.n), dim3(1024), lds, ctx->stream, nd, dn, it, ch, seed, sweep, site,
                          n_draws, 0, lse_out, scores_out, draws_out);
     } else {

@@ -842,6 +842,11 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
   }
   if (s->h_counts) (void)hipHostFree(s->h_counts);
   if (s->h_over) (void)hipHostFree(s->h_over);
+  for (int k = 0; k < SweepState::MAX_SIDE; ++k) {
+    if (s->side[k]) (void)hipStreamDestroy(s->side[k]);
+    if (s->side_join[k]) (void)hipEventDestroy(s->side_join[k]);
+  }
+  if (s->side_fork) (void)hipEventDestroy(s->side_fork);
   if (s->h_poll) (void)hipHostFree((void*)s->h_poll);
   s->dummy_dp.release();
   s->dummy_ctr.release();
@@ -889,7 +894,11 @@ static void apply_over_stats(pclean_ctx* ctx) {  // after that synchronisation
     const unsigned int h = s->h_over[i];
     ctx->timing.reserved += (int32_t)h;
     if (r.time_it) ctx->root_stats.overflow_items = (int32_t)h;
-    if (r.leaf && r.n_items >= 1024 && (size_t)h * 4 > (size_t)r.n_items) {
+    // (evidence sets, min_items 64: the re-run is the generic kernel over every candidate and the scan is the cheap part
+    // — measured at 1M rows, full iteration: 459 ms with the quarter rule, 412 ms at three quarters, 369 ms without — so
+    // the pre-filter is only given up for a list when EVERY item comes back)
+    const bool ev = r.min_items < 1024;
+    if (r.leaf && r.n_items >= r.min_items && (ev ? h >= (unsigned int)r.n_items : (size_t)h * 4 > (size_t)r.n_items)) {
       FastRoot& f = s->fast[r.block * 64 + r.node];
       f.disabled = f.backoff;
       f.backoff = std::min(f.backoff * 2, 1 << 20);
@@ -1886,16 +1895,22 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   static const bool no_fast_over = getenv("PCLEAN_NO_FAST_OVERFLOW") != nullptr;
   const bool list_mode = fast && !no_fast_over && pclean_overflow_fast_ok(fr, it) && s->over_rec.size() < OVER_SLOTS &&
                          s->over_ctr.p != nullptr;
-  unsigned int* over_count = list_mode ? s->over_ctr.p + s->over_rec.size() : s->counter.p + 1;
+  // Evidence sets: the scan appends the items it could not settle to a device list as well, and the generic kernel
+  // re-runs them as an indirect launch (ItemsDev::sel) of il.n workgroups that retire beyond the list's length — a
+  // latent sub-batch evaluates a dozen option lists, each of which used to wait for its count here.
+  static const bool no_ev_list = getenv("PCLEAN_NO_EV_LIST") != nullptr;
+  const bool ev_list_mode = fast_ev && !no_ev_list && s->over_rec.size() < OVER_SLOTS && s->over_ctr.p != nullptr;
+  unsigned int* over_count = (list_mode || ev_list_mode) ? s->over_ctr.p + s->over_rec.size() : s->counter.p + 1;
   int32_t* over_list = nullptr;
-  if (list_mode) {
+  if (list_mode || ev_list_mode) {
     over_list = scratch<int32_t>(ctx, il.n);
     if (!over_list) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-    s->over_rec.push_back(SweepState::OverRec{block_id, node_id, il.n, time_it, n.kind == PCLEAN_NODE_LEAF});
+    s->over_rec.push_back(SweepState::OverRec{block_id, node_id, il.n, time_it, n.kind == PCLEAN_NODE_LEAF, fast_ev ? 64 : 1024});
   } else {
     HIPCHK(ctx, hipMemsetAsync(s->counter.p + 1, 0, sizeof(unsigned int), ctx->stream));
   }
-  HIPCHK(ctx, hipMemsetAsync(oflag, 0, (size_t)il.n * sizeof(int32_t), ctx->stream));  // kernels only set overflow markers
+  if (!ev_list_mode)  // (the list stands for the markers there)
+    HIPCHK(ctx, hipMemsetAsync(oflag, 0, (size_t)il.n * sizeof(int32_t), ctx->stream));  // kernels only set overflow markers
   if (fast) {
     int32_t* desc = scratch<int32_t>(ctx, pclean_fast_desc_words(it.n));
     if (!desc) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
@@ -1928,8 +1943,17 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
       return done < 0 ? done : PCLEAN_OK;
     }
   } else {
-    ProfScope ps(ctx, "evidence_option_scan");
-    rc = pclean_launch_ev_leaf(ctx, nd, it, fr, seed, sweep, site, n_draws, lse_out, draws_out, oflag, s->counter.p + 1);
+    {
+      ProfScope ps(ctx, "evidence_option_scan");
+      rc = pclean_launch_ev_leaf(ctx, nd, it, fr, seed, sweep, site, n_draws, lse_out, draws_out, oflag, over_count, over_list);
+    }
+    if (!rc && ev_list_mode) {
+      ProfScope ps2(ctx, "overflow_rerun");
+      ItemsDev itr = it;
+      itr.sel = over_list;
+      itr.sel_n = over_count;
+      return pclean_launch_enum(ctx, nd, itr, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out);
+    }
   }
   if (rc) return rc;
   unsigned int n_over = 0;
@@ -1941,7 +1965,8 @@ static int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList&
   // between retries)
   // (latent sub-batches hold a few hundred rows: the same rule from 64 items on — an option list of short strings, where
   // the pre-filter keeps everything, otherwise pays a scan AND a full re-run in every sub-batch)
-  if (n.kind == PCLEAN_NODE_LEAF && il.n >= (il.ev_lo ? 64 : 1024) && (size_t)n_over * 4 > (size_t)il.n) {
+  if (n.kind == PCLEAN_NODE_LEAF && il.n >= (il.ev_lo ? 64 : 1024) &&
+      (il.ev_lo ? n_over >= (unsigned int)il.n : (size_t)n_over * 4 > (size_t)il.n)) {  // (see apply_over_stats)
     FastRoot& f = s->fast[block_id * 64 + node_id];
     f.disabled = f.backoff;
     f.backoff = std::min(f.backoff * 2, 1 << 20);
@@ -2677,6 +2702,64 @@ __global__ void gather_chosen_vals_kernel(int n_items, int P, int n_nodes, const
   vals[q] = c > 0 ? pv[((size_t)t * P + c) * n_nodes + k] : -2;
 }
 
+// Side streams of pclean_sweep_latent (sweep_state.h); PCLEAN_LATENT_STREAMS=0 keeps everything on the library's stream.
+static int side_streams(pclean_ctx* ctx) {
+  SweepState* s = st(ctx);
+  if (s->n_side >= 0) return s->n_side;
+  const char* e = getenv("PCLEAN_LATENT_STREAMS");
+  int want = e ? atoi(e) : 6;
+  want = std::max(0, std::min(want, (int)SweepState::MAX_SIDE));
+  s->n_side = 0;
+  if (want > 0 && hipEventCreateWithFlags(&s->side_fork, hipEventDisableTiming) != hipSuccess) return 0;
+  for (int k = 0; k < want; ++k) {
+    if (hipStreamCreateWithFlags(&s->side[k], hipStreamNonBlocking) != hipSuccess) break;
+    if (hipEventCreateWithFlags(&s->side_join[k], hipEventDisableTiming) != hipSuccess) break;
+    s->n_side = k + 1;
+  }
+  return s->n_side;
+}
+// Work of one call spread over the side streams: fork() after the inputs are queued on the library's stream, use(i) to
+// issue the i-th independent piece, join() before anything on the library's stream reads the results.  An early
+// return (error) waits for the side streams on the host: the scratch pool they use is rewound by the next call.
+struct SideFork {
+  pclean_ctx* ctx;
+  SweepState* s;
+  hipStream_t main;
+  bool forked = false, used[SweepState::MAX_SIDE] = {};
+  explicit SideFork(pclean_ctx* c) : ctx(c), s(st(c)), main(c->stream) {}
+  int use(int i) {
+    const int K = side_streams(ctx);
+    if (K <= 0) return PCLEAN_OK;
+    if (!forked) {
+      HIPCHK(ctx, hipEventRecord(s->side_fork, main));
+      forked = true;
+    }
+    const int k = i % K;
+    if (!used[k]) {
+      HIPCHK(ctx, hipStreamWaitEvent(s->side[k], s->side_fork, 0));
+      used[k] = true;
+    }
+    ctx->stream = s->side[k];
+    return PCLEAN_OK;
+  }
+  void back() { ctx->stream = main; }
+  int join() {
+    back();
+    for (int k = 0; k < SweepState::MAX_SIDE; ++k)
+      if (used[k]) {
+        used[k] = false;
+        HIPCHK(ctx, hipEventRecord(s->side_join[k], s->side[k]));
+        HIPCHK(ctx, hipStreamWaitEvent(main, s->side_join[k], 0));
+      }
+    return PCLEAN_OK;
+  }
+  ~SideFork() {
+    back();
+    for (int k = 0; k < SweepState::MAX_SIDE; ++k)
+      if (used[k]) (void)hipStreamSynchronize(s->side[k]);
+  }
+};
+
 extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
                                    int32_t block_id, int32_t n_roots, const int32_t* roots, int32_t n_items,
                                    const int32_t* keys, const int32_t* ev_off, const int32_t* ev_rows,
@@ -2834,65 +2917,108 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
     int32_t* evh = scratch<int32_t>(ctx, cnt);
     int32_t* part = scratch<int32_t>(ctx, cnt);
     int32_t* org = scratch<int32_t>(ctx, cnt);
-    int32_t* ex = scratch<int32_t>(ctx, cnt);
-    int32_t* draws = scratch<int32_t>(ctx, cnt);
-    if (!list || !rng || !evl || !evh || !part || !org || !ex || !draws)
-      return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    if (!list || !rng || !evl || !evh || !part || !org) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
     HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(compact_new_kernel, grid1(n_items), dim3(256), 0, ctx->stream, (size_t)n_items, d_flag, 1,
                        s->counter.p, list, nullptr);
     hipLaunchKernelGGL(latent_items_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, list, d_keys, d_off,
                        d_chosen, rng, evl, evh, part, org);
     ItemList il{(int)cnt, nullptr, nullptr, part, org, evl, evh, d_evr, d_evc, rng};
-    for (int r = 0; r < n_roots; ++r) {
-      const int root = roots[r];
-      const pclean_node& rn = b.nodes[root];
-      const int32_t* rex = nullptr;
-      if (rn.kind == PCLEAN_NODE_FK) {
+    // The roots of a latent row's plan are independent given its evidence (each writes its own column of d_vals, draws
+    // at its own RNG site).  Three passes: (A) the reference slots' enumerations on the library's stream — queued first,
+    // nothing in a sub-batch's pass waits for the host; (B) the option lists, each on a side stream, overlapping (A) and
+    // each other; (C) back on the library's stream, per reference slot: how many rows proposed a NEW referent (the one
+    // count the host needs) and the sampling of those referents' contents.  A batch large enough for the gate of the
+    // new-row branch (a count read-back inside eval_node) queues its option lists before (A) instead.
+    SideFork sf(ctx);
+    std::vector<int> fk_roots, leaf_roots;
+    for (int r = 0; r < n_roots; ++r) (b.nodes[roots[r]].kind == PCLEAN_NODE_LEAF ? leaf_roots : fk_roots).push_back(r);
+    unsigned int* c2ctr = scratch<unsigned int>(ctx, std::max(n_roots, 1));
+    if (!c2ctr) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    HIPCHK(ctx, hipMemsetAsync(c2ctr, 0, (size_t)std::max(n_roots, 1) * sizeof(unsigned int), ctx->stream));
+    std::vector<int32_t*> fk_ex(n_roots, nullptr), fk_l2(n_roots, nullptr);
+    auto pass_fk = [&]() -> int {
+      for (int r : fk_roots) {
+        const int root = roots[r];
+        const pclean_node& rn = b.nodes[root];
+        int32_t* ex = scratch<int32_t>(ctx, cnt);
+        int32_t* draws = scratch<int32_t>(ctx, cnt);
+        if (!ex || !draws) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
         hipLaunchKernelGGL(gather_i32_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, list,
                            d_excl + (size_t)r * n_items, ex);
-        rex = ex;
-      }
-      int rc = eval_node(ctx, block_id, root, il, rex, seed, sweep_idx, 1, nullptr, draws, nullptr, nullptr, false);
-      if (rc) return rc;
-      hipLaunchKernelGGL(scatter_vals_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, org, draws, nn, root,
-                         d_vals);
-      if (rn.kind == PCLEAN_NODE_FK && rn.n_children > 0) {
-        // referents proposed as NEW: sample their contents with the same evidence
-        HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-        hipLaunchKernelGGL(compact_new_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (size_t)cnt, draws, 0,
-                           s->counter.p, nullptr, nullptr);
-        unsigned int c2 = 0;
-        PCLEAN_READ_COUNT(ctx, s->counter.p, &c2);
-        if (c2) {
-          int32_t* l2 = scratch<int32_t>(ctx, c2);
-          int32_t* row2 = scratch<int32_t>(ctx, c2);
-          int32_t* cx2 = scratch<int32_t>(ctx, (size_t)c2 * PCLEAN_MAX_CTX);
-          int32_t* part2 = scratch<int32_t>(ctx, c2);
-          int32_t* org2 = scratch<int32_t>(ctx, c2);
-          int32_t* evl2 = scratch<int32_t>(ctx, c2);
-          int32_t* evh2 = scratch<int32_t>(ctx, c2);
-          int32_t* rng2 = scratch<int32_t>(ctx, c2);
-          int32_t* ex2 = scratch<int32_t>(ctx, c2);
-          if (!l2 || !row2 || !cx2 || !part2 || !org2 || !evl2 || !evh2 || !rng2 || !ex2)
-            return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-          HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-          hipLaunchKernelGGL(compact_new_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (size_t)cnt, draws, 1,
-                             s->counter.p, l2, nullptr);
-          hipLaunchKernelGGL(sublist_items_kernel, grid1(c2), dim3(256), 0, ctx->stream, (int)c2, l2, il.row, il.ctx,
-                             il.particle, il.origin, row2, cx2, part2, org2, il.ev_lo, il.ev_hi, il.rng_row, evl2, evh2,
-                             rng2);
-          hipLaunchKernelGGL(gather_i32_kernel, grid1(c2), dim3(256), 0, ctx->stream, (int)c2, l2, rex, ex2);
-          ItemList sub{(int)c2, nullptr, nullptr, part2, org2, evl2, evh2, d_evr, d_evc, rng2};
-          rc = sample_children(ctx, block_id, root, sub, ex2, seed, sweep_idx, d_vals, nn);
-          if (rc) return rc;
+        fk_ex[r] = ex;
+        int rc = eval_node(ctx, block_id, root, il, ex, seed, sweep_idx, 1, nullptr, draws, nullptr, nullptr, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(scatter_vals_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, org, draws, nn, root,
+                           d_vals);
+        if (rn.n_children > 0) {  // rows that proposed a NEW referent: listed now, counted by the host in pass C
+          fk_l2[r] = scratch<int32_t>(ctx, cnt);
+          if (!fk_l2[r]) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+          hipLaunchKernelGGL(compact_new_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (size_t)cnt, draws, 1, c2ctr + r,
+                             fk_l2[r], nullptr);
         }
       }
+      return PCLEAN_OK;
+    };
+    auto pass_leaf = [&]() -> int {
+      for (size_t oi = 0; oi < leaf_roots.size(); ++oi) {
+        const int r = leaf_roots[oi];
+        const int root = roots[r];
+        const int rcs = sf.use((int)oi);
+        if (rcs) return rcs;
+        int32_t* draws = scratch<int32_t>(ctx, cnt);
+        if (!draws) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+        int rc = eval_node(ctx, block_id, root, il, nullptr, seed, sweep_idx, 1, nullptr, draws, nullptr, nullptr, false);
+        if (rc) return rc;
+        hipLaunchKernelGGL(scatter_vals_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (int)cnt, org, draws, nn, root,
+                           d_vals);
+      }
+      sf.back();
+      return PCLEAN_OK;
+    };
+    const char* gm = getenv("PCLEAN_GATE_MIN");
+    const bool fk_first = (int)cnt < (gm ? atoi(gm) : 2048);
+    int rc = fk_first ? pass_fk() : pass_leaf();
+    if (!rc) rc = fk_first ? pass_leaf() : pass_fk();
+    if (rc) return rc;
+    for (int r : fk_roots) {
+      const int root = roots[r];
+      if (!fk_l2[r]) continue;
+      // referents proposed as NEW: sample their contents with the same evidence
+      unsigned int c2 = 0;
+      PCLEAN_READ_COUNT(ctx, c2ctr + r, &c2);
+      if (c2) {
+        int32_t* l2 = fk_l2[r];
+        int32_t* row2 = scratch<int32_t>(ctx, c2);
+        int32_t* cx2 = scratch<int32_t>(ctx, (size_t)c2 * PCLEAN_MAX_CTX);
+        int32_t* part2 = scratch<int32_t>(ctx, c2);
+        int32_t* org2 = scratch<int32_t>(ctx, c2);
+        int32_t* evl2 = scratch<int32_t>(ctx, c2);
+        int32_t* evh2 = scratch<int32_t>(ctx, c2);
+        int32_t* rng2 = scratch<int32_t>(ctx, c2);
+        int32_t* ex2 = scratch<int32_t>(ctx, c2);
+        if (!row2 || !cx2 || !part2 || !org2 || !evl2 || !evh2 || !rng2 || !ex2)
+          return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+        hipLaunchKernelGGL(sublist_items_kernel, grid1(c2), dim3(256), 0, ctx->stream, (int)c2, l2, il.row, il.ctx,
+                           il.particle, il.origin, row2, cx2, part2, org2, il.ev_lo, il.ev_hi, il.rng_row, evl2, evh2,
+                           rng2);
+        hipLaunchKernelGGL(gather_i32_kernel, grid1(c2), dim3(256), 0, ctx->stream, (int)c2, l2, fk_ex[r], ex2);
+        ItemList sub{(int)c2, nullptr, nullptr, part2, org2, evl2, evh2, d_evr, d_evc, rng2};
+        rc = sample_children(ctx, block_id, root, sub, ex2, seed, sweep_idx, d_vals, nn);
+        if (rc) return rc;
+      }
     }
+    const int rcj = sf.join();
+    if (rcj) return rcj;
   }
   HIPCHK(ctx, hipMemcpyAsync(chosen, d_chosen, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(vals, d_vals, (size_t)n_items * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+  {
+    const int rcq = queue_over_copy(ctx);  // the sync-free re-runs' counts ride on the call's one synchronisation
+    if (rcq) return rcq;
+  }
   PCLEAN_SYNC(ctx);
+  apply_over_stats(ctx);
   s->lat_agg.clear();
   if (s->prof_on) prof_collect(ctx);
   return finish_call(ctx);

@@ -111,8 +111,15 @@ struct SweepState {
   // (overflow_lds_kernel in list mode): counted into the statistics / heuristics at the end of the call
   bool scan_stats_used = false;
   DevBuf<unsigned int> over_ctr;   // [OVER_SLOTS + STAT_WORDS]: the tail = scan statistics of the timed root launch
-  struct OverRec { int block, node, n_items; bool time_it, leaf; };
+  struct OverRec { int block, node, n_items; bool time_it, leaf; int min_items; };  // min_items: from how many items on the "does the pre-filter pay" rule applies
   std::vector<OverRec> over_rec;
+  // pclean_sweep_latent: the option lists of a latent row are independent given its evidence — each is evaluated on one
+  // of these streams (forked from / joined into the library's stream by events), so that the few-hundred-workgroup
+  // launches of a sub-batch overlap on the chip instead of running one behind the other
+  static const int MAX_SIDE = 8;
+  hipStream_t side[MAX_SIDE] = {};
+  hipEvent_t side_fork = nullptr, side_join[MAX_SIDE] = {};
+  int n_side = -1;  // -1: not created yet
   unsigned int* h_over = nullptr;  // page-locked copy of over_ctr
   // dummy_correction_kernel: distance matrices of the strings drawn for chosen ProposalDummyValues
   DevBuf<int16_t> dummy_dp;
