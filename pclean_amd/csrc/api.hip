@@ -1,6 +1,7 @@
 // C ABI entry points: lifecycle, string pool, observed columns, pair tables,
 // density tables, StringPrior scores, candidate tables, plan upload.
 // The enumeration / sweep entry points live in sweep.hip.
+#include <chrono>
 #include <cmath>
 #include <limits>
 
@@ -38,6 +39,7 @@ extern "C" int pclean_ctx_destroy(pclean_ctx* ctx) {
   (void)pclean_comm_destroy(ctx);
   pclean_commit_state_free(ctx);
   pclean_sweep_state_free(ctx);
+  ctx->stage.release();
   ctx->stats_pack.release();
   ctx->sym.release();
   ctx->off.release();
@@ -373,6 +375,10 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
   if (!ctx || table_id < 0 || table_id >= PCLEAN_MAX_TABLES || n_rows < 0 || n_cols < 0 || !counts)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_table: bad arguments");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  static const bool dbg_upload = getenv("PCLEAN_DEBUG_UPLOAD") != nullptr;
+  const auto dbg_t0 = std::chrono::steady_clock::now();
+  auto dbg_ms = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - dbg_t0).count(); };
+  double dbg_a = 0, dbg_b = 0, dbg_c = 0;
   CandTable& t = ctx->cand[table_id];
   // cols == NULL: keep the columns uploaded before (same shape), refresh counts / CRP pieces only
   const bool keep_cols = !cols && (int64_t)n_rows * n_cols > 0;
@@ -387,6 +393,7 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
   if (t.cols.alloc(std::max<size_t>(n, 1)) || t.counts.alloc(nr) || t.logc_full.alloc(nr) || t.logc_m1.alloc(nr) ||
       t.stats.alloc(nr))
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  dbg_a = dbg_ms();
   int64_t total = 0, live = 0;
   t.h_counts.assign(counts, counts + n_rows);
   t.h_logc_full.resize(n_rows);
@@ -403,11 +410,32 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
   t.scal[1] = std::log((double)(total - 1) + strength);
   t.scal[2] = std::log(strength + discount * (double)live);
   t.scal[3] = std::log(strength + discount * (double)(live - 1));
-  if (n && !keep_cols) HIPCHK(ctx, hipMemcpy(t.cols.p, cols, n * sizeof(int32_t), hipMemcpyHostToDevice));
-  if (n_rows) {
-    HIPCHK(ctx, hipMemcpy(t.counts.p, counts, n_rows * sizeof(int64_t), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(t.logc_full.p, t.h_logc_full.data(), n_rows * sizeof(double), hipMemcpyHostToDevice));
-    HIPCHK(ctx, hipMemcpy(t.logc_m1.p, t.h_logc_m1.data(), n_rows * sizeof(double), hipMemcpyHostToDevice));
+  dbg_b = dbg_ms();
+  // (copies on the library's own stream, one wait at the end: a blocking hipMemcpy goes through the null stream, whose
+  // first operation after the library's stream has been busy was measured at ~21 ms for 48 bytes)
+  // through the library's page-locked staging area (ctx.h: HostStage), on the library's stream, one wait at the end
+  {
+    const size_t b_cols = (n && !keep_cols) ? n * sizeof(int32_t) : 0, b_r = (size_t)n_rows * 8;
+    if (ctx->stage.grow(b_cols + 3 * b_r + 4 * 256)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "page-locked staging alloc failed");
+    ctx->stage.rewind();
+    if (b_cols) {
+      void* h = ctx->stage.take(b_cols);
+      memcpy(h, cols, b_cols);
+      HIPCHK(ctx, hipMemcpyAsync(t.cols.p, h, b_cols, hipMemcpyHostToDevice, ctx->stream));
+    }
+    dbg_c = dbg_ms();
+    if (n_rows) {
+      void* h0 = ctx->stage.take(b_r);
+      void* h1 = ctx->stage.take(b_r);
+      void* h2 = ctx->stage.take(b_r);
+      memcpy(h0, counts, b_r);
+      memcpy(h1, t.h_logc_full.data(), b_r);
+      memcpy(h2, t.h_logc_m1.data(), b_r);
+      HIPCHK(ctx, hipMemcpyAsync(t.counts.p, h0, b_r, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(t.logc_full.p, h1, b_r, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(ctx, hipMemcpyAsync(t.logc_m1.p, h2, b_r, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (b_cols || n_rows) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }
   t.strength = strength;
   t.discount = discount;
@@ -420,6 +448,9 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
     t.cols_version = t.version;
     t.cols_delta_n = -1;
   }
+  if (dbg_upload && dbg_ms() > 1.0)
+    fprintf(stderr, "[pclean_set_table] table %d (%d x %d, cols %s): alloc %.2f, host logs %.2f, cols copy %.2f, rest %.2f ms\n", table_id,
+            n_rows, n_cols, keep_cols ? "kept" : "sent", dbg_a, dbg_b - dbg_a, dbg_c - dbg_b, dbg_ms() - dbg_c);
   return PCLEAN_OK;
 }
 
@@ -438,8 +469,18 @@ extern "C" int pclean_set_options(pclean_ctx* ctx, int32_t table_id, int32_t n_o
   // just the log-probabilities changed (ChooseProportionally options are re-uploaded with every parameter move)
   const bool same_vals = t.valid && t.is_options_1col && (int)t.h_vals.size() == n_options &&
                          memcmp(t.h_vals.data(), values, (size_t)n_options * sizeof(int32_t)) == 0;
-  HIPCHK(ctx, hipMemcpy(t.cols.p, values, n_options * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIPCHK(ctx, hipMemcpy(t.logc_full.p, logp, n_options * sizeof(double), hipMemcpyHostToDevice));
+  {
+    const size_t bv = (size_t)n_options * sizeof(int32_t), bl = (size_t)n_options * sizeof(double);
+    if (ctx->stage.grow(bv + bl + 2 * 256)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "page-locked staging alloc failed");
+    ctx->stage.rewind();
+    void* hv = ctx->stage.take(bv);
+    void* hl = ctx->stage.take(bl);
+    memcpy(hv, values, bv);
+    memcpy(hl, logp, bl);
+    HIPCHK(ctx, hipMemcpyAsync(t.cols.p, hv, bv, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(t.logc_full.p, hl, bl, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  }
   t.h_vals.assign(values, values + n_options);
   t.is_options_1col = true;
   t.h_logc_full.assign(logp, logp + n_options);

@@ -38,6 +38,41 @@ struct DevBuf {
   }
 };
 
+// Page-locked staging area owned by the library (grow-only).  Host arrays of the caller are copied through it instead
+// of being handed to hipMemcpy[Async]: the runtime page-locks a caller's pageable pages for the DMA and keeps that
+// registration; when the caller later frees them (NumPy returns large arrays to the OS) the kernel driver's MMU
+// notifier evicts the process's GPU queues to drop the mapping and restores them lazily — measured as 5-27 ms on
+// the next GPU operation, whatever its size (a 48-byte table upload after a latent sweep had uploaded 16 MB of evidence).
+struct HostStage {
+  unsigned char* p = nullptr;
+  size_t n = 0, used = 0;
+  void rewind() { used = 0; }
+  void* take(size_t bytes) {  // null when the area cannot hold it (grow() first)
+    const size_t at = (used + 255) & ~(size_t)255;
+    if (at + bytes > n) return nullptr;
+    used = at + bytes;
+    return p + at;
+  }
+  int grow(size_t bytes) {  // only between uses (nothing in flight reads the old area)
+    if (bytes <= n) return 0;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc((void**)&p, want, hipHostMallocDefault) != hipSuccess) {
+      p = nullptr;
+      return -1;
+    }
+    n = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    n = used = 0;
+  }
+};
+
 extern uint64_t g_pclean_version;  // bumped whenever a table is (re)uploaded; keys the leaf caches
 
 struct PairTable {
@@ -175,6 +210,7 @@ struct pclean_ctx {
   bool dev_cur_valid = false;
   bool defer_outputs = false;   // pclean_set_sweep_mode bit 0
   void* commit_state = nullptr;  // owned by commit.hip
+  HostStage stage;               // page-locked staging of caller arrays (table uploads, latent-sweep inputs / outputs)
   const int32_t* obs_override = nullptr;  // sweep.hip: ensure_leaf_cache scores "item t observes value t"
   int32_t active_begin = 0, active_count = -1;  // pclean_set_active_rows window (-1 = all rows)
   bool prior_mode = false;     // sweep.hip: the running sweep proposes from the priors (use_dd_proposals = false)

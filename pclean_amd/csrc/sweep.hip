@@ -2799,12 +2799,26 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   int32_t* d_flag = scratch<int32_t>(ctx, n_items);
   if (!d_keys || !d_off || !d_evr || (ev_ctx && !d_evc) || !d_excl || !d_chosen || !d_vals || !d_flag)
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-  HIPCHK(ctx, hipMemcpyAsync(d_keys, keys, (size_t)n_items * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(d_off, ev_off, ((size_t)n_items + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (n_ev) HIPCHK(ctx, hipMemcpyAsync(d_evr, ev_rows, (size_t)n_ev * 4, hipMemcpyHostToDevice, ctx->stream));
-  if (ev_ctx && n_ev)
-    HIPCHK(ctx, hipMemcpyAsync(d_evc, ev_ctx, (size_t)n_ev * PCLEAN_MAX_CTX * 4, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(d_excl, excl, (size_t)n_roots * n_items * 4, hipMemcpyHostToDevice, ctx->stream));
+  // inputs and outputs travel through the library's page-locked staging area (ctx.h: HostStage — never the caller's pages)
+  const size_t b_keys = (size_t)n_items * 4, b_off = ((size_t)n_items + 1) * 4, b_evr = (size_t)n_ev * 4,
+               b_evc = (ev_ctx && n_ev) ? (size_t)n_ev * PCLEAN_MAX_CTX * 4 : 0, b_excl = (size_t)n_roots * n_items * 4,
+               b_vals = (size_t)n_items * nn * 4;
+  if (ctx->stage.grow(2 * b_keys + b_off + b_evr + b_evc + b_excl + b_vals + 8 * 256))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "page-locked staging alloc failed");
+  ctx->stage.rewind();
+  auto stage_up = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+    if (!bytes) return hipSuccess;
+    void* h = ctx->stage.take(bytes);
+    memcpy(h, src, bytes);
+    return hipMemcpyAsync(dst, h, bytes, hipMemcpyHostToDevice, ctx->stream);
+  };
+  HIPCHK(ctx, stage_up(d_keys, keys, b_keys));
+  HIPCHK(ctx, stage_up(d_off, ev_off, b_off));
+  HIPCHK(ctx, stage_up(d_evr, ev_rows, b_evr));
+  HIPCHK(ctx, stage_up(d_evc, ev_ctx, b_evc));
+  HIPCHK(ctx, stage_up(d_excl, excl, b_excl));
+  int32_t* h_chosen = (int32_t*)ctx->stage.take(b_keys);
+  int32_t* h_vals = (int32_t*)ctx->stage.take(b_vals);
   int32_t* d_iop = scratch<int32_t>(ctx, std::max(n_ev, 1));
   if (!d_iop) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   if (n_ev) hipLaunchKernelGGL(item_of_pos_kernel, grid1(n_ev), dim3(256), 0, ctx->stream, n_ev, n_items, d_off, d_iop);
@@ -2892,9 +2906,11 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
                                         use_mh, wl, d_keys, seed, sweep_idx, (uint32_t)block_id, d_chosen));
     hipLaunchKernelGGL(gather_chosen_vals_kernel, grid1((size_t)n_items * nn), dim3(256), 0, ctx->stream, n_items, P, nn,
                        d_chosen, pv, d_vals);
-    HIPCHK(ctx, hipMemcpyAsync(chosen, d_chosen, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(vals, d_vals, (size_t)n_items * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_chosen, d_chosen, b_keys, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(h_vals, d_vals, b_vals, hipMemcpyDeviceToHost, ctx->stream));
     PCLEAN_SYNC(ctx);
+    memcpy(chosen, h_chosen, b_keys);
+    memcpy(vals, h_vals, b_vals);
     s->lat_agg.clear();
     if (s->prof_on) prof_collect(ctx);
     return finish_call(ctx);
@@ -3011,13 +3027,15 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
     const int rcj = sf.join();
     if (rcj) return rcj;
   }
-  HIPCHK(ctx, hipMemcpyAsync(chosen, d_chosen, (size_t)n_items * 4, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(vals, d_vals, (size_t)n_items * nn * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(h_chosen, d_chosen, b_keys, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(h_vals, d_vals, b_vals, hipMemcpyDeviceToHost, ctx->stream));
   {
     const int rcq = queue_over_copy(ctx);  // the sync-free re-runs' counts ride on the call's one synchronisation
     if (rcq) return rcq;
   }
   PCLEAN_SYNC(ctx);
+  memcpy(chosen, h_chosen, b_keys);
+  memcpy(vals, h_vals, b_vals);
   apply_over_stats(ctx);
   s->lat_agg.clear();
   if (s->prof_on) prof_collect(ctx);

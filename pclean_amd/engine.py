@@ -219,7 +219,13 @@ class Engine:
         m = lw.model
         last = self._last_upload
         dc = getattr(self, "_dc", None)
+        dbg = os.environ.get("PCLEAN_DEBUG_UPLOAD")
         for cname, t in trace.tables.items():
+            if dbg:
+                import time
+                if "t_dbg" in locals() and time.perf_counter() - t_dbg[1] > 1e-3:
+                    print(f"[upload] {t_dbg[0]}: {1e3 * (time.perf_counter() - t_dbg[1]):.1f} ms", flush=True)
+                t_dbg = (cname, time.perf_counter())
             cols, counts = t.view()
             cap = t.n
             if dc is not None and cname in dc["tables"]:
@@ -252,6 +258,12 @@ class Engine:
             if dc is not None and cname in dc["tables"]:
                 hip.commit_set_table_state(lw.table_id[cname], t.n, t.free)
                 dc["alloc"][cname] = alloc
+        if dbg and "t_dbg" in locals():
+            import time
+            if time.perf_counter() - t_dbg[1] > 1e-3:
+                print(f"[upload] {t_dbg[0]}: {1e3 * (time.perf_counter() - t_dbg[1]):.1f} ms (dirty cols / shapes: "
+                      f"{ {c: (bool(tt.cols_dirty), self._uploaded_shape.get(c)) for c, tt in trace.tables.items()} })", flush=True)
+            t_opt = time.perf_counter()
         for (cname, aname), dom in lw.latent_dom.items():
             d = m.classes[cname].attr(aname).dist
             if isinstance(d, ChooseProportionally):

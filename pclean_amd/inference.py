@@ -99,8 +99,8 @@ def build_evidence(lw, trace, cname):
         raise NotImplementedError(f"latent class {cname}: JuliaNode contexts together with MaybeSwap / Gaussian evidence contexts")
     if sources:  # slot s = the evidence row's value of source s (model.py: _build_latent_plans / _copy_subtree)
         from . import _lib
-        ev_ctx = np.zeros((len(ev_rows), max(2, len(sources))), dtype=np.int32)
         assert len(sources) <= _lib.MAX_CTX
+        ev_ctx = np.zeros((len(ev_rows), _lib.MAX_CTX), dtype=np.int32)  # (the width the library indexes)
         for s_, (ob, col) in enumerate(sources):
             rc = lw.blocks[ob]["root_class"]
             ev_ctx[:, s_] = trace.tables[rc].cols[col, trace.cur[ob]][ev_rows]
@@ -423,8 +423,10 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
     comm = comm or Comm()
     lw = engine.lw
     pl = lw.latent_plans[cname]
+    from ._lib import _ctx_cols
     with _timed(f"latent/{cname}/build_evidence"):
         live, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname)
+        ev_ctx = _ctx_cols(ev_ctx)  # padded to the library's width once, not in every sub-batch's call
     if len(live) == 0:
         return 0
     t = trace.tables[cname]
@@ -468,6 +470,7 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
                 pl = lw.latent_plans[cname]  # (the lowered model was rebuilt in place)
                 # placeholders became drawn strings: per-evidence-row ctx values may have held a dummy's id
                 live2, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname)
+                ev_ctx = _ctx_cols(ev_ctx)
                 assert np.array_equal(live2, live)
     for _ in range(deferred_moves):
         resample_class_parameters(trace, cname)
