@@ -845,6 +845,7 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
   for (int k = 0; k < SweepState::MAX_SIDE; ++k) {
     if (s->side[k]) (void)hipStreamDestroy(s->side[k]);
     if (s->side_join[k]) (void)hipEventDestroy(s->side_join[k]);
+    if (s->side_mid[k]) (void)hipEventDestroy(s->side_mid[k]);
   }
   if (s->side_fork) (void)hipEventDestroy(s->side_fork);
   if (s->h_poll) (void)hipHostFree((void*)s->h_poll);
@@ -2714,6 +2715,7 @@ static int side_streams(pclean_ctx* ctx) {
   for (int k = 0; k < want; ++k) {
     if (hipStreamCreateWithFlags(&s->side[k], hipStreamNonBlocking) != hipSuccess) break;
     if (hipEventCreateWithFlags(&s->side_join[k], hipEventDisableTiming) != hipSuccess) break;
+    if (hipEventCreateWithFlags(&s->side_mid[k], hipEventDisableTiming) != hipSuccess) break;
     s->n_side = k + 1;
   }
   return s->n_side;
@@ -2727,12 +2729,18 @@ struct SideFork {
   hipStream_t main;
   bool forked = false, used[SweepState::MAX_SIDE] = {};
   explicit SideFork(pclean_ctx* c) : ctx(c), s(st(c)), main(c->stream) {}
+  int fork() {  // what is queued on the library's stream so far is what the side streams wait for
+    if (side_streams(ctx) <= 0 || forked) return PCLEAN_OK;
+    HIPCHK(ctx, hipEventRecord(s->side_fork, main));
+    forked = true;
+    return PCLEAN_OK;
+  }
   int use(int i) {
     const int K = side_streams(ctx);
     if (K <= 0) return PCLEAN_OK;
     if (!forked) {
-      HIPCHK(ctx, hipEventRecord(s->side_fork, main));
-      forked = true;
+      const int rc = fork();
+      if (rc) return rc;
     }
     const int k = i % K;
     if (!used[k]) {
@@ -2743,6 +2751,15 @@ struct SideFork {
     return PCLEAN_OK;
   }
   void back() { ctx->stream = main; }
+  int mark() {  // the library's stream waits for what the current side stream holds so far (not for what follows on it)
+    if (ctx->stream == main) return PCLEAN_OK;
+    for (int k = 0; k < SweepState::MAX_SIDE; ++k)
+      if (ctx->stream == s->side[k]) {
+        HIPCHK(ctx, hipEventRecord(s->side_mid[k], s->side[k]));
+        HIPCHK(ctx, hipStreamWaitEvent(main, s->side_mid[k], 0));
+      }
+    return PCLEAN_OK;
+  }
   int join() {
     back();
     for (int k = 0; k < SweepState::MAX_SIDE; ++k)
@@ -2953,10 +2970,21 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
     if (!c2ctr) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
     HIPCHK(ctx, hipMemsetAsync(c2ctr, 0, (size_t)std::max(n_roots, 1) * sizeof(unsigned int), ctx->stream));
     std::vector<int32_t*> fk_ex(n_roots, nullptr), fk_l2(n_roots, nullptr);
+    {
+      const int rcf = sf.fork();  // (before pass A is queued: the side streams wait for the inputs, not for pass A)
+      if (rcf) return rcf;
+    }
+    const char* gm = getenv("PCLEAN_GATE_MIN");
+    const bool fk_first = (int)cnt < (gm ? atoi(gm) : 2048);
+    int n_side_used = 0;
     auto pass_fk = [&]() -> int {
       for (int r : fk_roots) {
         const int root = roots[r];
         const pclean_node& rn = b.nodes[root];
+        if (fk_first) {  // (no count read-back, no shared counter on this path below the gate's size: a stream of its own)
+          const int rcs = sf.use(n_side_used++);
+          if (rcs) return rcs;
+        }
         int32_t* ex = scratch<int32_t>(ctx, cnt);
         int32_t* draws = scratch<int32_t>(ctx, cnt);
         if (!ex || !draws) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
@@ -2973,14 +3001,17 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
           hipLaunchKernelGGL(compact_new_kernel, grid1(cnt), dim3(256), 0, ctx->stream, (size_t)cnt, draws, 1, c2ctr + r,
                              fk_l2[r], nullptr);
         }
+        const int rcm = sf.mark();  // pass C (library's stream) follows this root's pass A, not the option lists
+        if (rcm) return rcm;
       }
+      sf.back();
       return PCLEAN_OK;
     };
     auto pass_leaf = [&]() -> int {
       for (size_t oi = 0; oi < leaf_roots.size(); ++oi) {
         const int r = leaf_roots[oi];
         const int root = roots[r];
-        const int rcs = sf.use((int)oi);
+        const int rcs = sf.use(n_side_used++);
         if (rcs) return rcs;
         int32_t* draws = scratch<int32_t>(ctx, cnt);
         if (!draws) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
@@ -2992,8 +3023,6 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
       sf.back();
       return PCLEAN_OK;
     };
-    const char* gm = getenv("PCLEAN_GATE_MIN");
-    const bool fk_first = (int)cnt < (gm ? atoi(gm) : 2048);
     int rc = fk_first ? pass_fk() : pass_leaf();
     if (!rc) rc = fk_first ? pass_leaf() : pass_fk();
     if (rc) return rc;

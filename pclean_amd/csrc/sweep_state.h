@@ -118,7 +118,7 @@ struct SweepState {
   // launches of a sub-batch overlap on the chip instead of running one behind the other
   static const int MAX_SIDE = 8;
   hipStream_t side[MAX_SIDE] = {};
-  hipEvent_t side_fork = nullptr, side_join[MAX_SIDE] = {};
+  hipEvent_t side_fork = nullptr, side_join[MAX_SIDE] = {}, side_mid[MAX_SIDE] = {};
   int n_side = -1;  // -1: not created yet
   unsigned int* h_over = nullptr;  // page-locked copy of over_ctr
   // dummy_correction_kernel: distance matrices of the strings drawn for chosen ProposalDummyValues
