@@ -410,6 +410,22 @@ def main():
     eng.hip.set_profiling(False)
     acc = f1_now(tr)
 
+    # ---- full iterations in the steady state (after everything the line reports): the first one after the initialisation
+    # (full_iteration_ms) also pays the first build of every latent class's compact tables, caches and scratch buffers ---
+    full_steady_ms = None
+    if not args.no_full_iteration:
+        comm.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_full = 2
+        for i in range(n_full):
+            run_inference(eng, tr, cfg1, args.seed + 100 + i, comm=comm)
+        torch.cuda.synchronize()
+        comm.barrier()
+        full_steady_ms = 1e3 * comm.max_float(time.perf_counter() - t0) / n_full
+        log(f"[bench] full run_inference iteration, steady state (mean of {n_full}): {full_steady_ms:.0f} ms; F1 after them "
+            f"{f1_now(tr)['f1']:.4f}")
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = args.rows * args.steps / elapsed
@@ -456,6 +472,7 @@ def main():
                        "init": f"the build's own initialize_trace from an empty trace (batches <= {args.init_batch})"
                                + ("" if args.no_full_iteration else " + 1 full run_inference iteration"),
                        "init_s": init_s, "f1_after_init": acc_init["f1"], "full_iteration_ms": full_ms,
+                       "full_iteration_steady_ms": full_steady_ms,
                        "device_ms_per_step": dev_ms / args.steps,
                        "commit": ("device-resident (pclean_commit_device): tables, counts, free lists and referents stay in HBM, one "
                                   "synchronisation per step" if dc_on else "host (parallel.exchange_and_commit)"),

@@ -3011,7 +3011,9 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
       for (size_t oi = 0; oi < leaf_roots.size(); ++oi) {
         const int r = leaf_roots[oi];
         const int root = roots[r];
-        const int rcs = sf.use(n_side_used++);
+        // (the reference slots keep their streams to themselves: theirs are the longest chains of a sub-batch)
+        const int K = side_streams(ctx), n_fk_side = fk_first ? std::min((int)fk_roots.size(), std::max(K - 1, 0)) : 0;
+        const int rcs = sf.use(K > n_fk_side ? n_fk_side + (int)oi % (K - n_fk_side) : (int)oi);
         if (rcs) return rcs;
         int32_t* draws = scratch<int32_t>(ctx, cnt);
         if (!draws) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
