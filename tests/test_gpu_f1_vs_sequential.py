@@ -42,7 +42,9 @@ def _gpu_f1(name, seed, iters, mh, particles, n_rows):
 
 # the experiment scripts' MH configurations, BASELINE.json configs[1] / [2] (particle Gibbs, 20 particles) and the headline
 # workload's shape at a size the sequential schedule can finish (30 000 synthetic rows, 300 true hospitals)
-@pytest.mark.parametrize("name", ["hospital", "flights", "rents", "hospital_pg20", "rents_pg20", "synth_pg20"])
+# ... and with 3 000 true hospitals of ~10 rows each (a batched sweep freezes a table as large as its batch)
+@pytest.mark.parametrize("name", ["hospital", "flights", "rents", "hospital_pg20", "rents_pg20", "synth_pg20",
+                                  "synth_k3000_pg20"])
 def test_batched_gpu_f1_matches_the_sequential_reference(name, capsys):
     ref = json.load(open(os.path.join(ROOT, "tests", "golden", "sequential_f1.json")))[name]
     c = ref["config"]
