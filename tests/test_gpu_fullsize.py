@@ -164,9 +164,20 @@ def test_million_row_own_init_state_parity(oracle, capsys):
         assert len(starts) >= 8
         c = InferConfig(1, P, 1, 1, 0, 50, 100)
         kinds = np.zeros(4, dtype=np.int64)
+        n_pairs_checked = 0
         for start in starts:
             rows = np.arange(start, start + W)
             w, _ = bench.oracle_world_for_rows(oracle, lw, obs, tr, eng, rows)
+            if start == starts[1]:  # (one window: ~10^8 pairs, half a minute of the oracle's DP)
+                # the rows of the FULL-SIZE pair tables this window is scored with (read back from the device for the
+                # oracle's world) == the oracle's own distance computation on the same strings
+                sym, off, _, _ = lw.pool.arrays()
+                for key, (pid, odom, ldom) in lw.pair_id.items():
+                    u = np.unique(obs[lw.obs_index[key[0]], rows])
+                    got = eng.hip.get_pair_rows(pid, u, len(ldom))
+                    want = oracle.pair_table(sym, off, odom.id_array()[u], ldom.id_array(), eng.dist_mode)
+                    assert np.array_equal(np.asarray(got, dtype=np.uint16), want), (start, key)
+                    n_pairs_checked += got.size
             cur = np.ascontiguousarray(tr.cur[:, rows])
             och = np.empty((2, W), dtype=np.int32)
             ocp = np.empty(W, dtype=np.int32)
@@ -192,7 +203,8 @@ def test_million_row_own_init_state_parity(oracle, capsys):
                       int((choice[:, rows] != tr.cur[:, rows]).any(axis=0).sum()), int((choice[:, rows] < 0).any(axis=0).sum())]
         with capsys.disabled():
             print(f"[own-init 1M] {len(starts)} oracle windows of {W} rows: {kinds[0]} overflowed, {kinds[1]} guess-and-refine, "
-                  f"{kinds[2]} moved, {kinds[3]} new-referent rows — all bit-identical")
+                  f"{kinds[2]} moved, {kinds[3]} new-referent rows — all bit-identical; {n_pairs_checked} pairs of the full-size "
+                  f"tables recomputed by the oracle")
         assert kinds[1] > 0 and kinds[2] > 0 and kinds[3] > 0 and (kinds[0] > 0 or len(over) == 0)
         # (b) wave kernels == generic kernels on this state, every row
         eng.hip.force_generic(True)
