@@ -96,7 +96,7 @@ def oracle_world_for_rows(orc, lw, obs_local, tr, eng, rows):
 
 
 def hbm_traffic(args, world):
-    """HBM bytes per launch of the dominant kernel GROUP (group_desc_kernel + fk_root_wave_kernel<12> + group_lse_kernel of
+    """HBM bytes per launch of the dominant kernel GROUP (group_desc_kernel + group_settle_kernel + fk_root_wave_kernel<12> + group_lse_kernel of
     block 0's root: the launches `alg_bytes_per_launch` models) from this round's committed PMC passes (profiles/collect_r04.sh
     -> profiles/hbm_traffic.json: rocprofv3 FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc runs of this same
     command); only valid for the configuration it was measured on, otherwise null.  Counters cannot be read from inside
@@ -131,8 +131,8 @@ LINE = 128  # bytes the memory system moves for one random gather: the L2 line. 
 
 
 def roofline_model(rs, obs_local, particles):
-    """Algorithmic bytes of ONE launch of the dominant kernel group — group_desc_kernel + fk_root_wave_kernel<12> +
-    group_lse_kernel of block 0's root (root_wave.hip) — as implemented, each byte counted once, every random gather at
+    """Algorithmic bytes of ONE launch of the dominant kernel group — group_desc_kernel + group_settle_kernel +
+    fk_root_wave_kernel<12> + group_lse_kernel of block 0's root (root_wave.hip) — as implemented, each byte counted once, every random gather at
     the 128-byte line the memory system moves for it (LINE):
       * coarse level of the scan: one block-minimum row (cstride bytes, one byte per 64 candidates) per DISTINCT
         observed value of the pre-filter columns among the swept rows;
@@ -153,7 +153,9 @@ def roofline_model(rs, obs_local, particles):
         col = rs.pre_obs_col[p]
         if col >= 0:
             distinct += int(np.unique(obs_local[col]).size)
-    per_group = 2 * 128 + 4 * rs.n_terms + 4 + LINE * rs.n_terms
+    # (descriptor: written by group_desc_kernel, read by the scan kernel and — when it ran: rs.resolved_groups — by
+    # group_settle_kernel, whose fine blocks are in rs.fine_blocks and whose draws are the rows' draws below)
+    per_group = (3 if rs.resolved_groups > 0 else 2) * 128 + 4 * rs.n_terms + 4 + LINE * rs.n_terms
     per_item = 4 + 4 + 4 * rs.n_draws + 8 + 4
     common = rs.n_groups * per_group + rs.n_items * per_item
     two_level = distinct * rs.cstride + rs.fine_blocks * (3 * LINE + 8) + rs.scored_terms * LINE
@@ -495,11 +497,12 @@ def main():
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_components": traffic_parts,
                          "traffic_over_alg": (traffic / alg_bytes) if (traffic and alg_bytes) else None,
-                         "kernel": "group_desc_kernel + fk_root_wave_kernel<12> + group_lse_kernel (block 0 root: rows x candidate "
-                                   "hospitals); alg bytes, launch time and counter traffic all cover these three launches",
+                         "kernel": "group_desc_kernel + group_settle_kernel + fk_root_wave_kernel<12> + group_lse_kernel (block 0 root: "
+                                   "rows x candidate hospitals); alg bytes, launch time and counter traffic all cover these launches",
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": 1e3 * per_launch_s,
                          "groups": rs.n_groups, "items": rs.n_items, "kpad": rs.kpad, "overflow_items": rs.overflow_items,
                          "full_scans": rs.full_scans, "fine_blocks": rs.fine_blocks, "scored_terms": rs.scored_terms,
+                         "settled_groups": rs.resolved_groups,
                          "rows_streamed_once_model": {"bytes_per_launch": alg_bytes_rows_once,
                                                       "GBps": (alg_bytes_rows_once / per_launch_s / 1e9) if (alg_bytes_rows_once and per_launch_s > 0) else None,
                                                       "note": "round 2's byte model (every distinct pre-filter byte row "

@@ -418,6 +418,146 @@ struct WaveItems {
   int32_t draw_is, draw_ds;
 };
 
+// ---- SETTLED groups, a few lanes each ---------------------------------------------------------------------------------
+// Nine groups in ten of a steady-state sweep end the same way: the rows' current referent is the only live candidate
+// within the descriptor's cut-off and it (or the new row) outweighs the other by more than 28.5 nats — the fixed-point
+// total is exactly one unit and every draw returns the same entry.  The scan kernel spends a wavefront's serial phases
+// (~20 us per group per wave) on each of them; one THREAD per group (group_desc_kernel with g_res,
+// PCLEAN_RESOLVE_GROUPS) reads its block minima uncoalesced and was measured slower than what it saves.  Here
+// SETTLE_L lanes share a group: lane l reads 16 consecutive block minima of each pre-filter term (one coalesced 16-byte
+// load per term: a 10^4-candidate table is covered by 11 lanes), walks the fine blocks that pass, and the lanes agree by
+// ballot; a settled group is flagged in its descriptor (the scan kernel skips it), gets its maximum / total for
+// group_lse_kernel and its members' draws written right here.  Same arithmetic as the scan kernel's filter (integer
+// sums against the same cut-off), so the set of settled groups is exactly the set it would have found with one survivor.
+#define SETTLE_L 16
+#define SETTLE_MAX_BLOCKS 4  // a group with more fine blocks to look at is left to the scan kernel
+struct SettleArgs {          // the pre-filter terms' tables resolved on the host: no indexing of FastRootDev::terms[] in the kernel
+  const uint8_t* comp[3];
+  const uint8_t* cmin[3];
+  int32_t pre[3];            // descriptor word of the term's observed value: 10 + term index (-1: no such term)
+  int32_t kpad, cstride;
+  const uint16_t* alive;
+  const uint8_t* zero_row;
+};
+__global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, const WaveItems wi, int n_groups, int n_draws,
+                                                           int32_t* __restrict__ gd, double* __restrict__ g_m,
+                                                           uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out,
+                                                           unsigned int* __restrict__ scan_stats) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = tid / SETTLE_L, l = tid % SETTLE_L;
+  const int lane = threadIdx.x & 63, base = lane & ~(SETTLE_L - 1);
+  const unsigned long long gmask = ((1ull << SETTLE_L) - 1ull) << base;
+  // the group's 128-byte descriptor: lane l holds words l and 16 + l (two coalesced loads), fields by shuffle
+  int32_t* d = gd + (size_t)(g < n_groups ? g : 0) * GD_STRIDE;
+  const int w0 = g < n_groups ? d[l] : 0, w1 = g < n_groups ? d[16 + l] : 0;
+  auto word = [&](int w) { return __shfl(w < 16 ? w0 : w1, base + (w & 15), 64); };
+  const int flags = word(7), excl = word(4);
+  const double sn = __hiloint2double(word(27), word(26)), score_cur = __hiloint2double(word(31), word(30));
+  const double hi = fmax(score_cur, sn), lo = fmin(score_cur, sn);
+  const uint32_t cut = (uint32_t)word(28);
+  int op[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) op[p] = sa.pre[p] >= 0 ? word(sa.pre[p] >= 0 ? sa.pre[p] : 0) : -1;
+  // (have_cur, no guess-and-refine, and the lighter of the two explicit candidates weighs exactly 0: pclean_fixw)
+  const bool eligible = g < n_groups && (flags & 4) && !(flags & 2) && !(flags & 8) && hi > -__builtin_inf() &&
+                        score_cur != sn && !(lo - hi >= -28.5);
+  const uint8_t *r[3], *mn[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    r[p] = op[p] >= 0 ? sa.comp[p] + (size_t)op[p] * sa.kpad : sa.zero_row;
+    mn[p] = op[p] >= 0 ? sa.cmin[p] + (size_t)op[p] * sa.cstride : sa.zero_row;
+  }
+  const int kblk = (sa.kpad + 63) >> 6;
+  unsigned int st_blocks = 0;
+  bool has_excl = false, other = false;
+  // ---- level 1: block minima, 16 per lane and round; passing blocks of this lane as a bit mask per round
+  uint32_t pass = 0;   // passing blocks of the CURRENT round (bit e: block kb0 + e)
+  int kb_base = 0;
+  int n_seen = 0;      // fine blocks this group has looked at
+  for (int kb_round = 0; kb_round < kblk; kb_round += 16 * SETTLE_L) {  // (wave-uniform: kblk is a launch constant)
+    const int kb0 = kb_round + 16 * l;
+    pass = 0;
+    kb_base = kb0;
+    if (eligible && kb0 < kblk) {
+      const uint4 a = *reinterpret_cast<const uint4*>(mn[0] + kb0), b = *reinterpret_cast<const uint4*>(mn[1] + kb0),
+                  c = *reinterpret_cast<const uint4*>(mn[2] + kb0);
+      const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w}, cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const uint32_t sh = 8u * (e & 3);
+        const uint32_t dsum = ((aw[e >> 2] >> sh) & 0xffu) + ((bw[e >> 2] >> sh) & 0xffu) + ((cw[e >> 2] >> sh) & 0xffu);
+        if (kb0 + e < kblk && dsum <= cut) pass |= 1u << e;
+      }
+    }
+    // ---- level 2: the group's lanes walk its passing blocks together, 4 candidates per lane
+    for (int step = 0; step <= SETTLE_MAX_BLOCKS; ++step) {
+      const unsigned long long have = __ballot(pass != 0u), oth = __ballot(other);
+      if (have == 0ull) break;                      // (no group of this wavefront has a block left in this round)
+      const uint32_t mine = (uint32_t)((have & gmask) >> base);
+      if (mine == 0u) continue;                      // this group is done with the round
+      if (n_seen >= SETTLE_MAX_BLOCKS || (oth & gmask) != 0ull) {  // (group-uniform) too many blocks / already decided: the
+                                                                   // group is left to the scan kernel
+        other = true;
+        pass = 0;
+        continue;
+      }
+      const int src = __builtin_ctz(mine);
+      const int kb = __shfl(kb_base + (pass ? __builtin_ctz(pass) : 0), base + src, 64);
+      if (l == src) pass &= pass - 1u;
+      ++n_seen;
+      if (l == 0) ++st_blocks;
+      const int k = kb * 64 + 4 * l;
+      if (k < sa.kpad) {
+        const uint32_t xa = *reinterpret_cast<const uint32_t*>(r[0] + k), xb = *reinterpret_cast<const uint32_t*>(r[1] + k),
+                       xc = *reinterpret_cast<const uint32_t*>(r[2] + k);
+        const uint32_t al = (uint32_t)sa.alive[k >> 4] >> (k & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t dsum = ((xa >> (8 * i)) & 0xffu) + ((xb >> (8 * i)) & 0xffu) + ((xc >> (8 * i)) & 0xffu);
+          if (dsum <= cut && ((al >> i) & 1u)) {
+            if (k + i == excl)
+              has_excl = true;
+            else
+              other = true;
+          }
+        }
+      }
+    }
+    if (pass != 0u) other = true;  // (blocks left over after the walk)
+  }
+  // the group's lanes agree (every lane of the wavefront takes part in the ballots)
+  const unsigned long long b_other = __ballot(other), b_excl = __ballot(has_excl);
+  const bool settled = eligible && (b_excl & gmask) != 0ull && (b_other & gmask) == 0ull;
+  if (settled) {
+    const int res_val = sn > score_cur ? PCLEAN_CHOICE_NEW : excl;
+    if (l == 0) {
+      d[7] = flags | 8;
+      g_m[g] = hi;
+      g_U[g] = PCLEAN_FIX_ONE;
+    }
+    const int m_lo = word(0), m_hi = word(1), t0 = word(2);
+    const int n_out = (m_hi - m_lo) * n_draws;
+    for (int q = l; q < n_out; q += SETTLE_L) {
+      const int mi = m_lo + q / n_draws, j = q % n_draws;
+      const int tm = wi.members ? wi.members[mi] : t0;
+      const size_t to = (size_t)(wi.out_pos ? wi.out_pos[tm] : tm);
+      draws_out[to * wi.draw_is + (size_t)j * wi.draw_ds] = res_val;
+    }
+  }
+  if (scan_stats) {
+    unsigned int st_settled = (settled && l == 0) ? 1u : 0u;
+    for (int o = 32; o > 0; o >>= 1) {
+      st_blocks += __shfl_xor(st_blocks, o, 64);
+      st_settled += __shfl_xor(st_settled, o, 64);
+    }
+    if (lane == 0 && (st_blocks | st_settled)) {
+      unsigned int* sl = scan_stats + (size_t)((tid >> 6) & 63) * 32;
+      atomicAdd(&sl[1], st_blocks);
+      atomicAdd(&sl[3], st_settled);
+    }
+  }
+}
+
 // The per-term pointers of FastRootDev (16 terms x 9 fields) must not live in SGPRs: the compiler hoists them out of
 // the group loop and spills them to VGPR lanes (a third of the first version's vector instructions were that spill
 // traffic).  FastRootDev is the kernel's FIRST parameter; its terms[] are only read through the kernarg segment
@@ -1308,6 +1448,10 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   const bool resolve = n_draws > 0 && want_resolve && (!it.grp_off || n_items > 0);
   hipLaunchKernelGGL(group_desc_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, it, ch, it.n,
                      desc_scratch, chunk_ctr, g_m, g_U, resolve ? g_res : nullptr, scan_stats);
+  // the easy groups settled by a few lanes each (group_settle_kernel): launches that draw, large enough to matter
+  static const bool no_settle = getenv("PCLEAN_NO_SETTLE") != nullptr;
+  const bool settle = !no_settle && !resolve && n_draws > 0 && !fr.is_leaf && fr.n_pre >= 1 && fr.n_pre <= 3 && fr.cstride > 0 &&
+                      it.excl != nullptr && it.n >= 4096;
   // persistent grid = what is resident at once (a workgroup that starts late would find the counters drained anyway)
   const int wpg = 4;
   wave_kernel_t kern = pick_kernel(fr.n_terms);
@@ -1328,6 +1472,25 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   wgs = (wgs + 7) & ~7;  // a multiple of the 8 XCDs
   WaveItems wi{it.grp_off ? it.members : nullptr, it.row, it.rng_row, it.particle, it.out_pos, it.row_offset, it.draw_is,
                it.draw_ds};
+  if (settle) {
+    WaveItems ws = wi;
+    ws.draw_is = it.draw_is ? it.draw_is : n_draws;
+    ws.draw_ds = it.draw_ds ? it.draw_ds : 1;
+    SettleArgs sa{};
+    for (int p = 0; p < 3; ++p) {
+      const bool on = p < fr.n_pre && fr.terms[fr.pre[p]].comp && fr.terms[fr.pre[p]].cmin;
+      sa.comp[p] = on ? fr.terms[fr.pre[p]].comp : fr.zero_row;
+      sa.cmin[p] = on ? fr.terms[fr.pre[p]].cmin : fr.zero_row;
+      sa.pre[p] = on ? 10 + fr.pre[p] : -1;
+    }
+    sa.kpad = fr.kpad;
+    sa.cstride = fr.cstride;
+    sa.alive = fr.alive;
+    sa.zero_row = fr.zero_row;
+    const size_t n_thr = (size_t)it.n * SETTLE_L;
+    hipLaunchKernelGGL(group_settle_kernel, dim3((unsigned int)((n_thr + 255) / 256)), dim3(256), 0, ctx->stream, sa, ws, it.n,
+                       n_draws, desc_scratch, g_m, g_U, draws_out, scan_stats);
+  }
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * wpg), 0, ctx->stream, fr, wi, seed, sweep, site, n_draws, it.n, desc_scratch,
                      chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count, overflow_list, scan_stats);
 #ifdef WAVE_PHASE_CLOCK

@@ -13,7 +13,7 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 3 --warmup 2 --no-cpu-baseline --no-dl-sample"
-KRE="fk_root_wave_kernel|group_desc_kernel|group_lse_kernel"
+KRE="fk_root_wave_kernel|group_desc_kernel|group_settle_kernel|group_lse_kernel"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python "$ROOT/bench.py" $ARGS \
   > "$OUT/bench_trace.json" 2> "$OUT/bench_trace.log"
 echo "trace rc=$?"

@@ -49,7 +49,7 @@ def main():
             k = short(name)
             # the sweep kernels run on lists of every size (initialisation batches, nested slots, ...): the launches
             # within a factor 2 of the kernel's longest launch are its full-size launches, the rest is "[small]"
-            if any(t in k for t in ("fk_root_wave_kernel", "enum_node", "ev_leaf_wave", "group_desc", "group_lse", "gate_new", "particle_update")):
+            if any(t in k for t in ("fk_root_wave_kernel", "enum_node", "ev_leaf_wave", "group_desc", "group_settle", "group_lse", "gate_new", "particle_update")):
                 k += " [full-size]" if dur * 2 >= longest[k] else " [small]"
             m = merged.setdefault(k, dict(n=0, dur=0.0, counters={}))
             m["n"] += 1
@@ -87,7 +87,9 @@ def main():
             return (2 * c["FETCH_SIZE"][1] / c["FETCH_SIZE"][0] + c["WRITE_SIZE"][1] / c["WRITE_SIZE"][0]) * 1024
 
         keys = [next((k for k in merged if pat in k and "full-size" in k), None)
-                for pat in ("group_desc_kernel", "fk_root_wave_kernel<12", "group_lse_kernel")]
+                for pat in ("group_desc_kernel", "fk_root_wave_kernel<12", "group_lse_kernel", "group_settle_kernel")]
+        if keys[3] is None:  # (builds before the settle kernel / PCLEAN_NO_SETTLE)
+            keys = keys[:3]
         if all(keys) and all(hbm(k) is not None for k in keys):
             parts = {k: hbm(k) for k in keys}
             c = merged[keys[1]]["counters"]
@@ -95,12 +97,13 @@ def main():
                 data = json.load(open(out_json))
             except Exception:
                 data = {}
-            data.update(kernel="group_desc_kernel + fk_root_wave_kernel<12> + group_lse_kernel", pair_bytes_per_launch=sum(parts.values()),
+            data.update(kernel="group_desc_kernel + group_settle_kernel + fk_root_wave_kernel<12> + group_lse_kernel" if len(keys) == 4
+                        else "group_desc_kernel + fk_root_wave_kernel<12> + group_lse_kernel", pair_bytes_per_launch=sum(parts.values()),
                         pair_components=parts, bytes_per_launch=parts[keys[1]], rows=1000000, hospitals=10000, particles=20,
                         fetch_kib=c["FETCH_SIZE"][1] / c["FETCH_SIZE"][0], write_kib=c["WRITE_SIZE"][1] / c["WRITE_SIZE"][0],
                         avg_ms={k: merged[k]["dur"] / merged[k]["n"] for k in keys},
                         source=source + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, "
-                               "2 x FETCH_SIZE + WRITE_SIZE, KiB; full-size launches of the three kernels of block 0's root)")
+                               "2 x FETCH_SIZE + WRITE_SIZE, KiB; full-size launches of the kernels of block 0's root)")
             json.dump(data, open(out_json, "w"), indent=1)
 
 
