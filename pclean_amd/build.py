@@ -10,7 +10,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpclean_hip.so")
-SOURCES = ["api.hip", "comm.hip", "commit.hip", "dist_kernels.hip", "enum_kernels.hip", "root_wave.hip", "random_kernels.hip", "sweep.hip"]
+SOURCES = ["api.hip", "comm.hip", "commit.hip", "dist_kernels.hip", "enum_kernels.hip", "root_wave.hip", "random_kernels.hip", "sweep.hip", "eval.hip", "latent.hip"]
 HEADERS = ["ctx.h", "../../include/pclean_hip.h", "../../include/pclean_detmath.h", "../../include/pclean_philox.h"]
 # -ffp-contract=off: the parity contract (include/pclean_detmath.h) needs plain
 # IEEE mul/add on device, identical to the gcc-built oracle.
