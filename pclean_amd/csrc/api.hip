@@ -1,6 +1,6 @@
 // C ABI entry points: lifecycle, string pool, observed columns, pair tables,
 // density tables, StringPrior scores, candidate tables, plan upload.
-// The enumeration / sweep entry points live in sweep.hip.
+// The enumeration / sweep entry points live in sweep.hip (observed class), latent.hip (latent classes) and eval.hip (plan nodes).
 #include <chrono>
 #include <cmath>
 #include <limits>

@@ -112,7 +112,7 @@ struct CandTable {
   int32_t cols_delta_n = -1;
   const int32_t* cols_delta_rows = nullptr;
   bool h_mirror_stale = false;  // the device arrays moved on without the host mirrors (pclean_commit_device)
-  double h_lse = 0.0;         // options: log-sum of logp (+1e-9), valid for version h_lse_ver (sweep.hip: subtree_ub)
+  double h_lse = 0.0;         // options: log-sum of logp (+1e-9), valid for version h_lse_ver (eval.hip: subtree_ub)
   uint64_t h_lse_ver = 0;
 };
 
@@ -176,7 +176,7 @@ struct pclean_ctx {
   // observed columns
   int32_t n_rows = 0, n_cols = 0;
   DevBuf<int32_t> obs;  // [n_cols][n_rows]
-  uint64_t obs_version = 0;  // bumped by every pclean_load_columns (keys the static per-row tuple ids, sweep.hip)
+  uint64_t obs_version = 0;  // bumped by every pclean_load_columns (keys the static per-row tuple ids, eval.hip)
   std::vector<char> col_has_missing;  // per observed column: some row holds an explicitly missing value (-1)
   DevBuf<int32_t> iota; // identity column for per-unique-value leaf caches
   int32_t n_xcols = 0;
@@ -211,9 +211,9 @@ struct pclean_ctx {
   bool defer_outputs = false;   // pclean_set_sweep_mode bit 0
   void* commit_state = nullptr;  // owned by commit.hip
   HostStage stage;               // page-locked staging of caller arrays (table uploads, latent-sweep inputs / outputs)
-  const int32_t* obs_override = nullptr;  // sweep.hip: ensure_leaf_cache scores "item t observes value t"
+  const int32_t* obs_override = nullptr;  // eval.hip: ensure_leaf_cache scores "item t observes value t"
   int32_t active_begin = 0, active_count = -1;  // pclean_set_active_rows window (-1 = all rows)
-  bool prior_mode = false;     // sweep.hip: the running sweep proposes from the priors (use_dd_proposals = false)
+  bool prior_mode = false;     // sweep.hip / latent.hip: the running sweep proposes from the priors (use_dd_proposals = false)
   bool force_generic = false;  // debug: never take the compact-table root kernel
   bool no_item_agg = false;    // debug: aggregate evidence with the global sort + run-length encoding only
   void* sweep_state = nullptr;  // owned by sweep.hip

@@ -52,7 +52,7 @@ struct DensDev {
   const double* logn;       // log(n)
 };
 
-// Aggregated evidence of one term of a latent-class node (sweep.hip: ensure_agg): for original latent item i the
+// Aggregated evidence of one term of a latent-class node (latent.hip: ensure_agg): for original latent item i the
 // distinct (ctx value, observed value) pairs among its evidence rows, ascending, with multiplicities:
 // entries [off[i], off[i+1]) of key / cnt; key = item << 40 | ctx << 24 | (observed value index + 1) (0 = missing).
 struct AggDev {

@@ -856,7 +856,7 @@ int pclean_launch_prior_terms(pclean_ctx* ctx, size_t n_slots, int N, int n_node
 // ---- prior proposals for the rows of a LATENT class: likelihood of the referring rows given particle p's values ---
 // slot = item * P + particle; vals[slot][node] = the particle's choices (option / referent / NEW / -2 unused).
 // roots in order; each root's sub-tree as in prior_terms_kernel, every term summed over the item's evidence set
-// (candidate_score_ev onto 0.0).  aggs[node] = aggregated evidence of the node's terms (sweep.hip: ensure_agg).
+// (candidate_score_ev onto 0.0).  aggs[node] = aggregated evidence of the node's terms (latent.hip: ensure_agg).
 __global__ void prior_terms_ev_kernel(int n_items, int P, int n_nodes, const NodeDev* __restrict__ nds,
                                       const AggDev* const* __restrict__ aggs, const int32_t* __restrict__ n_children,
                                       const int32_t* __restrict__ child_begin, const int32_t* __restrict__ children,

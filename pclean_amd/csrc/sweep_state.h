@@ -1,4 +1,4 @@
-// Per-context state of the sweep entry points (sweep.hip) that other translation units of the library read
+// Per-context state of the sweep entry points (sweep.hip, eval.hip, latent.hip) that other translation units of the library read
 // (commit.hip: the device-resident commit consumes a sweep's device-side outputs).  Not part of the ABI.
 #pragma once
 #include <map>
