@@ -237,6 +237,8 @@ def main():
     ap.add_argument("--cpu-rows", type=int, default=10_000, help="minimum rows of the CPU baseline sample (SURVEY §8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-full-iteration", action="store_true")
+    ap.add_argument("--no-steady-iterations", action="store_true",
+                    help="skip the two steady-state full iterations after the timed steps (profiling runs: the tools read the last sweeps)")
     ap.add_argument("--distance", choices=("osa", "dl"), default="osa",
                     help="flavour of the AddTypos pair tables the workload runs on: restricted (OSA, bit-parallel; the default "
                          "of the headline since round 1) or unrestricted Damerau-Levenshtein (what the three real programs use)")
@@ -415,7 +417,7 @@ def main():
     # ---- full iterations in the steady state (after everything the line reports): the first one after the initialisation
     # (full_iteration_ms) also pays the first build of every latent class's compact tables, caches and scratch buffers ---
     full_steady_ms = None
-    if not args.no_full_iteration:
+    if not args.no_full_iteration and not args.no_steady_iterations:
         comm.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()

@@ -12,7 +12,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 2 --no-cpu-baseline --no-dl-sample"
+ARGS="--steps 3 --warmup 2 --no-cpu-baseline --no-dl-sample --no-steady-iterations"
 KRE="fk_root_wave_kernel|group_desc_kernel|group_settle_kernel|group_lse_kernel"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python "$ROOT/bench.py" $ARGS \
   > "$OUT/bench_trace.json" 2> "$OUT/bench_trace.log"
@@ -31,7 +31,7 @@ pass TCC TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum
 # whole-step traffic: the same two counters over EVERY kernel (no include filter), fewer sweeps
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_all_$C" -- python "$ROOT/bench.py" --steps 2 --warmup 1 --no-dl-sample \
-    --no-cpu-baseline > "$OUT/bench_all_$C.json" 2> "$OUT/bench_all_$C.log"
+    --no-steady-iterations --no-cpu-baseline > "$OUT/bench_all_$C.json" 2> "$OUT/bench_all_$C.log"
   echo "all $C rc=$?"
 done
 if [ -x "$ROOT/profiles/calib/fetch_calib" ]; then
