@@ -67,6 +67,34 @@ __global__ void calib_gather_row(const uint8_t* __restrict__ p, size_t n_rows, s
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+// ---- stores and the particle kernels' patterns (round 4): does a coalesced 4- / 8- / 16-byte-per-lane store of FRESH lines
+// make the L2 fetch them first?  Does a thread that walks its own 80 consecutive bytes (row-major draws, one row per
+// lane, 20 loop iterations) fetch each line once?
+template <typename T>
+__global__ void calib_store(T* __restrict__ p, size_t n, T v) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+// the shape of particle_update_kernel: thread i (one row) loops over P particles; reads a[i * P + p] (row-major), writes
+// b[p * N + i] (4 B) and c[p * N + i] (8 B) particle-major
+__global__ void calib_rowloop(const int32_t* __restrict__ a, int32_t* __restrict__ b, double* __restrict__ c, int N, int P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int p = 0; p < P; ++p) {
+    const int d = a[(size_t)i * P + p];
+    b[(size_t)p * N + i] = d;
+    c[(size_t)p * N + i] = 0.0 + (double)d;
+  }
+}
+__global__ void calib_rowloop_read(const int32_t* __restrict__ a, int32_t* __restrict__ out, int N, int P) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  int acc = 0;
+  for (int p = 0; p < P; ++p) acc += a[(size_t)i * P + p];
+  if (acc == 0x12345678) out[0] = acc;
+}
+
 int main() {
   const size_t bytes = (size_t)8 << 30;  // 8 GiB >> Infinity Cache
   uint8_t* buf;
@@ -84,6 +112,21 @@ int main() {
     hipLaunchKernelGGL(calib_gather_row, dim3(256 * 16), dim3(256), 0, 0, buf, bytes / 16384, n_wave_iters, out);
   }
   CHECK(hipDeviceSynchronize());
+  {  // round 4: stores of 1 GiB of fresh lines per flavour; the particle-update shape at N = 4 Mi rows, P = 20
+    const size_t nb = (size_t)1 << 30;
+    for (int rep = 0; rep < 2; ++rep) {
+      hipLaunchKernelGGL(calib_store<uint32_t>, dim3(256 * 32), dim3(256), 0, 0, (uint32_t*)buf, nb / 4, 7u);
+      hipLaunchKernelGGL(calib_store<uint64_t>, dim3(256 * 32), dim3(256), 0, 0, (uint64_t*)(buf + nb), nb / 8, (uint64_t)7);
+      hipLaunchKernelGGL(calib_store<uint4>, dim3(256 * 32), dim3(256), 0, 0, (uint4*)(buf + 2 * nb), nb / 16, make_uint4(1, 2, 3, 4));
+      const int N = 4 << 20, P = 20;
+      int32_t* a = (int32_t*)(buf + 3 * nb);                       // 320 MiB read
+      int32_t* b = (int32_t*)(buf + 4 * nb);                       // 320 MiB written
+      double* c = (double*)(buf + 5 * nb);                         // 640 MiB written
+      hipLaunchKernelGGL(calib_rowloop_read, dim3((N + 1023) / 1024), dim3(1024), 0, 0, a, (int32_t*)out, N, P);
+      hipLaunchKernelGGL(calib_rowloop, dim3((N + 1023) / 1024), dim3(1024), 0, 0, a, b, c, N, P);
+      CHECK(hipDeviceSynchronize());
+    }
+  }
   printf("calib: stream16 bytes %zu; gather_u8 gathers %zu (distinct 128-B lines ~ the same); gather_row gathers %zu\n",
          n16 * 16, n_gathers, n_wave_iters * 64);
   return 0;
