@@ -386,6 +386,7 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
     return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_set_table: cols == NULL needs a previous upload of the same shape");
   t.is_options = false;
   t.is_options_1col = false;
+  t.n_used = 0;  // (pclean_commit_set_table_state tells)
   t.n_rows = n_rows;
   t.n_cols = n_cols;
   const size_t n = (size_t)n_rows * n_cols;

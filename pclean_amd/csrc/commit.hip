@@ -285,6 +285,7 @@ extern "C" int pclean_commit_set_table_state(pclean_ctx* ctx, int32_t table_id, 
       s.origin.alloc(4 * st) || s.chg.alloc(st))
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   s.stride = t.n_rows;
+  t.n_used = n_hw;  // rows beyond the high-water mark are spare capacity (ctx.h)
   HIPCHK(ctx, hipMemsetAsync(s.gflag.p, 0, st * 4, ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(s.origin.p, 0, st * 16, ctx->stream));
   hipLaunchKernelGGL(pcc_live_kernel, dim3((unsigned)((st + 255) / 256)), dim3(256), 0, ctx->stream, t.n_rows, t.counts.p, s.live.p);
@@ -563,6 +564,7 @@ extern "C" int pclean_commit_device(pclean_ctx* ctx, int32_t n_blocks, uint32_t 
     pclean_commit_slot& o = out->slot[si];
     o.table_id = cs.table_id;
     o.n_hw = w[PCC_ST_NHW];
+    t.n_used = w[PCC_ST_NHW];
     o.n_free = w[PCC_ST_NFREE];
     o.cols_changed = w[PCC_ST_COLS_CHANGED];
     o.created = w[PCC_ST_CREATED];

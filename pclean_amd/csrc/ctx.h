@@ -94,6 +94,9 @@ struct CandTable {
   uint64_t cols_version = 0;  // re-upload of the value columns
   bool is_options = false;
   int32_t n_rows = 0, n_cols = 0;
+  // rows [n_used, n_rows) have never held a row (the spare capacity of the device-resident commit: count 0, weight
+  // exactly 0): a scan need not look at them.  0: unknown (every row may be in use)
+  int32_t n_used = 0;
   DevBuf<int32_t> cols;       // column-major [n_cols][n_rows]
   DevBuf<int64_t> counts;     // FK tables
   DevBuf<double> logc_full;   // FK: log(count-discount); options: logp

@@ -138,6 +138,8 @@ struct FastTermDev {
 };
 struct FastRootDev {
   int32_t n_cand, kpad, n_terms, lmax, dstride;
+  int32_t kscan;          // candidates [kscan, kpad) are spare capacity that never held a row (CandTable::n_used): the scans stop
+                          // there; a multiple of 64 (or kpad); kpad stays the stride of the byte rows
   int32_t is_leaf;        // 1: option list of a LEAF node (no exclusion, no "new row" candidate; prior_e / counts / logc_m1 null)
   const uint16_t* alive;  // [kpad / 16] bit e of word q: candidate 16 q + e is a live row / an option with a finite prior
   const double* prior_e;  // [kpad] log(count-discount) - logden_m1, -inf for free slots / padding

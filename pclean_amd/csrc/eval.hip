@@ -380,6 +380,11 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   }
   fr.n_cand = t.n_rows;
   fr.kpad = kpad;
+  {
+    static const bool no_kscan = getenv("PCLEAN_NO_KSCAN") != nullptr;
+    const int n_used = (t.n_used > 0 && t.n_used <= t.n_rows && !no_kscan) ? t.n_used : t.n_rows;
+    fr.kscan = std::min(kpad, (n_used + 63) & ~63);
+  }
   fr.n_terms = n.n_terms;
   fr.lmax = lmax;
   fr.dstride = dmax + 1;
@@ -635,8 +640,8 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
     rs.n_terms = n.n_terms;
     rs.n_draws = n_draws;
     if (fast) {
-      rs.kpad = fr.kpad;
-      rs.cstride = fr.cstride;
+      rs.kpad = fr.kscan;  // (what the scans walk: the candidates below the table's high-water mark, FastRootDev::kscan)
+      rs.cstride = std::min(fr.cstride, (((fr.kscan + 63) >> 6) + 15) & ~15);
       rs.n_pre = fr.n_pre;
       for (int p = 0; p < 3; ++p) rs.pre_obs_col[p] = p < fr.n_pre ? b.terms[n.term_begin + fr.pre[p]].obs_col : -1;
     }

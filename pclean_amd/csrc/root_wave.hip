@@ -306,7 +306,7 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
         r[p] = op >= 0 ? fr.terms[fr.pre[p]].comp + (size_t)op * fr.kpad : fr.zero_row;
         mn[p] = op >= 0 ? fr.terms[fr.pre[p]].cmin + (size_t)op * fr.cstride : fr.zero_row;
       }
-      const int nquads = fr.kpad >> 4, kblk = (fr.kpad + 63) >> 6;
+      const int nquads = fr.kscan >> 4, kblk = (fr.kscan + 63) >> 6;
       bool has_excl = false, other = false;
       for (int kb0 = 0; kb0 < kblk && !other; kb0 += 16) {
         const uint4 a = *reinterpret_cast<const uint4*>(mn[0] + kb0), b = *reinterpret_cast<const uint4*>(mn[1] + kb0),
@@ -435,7 +435,7 @@ struct SettleArgs {          // the pre-filter terms' tables resolved on the hos
   const uint8_t* comp[3];
   const uint8_t* cmin[3];
   int32_t pre[3];            // descriptor word of the term's observed value: 10 + term index (-1: no such term)
-  int32_t kpad, cstride;
+  int32_t kpad, kscan, cstride;
   const uint16_t* alive;
   const uint8_t* zero_row;
 };
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, 
     r[p] = op[p] >= 0 ? sa.comp[p] + (size_t)op[p] * sa.kpad : sa.zero_row;
     mn[p] = op[p] >= 0 ? sa.cmin[p] + (size_t)op[p] * sa.cstride : sa.zero_row;
   }
-  const int kblk = (sa.kpad + 63) >> 6;
+  const int kblk = (sa.kscan + 63) >> 6;
   unsigned int st_blocks = 0;
   bool has_excl = false, other = false;
   // ---- level 1: block minima, 16 per lane and round; passing blocks of this lane as a bit mask per round
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, 
       ++n_seen;
       if (l == 0) ++st_blocks;
       const int k = kb * 64 + 4 * l;
-      if (k < sa.kpad) {
+      if (k < sa.kscan) {
         const uint32_t xa = *reinterpret_cast<const uint32_t*>(r[0] + k), xb = *reinterpret_cast<const uint32_t*>(r[1] + k),
                        xc = *reinterpret_cast<const uint32_t*>(r[2] + k);
         const uint32_t al = (uint32_t)sa.alive[k >> 4] >> (k & 15);
@@ -624,7 +624,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
   double* scv = reinterpret_cast<double*>(s_pref[wave]);
   int32_t* ksv = s_k[wave];
   int32_t* blk = s_blk[wave];
-  const int kpad = fr.kpad, nquads = kpad >> 4, n_terms = fr.n_terms;
+  const int kpad = fr.kpad, nquads = fr.kscan >> 4, n_terms = fr.n_terms;
   const int nd_eff = n_draws > 0 ? n_draws : 1;
   const int draw_is = wi.draw_is ? wi.draw_is : n_draws, draw_ds = wi.draw_ds ? wi.draw_ds : 1;
   // lane -> (member slot, draw) of the draw phase, fixed for the launch
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
       const g_u8_t m0 = (g_u8_t)(po0 >= 0 ? (uint64_t)FK->terms[fr.pre[0]].cmin + (uint64_t)((uint32_t)po0 * cst) : zr);
       const g_u8_t m1 = (g_u8_t)(po1 >= 0 ? (uint64_t)FK->terms[fr.pre[1]].cmin + (uint64_t)((uint32_t)po1 * cst) : zr);
       const g_u8_t m2 = (g_u8_t)(po2 >= 0 ? (uint64_t)FK->terms[fr.pre[2]].cmin + (uint64_t)((uint32_t)po2 * cst) : zr);
-      const int kblk = (kpad + 63) >> 6;
+      const int kblk = (fr.kscan + 63) >> 6;
       for (;;) {
         // a byte of (c0 + c1 + c2 + addc) has bit 7 set iff its summed distance exceeds cs (sums <= 126: no carries)
         const uint32_t addc = 0x01010101u * (127u - cs);
@@ -1484,6 +1484,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
       sa.pre[p] = on ? 10 + fr.pre[p] : -1;
     }
     sa.kpad = fr.kpad;
+    sa.kscan = fr.kscan;
     sa.cstride = fr.cstride;
     sa.alive = fr.alive;
     sa.zero_row = fr.zero_row;
