@@ -219,13 +219,11 @@ class Engine:
         m = lw.model
         last = self._last_upload
         dc = getattr(self, "_dc", None)
-        dbg = os.environ.get("PCLEAN_DEBUG_UPLOAD")
+        dbg = os.environ.get("PCLEAN_DEBUG_UPLOAD")  # diagnostic: uploads of a table that take more than a millisecond
+        t_dbg = None
         for cname, t in trace.tables.items():
             if dbg:
-                import time
-                if "t_dbg" in locals() and time.perf_counter() - t_dbg[1] > 1e-3:
-                    print(f"[upload] {t_dbg[0]}: {1e3 * (time.perf_counter() - t_dbg[1]):.1f} ms", flush=True)
-                t_dbg = (cname, time.perf_counter())
+                t_dbg = self._debug_upload(t_dbg, cname)
             cols, counts = t.view()
             cap = t.n
             if dc is not None and cname in dc["tables"]:
@@ -258,12 +256,8 @@ class Engine:
             if dc is not None and cname in dc["tables"]:
                 hip.commit_set_table_state(lw.table_id[cname], t.n, t.free)
                 dc["alloc"][cname] = alloc
-        if dbg and "t_dbg" in locals():
-            import time
-            if time.perf_counter() - t_dbg[1] > 1e-3:
-                print(f"[upload] {t_dbg[0]}: {1e3 * (time.perf_counter() - t_dbg[1]):.1f} ms (dirty cols / shapes: "
-                      f"{ {c: (bool(tt.cols_dirty), self._uploaded_shape.get(c)) for c, tt in trace.tables.items()} })", flush=True)
-            t_opt = time.perf_counter()
+        if dbg:
+            self._debug_upload(t_dbg, None)
         for (cname, aname), dom in lw.latent_dom.items():
             d = m.classes[cname].attr(aname).dist
             if isinstance(d, ChooseProportionally):
@@ -288,6 +282,15 @@ class Engine:
             if self._gauss_pending:  # needs the mean table to exist
                 self._upload_gauss()
                 self._gauss_pending = False
+
+    @staticmethod
+    def _debug_upload(prev, cname):
+        """PCLEAN_DEBUG_UPLOAD: prints the table whose upload just ended when it took more than a millisecond"""
+        import time
+        now = time.perf_counter()
+        if prev is not None and now - prev[1] > 1e-3:
+            print(f"[upload] {prev[0]}: {1e3 * (now - prev[1]):.1f} ms", flush=True)
+        return (cname, now)
 
     def sweep(self, trace, config, seed, sweep_idx, lo=0, hi=None, reuse_buffers=False, light=False):
         """One batched sweep over the observed rows [lo, hi) of the trace (default: all of them).
