@@ -407,7 +407,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
 static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
                          uint64_t seed, uint32_t sweep, double* lse_out);
 static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
-                            ItemGroups& g, int split_m = 0);
+                            ItemGroups& g, int split_m = 0, bool want_members = true);
 
 // Upper bound of the log-marginal of plan sub-tree `node_id` (gate_new_kernel, enum_kernels.hip): every term
 // density of the sub-tree must be a probability mass (<= 1); +inf when it is not (Gaussian terms).
@@ -491,6 +491,14 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
       const char* gm = getenv("PCLEAN_GATE_MIN");
       const int gate_min = gm ? atoi(gm) : 2048;
       bool gate = excl && !scores_out && il.n >= gate_min && !getenv("PCLEAN_NO_GATE");
+      // (rejuvenation sweeps only: the initialisation's batches have no current referent to compare with)
+      SweepState::GateStat* gstat = (gate && node_id < 64 && sweep < 0x7ffffff0u && !il.ev_lo && !getenv("PCLEAN_GATE_ALWAYS"))
+                                        ? &s->gate_stat[block_id * 64 + node_id] : nullptr;
+      if (gstat && gstat->skip > 0) {
+        --gstat->skip;
+        gate = false;
+        gstat = nullptr;
+      }
       for (int c = 0; c < n.n_children; ++c) {
         const int cid = b.children[n.child_begin + c];
         const pclean_node& cn = b.nodes[cid];
@@ -526,6 +534,13 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
         hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, flag, 1,
                            s->counter.p + 2, list, nullptr);
         PCLEAN_READ_COUNT(ctx, s->counter.p + 2, &n_need);
+        if (gstat) {
+          gstat->all_need_run = n_need == (unsigned int)il.n ? gstat->all_need_run + 1 : 0;
+          if (gstat->all_need_run >= 3) {
+            gstat->skip = 16;
+            gstat->all_need_run = 2;  // one more useless evaluation after the pause starts the next one
+          }
+        }
       } else {
         gate = false;
       }
@@ -975,10 +990,194 @@ static int ensure_tuple_ids(pclean_ctx* ctx, int block_id, int node_id, const st
   return PCLEAN_OK;
 }
 
+// ---- grouping through a hash table ----------------------------------------------------------------------------------
+// The groups only have to be RIGHT (members of a group share the whole key: a group may be split, never merged), not sorted:
+// every result is a function of the item alone.  A radix sort of 10^6 (key, item) pairs is ~16 dispatches and ~0.2 ms, and
+// a sweep made three of them; here every item claims or joins a slot of an open-addressing table (the slot holds a
+// representative ITEM, the key comparison reads that item's attributes: no half-written keys) and one scan over the slots
+// numbers the groups.  Callers that only need "which group is item i in" (eval_node_lse_core) stop there; the root scans
+// also need the members of every group side by side: an item takes its position in the group from the slot's counter
+// (the lanes of a wavefront that landed in the same slot share ONE atomic) and the same scan turns (pieces, members) per
+// slot into offsets.  The slot order keeps what the scan kernels like about the sorted order where it is cheap to keep:
+// the table index is hash(referent, pre-filter values) * HG_BUCKET + (hash(tuple, ctx) mod HG_BUCKET), so groups that
+// share the referent and the pre-filter rows sit next to each other (root_wave.hip reuses the previous group's survivor
+// list).  PCLEAN_SORT_GROUPS=1: the radix-sort path below.
+#define HG_BUCKET 16
+struct HashGroupDev {
+  int32_t* rep;        // [cap] 0: empty, else representative item + 1
+  unsigned int* cnt;   // [cap] members so far (null: group ids only)
+  uint32_t mask;       // cap - 1
+  int32_t split_m;
+};
+__device__ __forceinline__ bool hg_same_key(const KeyColsDev& kc, const int32_t* row, const int32_t* ctxv, const int32_t* excl,
+                                            int a, int b) {
+  const int ra = row ? row[a] : a, rb = row ? row[b] : b;
+  bool same = true;
+  if (kc.tuple_id)
+    same = kc.tuple_id[ra] == kc.tuple_id[rb];
+  else
+    for (int c = 0; c < kc.n_cols && same; ++c) same = kc.col[c][ra] == kc.col[c][rb];
+  if (same && kc.use_ctx && ctxv)
+    for (int s = 0; s < PCLEAN_MAX_CTX && same; ++s)
+      same = ctxv[(size_t)a * PCLEAN_MAX_CTX + s] == ctxv[(size_t)b * PCLEAN_MAX_CTX + s];
+  if (same && excl) same = excl[a] == excl[b];
+  return same;
+}
+__global__ __launch_bounds__(256) void hg_insert_kernel(int n, KeyColsDev kc, const int32_t* __restrict__ row,
+                                                        const int32_t* __restrict__ ctxv, const int32_t* __restrict__ excl,
+                                                        HashGroupDev hg, int32_t* __restrict__ slot_of,
+                                                        int32_t* __restrict__ pos_of) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool on = i < n;
+  uint32_t slot = 0;
+  if (on) {
+    const int r = row ? row[i] : i;
+    uint64_t h = 0x2545f4914f6cdd1dull;
+    if (kc.tuple_id)
+      h = mix64(h, (uint32_t)kc.tuple_id[r]);
+    else
+      for (int c = 0; c < kc.n_cols; ++c) h = mix64(h, (uint32_t)kc.col[c][r]);
+    if (kc.use_ctx && ctxv)
+      for (int s = 0; s < PCLEAN_MAX_CTX; ++s) h = mix64(h, (uint32_t)ctxv[(size_t)i * PCLEAN_MAX_CTX + s]);
+    uint64_t hp = 0x9e3779b97f4a7c15ull;
+    if (kc.pre_hash)
+      hp = mix64(hp, kc.pre_hash[r]);
+    else
+      for (int c = 0; c < kc.n_pre; ++c) hp = mix64(hp, (uint32_t)kc.pre_col[c][r]);
+    if (excl) hp = mix64(hp, (uint32_t)excl[i]);
+    if (kc.n_pre == 0 && !excl) hp = h;  // nothing to keep adjacent: plain hashing
+    slot = (uint32_t)(((hp >> 24) * HG_BUCKET + ((h >> 40) & (HG_BUCKET - 1))) & hg.mask);
+    for (;;) {
+      int cur = hg.rep[slot];  // (a stale zero only costs the compare-and-swap below, which returns the truth)
+      if (cur == 0) {
+        cur = atomicCAS(&hg.rep[slot], 0, i + 1);
+        if (cur == 0) break;  // claimed: this item represents the group
+      }
+      if (cur - 1 == i || hg_same_key(kc, row, ctxv, excl, i, cur - 1)) break;
+      slot = (slot + 1) & hg.mask;
+    }
+    slot_of[i] = (int32_t)slot;
+  }
+  if (!hg.cnt) return;
+  // position within the group: the lanes of this wavefront that share a slot take consecutive positions from ONE atomic
+  // (a popular key — 10^5 rows observing the same clean string — would otherwise serialise 10^5 atomics on one address)
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(on);
+  int pos = 0;
+  while (todo) {
+    const int leader = __builtin_ctzll(todo);
+    const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slot, leader);
+    const unsigned long long same = __ballot(on && slot == sl) & todo;
+    unsigned int base = 0;
+    if (lane == leader) base = atomicAdd(&hg.cnt[sl], (unsigned int)__popcll(same));
+    base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+    if ((same >> lane) & 1ull) pos = (int)base + __popcll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  if (on) pos_of[i] = pos;
+}
+// per slot: groups only: 1 per claimed slot; with members: (groups the slot contributes) << 32 | members — a group of more
+// than 2 split_m - 1 members is cut into pieces of split_m (the last piece takes the remainder: split_m .. 2 split_m - 1
+// members), see item_head_kernel
+struct HgClaimed {
+  __host__ __device__ uint64_t operator()(const int32_t& rep) const { return rep != 0 ? 1ull : 0ull; }
+};
+struct HgPacked {
+  int32_t split_m;
+  __host__ __device__ uint64_t operator()(const unsigned int& c) const {
+    const unsigned int pieces = c == 0u ? 0u : (split_m > 0 ? (c / (unsigned int)split_m > 1u ? c / (unsigned int)split_m : 1u) : 1u);
+    return ((uint64_t)pieces << 32) | c;
+  }
+};
+__global__ void hg_fill_kernel(int n, uint32_t cap, const uint64_t* __restrict__ incl, const unsigned int* __restrict__ cnt,
+                               const int32_t* __restrict__ slot_of, const int32_t* __restrict__ pos_of, int split_m,
+                               int32_t* __restrict__ members, int32_t* __restrict__ head, int32_t* __restrict__ uid,
+                               int32_t* __restrict__ grp_off) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) grp_off[(uint32_t)(incl[cap - 1] >> 32)] = n;
+  if (i >= n) return;
+  const int sl = slot_of[i], pos = pos_of[i];
+  const uint64_t pk = HgPacked{split_m}(cnt[sl]), ex = incl[sl] - pk;
+  const int pieces = (int)(pk >> 32), g0 = (int)(ex >> 32), off0 = (int)(uint32_t)ex;
+  const int piece = split_m > 0 ? min(pos / split_m, pieces - 1) : 0;
+  const bool first = split_m > 0 ? pos == piece * split_m : pos == 0;
+  const int at = off0 + pos;
+  members[at] = i;
+  uid[at] = g0 + piece + 1;
+  head[at] = first ? 1 : 0;
+  if (first) grp_off[g0 + piece] = at;
+}
+// group ids only: uid_of_item[i], and the attributes of every group's representative
+__global__ void hg_unique_kernel(int n, const uint64_t* __restrict__ incl, const int32_t* __restrict__ rep,
+                                 const int32_t* __restrict__ slot_of, const int32_t* __restrict__ row,
+                                 const int32_t* __restrict__ ctxv, const int32_t* __restrict__ excl,
+                                 int32_t* __restrict__ uid_of_item, int32_t* __restrict__ row2, int32_t* __restrict__ ctx2,
+                                 int32_t* __restrict__ excl2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int sl = slot_of[i];
+  const int u = (int)incl[sl] - 1;
+  uid_of_item[i] = u;
+  if (rep[sl] - 1 == i) {
+    row2[u] = row ? row[i] : i;
+    if (ctxv)
+      for (int s = 0; s < PCLEAN_MAX_CTX; ++s) ctx2[(size_t)u * PCLEAN_MAX_CTX + s] = ctxv[(size_t)i * PCLEAN_MAX_CTX + s];
+    if (excl) excl2[u] = excl[i];
+  }
+}
+// members == false: g.n_groups and the state hg_unique_kernel needs (g.hg_incl, g.hg_rep, g.hg_slot_of) only
+static int make_item_groups_hash(pclean_ctx* ctx, const ItemList& il, const int32_t* excl, const KeyColsDev& kc, int split_m,
+                                 bool want_members, ItemGroups& g) {
+  const int n = il.n;
+  uint32_t cap = 1024;
+  while (cap < 2u * (uint32_t)n) cap <<= 1;
+  int32_t* rep = scratch<int32_t>(ctx, (size_t)cap * 2);  // rep[cap], then cnt[cap]: one memset
+  uint64_t* incl = scratch<uint64_t>(ctx, cap);
+  int32_t* slot_of = scratch<int32_t>(ctx, n);
+  int32_t* pos_of = want_members ? scratch<int32_t>(ctx, n) : nullptr;
+  size_t tmp_scan = 0, tmp_scan2 = 0;
+  hipcub::TransformInputIterator<uint64_t, HgClaimed, const int32_t*> in_claimed(rep, HgClaimed());
+  hipcub::TransformInputIterator<uint64_t, HgPacked, const unsigned int*> in_packed((const unsigned int*)(rep + cap), HgPacked{split_m});
+  HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan, in_claimed, incl, (int)cap, ctx->stream));
+  HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan2, in_packed, incl, (int)cap, ctx->stream));
+  unsigned char* tmp = scratch<unsigned char>(ctx, std::max<size_t>(std::max(tmp_scan, tmp_scan2), 16));
+  if (!rep || !incl || !slot_of || (want_members && !pos_of) || !tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  HashGroupDev hg{rep, want_members ? (unsigned int*)(rep + cap) : nullptr, cap - 1, split_m};
+  HIPCHK(ctx, hipMemsetAsync(rep, 0, (size_t)cap * (want_members ? 2 : 1) * sizeof(int32_t), ctx->stream));
+  hipLaunchKernelGGL(hg_insert_kernel, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, hg, slot_of, pos_of);
+  int32_t n_unique = 0;
+  if (want_members) {
+    HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(tmp, tmp_scan2, in_packed, incl, (int)cap, ctx->stream));
+    // (little-endian: the high word of the last inclusive sum = number of groups)
+    PCLEAN_READ_COUNT(ctx, reinterpret_cast<const uint32_t*>(incl + (cap - 1)) + 1, &n_unique);
+  } else {
+    HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(tmp, tmp_scan, in_claimed, incl, (int)cap, ctx->stream));
+    PCLEAN_READ_COUNT(ctx, reinterpret_cast<const uint32_t*>(incl + (cap - 1)), &n_unique);
+  }
+  if (n_unique <= 0 || (double)n_unique > 0.75 * n) return PCLEAN_OK;  // not worth the indirection
+  g.n_groups = n_unique;
+  g.hg_incl = incl;
+  g.hg_rep = rep;
+  g.hg_slot_of = slot_of;
+  if (!want_members) return PCLEAN_OK;
+  int32_t* members = scratch<int32_t>(ctx, n);
+  int32_t* head = scratch<int32_t>(ctx, n);
+  int32_t* uid = scratch<int32_t>(ctx, n);
+  int32_t* grp_off = scratch<int32_t>(ctx, (size_t)n_unique + 1);
+  if (!members || !head || !uid || !grp_off) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  hipLaunchKernelGGL(hg_fill_kernel, grid1(n), dim3(256), 0, ctx->stream, n, cap, incl, hg.cnt, slot_of, pos_of, split_m, members,
+                     head, uid, grp_off);
+  g.grp_off = grp_off;
+  g.members = members;
+  g.head = head;
+  g.uid = uid;
+  return PCLEAN_OK;
+}
+
 // Groups the items of `il` by (observed values of the sub-tree of node_id, ctx, excl).  g.n_groups == 0
 // when the sub-tree cannot be keyed, the list is small, or fewer than a quarter of the items are duplicates.
 static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
-                            ItemGroups& g, int split_m) {
+                            ItemGroups& g, int split_m, bool want_members) {
   Block& b = ctx->block[block_id];
   std::set<int> cols;
   bool use_ctx = false;
@@ -1017,6 +1216,8 @@ static int make_item_groups(pclean_ctx* ctx, int block_id, int node_id, const It
     if (rc) return rc;
     if (np2 == 0) kc.pre_hash = nullptr;
   }
+  static const bool sort_groups = getenv("PCLEAN_SORT_GROUPS") != nullptr;
+  if (!sort_groups) return make_item_groups_hash(ctx, il, excl, kc, split_m, want_members, g);
   uint64_t* key = scratch<uint64_t>(ctx, n);
   uint64_t* key_s = scratch<uint64_t>(ctx, n);
   int32_t* idx = scratch<int32_t>(ctx, n);
@@ -1233,15 +1434,12 @@ static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemL
 static int eval_node_lse_core(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
                               uint64_t seed, uint32_t sweep, double* lse_out) {
   ItemGroups g;
-  int rc0 = make_item_groups(ctx, block_id, node_id, il, excl, g);
+  int rc0 = make_item_groups(ctx, block_id, node_id, il, excl, g, 0, false);  // (which group is item i in: no member lists)
   if (rc0) return rc0;
   if (g.n_groups == 0)
     return eval_node(ctx, block_id, node_id, il, excl, seed, sweep, 0, lse_out, nullptr, nullptr, nullptr, false);
   const int n = il.n;
   const int32_t n_unique = g.n_groups;
-  const int32_t* idx_s = g.members;
-  const int32_t* head = g.head;
-  const int32_t* uid = g.uid;
   int32_t* uid_of_item = scratch<int32_t>(ctx, n);
   if (!uid_of_item) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   int32_t* row2 = scratch<int32_t>(ctx, n_unique);
@@ -1249,8 +1447,12 @@ static int eval_node_lse_core(pclean_ctx* ctx, int block_id, int node_id, const 
   int32_t* excl2 = scratch<int32_t>(ctx, n_unique);
   double* lse_u = scratch<double>(ctx, n_unique);
   if (!row2 || !ctx2 || !excl2 || !lse_u) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-  hipLaunchKernelGGL(item_unique_kernel, grid1(n), dim3(256), 0, ctx->stream, n, idx_s, head, uid, il.row, il.ctx, excl,
-                     uid_of_item, row2, ctx2, excl2);
+  if (g.hg_incl)
+    hipLaunchKernelGGL(hg_unique_kernel, grid1(n), dim3(256), 0, ctx->stream, n, g.hg_incl, g.hg_rep, g.hg_slot_of, il.row, il.ctx,
+                       excl, uid_of_item, row2, ctx2, excl2);
+  else
+    hipLaunchKernelGGL(item_unique_kernel, grid1(n), dim3(256), 0, ctx->stream, n, g.members, g.head, g.uid, il.row, il.ctx, excl,
+                       uid_of_item, row2, ctx2, excl2);
   ItemList il2;
   il2.n = n_unique;
   il2.row = row2;

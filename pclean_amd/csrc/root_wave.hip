@@ -611,7 +611,7 @@ __device__ unsigned long long g_wave_clk[16];
 template <int NT, int CAP, int WPG>
 __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_root_wave_kernel(
     const FastRootDev fr, const WaveItems wi, uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, int n_groups,
-    const int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr, double* __restrict__ g_m,
+    int chunk, const int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr, double* __restrict__ g_m,
     uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out, int32_t* __restrict__ overflow_flag,
     unsigned int* __restrict__ overflow_count, int32_t* __restrict__ overflow_list,
     unsigned int* __restrict__ scan_stats) {
@@ -654,8 +654,11 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
   // XCD-aware chunk hand-out: workgroup b runs on XCD b % 8 (each XCD has its own L2).  The groups arrive sorted by
   // referent, so consecutive groups stream the same byte rows: XCD x owns the x-th contiguous eighth of the groups.
   const int xcd = blockIdx.x & 7;
-  const int per = (((n_groups + 7) >> 3) + WAVE_CHUNK - 1) / WAVE_CHUNK * WAVE_CHUNK;  // groups per XCD, whole chunks
-  const int chunks_per = per / WAVE_CHUNK;
+  // (chunk = consecutive groups a wave takes at a time: WAVE_CHUNK for the large launches — a wave reuses its survivor list
+  // across neighbours —, fewer for short lists: the nested slots of a new-row branch hold a few hundred groups, and eight
+  // at a time left all but 32 waves of the chip idle behind a serial chain of ~15 us per group)
+  const int per = (((n_groups + 7) >> 3) + chunk - 1) / chunk * chunk;  // groups per XCD, whole chunks
+  const int chunks_per = per / chunk;
   int steal = 0;  // chunks come from the counter of XCD (xcd + steal) & 7; 8 = everything is handed out
   auto grab = [&]() -> int {  // the returned value is valid in lane 0 and looked at by resolve() only
     int c = 0;
@@ -667,8 +670,8 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     for (;;) {
       const int x = (xcd + steal) & 7;
       if (c < chunks_per) {
-        g_lo = x * per + c * WAVE_CHUNK;
-        g_hi = min(g_lo + WAVE_CHUNK, min((x + 1) * per, n_groups));
+        g_lo = x * per + c * chunk;
+        g_hi = min(g_lo + chunk, min((x + 1) * per, n_groups));
         if (g_lo < g_hi) return;
       }
       if (++steal >= 8) {
@@ -1411,7 +1414,7 @@ int pclean_launch_root_flags(pclean_ctx* ctx, int n_groups, const int32_t* gd, c
   return PCLEAN_OK;
 }
 
-typedef void (*wave_kernel_t)(const FastRootDev, const WaveItems, uint64_t, uint32_t, uint32_t, int, int, const int32_t*,
+typedef void (*wave_kernel_t)(const FastRootDev, const WaveItems, uint64_t, uint32_t, uint32_t, int, int, int, const int32_t*,
                               unsigned int*, double*, uint64_t*, int32_t*, int32_t*, unsigned int*, int32_t*, unsigned int*);
 
 static wave_kernel_t pick_kernel(int n_terms) {
@@ -1468,7 +1471,10 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   }
   int wgs = res;
   if (const char* e = getenv("PCLEAN_WAVE_WGS")) wgs = std::max(1, atoi(e));
-  wgs = std::min(wgs, (it.n + wpg * WAVE_CHUNK - 1) / (wpg * WAVE_CHUNK));
+  // groups per hand-out: every resident wave gets work before any wave takes several groups at a time
+  int chunk = std::max(1, std::min(WAVE_CHUNK, it.n / std::max(res * wpg, 1)));
+  if (const char* e = getenv("PCLEAN_WAVE_CHUNK")) chunk = std::max(1, atoi(e));
+  wgs = std::min(wgs, (it.n + wpg * chunk - 1) / (wpg * chunk));
   wgs = (wgs + 7) & ~7;  // a multiple of the 8 XCDs
   WaveItems wi{it.grp_off ? it.members : nullptr, it.row, it.rng_row, it.particle, it.out_pos, it.row_offset, it.draw_is,
                it.draw_ds};
@@ -1492,7 +1498,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
     hipLaunchKernelGGL(group_settle_kernel, dim3((unsigned int)((n_thr + 255) / 256)), dim3(256), 0, ctx->stream, sa, ws, it.n,
                        n_draws, desc_scratch, g_m, g_U, draws_out, scan_stats);
   }
-  hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * wpg), 0, ctx->stream, fr, wi, seed, sweep, site, n_draws, it.n, desc_scratch,
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * wpg), 0, ctx->stream, fr, wi, seed, sweep, site, n_draws, it.n, chunk, desc_scratch,
                      chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count, overflow_list, scan_stats);
 #ifdef WAVE_PHASE_CLOCK
   if (it.n > 100000) {

@@ -165,7 +165,8 @@ __global__ __launch_bounds__(PU_T) void particle_update_kernel(int N, int P, con
                                                               int32_t* __restrict__ pchoice, double* __restrict__ w,
                                                               unsigned int* __restrict__ n_new,
                                                               int32_t* __restrict__ new_list,
-                                                              int32_t* __restrict__ pnewpos, int first) {
+                                                              int32_t* __restrict__ pnewpos, int first,
+                                                              const int32_t* __restrict__ emit_rows) {
   __shared__ unsigned int wsum[PU_T / 64];
   __shared__ unsigned int bbase;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,6 +191,9 @@ __global__ __launch_bounds__(PU_T) void particle_update_kernel(int N, int P, con
       w[sp] = first ? 0.0 + l : w[sp] + l;  // (first block of the sweep: the weights start at +0.0)
       if (c == PCLEAN_CHOICE_NEW) newmask |= 1ull << p;
     }
+    // (last block, dummy values drawable for a few rows only: the list holds those rows' NEW slots — the others'
+    // contents are sampled after the final choice, for the chosen particle alone)
+    if (emit_rows && !emit_rows[i]) newmask = 0;
   }
   const unsigned int mine = (unsigned int)__popcll(newmask);
   unsigned int incl = mine;
@@ -416,11 +420,14 @@ __global__ __launch_bounds__(256) void finalize_block_kernel(int n_rows, const i
                                                              const int32_t* pnewpos, const int32_t* cur_b,
                                                              int32_t* choice, int32_t* chosen_newpos,
                                                              unsigned long long* stats, int hist_rows,
-                                                             int32_t* moved_flag, int32_t* new_flag) {
+                                                             int32_t* moved_flag, int32_t* new_flag,
+                                                             unsigned int* __restrict__ wg_moved,
+                                                             unsigned int* __restrict__ wg_new) {
   extern __shared__ int32_t hist[];
   for (int k = threadIdx.x; k < hist_rows; k += 256) hist[k] = 0;
   if (hist_rows) __syncthreads();
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int is_moved = 0, is_new = 0;
   if (i < n_rows) {
     const size_t s = (size_t)chosen[i] * n_rows + i;
     const int c = pchoice[s];
@@ -428,8 +435,8 @@ __global__ __launch_bounds__(256) void finalize_block_kernel(int n_rows, const i
     choice[i] = c;
     const int np = c == PCLEAN_CHOICE_NEW ? pnewpos[s] : -1;
     chosen_newpos[i] = np;
-    new_flag[i] = np >= 0 ? 1 : 0;
-    moved_flag[i] = c != o ? 1 : 0;
+    new_flag[i] = is_new = np >= 0 ? 1 : 0;
+    moved_flag[i] = is_moved = c != o ? 1 : 0;
     if (o != c) {
       if (hist_rows) {
         if (o >= 0) atomicAdd(&hist[o], -1);
@@ -447,6 +454,63 @@ __global__ __launch_bounds__(256) void finalize_block_kernel(int n_rows, const i
       if (v) atomicAdd(&stats[k], (unsigned long long)(long long)v);
     }
   }
+  // this workgroup's share of the two ordered lists (tail_scan_kernel / tail_scatter_kernel)
+  const int n_moved = __syncthreads_count(is_moved), n_newr = __syncthreads_count(is_new);
+  if (threadIdx.x == 0) {
+    wg_moved[blockIdx.x] = (unsigned int)n_moved;
+    wg_new[blockIdx.x] = (unsigned int)n_newr;
+  }
+}
+
+// ---- ordered lists of the rows that moved / got a new referent, every block's at once: the per-workgroup counts
+// finalize_block_kernel left -> offsets (one workgroup per list) -> the rows, ascending (one workgroup per 256-row tile and
+// list).  Two dispatches per sweep where four hipcub::DeviceSelect calls were sixteen.
+#define TAIL_MAX_LISTS (2 * PCLEAN_MAX_BLOCKS)
+__global__ __launch_bounds__(1024) void tail_scan_kernel(int nb, unsigned int* __restrict__ wg_cnt, int32_t* __restrict__ totals) {
+  __shared__ unsigned int wsum[16];
+  unsigned int* c = wg_cnt + (size_t)blockIdx.x * nb;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int carry = 0;
+  for (int base = 0; base < nb; base += 1024) {
+    const int j = base + threadIdx.x;
+    const unsigned int v = j < nb ? c[j] : 0u;
+    unsigned int incl = v;
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned int x = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += x;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    unsigned int wbase = 0, tot = 0;
+    for (int k = 0; k < 16; ++k) {
+      if (k < wave) wbase += wsum[k];
+      tot += wsum[k];
+    }
+    if (j < nb) c[j] = carry + wbase + incl - v;
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = (int32_t)carry;
+}
+struct TailLists {
+  const int32_t* flag[TAIL_MAX_LISTS];  // null: no such list (scoring block)
+  int32_t* list[TAIL_MAX_LISTS];
+};
+__global__ __launch_bounds__(256) void tail_scatter_kernel(int n_rows, int nb, TailLists tl, const unsigned int* __restrict__ wg_off) {
+  __shared__ unsigned int wcnt[4];
+  const int l = blockIdx.y;
+  const int32_t* flag = tl.flag[l];
+  if (!flag) return;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool f = i < n_rows && flag[i] != 0;
+  const unsigned long long mk = __ballot(f);
+  if (lane == 0) wcnt[wave] = (unsigned int)__popcll(mk);
+  __syncthreads();
+  if (!f) return;
+  unsigned int pos = wg_off[(size_t)l * nb + blockIdx.x] + (unsigned int)__popcll(mk & ((1ull << lane) - 1ull));
+  for (int w = 0; w < wave; ++w) pos += wcnt[w];
+  tl.list[l][pos] = i;
 }
 
 // own enumerated choices (locals) of the chosen particle, drawn from their conditional given
@@ -892,14 +956,16 @@ extern "C" int pclean_score_node(pclean_ctx* ctx, int32_t block_id, int32_t node
 
 // Can a particle of this sweep draw the ProposalDummyValue of some option list of block bi?  Cacheable lists know it
 // per observed value (ensure_leaf_cache: weight of the dummy option); any other list with a dummy is assumed to.
-static int block_dummy_drawable(pclean_ctx* ctx, int bi, bool* out) {
+static int block_dummy_drawable(pclean_ctx* ctx, int bi, bool* out, bool* by_row = nullptr) {
   Block& b = ctx->block[bi];
   *out = false;
+  if (by_row) *by_row = true;  // every list that can draw its dummy knows for which observed values (leaf_udummy)
   for (int node = 0; node < (int)b.nodes.size(); ++node) {
     const pclean_node& n = b.nodes[node];
     if (n.kind != PCLEAN_NODE_LEAF || n.dummy_value == 0) continue;
     if (!n.cacheable || (node < (int)b.node_gauss.size() && b.node_gauss[node] >= 0)) {
       *out = true;
+      if (by_row) *by_row = false;
       return PCLEAN_OK;
     }
     const double* cache;
@@ -911,9 +977,66 @@ static int block_dummy_drawable(pclean_ctx* ctx, int bi, bool* out) {
       static const bool dbg = getenv("PCLEAN_DEBUG_DUMMY") != nullptr;
       if (dbg) fprintf(stderr, "[pclean] block %d node %d: its ProposalDummyValue can be drawn (flag %d)\n", bi, node, b.leaf_drawable[node]);
       *out = true;
-      return PCLEAN_OK;
+      if (b.leaf_drawable[node] < 0 || !b.leaf_udummy[node].p) {
+        if (by_row) *by_row = false;
+        return PCLEAN_OK;
+      }
+      if (!by_row) return PCLEAN_OK;
     }
   }
+  return PCLEAN_OK;
+}
+
+// flag[i] = 1 when some cacheable option list of block bi can draw its ProposalDummyValue for row i of the active window:
+// the fixed-point weight of the dummy option for the row's observed value (ensure_leaf_cache: leaf_udummy) is not zero.
+// Rebuilt when a cache, the observations or the window change.
+struct DummyFlagLeaf {
+  const int32_t* obs_col;
+  const uint64_t* udummy;
+  int32_t n_obs, pad;
+};
+struct DummyFlagPack {
+  int32_t n_leaves, pad;
+  DummyFlagLeaf leaf[DUMMY_MAX_LEAVES];
+};
+__global__ void dummy_rows_kernel(int n, DummyFlagPack pk, int32_t* __restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int f = 0;
+  for (int l = 0; l < pk.n_leaves; ++l) {
+    const int o = pk.leaf[l].obs_col[i];
+    f |= pk.leaf[l].udummy[o < 0 ? pk.leaf[l].n_obs : o] != 0ull ? 1 : 0;
+  }
+  flag[i] = f;
+}
+static int dummy_rows_flags(pclean_ctx* ctx, int bi, int N, const int32_t** out) {
+  Block& b = ctx->block[bi];
+  SweepState* s = st(ctx);
+  SweepState::DummyRows& dr = s->dummy_rows[bi];
+  DummyFlagPack pk{};
+  uint64_t sig = (uint64_t)N * 0x9e3779b97f4a7c15ull + (uint64_t)ctx->active_begin * 0xd6e8feb86659fd93ull + ctx->obs_version + b.version * 7919ull;
+  for (int node = 0; node < (int)b.nodes.size(); ++node) {
+    const pclean_node& n = b.nodes[node];
+    if (n.kind != PCLEAN_NODE_LEAF || n.dummy_value == 0 || b.leaf_drawable[node] == 0) continue;
+    if (pk.n_leaves >= DUMMY_MAX_LEAVES) {
+      *out = nullptr;  // (more lists than the pack holds: the caller samples every NEW slot)
+      return PCLEAN_OK;
+    }
+    const pclean_term& tm = b.terms[n.term_begin];
+    const PairTable& pt = ctx->pair[tm.pair_table];
+    DummyFlagLeaf& lf = pk.leaf[pk.n_leaves++];
+    lf.obs_col = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows + ctx->active_begin;
+    lf.udummy = b.leaf_udummy[node].p;
+    lf.n_obs = pt.n_obs;
+    sig = sig * 1000003ull + s->leaf_version[bi * 256 + node] + (uint64_t)(uintptr_t)lf.udummy;
+  }
+  if (dr.sig != sig || dr.n != N || !dr.flag.p) {
+    if (dr.flag.alloc(std::max(N, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+    hipLaunchKernelGGL(dummy_rows_kernel, grid1(N), dim3(256), 0, ctx->stream, N, pk, dr.flag.p);
+    dr.sig = sig;
+    dr.n = N;
+  }
+  *out = dr.flag.p;
   return PCLEAN_OK;
 }
 
@@ -1071,6 +1194,39 @@ static int ensure_it_ctx(pclean_ctx* ctx, BlockRun& r, size_t NP, int n_ctx) {
   return PCLEAN_OK;
 }
 
+// ---- several small buffers zeroed by ONE launch (a hipMemsetAsync apiece is a dispatch apiece) -------------------------
+#define ZERO_LIST_MAX 16
+struct ZeroList {
+  int32_t n, pad;
+  void* p[ZERO_LIST_MAX];
+  uint32_t words[ZERO_LIST_MAX];  // 4-byte words
+};
+__global__ __launch_bounds__(256) void zero_list_kernel(ZeroList zl) {
+  uint32_t* p = (uint32_t*)zl.p[blockIdx.y];
+  const uint32_t nw = zl.words[blockIdx.y];
+  for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nw; k += gridDim.x * 256) p[k] = 0u;
+}
+static int zero_list_flush(pclean_ctx* ctx, ZeroList& zl) {
+  if (zl.n == 0) return PCLEAN_OK;
+  uint32_t mx = 0;
+  for (int k = 0; k < zl.n; ++k) mx = std::max(mx, zl.words[k]);
+  const unsigned gx = std::max(1u, std::min(1024u, (mx + 255u) / 256u));
+  hipLaunchKernelGGL(zero_list_kernel, dim3(gx, zl.n), dim3(256), 0, ctx->stream, zl);
+  zl.n = 0;
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
+static void zero_list_add(pclean_ctx* ctx, ZeroList& zl, void* p, size_t bytes) {  // bytes: a multiple of 4
+  if (!p || bytes == 0) return;
+  if (zl.n == ZERO_LIST_MAX || bytes > (size_t)0xffffffffu * 4) {  // (full, or too large for the word count: the plain way)
+    (void)hipMemsetAsync(p, 0, bytes, ctx->stream);
+    return;
+  }
+  zl.p[zl.n] = p;
+  zl.words[zl.n] = (uint32_t)(bytes / 4);
+  ++zl.n;
+}
+
 extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
                             int32_t n_blocks, const int32_t* cur, int32_t* choice, int32_t* chosen_particle,
                             double* logml) {
@@ -1200,6 +1356,25 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     int rc = ensure_plan_dev(ctx, bi);
     if (rc) return rc;
     const bool has_ctx = b.n_ctx > 0;
+    // The contents of a proposed new row matter (a) as context / scored values of LATER blocks — every particle's —
+    // and (b) for the particle that is finally chosen.  For the last block only (b) is left: its sampling is
+    // deferred until after the final choice and done for the chosen particles alone (same Philox counters, so
+    // the values are the ones eager sampling would have produced; typically 20x fewer items).
+    // A chosen ProposalDummyValue changes its particle's weight (apply_dummy_corrections): where one can be drawn
+    // the NEW slots are sampled before the final choice — all of them, or, when every list that can draw its dummy knows
+    // for which observed values (cacheable lists: leaf_udummy), those of the few rows that hold such a value (emit_rows).
+    static const bool eager_all = getenv("PCLEAN_EAGER_NEW") != nullptr;
+    static const bool no_partial = getenv("PCLEAN_NO_PARTIAL_EAGER") != nullptr;
+    bool drawable = prior_mode, dummy_by_row = false;  // (prior draws of a StringPrior choice are the dummy almost surely)
+    if (!prior_mode) {
+      rc = block_dummy_drawable(ctx, bi, &drawable, &dummy_by_row);
+      if (rc) return rc;
+    }
+    const int32_t* emit_rows = nullptr;
+    if (bi == n_blocks - 1 && !eager_all && !no_partial && !prior_mode && drawable && dummy_by_row) {
+      rc = dummy_rows_flags(ctx, bi, N, &emit_rows);
+      if (rc) return rc;
+    }
     ItemList il;
     const int32_t* excl;
     if (prior_mode) {
@@ -1217,7 +1392,8 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
-                         s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0);
+                         s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0,
+                         (const int32_t*)nullptr);
       if (has_ctx) {  // the particles' contexts: read by the likelihood terms and handed to the new rows' items
         { const int rci = ensure_it_ctx(ctx, r, NP, b.n_ctx); if (rci) return rci; }
         CtxSrc cs{};
@@ -1252,7 +1428,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
-                         s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0);
+                         s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows);
     } else {
       { const int rci = ensure_it_ctx(ctx, r, NP, b.n_ctx); if (rci) return rci; }
       CtxSrc cs{};
@@ -1306,26 +1482,15 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, (const int32_t*)nullptr,
                          (const double*)nullptr, slot_item, draws_item, lse_item, cur_b, r.pchoice.p, s->w.p,
-                         s->counter.p, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0);
+                         s->counter.p, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows);
     }
     // ---- particles that proposed a NEW referent: sample the new row's contents
     unsigned int n_new = 0;
     PCLEAN_READ_COUNT(ctx, s->counter.p, &n_new);
     r.n_new = (int)n_new;
-    // The contents of a proposed new row matter (a) as context / scored values of LATER blocks — every particle's —
-    // and (b) for the particle that is finally chosen.  For the last block only (b) is left: its sampling is
-    // deferred until after the final choice and done for the chosen particles alone (same Philox counters, so
-    // the values are the ones eager sampling would have produced; typically 20x fewer items).
-    static const bool eager_all = getenv("PCLEAN_EAGER_NEW") != nullptr;
-    // A chosen ProposalDummyValue changes its particle's weight (apply_dummy_corrections): where one can be drawn
-    // every NEW slot is sampled before the final choice.
-    bool drawable = prior_mode;  // (prior draws of a StringPrior choice are the dummy almost surely)
-    if (!prior_mode) {
-      rc = block_dummy_drawable(ctx, bi, &drawable);
-      if (rc) return rc;
-    }
-    r.lazy_new = bi == n_blocks - 1 && !eager_all && !drawable;
-    if (r.lazy_new) n_new = 0;  // nothing sampled now
+    r.lazy_new = bi == n_blocks - 1 && !eager_all && (!drawable || emit_rows != nullptr);
+    if (r.lazy_new && !emit_rows) n_new = 0;  // nothing sampled now
+    if (emit_rows) r.n_new = -1;  // (the list held the flagged rows' slots only: whether anybody proposed a NEW referent is not known)
     if (r.vals.alloc(std::max<size_t>((size_t)n_new * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
     if (n_new) {
       ProfScope ps(ctx, "new_row_sampling");
@@ -1430,12 +1595,23 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       int rc = sample_children(ctx, bi, 0, sub, ex, seed, sweep_idx, r.vals.p, nn);
       if (rc) return rc;
     }
-    size_t tmp_sel = 0;
-    HIPCHK(ctx, hipcub::DeviceSelect::Flagged(nullptr, tmp_sel, hipcub::CountingInputIterator<int32_t>(0),
-                                              (const int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, N,
-                                              ctx->stream));
-    unsigned char* tmp = scratch<unsigned char>(ctx, std::max<size_t>(tmp_sel, 16));
-    if (!tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    const int nb_wg = (N + 255) / 256;
+    unsigned int* wg_cnt = scratch<unsigned int>(ctx, (size_t)2 * n_blocks * nb_wg);
+    if (!wg_cnt) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    TailLists tl{};
+    // the tables' delta reference counts start at zero: one kernel over every root table instead of a memset apiece
+    {
+      ZeroList zl{};
+      for (int bi = 0; bi < n_blocks; ++bi) {
+        if (ctx->block[bi].is_score) continue;
+        CandTable& rt = ctx->cand[ctx->block[bi].nodes[0].table];
+        bool seen = false;
+        for (int k = 0; k < zl.n; ++k) seen |= zl.p[k] == (void*)rt.stats.p;
+        if (!seen) zero_list_add(ctx, zl, rt.stats.p, (size_t)std::max(rt.n_rows, 1) * 8);
+      }
+      const int rcz = zero_list_flush(ctx, zl);
+      if (rcz) return rcz;
+    }
     for (int bi = 0; bi < n_blocks; ++bi) {
       BlockRun& r = s->run[bi];
       Block& bb = ctx->block[bi];
@@ -1444,15 +1620,15 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       if (bb.is_score) continue;
       const int32_t* cur_b = cur_base + (size_t)bi * cur_ld;
       CandTable& rt = ctx->cand[bb.nodes[0].table];
-      HIPCHK(ctx, hipMemsetAsync(rt.stats.p, 0, (size_t)std::max(rt.n_rows, 1) * 8, ctx->stream));
       const int hist_rows = rt.n_rows <= 12288 ? rt.n_rows : 0;  // (48 KB of LDS per workgroup at most)
       hipLaunchKernelGGL(finalize_block_kernel, grid1(N), dim3(256), (size_t)hist_rows * sizeof(int32_t), ctx->stream, N,
                          s->chosen.p, r.pchoice.p, r.pnewpos.p, cur_b, r.choice.p, r.chosen_newpos.p,
-                         (unsigned long long*)rt.stats.p, hist_rows, r.moved_flag.p, r.new_flag.p);
-      HIPCHK(ctx, hipcub::DeviceSelect::Flagged(tmp, tmp_sel, hipcub::CountingInputIterator<int32_t>(0), r.moved_flag.p,
-                                                r.moved_list.p, s->tail_counts.p + 2 * bi, N, ctx->stream));
-      HIPCHK(ctx, hipcub::DeviceSelect::Flagged(tmp, tmp_sel, hipcub::CountingInputIterator<int32_t>(0), r.new_flag.p,
-                                                r.new_list.p, s->tail_counts.p + 2 * bi + 1, N, ctx->stream));
+                         (unsigned long long*)rt.stats.p, hist_rows, r.moved_flag.p, r.new_flag.p,
+                         wg_cnt + (size_t)(2 * bi) * nb_wg, wg_cnt + (size_t)(2 * bi + 1) * nb_wg);
+      tl.flag[2 * bi] = r.moved_flag.p;
+      tl.list[2 * bi] = r.moved_list.p;
+      tl.flag[2 * bi + 1] = r.new_flag.p;
+      tl.list[2 * bi + 1] = r.new_list.p;
       if (choice)
         HIPCHK(ctx, hipMemcpyAsync(choice + (size_t)bi * N, r.choice.p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
       if (!bb.node_gauss.empty() && bb.node_gauss[0] >= 0 && bb.gauss[bb.node_gauss[0]].n_locals > 0) {
@@ -1469,6 +1645,13 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
           HIPCHK(ctx, hipMemcpyAsync(bb.locals_host.data(), r.locals.p, (size_t)N * 8, hipMemcpyDeviceToHost, ctx->stream));
         }
       }
+    }
+    {  // (a scoring block's two slots: their workgroup counts were never written — zero them so that the totals read 0)
+      for (int bi = 0; bi < n_blocks; ++bi)
+        if (ctx->block[bi].is_score)
+          HIPCHK(ctx, hipMemsetAsync(wg_cnt + (size_t)(2 * bi) * nb_wg, 0, (size_t)2 * nb_wg * sizeof(unsigned int), ctx->stream));
+      hipLaunchKernelGGL(tail_scan_kernel, dim3(2 * n_blocks), dim3(1024), 0, ctx->stream, nb_wg, wg_cnt, s->tail_counts.p);
+      hipLaunchKernelGGL(tail_scatter_kernel, dim3(nb_wg, 2 * n_blocks), dim3(256), 0, ctx->stream, N, nb_wg, tl, wg_cnt);
     }
     (void)hipEventRecord(s->eve, ctx->stream);
     if (chosen_particle) HIPCHK(ctx, hipMemcpyAsync(chosen_particle, s->chosen.p, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));

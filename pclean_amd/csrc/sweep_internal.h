@@ -60,6 +60,11 @@ struct ItemGroups {
   const int32_t* members = nullptr;  // [n] item ids, groups contiguous
   const int32_t* head = nullptr;     // [n] 1 at the first member of each group (sorted order)
   const int32_t* uid = nullptr;      // [n] inclusive scan of head
+  // hash-table grouping (eval.hip: make_item_groups_hash): inclusive scan over the slots, the slots' representatives, slot of
+  // every item — all a caller needs that only asks which group an item is in (hg_unique_kernel)
+  const uint64_t* hg_incl = nullptr;
+  const int32_t* hg_rep = nullptr;
+  const int32_t* hg_slot_of = nullptr;
 };
 
 // bump-style scratch: buffers persist across sweeps, handed out in order

@@ -92,6 +92,14 @@ struct SweepState {
     uint64_t sig = 0;
   };
   std::map<int, TupleIds> tuple_ids;
+  // gate of the new-row branch (eval.hip): a node whose gate let EVERY item through three evaluations in a row (the
+  // Measure slot of the 1M-row table: the new-row candidate is never 28.5 nats behind) skips it for a while — the gate
+  // only ever removes work whose weight is exactly 0, so results do not depend on it.  key = block * 64 + node
+  struct GateStat { int all_need_run = 0, skip = 0; };
+  std::map<int, GateStat> gate_stat;
+  // rows for which some cacheable option list of the block can draw its ProposalDummyValue (sweep.hip: dummy_rows_flags)
+  struct DummyRows { DevBuf<int32_t> flag; uint64_t sig = 0; int n = 0; };
+  std::map<int, DummyRows> dummy_rows;  // key = block
   // evidence of the running pclean_sweep_latent call (ensure_agg)
   const int32_t* lat_off = nullptr;      // [lat_items + 1] CSR offsets of the original items into the evidence list
   const int32_t* lat_item_of_pos = nullptr;  // [lat_ev]
