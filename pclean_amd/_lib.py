@@ -612,6 +612,14 @@ class HipContext:
               "pclean_commit_device")
         return out
 
+    def commit_device_dist(self, n_blocks, sweep_idx, local_empty, max_local_rows):
+        """collective over the ranks of comm_init: the commit of a sweep whose rows are sharded over them"""
+        out = CommitSummary()
+        check(self.h, self.lib.pclean_commit_device_dist(self.h, C.c_int32(n_blocks), C.c_uint32(sweep_idx),
+                                                         C.c_int32(int(bool(local_empty))), C.c_int32(int(max_local_rows)),
+                                                         C.byref(out)), "pclean_commit_device_dist")
+        return out
+
     def commit_pull_table(self, table_id):
         """(state words, cols [n_cols][cap], counts, live, free stack, origin [cap][4]) of a latent table's device state"""
         cap, nc = self.table_shape(table_id)

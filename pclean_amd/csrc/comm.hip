@@ -17,9 +17,11 @@ struct UniqueId {
 typedef int (*get_unique_id_t)(UniqueId*);
 typedef int (*comm_init_rank_t)(void**, int, UniqueId, int);
 typedef int (*all_reduce_t)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*all_gather_t)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef int (*comm_destroy_t)(void*);
 typedef const char* (*get_error_string_t)(int);
 const int kNcclInt64 = 4;  // ncclInt64
+const int kNcclInt32 = 2;  // ncclInt32
 const int kNcclSum = 0;    // ncclSum
 
 struct Rccl {
@@ -27,6 +29,7 @@ struct Rccl {
   get_unique_id_t get_unique_id = nullptr;
   comm_init_rank_t comm_init_rank = nullptr;
   all_reduce_t all_reduce = nullptr;
+  all_gather_t all_gather = nullptr;
   comm_destroy_t comm_destroy = nullptr;
   get_error_string_t error_string = nullptr;
 };
@@ -52,6 +55,7 @@ Rccl* rccl(pclean_ctx* ctx) {
   r.get_unique_id = (get_unique_id_t)dlsym(r.handle, "ncclGetUniqueId");
   r.comm_init_rank = (comm_init_rank_t)dlsym(r.handle, "ncclCommInitRank");
   r.all_reduce = (all_reduce_t)dlsym(r.handle, "ncclAllReduce");
+  r.all_gather = (all_gather_t)dlsym(r.handle, "ncclAllGather");
   r.comm_destroy = (comm_destroy_t)dlsym(r.handle, "ncclCommDestroy");
   r.error_string = (get_error_string_t)dlsym(r.handle, "ncclGetErrorString");
   if (!r.get_unique_id || !r.comm_init_rank || !r.all_reduce || !r.comm_destroy) {
@@ -93,6 +97,7 @@ extern "C" int pclean_comm_init(pclean_ctx* ctx, int32_t n_ranks, int32_t rank, 
   if (rc) return rccl_fail(ctx, r, "ncclCommInitRank", rc);
   ctx->rccl_comm = comm;
   ctx->comm_ranks = n_ranks;
+  ctx->comm_rank = rank;
   return PCLEAN_OK;
 }
 
@@ -121,8 +126,33 @@ __global__ void stats_pack_kernel(int n, const int64_t* __restrict__ src, int64_
 // The delta reference counts of several latent tables as ONE int64 vector: packed into a device buffer, summed over
 // the ranks with a single RCCL all-reduce (the payload is ~80 KB: latency-bound, so one collective instead of one
 // per table), unpacked into every table's stats buffer and copied to the host once.
+static int allreduce_stats_queue(pclean_ctx* ctx, int32_t n_tables, const int32_t* table_ids, int32_t local_is_zero, int64_t* out,
+                                 size_t* total_out);
 extern "C" int pclean_allreduce_stats_fused(pclean_ctx* ctx, int32_t n_tables, const int32_t* table_ids,
                                             int32_t local_is_zero, int64_t* out) {
+  size_t total = 0;
+  const int rc = allreduce_stats_queue(ctx, n_tables, table_ids, local_is_zero, out, &total);
+  if (rc || total == 0) return rc;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLEAN_OK;
+}
+// the same, queued on the library's stream and left there (the device-resident commit of several ranks: commit.hip)
+int pclean_comm_allreduce_stats_queue(pclean_ctx* ctx, int32_t n_tables, const int32_t* table_ids, int32_t local_is_zero) {
+  size_t total = 0;
+  return allreduce_stats_queue(ctx, n_tables, table_ids, local_is_zero, nullptr, &total);
+}
+// all-gather of words_per_rank int32 words per rank (rank r's words land at recv + r * words_per_rank); queued, no sync
+int pclean_comm_allgather_i32(pclean_ctx* ctx, const int32_t* send, int32_t* recv, size_t words_per_rank) {
+  if (!ctx->rccl_comm) return pclean_fail(ctx, PCLEAN_ERR_STATE, "all-gather: call pclean_comm_init first");
+  Rccl* r = rccl(ctx);
+  if (!r) return PCLEAN_ERR_STATE;
+  if (!r->all_gather) return pclean_fail(ctx, PCLEAN_ERR_STATE, "ncclAllGather missing in librccl.so");
+  const int rc = r->all_gather(send, recv, words_per_rank, kNcclInt32, ctx->rccl_comm, ctx->stream);
+  if (rc) return rccl_fail(ctx, r, "ncclAllGather", rc);
+  return PCLEAN_OK;
+}
+static int allreduce_stats_queue(pclean_ctx* ctx, int32_t n_tables, const int32_t* table_ids, int32_t local_is_zero, int64_t* out,
+                                 size_t* total_out) {
   if (!ctx || n_tables <= 0 || n_tables > PCLEAN_MAX_TABLES || !table_ids)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_allreduce_stats_fused: bad arguments");
   if (!ctx->rccl_comm) return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_allreduce_stats_fused: call pclean_comm_init first");
@@ -135,6 +165,7 @@ extern "C" int pclean_allreduce_stats_fused(pclean_ctx* ctx, int32_t n_tables, c
       return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_allreduce_stats_fused: bad table id");
     total += (size_t)ctx->cand[table_ids[i]].n_rows;
   }
+  *total_out = total;
   if (total == 0) return PCLEAN_OK;
   if (ctx->stats_pack.alloc(total)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   size_t off = 0;
@@ -157,7 +188,6 @@ extern "C" int pclean_allreduce_stats_fused(pclean_ctx* ctx, int32_t n_tables, c
     off += (size_t)t.n_rows;
   }
   if (out) HIPCHK(ctx, hipMemcpyAsync(out, ctx->stats_pack.p, total * 8, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   return PCLEAN_OK;
 }
 
@@ -168,5 +198,6 @@ extern "C" int pclean_comm_destroy(pclean_ctx* ctx) {
   if (r) (void)r->comm_destroy(ctx->rccl_comm);
   ctx->rccl_comm = nullptr;
   ctx->comm_ranks = 0;
+  ctx->comm_rank = 0;
   return PCLEAN_OK;
 }

@@ -70,6 +70,15 @@ struct CommitState {
       newid[PCC_MAX_BLOCKS], recpos[PCC_MAX_BLOCKS];
   DevBuf<PccResult> d_res;
   DevBuf<PccSums> d_sums;
+  // several ranks (pclean_commit_device_dist): segment capacities (the same on every rank: from the window's size, then
+  // from the last commit's global totals), the all-gather buffers, the gathered lists and the gathered-form blocks
+  int cap_m[PCC_MAX_BLOCKS] = {0}, cap_k[PCC_MAX_BLOCKS] = {0};
+  DevBuf<int32_t> seg, seg_all, g_counts2;
+  DevBuf<int32_t> g_moved[PCC_MAX_BLOCKS], g_choice[PCC_MAX_BLOCKS], g_new[PCC_MAX_BLOCKS], g_chosen[PCC_MAX_BLOCKS],
+      g_vals[PCC_MAX_BLOCKS];
+  DevBuf<PccBlock> d_blocks_g;
+  PccBlock* h_blocks_g = nullptr;
+  int32_t* h_g_counts2 = nullptr;
   // page-locked mirrors
   PccBlock* h_blocks = nullptr;
   PccResult* h_res = nullptr;
@@ -99,6 +108,12 @@ void pclean_commit_state_free(pclean_ctx* ctx) {
   if (c->h_res) (void)hipHostFree(c->h_res);
   if (c->h_sums) (void)hipHostFree(c->h_sums);
   if (c->h_states) (void)hipHostFree(c->h_states);
+  if (c->h_blocks_g) (void)hipHostFree(c->h_blocks_g);
+  if (c->h_g_counts2) (void)hipHostFree(c->h_g_counts2);
+  c->seg.release(); c->seg_all.release(); c->g_counts2.release(); c->d_blocks_g.release();
+  for (int b = 0; b < PCC_MAX_BLOCKS; ++b) {
+    c->g_moved[b].release(); c->g_choice[b].release(); c->g_new[b].release(); c->g_chosen[b].release(); c->g_vals[b].release();
+  }
   ctx->dev_cur.release();
   delete c;
   ctx->commit_state = nullptr;
@@ -106,9 +121,10 @@ void pclean_commit_state_free(pclean_ctx* ctx) {
 
 // ---- kernels --------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void pcc_commit_kernel(PccTable* tb, int n_slots, const PccPlan* plans, const PccBlock* blocks,
-                                                          int n_blocks, PccResult* res) {
+                                                          int n_blocks, PccResult* res, int gathered) {
   __shared__ int32_t part[1025];
   if (threadIdx.x == 0) pcc_prof_n = 0;
+  if (threadIdx.x == 0 && !gathered) res->fallback_in = 0;  // (several ranks: pcc_merge_kernel wrote it; read by this thread)
   if (threadIdx.x == 0)
     for (int s = 0; s < n_slots; ++s) {
       tb[s].state[PCC_ST_COLS_CHANGED] = 0;
@@ -123,6 +139,26 @@ __global__ __launch_bounds__(1024) void pcc_commit_kernel(PccTable* tb, int n_sl
 __global__ __launch_bounds__(256) void pcc_cur_kernel(const PccBlock* blocks, const PccResult* res) {
   if (res->fallback) return;
   pcc_update_cur(blocks[blockIdx.y], (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
+}
+
+// several ranks: this rank's lists -> its segment of the all-gather buffer; the gathered segments -> global lists
+// (grid.y = plan; commit_core.h: pcc_pack / pcc_merge)
+struct PccGathered {  // per plan: where pcc_merge puts the concatenated lists
+  int32_t* g_moved[PCC_MAX_BLOCKS];
+  int32_t* g_choice[PCC_MAX_BLOCKS];
+  int32_t* g_new[PCC_MAX_BLOCKS];
+  int32_t* g_chosen[PCC_MAX_BLOCKS];
+  int32_t* g_vals[PCC_MAX_BLOCKS];
+  int32_t cap_out_m[PCC_MAX_BLOCKS], cap_out_k[PCC_MAX_BLOCKS];
+};
+__global__ __launch_bounds__(256) void pcc_pack_kernel(PccSegLayout L, const PccBlock* blocks, int empty, int32_t* seg) {
+  pcc_pack(L, (int)blockIdx.y, blocks[blockIdx.y], empty, seg, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
+}
+__global__ __launch_bounds__(256) void pcc_merge_kernel(PccSegLayout L, int n_ranks, const int32_t* all, PccGathered g,
+                                                        int32_t* counts2, PccResult* res) {
+  const int p = blockIdx.y;
+  pcc_merge(L, p, n_ranks, all, g.cap_out_m[p], g.cap_out_k[p], g.g_moved[p], g.g_choice[p], g.g_new[p], g.g_chosen[p], g.g_vals[p],
+            counts2 + 2 * p, &res->fallback_in, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
 }
 
 __global__ void pcc_live_kernel(int n, const int64_t* counts, uint8_t* live) {
@@ -403,24 +439,46 @@ static int launch_refresh(pclean_ctx* ctx, CommitState* c) {
 
 // Commit the last pclean_sweep (run with cur == NULL and deferred outputs) on the device.  One stream synchronisation.
 // out->fallback != 0: nothing was modified; finish the sweep with pclean_sweep_fetch and commit on the host.
+static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_idx, bool dist, bool local_empty,
+                              int32_t max_local_rows, pclean_commit_summary* out);
 extern "C" int pclean_commit_device(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_idx, pclean_commit_summary* out) {
+  if (ctx && ctx->comm_ranks > 1)
+    return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_commit_device: several ranks commit through pclean_commit_device_dist "
+                                              "(every rank's moved rows and new-row records are gathered on the device first)");
+  return commit_device_impl(ctx, n_blocks, sweep_idx, false, false, 0, out);
+}
+// The commit of a sweep whose rows are sharded over the ranks of pclean_comm_init (collective: every rank calls it at
+// the same point with the same n_blocks / sweep_idx / max_local_rows).  The delta reference counts are summed over the ranks
+// (one all-reduce), every rank's moved rows and new-row records are all-gathered into every rank's HBM (one fixed-capacity
+// all-gather, rank order = row order) and the SAME commit kernel runs over the concatenation on every rank: identical
+// tables, free lists, counts and referents everywhere, nothing crosses PCIe.  local_empty != 0: this rank swept no row of
+// the window (no pclean_sweep before the call).  max_local_rows: the largest shard of the window (bounds the first
+// exchange's segments).  A one-rank communicator takes the same path (PCLEAN_FORCE_DIST runs).
+extern "C" int pclean_commit_device_dist(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_idx, int32_t local_empty,
+                                         int32_t max_local_rows, pclean_commit_summary* out) {
+  if (!ctx || !ctx->rccl_comm || ctx->comm_ranks < 1 || max_local_rows < 0)
+    return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_commit_device_dist: pclean_comm_init first");
+  return commit_device_impl(ctx, n_blocks, sweep_idx, true, local_empty != 0, max_local_rows, out);
+}
+static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_idx, bool dist, bool local_empty,
+                              int32_t max_local_rows, pclean_commit_summary* out) {
   if (!ctx || !out) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_commit_device: bad arguments");
   CommitState* c = cst(ctx);
   SweepState* s = st(ctx);
   if (!c->enabled || c->n_blocks != n_blocks) return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_commit_device: pclean_commit_enable first");
-  if (!s->outputs_pending || !s->last_dev_cur || s->last_blocks != n_blocks)
+  if (!local_empty && (!s->outputs_pending || !s->last_dev_cur || s->last_blocks != n_blocks))
     return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_commit_device: needs a pclean_sweep with device-resident referents "
                                               "(cur == NULL) and deferred outputs right before it");
-  if (ctx->comm_ranks > 1)
-    return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_commit_device: the new-row records of other ranks are not gathered on the "
-                                              "device yet; commit on the host");
+  if (dist && (!ctx->dev_cur_valid || ctx->dev_cur_blocks != n_blocks))
+    return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_commit_device_dist: pclean_set_cur first");
   for (int si = 0; si < c->n_slots; ++si)
     if (!c->slot[si].state_set || c->slot[si].stride != ctx->cand[c->slot[si].table_id].n_rows)
       return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_commit_device: table %d was re-uploaded without "
                                                 "pclean_commit_set_table_state", c->slot[si].table_id);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   memset(out, 0, sizeof *out);
-  const int N = s->last_N;
+  const int N = local_empty ? 0 : s->last_N;
+  const int world = dist ? ctx->comm_ranks : 1;
   // option-value pointers / table pointers may have moved with a re-upload
   for (int p = 0; p < c->n_plans; ++p) {
     const Block& b = ctx->block[c->plan_block[p]];
@@ -482,7 +540,9 @@ extern "C" int pclean_commit_device(pclean_ctx* ctx, int32_t n_blocks, uint32_t 
     pb.moved_list = r.moved_list.p;
     pb.new_list = r.new_list.p;
     pb.counts2 = s->tail_counts.p + 2 * bi;
-    pb.cur = const_cast<int32_t*>(s->last_cur_base) + (size_t)bi * s->last_cur_ld;
+    pb.cur = local_empty ? nullptr : const_cast<int32_t*>(s->last_cur_base) + (size_t)bi * s->last_cur_ld;
+    pb.moved_choice = nullptr;
+    pb.rec_chosen = nullptr;
     pb.delta = ctx->cand[b.nodes[0].table].stats.p;
     pb.kcap = kcap;
     pb.hmask = hsz - 1;
@@ -495,10 +555,111 @@ extern "C" int pclean_commit_device(pclean_ctx* ctx, int32_t n_blocks, uint32_t 
     pb.recpos = c->recpos[p].p;
   }
   HIPCHK(ctx, hipMemcpyAsync(c->d_blocks.p, c->h_blocks, sizeof(PccBlock) * c->n_plans, hipMemcpyHostToDevice, ctx->stream));
+  const PccBlock* commit_blocks = c->d_blocks.p;
+  int cur_rows = N;  // rows pcc_cur_kernel's grid is sized for
+  if (dist) {
+    // 1. the delta reference counts of the root tables, summed over the ranks (in place)
+    int32_t tids[PCC_MAX_BLOCKS];
+    int n_t = 0;
+    for (int p = 0; p < c->n_plans; ++p) {
+      const int t = ctx->block[c->plan_block[p]].nodes[0].table;
+      bool seen = false;
+      for (int k = 0; k < n_t; ++k) seen |= tids[k] == t;
+      if (!seen) tids[n_t++] = t;
+    }
+    int rc = pclean_comm_allreduce_stats_queue(ctx, n_t, tids, local_empty ? 1 : 0);
+    if (rc) return rc;
+    // 2. this rank's lists -> its segment; all-gather; the concatenated lists
+    PccSegLayout L{};
+    L.n_plans = c->n_plans;
+    int32_t off = 0;
+    for (int p = 0; p < c->n_plans; ++p) {
+      if (c->cap_m[p] <= 0) c->cap_m[p] = std::max(max_local_rows, 16);  // (first exchange / after a refusal: whatever a shard can hold)
+      if (c->cap_k[p] <= 0) c->cap_k[p] = std::max(max_local_rows, 16);
+      L.off[p] = off;
+      L.cap_m[p] = c->cap_m[p];
+      L.cap_k[p] = c->cap_k[p];
+      L.nn[p] = (int)ctx->block[c->plan_block[p]].nodes.size();
+      off += pcc_seg_words(L.cap_m[p], L.cap_k[p], L.nn[p]);
+    }
+    L.seg_words = off;
+    if (c->seg.alloc((size_t)off) || c->seg_all.alloc((size_t)off * world) || c->g_counts2.alloc(2 * PCC_MAX_BLOCKS) ||
+        c->d_blocks_g.alloc(PCC_MAX_BLOCKS))
+      return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+    if (!c->h_blocks_g) {
+      HIPCHK(ctx, hipHostMalloc((void**)&c->h_blocks_g, sizeof(PccBlock) * PCC_MAX_BLOCKS, hipHostMallocDefault));
+      HIPCHK(ctx, hipHostMalloc((void**)&c->h_g_counts2, sizeof(int32_t) * 2 * PCC_MAX_BLOCKS, hipHostMallocDefault));
+    }
+    PccGathered G{};
+    for (int p = 0; p < c->n_plans; ++p) {
+      const size_t om = (size_t)L.cap_m[p] * world, ok = (size_t)L.cap_k[p] * world;
+      if (c->g_moved[p].alloc(om) || c->g_choice[p].alloc(om) || c->g_new[p].alloc(ok) || c->g_chosen[p].alloc(ok) ||
+          c->g_vals[p].alloc(ok * L.nn[p]))
+        return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+      G.g_moved[p] = c->g_moved[p].p;
+      G.g_choice[p] = c->g_choice[p].p;
+      G.g_new[p] = c->g_new[p].p;
+      G.g_chosen[p] = c->g_chosen[p].p;
+      G.g_vals[p] = c->g_vals[p].p;
+      G.cap_out_m[p] = (int32_t)std::min<size_t>(om, 0x7fffffff);
+      G.cap_out_k[p] = (int32_t)std::min<size_t>(ok, 0x7fffffff);
+      // scratch of the commit kernel: every gathered record
+      if ((size_t)c->kcap[p] < ok) {
+        c->kcap[p] = (int)ok;
+        const int kcap = c->kcap[p];
+        int hsz = 1;
+        while (hsz < 4 * kcap) hsz <<= 1;
+        const PccPlan& pl = c->h_plans[p];
+        if (c->ht[p].alloc(hsz) || c->rep[p].alloc(kcap) || c->flags[p].alloc(kcap) || c->scan[p].alloc(kcap) ||
+            c->base[p].alloc((size_t)kcap * pl.n_used) || c->newid[p].alloc(kcap) || c->recpos[p].alloc(kcap))
+          return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+      }
+    }
+    for (int p = 0; p < c->n_plans; ++p) {  // the gathered-form blocks
+      const int bi = c->plan_block[p];
+      PccBlock& pb = c->h_blocks_g[p];
+      pb = c->h_blocks[p];
+      int hsz = 1;
+      while (hsz < 4 * c->kcap[p]) hsz <<= 1;
+      pb.kcap = c->kcap[p];
+      pb.hmask = hsz - 1;
+      pb.ht = c->ht[p].p;
+      pb.rep = c->rep[p].p;
+      pb.flags = c->flags[p].p;
+      pb.scan = c->scan[p].p;
+      pb.base = c->base[p].p;
+      pb.newid = c->newid[p].p;
+      pb.recpos = c->recpos[p].p;
+      pb.N = ctx->n_rows;
+      pb.row_lo = 0;
+      pb.choice = nullptr;
+      pb.chosen = nullptr;
+      pb.chosen_newpos = nullptr;
+      pb.vals = c->g_vals[p].p;
+      pb.moved_list = c->g_moved[p].p;
+      pb.new_list = c->g_new[p].p;
+      pb.moved_choice = c->g_choice[p].p;
+      pb.rec_chosen = c->g_chosen[p].p;
+      pb.counts2 = c->g_counts2.p + 2 * p;
+      pb.cur = ctx->dev_cur.p + (size_t)bi * ctx->n_rows;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(c->d_blocks_g.p, c->h_blocks_g, sizeof(PccBlock) * c->n_plans, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(c->d_res.p, 0, sizeof(PccResult), ctx->stream));
+    hipLaunchKernelGGL(pcc_pack_kernel, dim3(64, c->n_plans), dim3(256), 0, ctx->stream, L, c->d_blocks.p, local_empty ? 1 : 0,
+                       c->seg.p);
+    rc = pclean_comm_allgather_i32(ctx, c->seg.p, c->seg_all.p, (size_t)L.seg_words);
+    if (rc) return rc;
+    hipLaunchKernelGGL(pcc_merge_kernel, dim3(64, c->n_plans), dim3(256), 0, ctx->stream, L, world, c->seg_all.p, G, c->g_counts2.p,
+                       c->d_res.p);
+    HIPCHK(ctx, hipMemcpyAsync(c->h_g_counts2, c->g_counts2.p, sizeof(int32_t) * 2 * c->n_plans, hipMemcpyDeviceToHost, ctx->stream));
+    commit_blocks = c->d_blocks_g.p;
+    cur_rows = 0;
+    for (int p = 0; p < c->n_plans; ++p) cur_rows = std::max<int64_t>(cur_rows, (int64_t)L.cap_m[p] * world);
+  }
   hipLaunchKernelGGL(pcc_commit_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_tables.p, c->n_slots, c->d_plans.p,
-                     c->d_blocks.p, c->n_plans, c->d_res.p);
-  hipLaunchKernelGGL(pcc_cur_kernel, dim3(std::min(1024, (N + 255) / 256), c->n_plans), dim3(256), 0, ctx->stream, c->d_blocks.p,
-                     c->d_res.p);
+                     commit_blocks, c->n_plans, c->d_res.p, dist ? 1 : 0);
+  hipLaunchKernelGGL(pcc_cur_kernel, dim3(std::max(1, std::min(1024, (cur_rows + 255) / 256)), c->n_plans), dim3(256), 0, ctx->stream,
+                     commit_blocks, c->d_res.p);
   int rc = launch_refresh(ctx, c);
   if (rc) return rc;
   HIPCHK(ctx, hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(PccResult), hipMemcpyDeviceToHost, ctx->stream));
@@ -528,6 +689,16 @@ extern "C" int pclean_commit_device(pclean_ctx* ctx, int32_t n_blocks, uint32_t 
     out->n_distinct[c->plan_block[p]] = c->h_res->n_distinct[p];
     // scratch for the next sweep: twice what this one needed
     if (2 * c->h_res->n_records[p] > c->kcap[p]) c->kcap[p] = 2 * c->h_res->n_records[p];
+    if (dist) {  // the next exchange's segments: twice this commit's GLOBAL totals (known to every rank alike); a refused
+      // commit starts over from what a shard can hold
+      c->cap_m[p] = out->fallback ? 0 : std::max(4096, 2 * c->h_g_counts2[2 * p]);
+      c->cap_k[p] = out->fallback ? 0 : std::max(1024, 2 * c->h_g_counts2[2 * p + 1]);
+    }
+  }
+  if (dist && !out->fallback) {
+    int64_t moved = 0;
+    for (int p = 0; p < c->n_plans; ++p) moved += c->h_g_counts2[2 * p];
+    out->n_changed = (int32_t)moved;
   }
   if (out->fallback) return PCLEAN_OK;
   for (int guard = 0; c->h_sums->lut_overflow && guard < 4; ++guard) {  // a count beyond the log table: rebuild it, redo the priors

@@ -125,6 +125,11 @@ struct PccBlock {  // one block of one sweep: the sweep's outputs (device-reside
   int32_t* base;                 // [kcap][n_used] first allocation index of the record in every used table
   int32_t* newid;                // [kcap] id of the record's root row
   int32_t* recpos;               // [kcap] chosen_newpos[new_list[j]] (filled by phase A)
+  // GATHERED form (several ranks: every rank's lists concatenated in rank order = row order, pcc_pack / pcc_merge; the
+  // per-row arrays choice / chosen / chosen_newpos are null, N = all rows, row_lo = 0, moved_list / new_list hold GLOBAL
+  // rows, record j of new_list is vals + j * nn and cur covers every observed row):
+  const int32_t* moved_choice;   // [n_moved] new referent of moved_list[m]
+  const int32_t* rec_chosen;     // [k] chosen particle of the proposing row of record j
 };
 
 struct PccResult {
@@ -134,6 +139,7 @@ struct PccResult {
   int32_t n_distinct[PCC_MAX_BLOCKS];
   int32_t n_nested[PCC_MAX_BLOCKS];   // distinct proposals with a nested NEW referent
   int32_t alloc_upper[PCC_MAX_SLOTS];  // rows the commit may create per table (before reuse)
+  int32_t fallback_in, pad;      // set by the caller before the commit (pcc_merge: PCC_FB_RECORDS), 0 otherwise
 };
 
 #define PCC_F_FIRST 1
@@ -369,7 +375,7 @@ PCC_FN void pcc_prepare_block(const PccTable* tb, const PccPlan& pl, const PccBl
     return;
   }
   if (k == 0) return;
-  for (int j = tid; j < k; j += nt) b.recpos[j] = b.chosen_newpos[b.new_list[j]];
+  for (int j = tid; j < k; j += nt) b.recpos[j] = b.chosen_newpos ? b.chosen_newpos[b.new_list[j]] : j;
   int hm = b.hmask < 63 ? b.hmask : 63;  // hash table of this sweep: the smallest power of two >= 4 k (at most the scratch's)
   while (hm + 1 < 4 * k && hm < b.hmask) hm = 2 * hm + 1;
   const uint32_t hmask = (uint32_t)hm;
@@ -439,7 +445,7 @@ PCC_FN void pcc_update_cur(const PccBlock& b, int tid, int nt) {
   const int k = b.counts2[1], n_moved = b.counts2[0];
   for (int m = tid; m < n_moved; m += nt) {
     const int r = b.moved_list[m];
-    const int c = b.choice[r];
+    const int c = b.moved_choice ? b.moved_choice[m] : b.choice[r];
     if (c >= 0) b.cur[r] = c;
   }
   for (int j = tid; j < k; j += nt) b.cur[b.new_list[j]] = b.newid[j];
@@ -526,7 +532,7 @@ PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, 
       if (pl.track) {
         t.origin[4 * (size_t)id] = 1 + b.block_id;
         t.origin[4 * (size_t)id + 1] = b.row_lo + obs_row;
-        t.origin[4 * (size_t)id + 2] = b.chosen[obs_row];
+        t.origin[4 * (size_t)id + 2] = b.rec_chosen ? b.rec_chosen[j] : b.chosen[obs_row];
         t.origin[4 * (size_t)id + 3] = b.sweep_idx;
       } else if (!(fl & PCC_F_SIMPLE)) {
         t.origin[4 * (size_t)id] = -1;
@@ -570,16 +576,110 @@ PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, 
   PCC_STAMP("collect");
 }
 
+// ---- several ranks: every rank's moved rows and new-row records, concatenated in rank order ----------------------------
+// Rows are block-partitioned over the ranks (contiguous shards, ascending), so rank order IS row order: the concatenation of
+// the ranks' ascending lists is the ascending global list the one-rank commit works on (SURVEY §8e "second exchange").
+// A rank's SEGMENT of the all-gather buffer holds, per plan p (PccSegLayout): a 4-word header (moved rows, new-row records
+// of the rank, 0, 0), moved rows [cap_m] (GLOBAL row ids), their new referents [cap_m], proposing rows [cap_k] (global),
+// their chosen particles [cap_k], the records [cap_k][nn].  A rank with more entries than a capacity still reports its true
+// counts: pcc_merge then refuses the commit (PCC_FB_RECORDS) on every rank alike, before anything is modified.
+struct PccSegLayout {
+  int32_t n_plans, seg_words;            // words of one rank's segment
+  int32_t off[PCC_MAX_BLOCKS];           // first word of plan p inside a segment
+  int32_t cap_m[PCC_MAX_BLOCKS], cap_k[PCC_MAX_BLOCKS], nn[PCC_MAX_BLOCKS];
+};
+static inline int32_t pcc_seg_words(int cap_m, int cap_k, int nn) { return 4 + 2 * cap_m + 2 * cap_k + cap_k * nn; }  // (host side)
+
+// this rank's lists of plan p (per-row form of the block: choice / chosen / chosen_newpos given) -> its segment.
+// empty != 0: the rank swept no row of the window (its sweep buffers hold an older sweep): header zero.
+PCC_FN void pcc_pack(const PccSegLayout& L, int p, const PccBlock& b, int empty, int32_t* seg, int tid, int nt) {
+  int32_t* o = seg + L.off[p];
+  const int cm = L.cap_m[p], ck = L.cap_k[p], nn = L.nn[p];
+  const int n_moved = empty ? 0 : b.counts2[0], k = empty ? 0 : b.counts2[1];
+  if (tid == 0) {
+    o[0] = n_moved;
+    o[1] = k;
+    o[2] = o[3] = 0;
+  }
+  int32_t* mrow = o + 4;
+  int32_t* mch = mrow + cm;
+  int32_t* nrow = mch + cm;
+  int32_t* nchs = nrow + ck;
+  int32_t* rec = nchs + ck;
+  const int nm = n_moved < cm ? n_moved : cm, nk = k < ck ? k : ck;
+  for (int m = tid; m < nm; m += nt) {
+    const int r = b.moved_list[m];
+    mrow[m] = b.row_lo + r;
+    mch[m] = b.choice[r];
+  }
+  for (int j = tid; j < nk; j += nt) {
+    const int r = b.new_list[j];
+    nrow[j] = b.row_lo + r;
+    nchs[j] = b.chosen[r];
+  }
+  for (int x = tid; x < nk * nn; x += nt) {
+    const int j = x / nn, c = x - j * nn;
+    rec[x] = b.vals[(size_t)b.chosen_newpos[b.new_list[j]] * nn + c];
+  }
+}
+
+// the gathered lists of plan p from the n_ranks segments of `all` (rank r's segment at all + r * L.seg_words):
+// g_moved / g_choice [sum of moved], g_new / g_chosen [sum of records], g_vals [.][nn], counts2[2] = the totals;
+// *fallback |= PCC_FB_RECORDS when a rank's lists did not fit its segment (or the totals do not fit cap_out_*)
+PCC_FN void pcc_merge(const PccSegLayout& L, int p, int n_ranks, const int32_t* all, int cap_out_m, int cap_out_k,
+                      int32_t* g_moved, int32_t* g_choice, int32_t* g_new, int32_t* g_chosen, int32_t* g_vals, int32_t* counts2,
+                      int32_t* fallback, int tid, int nt) {
+  const int cm = L.cap_m[p], ck = L.cap_k[p], nn = L.nn[p];
+  int tot_m = 0, tot_k = 0;
+  bool bad = false;
+  for (int r = 0; r < n_ranks; ++r) {
+    const int32_t* o = all + (size_t)r * L.seg_words + L.off[p];
+    bad |= o[0] > cm || o[1] > ck || o[0] < 0 || o[1] < 0;
+    tot_m += o[0];
+    tot_k += o[1];
+  }
+  bad |= tot_m > cap_out_m || tot_k > cap_out_k;
+  if (tid == 0) {
+    counts2[0] = bad ? 0 : tot_m;
+    counts2[1] = bad ? 0 : tot_k;
+    if (bad) PCC_OR32(fallback, PCC_FB_RECORDS);
+  }
+  if (bad) return;
+  int base_m = 0, base_k = 0;
+  for (int r = 0; r < n_ranks; ++r) {
+    const int32_t* o = all + (size_t)r * L.seg_words + L.off[p];
+    const int32_t* mrow = o + 4;
+    const int32_t* mch = mrow + cm;
+    const int32_t* nrow = mch + cm;
+    const int32_t* nchs = nrow + ck;
+    const int32_t* rec = nchs + ck;
+    const int nm = o[0], nk = o[1];
+    for (int m = tid; m < nm; m += nt) {
+      g_moved[base_m + m] = mrow[m];
+      g_choice[base_m + m] = mch[m];
+    }
+    for (int j = tid; j < nk; j += nt) {
+      g_new[base_k + j] = nrow[j];
+      g_chosen[base_k + j] = nchs[j];
+    }
+    for (int x = tid; x < nk * nn; x += nt) g_vals[(size_t)base_k * nn + x] = rec[x];
+    base_m += nm;
+    base_k += nk;
+  }
+}
+
 // ---- the whole commit ------------------------------------------------------------------------------------------------
 PCC_FN void pcc_commit(PccTable* tb, int n_slots, const PccPlan* plans, const PccBlock* blocks, int n_blocks, PccResult* res,
                        int32_t* part, int tid, int nt) {
   if (tid == 0) {
-    res->fallback = 0;
+    res->fallback = res->fallback_in;  // (what pcc_merge found wrong with the gathered lists; 0 on one rank)
     res->n_changed = 0;
     for (int s = 0; s < PCC_MAX_SLOTS; ++s) res->alloc_upper[s] = 0;
+    for (int bi = 0; bi < PCC_MAX_BLOCKS; ++bi) res->n_records[bi] = res->n_distinct[bi] = res->n_nested[bi] = 0;
   }
   PCC_BARRIER();
   PCC_STAMP("start");
+  if (res->fallback) return;
   for (int bi = 0; bi < n_blocks; ++bi) {
     pcc_prepare_block(tb, plans[bi], blocks[bi], bi, res, tid, nt);
     PCC_STAMP("prepare");

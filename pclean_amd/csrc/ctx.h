@@ -222,7 +222,7 @@ struct pclean_ctx {
   void* sweep_state = nullptr;  // owned by sweep.hip
   void* rccl_comm = nullptr;    // ncclComm_t of pclean_comm_init (comm.hip)
   DevBuf<int64_t> stats_pack;   // pclean_allreduce_stats_fused: the tables' delta counts as one vector
-  int32_t comm_ranks = 0;
+  int32_t comm_ranks = 0, comm_rank = 0;
 };
 
 inline int pclean_fail(pclean_ctx* ctx, int code, const char* fmt, ...) {
@@ -254,3 +254,6 @@ int pclean_ensure_density(pclean_ctx* ctx, int max_len);
 void pclean_sweep_state_free(pclean_ctx* ctx);
 // commit.hip
 void pclean_commit_state_free(pclean_ctx* ctx);
+// comm.hip: collectives queued on the library's stream (no synchronisation)
+int pclean_comm_allreduce_stats_queue(pclean_ctx* ctx, int32_t n_tables, const int32_t* table_ids, int32_t local_is_zero);
+int pclean_comm_allgather_i32(pclean_ctx* ctx, const int32_t* send, int32_t* recv, size_t words_per_rank);

@@ -1002,12 +1002,14 @@ static int ensure_tuple_ids(pclean_ctx* ctx, int block_id, int node_id, const st
 // the table index is hash(referent, pre-filter values) * HG_BUCKET + (hash(tuple, ctx) mod HG_BUCKET), so groups that
 // share the referent and the pre-filter rows sit next to each other (root_wave.hip reuses the previous group's survivor
 // list).  PCLEAN_SORT_GROUPS=1: the radix-sort path below.
-#define HG_BUCKET 16
+#define HG_WBITS 12   // slots per window: 4096
+#define HG_INWIN 32   // probes inside the window before a key goes looking elsewhere
 struct HashGroupDev {
   int32_t* rep;        // [cap] 0: empty, else representative item + 1
   unsigned int* cnt;   // [cap] members so far (null: group ids only)
   uint32_t mask;       // cap - 1
   int32_t split_m;
+  uint32_t wbits;      // log2 of the window size (at most the table)
 };
 __device__ __forceinline__ bool hg_same_key(const KeyColsDev& kc, const int32_t* row, const int32_t* ctxv, const int32_t* excl,
                                             int a, int b) {
@@ -1023,13 +1025,20 @@ __device__ __forceinline__ bool hg_same_key(const KeyColsDev& kc, const int32_t*
   if (same && excl) same = excl[a] == excl[b];
   return same;
 }
+// probe sequence of a key: HG_INWIN slots of its family's window (the window is chosen by hash(referent, pre-filter values),
+// the start inside it by hash(tuple, ctx): a family's groups sit in one window, spread evenly — a family of thousands of
+// groups neither piles up behind one bucket nor loses its neighbourhood), then linear probing from a uniform position
+__device__ __forceinline__ uint32_t hg_slot(uint32_t base, uint32_t pos0, uint32_t alt, uint32_t wmask, uint32_t mask, int t) {
+  return t < HG_INWIN ? base + ((pos0 + (uint32_t)t) & wmask) : (alt + (uint32_t)(t - HG_INWIN)) & mask;
+}
 __global__ __launch_bounds__(256) void hg_insert_kernel(int n, KeyColsDev kc, const int32_t* __restrict__ row,
                                                         const int32_t* __restrict__ ctxv, const int32_t* __restrict__ excl,
                                                         HashGroupDev hg, int32_t* __restrict__ slot_of,
                                                         int32_t* __restrict__ pos_of) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const bool on = i < n;
-  uint32_t slot = 0;
+  uint32_t base = 0, pos0 = 0, alt = 0;
   if (on) {
     const int r = row ? row[i] : i;
     uint64_t h = 0x2545f4914f6cdd1dull;
@@ -1039,6 +1048,7 @@ __global__ __launch_bounds__(256) void hg_insert_kernel(int n, KeyColsDev kc, co
       for (int c = 0; c < kc.n_cols; ++c) h = mix64(h, (uint32_t)kc.col[c][r]);
     if (kc.use_ctx && ctxv)
       for (int s = 0; s < PCLEAN_MAX_CTX; ++s) h = mix64(h, (uint32_t)ctxv[(size_t)i * PCLEAN_MAX_CTX + s]);
+    if (excl) h = mix64(h, (uint32_t)excl[i]);
     uint64_t hp = 0x9e3779b97f4a7c15ull;
     if (kc.pre_hash)
       hp = mix64(hp, kc.pre_hash[r]);
@@ -1046,32 +1056,52 @@ __global__ __launch_bounds__(256) void hg_insert_kernel(int n, KeyColsDev kc, co
       for (int c = 0; c < kc.n_pre; ++c) hp = mix64(hp, (uint32_t)kc.pre_col[c][r]);
     if (excl) hp = mix64(hp, (uint32_t)excl[i]);
     if (kc.n_pre == 0 && !excl) hp = h;  // nothing to keep adjacent: plain hashing
-    slot = (uint32_t)(((hp >> 24) * HG_BUCKET + ((h >> 40) & (HG_BUCKET - 1))) & hg.mask);
-    for (;;) {
-      int cur = hg.rep[slot];  // (a stale zero only costs the compare-and-swap below, which returns the truth)
-      if (cur == 0) {
-        cur = atomicCAS(&hg.rep[slot], 0, i + 1);
-        if (cur == 0) break;  // claimed: this item represents the group
-      }
-      if (cur - 1 == i || hg_same_key(kc, row, ctxv, excl, i, cur - 1)) break;
-      slot = (slot + 1) & hg.mask;
-    }
-    slot_of[i] = (int32_t)slot;
+    base = ((uint32_t)(hp >> 24) & (hg.mask >> hg.wbits)) << hg.wbits;
+    pos0 = (uint32_t)(h >> 40);
+    alt = (uint32_t)(h >> 8) & hg.mask;
   }
+  const uint32_t wmask = (1u << hg.wbits) - 1u;
+  // Claim or join a slot.  Wave-uniform loop: of the lanes that meet an EMPTY slot in a round, one per distinct slot tries
+  // the compare-and-swap, the others look again in the next round (10^5 rows of one popular key would otherwise all
+  // find the slot empty at the start of the launch and queue 10^5 atomics on one address).
+  bool active = on;
+  int t = 0;
+  uint32_t slot = hg_slot(base, pos0, alt, wmask, hg.mask, 0);
+  while (__ballot(active)) {
+    int cur = -1;
+    if (active) cur = __hip_atomic_load(&hg.rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool need = active && cur == 0;
+    bool elected = false;
+    for (unsigned long long pend = __ballot(need); pend;) {
+      const int ld = __builtin_ctzll(pend);
+      const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slot, ld);
+      if (lane == ld) elected = true;
+      pend &= ~__ballot(need && slot == sl);
+    }
+    if (elected) cur = atomicCAS(&hg.rep[slot], 0, i + 1);  // (0: claimed; else: somebody else's item, looked at below)
+    if (need && !elected) continue;                           // the elected lane of this slot decides; look again
+    if (active) {
+      if (cur == 0 || cur - 1 == i || hg_same_key(kc, row, ctxv, excl, i, cur - 1)) {
+        active = false;
+      } else {
+        ++t;
+        slot = hg_slot(base, pos0, alt, wmask, hg.mask, t);
+      }
+    }
+  }
+  if (on) slot_of[i] = (int32_t)slot;
   if (!hg.cnt) return;
   // position within the group: the lanes of this wavefront that share a slot take consecutive positions from ONE atomic
-  // (a popular key — 10^5 rows observing the same clean string — would otherwise serialise 10^5 atomics on one address)
-  const int lane = threadIdx.x & 63;
   unsigned long long todo = __ballot(on);
   int pos = 0;
   while (todo) {
     const int leader = __builtin_ctzll(todo);
     const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slot, leader);
     const unsigned long long same = __ballot(on && slot == sl) & todo;
-    unsigned int base = 0;
-    if (lane == leader) base = atomicAdd(&hg.cnt[sl], (unsigned int)__popcll(same));
-    base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
-    if ((same >> lane) & 1ull) pos = (int)base + __popcll(same & ((1ull << lane) - 1ull));
+    unsigned int bse = 0;
+    if (lane == leader) bse = atomicAdd(&hg.cnt[sl], (unsigned int)__popcll(same));
+    bse = (unsigned int)__builtin_amdgcn_readlane((int)bse, leader);
+    if ((same >> lane) & 1ull) pos = (int)bse + __popcll(same & ((1ull << lane) - 1ull));
     todo &= ~same;
   }
   if (on) pos_of[i] = pos;
@@ -1142,7 +1172,9 @@ static int make_item_groups_hash(pclean_ctx* ctx, const ItemList& il, const int3
   HIPCHK(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, tmp_scan2, in_packed, incl, (int)cap, ctx->stream));
   unsigned char* tmp = scratch<unsigned char>(ctx, std::max<size_t>(std::max(tmp_scan, tmp_scan2), 16));
   if (!rep || !incl || !slot_of || (want_members && !pos_of) || !tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-  HashGroupDev hg{rep, want_members ? (unsigned int*)(rep + cap) : nullptr, cap - 1, split_m};
+  uint32_t wbits = HG_WBITS;
+  while ((1u << wbits) > cap) --wbits;
+  HashGroupDev hg{rep, want_members ? (unsigned int*)(rep + cap) : nullptr, cap - 1, split_m, wbits};
   HIPCHK(ctx, hipMemsetAsync(rep, 0, (size_t)cap * (want_members ? 2 : 1) * sizeof(int32_t), ctx->stream));
   hipLaunchKernelGGL(hg_insert_kernel, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, hg, slot_of, pos_of);
   int32_t n_unique = 0;

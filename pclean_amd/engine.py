@@ -352,7 +352,15 @@ class Engine:
             return True
         if getattr(self, "_dc_refused", False):
             return False
-        if (comm is not None and comm.world > 1) or self.row_offset:
+        self._dc_dist = False
+        if comm is not None and (comm.world > 1 or (getattr(self, "_dev_comm", False) and os.environ.get("PCLEAN_FORCE_DIST"))):
+            # several ranks: every rank's moved rows and new-row records are all-gathered on the device and the same commit
+            # kernel runs everywhere (pclean_commit_device_dist) — needs the library's own RCCL communicator
+            if not getattr(self, "_dev_comm", False) or os.environ.get("PCLEAN_DIST_HOST_COMMIT"):
+                self._dc_refused = True
+                return False
+            self._dc_dist = True
+        if self.row_offset:
             self._dc_refused = True
             return False
         lw = self.lw
@@ -375,7 +383,7 @@ class Engine:
             self.hip.set_cur(trace._cur)
             dc["cur_version"] = (id(trace), trace._cur_version)
 
-    def sweep_commit_device(self, trace, config, seed, sweep_idx, lo=0, hi=None):
+    def sweep_commit_device(self, trace, config, seed, sweep_idx, lo=0, hi=None, comm=None, window=None):
         """One batched sweep of the observed rows [lo, hi) against the device-resident tables AND its commit on the
         device: ONE stream synchronisation, a summary comes back.  Returns the number of rows whose referent changed,
         or None when the device refused the commit (nothing was modified; the sweep's outputs are on the host as after
@@ -389,12 +397,20 @@ class Engine:
             self._sync_cur(trace)
         elif trace._dev is not self:
             raise _lib.PCleanHipError("the trace is ahead on another engine")
-        self._empty_sweep = False
-        self.hip.set_active_rows(lo, hi - lo)
+        dist = getattr(self, "_dc_dist", False)
+        local_empty = hi <= lo  # (several ranks: a rank may own no row of a small window; it still takes part in the exchange)
+        self._empty_sweep = local_empty
         self.hip.set_sweep_mode(True)
         try:
-            self.hip.sweep_device_cur(cfg, seed, sweep_idx, len(self.lw.blocks))
-            summ = self.hip.commit_device(len(self.lw.blocks), sweep_idx)
+            if not local_empty:
+                self.hip.set_active_rows(lo, hi - lo)
+                self.hip.sweep_device_cur(cfg, seed, sweep_idx, len(self.lw.blocks))
+            if dist:
+                world = comm.world if comm is not None else 1
+                b0, b1 = window if window is not None else (lo, hi)
+                summ = self.hip.commit_device_dist(len(self.lw.blocks), sweep_idx, local_empty, -(-(b1 - b0) // world))
+            else:
+                summ = self.hip.commit_device(len(self.lw.blocks), sweep_idx)
         finally:
             self.hip.set_sweep_mode(False)
         dc["commits"] += 1
@@ -402,7 +418,10 @@ class Engine:
         if summ.fallback:
             dc["fallbacks"] += 1
             dc["last_fallback"] = int(summ.fallback)
-            self.hip.sweep_fetch()
+            if not local_empty:
+                self.hip.sweep_fetch()
+            # (several ranks: the delta reference counts in the device buffers are already summed over the ranks)
+            self._stats_reduced_on_device = dist
             return None  # (a table about to outgrow its capacity gets more room at the next upload: upload_trace)
         if os.environ.get("PCLEAN_DEBUG_COMMIT"):
             print("[pclean] device commit: changed", summ.n_changed, "records", list(summ.n_records[:len(self.lw.blocks)]),
@@ -416,7 +435,13 @@ class Engine:
             dc["created"][c] = max(grown, dc["created"].get(c, 0) // 2)
             dc["alloc"][c] = (int(sl.n_hw), int(sl.n_free))
         for bi in lw_locals(self.lw):  # own enumerated choices of the chosen particles: host-owned (parameter moves read them)
-            trace._locals[bi][lo:hi] = self.hip.get_locals(bi, hi - lo)
+            loc = self.hip.get_locals(bi, hi - lo) if not local_empty else np.zeros((0, 2), dtype=np.int32)
+            if dist and comm is not None and comm.world > 1:  # every rank learns all of them (rank order = row order)
+                b0 = window[0] if window is not None else lo
+                loc = comm.allgather_varlen_i32(np.ascontiguousarray(loc, dtype=np.int32)).reshape(-1, 2)
+                trace._locals[bi][b0:b0 + len(loc)] = loc
+            else:
+                trace._locals[bi][lo:hi] = loc
         trace._dev = self
         return int(summ.n_changed)
 
@@ -424,6 +449,10 @@ class Engine:
         """new-row records of the last sweep once its outputs are on the host (a refused device commit: pclean_sweep_fetch
         ran) — what sweep(..., light=True) returns as new_rows; own enumerated choices go to trace.pending_locals"""
         new_rows = {}
+        if getattr(self, "_empty_sweep", False):  # (several ranks: this rank swept no row of the window)
+            for bi in lw_locals(self.lw):
+                trace.pending_locals[bi] = np.zeros((0, 2), dtype=np.int32)
+            return new_rows
         for bi, blk in enumerate(self.lw.blocks):
             if blk.get("score"):
                 continue
@@ -521,6 +550,10 @@ class Engine:
         if not getattr(self, "_dev_comm", False):
             return None
         blocks = [bi for bi, blk in enumerate(self.lw.blocks) if not blk.get("score")]
+        if getattr(self, "_stats_reduced_on_device", False):  # a refused pclean_commit_device_dist already summed them in place
+            self._stats_reduced_on_device = False
+            return {bi: self.hip.get_stats(self.lw.table_id[self.lw.blocks[bi]["root_class"]],
+                                           trace.tables[self.lw.blocks[bi]["root_class"]].n) for bi in blocks}
         tids = [self.lw.table_id[self.lw.blocks[bi]["root_class"]] for bi in blocks]
         ns = [trace.tables[self.lw.blocks[bi]["root_class"]].n for bi in blocks]
         # a rank that swept nothing contributes zeros (its device buffers hold stale counts)

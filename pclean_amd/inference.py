@@ -497,11 +497,14 @@ def _sweep_window(engine, trace, config, seed, sweep_idx, b0, b1, comm):
     lo, hi = lo + b0, hi + b0
     light = hasattr(engine, "sweep_moved")  # the HIP engine reports the moved rows: no per-row outputs needed
     fetched = False
-    if hi > lo and DEVICE_COMMIT and hasattr(engine, "enable_device_commit") and engine.enable_device_commit(trace, comm):
+    if (hi > lo or comm.world > 1) and DEVICE_COMMIT and hasattr(engine, "enable_device_commit") and \
+            engine.enable_device_commit(trace, comm):
         # the sweep AND its commit on the device (csrc/commit.hip): tables, counts and referents stay in HBM, the host
-        # arrays of the trace fall behind until something reads them (Trace._sync)
+        # arrays of the trace fall behind until something reads them (Trace._sync).  Several ranks: every rank's moved
+        # rows and new-row records are all-gathered in HBM and the same commit kernel runs everywhere (collective: a
+        # rank that owns no row of the window takes part with empty lists)
         with _timed("observed/device_sweep_commit"):
-            changed = engine.sweep_commit_device(trace, config, seed, sweep_idx, lo, hi)
+            changed = engine.sweep_commit_device(trace, config, seed, sweep_idx, lo, hi, comm=comm, window=(b0, b1))
         if changed is not None:
             # (no created row holds a ProposalDummyValue — the device refuses such commits — so resample_dummies has
             # nothing to draw; the commit still counts for the draw streams of later ones)

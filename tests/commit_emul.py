@@ -144,6 +144,79 @@ class EmulatedDevice:
                 tb["origin"][:] = 0
         return int(res[0]), int(res[1]), res[2:18].copy(), res[18:34].copy()
 
+    def commit_gathered(self, shards, stats, sweep_idx, cap_m=None, cap_k=None):
+        """The commit of a sweep whose rows were sharded over len(shards) ranks (pclean_commit_device_dist: pcc_pack per rank,
+        the segments side by side, pcc_merge, the commit in its gathered form).  shards: [(lo, hi, choice [n_blocks][hi - lo],
+        chosen [hi - lo], new_rows {block: (rows relative to lo, vals)})], contiguous and ascending; stats {block: delta counts
+        summed over the shards}.  Returns what commit() returns."""
+        lw = self.lw
+        R, P = len(shards), len(self.plans)
+        keep = []
+        rp = {k: np.zeros(R * P, dtype=np.int64) for k in ("choice", "newpos", "vals", "moved", "newl", "counts2")}
+        chosen_p = np.zeros(R, dtype=np.int64)
+        N_r = np.array([hi - lo for lo, hi, *_ in shards], dtype=np.int32)
+        lo_r = np.array([lo for lo, *_ in shards], dtype=np.int32)
+        empty_r = (N_r == 0).astype(np.int32)
+        nn = np.array([len(lw.blocks[bi]["nodes"]) for bi in self.plans], dtype=np.int32)
+        max_m = np.zeros(P, dtype=np.int32)
+        max_k = np.zeros(P, dtype=np.int32)
+        for r, (lo, hi, choice, chosen, new_rows) in enumerate(shards):
+            n = hi - lo
+            ch_all = np.ascontiguousarray(chosen, dtype=np.int32) if n else np.zeros(1, np.int32)
+            keep.append(ch_all)
+            chosen_p[r] = ch_all.ctypes.data
+            for p, bi in enumerate(self.plans):
+                ch = np.ascontiguousarray(choice[bi], dtype=np.int32) if n else np.zeros(1, np.int32)
+                rows, vals = new_rows.get(bi, (np.zeros(0, np.int32), np.zeros((0, nn[p]), np.int32)))
+                rows = np.ascontiguousarray(rows, dtype=np.int32)
+                vals = np.ascontiguousarray(np.array(vals, dtype=np.int32).reshape(-1, nn[p]))
+                perm = np.random.default_rng(bi + 17 + r).permutation(len(rows))
+                store = np.ascontiguousarray(vals[perm]) if len(rows) else np.zeros((1, nn[p]), np.int32)
+                newpos = np.full(max(n, 1), -1, dtype=np.int32)
+                inv = np.empty(len(rows), dtype=np.int32)
+                inv[perm] = np.arange(len(rows), dtype=np.int32)
+                newpos[rows] = inv
+                moved = np.flatnonzero(ch[:n] != self.cur[bi][lo:hi]).astype(np.int32) if n else np.zeros(0, np.int32)
+                counts2 = np.array([len(moved), len(rows)], dtype=np.int32)
+                max_m[p] = max(max_m[p], len(moved))
+                max_k[p] = max(max_k[p], len(rows))
+                for k, a in (("choice", ch), ("newpos", newpos), ("vals", store), ("moved", moved if len(moved) else np.zeros(1, np.int32)),
+                             ("newl", rows if len(rows) else np.zeros(1, np.int32)), ("counts2", counts2)):
+                    keep.append(a)
+                    rp[k][r * P + p] = a.ctypes.data
+        cap_m = np.maximum(max_m, 4).astype(np.int32) if cap_m is None else np.full(P, cap_m, dtype=np.int32)
+        cap_k = np.maximum(max_k, 4).astype(np.int32) if cap_k is None else np.full(P, cap_k, dtype=np.int32)
+        cur_p = np.zeros(P, dtype=np.int64)
+        delta_p = np.zeros(P, dtype=np.int64)
+        for p, bi in enumerate(self.plans):
+            cap = self.tab[lw.blocks[bi]["root_class"]]["cap"]
+            delta = np.zeros(cap, dtype=np.int64)
+            d = np.asarray(stats[bi], dtype=np.int64)
+            delta[:len(d)] = d
+            keep.append(delta)
+            delta_p[p] = delta.ctypes.data
+            assert self.cur[bi].flags.c_contiguous
+            cur_p[p] = self.cur[bi].ctypes.data
+        res = np.zeros(34, dtype=np.int32)
+        rc = self.L.pcch_commit_gathered(self.h, R, int(self.cur.shape[1]), int(sweep_idx), C.c_void_p(_ptr(N_r)), C.c_void_p(_ptr(lo_r)),
+                                         C.c_void_p(_ptr(empty_r)), C.c_void_p(_ptr(nn)), C.c_void_p(_ptr(cap_m)), C.c_void_p(_ptr(cap_k)),
+                                         C.c_void_p(_ptr(rp["choice"])), C.c_void_p(_ptr(chosen_p)), C.c_void_p(_ptr(rp["newpos"])),
+                                         C.c_void_p(_ptr(rp["vals"])), C.c_void_p(_ptr(rp["moved"])), C.c_void_p(_ptr(rp["newl"])),
+                                         C.c_void_p(_ptr(rp["counts2"])), C.c_void_p(_ptr(cur_p)), C.c_void_p(_ptr(delta_p)),
+                                         C.c_void_p(_ptr(res)))
+        assert rc == 0
+        if not res[0]:
+            for cname, tb in self.tab.items():
+                for r in np.flatnonzero(tb["origin"][:, 0]):
+                    mark = int(tb["origin"][r, 0])
+                    if mark > 0:
+                        self.row_origin[(cname, int(r))] = (int(tb["origin"][r, 1]), int(tb["origin"][r, 2]), int(tb["origin"][r, 3]),
+                                                            mark - 1)
+                    else:
+                        self.row_origin.pop((cname, int(r)), None)
+                tb["origin"][:] = 0
+        return int(res[0]), int(res[1]), res[2:18].copy(), res[18:34].copy()
+
     def assert_equals_trace(self, trace, what=""):
         """the emulated device state == the host trace after the host commit of the same sweeps"""
         for cname, tb in self.tab.items():

@@ -257,3 +257,76 @@ def test_commit_core_refuses_chosen_dummies(oracle):
         assert np.array_equal(dev.cur, before[1])
     finally:
         dev.close()
+
+
+def _sharded_sweep(eng, tr, cfg, seed, sweep, bounds):
+    """the same sweep, its rows block-partitioned over `bounds` = [(lo, hi)] (frozen tables: a shard's outputs do not depend
+    on who else sweeps): per shard (lo, hi, choice, chosen, new_rows); plus the whole window's outputs for the host commit"""
+    shards, nb = [], tr.cur.shape[0]
+    for lo, hi in bounds:
+        if hi <= lo:
+            shards.append((lo, hi, np.zeros((nb, 0), np.int32), np.zeros(0, np.int32), {}))
+            continue
+        choice, chosen, logml, new_rows = eng.sweep(tr, cfg, seed, sweep, lo, hi)
+        shards.append((lo, hi, choice.copy(), chosen.copy(), {b: (np.asarray(r).copy(), np.asarray(v).copy()) for b, (r, v) in new_rows.items()}))
+    choice = np.concatenate([s[2] for s in shards], axis=1)
+    chosen = np.concatenate([s[3] for s in shards])
+    new_rows = {}
+    for lo, hi, _, _, nr in shards:
+        for b, (r, v) in nr.items():
+            pr, pv = new_rows.get(b, (np.zeros(0, np.int32), np.zeros((0, v.shape[1]), np.int32)))
+            new_rows[b] = (np.concatenate([pr, (r + lo).astype(np.int32)]), np.concatenate([pv, v]))
+    return shards, choice, chosen, new_rows
+
+
+@pytest.mark.parametrize("program", ["hospital", "rents"])
+def test_commit_core_gathered_form_equals_single_rank(oracle, program):
+    """Several ranks (pclean_commit_device_dist): every rank's moved rows and new-row records packed into its segment
+    (pcc_pack), the segments side by side as the all-gather leaves them, concatenated (pcc_merge), then the SAME commit over
+    the concatenation — equal to the host commit of the whole window (= the one-rank commit) after every sweep, with shards
+    of unequal size and one rank that owns no row; a segment too small for a rank's lists refuses the commit on every rank."""
+    if program == "hospital":
+        S = helpers.hospital_setup(n_rows=400)
+        lw, obs = S["lw"], S["obs"]
+        tr = Trace(lw, obs.shape[1], 1)
+        cfg = InferenceConfig(1, 6)
+        initialize_trace(OracleEngine(oracle, lw, obs), tr, cfg, 11, max_batch=64)
+    else:
+        R = helpers.rents_setup(n_rows=600)
+        lw, obs, tr = R["lw"], R["obs"], R["trace"]
+        cfg = InferenceConfig(1, 4)
+    eng = OracleEngine(oracle, lw, obs)
+    n = obs.shape[1]
+    dev = commit_emul.EmulatedDevice(lw, tr, slack=4096)
+    assert dev.supported, dev.why
+    created = 0
+    try:
+        for sweep, cuts in enumerate(([0, n // 3, n // 3, n], [0, n // 2, n], [0, 1, n - 1, n], [0, n])):
+            bounds = list(zip(cuts[:-1], cuts[1:]))
+            shards, choice, chosen, new_rows = _sharded_sweep(eng, tr, cfg, 31, sweep, bounds)
+            stats, moved = _stats_and_moved(lw, tr, choice)
+            if sweep == 1 and sum(len(r) for r, _ in new_rows.values()) + sum(len(m[0]) for m in moved.values()) > 8:
+                before = copy.deepcopy(dev.tab), dev.cur.copy()
+                fb, _, _, _ = dev.commit_gathered(shards, stats, sweep, cap_m=1, cap_k=1)  # segments that hold one entry
+                assert fb & 1, fb  # PCC_FB_RECORDS
+                for c, tb in dev.tab.items():
+                    for k in ("cols", "counts", "live", "free"):
+                        assert np.array_equal(tb[k], before[0][c][k]), (c, k)
+                assert np.array_equal(dev.cur, before[1])
+            fb, n_changed, nrec, ndist = dev.commit_gathered(shards, stats, sweep)
+            assert fb == 0, fb
+            eng_locals = dict(tr.pending_locals)
+            tr.pending_locals = {}
+            changed = exchange_and_commit(tr, lw, Comm(), 0, choice, stats, new_rows, global_cur=True, moved_local=moved,
+                                          n_local=n, sweep_idx=sweep)
+            tr.pending_locals = eng_locals
+            if program != "rents":  # (the shards' own choices are not reassembled here: the trace keeps its old ones)
+                tr.commit_locals()
+            else:
+                tr.pending_locals = {}
+            assert changed == n_changed, (sweep, changed, n_changed)
+            dev.assert_equals_trace(tr, f"sweep {sweep} over {len(bounds)} shards")
+            created += sum(int(tb["state"][3]) for tb in dev.tab.values())
+    finally:
+        dev.close()
+    assert program != "hospital" or created > 0

@@ -197,3 +197,37 @@ def test_device_commit_capacity_refusal_and_regrowth():
     finally:
         eng.close()
         ref.close()
+
+
+@pytest.mark.parametrize("program", ["hospital", "synthetic", "rents"])
+def test_device_commit_through_the_rank_exchange_equals_plain_device_commit(program, monkeypatch):
+    """pclean_commit_device_dist — the commit of several ranks: delta counts all-reduced in place, every rank's moved rows
+    and new-row records packed, all-gathered (RCCL) and concatenated on the device, the commit kernel over the gathered
+    lists — on a ONE-rank communicator (all a 1-GPU box can run; the gathered form itself is held against the host commit
+    with several shards by tests/test_commit_core.py) == the plain one-rank device commit, state for state, sweep after
+    sweep; including the capacities of the exchange segments adapting between sweeps."""
+    name, lw, obs, tr0, cfg, n_sweeps = next(p for p in _programs() if p[0] == program)
+    plain = Engine(lw, obs, dist_mode=_lib.DIST_DL)
+    dist = Engine(lw, obs, dist_mode=_lib.DIST_DL)
+    try:
+        if tr0 is None:
+            tr0 = Trace(lw, obs.shape[1], 1)
+            inf.initialize_trace(plain, tr0, cfg, 11, max_batch=64 if name == "hospital" else 4096)
+        a, b = copy.deepcopy(tr0), copy.deepcopy(tr0)
+        for t in list(a.tables.values()) + list(b.tables.values()):
+            t.cols_dirty = True
+        dist.hip.comm_init(1, 0, dist.hip.comm_unique_id())
+        dist._dev_comm = True
+        monkeypatch.setenv("PCLEAN_FORCE_DIST", "1")
+        n = obs.shape[1]
+        for sweep in range(n_sweeps + 2):
+            ca = inf._sweep_window(plain, a, cfg, 42, sweep, 0, n, Comm())
+            cb = inf._sweep_window(dist, b, cfg, 42, sweep, 0, n, Comm())
+            assert ca == cb, (name, sweep, ca, cb)
+            _same_state(a, b, f"{name} sweep {sweep}: exchange path vs plain device commit")
+        assert getattr(dist, "_dc_dist", False) and dist._dc["commits"] == plain._dc["commits"], (dist._dc, plain._dc)
+        assert dist._dc["fallbacks"] == plain._dc["fallbacks"], (dist._dc, plain._dc)
+        print(f"[dist commit] {name}: {dist._dc['commits']} commits through the exchange, {dist._dc['fallbacks']} refused")
+    finally:
+        plain.close()
+        dist.close()
