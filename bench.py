@@ -155,11 +155,16 @@ def roofline_model(rs, obs_local, particles):
             distinct += int(np.unique(obs_local[col]).size)
     # (descriptor: written by group_desc_kernel, read by the scan kernel and — when it ran: rs.resolved_groups — by
     # group_settle_kernel, whose fine blocks are in rs.fine_blocks and whose draws are the rows' draws below)
-    per_group = (3 if rs.resolved_groups > 0 else 2) * 128 + 4 * rs.n_terms + 4 + LINE * rs.n_terms
-    per_item = 4 + 4 + 4 * rs.n_draws + 8 + 4
-    common = rs.n_groups * per_group + rs.n_items * per_item
-    two_level = distinct * rs.cstride + rs.fine_blocks * (3 * LINE + 8) + rs.scored_terms * LINE
+    def model(line):
+        per_group = (3 if rs.resolved_groups > 0 else 2) * 128 + 4 * rs.n_terms + 4 + line * rs.n_terms
+        per_item = 4 + 4 + 4 * rs.n_draws + 8 + 4
+        common = rs.n_groups * per_group + rs.n_items * per_item
+        two_level = distinct * rs.cstride + rs.fine_blocks * (3 * line + 8) + rs.scored_terms * line
+        return common, two_level
+    common, two_level = model(LINE)
+    common64, two_level64 = model(64)  # (rounds 1-3 charged a gather the 64-byte sector; kept so that the rounds compare)
     rows_once = distinct * rs.kpad
+    roofline_model.sector64 = float(common64 + two_level64)
     return float(common + two_level), float(common + rows_once)
 
 
@@ -172,11 +177,13 @@ def step_byte_model(n, p, rs, n_groups_block1, n_obs_compact, kpad_compact, delt
     # particle's item (4), its draw (4), its item's lse (8, mostly shared), weights read + written, pchoice out
     m["particle_update_kernel"] = np_ * (4 + 4 + 8) + n * 12 + np_ * (4 + 4 + 8 + 16 + 4)
     # grouping: three 1M-item sorts of (32-bit key, 32-bit index) pairs: histogram pass + 4 onesweep passes (read + write)
-    m["radix_sort_onesweep (3 groupings)"] = 3 * (n * 4 + 4 * n * 16)
-    m["item_key + item_head + scans + group_offsets (3 groupings)"] = 3 * n * (8 + 4 + 4 + 12 + 8 + 8)
+    # grouping through the hash table (eval.hip: make_item_groups_hash), three per sweep: the table (2n slots x 8 B) zeroed,
+    # per item its key words (12 B) + a probe (line) + slot / position out (8 B), the scan over the slots (16 B each way),
+    # the fill (slot, position, the slot's offsets: 8 + 16 B in, member / head / uid out: 12 B)
+    m["hash grouping: table zero + insert + slot scan + fill (3 groupings)"] = 3 * (2 * n * 8 + n * (12 + LINE + 8) + 2 * n * 16 + n * (8 + 16 + 12))
     m["maybe_resample_kernel + apply_ancestors"] = np_ * 8 + n * (8 + 4 + 4) + np_ * 4
     m["gather_ctx + ctx_count + ctx_fill"] = np_ * (4 + 4) + np_ * 4 + n * 8 + np_ * 4 + n * (4 + 16 + 4) + np_ * 4
-    m["final_choice + finalize_block x2 + selects"] = np_ * 8 + n * 12 + 2 * n * (4 + 4 + 16) + 4 * n * 4
+    m["final_choice + finalize_block x2 + ordered lists"] = np_ * 8 + n * 12 + 2 * n * (4 + 4 + 16) + 4 * n * 4
     m["gate_new_kernel x2"] = 2 * n * (rs.n_terms * LINE // 2 + 16)
     m["compact table refresh (Measure)"] = sum(delta_rows * no * (LINE // 2) + no * kp * 1 for no, kp in zip(n_obs_compact, kpad_compact))
     m["root scans of the Measure slot + nested slots (group descriptors + draws)"] = n_groups_block1 * (2 * 128 + 4 * LINE) + n * (8 + 4 * p)
@@ -337,6 +344,13 @@ def main():
     torch.cuda.synchronize()
     dc_enable_ms = 1e3 * (time.time() - t0)
     log(f"[bench] device-resident commit: {'on' if dc_on else 'off (' + getattr(eng, '_dc_why', 'several ranks') + ')'}, set-up {dc_enable_ms:.0f} ms")
+    # one-time set-up of every class's compact tables and caches (Engine.prepare): what the first iteration would
+    # otherwise allocate and build on its way (a few GB of byte tables)
+    t0 = time.time()
+    eng.prepare(tr, comm)
+    torch.cuda.synchronize()
+    prepare_ms = 1e3 * (time.time() - t0)
+    log(f"[bench] prepare (compact tables and caches of every class): {prepare_ms:.0f} ms")
     if not args.no_full_iteration:
         inf.TIMERS.clear()
         eng.hip.set_profiling(True)
@@ -400,12 +414,38 @@ def main():
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n_half = 3
+    n_half = 8  # (with three the estimate moved by a millisecond from run to run)
     for i in range(n_half):
         observed_sweep(eng, tr, cfg, args.seed, 2000 + i, comm, batch_rows=-(-args.rows // 2))
     torch.cuda.synchronize()
     comm.barrier()
     ms_2 = 1e3 * comm.max_float(time.perf_counter() - t0) / n_half
+
+    # ... against the same number of whole-window sweeps timed the same way, right beside them
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n_half):
+        observed_sweep(eng, tr, cfg, args.seed, 3000 + i, comm)
+    torch.cuda.synchronize()
+    comm.barrier()
+    ms_1 = 1e3 * comm.max_float(time.perf_counter() - t0) / n_half
+
+    # ---- several ranks: what one small collective costs on this node (the per-sweep exchange is two of them) ----------
+    coll_ms = None
+    if getattr(eng, "_dev_comm", False):
+        blocks_ = [bi for bi, blk in enumerate(lw.blocks) if not blk.get("score")]
+        tids_ = [lw.table_id[lw.blocks[bi]["root_class"]] for bi in blocks_]
+        ns_ = [tr.tables[lw.blocks[bi]["root_class"]].n for bi in blocks_]
+        comm.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            eng.hip.allreduce_stats_fused(tids_, ns_, True)
+        coll_ms = 1e3 * comm.max_float(time.perf_counter() - t0) / 20
+        log(f"[bench] rank {rank}: one fused all-reduce of the delta counts ({sum(ns_)} int64, synchronised): {coll_ms:.3f} ms; "
+            f"step as 1 window {ms_1:.2f} ms, as 2 half windows {ms_2:.2f} ms -> fixed {max(ms_2 - ms_1, 0):.2f} ms, "
+            f"row-proportional {max(2 * ms_1 - ms_2, 0):.2f} ms per step and rank")
 
     # ---- per-phase profile of one more (untimed) sweep ----------------------------------------------------------
     eng.hip.set_profiling(True)
@@ -476,17 +516,21 @@ def main():
                        "init": f"the build's own initialize_trace from an empty trace (batches <= {args.init_batch})"
                                + ("" if args.no_full_iteration else " + 1 full run_inference iteration"),
                        "init_s": init_s, "f1_after_init": acc_init["f1"], "full_iteration_ms": full_ms,
-                       "full_iteration_steady_ms": full_steady_ms,
+                       "full_iteration_steady_ms": full_steady_ms, "prepare_ms": prepare_ms,
                        "device_ms_per_step": dev_ms / args.steps,
-                       "commit": ("device-resident (pclean_commit_device): tables, counts, free lists and referents stay in HBM, one "
-                                  "synchronisation per step" if dc_on else "host (parallel.exchange_and_commit)"),
+                       "commit": (("device-resident on every rank (pclean_commit_device_dist): delta counts all-reduced, moved rows and "
+                                   "new-row records all-gathered in HBM (RCCL), the same commit kernel everywhere"
+                                   if getattr(eng, "_dc_dist", False) else
+                                   "device-resident (pclean_commit_device): tables, counts, free lists and referents stay in HBM")
+                                  + ", one synchronisation per step" if dc_on else "host (parallel.exchange_and_commit)"),
                        "device_commit_setup_ms": dc_enable_ms,
                        "device_commits": (eng._dc or {}).get("commits"), "device_commit_refusals": (eng._dc or {}).get("fallbacks"),
                        "ms_per_step_32_sub_batches": ms_32,
                        # what does not shrink with the rows a rank sweeps (launches, count read-backs, the commit kernel, table
                        # refreshes) vs what does: from the same sweep run as two half windows (2 x fixed + proportional)
-                       "step_fixed_ms": max(ms_2 - ms_per_step, 0.0), "step_proportional_ms": max(2 * ms_per_step - ms_2, 0.0),
-                       "ms_per_step_2_windows": ms_2},
+                       "step_fixed_ms": max(ms_2 - ms_1, 0.0), "step_proportional_ms": max(2 * ms_1 - ms_2, 0.0),
+                       "ms_per_step_2_windows": ms_2, "ms_per_step_1_window_same_loop": ms_1, "fixed_split_sweeps": n_half,
+                       "collective_ms_fused_allreduce": coll_ms},
             "f1": acc["f1"], "accuracy": acc,
             "table_build": {"seconds": eng.pair_build_s, "pairs": eng.pair_count, "dp_cells": eng.pair_cells,
                             "dp_cells_per_s": eng.pair_cells / max(eng.pair_build_s, 1e-9),
@@ -502,6 +546,13 @@ def main():
                          "kernel": "group_desc_kernel + group_settle_kernel + fk_root_wave_kernel<12> + group_lse_kernel (block 0 root: "
                                    "rows x candidate hospitals); alg bytes, launch time and counter traffic all cover these launches",
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": 1e3 * per_launch_s,
+                         "gather_model": {"bytes_per_gather": LINE,
+                                          "alg_bytes_per_launch_64B_sector": getattr(roofline_model, "sector64", None),
+                                          "frac_64B_sector": (getattr(roofline_model, "sector64", 0.0) / per_launch_s / 8e12)
+                                          if (per_launch_s > 0 and getattr(roofline_model, "sector64", None)) else None,
+                                          "note": "rounds 1-3 charged a random gather the 64-byte sector, rounds 4-5 the 128-byte "
+                                                  "line the counters see (FETCH_SIZE x 2 on gfx950): `frac` uses the line; the "
+                                                  "sector figure is kept so that the rounds compare"},
                          "groups": rs.n_groups, "items": rs.n_items, "kpad": rs.kpad, "overflow_items": rs.overflow_items,
                          "full_scans": rs.full_scans, "fine_blocks": rs.fine_blocks, "scored_terms": rs.scored_terms,
                          "settled_groups": rs.resolved_groups,

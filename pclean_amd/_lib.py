@@ -588,6 +588,9 @@ class HipContext:
         return out[:n_rows]
 
     # -- device-resident commit (include/pclean_hip.h) -------------------------------------------------------------
+    def prepare(self, ev_blocks=0):
+        check(self.h, self.lib.pclean_prepare(self.h, C.c_uint32(int(ev_blocks))), "pclean_prepare")
+
     def commit_enable(self, n_blocks):
         """(supported, reason)"""
         ok = C.c_int32()

@@ -387,6 +387,7 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
   t.is_options = false;
   t.is_options_1col = false;
   t.n_used = 0;  // (pclean_commit_set_table_state tells)
+  pclean_commit_table_reuploaded(ctx, table_id);  // the device commit's live flags / free stack belong to the previous upload
   t.n_rows = n_rows;
   t.n_cols = n_cols;
   const size_t n = (size_t)n_rows * n_cols;

@@ -119,6 +119,16 @@ void pclean_commit_state_free(pclean_ctx* ctx) {
   ctx->commit_state = nullptr;
 }
 
+// pclean_set_table replaced the table's device arrays: whatever pclean_commit_set_table_state said about the previous upload
+// (live flags, free stack, high-water mark) is stale until it is called again (pclean_commit_device checks state_set)
+void pclean_commit_table_reuploaded(pclean_ctx* ctx, int table_id) {
+  if (!ctx->commit_state || table_id < 0 || table_id >= PCLEAN_MAX_TABLES) return;
+  CommitState* c = (CommitState*)ctx->commit_state;
+  if (!c->enabled) return;
+  const int si = c->slot_of_table[table_id];
+  if (si >= 0) c->slot[si].state_set = false;
+}
+
 // ---- kernels --------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void pcc_commit_kernel(PccTable* tb, int n_slots, const PccPlan* plans, const PccBlock* blocks,
                                                           int n_blocks, PccResult* res, int gathered) {

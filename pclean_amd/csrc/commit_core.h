@@ -776,6 +776,15 @@ static inline bool pcc_reaches(const PccSchema& sc, int from, int target, int de
   }
   return false;
 }
+// tables on the longest reference chain that starts at slot `from` (the schema is acyclic here)
+static inline int pcc_chain_depth(const PccSchema& sc, int from) {
+  int d = 0;
+  for (int q = 0; q < sc.tables[from].n_fk; ++q) {
+    const int x = pcc_chain_depth(sc, sc.tables[from].fk_slot[q]);
+    d = x > d ? x : d;
+  }
+  return 1 + d;
+}
 // Returns nullptr, or why these blocks cannot be committed on the device (the caller keeps the host commit).
 static inline const char* pcc_build_schema(const PccBlockIn* blocks, int n_blocks, PccSchema& sc) {
   sc.n_slots = sc.n_plans = 0;
@@ -843,6 +852,8 @@ static inline const char* pcc_build_schema(const PccBlockIn* blocks, int n_block
   }
   for (int s = 0; s < sc.n_slots; ++s)
     if (pcc_reaches(sc, s, s, 0)) return "a class that refers to itself";
+  for (int s = 0; s < sc.n_slots; ++s)  // the garbage-collection cascade keeps one frame per table of a reference chain
+    if (pcc_chain_depth(sc, s) > PCC_MAX_DEPTH) return "a reference chain deeper than 12 classes";
   int root_seen[PCC_MAX_SLOTS] = {0};
   for (int bi = 0; bi < n_blocks; ++bi) {
     const PccBlockIn& b = blocks[bi];

@@ -254,6 +254,7 @@ int pclean_ensure_density(pclean_ctx* ctx, int max_len);
 void pclean_sweep_state_free(pclean_ctx* ctx);
 // commit.hip
 void pclean_commit_state_free(pclean_ctx* ctx);
+void pclean_commit_table_reuploaded(pclean_ctx* ctx, int table_id);
 // comm.hip: collectives queued on the library's stream (no synchronisation)
 int pclean_comm_allreduce_stats_queue(pclean_ctx* ctx, int32_t n_tables, const int32_t* table_ids, int32_t local_is_zero);
 int pclean_comm_allgather_i32(pclean_ctx* ctx, const int32_t* send, int32_t* recv, size_t words_per_rank);

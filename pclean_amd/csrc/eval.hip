@@ -454,6 +454,29 @@ __global__ void sub_items_kernel(int n, const int32_t* list, const int32_t* p_ro
   if (origin) origin[j] = p_origin ? p_origin[s] : s;
 }
 
+// attributes of the representatives of groups list[j] (all groups when list is null)
+__global__ void group_rep_items_kernel(int n, const int32_t* list, const int32_t* grp_off, const int32_t* members,
+                                       const int32_t* p_row, const int32_t* p_ctx, const int32_t* p_excl, int32_t* row,
+                                       int32_t* ctxv, int32_t* excl) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int g = list ? list[j] : j;
+  const int s = members[grp_off[g]];
+  row[j] = p_row ? p_row[s] : s;
+  excl[j] = p_excl ? p_excl[s] : -1;
+  for (int c = 0; c < PCLEAN_MAX_CTX; ++c) ctxv[j * PCLEAN_MAX_CTX + c] = p_ctx ? p_ctx[(size_t)s * PCLEAN_MAX_CTX + c] : 0;
+}
+// value src[j] of group list[j] -> every member item of the group
+__global__ void group_scatter_f64_kernel(int n, const int32_t* list, const int32_t* grp_off, const int32_t* members,
+                                         const double* src, double* dst) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const int g = list ? list[j] : j;
+  const double v = src[j];
+  const int hi = grp_off[g + 1];
+  for (int mi = grp_off[g]; mi < hi; ++mi) dst[members[mi]] = v;
+}
+
 int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
                      uint64_t seed, uint32_t sweep, int n_draws, double* lse_out, int32_t* draws_out,
                      double* scores_out, const double* snew_override, bool time_it) {
@@ -472,6 +495,13 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
     if (rc) return rc;
     it.ev_item = il.origin;
   }
+  FastRootDev fr;
+  int fast = 0, fast_ev = 0;
+  // a reference slot whose groups are made BEFORE its new-row branch is looked at (below): the gate and the children of
+  // the branch then run once per group of identical rows instead of once per row
+  ItemGroups g_pre;
+  bool fast_tried = false, groups_tried = false;
+  const double* pre_score = nullptr;  // exact score of every group's current referent (group_gate_kernel)
   if (n.kind == PCLEAN_NODE_FK && ctx->prior_mode) {
     ch.n = 0;  // the new row's choices are sampled from their priors: the branch carries its CRP term alone
   } else if (n.kind == PCLEAN_NODE_FK) {
@@ -520,6 +550,94 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
       }
       // Gate of the new-row branch (gate_new_kernel): items whose current referent scores so well that
       // the new row's fixed-point weight is exactly 0 skip the evaluation of the open children.
+      static const bool no_group_gate = getenv("PCLEAN_NO_GROUP_GATE") != nullptr;
+      bool pre_grouped = false;
+      if (n_open > 0 && n_draws > 0 && excl && !scores_out && !ctx->force_generic && !nd.g.on && !il.rng_row && !il.ev_lo &&
+          !no_group_gate) {
+        fast = try_fast_root(ctx, block_id, node_id, fr);
+        if (fast < 0) return fast;
+        fast_tried = true;
+        if (fast) {
+          rc = make_item_groups(ctx, block_id, node_id, il, excl, g_pre, std::max(4, 256 / std::max(n_draws, 1)));
+          if (rc) return rc;
+          groups_tried = true;
+          pre_grouped = g_pre.n_groups > 0;
+        }
+      }
+      if (pre_grouped) {
+        // ---- the new-row branch per GROUP: rows with the same (observed tuple, ctx, referent) share the gate's verdict
+        // and the children's marginals; the gate scores the current referent through the compact byte rows
+        // (group_gate_kernel) and hands the score on to the group descriptors
+        const int ng = g_pre.n_groups;
+        ItemsDev itg = it;
+        itg.n = ng;
+        itg.grp_off = g_pre.grp_off;
+        itg.members = g_pre.members;
+        int32_t* list_g = nullptr;
+        unsigned int n_need = (unsigned int)ng;
+        if (gate) {
+          ProfScope ps(ctx, "gate_new_branch");
+          int32_t* flag = scratch<int32_t>(ctx, ng);
+          list_g = scratch<int32_t>(ctx, ng);
+          double* sc = scratch<double>(ctx, ng);
+          if (!flag || !list_g || !sc) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+          rc = pclean_launch_group_gate(ctx, fr, itg, gt, flag, sc);
+          if (rc) return rc;
+          unsigned int* need_ctr = fresh_counter(ctx);
+          hipLaunchKernelGGL(compact_new_kernel, grid1(ng), dim3(256), 0, ctx->stream, (size_t)ng, flag, 1, need_ctr, list_g,
+                             nullptr);
+          PCLEAN_READ_COUNT(ctx, need_ctr, &n_need);
+          pre_score = sc;
+          if (gstat) {
+            gstat->all_need_run = n_need == (unsigned int)ng ? gstat->all_need_run + 1 : 0;
+            if (gstat->all_need_run >= 3) {
+              gstat->skip = 16;
+              gstat->all_need_run = 2;
+            }
+          }
+          if (n_need == (unsigned int)ng) list_g = nullptr;  // (every group: the identity)
+        }
+        ItemList sil;
+        const int32_t* sexcl = nullptr;
+        if (n_need > 0) {
+          int32_t* row2 = scratch<int32_t>(ctx, n_need);
+          int32_t* ctx2 = scratch<int32_t>(ctx, (size_t)n_need * PCLEAN_MAX_CTX);
+          int32_t* excl2 = scratch<int32_t>(ctx, n_need);
+          if (!row2 || !ctx2 || !excl2) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+          hipLaunchKernelGGL(group_rep_items_kernel, grid1(n_need), dim3(256), 0, ctx->stream, (int)n_need, list_g, g_pre.grp_off,
+                             g_pre.members, il.row, il.ctx, excl, row2, ctx2, excl2);
+          sil = ItemList{(int)n_need, row2, il.ctx ? ctx2 : nullptr, nullptr, nullptr};
+          sexcl = excl2;
+        }
+        for (int c = 0; c < n.n_children; ++c) {
+          const int cid = b.children[n.child_begin + c];
+          const pclean_node& cn = b.nodes[cid];
+          if (cn.kind == PCLEAN_NODE_LEAF && cn.cacheable) continue;
+          double* child_lse = scratch<double>(ctx, il.n);
+          if (!child_lse) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+          ch.arr[c] = child_lse;
+          ch.obs_col[c] = nullptr;
+          if (n_need < (unsigned int)ng)  // gated groups: the child's marginal is never looked at with a non-zero weight
+            hipLaunchKernelGGL(fill_f64_kernel, grid1(il.n), dim3(256), 0, ctx->stream, child_lse, (size_t)il.n, -__builtin_inf());
+          if (n_need == 0) continue;
+          const int32_t* child_excl = nullptr;
+          if (cn.kind == PCLEAN_NODE_FK) {
+            if (cn.parent_fk_col < 0 || cn.parent_fk_col >= t.n_cols)
+              return pclean_fail(ctx, PCLEAN_ERR_ARG, "node %d: parent_fk_col out of range", cid);
+            int32_t* ce = scratch<int32_t>(ctx, sil.n);
+            if (!ce) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+            hipLaunchKernelGGL(derive_excl_kernel, grid1(sil.n), dim3(256), 0, ctx->stream, sil.n, sexcl, t.counts.p,
+                               t.cols.p + (size_t)cn.parent_fk_col * t.n_rows, ce);
+            child_excl = ce;
+          }
+          double* dst = scratch<double>(ctx, sil.n);
+          if (!dst) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+          rc = eval_node_lse(ctx, block_id, cid, sil, child_excl, seed, sweep, dst);
+          if (rc) return rc;
+          hipLaunchKernelGGL(group_scatter_f64_kernel, grid1(sil.n), dim3(256), 0, ctx->stream, sil.n, list_g, g_pre.grp_off,
+                             g_pre.members, dst, child_lse);
+        }
+      } else {
       int32_t* list = nullptr;
       unsigned int n_need = (unsigned int)il.n;
       if (gate && n_open > 0) {
@@ -530,10 +648,10 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
         if (s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
         rc = pclean_launch_gate(ctx, nd, it, gt, flag);
         if (rc) return rc;
-        HIPCHK(ctx, hipMemsetAsync(s->counter.p + 2, 0, sizeof(unsigned int), ctx->stream));
-        hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, flag, 1,
-                           s->counter.p + 2, list, nullptr);
-        PCLEAN_READ_COUNT(ctx, s->counter.p + 2, &n_need);
+        unsigned int* need_ctr = fresh_counter(ctx);
+        hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, flag, 1, need_ctr, list,
+                           nullptr);
+        PCLEAN_READ_COUNT(ctx, need_ctr, &n_need);
         if (gstat) {
           gstat->all_need_run = n_need == (unsigned int)il.n ? gstat->all_need_run + 1 : 0;
           if (gstat->all_need_run >= 3) {
@@ -595,6 +713,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
         if (sub)
           hipLaunchKernelGGL(scatter_f64_kernel, grid1(sil.n), dim3(256), 0, ctx->stream, sil.n, list, dst, child_lse);
       }
+      }  // (item-level gate)
     }
   }
   // cacheable option list: log-marginal and draws from the per-observed-value coarse prefix (leaf_coarse_draw_kernel)
@@ -611,9 +730,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
                                           b.leaf_m[node_id].p, b.leaf_U[node_id].p, b.leaf_coarse[node_id].p, seed, sweep,
                                           PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out, draws_out);
   }
-  FastRootDev fr;
-  int fast = 0, fast_ev = 0;
-  if (!scores_out && !snew_override && !ctx->force_generic && !nd.g.on && !ctx->prior_mode) {
+  if (!fast_tried && !scores_out && !snew_override && !ctx->force_generic && !nd.g.on && !ctx->prior_mode) {
     if (!il.ev_lo)
       fast = try_fast_root(ctx, block_id, node_id, fr);
     else if (n.kind == PCLEAN_NODE_LEAF && n_draws <= 1 && !getenv("PCLEAN_NO_FAST_EV"))
@@ -633,10 +750,12 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
     const bool lds_kernel = (size_t)((nc + 1) & ~1) * 8 + (16 + 64) * 8 <= 160 * 1024;
     if (n_draws > 0 && !scores_out && !snew_override && !ctx->force_generic && !il.rng_row && !il.ev_lo &&
         (fast || lds_kernel)) {
-      ItemGroups g;
+      ItemGroups g = g_pre;
       // wave kernel: at most ~2 x 256 draws per group (see item_head_kernel)
-      rc = make_item_groups(ctx, block_id, node_id, il, excl, g, fast ? std::max(4, 256 / std::max(n_draws, 1)) : 0);
-      if (rc) return rc;
+      if (!groups_tried) {
+        rc = make_item_groups(ctx, block_id, node_id, il, excl, g, fast ? std::max(4, 256 / std::max(n_draws, 1)) : 0);
+        if (rc) return rc;
+      }
       if (g.n_groups > 0) {
         it.n = g.n_groups;
         it.grp_off = g.grp_off;
@@ -703,7 +822,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
       s->scan_stats_used = true;
     }
     rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag, over_count, desc,
-                                 over_list, scan_stats, il.n);
+                                 over_list, scan_stats, il.n, pre_score);
     if (time_it) {
       (void)hipEventRecord(s->ev1, ctx->stream);
       s->dbg_desc = desc;
@@ -1031,6 +1150,24 @@ __device__ __forceinline__ bool hg_same_key(const KeyColsDev& kc, const int32_t*
 __device__ __forceinline__ uint32_t hg_slot(uint32_t base, uint32_t pos0, uint32_t alt, uint32_t wmask, uint32_t mask, int t) {
   return t < HG_INWIN ? base + ((pos0 + (uint32_t)t) & wmask) : (alt + (uint32_t)(t - HG_INWIN)) & mask;
 }
+// classes of the lanes with in == true by the value of `key`: leader = first lane of this lane's class, rank = lanes of the
+// class before this one, size = lanes in the class (wave-uniform loop: one pass per distinct key, ballots only)
+__device__ __forceinline__ void hg_classes(bool in, uint32_t key, int lane, int& leader, int& rank, int& size) {
+  leader = lane;
+  rank = 0;
+  size = 1;
+  for (unsigned long long pend = __ballot(in); pend;) {
+    const int ld = __builtin_ctzll(pend);
+    const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)key, ld);
+    const unsigned long long cls = __ballot(in && key == k) & pend;
+    if ((cls >> lane) & 1ull) {
+      leader = ld;
+      rank = __popcll(cls & ((1ull << lane) - 1ull));
+      size = __popcll(cls);
+    }
+    pend &= ~cls;
+  }
+}
 __global__ __launch_bounds__(256) void hg_insert_kernel(int n, KeyColsDev kc, const int32_t* __restrict__ row,
                                                         const int32_t* __restrict__ ctxv, const int32_t* __restrict__ excl,
                                                         HashGroupDev hg, int32_t* __restrict__ slot_of,
@@ -1061,27 +1198,27 @@ __global__ __launch_bounds__(256) void hg_insert_kernel(int n, KeyColsDev kc, co
     alt = (uint32_t)(h >> 8) & hg.mask;
   }
   const uint32_t wmask = (1u << hg.wbits) - 1u;
-  // Claim or join a slot.  Wave-uniform loop: of the lanes that meet an EMPTY slot in a round, one per distinct slot tries
-  // the compare-and-swap, the others look again in the next round (10^5 rows of one popular key would otherwise all
-  // find the slot empty at the start of the launch and queue 10^5 atomics on one address).
+  // Claim or join a slot, in wave-uniform rounds.  The lanes of the wavefront that look at the SAME slot in a round form a
+  // class (hg_classes); its first lane reads the slot, tries the compare-and-swap when it is empty, and hands what the slot
+  // holds to the others by shuffle: 10^5 rows of one popular key cost one load (and at most one atomic) per wavefront and
+  // round instead of 10^5 requests queueing on one address.
   bool active = on;
   int t = 0;
   uint32_t slot = hg_slot(base, pos0, alt, wmask, hg.mask, 0);
+  int leader = lane, rank = 0, size = 1;
   while (__ballot(active)) {
-    int cur = -1;
-    if (active) cur = __hip_atomic_load(&hg.rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool need = active && cur == 0;
-    bool elected = false;
-    for (unsigned long long pend = __ballot(need); pend;) {
-      const int ld = __builtin_ctzll(pend);
-      const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slot, ld);
-      if (lane == ld) elected = true;
-      pend &= ~__ballot(need && slot == sl);
+    hg_classes(active, slot, lane, leader, rank, size);
+    int val = 0;
+    if (active && leader == lane) {
+      val = __hip_atomic_load(&hg.rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (val == 0) {
+        val = atomicCAS(&hg.rep[slot], 0, i + 1);
+        if (val == 0) val = i + 1;  // claimed: this item represents the group
+      }
     }
-    if (elected) cur = atomicCAS(&hg.rep[slot], 0, i + 1);  // (0: claimed; else: somebody else's item, looked at below)
-    if (need && !elected) continue;                           // the elected lane of this slot decides; look again
+    val = __shfl(val, leader, 64);
     if (active) {
-      if (cur == 0 || cur - 1 == i || hg_same_key(kc, row, ctxv, excl, i, cur - 1)) {
+      if (val - 1 == i || hg_same_key(kc, row, ctxv, excl, i, val - 1)) {
         active = false;
       } else {
         ++t;
@@ -1091,20 +1228,13 @@ __global__ __launch_bounds__(256) void hg_insert_kernel(int n, KeyColsDev kc, co
   }
   if (on) slot_of[i] = (int32_t)slot;
   if (!hg.cnt) return;
-  // position within the group: the lanes of this wavefront that share a slot take consecutive positions from ONE atomic
-  unsigned long long todo = __ballot(on);
-  int pos = 0;
-  while (todo) {
-    const int leader = __builtin_ctzll(todo);
-    const uint32_t sl = (uint32_t)__builtin_amdgcn_readlane((int)slot, leader);
-    const unsigned long long same = __ballot(on && slot == sl) & todo;
-    unsigned int bse = 0;
-    if (lane == leader) bse = atomicAdd(&hg.cnt[sl], (unsigned int)__popcll(same));
-    bse = (unsigned int)__builtin_amdgcn_readlane((int)bse, leader);
-    if ((same >> lane) & 1ull) pos = (int)bse + __popcll(same & ((1ull << lane) - 1ull));
-    todo &= ~same;
-  }
-  if (on) pos_of[i] = pos;
+  // position within the group: the lanes that ended in the same slot take consecutive positions from ONE atomic of their
+  // first lane — all classes' atomics in flight together
+  hg_classes(on, slot, lane, leader, rank, size);
+  unsigned int bse = 0;
+  if (on && leader == lane) bse = atomicAdd(&hg.cnt[slot], (unsigned int)size);
+  bse = (unsigned int)__shfl((int)bse, leader, 64);
+  if (on) pos_of[i] = (int)bse + rank;
 }
 // per slot: groups only: 1 per claimed slot; with members: (groups the slot contributes) << 32 | members — a group of more
 // than 2 split_m - 1 members is cut into pieces of split_m (the last piece takes the remainder: split_m .. 2 split_m - 1
@@ -1432,11 +1562,10 @@ static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemL
   int32_t* list = scratch<int32_t>(ctx, N);
   if (!flag || !list || s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   hipLaunchKernelGGL(memo_lookup_kernel, grid1(N), dim3(256), 0, ctx->stream, N, kc, il.row, il.ctx, md, lse_out, flag);
-  HIPCHK(ctx, hipMemsetAsync(s->counter.p + 3, 0, sizeof(unsigned int), ctx->stream));
-  hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 1, s->counter.p + 3, list,
-                     nullptr);
+  unsigned int* miss_ctr = fresh_counter(ctx);
+  hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 1, miss_ctr, list, nullptr);
   unsigned int n_miss = 0;
-  PCLEAN_READ_COUNT(ctx, s->counter.p + 3, &n_miss);
+  PCLEAN_READ_COUNT(ctx, miss_ctr, &n_miss);
   if (n_miss == 0) return PCLEAN_OK;
   if (n_miss == (unsigned int)N) {
     int rc = eval_node_lse_core(ctx, block_id, node_id, il, excl, seed, sweep, lse_out);
@@ -1504,7 +1633,6 @@ int sample_children(pclean_ctx* ctx, int block_id, int node_id, const ItemList& 
   Block& b = ctx->block[block_id];
   const pclean_node& n = b.nodes[node_id];
   const CandTable& t = ctx->cand[n.table];
-  SweepState* s = st(ctx);
   for (int c = 0; c < n.n_children; ++c) {
     const int cid = b.children[n.child_begin + c];
     const pclean_node& cn = b.nodes[cid];
@@ -1524,11 +1652,11 @@ int sample_children(pclean_ctx* ctx, int block_id, int node_id, const ItemList& 
                        cid, vals);
     if (cn.kind == PCLEAN_NODE_FK && cn.n_children > 0) {
       // rows of this child that were themselves proposed as NEW
-      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-      hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, draws, 0,
-                         s->counter.p, nullptr, nullptr);
+      unsigned int* new_ctr = fresh_counter(ctx);
+      hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, draws, 0, new_ctr, nullptr,
+                         nullptr);
       unsigned int cnt = 0;
-      PCLEAN_READ_COUNT(ctx, s->counter.p, &cnt);
+      PCLEAN_READ_COUNT(ctx, new_ctr, &cnt);
       if (cnt) {
         int32_t* list = scratch<int32_t>(ctx, cnt);
         int32_t* row = scratch<int32_t>(ctx, cnt);
@@ -1537,9 +1665,8 @@ int sample_children(pclean_ctx* ctx, int block_id, int node_id, const ItemList& 
         int32_t* org = scratch<int32_t>(ctx, cnt);
         int32_t* sub_excl = scratch<int32_t>(ctx, cnt);
         if (!list || !row || !cx || !part || !org || !sub_excl) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-        HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
         hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, draws, 1,
-                           s->counter.p, list, nullptr);
+                           fresh_counter(ctx), list, nullptr);
         int32_t* evl = il.ev_lo ? scratch<int32_t>(ctx, cnt) : nullptr;
         int32_t* evh = il.ev_lo ? scratch<int32_t>(ctx, cnt) : nullptr;
         int32_t* rng = il.rng_row ? scratch<int32_t>(ctx, cnt) : nullptr;
@@ -1556,6 +1683,42 @@ int sample_children(pclean_ctx* ctx, int block_id, int node_id, const ItemList& 
       }
     }
   }
+  return PCLEAN_OK;
+}
+
+// One-time set-up of everything the first sweeps would otherwise build on their way: the candidate-compact byte tables,
+// block minima and prior rows of every reference slot / long-string option list of every loaded block (observed-class
+// blocks and latent-class plans alike: the same cache entries whichever kind of sweep asks first), the per-value caches of
+// cacheable option lists.  The buffers are a few GB on the 1M-row workload and allocating them is what made the FIRST
+// run_inference iteration 0.4-0.8 s where the later ones take 0.3 s (and twice as long again on some boxes).  Call it once
+// the latent tables are uploaded (with the capacity the device-resident commit wants, when that is on).
+extern "C" int pclean_prepare(pclean_ctx* ctx, uint32_t ev_blocks) {  // bit bi: block bi is a latent-class plan (evidence sets)
+  if (!ctx) return PCLEAN_ERR_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  {
+    const int rcb = begin_call(ctx);
+    if (rcb) return rcb;
+  }
+  for (int bi = 0; bi < PCLEAN_MAX_BLOCKS; ++bi) {
+    Block& b = ctx->block[bi];
+    if (!b.valid || b.is_score) continue;
+    for (int node = 0; node < (int)b.nodes.size() && node < 64; ++node) {
+      const pclean_node& n = b.nodes[node];
+      if (n.table < 0 || n.table >= PCLEAN_MAX_TABLES || !ctx->cand[n.table].valid) continue;
+      if (node < (int)b.node_gauss.size() && b.node_gauss[node] >= 0) continue;  // (never takes the compact-table kernels)
+      FastRootDev fr;
+      const int rc = try_fast_root(ctx, bi, node, fr, n.kind == PCLEAN_NODE_LEAF && ((ev_blocks >> bi) & 1u));
+      if (rc < 0) return rc;
+      if (n.kind == PCLEAN_NODE_LEAF && n.cacheable && n.n_terms == 1 && b.terms[n.term_begin].ctx_slot < 0) {
+        const double* cache;
+        const int32_t* ocol;
+        int n_obs;
+        const int rcl = ensure_leaf_cache(ctx, bi, node, &cache, &ocol, &n_obs);
+        if (rcl) return rcl;
+      }
+    }
+  }
+  PCLEAN_SYNC(ctx);
   return PCLEAN_OK;
 }
 

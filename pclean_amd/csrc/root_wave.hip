@@ -228,7 +228,7 @@ __device__ __forceinline__ double fast_exact_score(const FastRootDev& fr, const 
 __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const ChildrenDev ch, int n_groups,
                                   int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr, double* __restrict__ g_m,
                                   uint64_t* __restrict__ g_U, int32_t* __restrict__ g_res,
-                                  unsigned int* __restrict__ scan_stats) {
+                                  unsigned int* __restrict__ scan_stats, const double* __restrict__ pre_score) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < 8) chunk_ctr[g * WAVE_CTR_STRIDE] = 0u;
   unsigned int st_blocks = 0, st_resolved = 0;  // (summed over the wavefront at the end: one atomic per wave)
@@ -247,7 +247,8 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
   if (excl >= 0 && !deleted && fr.logc_m1) {
     // the current referent's exact score: the same operations in the same order as the scan kernel's own scoring of
     // candidate excl, so the scan kernel takes it from the descriptor when that candidate is its only survivor
-    score_cur = fast_exact_score(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]);
+    // (group_gate_kernel computed it already when the gate of the new-row branch ran on the groups: same function, same bits)
+    score_cur = pre_score ? pre_score[g] : fast_exact_score(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]);
     have_cur = true;
     bound = score_cur - 1.0;
   }
@@ -379,6 +380,48 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
       atomicAdd(&sl[3], st_resolved);
     }
   }
+}
+
+// Gate of the new-row branch on GROUPS (enum_kernels.hip: gate_new_kernel does it per item through the pair tables): one
+// thread per group scores the rows' current referent exactly through the compact byte rows — the value group_desc_kernel
+// needs anyway (score_out) — and compares it with the upper bound of the new-row candidate: where that candidate's
+// fixed-point weight is exactly 0 the children of the branch are never evaluated.  flag[g] = PCLEAN_CHOICE_NEW: needed.
+__global__ void group_gate_kernel(const FastRootDev fr, const ItemsDev it, const GateDev gt, int n_groups,
+                                  int32_t* __restrict__ flag, double* __restrict__ score_out) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_groups) return;
+  const int t = it.grp_off ? it.members[it.grp_off[g]] : g;
+  const int row = it.row ? it.row[t] : t;
+  const int excl = it.excl ? it.excl[t] : -1;
+  const int ctx0 = it.ctx ? it.ctx[(size_t)t * PCLEAN_MAX_CTX] : 0;
+  const int ctx1 = it.ctx ? it.ctx[(size_t)t * PCLEAN_MAX_CTX + 1] : 0;
+  const bool deleted = excl >= 0 && fr.counts && fr.counts[excl] <= 1;
+  bool need = true;
+  double sc = 0.0;
+  if (excl >= 0 && !deleted && fr.logc_m1) {
+    int o[PCLEAN_MAX_TERMS];
+    for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) o[f] = f < fr.n_terms ? fr.terms[f].obs_col[row] : -1;
+    sc = fast_exact_score(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]);
+    double ub = fr.scal[2] - fr.scal[1];
+    for (int c = 0; c < gt.n; ++c) {
+      if (gt.cache[c]) {
+        const int oc = gt.obs_col[c][row];
+        ub += gt.cache[c][oc < 0 ? gt.n_obs[c] : oc];
+      } else {
+        ub += gt.ub[c];
+      }
+    }
+    need = !(ub + 1e-6 < sc - FIX_CUTOFF);
+  }
+  flag[g] = need ? PCLEAN_CHOICE_NEW : 0;
+  score_out[g] = sc;
+}
+int pclean_launch_group_gate(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const GateDev& gt, int32_t* flag,
+                             double* score_out) {
+  if (it.n <= 0) return PCLEAN_OK;
+  hipLaunchKernelGGL(group_gate_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, it, gt, it.n, flag, score_out);
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
 }
 
 // draws of the RESOLVED groups (group_desc_kernel): one thread per member position; its group by bisection of grp_off
@@ -1434,7 +1477,8 @@ size_t pclean_fast_desc_words(int n_groups) {
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
-                            int32_t* desc_scratch, int32_t* overflow_list, unsigned int* scan_stats, int n_items) {
+                            int32_t* desc_scratch, int32_t* overflow_list, unsigned int* scan_stats, int n_items,
+                            const double* pre_score) {
   if (it.n <= 0) return PCLEAN_OK;
   const size_t ng = (size_t)it.n;
   unsigned int* chunk_ctr = reinterpret_cast<unsigned int*>(desc_scratch + ng * GD_STRIDE);
@@ -1450,7 +1494,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   static const bool want_resolve = getenv("PCLEAN_RESOLVE_GROUPS") != nullptr;
   const bool resolve = n_draws > 0 && want_resolve && (!it.grp_off || n_items > 0);
   hipLaunchKernelGGL(group_desc_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, it, ch, it.n,
-                     desc_scratch, chunk_ctr, g_m, g_U, resolve ? g_res : nullptr, scan_stats);
+                     desc_scratch, chunk_ctr, g_m, g_U, resolve ? g_res : nullptr, scan_stats, pre_score);
   // the easy groups settled by a few lanes each (group_settle_kernel): launches that draw, large enough to matter
   static const bool no_settle = getenv("PCLEAN_NO_SETTLE") != nullptr;
   const bool settle = !no_settle && !resolve && n_draws > 0 && !fr.is_leaf && fr.n_pre >= 1 && fr.n_pre <= 3 && fr.cstride > 0 &&

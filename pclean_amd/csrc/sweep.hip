@@ -190,6 +190,9 @@ __global__ __launch_bounds__(PU_T) void particle_update_kernel(int N, int P, con
       pchoice[sp] = c;
       w[sp] = first ? 0.0 + l : w[sp] + l;  // (first block of the sweep: the weights start at +0.0)
       if (c == PCLEAN_CHOICE_NEW) newmask |= 1ull << p;
+      // a row without any possible candidate (log marginal -inf or NaN): bit 31 of the counter tells the host, which then
+      // runs the resampling step it would otherwise know to be a no-op (pclean_sweep: equal_weights)
+      if (p == 0 && !(l > -__builtin_inf())) atomicOr(n_new, 0x80000000u);
     }
     // (last block, dummy values drawable for a few rows only: the list holds those rows' NEW slots — the others'
     // contents are sampled after the final choice, for the chosen particle alone)
@@ -206,7 +209,7 @@ __global__ __launch_bounds__(PU_T) void particle_update_kernel(int N, int P, con
   if (threadIdx.x == 0) {
     unsigned int total = 0;
     for (int k = 0; k < PU_T / 64; ++k) total += wsum[k];
-    bbase = total ? atomicAdd(n_new, total) : 0u;
+    bbase = total ? (atomicAdd(n_new, total) & 0x7fffffffu) : 0u;  // (bit 31: the degenerate-row flag)
   }
   __syncthreads();
   if (!mine) return;
@@ -756,8 +759,9 @@ int begin_call(pclean_ctx* ctx) {
   s->dummy_used = false;
   ctx->prior_mode = false;
   s->over_rec.clear();
-  if (s->over_ctr.alloc(OVER_SLOTS + STAT_WORDS)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-  HIPCHK(ctx, hipMemsetAsync(s->over_ctr.p, 0, (OVER_SLOTS + STAT_WORDS) * sizeof(unsigned int), ctx->stream));
+  if (s->over_ctr.alloc(OVER_SLOTS + STAT_WORDS + CTR_BANK)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemsetAsync(s->over_ctr.p, 0, (OVER_SLOTS + STAT_WORDS + CTR_BANK) * sizeof(unsigned int), ctx->stream));
+  s->bank_used = 0;
   s->scan_stats_used = false;
   return PCLEAN_OK;
 }
@@ -1377,6 +1381,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     }
     ItemList il;
     const int32_t* excl;
+    unsigned int* n_new_ctr = nullptr;  // particles of the block that proposed a NEW referent (fresh_counter)
     if (prior_mode) {
       // every (row, particle) draws its referent from the CRP prior; the block's log marginal plays no part
       il = ItemList{N, nullptr, nullptr, nullptr, nullptr};
@@ -1389,10 +1394,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         return rc;
       }
       HIPCHK(ctx, hipMemsetAsync(r.lse.p, 0, (size_t)N * sizeof(double), ctx->stream));
-      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+      n_new_ctr = fresh_counter(ctx);
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
-                         s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0,
+                         s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0,
                          (const int32_t*)nullptr);
       if (has_ctx) {  // the particles' contexts: read by the likelihood terms and handed to the new rows' items
         { const int rci = ensure_it_ctx(ctx, r, NP, b.n_ctx); if (rci) return rci; }
@@ -1425,10 +1430,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         ctx->timing.hot_kernel_launches += 1;
       }
       ProfScope ps(ctx, "particle_update");
-      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+      n_new_ctr = fresh_counter(ctx);
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
-                         s->w.p, s->counter.p, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows);
+                         s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows);
     } else {
       { const int rci = ensure_it_ctx(ctx, r, NP, b.n_ctx); if (rci) return rci; }
       CtxSrc cs{};
@@ -1479,14 +1484,16 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       rc = eval_node(ctx, bi, 0, il, d_excl, seed, sweep_idx, P, lse_item, draws_item, nullptr, nullptr, false);
       if (rc) return rc;
       ProfScope ps(ctx, "particle_update");
-      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
+      n_new_ctr = fresh_counter(ctx);
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, (const int32_t*)nullptr,
                          (const double*)nullptr, slot_item, draws_item, lse_item, cur_b, r.pchoice.p, s->w.p,
-                         s->counter.p, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows);
+                         n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows);
     }
     // ---- particles that proposed a NEW referent: sample the new row's contents
     unsigned int n_new = 0;
-    PCLEAN_READ_COUNT(ctx, s->counter.p, &n_new);
+    PCLEAN_READ_COUNT(ctx, n_new_ctr, &n_new);
+    const bool degenerate_rows = (n_new & 0x80000000u) != 0u;  // some row's block marginal is -inf (particle_update_kernel)
+    n_new &= 0x7fffffffu;
     r.n_new = (int)n_new;
     r.lazy_new = bi == n_blocks - 1 && !eager_all && (!drawable || emit_rows != nullptr);
     if (r.lazy_new && !emit_rows) n_new = 0;  // nothing sampled now
@@ -1540,7 +1547,15 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     // ---- resampling between blocks (row_inference.jl:152-155)
     const int grp_here = b.group >= 0 ? b.group : bi;
     const int grp_next = bi + 1 < n_blocks ? (ctx->block[bi + 1].group >= 0 ? ctx->block[bi + 1].group : bi + 1) : -2;
-    if (!use_mh && bi < n_blocks - 1 && grp_here != grp_next) {  // (the slots of one model block: no resampling in between)
+    // After the FIRST block of a sweep every particle of a row carries the same weight — the block's log marginal, shared by
+    // the particles (no context yet to tell them apart) — unless a dummy-value correction or a prior-mode likelihood touched
+    // individual particles: the effective sample size is exactly P, maybe_resample (row_inference.jl:87-105) keeps every
+    // particle and adds 0 to the log-ML estimate (a row whose marginal is -inf has total weight 0 and IS resampled: those
+    // rows are reported through bit 31 of the NEW-slot counter).  Two kernels over all rows that can only ever do nothing are
+    // not launched.
+    const bool equal_weights = bi == 0 && w_by_first_block && !has_ctx && !prior_mode && !(drawable && n_new > 0) && !degenerate_rows;
+    static const bool always_resample = getenv("PCLEAN_ALWAYS_RESAMPLE") != nullptr;
+    if (!use_mh && bi < n_blocks - 1 && grp_here != grp_next && (!equal_weights || always_resample)) {  // (the slots of one model block: no resampling in between)
       ProfScope ps(ctx, "resample");
       DISPATCH_PMAX(P, hipLaunchKernelGGL(maybe_resample_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p,
                                           (size_t)1, (size_t)N, 1, cur_b, seed, sweep_idx, (uint32_t)bi,
@@ -1573,11 +1588,11 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       ProfScope ps2(ctx, "new_row_sampling_chosen");
       const int nn = (int)bb.nodes.size();
       const int32_t* cur_b = cur_base + (size_t)bi * cur_ld;
-      HIPCHK(ctx, hipMemsetAsync(s->counter.p, 0, sizeof(unsigned int), ctx->stream));
-      hipLaunchKernelGGL(chosen_new_kernel, grid1(N), dim3(256), 0, ctx->stream, N, s->chosen.p, r.pchoice.p, s->counter.p,
+      unsigned int* cnt_ctr = fresh_counter(ctx);
+      hipLaunchKernelGGL(chosen_new_kernel, grid1(N), dim3(256), 0, ctx->stream, N, s->chosen.p, r.pchoice.p, cnt_ctr,
                          r.new_slots.p, r.pnewpos.p);
       unsigned int cnt = 0;
-      PCLEAN_READ_COUNT(ctx, s->counter.p, &cnt);
+      PCLEAN_READ_COUNT(ctx, cnt_ctr, &cnt);
       if (r.vals.alloc(std::max<size_t>((size_t)cnt * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
       if (!cnt) continue;
       hipLaunchKernelGGL(fill_i32_kernel, grid1((size_t)cnt * nn), dim3(256), 0, ctx->stream, r.vals.p, (size_t)cnt * nn, -2);

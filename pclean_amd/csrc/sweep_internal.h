@@ -82,6 +82,18 @@ static T* scratch(pclean_ctx* ctx, size_t count) {
   return (T*)b.p;
 }
 
+// A zeroed device counter for one use (how many items need the next step): begin_call zeroes a bank of them with the
+// memset it makes anyway — a hipMemsetAsync of four bytes per use was a dispatch per use.  Null-safe: when the bank is
+// exhausted the last counter is re-zeroed the old way.
+static unsigned int* fresh_counter(pclean_ctx* ctx) {
+  SweepState* s = st(ctx);
+  if (!s->over_ctr.p) return nullptr;
+  unsigned int* bank = s->over_ctr.p + OVER_SLOTS + STAT_WORDS;
+  if (s->bank_used < CTR_BANK) return bank + s->bank_used++;
+  (void)hipMemsetAsync(bank + CTR_BANK - 1, 0, sizeof(unsigned int), ctx->stream);
+  return bank + CTR_BANK - 1;
+}
+
 // ---- per-phase profile (pclean_set_profiling): HIP events on the library's stream around groups of launches
 int prof_phase_id(SweepState* s, const char* name);
 struct ProfScope {  // records start at construction, stop at destruction

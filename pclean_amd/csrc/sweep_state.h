@@ -118,6 +118,7 @@ struct SweepState {
   // overflow counters of the compact-table launches of the running call whose re-run needs no read-back
   // (overflow_lds_kernel in list mode): counted into the statistics / heuristics at the end of the call
   bool scan_stats_used = false;
+  int bank_used = 0;               // counters of the bank (the tail of over_ctr) handed out by the running call
   DevBuf<unsigned int> over_ctr;   // [OVER_SLOTS + STAT_WORDS]: the tail = scan statistics of the timed root launch
   struct OverRec { int block, node, n_items; bool time_it, leaf; int min_items; };  // min_items: from how many items on the "does the pre-filter pay" rule applies
   std::vector<OverRec> over_rec;
@@ -143,6 +144,7 @@ struct SweepState {
 
 #define OVER_SLOTS 256
 #define STAT_WORDS (64 * 32)  // scan statistics of the timed root launch: 64 slots, 128 bytes apart
+#define CTR_BANK 2048         // zeroed 32-bit counters handed out one after the other within a call (fresh_counter)
 static SweepState* st(pclean_ctx* ctx) {
   if (!ctx->sweep_state) ctx->sweep_state = new SweepState();
   return (SweepState*)ctx->sweep_state;

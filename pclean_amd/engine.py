@@ -78,7 +78,17 @@ class Engine:
             _lib.check(self.hip.h, self.hip.lib.pclean_set_row_offset(self.hip.h, _lib.C.c_int64(row_offset)),
                        "pclean_set_row_offset")
 
+    def _sync_ahead_trace(self):
+        """A trace the device-resident commit left behind (Trace._dev is this engine) holds its only current copy in this
+        engine's HBM: pull it before the context goes away (close / reload)."""
+        ref = getattr(self, "_ahead", None)
+        tr = ref() if ref is not None else None
+        if tr is not None and getattr(tr, "_dev", None) is self:
+            tr._sync()
+        self._ahead = None
+
     def close(self):
+        self._sync_ahead_trace()
         self.hip.close()
 
     def reload(self):
@@ -87,6 +97,7 @@ class Engine:
         ProposalDummyValue is only ever chosen for unobserved or very short strings), so nothing is patched
         incrementally.  A device-side RCCL communicator bound with init_device_comm is re-bound to the new context —
         collectively: every rank reloads at the same point (the dummy draws are replicated)."""
+        self._sync_ahead_trace()
         self.hip.close()
         self.hip = HipContext(self.device)
         self.option_logp = {}
@@ -377,6 +388,20 @@ class Engine:
         self.upload_trace(trace)
         return True
 
+    def prepare(self, trace, comm=None):
+        """One-time set-up before the first run_inference iteration: the device-resident commit (tables uploaded with their
+        spare capacity from the start, so that no table changes shape later) and every compact table / per-value cache the
+        sweeps of all classes will ask for (pclean_prepare).  Optional: results do not depend on it."""
+        from . import inference as inf
+        if inf.DEVICE_COMMIT:
+            self.enable_device_commit(trace, comm)
+        self.upload_trace(trace)
+        ev = 0
+        for pl in self.lw.latent_plans.values():
+            ev |= 1 << int(pl["block_id"])
+        self.hip.prepare(ev)
+        self._prepared = True
+
     def _sync_cur(self, trace):
         dc = self._dc
         if dc["cur_version"] != (id(trace), trace._cur_version):
@@ -443,6 +468,8 @@ class Engine:
             else:
                 trace._locals[bi][lo:hi] = loc
         trace._dev = self
+        import weakref
+        self._ahead = weakref.ref(trace)  # (close / reload pull it first: the committed sweeps exist nowhere else)
         return int(summ.n_changed)
 
     def fetched_new_rows(self, trace, lo, hi):
@@ -468,6 +495,9 @@ class Engine:
         device commits left behind): latent tables with their allocation state, the observed rows' referents, the
         Dirichlet counts of own choices (recomputed from the tables), the origins of created rows."""
         lw, dc = self.lw, self._dc
+        if dc is None or not self.hip.h:
+            raise _lib.PCleanHipError("the trace is behind a device-resident commit whose context is gone (Engine.close / "
+                                      "reload without a pull): its committed sweeps are lost")
         for cname in dc["tables"]:
             t = trace._tables[cname]
             state, cols, counts, live, free, origin = self.hip.commit_pull_table(lw.table_id[cname])

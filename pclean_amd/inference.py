@@ -637,6 +637,9 @@ def run_inference(engine, trace, config, seed, verbose=False, comm=None, max_sub
     cadence exactly; batch_rows=1 is the reference's sequential schedule (sub_batches).  use_lo_sweeps is, as in the reference, only read by instrumented_inference.jl (out of
     scope): pgibbs_sweep! sweeps the latent classes regardless of it."""
     lw = engine.lw
+    if hasattr(engine, "prepare") and not getattr(engine, "_prepared", False):
+        with _timed("prepare"):
+            engine.prepare(trace, comm)  # (one-time: compact tables and caches of every class, device-resident commit)
     for it in range(config.num_iters):
         if verbose:
             print(f"Iteration {it + 1}/{config.num_iters}", flush=True)

@@ -14,6 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# per-configuration exceptions to the symmetric +-0.5 pt band: (lower, upper) difference of the means — none
+BAND = {}
+
+
 def _gpu_f1(name, seed, iters, mh, particles, n_rows):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     from pclean_amd import experiments as ex
@@ -32,7 +36,7 @@ def _gpu_f1(name, seed, iters, mh, particles, n_rows):
     try:
         tr = Trace(lw, obs.shape[1], seed)
         cfg = InferenceConfig(iters, particles, use_mh_instead_of_pg=mh, rejuv_frequency=sr.rejuv_of(name))
-        initialize_trace(eng, tr, cfg, seed, max_batch=256 if name.startswith("hospital") else 1024)
+        initialize_trace(eng, tr, cfg, seed)  # (the product's default batches: max_batch = 256)
         run_inference(eng, tr, cfg, seed)
         tr.check_consistency()
         return evaluate_accuracy(lw, tr, dirty, clean)["f1"]
@@ -54,18 +58,21 @@ def test_batched_gpu_f1_matches_the_sequential_reference(name, capsys):
     with capsys.disabled():
         print(f"\n[f1 vs sequential] {name}: batched GPU {np.round(got, 4).tolist()} (mean {np.mean(got):.4f})  "
               f"sequential reference {np.round(want, 4).tolist()} (mean {np.mean(want):.4f})")
-    # The north star's band is +-0.5 pt.  The lower side is held strictly: the batched schedule never costs more than
-    # 0.5 pt of F1.  On the upper side two configurations sit at / beyond the band with enough seeds to say so — rents
-    # PG-20: +0.60 pt (paired over 8 seeds: +-0.16), synth_k3000_pg20: +0.49 pt (6 seeds) — the batched schedule (frozen
-    # tables per batch, identical new-row proposals merged) is measurably a little BETTER there, not noisier; DESIGN.md
-    # §9 reports it as outside the symmetric band.  The upper bound below only catches an implausible gain.
+    # The north star's band: +-0.5 pt, both sides, every configuration (BAND holds the named exceptions: none).
+    # Round 4 ran rents PG-20 at +0.60 pt (paired s.e. 0.16, 8 seeds) with an asymmetric bound.  scripts/schedule_knobs.py
+    # (CPU oracle engine = this path bit for bit, same 8 seeds) found the knob: the batch size of the INITIALISATION —
+    # sequential initialisation + batched sweeps +0.00 pt (s.e. 0.09), batches of at most 16 / 64 / 256 / 1024 rows
+    # -0.16 / +0.29 / +0.27 / +0.60 pt; sequential sweeps after the 1024-row initialisation still +0.66 pt: the batched
+    # SWEEPS are neutral, a large initialisation batch creates one latent row per distinct spelling at once and lets the
+    # later rows choose among them where the reference commits to the first spelling it meets.  The test had asked for
+    # 1024-row batches; it now runs the product's default (initialize_trace: max_batch = 256), which is inside the band.
     diff = float(np.mean(got) - np.mean(want))
     with capsys.disabled():
         d = np.asarray(got) - np.asarray(want)
         print(f"[f1 vs sequential] {name}: difference of means {100 * diff:+.2f} pt (paired standard error "
               f"{100 * d.std(ddof=1) / np.sqrt(len(d)):.2f} pt, {len(d)} seeds)")
-    assert diff >= -0.005, (got, want)
-    assert diff <= 0.010, (got, want)
+    lo, hi = BAND.get(name, (-0.005, 0.005))
+    assert lo <= diff <= hi, (name, diff, got, want)
     lit = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_sequential.json")))
     if name in lit:  # ... and of the INDEPENDENT literal sequential reference (oracle/literal_inference.py)
         with capsys.disabled():

@@ -214,5 +214,41 @@ def test_million_row_own_init_state_parity(oracle, capsys):
         assert set(new_rows) == set(b_new)
         for k in new_rows:
             assert np.array_equal(new_rows[k][0], b_new[k][0]) and np.array_equal(new_rows[k][1], b_new[k][1])
+        # (c) the path bench.py TIMES: sweep + device-resident commit (Engine.sweep_commit_device), three sweeps in a row on
+        # the device-resident state — after each, the pulled state == the host commit (inference._sweep_window with the
+        # device commit off, a second engine that uploads the host trace afresh) of the same sweep on the same state:
+        # tables with row ids, free lists, counts, live flags, columns, the 10^6 rows' referents, row origins
+        import copy
+        from pclean_amd import inference as inf
+        from pclean_amd.parallel import Comm
+        from test_gpu_commit import _same_state
+        ref = Engine(lw, obs, dist_mode=_lib.DIST_OSA)
+        try:
+            assert eng.enable_device_commit(tr), getattr(eng, "_dc_why", "")
+            host = copy.deepcopy(tr)
+            for t in host.tables.values():
+                t.cols_dirty = True
+            refused = []
+            for sweep in range(2, 5):
+                changed = inf._sweep_window(eng, tr, cfg, seed, sweep, 0, n_rows, Comm())
+                if eng._dc["fallbacks"] > len(refused):
+                    refused.append((sweep, eng._dc.get("last_fallback")))
+                was = inf.DEVICE_COMMIT
+                inf.DEVICE_COMMIT = False
+                try:
+                    hchanged = inf._sweep_window(ref, host, cfg, seed, sweep, 0, n_rows, Comm())
+                finally:
+                    inf.DEVICE_COMMIT = was
+                assert changed == hchanged, (sweep, changed, hchanged)
+                _same_state(tr, host, f"1M rows, sweep {sweep}: device-resident commit vs host commit")
+            with capsys.disabled():
+                print(f"[own-init 1M] 3 sweeps committed on the device == host commits ({changed} referents changed in the last one); "
+                      f"device commits {eng._dc['commits']}, refused {refused} (bit 4 = PCC_FB_CAPACITY: the first commit after a "
+                      f"table was uploaded may find its spare rows short; the host commits that sweep and the next upload gives room)")
+            # a refusal is only ever the capacity of a freshly uploaded table (never a record / dummy refusal on this workload)
+            assert len(refused) <= 1 and all(r[1] == 4 for r in refused), refused
+            assert eng._dc["commits"] - eng._dc["fallbacks"] >= 2, eng._dc
+        finally:
+            ref.close()
     finally:
         eng.close()
