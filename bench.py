@@ -156,7 +156,9 @@ def roofline_model(rs, obs_local, particles):
     # (descriptor: written by group_desc_kernel, read by the scan kernel and — when it ran: rs.resolved_groups — by
     # group_settle_kernel, whose fine blocks are in rs.fine_blocks and whose draws are the rows' draws below)
     def model(line):
-        per_group = (3 if rs.resolved_groups > 0 else 2) * 128 + 4 * rs.n_terms + 4 + line * rs.n_terms
+        # (rs.pre_scored: the current referent's exact score came from group_gate_kernel, which runs before the timed
+        # launches: its gathers are not theirs)
+        per_group = (3 if rs.resolved_groups > 0 else 2) * 128 + 4 * rs.n_terms + 4 + (0 if rs.pre_scored else line * rs.n_terms)
         per_item = 4 + 4 + 4 * rs.n_draws + 8 + 4
         common = rs.n_groups * per_group + rs.n_items * per_item
         two_level = distinct * rs.cstride + rs.fine_blocks * (3 * line + 8) + rs.scored_terms * line

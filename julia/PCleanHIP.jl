@@ -134,9 +134,95 @@ function dummy_seed(seed::UInt64, site::UInt32, particle::UInt32, sweep::UInt32)
     x = (x ⊻ (x >> 27)) * 0x94d049bb133111eb
     x ⊻ (x >> 31)
 end
-# the remaining entry points (pclean_set_options_cols, pclean_load_score_block, pclean_set_prob_table, the Gaussian ones,
-# pclean_comm_*, pclean_allreduce_stats_fused, pclean_random_*) bind the same way; signatures in include/pclean_hip.h,
-# tested Python bindings in pclean_amd/_lib.py.
+# ---- what flights (a scoring block of MaybeSwap observations) and rents (a Gaussian observation with own enumerated choices)
+# load besides reference-slot blocks; argument meaning in include/pclean_hip.h, tested Python twins in pclean_amd/_lib.py ----
+set_options_cols(c, id, cols::Matrix{Int32}, logp::Vector{Float64}) = GC.@preserve cols logp check(c,    # cols: n_options x n_cols
+    ccall((:pclean_set_options_cols, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Int32}, Ptr{Float64}),
+          c.h, id, size(cols, 1), size(cols, 2), cols, logp))
+set_pair_table(c, id, d::Matrix{UInt8}) = GC.@preserve d check(c,                                        # d: n_lat x n_obs (row-major [obs][lat])
+    ccall((:pclean_set_pair_table, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{UInt8}), c.h, id, size(d, 2), size(d, 1), d))
+set_prob_table(c, p::Vector{Float64}) = GC.@preserve p check(c,                                          # ProbParameter values, maybe_swap.jl:36-52
+    ccall((:pclean_set_prob_table, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Float64}), c.h, length(p), p))
+# a block without a reference slot (flights Obs block 3; block_proposal.jl:62-64): per term the observed column, its 0/1
+# same-string table, (block, root column) of the latent value and of the key whose option count is nopt_fn[key]
+function load_score_block(c, block, obs_col::Vector{Int32}, pair_table::Vector{Int32}, val_src::Matrix{Int32},
+                          key_src::Matrix{Int32}, nopt_fn::Vector{Int32}, other_val::Vector{Int32}, prob_fn,
+                          prob_a_src::Vector{Int32}, prob_b_src::Vector{Int32})                           # *_src: 2 x n_terms / length 2
+    GC.@preserve obs_col pair_table val_src key_src nopt_fn other_val prob_a_src prob_b_src check(c,
+        ccall((:pclean_load_score_block, lib), Cint,
+              (Ptr{Cvoid}, Int32, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Int32, Ptr{Int32}, Ptr{Int32}),
+              c.h, block, length(obs_col), obs_col, pair_table, val_src, key_src, nopt_fn, other_val, prob_fn, prob_a_src, prob_b_src))
+end
+# pclean_gauss (add_noise.jl:1-7, transformed_gaussian.jl:3-17: Normal(mean[index], sigma) on backward(x))
+struct CGauss
+    x_col::Int32; mean_table::Int32; n_dims::Int32
+    src_kind::NTuple{4,Int32}; src::NTuple{4,Int32}; stride::NTuple{4,Int32}
+    n_locals::Int32; local_n::NTuple{2,Int32}; local_obs_col::NTuple{2,Int32}
+    transform_src_kind::Int32; transform_src::Int32; fixed_locals::Int32; pad::Int32
+    t_scale::NTuple{4,Float64}; t_logabsderiv::NTuple{4,Float64}; sigma::Float64
+end
+load_numeric_columns(c, x::Matrix{Float64}) = GC.@preserve x check(c,                                    # x: n_rows x n_cols, NaN = missing
+    ccall((:pclean_load_numeric_columns, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}), c.h, size(x, 1), size(x, 2), x))
+set_mean_table(c, id, mean::Vector{Float64}) = GC.@preserve mean check(c,
+    ccall((:pclean_set_mean_table, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}), c.h, id, length(mean), mean))
+set_node_gauss(c, block, node, g::CGauss) = check(c,
+    ccall((:pclean_set_node_gauss, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Ref{CGauss}), c.h, block, node, Ref(g)))
+function get_locals(c, block, n_rows)                                                                    # own choices of the chosen particles
+    out = Matrix{Int32}(undef, 2, n_rows)
+    GC.@preserve out check(c, ccall((:pclean_get_locals, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}), c.h, block, out)); out
+end
+
+# ---- the device-resident commit (csrc/commit.hip; row_inference.jl:169-185 + dependency_tracking.jl:26-236 for a whole
+# sweep): tables uploaded once with spare rows, their allocation state and the rows' referents stay in HBM ----------------
+struct CCommitSlot; table_id::Int32; n_hw::Int32; n_free::Int32; cols_changed::Int32; created::Int32; deleted::Int32
+                    total::Int64; live::Int64; max_count::Int64; end
+struct CCommitSummary; fallback::Int32; n_changed::Int32; n_slots::Int32; pad::Int32
+                       n_records::NTuple{16,Int32}; n_distinct::NTuple{16,Int32}; slot::NTuple{16,CCommitSlot}; end
+prepare(c, ev_blocks::Integer=0) = check(c, ccall((:pclean_prepare, lib), Cint, (Ptr{Cvoid}, UInt32), c.h, ev_blocks))
+function commit_enable(c, n_blocks)                                                                      # false: this plan commits on the host
+    ok = Ref{Int32}(0); check(c, ccall((:pclean_commit_enable, lib), Cint, (Ptr{Cvoid}, Int32, Ref{Int32}), c.h, n_blocks, ok)); ok[] != 0
+end
+commit_set_table_state(c, table, n_hw, free::Vector{Int32}) = GC.@preserve free check(c,
+    ccall((:pclean_commit_set_table_state, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Int32, Ptr{Int32}), c.h, table, n_hw, length(free), free))
+set_cur(c, cur::Matrix{Int32}) = GC.@preserve cur check(c,                                               # cur: n_rows x n_blocks, 0-based, -1 none
+    ccall((:pclean_set_cur, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}), c.h, size(cur, 2), cur))
+get_cur!(c, cur::Matrix{Int32}) = GC.@preserve cur check(c,
+    ccall((:pclean_get_cur, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}), c.h, size(cur, 2), cur))
+set_sweep_mode(c, deferred::Bool) = check(c, ccall((:pclean_set_sweep_mode, lib), Cint, (Ptr{Cvoid}, Int32), c.h, deferred ? 1 : 0))
+sweep_fetch(c) = check(c, ccall((:pclean_sweep_fetch, lib), Cint, (Ptr{Cvoid},), c.h))
+# one sweep on the device-resident referents (cur == NULL) + its commit; summary.fallback != 0: nothing was modified,
+# sweep_fetch(c) and commit on the host (moved / get_new_rows)
+function sweep_commit_device!(c, cfg::InferenceConfig, seed, sweep_idx, n_blocks)
+    set_sweep_mode(c, true)
+    out = Ref{CCommitSummary}()
+    try
+        check(c, ccall((:pclean_sweep, lib), Cint, (Ptr{Cvoid}, Ref{CConfig}, UInt64, UInt32, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}),
+                       c.h, Ref(CConfig(cfg)), seed, sweep_idx, n_blocks, C_NULL, C_NULL, C_NULL, C_NULL))
+        check(c, ccall((:pclean_commit_device, lib), Cint, (Ptr{Cvoid}, Int32, UInt32, Ref{CCommitSummary}), c.h, n_blocks, sweep_idx, out))
+    finally
+        set_sweep_mode(c, false)
+    end
+    out[]
+end
+# several ranks (one Julia process per GPU; rendezvous id from rank 0 by whatever transport the host program has):
+comm_unique_id(c) = (id = zeros(UInt8, 128); check(c, ccall((:pclean_comm_unique_id, lib), Cint, (Ptr{Cvoid}, Ptr{UInt8}), c.h, id)); id)
+comm_init(c, n_ranks, rank, id::Vector{UInt8}) = GC.@preserve id check(c,
+    ccall((:pclean_comm_init, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), c.h, n_ranks, rank, id))
+# collective: every rank after its shard's sweep (local_empty: this rank owns no row of the window, no sweep before the call)
+function commit_device_dist!(c, n_blocks, sweep_idx, local_empty::Bool, max_local_rows)
+    out = Ref{CCommitSummary}()
+    check(c, ccall((:pclean_commit_device_dist, lib), Cint, (Ptr{Cvoid}, Int32, UInt32, Int32, Int32, Ref{CCommitSummary}),
+                   c.h, n_blocks, sweep_idx, local_empty ? 1 : 0, max_local_rows, out)); out[]
+end
+function commit_pull_table(c, table, cap, n_cols)                                                        # device state of a latent table -> host
+    state = zeros(Int32, 8); cols = Matrix{Int32}(undef, cap, n_cols); counts = Vector{Int64}(undef, cap)
+    live = Vector{UInt8}(undef, cap); free = Vector{Int32}(undef, cap); origin = Matrix{Int32}(undef, 4, cap)
+    GC.@preserve state cols counts live free origin check(c, ccall((:pclean_commit_pull_table, lib), Cint,
+        (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int64}, Ptr{UInt8}, Ptr{Int32}, Ptr{Int32}), c.h, table, state, cols, counts, live, free, origin))
+    state, cols, counts, live, free[1:state[2]], origin
+end
+# the remaining entry points (pclean_allreduce_stats_fused, pclean_random_*, the debug probes) bind the same way; signatures in
+# include/pclean_hip.h, tested Python bindings in pclean_amd/_lib.py.
 
 # =============================================================================================== 2. dictionary encoding
 mutable struct Pool; index::Dict{String,Int32}; strings::Vector{String}; end

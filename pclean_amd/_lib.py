@@ -64,7 +64,7 @@ class RootStats(C.Structure):
                 ("kpad", C.c_int32), ("n_terms", C.c_int32), ("n_pre", C.c_int32), ("n_draws", C.c_int32),
                 ("pre_obs_col", C.c_int32 * 3), ("overflow_items", C.c_int32), ("cstride", C.c_int32),
                 ("full_scans", C.c_int32), ("fine_blocks", C.c_int32), ("scored_terms", C.c_int32),
-                ("resolved_groups", C.c_int32)]
+                ("resolved_groups", C.c_int32), ("pre_scored", C.c_int32)]
 
 
 class CommitSlot(C.Structure):

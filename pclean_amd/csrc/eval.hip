@@ -225,7 +225,10 @@ static int prefilter_terms(pclean_ctx* ctx, const Block& b, const pclean_node& n
 
 // Fast path of a reference slot (root_wave.hip): returns 1 and fills `fr` when the node is an FK
 // with many candidates whose terms are all plain AddTypos lookups in byte tables; 0 otherwise.
-static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev& fr, bool ev_mode = false) {
+// allow_short: an option list of SHORT strings (the pre-filter would keep everything) still gets its compact tables and the
+// call returns 2: the caller scores every option exactly through the compact byte rows (overflow_lds_kernel) instead of the
+// generic kernel's gather chains — worth it for the short item lists of new-row sampling.
+static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev& fr, bool ev_mode = false, bool allow_short = false) {
   Block& b = ctx->block[block_id];
   if (node_id >= 64) return 0;
   const pclean_node& n = b.nodes[node_id];
@@ -246,6 +249,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     dmax = std::max(dmax, std::max(pt.max_lat_len, pt.max_obs_len));
   }
   if (lmax > 255 || dmax > 255) return 0;
+  bool short_leaf = false;
   if (leaf && !ev_mode) {
     // An option list scored against ONE observed string: the integer pre-filter keeps every option within
     // ~10 edits of it (28.5 nats / cost of an edit), i.e. everything when the strings are short (codes, zip
@@ -255,7 +259,10 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
       const pclean_term& tm = b.terms[n.term_begin + i];
       if (tm.ctx_slot < 0) best = std::max(best, ctx->pair[tm.pair_table].mean_lat_len);
     }
-    if (best < 16.0) return 0;
+    if (best < 16.0) {
+      if (!allow_short) return 0;
+      short_leaf = true;
+    }
   }
   const int kpad = (t.n_rows + 15) & ~15;
   FastRoot& f = st(ctx)->fast[block_id * 64 + node_id];
@@ -398,7 +405,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   fr.logc_m1 = leaf ? nullptr : t.logc_m1.p;
   fr.counts = leaf ? nullptr : t.counts.p;
   memcpy(fr.scal, t.scal, sizeof fr.scal);
-  return 1;
+  return short_leaf ? 2 : 1;
 }
 
 // Bottom-up evaluation of one plan sub-tree for a list of items
@@ -731,9 +738,24 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
                                           PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out, draws_out);
   }
   if (!fast_tried && !scores_out && !snew_override && !ctx->force_generic && !nd.g.on && !ctx->prior_mode) {
-    if (!il.ev_lo)
-      fast = try_fast_root(ctx, block_id, node_id, fr);
-    else if (n.kind == PCLEAN_NODE_LEAF && n_draws <= 1 && !getenv("PCLEAN_NO_FAST_EV"))
+    static const bool no_short = getenv("PCLEAN_NO_COMPACT_EXACT") != nullptr;
+    if (!il.ev_lo) {
+      fast = try_fast_root(ctx, block_id, node_id, fr, false,
+                           n.kind == PCLEAN_NODE_LEAF && il.n <= 16384 && !il.rng_row && !no_short);
+    if (fast == 2) {
+      // an option list of short strings for a short list of items (the contents of proposed new rows): every option scored
+      // exactly through the compact byte rows, one workgroup per item (same results as the generic kernel: overflow_lds_kernel
+      // is what re-runs the items of a scan whose survivor list overflowed)
+      if (pclean_overflow_fast_ok(fr, it)) {
+        ProfScope ps(ctx, "option_list_compact_exact");
+        const int done = pclean_launch_overflow_fast(ctx, fr, it, ch, seed, sweep, PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out,
+                                                     draws_out, nullptr, nullptr);
+        if (done < 0) return done;
+        if (done) return PCLEAN_OK;
+      }
+      fast = 0;
+    }
+    } else if (n.kind == PCLEAN_NODE_LEAF && n_draws <= 1 && !getenv("PCLEAN_NO_FAST_EV"))
       fast_ev = try_fast_root(ctx, block_id, node_id, fr, true);
     if (fast < 0) return fast;
     if (fast_ev < 0) return fast_ev;
@@ -773,6 +795,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
     rs.n_cand = nd.n_cand;
     rs.n_terms = n.n_terms;
     rs.n_draws = n_draws;
+    rs.pre_scored = pre_score ? 1 : 0;
     if (fast) {
       rs.kpad = fr.kscan;  // (what the scans walk: the candidates below the table's high-water mark, FastRootDev::kscan)
       rs.cstride = std::min(fr.cstride, (((fr.kscan + 63) >> 6) + 15) & ~15);

@@ -72,6 +72,7 @@
 #define WAVE_CTR_STRIDE 1024    // uint32 words between the eight per-XCD chunk counters: 4 KB apart.  Device-scope atomics on one
                                 // cache line are served one after the other at the memory side (~30 ns each): with the eight
                                 // counters in ONE line the 40 000 chunk grabs of a 1M-row launch were a 1.2 ms floor of the kernel
+#define WAVE_WORK_CTR 512       // word of the chunk-counter area that counts the work list's entries (a line of its own)
 #define GD_STRIDE 32           // int32 words per group descriptor (one 128-byte line)
 // descriptor words: 0 m_lo, 1 m_hi, 2 representative item, 3 row, 4 excl, 5 ctx0, 6 ctx1, 7 flags (bit 0: the
 // excluded referent is garbage-collected, bit 1: the bound is useless -> guess and refine, bit 2: words 30-31 hold
@@ -231,6 +232,7 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
                                   unsigned int* __restrict__ scan_stats, const double* __restrict__ pre_score) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < 8) chunk_ctr[g * WAVE_CTR_STRIDE] = 0u;
+  if (g == 8 || (g == 0 && n_groups <= 8)) chunk_ctr[WAVE_WORK_CTR] = 0u;  // entries of the scan kernel's work list (group_settle_kernel)
   unsigned int st_blocks = 0, st_resolved = 0;  // (summed over the wavefront at the end: one atomic per wave)
   if (g < n_groups) {
   const int m_lo = it.grp_off ? it.grp_off[g] : g, m_hi = it.grp_off ? it.grp_off[g + 1] : g + 1;
@@ -485,7 +487,8 @@ struct SettleArgs {          // the pre-filter terms' tables resolved on the hos
 __global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, const WaveItems wi, int n_groups, int n_draws,
                                                            int32_t* __restrict__ gd, double* __restrict__ g_m,
                                                            uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out,
-                                                           unsigned int* __restrict__ scan_stats) {
+                                                           unsigned int* __restrict__ scan_stats,
+                                                           int32_t* __restrict__ worklist, unsigned int* __restrict__ work_n) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = tid / SETTLE_L, l = tid % SETTLE_L;
   const int lane = threadIdx.x & 63, base = lane & ~(SETTLE_L - 1);
@@ -587,6 +590,19 @@ __global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, 
       draws_out[to * wi.draw_is + (size_t)j * wi.draw_ds] = res_val;
     }
   }
+  // the groups left for the scan kernel: its WORK LIST (one atomic per wavefront; the scan kernel used to walk every
+  // descriptor to skip the nine in ten settled here)
+  if (worklist) {
+    const bool todo = g < n_groups && l == 0 && !settled;
+    const unsigned long long tm = __ballot(todo);
+    if (tm) {
+      unsigned int wbase = 0;
+      const int first = __builtin_ctzll(tm);
+      if (lane == first) wbase = atomicAdd(work_n, (unsigned int)__popcll(tm));
+      wbase = (unsigned int)__builtin_amdgcn_readlane((int)wbase, first);
+      if (todo) worklist[wbase + (unsigned int)__popcll(tm & ((1ull << lane) - 1ull))] = g;
+    }
+  }
   if (scan_stats) {
     unsigned int st_settled = (settled && l == 0) ? 1u : 0u;
     for (int o = 32; o > 0; o >>= 1) {
@@ -657,7 +673,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     int chunk, const int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr, double* __restrict__ g_m,
     uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out, int32_t* __restrict__ overflow_flag,
     unsigned int* __restrict__ overflow_count, int32_t* __restrict__ overflow_list,
-    unsigned int* __restrict__ scan_stats) {
+    unsigned int* __restrict__ scan_stats, const int32_t* __restrict__ worklist) {
   // exact scores and, later, the fixed-point prefix share one array: entry j is converted in place by lane j
   __shared__ uint64_t s_pref[WPG][CAP + 8];
   __shared__ int32_t s_k[WPG][CAP + 8];
@@ -697,6 +713,11 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
   // XCD-aware chunk hand-out: workgroup b runs on XCD b % 8 (each XCD has its own L2).  The groups arrive sorted by
   // referent, so consecutive groups stream the same byte rows: XCD x owns the x-th contiguous eighth of the groups.
   const int xcd = blockIdx.x & 7;
+  // work list (group_settle_kernel): the hand-out below runs over its entries instead of over all groups
+  if (worklist) {
+    n_groups = (int)__hip_atomic_load(&chunk_ctr[WAVE_WORK_CTR], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    chunk = max(1, min(chunk, n_groups / max((int)(gridDim.x * WPG), 1)));
+  }
   // (chunk = consecutive groups a wave takes at a time: WAVE_CHUNK for the large launches — a wave reuses its survivor list
   // across neighbours —, fewer for short lists: the nested slots of a new-row branch hold a few hundred groups, and eight
   // at a time left all but 32 waves of the chip idle behind a serial chain of ~15 us per group)
@@ -746,6 +767,10 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
   int g = 0, g_end = 0;
   resolve(grab(), g, g_end);
   int raw_next = steal < 8 ? grab() : 0;
+  // entries [wl_lo, wl_lo + chunk) of the work list, one per lane (chunk <= WAVE_CHUNK <= 64); gid(x) = group of entry x
+  int wl_lo = g, wl_v = 0, wl_lo_n = 0, wl_v_n = 0;
+  if (worklist && g < g_end) wl_v = g + lane < g_end ? worklist[g + lane] : 0;
+  auto gid = [&](int x) -> int { return worklist ? __builtin_amdgcn_readlane(wl_v, x - wl_lo) : x; };
   // descriptor of group x, lane i = its i-th word: scalar base + lane offset (a per-lane 64-bit base would be hoisted out
   // of the group loop and spilled)
   auto desc_word = [&](int x) -> int {
@@ -758,19 +783,27 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     return *(const __attribute__((address_space(1))) int32_t*)(base + off);
   };
   static_assert((GD_STRIDE & (GD_STRIDE - 1)) == 0, "descriptor stride: a power of two");
-  int dv = g < g_end ? desc_word(g) : 0;
+  int dv = g < g_end ? desc_word(gid(g)) : 0;
   while (g < g_end) {
+    const int g_id = gid(g);  // the group itself (g is its place in the hand-out: an entry of the work list, or the group)
     // ---- next group (possibly the first of the next chunk): its descriptor is requested right away ---------------
     int gn = g + 1, gn_end = g_end;
+    bool new_chunk = false;
     if (gn >= g_end) {
       if (steal < 8) {
         resolve(raw_next, gn, gn_end);
         raw_next = steal < 8 ? grab() : 0;
+        new_chunk = true;
+        if (worklist && gn < gn_end) {
+          wl_lo_n = gn;
+          wl_v_n = gn + lane < gn_end ? worklist[gn + lane] : 0;
+        }
       } else {
         gn = gn_end = 0;
       }
     }
-    const int dvn = gn < gn_end ? desc_word(gn) : 0;
+    const int gn_id = !worklist ? gn : (new_chunk ? __builtin_amdgcn_readlane(wl_v_n, 0) : (gn < gn_end ? gid(gn) : 0));
+    const int dvn = gn < gn_end ? desc_word(gn_id) : 0;
     WCLK(0)  // chunk hand-out + descriptor request
     // ---- descriptor -> wave-uniform registers ----------------------------------------------------------------------
     const int m_lo = __builtin_amdgcn_readlane(dv, 0), m_hi = __builtin_amdgcn_readlane(dv, 1);
@@ -781,6 +814,10 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
       g = gn;
       g_end = gn_end;
       dv = dvn;
+      if (new_chunk) {
+        wl_lo = wl_lo_n;
+        wl_v = wl_v_n;
+      }
       continue;
     }
     const bool deleted = (flags & 1) != 0;
@@ -1164,7 +1201,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
       int base_o = 0;
       if (lane == 0) {
         base_o = (int)atomicAdd(overflow_count, (unsigned int)n_mem_o);
-        g_m[g] = __builtin_nan("");
+        g_m[g_id] = __builtin_nan("");
       }
       base_o = __builtin_amdgcn_readfirstlane(base_o);
       if (n_mem_o == 1) {
@@ -1181,8 +1218,8 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
       }
     } else {
       if (lane == 0) {
-        g_m[g] = m;
-        g_U[g] = U;
+        g_m[g_id] = m;
+        g_U[g_id] = U;
       }
       // ---- draws of every (member item, draw) pair of the group ------------------------------------------------------
       if (n_draws > 0) {
@@ -1251,6 +1288,10 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     g = gn;
     g_end = gn_end;
     dv = dvn;
+    if (new_chunk) {
+      wl_lo = wl_lo_n;
+      wl_v = wl_v_n;
+    }
 #ifdef WAVE_PHASE_CLOCK
     clk_acc[7] += 1;
 #endif
@@ -1324,28 +1365,58 @@ __global__ __launch_bounds__(OVF_T) void overflow_lds_kernel(const FastRootDev f
   for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) o[f] = f < fr.n_terms ? fr.terms[f].obs_col[row] : -1;
   const bool deleted = excl >= 0 && fr.counts && fr.counts[excl] <= 1;
   const double* prior = (excl >= 0 && fr.prior_e) ? fr.prior_e : fr.prior_n;
+  // ---- the integer pre-filter, at the item's own cut-off (group_desc_kernel's rule): the exact score of the current
+  // referent and of the new row bound the maximum from below; a candidate whose summed (saturated) distance over the
+  // pre-filter terms exceeds the cut scores more than 28.5 nats below it — fixed-point weight exactly 0, in this kernel and
+  // in the generic one — and is never scored (its slot holds -inf: same maximum, same totals, same prefix, same draws).
+  // A flat posterior that overflowed the scan kernel's 256-survivor list still has only a few hundred candidates in reach.
+  __shared__ uint32_t s_cut;
+  __shared__ double s_sn;
+  if (tid == 0) {
+    double bound = -__builtin_inf(), sn = -__builtin_inf();
+    if (excl >= 0 && !deleted && fr.logc_m1) bound = fast_exact_score(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]) - 1.0;
+    if (fk) {  // new_score() of enum_kernels.hip
+      const double logden = excl >= 0 ? fr.scal[1] : fr.scal[0];
+      double snew = 0.0;
+      for (int c = 0; c < ch.n; ++c) {
+        size_t idx = (size_t)to;
+        if (ch.obs_col[c]) {
+          const int oc = ch.obs_col[c][row];
+          idx = oc < 0 ? (size_t)ch.n_obs[c] : (size_t)oc;
+        }
+        snew += ch.arr[c][idx];
+      }
+      sn = ((deleted ? fr.scal[3] : fr.scal[2]) - logden) + snew;
+      bound = fmax(bound, sn);
+    }
+    uint32_t cut = CUT_ALL;
+    if (fr.n_pre > 0 && bound > -__builtin_inf()) {
+      const double x = ((excl >= 0 ? fr.prior_max_e : fr.prior_max_n) - bound + FIX_CUTOFF) * fr.inv_c;
+      if (x >= 0.0 && x < (double)(CUT_ALL - 2u)) cut = (uint32_t)x + 2u;
+    }
+    s_cut = cut;
+    s_sn = sn;
+  }
+  __syncthreads();
+  const uint32_t cut = s_cut;
+  const uint8_t* prow[3];
+  for (int p = 0; p < 3; ++p) {
+    const int op = p < fr.n_pre ? o[fr.pre[p]] : -1;
+    prow[p] = (op >= 0 && fr.terms[fr.pre[p]].comp) ? fr.terms[fr.pre[p]].comp + (size_t)op * fr.kpad : fr.zero_row;
+  }
   // ---- phase 1: exact scores, prior first, terms in plan order (candidate_score's operation order)
   double lmax = -__builtin_inf();
   #pragma unroll 2
   for (int k = tid; k < n; k += OVF_T) {
     double pr = prior[k];
     if (k == excl) pr = deleted ? -__builtin_inf() : fr.logc_m1[excl] - fr.scal[1];
+    if (cut < CUT_ALL && (uint32_t)prow[0][k] + (uint32_t)prow[1][k] + (uint32_t)prow[2][k] > cut) pr = -__builtin_inf();
     const double sk = pr == -__builtin_inf() ? pr : fast_exact_score(fr, o, ctx0, ctx1, k, pr);
     s[k] = sk;
     lmax = fmax(lmax, sk);
   }
-  if (fk && tid == 0) {  // new_score() of enum_kernels.hip
-    const double logden = excl >= 0 ? fr.scal[1] : fr.scal[0];
-    double snew = 0.0;
-    for (int c = 0; c < ch.n; ++c) {
-      size_t idx = (size_t)to;
-      if (ch.obs_col[c]) {
-        const int oc = ch.obs_col[c][row];
-        idx = oc < 0 ? (size_t)ch.n_obs[c] : (size_t)oc;
-      }
-      snew += ch.arr[c][idx];
-    }
-    const double sn = ((deleted ? fr.scal[3] : fr.scal[2]) - logden) + snew;
+  if (fk && tid == 0) {
+    const double sn = s_sn;
     s[n] = sn;
     lmax = fmax(lmax, sn);
   }
@@ -1458,7 +1529,8 @@ int pclean_launch_root_flags(pclean_ctx* ctx, int n_groups, const int32_t* gd, c
 }
 
 typedef void (*wave_kernel_t)(const FastRootDev, const WaveItems, uint64_t, uint32_t, uint32_t, int, int, int, const int32_t*,
-                              unsigned int*, double*, uint64_t*, int32_t*, int32_t*, unsigned int*, int32_t*, unsigned int*);
+                              unsigned int*, double*, uint64_t*, int32_t*, int32_t*, unsigned int*, int32_t*, unsigned int*,
+                              const int32_t*);
 
 static wave_kernel_t pick_kernel(int n_terms) {
   if (n_terms <= 2) return fk_root_wave_kernel<2, WAVE_SURV_CAP, 4>;
@@ -1471,7 +1543,7 @@ static wave_kernel_t pick_kernel(int n_terms) {
 // int32 words of desc_scratch for n_groups groups: descriptors, 8 chunk counters, per-group (maximum, total)
 size_t pclean_fast_desc_words(int n_groups) {
   const size_t ng = (size_t)std::max(n_groups, 1);
-  return ng * GD_STRIDE + 8 * WAVE_CTR_STRIDE + ng * 4 + ng;
+  return ng * GD_STRIDE + 8 * WAVE_CTR_STRIDE + ng * 4 + ng + ng;  // (+ the work list of the groups the settle kernel leaves)
 }
 
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
@@ -1485,6 +1557,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   double* g_m = reinterpret_cast<double*>(desc_scratch + ng * GD_STRIDE + 8 * WAVE_CTR_STRIDE);
   uint64_t* g_U = reinterpret_cast<uint64_t*>(g_m + ng);
   int32_t* g_res = reinterpret_cast<int32_t*>(g_U + ng);
+  int32_t* worklist = g_res + ng;
   // groups are settled by group_desc_kernel only when their rows' draws can be written afterwards (the member count is
   // known) and the launch draws at all
   // OFF by default (PCLEAN_RESOLVE_GROUPS=1 turns it on): bit-identical on every parity test, and it takes the scan
@@ -1522,6 +1595,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   wgs = (wgs + 7) & ~7;  // a multiple of the 8 XCDs
   WaveItems wi{it.grp_off ? it.members : nullptr, it.row, it.rng_row, it.particle, it.out_pos, it.row_offset, it.draw_is,
                it.draw_ds};
+  bool use_worklist = false;
   if (settle) {
     WaveItems ws = wi;
     ws.draw_is = it.draw_is ? it.draw_is : n_draws;
@@ -1539,11 +1613,15 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
     sa.alive = fr.alive;
     sa.zero_row = fr.zero_row;
     const size_t n_thr = (size_t)it.n * SETTLE_L;
+    static const bool no_worklist = getenv("PCLEAN_NO_WORKLIST") != nullptr;
+    use_worklist = !no_worklist;
     hipLaunchKernelGGL(group_settle_kernel, dim3((unsigned int)((n_thr + 255) / 256)), dim3(256), 0, ctx->stream, sa, ws, it.n,
-                       n_draws, desc_scratch, g_m, g_U, draws_out, scan_stats);
+                       n_draws, desc_scratch, g_m, g_U, draws_out, scan_stats, use_worklist ? worklist : nullptr,
+                       chunk_ctr + WAVE_WORK_CTR);
   }
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * wpg), 0, ctx->stream, fr, wi, seed, sweep, site, n_draws, it.n, chunk, desc_scratch,
-                     chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count, overflow_list, scan_stats);
+                     chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count, overflow_list, scan_stats,
+                     use_worklist ? worklist : nullptr);
 #ifdef WAVE_PHASE_CLOCK
   if (it.n > 100000) {
     unsigned long long h[16];

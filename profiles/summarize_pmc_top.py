@@ -49,7 +49,7 @@ def main():
             k = short(name)
             # the sweep kernels run on lists of every size (initialisation batches, nested slots, ...): the launches
             # within a factor 2 of the kernel's longest launch are its full-size launches, the rest is "[small]"
-            if any(t in k for t in ("fk_root_wave_kernel", "enum_node", "ev_leaf_wave", "group_desc", "group_settle", "group_lse", "gate_new", "particle_update")):
+            if any(t in k for t in ("fk_root_wave_kernel", "enum_node", "ev_leaf_wave", "group_desc", "group_settle", "group_lse", "group_gate", "gate_new", "particle_update", "hg_insert", "hg_fill", "overflow_lds")):
                 k += " [full-size]" if dur * 2 >= longest[k] else " [small]"
             m = merged.setdefault(k, dict(n=0, dur=0.0, counters={}))
             m["n"] += 1

@@ -78,4 +78,6 @@ def test_batched_gpu_f1_matches_the_sequential_reference(name, capsys):
         with capsys.disabled():
             print(f"[f1 vs literal sequential] {name}: literal reference mean {lit[name]['f1_mean']:.4f}")
         assert abs(np.mean(got) - lit[name]["f1_mean"]) <= 0.005, (got, lit[name]["f1_mean"])
-    assert min(got) >= np.mean(want) - 0.01                              # and no seed more than 1 pt below the reference
+    # ... and no seed more than 1 pt below the reference's own worst seed (the reference's seeds spread by more than a point
+    # themselves: rents PG-20 0.6654 .. 0.6862)
+    assert min(got) >= min(want) - 0.01, (got, want)
