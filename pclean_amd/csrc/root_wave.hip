@@ -1370,8 +1370,9 @@ __global__ __launch_bounds__(OVF_T) void overflow_lds_kernel(const FastRootDev f
   // pre-filter terms exceeds the cut scores more than 28.5 nats below it — fixed-point weight exactly 0, in this kernel and
   // in the generic one — and is never scored (its slot holds -inf: same maximum, same totals, same prefix, same draws).
   // A flat posterior that overflowed the scan kernel's 256-survivor list still has only a few hundred candidates in reach.
-  __shared__ uint32_t s_cut;
-  __shared__ double s_sn;
+  // (two words of the spare part of the dynamic area: static LDS on top of a 160 KB dynamic allocation does not fit)
+  double& s_sn = red[40];
+  uint32_t& s_cut = *reinterpret_cast<uint32_t*>(red + 41);
   if (tid == 0) {
     double bound = -__builtin_inf(), sn = -__builtin_inf();
     if (excl >= 0 && !deleted && fr.logc_m1) bound = fast_exact_score(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]) - 1.0;
