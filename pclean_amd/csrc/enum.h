@@ -161,7 +161,8 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
                             int32_t* desc_scratch, int32_t* overflow_list,
-                            unsigned int* scan_stats = nullptr, int n_items = 0, const double* pre_score = nullptr);
+                            unsigned int* scan_stats = nullptr, int n_items = 0, const double* pre_score = nullptr,
+                            bool want_worklist = true, unsigned int* wl_stat = nullptr);
 // gate of the new-row branch per GROUP of `it` (grouped view), with the exact score of every group's current referent
 int pclean_launch_group_gate(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const GateDev& gt, int32_t* flag,
                              double* score_out);

@@ -225,10 +225,7 @@ static int prefilter_terms(pclean_ctx* ctx, const Block& b, const pclean_node& n
 
 // Fast path of a reference slot (root_wave.hip): returns 1 and fills `fr` when the node is an FK
 // with many candidates whose terms are all plain AddTypos lookups in byte tables; 0 otherwise.
-// allow_short: an option list of SHORT strings (the pre-filter would keep everything) still gets its compact tables and the
-// call returns 2: the caller scores every option exactly through the compact byte rows (overflow_lds_kernel) instead of the
-// generic kernel's gather chains — worth it for the short item lists of new-row sampling.
-static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev& fr, bool ev_mode = false, bool allow_short = false) {
+static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev& fr, bool ev_mode = false) {
   Block& b = ctx->block[block_id];
   if (node_id >= 64) return 0;
   const pclean_node& n = b.nodes[node_id];
@@ -249,7 +246,6 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     dmax = std::max(dmax, std::max(pt.max_lat_len, pt.max_obs_len));
   }
   if (lmax > 255 || dmax > 255) return 0;
-  bool short_leaf = false;
   if (leaf && !ev_mode) {
     // An option list scored against ONE observed string: the integer pre-filter keeps every option within
     // ~10 edits of it (28.5 nats / cost of an edit), i.e. everything when the strings are short (codes, zip
@@ -259,10 +255,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
       const pclean_term& tm = b.terms[n.term_begin + i];
       if (tm.ctx_slot < 0) best = std::max(best, ctx->pair[tm.pair_table].mean_lat_len);
     }
-    if (best < 16.0) {
-      if (!allow_short) return 0;
-      short_leaf = true;
-    }
+    if (best < 16.0) return 0;
   }
   const int kpad = (t.n_rows + 15) & ~15;
   FastRoot& f = st(ctx)->fast[block_id * 64 + node_id];
@@ -405,7 +398,7 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
   fr.logc_m1 = leaf ? nullptr : t.logc_m1.p;
   fr.counts = leaf ? nullptr : t.counts.p;
   memcpy(fr.scal, t.scal, sizeof fr.scal);
-  return short_leaf ? 2 : 1;
+  return 1;
 }
 
 // Bottom-up evaluation of one plan sub-tree for a list of items
@@ -738,24 +731,9 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
                                           PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out, draws_out);
   }
   if (!fast_tried && !scores_out && !snew_override && !ctx->force_generic && !nd.g.on && !ctx->prior_mode) {
-    static const bool no_short = getenv("PCLEAN_NO_COMPACT_EXACT") != nullptr;
-    if (!il.ev_lo) {
-      fast = try_fast_root(ctx, block_id, node_id, fr, false,
-                           n.kind == PCLEAN_NODE_LEAF && il.n <= 16384 && !il.rng_row && !no_short);
-    if (fast == 2) {
-      // an option list of short strings for a short list of items (the contents of proposed new rows): every option scored
-      // exactly through the compact byte rows, one workgroup per item (same results as the generic kernel: overflow_lds_kernel
-      // is what re-runs the items of a scan whose survivor list overflowed)
-      if (pclean_overflow_fast_ok(fr, it)) {
-        ProfScope ps(ctx, "option_list_compact_exact");
-        const int done = pclean_launch_overflow_fast(ctx, fr, it, ch, seed, sweep, PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out,
-                                                     draws_out, nullptr, nullptr);
-        if (done < 0) return done;
-        if (done) return PCLEAN_OK;
-      }
-      fast = 0;
-    }
-    } else if (n.kind == PCLEAN_NODE_LEAF && n_draws <= 1 && !getenv("PCLEAN_NO_FAST_EV"))
+    if (!il.ev_lo)
+      fast = try_fast_root(ctx, block_id, node_id, fr);
+    else if (n.kind == PCLEAN_NODE_LEAF && n_draws <= 1 && !getenv("PCLEAN_NO_FAST_EV"))
       fast_ev = try_fast_root(ctx, block_id, node_id, fr, true);
     if (fast < 0) return fast;
     if (fast_ev < 0) return fast_ev;
@@ -844,8 +822,17 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
       scan_stats = s->over_ctr.p + OVER_SLOTS;
       s->scan_stats_used = true;
     }
+    // the work list of the groups the settle kernel leaves pays when it settles most of them; how many it left last time
+    // comes back with the call's statistics (apply_over_stats)
+    FastRoot& fwl = s->fast[block_id * 64 + node_id];
+    unsigned int* wl_stat = nullptr;
+    if (!fwl.wl_off && node_id < 64 && s->over_rec.size() < OVER_SLOTS && s->over_ctr.p) {
+      wl_stat = s->over_ctr.p + s->over_rec.size();
+      s->over_rec.push_back(SweepState::OverRec{block_id, node_id, it.n, false, false, -1});  // min_items -1: a work-list record
+    }
+    if (fwl.wl_off > 0) --fwl.wl_off;
     rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag, over_count, desc,
-                                 over_list, scan_stats, il.n, pre_score);
+                                 over_list, scan_stats, il.n, pre_score, wl_stat != nullptr, wl_stat);
     if (time_it) {
       (void)hipEventRecord(s->ev1, ctx->stream);
       s->dbg_desc = desc;

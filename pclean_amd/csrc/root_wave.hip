@@ -72,7 +72,9 @@
 #define WAVE_CTR_STRIDE 1024    // uint32 words between the eight per-XCD chunk counters: 4 KB apart.  Device-scope atomics on one
                                 // cache line are served one after the other at the memory side (~30 ns each): with the eight
                                 // counters in ONE line the 40 000 chunk grabs of a 1M-row launch were a 1.2 ms floor of the kernel
-#define WAVE_WORK_CTR 512       // word of the chunk-counter area that counts the work list's entries (a line of its own)
+#define WAVE_WORK_CTR 512       // word of the chunk-counter area that counts the work list's entries
+#define WL_SEGS 64              // segments of the work list while group_settle_kernel appends to it ...
+#define WL_SEG_CTR(s) (16 + 32 * (s))  // ... and the word of the chunk-counter area that counts segment s (128 bytes apart)
 #define GD_STRIDE 32           // int32 words per group descriptor (one 128-byte line)
 // descriptor words: 0 m_lo, 1 m_hi, 2 representative item, 3 row, 4 excl, 5 ctx0, 6 ctx1, 7 flags (bit 0: the
 // excluded referent is garbage-collected, bit 1: the bound is useless -> guess and refine, bit 2: words 30-31 hold
@@ -232,7 +234,8 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
                                   unsigned int* __restrict__ scan_stats, const double* __restrict__ pre_score) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < 8) chunk_ctr[g * WAVE_CTR_STRIDE] = 0u;
-  if (g == 8 || (g == 0 && n_groups <= 8)) chunk_ctr[WAVE_WORK_CTR] = 0u;  // entries of the scan kernel's work list (group_settle_kernel)
+  if (g >= 8 && g < 8 + WL_SEGS) chunk_ctr[WL_SEG_CTR(g - 8)] = 0u;  // segment counters of the scan kernel's work list (group_settle_kernel)
+  if (g == 8 + WL_SEGS) chunk_ctr[WAVE_WORK_CTR] = 0u;
   unsigned int st_blocks = 0, st_resolved = 0;  // (summed over the wavefront at the end: one atomic per wave)
   if (g < n_groups) {
   const int m_lo = it.grp_off ? it.grp_off[g] : g, m_hi = it.grp_off ? it.grp_off[g + 1] : g + 1;
@@ -488,7 +491,8 @@ __global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, 
                                                            int32_t* __restrict__ gd, double* __restrict__ g_m,
                                                            uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out,
                                                            unsigned int* __restrict__ scan_stats,
-                                                           int32_t* __restrict__ worklist, unsigned int* __restrict__ work_n) {
+                                                           int32_t* __restrict__ worklist, unsigned int* __restrict__ work_n,
+                                                           int seg_cap) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = tid / SETTLE_L, l = tid % SETTLE_L;
   const int lane = threadIdx.x & 63, base = lane & ~(SETTLE_L - 1);
@@ -590,17 +594,27 @@ __global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, 
       draws_out[to * wi.draw_is + (size_t)j * wi.draw_ds] = res_val;
     }
   }
-  // the groups left for the scan kernel: its WORK LIST (one atomic per wavefront; the scan kernel used to walk every
-  // descriptor to skip the nine in ten settled here)
+  // the groups left for the scan kernel: its WORK LIST (the scan kernel used to walk every descriptor to skip the nine in
+  // ten settled here).  One atomic per WORKGROUP on one of WL_SEGS counters, 128 bytes apart — a single counter serves its
+  // atomics one after the other (~30 ns each: 42 000 of them were 0.48 ms when no group of a launch could be settled) —,
+  // each with its own segment of the list; worklist_pack_kernel makes the list dense.
   if (worklist) {
+    __shared__ unsigned int wl_cnt[4], wl_base;
+    const int wv = threadIdx.x >> 6;
     const bool todo = g < n_groups && l == 0 && !settled;
     const unsigned long long tm = __ballot(todo);
-    if (tm) {
-      unsigned int wbase = 0;
-      const int first = __builtin_ctzll(tm);
-      if (lane == first) wbase = atomicAdd(work_n, (unsigned int)__popcll(tm));
-      wbase = (unsigned int)__builtin_amdgcn_readlane((int)wbase, first);
-      if (todo) worklist[wbase + (unsigned int)__popcll(tm & ((1ull << lane) - 1ull))] = g;
+    if (lane == 0) wl_cnt[wv] = (unsigned int)__popcll(tm);
+    __syncthreads();
+    const int seg = blockIdx.x & (WL_SEGS - 1);
+    if (threadIdx.x == 0) {
+      const unsigned int tot = wl_cnt[0] + wl_cnt[1] + wl_cnt[2] + wl_cnt[3];
+      wl_base = tot ? atomicAdd(work_n + WL_SEG_CTR(seg), tot) : 0u;
+    }
+    __syncthreads();
+    if (todo) {
+      unsigned int at = wl_base + (unsigned int)__popcll(tm & ((1ull << lane) - 1ull));
+      for (int w = 0; w < wv; ++w) at += wl_cnt[w];
+      worklist[(size_t)seg * seg_cap + at] = g;
     }
   }
   if (scan_stats) {
@@ -614,6 +628,29 @@ __global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, 
       atomicAdd(&sl[1], st_blocks);
       atomicAdd(&sl[3], st_settled);
     }
+  }
+}
+
+// the segments of the work list -> one dense list (segment order; inside a segment the order the workgroups arrived in) and
+// its length in chunk_ctr[WAVE_WORK_CTR]; stat (optional): the length once more, for the host's statistics
+__global__ __launch_bounds__(1024) void worklist_pack_kernel(const int32_t* __restrict__ seg_list, int seg_cap,
+                                                             unsigned int* __restrict__ chunk_ctr, int32_t* __restrict__ dense,
+                                                             unsigned int* __restrict__ stat) {
+  __shared__ unsigned int off[WL_SEGS + 1];
+  if (threadIdx.x == 0) {
+    unsigned int run = 0;
+    for (int sgm = 0; sgm < WL_SEGS; ++sgm) {
+      off[sgm] = run;
+      run += chunk_ctr[WL_SEG_CTR(sgm)];
+    }
+    off[WL_SEGS] = run;
+    chunk_ctr[WAVE_WORK_CTR] = run;
+    if (stat) *stat = run;
+  }
+  __syncthreads();
+  for (int sgm = 0; sgm < WL_SEGS; ++sgm) {
+    const unsigned int n = off[sgm + 1] - off[sgm];
+    for (unsigned int j = threadIdx.x; j < n; j += 1024) dense[off[sgm] + j] = seg_list[(size_t)sgm * seg_cap + j];
   }
 }
 
@@ -1365,59 +1402,28 @@ __global__ __launch_bounds__(OVF_T) void overflow_lds_kernel(const FastRootDev f
   for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) o[f] = f < fr.n_terms ? fr.terms[f].obs_col[row] : -1;
   const bool deleted = excl >= 0 && fr.counts && fr.counts[excl] <= 1;
   const double* prior = (excl >= 0 && fr.prior_e) ? fr.prior_e : fr.prior_n;
-  // ---- the integer pre-filter, at the item's own cut-off (group_desc_kernel's rule): the exact score of the current
-  // referent and of the new row bound the maximum from below; a candidate whose summed (saturated) distance over the
-  // pre-filter terms exceeds the cut scores more than 28.5 nats below it — fixed-point weight exactly 0, in this kernel and
-  // in the generic one — and is never scored (its slot holds -inf: same maximum, same totals, same prefix, same draws).
-  // A flat posterior that overflowed the scan kernel's 256-survivor list still has only a few hundred candidates in reach.
-  // (two words of the spare part of the dynamic area: static LDS on top of a 160 KB dynamic allocation does not fit)
-  double& s_sn = red[40];
-  uint32_t& s_cut = *reinterpret_cast<uint32_t*>(red + 41);
-  if (tid == 0) {
-    double bound = -__builtin_inf(), sn = -__builtin_inf();
-    if (excl >= 0 && !deleted && fr.logc_m1) bound = fast_exact_score(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]) - 1.0;
-    if (fk) {  // new_score() of enum_kernels.hip
-      const double logden = excl >= 0 ? fr.scal[1] : fr.scal[0];
-      double snew = 0.0;
-      for (int c = 0; c < ch.n; ++c) {
-        size_t idx = (size_t)to;
-        if (ch.obs_col[c]) {
-          const int oc = ch.obs_col[c][row];
-          idx = oc < 0 ? (size_t)ch.n_obs[c] : (size_t)oc;
-        }
-        snew += ch.arr[c][idx];
-      }
-      sn = ((deleted ? fr.scal[3] : fr.scal[2]) - logden) + snew;
-      bound = fmax(bound, sn);
-    }
-    uint32_t cut = CUT_ALL;
-    if (fr.n_pre > 0 && bound > -__builtin_inf()) {
-      const double x = ((excl >= 0 ? fr.prior_max_e : fr.prior_max_n) - bound + FIX_CUTOFF) * fr.inv_c;
-      if (x >= 0.0 && x < (double)(CUT_ALL - 2u)) cut = (uint32_t)x + 2u;
-    }
-    s_cut = cut;
-    s_sn = sn;
-  }
-  __syncthreads();
-  const uint32_t cut = s_cut;
-  const uint8_t* prow[3];
-  for (int p = 0; p < 3; ++p) {
-    const int op = p < fr.n_pre ? o[fr.pre[p]] : -1;
-    prow[p] = (op >= 0 && fr.terms[fr.pre[p]].comp) ? fr.terms[fr.pre[p]].comp + (size_t)op * fr.kpad : fr.zero_row;
-  }
   // ---- phase 1: exact scores, prior first, terms in plan order (candidate_score's operation order)
   double lmax = -__builtin_inf();
   #pragma unroll 2
   for (int k = tid; k < n; k += OVF_T) {
     double pr = prior[k];
     if (k == excl) pr = deleted ? -__builtin_inf() : fr.logc_m1[excl] - fr.scal[1];
-    if (cut < CUT_ALL && (uint32_t)prow[0][k] + (uint32_t)prow[1][k] + (uint32_t)prow[2][k] > cut) pr = -__builtin_inf();
     const double sk = pr == -__builtin_inf() ? pr : fast_exact_score(fr, o, ctx0, ctx1, k, pr);
     s[k] = sk;
     lmax = fmax(lmax, sk);
   }
-  if (fk && tid == 0) {
-    const double sn = s_sn;
+  if (fk && tid == 0) {  // new_score() of enum_kernels.hip
+    const double logden = excl >= 0 ? fr.scal[1] : fr.scal[0];
+    double snew = 0.0;
+    for (int c = 0; c < ch.n; ++c) {
+      size_t idx = (size_t)to;
+      if (ch.obs_col[c]) {
+        const int oc = ch.obs_col[c][row];
+        idx = oc < 0 ? (size_t)ch.n_obs[c] : (size_t)oc;
+      }
+      snew += ch.arr[c][idx];
+    }
+    const double sn = ((deleted ? fr.scal[3] : fr.scal[2]) - logden) + snew;
     s[n] = sn;
     lmax = fmax(lmax, sn);
   }
@@ -1544,14 +1550,15 @@ static wave_kernel_t pick_kernel(int n_terms) {
 // int32 words of desc_scratch for n_groups groups: descriptors, 8 chunk counters, per-group (maximum, total)
 size_t pclean_fast_desc_words(int n_groups) {
   const size_t ng = (size_t)std::max(n_groups, 1);
-  return ng * GD_STRIDE + 8 * WAVE_CTR_STRIDE + ng * 4 + ng + ng;  // (+ the work list of the groups the settle kernel leaves)
+  // (+ the work list of the groups the settle kernel leaves: dense, and in WL_SEGS segments while it is being written)
+  return ng * GD_STRIDE + 8 * WAVE_CTR_STRIDE + ng * 4 + ng + ng + (ng + 16 * (WL_SEGS + 1) + 64);
 }
 
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
                             int32_t* desc_scratch, int32_t* overflow_list, unsigned int* scan_stats, int n_items,
-                            const double* pre_score) {
+                            const double* pre_score, bool want_worklist, unsigned int* wl_stat) {
   if (it.n <= 0) return PCLEAN_OK;
   const size_t ng = (size_t)it.n;
   unsigned int* chunk_ctr = reinterpret_cast<unsigned int*>(desc_scratch + ng * GD_STRIDE);
@@ -1615,10 +1622,14 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
     sa.zero_row = fr.zero_row;
     const size_t n_thr = (size_t)it.n * SETTLE_L;
     static const bool no_worklist = getenv("PCLEAN_NO_WORKLIST") != nullptr;
-    use_worklist = !no_worklist;
-    hipLaunchKernelGGL(group_settle_kernel, dim3((unsigned int)((n_thr + 255) / 256)), dim3(256), 0, ctx->stream, sa, ws, it.n,
-                       n_draws, desc_scratch, g_m, g_U, draws_out, scan_stats, use_worklist ? worklist : nullptr,
-                       chunk_ctr + WAVE_WORK_CTR);
+    use_worklist = !no_worklist && want_worklist;
+    const unsigned int n_wg = (unsigned int)((n_thr + 255) / 256);
+    const int seg_cap = (int)((n_wg / WL_SEGS + 1) * 16);  // 16 groups per workgroup, workgroups dealt round-robin
+    int32_t* seg_list = worklist + ng;
+    hipLaunchKernelGGL(group_settle_kernel, dim3(n_wg), dim3(256), 0, ctx->stream, sa, ws, it.n, n_draws, desc_scratch, g_m, g_U,
+                       draws_out, scan_stats, use_worklist ? seg_list : nullptr, chunk_ctr, seg_cap);
+    if (use_worklist)
+      hipLaunchKernelGGL(worklist_pack_kernel, dim3(1), dim3(1024), 0, ctx->stream, seg_list, seg_cap, chunk_ctr, worklist, wl_stat);
   }
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * wpg), 0, ctx->stream, fr, wi, seed, sweep, site, n_draws, it.n, chunk, desc_scratch,
                      chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count, overflow_list, scan_stats,

@@ -784,6 +784,10 @@ void apply_over_stats(pclean_ctx* ctx) {  // after that synchronisation
   for (size_t i = 0; i < s->over_rec.size(); ++i) {
     const SweepState::OverRec& r = s->over_rec[i];
     const unsigned int h = s->h_over[i];
+    if (r.min_items < 0) {  // a work-list record (eval.hip): h = groups the settle kernel left of r.n_items
+      if ((size_t)h * 2 > (size_t)r.n_items) s->fast[r.block * 64 + r.node].wl_off = 32;  // (most of them: no list for a while)
+      continue;
+    }
     ctx->timing.reserved += (int32_t)h;
     if (r.time_it) ctx->root_stats.overflow_items = (int32_t)h;
     // (evidence sets, min_items 64: the re-run is the generic kernel over every candidate and the scan is the cheap part

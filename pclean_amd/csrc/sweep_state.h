@@ -52,6 +52,7 @@ struct FastRoot {  // candidate-compact tables of a reference slot (root_wave.hi
   uint64_t prior_ver = 0;
   int kpad = 0;
   double logc_max = 0.0;  // max over candidates of log(count - discount)
+  int wl_off = 0;  // > 0: the settle kernel left most groups of this node unsettled: that many launches run without the work list
 };
 
 struct SweepState {
