@@ -156,9 +156,9 @@ def roofline_model(rs, obs_local, particles):
     # (descriptor: written by group_desc_kernel, read by the scan kernel and — when it ran: rs.resolved_groups — by
     # group_settle_kernel, whose fine blocks are in rs.fine_blocks and whose draws are the rows' draws below)
     def model(line):
-        # (rs.pre_scored: the current referent's exact score came from group_gate_kernel, which runs before the timed
-        # launches: its gathers are not theirs)
-        per_group = (3 if rs.resolved_groups > 0 else 2) * 128 + 4 * rs.n_terms + 4 + (0 if rs.pre_scored else line * rs.n_terms)
+        # (rs.pre_scored: the current referent's exact score comes from group_gate_kernel — part of the timed launch group
+        # since round 5 — instead of group_desc_kernel: the same gathers, + a flag and the score written and read per group)
+        per_group = (3 if rs.resolved_groups > 0 else 2) * 128 + 4 * rs.n_terms + 4 + line * rs.n_terms + (20 if rs.pre_scored else 0)
         per_item = 4 + 4 + 4 * rs.n_draws + 8 + 4
         common = rs.n_groups * per_group + rs.n_items * per_item
         two_level = distinct * rs.cstride + rs.fine_blocks * (3 * line + 8) + rs.scored_terms * line
@@ -545,8 +545,9 @@ def main():
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_components": traffic_parts,
                          "traffic_over_alg": (traffic / alg_bytes) if (traffic and alg_bytes) else None,
-                         "kernel": "group_desc_kernel + group_settle_kernel + fk_root_wave_kernel<12> + group_lse_kernel (block 0 root: "
-                                   "rows x candidate hospitals); alg bytes, launch time and counter traffic all cover these launches",
+                         "kernel": "group_gate_kernel + group_desc_kernel + group_settle_kernel + worklist_pack_kernel + fk_root_wave_kernel<12> + "
+                                   "group_lse_kernel (block 0 root: rows x candidate hospitals); alg bytes, launch time and counter "
+                                   "traffic all cover these launches",
                          "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": 1e3 * per_launch_s,
                          "gather_model": {"bytes_per_gather": LINE,
                                           "alg_bytes_per_launch_64B_sector": getattr(roofline_model, "sector64", None),

@@ -581,8 +581,13 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
           list_g = scratch<int32_t>(ctx, ng);
           double* sc = scratch<double>(ctx, ng);
           if (!flag || !list_g || !sc) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+          if (time_it && s->evg0) (void)hipEventRecord(s->evg0, ctx->stream);
           rc = pclean_launch_group_gate(ctx, fr, itg, gt, flag, sc);
           if (rc) return rc;
+          if (time_it && s->evg0) {
+            (void)hipEventRecord(s->evg1, ctx->stream);
+            s->gate_timed = true;
+          }
           unsigned int* need_ctr = fresh_counter(ctx);
           hipLaunchKernelGGL(compact_new_kernel, grid1(ng), dim3(256), 0, ctx->stream, (size_t)ng, flag, 1, need_ctr, list_g,
                              nullptr);
@@ -1694,6 +1699,19 @@ int sample_children(pclean_ctx* ctx, int block_id, int node_id, const ItemList& 
     }
   }
   return PCLEAN_OK;
+}
+
+// The candidate-compact tables (and prior rows) of a reference slot brought up to date on ANOTHER stream: the refresh after a
+// commit wrote a few hundred rows of the table (compact_update / compact_min, ~0.18 ms for the Measure slot at 1M rows) does
+// not depend on the blocks before it, so pclean_sweep lets it run beside block 0 (sweep.hip).  The launches go to `side`;
+// the host-side versions move at once, so the later call on the library's stream finds nothing left to do.
+int prefetch_fast_root(pclean_ctx* ctx, int block_id, int node_id, hipStream_t side) {
+  hipStream_t saved = ctx->stream;
+  ctx->stream = side;
+  FastRootDev fr;
+  const int rc = try_fast_root(ctx, block_id, node_id, fr);
+  ctx->stream = saved;
+  return rc < 0 ? rc : PCLEAN_OK;
 }
 
 // One-time set-up of everything the first sweeps would otherwise build on their way: the candidate-compact byte tables,

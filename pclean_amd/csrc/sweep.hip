@@ -415,6 +415,67 @@ __global__ void final_choice_kernel(int n_rows, int P, const double* logw, size_
 }
 
 
+// The LAST block's particle update and the final choice in one pass (when nothing can touch individual particle weights
+// in between: no drawable ProposalDummyValue, no prior-mode likelihood, no scoring block behind it): a thread has its row's
+// P weights in registers anyway — they are never stored (160 MB written and read back by the two separate kernels at 1M
+// rows x 20 particles), nor is the list of NEW slots built (their contents are sampled for the chosen particle alone).
+// Same operations in the same order as particle_update_kernel followed by final_choice_kernel: bit-identical results.
+template <int PMAX>
+__global__ __launch_bounds__(256) void particle_update_final_kernel(
+    int N, int P, const int32_t* __restrict__ draws_rm, const double* __restrict__ lse, const int32_t* __restrict__ slot_item,
+    const int32_t* __restrict__ draws_item, const double* __restrict__ lse_item, const int32_t* __restrict__ cur_b,
+    int32_t* __restrict__ pchoice, const double* __restrict__ w, int first, int use_mh, const int32_t* __restrict__ csmc_flag,
+    uint64_t seed, uint32_t sweep, int64_t row_offset, int32_t* __restrict__ chosen, const double* __restrict__ logml_acc,
+    double* __restrict__ logml) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int keep = cur_b ? cur_b[i] : -1;
+  FixW<PMAX> f;
+  double wv[PMAX];
+  f.m = -__builtin_inf();
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p) {
+    wv[p] = 0.0;
+    if (p < P) {
+      const size_t sp = (size_t)p * N + i;
+      int d;
+      double l;
+      if (slot_item) {
+        const int item = slot_item[sp];
+        d = draws_item[(size_t)item * P + p];
+        l = lse_item[item];
+      } else {
+        d = draws_rm[(size_t)i * P + p];
+        l = lse[i];
+      }
+      pchoice[sp] = (p == 0 && keep >= 0) ? keep : d;
+      wv[p] = first ? 0.0 + l : w[sp] + l;
+      f.m = fmax(f.m, wv[p]);
+    }
+  }
+  f.U = 0;
+#pragma unroll
+  for (int p = 0; p < PMAX; ++p) {
+    f.u[p] = (p < P && f.m != -__builtin_inf()) ? pclean_fixw(wv[p] - f.m) : 0ull;
+    f.U += f.u[p];
+  }
+  const uint32_t rr = (uint32_t)((int64_t)i + row_offset);
+  const bool csmc = csmc_flag[i] >= 0;
+  int c;
+  if (use_mh && csmc && P >= 2) {
+    const double Ud = (double)f.U;
+    const double w0 = (double)f.u[0] / Ud, w1 = (double)f.u[PMAX > 1 ? 1 : 0] / Ud;
+    double ratio = w1 / (1e-10 + w0);
+    if (ratio > 1.0) ratio = 1.0;
+    const double x = pclean_u01(pclean_rand64(seed, rr, PCLEAN_SITE_MH, 0u, sweep));
+    c = (f.U != 0 && x < ratio) ? 1 : 0;
+  } else {
+    c = fix_pick<PMAX>(f, P, pclean_rand64(seed, rr, PCLEAN_SITE_FINAL, 0u, sweep));
+  }
+  chosen[i] = c;
+  logml[i] = logml_acc[i] + pclean_lse_from_fix(f.m, f.U) - pclean_log((double)P);
+}
+
 // per block after the final choice: the chosen particle's referent, its new-row record, the delta reference
 // counts (the all-reduce payload) and the flags of moved rows / rows with a new referent.  Tables with few rows
 // (hist_rows > 0: a handful of very popular referents, e.g. 28 measures for 1M records) accumulate the deltas in an
@@ -745,6 +806,11 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
   for (auto e : s->prof_ev) (void)hipEventDestroy(e);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
+  if (s->pre_stream) (void)hipStreamDestroy(s->pre_stream);
+  if (s->pre_fork) (void)hipEventDestroy(s->pre_fork);
+  if (s->pre_join) (void)hipEventDestroy(s->pre_join);
+  if (s->evg0) (void)hipEventDestroy(s->evg0);
+  if (s->evg1) (void)hipEventDestroy(s->evg1);
   if (s->evs) (void)hipEventDestroy(s->evs);
   if (s->eve) (void)hipEventDestroy(s->eve);
   delete s;
@@ -1007,17 +1073,22 @@ struct DummyFlagPack {
   int32_t n_leaves, pad;
   DummyFlagLeaf leaf[DUMMY_MAX_LEAVES];
 };
-__global__ void dummy_rows_kernel(int n, DummyFlagPack pk, int32_t* __restrict__ flag) {
+__global__ void dummy_rows_kernel(int n, DummyFlagPack pk, int32_t* __restrict__ flag, unsigned int* __restrict__ n_flagged) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
   int f = 0;
-  for (int l = 0; l < pk.n_leaves; ++l) {
-    const int o = pk.leaf[l].obs_col[i];
-    f |= pk.leaf[l].udummy[o < 0 ? pk.leaf[l].n_obs : o] != 0ull ? 1 : 0;
+  if (i < n) {
+    for (int l = 0; l < pk.n_leaves; ++l) {
+      const int o = pk.leaf[l].obs_col[i];
+      f |= pk.leaf[l].udummy[o < 0 ? pk.leaf[l].n_obs : o] != 0ull ? 1 : 0;
+    }
+    flag[i] = f;
   }
-  flag[i] = f;
+  const unsigned long long mk = __ballot(f != 0);
+  if ((threadIdx.x & 63) == 0 && mk) atomicAdd(n_flagged, (unsigned int)__popcll(mk));
 }
-static int dummy_rows_flags(pclean_ctx* ctx, int bi, int N, const int32_t** out) {
+// *out = null with *none = true: no row of the window can draw any dummy (nothing to sample before the final choice)
+static int dummy_rows_flags(pclean_ctx* ctx, int bi, int N, const int32_t** out, bool* none) {
+  *none = false;
   Block& b = ctx->block[bi];
   SweepState* s = st(ctx);
   SweepState::DummyRows& dr = s->dummy_rows[bi];
@@ -1040,11 +1111,17 @@ static int dummy_rows_flags(pclean_ctx* ctx, int bi, int N, const int32_t** out)
   }
   if (dr.sig != sig || dr.n != N || !dr.flag.p) {
     if (dr.flag.alloc(std::max(N, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-    hipLaunchKernelGGL(dummy_rows_kernel, grid1(N), dim3(256), 0, ctx->stream, N, pk, dr.flag.p);
+    unsigned int* ctr = fresh_counter(ctx);
+    if (!ctr) return pclean_fail(ctx, PCLEAN_ERR_STATE, "counter bank missing");
+    hipLaunchKernelGGL(dummy_rows_kernel, grid1(N), dim3(256), 0, ctx->stream, N, pk, dr.flag.p, ctr);
+    unsigned int nf = 0;
+    PCLEAN_READ_COUNT(ctx, ctr, &nf);  // (once per rebuild of the caches: a read-back is affordable)
+    dr.n_flagged = (int)nf;
     dr.sig = sig;
     dr.n = N;
   }
-  *out = dr.flag.p;
+  *out = dr.n_flagged > 0 ? dr.flag.p : nullptr;
+  *none = dr.n_flagged == 0;
   return PCLEAN_OK;
 }
 
@@ -1276,7 +1353,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     HIPCHK(ctx, hipEventCreate(&s->ev1));
     HIPCHK(ctx, hipEventCreate(&s->evs));
     HIPCHK(ctx, hipEventCreate(&s->eve));
+    HIPCHK(ctx, hipEventCreate(&s->evg0));
+    HIPCHK(ctx, hipEventCreate(&s->evg1));
   }
+  s->gate_timed = false;
   if (!s->h_counts) HIPCHK(ctx, hipHostMalloc((void**)&s->h_counts, 4 * PCLEAN_MAX_BLOCKS * sizeof(int32_t), hipHostMallocDefault));
   const size_t NP = (size_t)N * P;
   if (s->cur.alloc((size_t)N * n_blocks) || s->chosen.alloc(N) || s->ancestors.alloc(NP) || s->w.alloc(NP) ||
@@ -1310,7 +1390,29 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   if (!w_by_first_block) HIPCHK(ctx, hipMemsetAsync(s->w.p, 0, NP * sizeof(double), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(s->logml_acc.p, 0, (size_t)N * sizeof(double), ctx->stream));
   ctx->timing = pclean_timing{};
+  // the later blocks' root tables refresh on a side stream while block 0 runs (eval.hip: prefetch_fast_root)
+  static const bool no_prefetch = getenv("PCLEAN_NO_COMPACT_PREFETCH") != nullptr;
+  bool prefetching = false;
+  if (!no_prefetch && !prior_mode && !ctx->force_generic && n_blocks > 1) {
+    if (!s->pre_stream) {
+      HIPCHK(ctx, hipStreamCreateWithFlags(&s->pre_stream, hipStreamNonBlocking));
+      HIPCHK(ctx, hipEventCreateWithFlags(&s->pre_fork, hipEventDisableTiming));
+      HIPCHK(ctx, hipEventCreateWithFlags(&s->pre_join, hipEventDisableTiming));
+    }
+    HIPCHK(ctx, hipEventRecord(s->pre_fork, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(s->pre_stream, s->pre_fork, 0));
+    for (int bi = 1; bi < n_blocks; ++bi) {
+      const Block& pb = ctx->block[bi];
+      if (pb.is_score || pb.nodes.empty() || (!pb.node_gauss.empty() && pb.node_gauss[0] >= 0)) continue;
+      const int rcp = prefetch_fast_root(ctx, bi, 0, s->pre_stream);
+      if (rcp) return rcp;
+    }
+    HIPCHK(ctx, hipEventRecord(s->pre_join, s->pre_stream));
+    prefetching = true;
+  }
   bool hot_timed = false;
+  bool final_fused = false;            // the last block's particle update made the final choice as well
+  const bool defer_final_off = false;  // (placeholder of a condition that would forbid it)
 
   for (int bi = 0; bi < n_blocks; ++bi) {
     Block& b = ctx->block[bi];
@@ -1356,6 +1458,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       hipLaunchKernelGGL(score_block_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, sb, s->w.p);
       continue;
     }
+    if (prefetching && bi >= 1) {  // (the refreshed tables of this and the later blocks: one join)
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->pre_join, 0));
+      prefetching = false;
+    }
     const int nn = (int)b.nodes.size();
     const int32_t* cur_b = cur_base + (size_t)bi * cur_ld;
     if (r.pchoice.alloc(NP) || r.pnewpos.alloc(NP) || r.new_slots.alloc(NP) || r.choice.alloc(N) || r.chosen_newpos.alloc(N) ||
@@ -1380,9 +1486,14 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     }
     const int32_t* emit_rows = nullptr;
     if (bi == n_blocks - 1 && !eager_all && !no_partial && !prior_mode && drawable && dummy_by_row) {
-      rc = dummy_rows_flags(ctx, bi, N, &emit_rows);
+      bool none = false;
+      rc = dummy_rows_flags(ctx, bi, N, &emit_rows, &none);
       if (rc) return rc;
+      if (none) drawable = false;  // the dummy's fixed-point weight is 0 for every row of the window: it cannot be drawn
     }
+    // last block and nothing between its particle update and the final choice: one fused kernel (particle_update_final_kernel)
+    static const bool no_fuse_final = getenv("PCLEAN_NO_FUSED_FINAL") != nullptr;
+    const bool fuse_final = bi == n_blocks - 1 && !prior_mode && !drawable && !eager_all && !no_fuse_final && !defer_final_off;
     ItemList il;
     const int32_t* excl;
     unsigned int* n_new_ctr = nullptr;  // particles of the block that proposed a NEW referent (fresh_counter)
@@ -1434,10 +1545,18 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         ctx->timing.hot_kernel_launches += 1;
       }
       ProfScope ps(ctx, "particle_update");
+      if (fuse_final) {
+        DISPATCH_PMAX(P, hipLaunchKernelGGL(particle_update_final_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, r.draws.p,
+                                            r.lse.p, (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b,
+                                            r.pchoice.p, s->w.p, (w_by_first_block && bi == 0) ? 1 : 0, use_mh, cur_base, seed,
+                                            sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->logml_acc.p, s->logml.p));
+        final_fused = true;
+      } else {
       n_new_ctr = fresh_counter(ctx);
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
                          s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows);
+      }
     } else {
       { const int rci = ensure_it_ctx(ctx, r, NP, b.n_ctx); if (rci) return rci; }
       CtxSrc cs{};
@@ -1488,18 +1607,26 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       rc = eval_node(ctx, bi, 0, il, d_excl, seed, sweep_idx, P, lse_item, draws_item, nullptr, nullptr, false);
       if (rc) return rc;
       ProfScope ps(ctx, "particle_update");
+      if (fuse_final) {
+        DISPATCH_PMAX(P, hipLaunchKernelGGL(particle_update_final_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P,
+                                            (const int32_t*)nullptr, (const double*)nullptr, slot_item, draws_item, lse_item, cur_b,
+                                            r.pchoice.p, s->w.p, (w_by_first_block && bi == 0) ? 1 : 0, use_mh, cur_base, seed,
+                                            sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->logml_acc.p, s->logml.p));
+        final_fused = true;
+      } else {
       n_new_ctr = fresh_counter(ctx);
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, (const int32_t*)nullptr,
                          (const double*)nullptr, slot_item, draws_item, lse_item, cur_b, r.pchoice.p, s->w.p,
                          n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows);
+      }
     }
     // ---- particles that proposed a NEW referent: sample the new row's contents
     unsigned int n_new = 0;
-    PCLEAN_READ_COUNT(ctx, n_new_ctr, &n_new);
+    if (!final_fused) PCLEAN_READ_COUNT(ctx, n_new_ctr, &n_new);  // (fused with the final choice: nothing is sampled now, nobody asks)
     const bool degenerate_rows = (n_new & 0x80000000u) != 0u;  // some row's block marginal is -inf (particle_update_kernel)
     n_new &= 0x7fffffffu;
-    r.n_new = (int)n_new;
-    r.lazy_new = bi == n_blocks - 1 && !eager_all && (!drawable || emit_rows != nullptr);
+    r.n_new = final_fused ? -1 : (int)n_new;
+    r.lazy_new = final_fused || (bi == n_blocks - 1 && !eager_all && (!drawable || emit_rows != nullptr));
     if (r.lazy_new && !emit_rows) n_new = 0;  // nothing sampled now
     if (emit_rows) r.n_new = -1;  // (the list held the flagged rows' slots only: whether anybody proposed a NEW referent is not known)
     if (r.vals.alloc(std::max<size_t>((size_t)n_new * nn, 1))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
@@ -1577,10 +1704,12 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     }
   }
 
+  if (prefetching) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->pre_join, 0));  // (no later block took it)
   // ---- final choice + per-block outputs: one pass per block, ordered compaction of the rows that moved /
   // got a new referent (hipcub select keeps ascending row order), ONE read-back of the counts
   {
     ProfScope ps(ctx, "final_choice_and_outputs");
+    if (!final_fused)
     DISPATCH_PMAX(P, hipLaunchKernelGGL(final_choice_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p,
                                         (size_t)1, (size_t)N, use_mh, 1, cur_base, seed, sweep_idx,
                                         s->row_offset + ctx->active_begin, s->chosen.p, (double*)nullptr,
@@ -1730,6 +1859,11 @@ int pclean_sweep_finish_synced(pclean_ctx* ctx) {
     float ms = 0;
     HIPCHK(ctx, hipEventElapsedTime(&ms, s->ev0, s->ev1));
     ctx->timing.hot_kernel_ms = ms;
+    if (s->gate_timed) {  // the gate of the new-row branch on the root's groups: it computes what group_desc_kernel used to
+      float mg = 0;
+      HIPCHK(ctx, hipEventElapsedTime(&mg, s->evg0, s->evg1));
+      ctx->timing.hot_kernel_ms += mg;
+    }
   }
   if (s->h_counts[3 * PCLEAN_MAX_BLOCKS])
     return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "pclean_sweep: an observed string longer than %d symbols below a chosen "

@@ -287,4 +287,5 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
 int sample_children(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
                            uint64_t seed, uint32_t sweep, int32_t* vals, int n_nodes);
 int ensure_plan_dev(pclean_ctx* ctx, int block_id);
+int prefetch_fast_root(pclean_ctx* ctx, int block_id, int node_id, hipStream_t side);
 int ensure_agg(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const AggDev** out);

@@ -78,6 +78,10 @@ struct SweepState {
   std::map<int, uint64_t> leaf_version;
   int64_t row_offset = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evs = nullptr, eve = nullptr;
+  hipEvent_t evg0 = nullptr, evg1 = nullptr;  // around group_gate_kernel of the timed root (part of its launch group)
+  hipStream_t pre_stream = nullptr;           // compact-table refresh of the later blocks' roots, beside block 0 (pclean_sweep)
+  hipEvent_t pre_fork = nullptr, pre_join = nullptr;
+  bool gate_timed = false;
   // memo tables of option-list marginals (leaf_memo_*): key = block * 64 + node
   struct LeafMemo {
     DevBuf<uint64_t> keys;   // [cap][3]
@@ -99,7 +103,7 @@ struct SweepState {
   struct GateStat { int all_need_run = 0, skip = 0; };
   std::map<int, GateStat> gate_stat;
   // rows for which some cacheable option list of the block can draw its ProposalDummyValue (sweep.hip: dummy_rows_flags)
-  struct DummyRows { DevBuf<int32_t> flag; uint64_t sig = 0; int n = 0; };
+  struct DummyRows { DevBuf<int32_t> flag; uint64_t sig = 0; int n = 0, n_flagged = 0; };
   std::map<int, DummyRows> dummy_rows;  // key = block
   // evidence of the running pclean_sweep_latent call (ensure_agg)
   const int32_t* lat_off = nullptr;      // [lat_items + 1] CSR offsets of the original items into the evidence list

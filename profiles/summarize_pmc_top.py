@@ -87,7 +87,9 @@ def main():
             return (2 * c["FETCH_SIZE"][1] / c["FETCH_SIZE"][0] + c["WRITE_SIZE"][1] / c["WRITE_SIZE"][0]) * 1024
 
         keys = [next((k for k in merged if pat in k and "full-size" in k), None)
-                for pat in ("group_desc_kernel", "fk_root_wave_kernel<12", "group_lse_kernel", "group_settle_kernel")]
+                for pat in ("group_desc_kernel", "fk_root_wave_kernel<12", "group_lse_kernel", "group_settle_kernel", "group_gate_kernel")]
+        if keys[4] is None:  # (builds before round 5's gate on the groups)
+            keys = keys[:4]
         if keys[3] is None:  # (builds before the settle kernel / PCLEAN_NO_SETTLE)
             keys = keys[:3]
         if all(keys) and all(hbm(k) is not None for k in keys):
@@ -97,8 +99,7 @@ def main():
                 data = json.load(open(out_json))
             except Exception:
                 data = {}
-            data.update(kernel="group_desc_kernel + group_settle_kernel + fk_root_wave_kernel<12> + group_lse_kernel" if len(keys) == 4
-                        else "group_desc_kernel + fk_root_wave_kernel<12> + group_lse_kernel", pair_bytes_per_launch=sum(parts.values()),
+            data.update(kernel=" + ".join(k.split(" [")[0] for k in keys), pair_bytes_per_launch=sum(parts.values()),
                         pair_components=parts, bytes_per_launch=parts[keys[1]], rows=1000000, hospitals=10000, particles=20,
                         fetch_kib=c["FETCH_SIZE"][1] / c["FETCH_SIZE"][0], write_kib=c["WRITE_SIZE"][1] / c["WRITE_SIZE"][0],
                         avg_ms={k: merged[k]["dur"] / merged[k]["n"] for k in keys},
