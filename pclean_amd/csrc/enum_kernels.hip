@@ -941,11 +941,7 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
                                       160 * 1024));
       attr_set = true;
     }
-    // (up to 4096 items when a workgroup has work for 1024 threads — a few thousand candidates: the contents of the new rows
-    // the chosen particles proposed, 2 600 items x 4 900 options at 1M rows, took 0.18 ms with 256 threads per item: every
-    // thread walks ~40 candidates through four dependent loads each)
-    static const bool wide_off = getenv("PCLEAN_NO_WIDE_ENUM") != nullptr;
-    if (few || (!wide_off && it.n <= 4096 && nd.n_cand >= 2048)) {  // (groups or items) too few workgroups to fill the chip: more threads per item
+    if (few) {  // (groups or items) too few workgroups to fill the chip: more threads per item
       hipLaunchKernelGGL(enum_node_kernel<1024>, dim3(it.n), dim3(1024), lds, ctx->stream, nd, dn, it, ch, seed, sweep, site,
                          n_draws, 0, lse_out, scores_out, draws_out);
     } else {

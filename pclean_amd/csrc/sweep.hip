@@ -166,13 +166,14 @@ __global__ __launch_bounds__(PU_T) void particle_update_kernel(int N, int P, con
                                                               unsigned int* __restrict__ n_new,
                                                               int32_t* __restrict__ new_list,
                                                               int32_t* __restrict__ pnewpos, int first,
-                                                              const int32_t* __restrict__ emit_rows) {
+                                                              const int32_t* __restrict__ emit_rows, int only_emit) {
   __shared__ unsigned int wsum[PU_T / 64];
   __shared__ unsigned int bbase;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint64_t newmask = 0;
-  if (i < N) {
+  // (only_emit: the rows outside emit_rows are not this kernel's — particle_update_final_kernel takes them)
+  if (i < N && !(only_emit && !emit_rows[i])) {
     const int keep = cur_b ? cur_b[i] : -1;
     for (int p = 0; p < P; ++p) {
       const size_t sp = (size_t)p * N + i;
@@ -390,9 +391,10 @@ template <int PMAX>
 __global__ void final_choice_kernel(int n_rows, int P, const double* logw, size_t sr, size_t sp, int use_mh,
                                     int is_csmc, const int32_t* csmc_flag, uint64_t seed, uint32_t sweep,
                                     int64_t row_offset, int32_t* chosen, double* log_total, const double* logml_acc,
-                                    double* logml) {
+                                    double* logml, const int32_t* __restrict__ only_rows) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rows) return;
+  if (only_rows && !only_rows[i]) return;  // (the other rows were finished by particle_update_final_kernel)
   FixW<PMAX> f;
   fix_weights<PMAX>(logw + (size_t)i * sr, sp, P, f);
   const uint32_t rr = (uint32_t)((int64_t)i + row_offset);
@@ -426,9 +428,10 @@ __global__ __launch_bounds__(256) void particle_update_final_kernel(
     const int32_t* __restrict__ draws_item, const double* __restrict__ lse_item, const int32_t* __restrict__ cur_b,
     int32_t* __restrict__ pchoice, const double* __restrict__ w, int first, int use_mh, const int32_t* __restrict__ csmc_flag,
     uint64_t seed, uint32_t sweep, int64_t row_offset, int32_t* __restrict__ chosen, const double* __restrict__ logml_acc,
-    double* __restrict__ logml) {
+    double* __restrict__ logml, const int32_t* __restrict__ skip_rows) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
+  if (skip_rows && skip_rows[i]) return;  // (a row that can draw a dummy value: the separate kernels, with the weight corrections between them)
   const int keep = cur_b ? cur_b[i] : -1;
   FixW<PMAX> f;
   double wv[PMAX];
@@ -1412,6 +1415,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   }
   bool hot_timed = false;
   bool final_fused = false;            // the last block's particle update made the final choice as well
+  const int32_t* final_only_rows = nullptr;  // ... for the rows outside this flag array (the final choice kernel takes the flagged ones)
   const bool defer_final_off = false;  // (placeholder of a condition that would forbid it)
 
   for (int bi = 0; bi < n_blocks; ++bi) {
@@ -1493,7 +1497,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     }
     // last block and nothing between its particle update and the final choice: one fused kernel (particle_update_final_kernel)
     static const bool no_fuse_final = getenv("PCLEAN_NO_FUSED_FINAL") != nullptr;
-    const bool fuse_final = bi == n_blocks - 1 && !prior_mode && !drawable && !eager_all && !no_fuse_final && !defer_final_off;
+    const bool last_plain = bi == n_blocks - 1 && !prior_mode && !eager_all && !no_fuse_final && !defer_final_off;
+    const bool fuse_final = last_plain && !drawable;
+    // ... and when only a few rows can draw one (emit_rows): those rows take the separate kernels, all the others the fused one
+    const bool split_final = last_plain && drawable && emit_rows != nullptr;
     ItemList il;
     const int32_t* excl;
     unsigned int* n_new_ctr = nullptr;  // particles of the block that proposed a NEW referent (fresh_counter)
@@ -1513,7 +1520,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
                          s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0,
-                         (const int32_t*)nullptr);
+                         (const int32_t*)nullptr, 0);
       if (has_ctx) {  // the particles' contexts: read by the likelihood terms and handed to the new rows' items
         { const int rci = ensure_it_ctx(ctx, r, NP, b.n_ctx); if (rci) return rci; }
         CtxSrc cs{};
@@ -1549,13 +1556,22 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         DISPATCH_PMAX(P, hipLaunchKernelGGL(particle_update_final_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, r.draws.p,
                                             r.lse.p, (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b,
                                             r.pchoice.p, s->w.p, (w_by_first_block && bi == 0) ? 1 : 0, use_mh, cur_base, seed,
-                                            sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->logml_acc.p, s->logml.p));
+                                            sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->logml_acc.p, s->logml.p,
+                                            (const int32_t*)nullptr));
         final_fused = true;
       } else {
       n_new_ctr = fresh_counter(ctx);
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
-                         s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows);
+                         s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows, split_final ? 1 : 0);
+      if (split_final) {
+        DISPATCH_PMAX(P, hipLaunchKernelGGL(particle_update_final_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, r.draws.p,
+                                            r.lse.p, (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b,
+                                            r.pchoice.p, s->w.p, (w_by_first_block && bi == 0) ? 1 : 0, use_mh, cur_base, seed,
+                                            sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->logml_acc.p, s->logml.p,
+                                            emit_rows));
+        final_only_rows = emit_rows;
+      }
       }
     } else {
       { const int rci = ensure_it_ctx(ctx, r, NP, b.n_ctx); if (rci) return rci; }
@@ -1611,13 +1627,22 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         DISPATCH_PMAX(P, hipLaunchKernelGGL(particle_update_final_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P,
                                             (const int32_t*)nullptr, (const double*)nullptr, slot_item, draws_item, lse_item, cur_b,
                                             r.pchoice.p, s->w.p, (w_by_first_block && bi == 0) ? 1 : 0, use_mh, cur_base, seed,
-                                            sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->logml_acc.p, s->logml.p));
+                                            sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->logml_acc.p, s->logml.p,
+                                            (const int32_t*)nullptr));
         final_fused = true;
       } else {
       n_new_ctr = fresh_counter(ctx);
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, (const int32_t*)nullptr,
                          (const double*)nullptr, slot_item, draws_item, lse_item, cur_b, r.pchoice.p, s->w.p,
-                         n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows);
+                         n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows, split_final ? 1 : 0);
+      if (split_final) {
+        DISPATCH_PMAX(P, hipLaunchKernelGGL(particle_update_final_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P,
+                                            (const int32_t*)nullptr, (const double*)nullptr, slot_item, draws_item, lse_item, cur_b,
+                                            r.pchoice.p, s->w.p, (w_by_first_block && bi == 0) ? 1 : 0, use_mh, cur_base, seed,
+                                            sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->logml_acc.p, s->logml.p,
+                                            emit_rows));
+        final_only_rows = emit_rows;
+      }
       }
     }
     // ---- particles that proposed a NEW referent: sample the new row's contents
@@ -1713,7 +1738,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     DISPATCH_PMAX(P, hipLaunchKernelGGL(final_choice_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p,
                                         (size_t)1, (size_t)N, use_mh, 1, cur_base, seed, sweep_idx,
                                         s->row_offset + ctx->active_begin, s->chosen.p, (double*)nullptr,
-                                        s->logml_acc.p, s->logml.p));
+                                        s->logml_acc.p, s->logml.p, final_only_rows));
     for (int bi = 0; bi < n_blocks; ++bi) {  // deferred new-row contents of the last block (chosen particles only)
       BlockRun& r = s->run[bi];
       Block& bb = ctx->block[bi];
@@ -2058,7 +2083,7 @@ extern "C" int pclean_final_choice(pclean_ctx* ctx, int32_t n_rows, int32_t n_pa
   DISPATCH_PMAX(n_particles, hipLaunchKernelGGL(final_choice_kernel<PMAX>, grid1(n_rows), dim3(256), 0, ctx->stream,
                                                 n_rows, n_particles, d_w, (size_t)n_particles, (size_t)1, use_mh, is_csmc,
                                                 (const int32_t*)nullptr, seed, sweep, s->row_offset, d_c, d_t,
-                                                (const double*)nullptr, (double*)nullptr));
+                                                (const double*)nullptr, (double*)nullptr, (const int32_t*)nullptr));
   HIPCHK(ctx, hipMemcpyAsync(chosen, d_c, (size_t)n_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (log_total) HIPCHK(ctx, hipMemcpyAsync(log_total, d_t, (size_t)n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
   PCLEAN_SYNC(ctx);
