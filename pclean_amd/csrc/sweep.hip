@@ -1393,17 +1393,20 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   if (!w_by_first_block) HIPCHK(ctx, hipMemsetAsync(s->w.p, 0, NP * sizeof(double), ctx->stream));
   HIPCHK(ctx, hipMemsetAsync(s->logml_acc.p, 0, (size_t)N * sizeof(double), ctx->stream));
   ctx->timing = pclean_timing{};
-  // the later blocks' root tables refresh on a side stream while block 0 runs (eval.hip: prefetch_fast_root)
+  // the later blocks' root tables refresh on a side stream while block 0 runs (eval.hip: prefetch_fast_root): enqueued
+  // once block 0's kernels are (see the block loop), so that the host time of those launches is not block 0's
   static const bool no_prefetch = getenv("PCLEAN_NO_COMPACT_PREFETCH") != nullptr;
-  bool prefetching = false;
-  if (!no_prefetch && !prior_mode && !ctx->force_generic && n_blocks > 1) {
-    if (!s->pre_stream) {
-      HIPCHK(ctx, hipStreamCreateWithFlags(&s->pre_stream, hipStreamNonBlocking));
-      HIPCHK(ctx, hipEventCreateWithFlags(&s->pre_fork, hipEventDisableTiming));
-      HIPCHK(ctx, hipEventCreateWithFlags(&s->pre_join, hipEventDisableTiming));
-    }
-    HIPCHK(ctx, hipEventRecord(s->pre_fork, ctx->stream));
-    HIPCHK(ctx, hipStreamWaitEvent(s->pre_stream, s->pre_fork, 0));
+  bool prefetching = false, prefetch_started = false;
+  if (!s->pre_stream) {
+    HIPCHK(ctx, hipStreamCreateWithFlags(&s->pre_stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreateWithFlags(&s->pre_fork, hipEventDisableTiming));
+    HIPCHK(ctx, hipEventCreateWithFlags(&s->pre_join, hipEventDisableTiming));
+  }
+  HIPCHK(ctx, hipEventRecord(s->pre_fork, ctx->stream));
+  auto start_prefetch = [&]() -> int {
+    prefetch_started = true;
+    if (no_prefetch || prior_mode || ctx->force_generic || n_blocks <= 1) return PCLEAN_OK;
+    HIPCHK(ctx, hipStreamWaitEvent(s->pre_stream, s->pre_fork, 0));  // (recorded at the START of the sweep: nothing of block 0)
     for (int bi = 1; bi < n_blocks; ++bi) {
       const Block& pb = ctx->block[bi];
       if (pb.is_score || pb.nodes.empty() || (!pb.node_gauss.empty() && pb.node_gauss[0] >= 0)) continue;
@@ -1412,7 +1415,8 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     }
     HIPCHK(ctx, hipEventRecord(s->pre_join, s->pre_stream));
     prefetching = true;
-  }
+    return PCLEAN_OK;
+  };
   bool hot_timed = false;
   bool final_fused = false;            // the last block's particle update made the final choice as well
   const int32_t* final_only_rows = nullptr;  // ... for the rows outside this flag array (the final choice kernel takes the flagged ones)
@@ -1646,6 +1650,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       }
     }
     // ---- particles that proposed a NEW referent: sample the new row's contents
+    if (!prefetch_started) {  // (this block's kernels are queued: the host has time for the later blocks' table refresh)
+      const int rcp = start_prefetch();
+      if (rcp) return rcp;
+    }
     unsigned int n_new = 0;
     if (!final_fused) PCLEAN_READ_COUNT(ctx, n_new_ctr, &n_new);  // (fused with the final choice: nothing is sampled now, nobody asks)
     const bool degenerate_rows = (n_new & 0x80000000u) != 0u;  // some row's block marginal is -inf (particle_update_kernel)
