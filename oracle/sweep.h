@@ -105,15 +105,16 @@ inline void sample_new(const RowCtx& rc, int node, int excl, uint32_t particle, 
  * discrete choice of a new row from its prior proposal (42-56: q_cont += lprobs[chosen], p += logdensity of the same
  * value — they cancel; a chosen ProposalDummyValue leaves -log(dummy mass) and gets random(dist), 58-60), then
  * p accumulates the log-density of every observed choice given the sampled values (62-64).  The particle's weight
- * increment is therefore the likelihood of its sampled sub-tree.  Supported for plans whose terms are AddTypos
- * observations (plain or through a JuliaNode); blocks with equality constraints, MaybeSwap or Gaussian terms are
- * refused by the callers. ---- */
+ * increment is therefore the likelihood of its sampled sub-tree: AddTypos observations (plain or through a JuliaNode),
+ * noise-free observations (equality: 0 or -inf), MaybeSwap observations of the referring rows (latent classes); a
+ * scoring block has nothing to propose and scores as always (62-64).  Blocks with a Gaussian term are refused by the
+ * callers (their own enumerated choices would be sampled from their priors, the retained particle keeping its own). ---- */
 inline bool prior_mode_supported(const OBlock& b) {
-  if (b.is_score) return false;
   for (const pclean_term& tm : b.terms)
-    if (tm.dens_kind != PCLEAN_DENS_ADD_TYPOS) return false;
+    if (tm.dens_kind != PCLEAN_DENS_ADD_TYPOS && tm.dens_kind != PCLEAN_DENS_EQUAL && tm.dens_kind != PCLEAN_DENS_MAYBE_SWAP)
+      return false;
   for (int g : b.node_gauss)
-    if (g >= 0) return false;
+    if (g >= 0) return false; /* own choices enumerated inside the candidate branch: not restated for prior proposals */
   return true;
 }
 

@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void pcc_merge_kernel(PccSegLayout L, int n_ra
                                                         int32_t* counts2, PccResult* res) {
   const int p = blockIdx.y;
   pcc_merge(L, p, n_ranks, all, g.cap_out_m[p], g.cap_out_k[p], g.g_moved[p], g.g_choice[p], g.g_new[p], g.g_chosen[p], g.g_vals[p],
-            counts2 + 2 * p, &res->fallback_in, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256));
+            counts2 + 2 * p, &res->fallback_in, (int)(blockIdx.x * 256 + threadIdx.x), (int)(gridDim.x * 256),
+            blockIdx.x == 0 ? counts2 + 2 * PCC_MAX_BLOCKS + 2 * p : nullptr);
 }
 
 __global__ void pcc_live_kernel(int n, const int64_t* counts, uint8_t* live) {
@@ -593,12 +594,12 @@ static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_
       off += pcc_seg_words(L.cap_m[p], L.cap_k[p], L.nn[p]);
     }
     L.seg_words = off;
-    if (c->seg.alloc((size_t)off) || c->seg_all.alloc((size_t)off * world) || c->g_counts2.alloc(2 * PCC_MAX_BLOCKS) ||
+    if (c->seg.alloc((size_t)off) || c->seg_all.alloc((size_t)off * world) || c->g_counts2.alloc(4 * PCC_MAX_BLOCKS) ||
         c->d_blocks_g.alloc(PCC_MAX_BLOCKS))
       return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
     if (!c->h_blocks_g) {
       HIPCHK(ctx, hipHostMalloc((void**)&c->h_blocks_g, sizeof(PccBlock) * PCC_MAX_BLOCKS, hipHostMallocDefault));
-      HIPCHK(ctx, hipHostMalloc((void**)&c->h_g_counts2, sizeof(int32_t) * 2 * PCC_MAX_BLOCKS, hipHostMallocDefault));
+      HIPCHK(ctx, hipHostMalloc((void**)&c->h_g_counts2, sizeof(int32_t) * 4 * PCC_MAX_BLOCKS, hipHostMallocDefault));
     }
     PccGathered G{};
     for (int p = 0; p < c->n_plans; ++p) {
@@ -661,7 +662,7 @@ static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_
     if (rc) return rc;
     hipLaunchKernelGGL(pcc_merge_kernel, dim3(64, c->n_plans), dim3(256), 0, ctx->stream, L, world, c->seg_all.p, G, c->g_counts2.p,
                        c->d_res.p);
-    HIPCHK(ctx, hipMemcpyAsync(c->h_g_counts2, c->g_counts2.p, sizeof(int32_t) * 2 * c->n_plans, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(c->h_g_counts2, c->g_counts2.p, sizeof(int32_t) * 4 * PCC_MAX_BLOCKS, hipMemcpyDeviceToHost, ctx->stream));
     commit_blocks = c->d_blocks_g.p;
     cur_rows = 0;
     for (int p = 0; p < c->n_plans; ++p) cur_rows = std::max<int64_t>(cur_rows, (int64_t)L.cap_m[p] * world);
@@ -699,10 +700,10 @@ static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_
     out->n_distinct[c->plan_block[p]] = c->h_res->n_distinct[p];
     // scratch for the next sweep: twice what this one needed
     if (2 * c->h_res->n_records[p] > c->kcap[p]) c->kcap[p] = 2 * c->h_res->n_records[p];
-    if (dist) {  // the next exchange's segments: twice this commit's GLOBAL totals (known to every rank alike); a refused
-      // commit starts over from what a shard can hold
-      c->cap_m[p] = out->fallback ? 0 : std::max(4096, 2 * c->h_g_counts2[2 * p]);
-      c->cap_k[p] = out->fallback ? 0 : std::max(1024, 2 * c->h_g_counts2[2 * p + 1]);
+    if (dist) {  // the next exchange's segments: twice the LARGEST rank's lists of this commit (every rank read the same
+      // headers: the same capacities everywhere); a refused commit starts over from what a shard can hold
+      c->cap_m[p] = out->fallback ? 0 : std::max(1024, 2 * c->h_g_counts2[2 * PCC_MAX_BLOCKS + 2 * p] + 64);
+      c->cap_k[p] = out->fallback ? 0 : std::max(256, 2 * c->h_g_counts2[2 * PCC_MAX_BLOCKS + 2 * p + 1] + 64);
     }
   }
   if (dist && !out->fallback) {

@@ -628,7 +628,7 @@ PCC_FN void pcc_pack(const PccSegLayout& L, int p, const PccBlock& b, int empty,
 // *fallback |= PCC_FB_RECORDS when a rank's lists did not fit its segment (or the totals do not fit cap_out_*)
 PCC_FN void pcc_merge(const PccSegLayout& L, int p, int n_ranks, const int32_t* all, int cap_out_m, int cap_out_k,
                       int32_t* g_moved, int32_t* g_choice, int32_t* g_new, int32_t* g_chosen, int32_t* g_vals, int32_t* counts2,
-                      int32_t* fallback, int tid, int nt) {
+                      int32_t* fallback, int tid, int nt, int32_t* rank_max = nullptr) {
   const int cm = L.cap_m[p], ck = L.cap_k[p], nn = L.nn[p];
   int tot_m = 0, tot_k = 0;
   bool bad = false;
@@ -643,6 +643,16 @@ PCC_FN void pcc_merge(const PccSegLayout& L, int p, int n_ranks, const int32_t* 
     counts2[0] = bad ? 0 : tot_m;
     counts2[1] = bad ? 0 : tot_k;
     if (bad) PCC_OR32(fallback, PCC_FB_RECORDS);
+    if (rank_max) {  // the largest single rank's lists: what the next exchange's segments are sized by
+      int mm = 0, mk = 0;
+      for (int r = 0; r < n_ranks; ++r) {
+        const int32_t* o = all + (size_t)r * L.seg_words + L.off[p];
+        mm = o[0] > mm ? o[0] : mm;
+        mk = o[1] > mk ? o[1] : mk;
+      }
+      rank_max[0] = mm;
+      rank_max[1] = mk;
+    }
   }
   if (bad) return;
   int base_m = 0, base_k = 0;

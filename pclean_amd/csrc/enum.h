@@ -154,6 +154,7 @@ struct FastRootDev {
   double inv_c, prior_max_e, prior_max_n;
   const double* atd;         // [max_len + 1][atd_stride] AddTypos log-density by (latent length, distance) (ctx->atd)
   const uint8_t* zero_row;   // kpad zero bytes: stands in for the byte row of a missing observation
+  const int32_t* obs_rm;     // [rows][PCLEAN_MAX_TERMS] the terms' observed values row-major (null: gather obs_col[f][row])
   FastTermDev terms[PCLEAN_MAX_TERMS];
 };
 
@@ -162,10 +163,11 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
                             int32_t* desc_scratch, int32_t* overflow_list,
                             unsigned int* scan_stats = nullptr, int n_items = 0, const double* pre_score = nullptr,
-                            bool want_worklist = true, unsigned int* wl_stat = nullptr);
-// gate of the new-row branch per GROUP of `it` (grouped view), with the exact score of every group's current referent
+                            bool want_worklist = true, unsigned int* wl_stat = nullptr, const int32_t* pre_obs = nullptr);
+// gate of the new-row branch per GROUP of `it` (grouped view), with the exact score of every group's current referent and
+// the observed values of its row (obs_out: PCLEAN_MAX_TERMS words per group, what group_desc_kernel would gather again)
 int pclean_launch_group_gate(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const GateDev& gt, int32_t* flag,
-                             double* score_out);
+                             double* score_out, int32_t* obs_out);
 int pclean_launch_overflow_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                                 uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                                 int32_t* draws_out, const int32_t* over_list, const unsigned int* over_count);
@@ -173,6 +175,8 @@ int pclean_overflow_fast_ok(const FastRootDev& fr, const ItemsDev& it);
 int pclean_launch_root_flags(pclean_ctx* ctx, int n_groups, const int32_t* gd, const int32_t* grp_off,
                              const int32_t* members, const int32_t* oflag, int32_t* out);
 size_t pclean_fast_desc_words(int n_groups);  // int32 words of desc_scratch for n_groups groups
+// out[row][f] = obs_col[f][row] (f < n_terms, else -1), rows [0, n_rows): the row-major copy FastRootDev::obs_rm points into
+int pclean_build_obs_rowmajor(pclean_ctx* ctx, const int32_t* const* obs_cols, int n_terms, int n_rows, int32_t* out);
 int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_lat, const int32_t* cand_col,
                          const uint16_t* lat_len, int n_cand, int kpad, uint8_t* comp, uint8_t* clen);
 // block minima of a compact table: cmin[o][kb] = min of comp[o][64 kb .. 64 kb + 63] (root_wave.hip: the coarse level

@@ -378,6 +378,22 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
     fr.prior_max_e = f.logc_max - t.scal[1];
     fr.prior_max_n = f.logc_max - t.scal[0];
   }
+  // the observed values row-major, for the launches that look at one row per group (group_gate_kernel, group_desc_kernel);
+  // large tables only; not for evidence sets and not under an observation override (leaf caches)
+  fr.obs_rm = nullptr;
+  static const bool no_obs_rm = getenv("PCLEAN_NO_OBS_ROWMAJOR") != nullptr;
+  if (!leaf && !ev_mode && !ctx->obs_override && !no_obs_rm && ctx->n_rows >= 4096) {
+    const uint64_t key = ctx->obs_version * 1000003ull + (uint64_t)ctx->n_rows + 1ull;
+    if (f.obs_rm_key != key || !f.obs_rm.p) {
+      if (f.obs_rm.alloc((size_t)ctx->n_rows * PCLEAN_MAX_TERMS)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+      const int32_t* cols[PCLEAN_MAX_TERMS] = {};
+      for (int i = 0; i < n.n_terms; ++i) cols[i] = ctx->obs.p + (size_t)b.terms[n.term_begin + i].obs_col * ctx->n_rows;
+      int rc = pclean_build_obs_rowmajor(ctx, cols, n.n_terms, ctx->n_rows, f.obs_rm.p);
+      if (rc) return rc;
+      f.obs_rm_key = key;
+    }
+    fr.obs_rm = f.obs_rm.p + (size_t)ctx->active_begin * PCLEAN_MAX_TERMS;
+  }
   fr.n_cand = t.n_rows;
   fr.kpad = kpad;
   {
@@ -502,6 +518,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
   ItemGroups g_pre;
   bool fast_tried = false, groups_tried = false;
   const double* pre_score = nullptr;  // exact score of every group's current referent (group_gate_kernel)
+  const int32_t* pre_obs = nullptr;   // observed values of every group's row (group_gate_kernel)
   if (n.kind == PCLEAN_NODE_FK && ctx->prior_mode) {
     ch.n = 0;  // the new row's choices are sampled from their priors: the branch carries its CRP term alone
   } else if (n.kind == PCLEAN_NODE_FK) {
@@ -580,9 +597,10 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
           int32_t* flag = scratch<int32_t>(ctx, ng);
           list_g = scratch<int32_t>(ctx, ng);
           double* sc = scratch<double>(ctx, ng);
-          if (!flag || !list_g || !sc) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+          int32_t* ow = scratch<int32_t>(ctx, (size_t)ng * PCLEAN_MAX_TERMS);
+          if (!flag || !list_g || !sc || !ow) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
           if (time_it && s->evg0) (void)hipEventRecord(s->evg0, ctx->stream);
-          rc = pclean_launch_group_gate(ctx, fr, itg, gt, flag, sc);
+          rc = pclean_launch_group_gate(ctx, fr, itg, gt, flag, sc, ow);
           if (rc) return rc;
           if (time_it && s->evg0) {
             (void)hipEventRecord(s->evg1, ctx->stream);
@@ -593,6 +611,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
                              nullptr);
           PCLEAN_READ_COUNT(ctx, need_ctr, &n_need);
           pre_score = sc;
+          pre_obs = ow;
           if (gstat) {
             gstat->all_need_run = n_need == (unsigned int)ng ? gstat->all_need_run + 1 : 0;
             if (gstat->all_need_run >= 3) {
@@ -837,7 +856,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
     }
     if (fwl.wl_off > 0) --fwl.wl_off;
     rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag, over_count, desc,
-                                 over_list, scan_stats, il.n, pre_score, wl_stat != nullptr, wl_stat);
+                                 over_list, scan_stats, il.n, pre_score, wl_stat != nullptr, wl_stat, pre_obs);
     if (time_it) {
       (void)hipEventRecord(s->ev1, ctx->stream);
       s->dbg_desc = desc;

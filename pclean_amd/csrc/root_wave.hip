@@ -225,13 +225,50 @@ __device__ __forceinline__ double fast_exact_score(const FastRootDev& fr, const 
   return b;
 }
 
+// observed values of `row` for the node's terms (-1 beyond n_terms): from the row-major copy when there is one
+__device__ __forceinline__ void load_row_obs(const FastRootDev& fr, int row, int* o) {
+  static_assert(PCLEAN_MAX_TERMS == 16, "four 16-byte loads");
+  if (fr.obs_rm) {
+    const int4* po = reinterpret_cast<const int4*>(fr.obs_rm + (size_t)row * PCLEAN_MAX_TERMS);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int4 v = po[q];
+      o[4 * q] = v.x;
+      o[4 * q + 1] = v.y;
+      o[4 * q + 2] = v.z;
+      o[4 * q + 3] = v.w;
+    }
+  } else {
+    for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) o[f] = f < fr.n_terms ? fr.terms[f].obs_col[row] : -1;
+  }
+}
+struct ObsColsDev {
+  const int32_t* col[PCLEAN_MAX_TERMS];
+};
+__global__ void obs_rowmajor_kernel(ObsColsDev oc, int n_terms, int n_rows, int32_t* __restrict__ out) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one (row, term) word per thread: coalesced stores
+  if (i >= (size_t)n_rows * PCLEAN_MAX_TERMS) return;
+  const int row = (int)(i / PCLEAN_MAX_TERMS), f = (int)(i % PCLEAN_MAX_TERMS);
+  out[i] = f < n_terms ? oc.col[f][row] : -1;
+}
+int pclean_build_obs_rowmajor(pclean_ctx* ctx, const int32_t* const* obs_cols, int n_terms, int n_rows, int32_t* out) {
+  if (n_rows <= 0) return PCLEAN_OK;
+  ObsColsDev oc{};
+  for (int f = 0; f < n_terms && f < PCLEAN_MAX_TERMS; ++f) oc.col[f] = obs_cols[f];
+  const size_t n = (size_t)n_rows * PCLEAN_MAX_TERMS;
+  hipLaunchKernelGGL(obs_rowmajor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, oc, n_terms, n_rows, out);
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
+
 // One thread per group: the descriptor the scan kernel consumes, including the lower bound of the maximum
 // from the exact score of the rows' current referent (only ever used as a filter, never as a score) and the
 // pre-filter cut-off that follows from it.
 __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const ChildrenDev ch, int n_groups,
                                   int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr, double* __restrict__ g_m,
                                   uint64_t* __restrict__ g_U, int32_t* __restrict__ g_res,
-                                  unsigned int* __restrict__ scan_stats, const double* __restrict__ pre_score) {
+                                  unsigned int* __restrict__ scan_stats, const double* __restrict__ pre_score,
+                                  const int32_t* __restrict__ pre_obs) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < 8) chunk_ctr[g * WAVE_CTR_STRIDE] = 0u;
   if (g >= 8 && g < 8 + WL_SEGS) chunk_ctr[WL_SEG_CTR(g - 8)] = 0u;  // segment counters of the scan kernel's work list (group_settle_kernel)
@@ -245,7 +282,20 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
   const int ctx0 = it.ctx ? it.ctx[(size_t)t * PCLEAN_MAX_CTX] : 0;
   const int ctx1 = it.ctx ? it.ctx[(size_t)t * PCLEAN_MAX_CTX + 1] : 0;
   int o[PCLEAN_MAX_TERMS];
-  for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) o[f] = f < fr.n_terms ? fr.terms[f].obs_col[row] : -1;
+  if (pre_obs) {  // group_gate_kernel gathered the observed values of this group's row already: 64 contiguous bytes
+    static_assert(PCLEAN_MAX_TERMS == 16, "four 16-byte loads");
+    const int4* po = reinterpret_cast<const int4*>(pre_obs + (size_t)g * PCLEAN_MAX_TERMS);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int4 v = po[q];
+      o[4 * q] = v.x;
+      o[4 * q + 1] = v.y;
+      o[4 * q + 2] = v.z;
+      o[4 * q + 3] = v.w;
+    }
+  } else {
+    load_row_obs(fr, row, o);
+  }
   const bool deleted = excl >= 0 && fr.counts && fr.counts[excl] <= 1;
   double bound = -__builtin_inf(), score_cur = 0.0;
   bool have_cur = false;
@@ -392,7 +442,8 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
 // needs anyway (score_out) — and compares it with the upper bound of the new-row candidate: where that candidate's
 // fixed-point weight is exactly 0 the children of the branch are never evaluated.  flag[g] = PCLEAN_CHOICE_NEW: needed.
 __global__ void group_gate_kernel(const FastRootDev fr, const ItemsDev it, const GateDev gt, int n_groups,
-                                  int32_t* __restrict__ flag, double* __restrict__ score_out) {
+                                  int32_t* __restrict__ flag, double* __restrict__ score_out,
+                                  int32_t* __restrict__ obs_out) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_groups) return;
   const int t = it.grp_off ? it.members[it.grp_off[g]] : g;
@@ -403,9 +454,15 @@ __global__ void group_gate_kernel(const FastRootDev fr, const ItemsDev it, const
   const bool deleted = excl >= 0 && fr.counts && fr.counts[excl] <= 1;
   bool need = true;
   double sc = 0.0;
+  // the observed values of the group's row: gathered once, here, and handed on to group_desc_kernel (obs_out)
+  int o[PCLEAN_MAX_TERMS];
+  load_row_obs(fr, row, o);
+  {
+    int4* po = reinterpret_cast<int4*>(obs_out + (size_t)g * PCLEAN_MAX_TERMS);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) po[q] = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+  }
   if (excl >= 0 && !deleted && fr.logc_m1) {
-    int o[PCLEAN_MAX_TERMS];
-    for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) o[f] = f < fr.n_terms ? fr.terms[f].obs_col[row] : -1;
     sc = fast_exact_score(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]);
     double ub = fr.scal[2] - fr.scal[1];
     for (int c = 0; c < gt.n; ++c) {
@@ -422,9 +479,10 @@ __global__ void group_gate_kernel(const FastRootDev fr, const ItemsDev it, const
   score_out[g] = sc;
 }
 int pclean_launch_group_gate(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const GateDev& gt, int32_t* flag,
-                             double* score_out) {
+                             double* score_out, int32_t* obs_out) {
   if (it.n <= 0) return PCLEAN_OK;
-  hipLaunchKernelGGL(group_gate_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, it, gt, it.n, flag, score_out);
+  hipLaunchKernelGGL(group_gate_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, it, gt, it.n, flag, score_out,
+                     obs_out);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }
@@ -636,21 +694,35 @@ __global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, 
 __global__ __launch_bounds__(1024) void worklist_pack_kernel(const int32_t* __restrict__ seg_list, int seg_cap,
                                                              unsigned int* __restrict__ chunk_ctr, int32_t* __restrict__ dense,
                                                              unsigned int* __restrict__ stat) {
+  static_assert(WL_SEGS == 64, "one wavefront reads the segment counters");
   __shared__ unsigned int off[WL_SEGS + 1];
-  if (threadIdx.x == 0) {
-    unsigned int run = 0;
-    for (int sgm = 0; sgm < WL_SEGS; ++sgm) {
-      off[sgm] = run;
-      run += chunk_ctr[WL_SEG_CTR(sgm)];
+  if (threadIdx.x < 64) {  // exclusive prefix of the 64 segment lengths: lane s holds segment s
+    const unsigned int n = chunk_ctr[WL_SEG_CTR(threadIdx.x)];
+    unsigned int incl = n;
+    for (int sh = 1; sh < 64; sh <<= 1) {
+      const unsigned int x = __shfl_up(incl, sh, 64);
+      if ((int)threadIdx.x >= sh) incl += x;
     }
-    off[WL_SEGS] = run;
-    chunk_ctr[WAVE_WORK_CTR] = run;
-    if (stat) *stat = run;
+    off[threadIdx.x] = incl - n;
+    if (threadIdx.x == 63) {
+      off[WL_SEGS] = incl;
+      chunk_ctr[WAVE_WORK_CTR] = incl;
+      if (stat) *stat = incl;
+    }
   }
   __syncthreads();
-  for (int sgm = 0; sgm < WL_SEGS; ++sgm) {
-    const unsigned int n = off[sgm + 1] - off[sgm];
-    for (unsigned int j = threadIdx.x; j < n; j += 1024) dense[off[sgm] + j] = seg_list[(size_t)sgm * seg_cap + j];
+  // every entry of the dense list in one pass: its segment by bisection of the offsets
+  const unsigned int total = off[WL_SEGS];
+  for (unsigned int i = threadIdx.x; i < total; i += 1024) {
+    int lo = 0, hi = WL_SEGS - 1;  // largest s with off[s] <= i
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (off[mid] <= i)
+        lo = mid;
+      else
+        hi = mid - 1;
+    }
+    dense[i] = seg_list[(size_t)lo * seg_cap + (i - off[lo])];
   }
 }
 
@@ -1558,7 +1630,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
                             int32_t* desc_scratch, int32_t* overflow_list, unsigned int* scan_stats, int n_items,
-                            const double* pre_score, bool want_worklist, unsigned int* wl_stat) {
+                            const double* pre_score, bool want_worklist, unsigned int* wl_stat, const int32_t* pre_obs) {
   if (it.n <= 0) return PCLEAN_OK;
   const size_t ng = (size_t)it.n;
   unsigned int* chunk_ctr = reinterpret_cast<unsigned int*>(desc_scratch + ng * GD_STRIDE);
@@ -1575,7 +1647,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   static const bool want_resolve = getenv("PCLEAN_RESOLVE_GROUPS") != nullptr;
   const bool resolve = n_draws > 0 && want_resolve && (!it.grp_off || n_items > 0);
   hipLaunchKernelGGL(group_desc_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, it, ch, it.n,
-                     desc_scratch, chunk_ctr, g_m, g_U, resolve ? g_res : nullptr, scan_stats, pre_score);
+                     desc_scratch, chunk_ctr, g_m, g_U, resolve ? g_res : nullptr, scan_stats, pre_score, pre_obs);
   // the easy groups settled by a few lanes each (group_settle_kernel): launches that draw, large enough to matter
   static const bool no_settle = getenv("PCLEAN_NO_SETTLE") != nullptr;
   const bool settle = !no_settle && !resolve && n_draws > 0 && !fr.is_leaf && fr.n_pre >= 1 && fr.n_pre <= 3 && fr.cstride > 0 &&

@@ -1227,15 +1227,19 @@ __global__ void gather_moved_kernel(int n, const int32_t* list, const int32_t* c
 // unobserved discrete choices of a new row from their prior proposals (42-56; q_cont and p cancel, a chosen
 // ProposalDummyValue leaves -log(dummy mass) and gets random(dist), 58-60) and p accumulates the log-density of the
 // observed choices given the sampled values (62-64): the particle's weight increment is the likelihood of its sampled
-// sub-tree.  Implemented for plans whose likelihood terms are AddTypos observations (plain or through a JuliaNode).
+// sub-tree: AddTypos observations (plain or through a JuliaNode), noise-free observations (equality constraints: 0 or
+// -inf), the MaybeSwap observations of the referring rows of a latent class; a scoring block proposes nothing and scores as
+// always (62-64).  NOT implemented: blocks with a Gaussian term — their own choices (enumerated inside the candidate branch
+// by the data-driven proposal) would be sampled from their priors, the retained particle keeping the row's current ones.
 int prior_mode_supported(pclean_ctx* ctx, const Block& b, const char* who) {
-  bool ok = b.valid && !b.is_score;
-  for (const pclean_term& tm : b.terms) ok = ok && tm.dens_kind == PCLEAN_DENS_ADD_TYPOS;
+  bool ok = b.valid;
+  for (const pclean_term& tm : b.terms)
+    ok = ok && (tm.dens_kind == PCLEAN_DENS_ADD_TYPOS || tm.dens_kind == PCLEAN_DENS_EQUAL || tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP);
   for (int g : b.node_gauss) ok = ok && g < 0;
   if (!ok)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "%s: use_dd_proposals = false (prior proposals, block_proposal.jl:168) is implemented "
-                                            "for plans whose likelihood terms are AddTypos observations; this plan has equality "
-                                            "constraints, MaybeSwap, Gaussian terms or a scoring block", who);
+                                            "for plans whose likelihood terms are AddTypos, equality or MaybeSwap observations and "
+                                            "for scoring blocks; this plan has a Gaussian term", who);
   return PCLEAN_OK;
 }
 

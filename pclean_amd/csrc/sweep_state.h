@@ -53,6 +53,10 @@ struct FastRoot {  // candidate-compact tables of a reference slot (root_wave.hi
   int kpad = 0;
   double logc_max = 0.0;  // max over candidates of log(count - discount)
   int wl_off = 0;  // > 0: the settle kernel left most groups of this node unsettled: that many launches run without the work list
+  // the node's observed values ROW-MAJOR ([n_rows][PCLEAN_MAX_TERMS] int32: the 64 bytes a group's descriptor wants of its
+  // row in one piece instead of one line per term column); the observations never change during a run: built once
+  DevBuf<int32_t> obs_rm;
+  uint64_t obs_rm_key = 0;
 };
 
 struct SweepState {

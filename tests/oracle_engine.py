@@ -89,7 +89,7 @@ class OracleEngine:
                                              orc._p(cur, C.c_int32), orc._p(choice, C.c_int32), orc._p(chosen, C.c_int32),
                                              orc._p(logml, C.c_double))
             if rc:
-                raise ValueError("use_dd_proposals = false is implemented for plans whose likelihood terms are AddTypos observations")
+                raise ValueError("use_dd_proposals = false is not implemented for plans with a Gaussian term")
             for b, blk in enumerate(lw.blocks):
                 if blk.get("score"):
                     continue

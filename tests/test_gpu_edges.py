@@ -146,7 +146,8 @@ def test_use_dd_proposals_false_prior_proposals(oracle):
     their prior proposals, weight = likelihood of the sampled values (propose_non_enumerable!, 24-157).  HIP == oracle
     bit for bit on hospital (two blocks, the second with a JuliaNode context; PG and MH) and on the `people` program
     (prior draws of a StringPrior choice are the ProposalDummyValue: random strings weighed against the observation);
-    plans with equality constraints / MaybeSwap / Gaussian terms are refused with a message."""
+    plans with a Gaussian term are refused with a message (equality constraints, MaybeSwap and scoring blocks:
+    test_gpu_flights.py)."""
     import dummy_program as dp
     S = helpers.hospital_setup(n_rows=300)
     cases = [(S["lw"], S["obs"], S["trace"], 2)]
@@ -186,7 +187,7 @@ def test_use_dd_proposals_false_prior_proposals(oracle):
     eng = Engine(R["lw"], R["obs"], dist_mode=1)
     try:
         eng.upload_trace(R["trace"])
-        with pytest.raises(PCleanHipError, match="AddTypos"):
+        with pytest.raises(PCleanHipError, match="Gaussian"):
             eng.sweep(R["trace"], InferenceConfig(1, 4, use_dd_proposals=False), 1, 0)
     finally:
         eng.close()

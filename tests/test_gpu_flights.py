@@ -17,22 +17,28 @@ from test_flights_cpu import flights_setup, oracle_sweep
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("particles,mh", [(2, True), (10, False)])
-def test_flights_sweep_and_latent_parity(oracle, particles, mh):
+@pytest.mark.parametrize("particles,mh,dd", [(2, True, True), (10, False, True), (2, True, False), (6, False, False)])
+def test_flights_sweep_and_latent_parity(oracle, particles, mh, dd):
+    """dd = False: prior proposals (use_dd_proposals = false, block_proposal.jl:42-84,168) on a plan with equality-constrained
+    slots, a MaybeSwap scoring block and MaybeSwap evidence terms in the latent sweeps — referents from the CRP prior, new
+    rows' choices from their (keyed) prior proposals, weights = likelihood of the sampled values; particle 0 retained."""
+    from pclean_amd.inference import latent_current_choices
     dirty, clean, lw, obs = flights_setup()
     eng = Engine(lw, obs, dist_mode=1)
     try:
-        cfg = InferenceConfig(1, particles, use_mh_instead_of_pg=mh, rejuv_frequency=500)
-        c = InferConfig(1, cfg.num_particles, 1, 1, int(mh), 50, 100)
+        cfg0 = InferenceConfig(1, particles, use_mh_instead_of_pg=mh, rejuv_frequency=500)
+        cfg = InferenceConfig(1, particles, use_mh_instead_of_pg=mh, rejuv_frequency=500, use_dd_proposals=dd)
+        c = InferConfig(1, cfg.num_particles, int(dd), 1, int(mh), 50, 100)
         tr = Trace(lw, obs.shape[1], 2)
-        initialize_trace(eng, tr, cfg, 2, max_batch=512)
+        initialize_trace(eng, tr, cfg0, 2, max_batch=512)
         tr.check_consistency()
         for sweep in range(2):
             tr.resample_parameters()
             for cname in ["TrackingWebsite", "Flight"]:
                 pl = lw.latent_plans[cname]
                 live, ev_off, ev_rows, ev_ctx = build_evidence(lw, tr, cname)
-                excl = np.full((len(pl["roots"]), len(live)), -1, dtype=np.int32)
+                excl = (np.full((len(pl["roots"]), len(live)), -1, dtype=np.int32) if dd
+                        else latent_current_choices(lw, tr, cname, live, cfg))
                 eng.upload_trace(tr)
                 eng.hip.set_active_rows(0, -1)
                 world = helpers.mirror_world(oracle, lw, obs, tr, eng)

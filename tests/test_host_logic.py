@@ -415,6 +415,27 @@ def test_prior_proposals_end_to_end(oracle):
     assert 0.0 <= f1[False] <= f1[True]
 
 
+def test_prior_proposals_end_to_end_flights(oracle):
+    """use_dd_proposals = false on a plan with equality-constrained slots, a MaybeSwap scoring block and MaybeSwap evidence
+    in the latent sweeps (flights): the product's host code runs through with the oracle engine and leaves a consistent
+    trace.  (Prior draws almost never satisfy a noise-free observation: nearly every weight is -inf and the result is as
+    poor as the reference's would be — the flag is there for completeness, block_proposal.jl:168.)"""
+    from oracle_engine import OracleEngine
+    from test_flights_cpu import flights_setup
+    from pclean_amd.analysis import evaluate_accuracy
+    from pclean_amd.engine import InferenceConfig
+    from pclean_amd.inference import initialize_trace, run_inference
+    from pclean_amd.trace import Trace
+    dirty, clean, lw, obs = flights_setup()
+    eng = OracleEngine(oracle, lw, obs)
+    tr = Trace(lw, obs.shape[1], 1)
+    cfg = InferenceConfig(1, 3, use_dd_proposals=False, rejuv_frequency=500)
+    initialize_trace(eng, tr, cfg, 5, max_batch=256)
+    run_inference(eng, tr, cfg, 5)
+    tr.check_consistency()
+    assert 0.0 <= evaluate_accuracy(lw, tr, dirty, clean)["f1"] < 0.5
+
+
 def test_py_moves_commute_with_the_sweep_of_the_class_own_rows(oracle):
     """A latent class without learned parameters is swept in ONE batch and its table's Pitman-Yor moves are made after
     the batch (inference.latent_sweep).  The claim behind it: those moves' conditional (the table's reference counts,

@@ -181,3 +181,40 @@ def test_prior_proposal_weights_equal_the_literal_likelihood(oracle):
         assert abs(logml[i] - want) <= 1e-10 * max(1.0, abs(want)), (i, logml[i], want)
         checked += 1
     assert checked > 200
+
+
+def test_prior_proposal_weights_flights_equal_the_literal_likelihood(oracle):
+    """use_dd_proposals = false on flights (block_proposal.jl:62-64,168): equality-constrained slots and the MaybeSwap
+    scoring block.  One particle that is the retained one (every row keeps its current referents): the log marginal
+    likelihood estimate of a row is the likelihood of its observations given those referents — 0 for the noise-free
+    observations that hold, plus the four MaybeSwap densities through the learned error probabilities, which the literal
+    interpreter evaluates from the model description (score_block).  The data-driven sweep of the same state gives the
+    enumeration's marginal instead: the flag really switches the weight."""
+    import literal as lit
+    from oracle_engine import OracleEngine
+    from pclean_amd.engine import InferenceConfig
+    S = helpers.flights_setup()
+    lw, tr, dirty, m, q = S["lw"], S["trace"], S["dirty"], S["model"], S["query"]
+    ocls = m.classes[q.cls]
+    lt = lit.lit_trace_from(lw, tr)
+    eng = OracleEngine(oracle, lw, S["obs"])
+    n = 400
+    choice, chosen, logml, new_rows = eng.sweep(tr, InferenceConfig(1, 1, use_dd_proposals=False), 5, 0, 0, n)
+    assert np.array_equal(choice[:, :n], tr.cur[:, :n]) and not new_rows
+    dd = eng.sweep(tr, InferenceConfig(1, 1), 5, 0, 0, n)
+    blocks = [b for b in ocls.blocks]
+    slot_blocks = [b for b in blocks if any(ocls.attr(a).kind == "fk" for a in b)]
+    score_blocks = [b for b in blocks if not any(ocls.attr(a).kind == "fk" for a in b)]
+    assert len(score_blocks) == 1
+    checked = differs = 0
+    for i in range(n):
+        row = {c: dirty[c][i] for c in q.obsmap}
+        referents = {}
+        for bi, battrs in enumerate(slot_blocks):
+            fk = [a for a in battrs if ocls.attr(a).kind == "fk"][0]
+            referents[fk] = int(tr.cur[bi, i])  # (lit_trace_from keeps the product's row ids as keys)
+        want = lit.score_block(lt, q, score_blocks[0], row, referents)
+        assert abs(logml[i] - want) <= 1e-10 * max(1.0, abs(want)), (i, logml[i], want)
+        checked += 1
+        differs += abs(dd[2][i] - logml[i]) > 1e-9
+    assert checked == n and differs > 0
