@@ -171,22 +171,22 @@ def roofline_model(rs, obs_local, particles):
 
 
 def step_byte_model(n, p, rs, n_groups_block1, n_obs_compact, kpad_compact, delta_rows):
-    """Algorithmic bytes of the five largest movers of one sweep besides the root scan (profiles/r04_step_traffic.txt names
-    them), per kernel: what each has to read and write once, in bytes.  n rows, p particles."""
+    """Algorithmic bytes of the largest movers of one sweep besides the root scan of block 0 (profiles/r05_step_traffic.txt
+    names them), per kernel group of the ROUND-5 step: what each has to read and write once, in bytes.  n rows, p particles.
+    (Gone since round 4: the per-item gate of the new-row branch — the gate runs per group inside the root-scan launch
+    group, roofline.alg_bytes_per_launch — and the resampling step after the first block, a no-op that is not launched.)"""
     np_ = n * p
     m = {}
-    # block 0: draws [N][P] + lse + cur in, pchoice + weights out (the first block stores the weights); block 1: the
-    # particle's item (4), its draw (4), its item's lse (8, mostly shared), weights read + written, pchoice out
-    m["particle_update_kernel"] = np_ * (4 + 4 + 8) + n * 12 + np_ * (4 + 4 + 8 + 16 + 4)
-    # grouping: three 1M-item sorts of (32-bit key, 32-bit index) pairs: histogram pass + 4 onesweep passes (read + write)
+    # block 0 (particle_update_kernel): draws [N][P] + lse + cur in, pchoice + weights out (the first block stores the
+    # weights); block 1 (particle_update_final_kernel): the particle's item (4), its draw (4), its item's lse (8, mostly
+    # shared), weights read, the final choice made in the same kernel: chosen particle + choice out per row
+    m["particle_update_kernel + particle_update_final_kernel"] = np_ * (4 + 4 + 8) + n * 12 + np_ * (4 + 4 + 8 + 8) + n * 12
     # grouping through the hash table (eval.hip: make_item_groups_hash), three per sweep: the table (2n slots x 8 B) zeroed,
     # per item its key words (12 B) + a probe (line) + slot / position out (8 B), the scan over the slots (16 B each way),
     # the fill (slot, position, the slot's offsets: 8 + 16 B in, member / head / uid out: 12 B)
     m["hash grouping: table zero + insert + slot scan + fill (3 groupings)"] = 3 * (2 * n * 8 + n * (12 + LINE + 8) + 2 * n * 16 + n * (8 + 16 + 12))
-    m["maybe_resample_kernel + apply_ancestors"] = np_ * 8 + n * (8 + 4 + 4) + np_ * 4
     m["gather_ctx + ctx_count + ctx_fill"] = np_ * (4 + 4) + np_ * 4 + n * 8 + np_ * 4 + n * (4 + 16 + 4) + np_ * 4
-    m["final_choice + finalize_block x2 + ordered lists"] = np_ * 8 + n * 12 + 2 * n * (4 + 4 + 16) + 4 * n * 4
-    m["gate_new_kernel x2"] = 2 * n * (rs.n_terms * LINE // 2 + 16)
+    m["final choice of the flagged rows + finalize_block x2 + tail lists"] = n * 12 + 2 * n * (4 + 4 + 16) + 4 * n * 4
     m["compact table refresh (Measure)"] = sum(delta_rows * no * (LINE // 2) + no * kp * 1 for no, kp in zip(n_obs_compact, kpad_compact))
     m["root scans of the Measure slot + nested slots (group descriptors + draws)"] = n_groups_block1 * (2 * 128 + 4 * LINE) + n * (8 + 4 * p)
     return {k: float(v) for k, v in m.items()}
@@ -501,8 +501,10 @@ def main():
                           "dispatches_per_step": st.get("dispatches"), "source": st.get("source"),
                           "by_kernel_counters": st.get("by_kernel")}
         step_model = dict(step_model or {}, alg_bytes_model=per_kernel, alg_bytes_modelled=sum(per_kernel.values()),
-                          note="alg_bytes_model: what each kernel group has to read and write once (bench.step_byte_model); the Measure "
-                               "slot's root scan and the nested slots are covered by counters only")
+                          note="alg_bytes_model: what each kernel group of the round-5 step has to read and write once "
+                               "(bench.step_byte_model); the Measure slot's root scan, the new-row sampling and the commit are "
+                               "covered by counters only, so hbm_bytes_per_step / alg_bytes_modelled over-states the waste",
+                          traffic_over_alg_modelled=(st["hbm_bytes_per_step"] / sum(per_kernel.values())) if st and per_kernel else None)
         out = {
             "metric": "rows/sec per Gibbs sweep on 1M-row synthetic hospital; F1 vs ground truth",
             "value": value, "unit": "rows/s/sweep", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -85,6 +85,9 @@ struct World {
    * ProposalDummyValue needs (block_proposal.jl:58-60; sweep.h: dummy_correction) */
   std::vector<uint16_t> sym;
   std::vector<int64_t> off;
+  /* current own choices of the observed rows per block ([n_rows][2], local row index; empty: none): what the retained
+   * particle of a prior-proposal sweep keeps (sweep.h: gauss_prior_term) */
+  std::vector<std::vector<int32_t>> cur_locals;
   std::vector<double> lm_init, lm_trans; /* [28], [28*28] ([prev][next]) */
   std::vector<uint16_t> letter_sym;      /* [28] pool symbol of every alphabet letter, 0xFFFF = absent */
   /* evidence sets added ROW BY ROW (every term of an evidence row, then the next row): the reference's own order of
@@ -92,7 +95,7 @@ struct World {
    * order the HIP path uses (per term, distinct (ctx, observed value) pairs x multiplicity).  A CPU test holds the
    * two within 1e-9 of each other (tests/test_literal_fixtures.py). */
   bool ev_row_by_row = false;
-  World() : mean(64), pair(64), table(64), fn(64), block(16) {}
+  World() : mean(64), pair(64), table(64), fn(64), block(16), cur_locals(16) {}
 };
 
 static const double HALF_LOG26 = 1.629048269010741; /* log(26)/2, add_typos.jl:63 */
@@ -337,7 +340,9 @@ inline void node_scores(const World& w, int block_id, int node_id, int row, cons
       out[k] += term_density(w, tm, pt, d, val);
     }
   }
-  if (gs && w.xnum[(size_t)gs->x_col * w.n_rows + row] == w.xnum[(size_t)gs->x_col * w.n_rows + row])
+  /* (SCORE_TERMS on a single row = a prior-proposal sweep of the observed class: the Gaussian term is scored by
+   * gauss_prior_term at the sampled own choices, sweep.h — not marginalised here) */
+  if (gs && mode != SCORE_TERMS && w.xnum[(size_t)gs->x_col * w.n_rows + row] == w.xnum[(size_t)gs->x_col * w.n_rows + row])
     for (int k = 0; k < n; ++k) {
       if (!(out[k] > NEG_INF)) continue;
       out[k] += gauss_lse(gauss_combo_scores(w, *gs, row, nullptr, [&](int d) -> int {

@@ -317,6 +317,11 @@ class World:
     def set_gauss(self, block, node, g):
         self.L.pco_world_set_gauss(self.h, block, node, C.byref(g))
 
+    def set_cur_locals(self, block, locals_):
+        """current own choices ([n][2]) of the sweep window's rows: kept by the retained particle of a prior-proposal sweep"""
+        a = np.ascontiguousarray(locals_, dtype=np.int32).reshape(-1, 2)
+        self.L.pco_world_set_cur_locals(self.h, block, len(a), _p(a, C.c_int32))
+
     def get_locals(self, block, n_rows):
         out = np.empty((n_rows, 2), dtype=np.int32)
         self.L.pco_get_locals(block, n_rows, _p(out, C.c_int32))

@@ -282,6 +282,11 @@ int pco_sweep_latent(const pco::World* w, const pclean_infer_config* cfg, uint64
                     chosen, vals);
   return 0;
 }
+/* current own choices of the rows of `block` ([n_rows][2], the sweep window's row index): the retained particle of a
+ * prior-proposal sweep keeps them; n_rows = 0 clears */
+void pco_world_set_cur_locals(pco::World* w, int block, int n_rows, const int32_t* locals) {
+  w->cur_locals[block].assign(locals, locals + (size_t)n_rows * 2);
+}
 void pco_get_locals(int block, int n_rows, int32_t* out) {
   for (int i = 0; i < n_rows; ++i) {
     out[2 * i] = g_locals[((size_t)i * g_locals_blocks + block) * 2];

@@ -107,15 +107,67 @@ inline void sample_new(const RowCtx& rc, int node, int excl, uint32_t particle, 
  * p accumulates the log-density of every observed choice given the sampled values (62-64).  The particle's weight
  * increment is therefore the likelihood of its sampled sub-tree: AddTypos observations (plain or through a JuliaNode),
  * noise-free observations (equality: 0 or -inf), MaybeSwap observations of the referring rows (latent classes); a
- * scoring block has nothing to propose and scores as always (62-64).  Blocks with a Gaussian term are refused by the
- * callers (their own enumerated choices would be sampled from their priors, the retained particle keeping its own). ---- */
+ * scoring block has nothing to propose and scores as always (62-64).  A block with a Gaussian term on its slot
+ * (experiments/rents/run.jl:19-25): the own choices the data-driven proposal enumerates inside the candidate branch are
+ * sampled from their priors as well (gauss_prior_term); the Gaussian evidence of a latent class, whose rows' own choices are
+ * given, is a likelihood term like any other.  Refused: Gaussian terms on other nodes or with context sources. ---- */
 inline bool prior_mode_supported(const OBlock& b) {
   for (const pclean_term& tm : b.terms)
     if (tm.dens_kind != PCLEAN_DENS_ADD_TYPOS && tm.dens_kind != PCLEAN_DENS_EQUAL && tm.dens_kind != PCLEAN_DENS_MAYBE_SWAP)
       return false;
-  for (int g : b.node_gauss)
-    if (g >= 0) return false; /* own choices enumerated inside the candidate branch: not restated for prior proposals */
+  /* (observed class) the slot's Gaussian term is scored once per particle by gauss_prior_term, whatever was sampled below
+   * the slot: the copies of the term on the nodes of a new row's choices — there for the enumeration — are not looked at */
+  const bool root_g = !b.node_gauss.empty() && b.node_gauss[0] >= 0;
+  for (size_t i = 0; i < b.node_gauss.size(); ++i) {
+    if (b.node_gauss[i] < 0) continue;
+    const pclean_gauss& g = b.gauss[b.node_gauss[i]];
+    if (i != 0) {
+      if (g.n_locals > 0 && !root_g) return false;
+      continue; /* n_locals == 0: the evidence of a latent class, a likelihood term like any other */
+    }
+    for (int d = 0; d < g.n_dims; ++d)
+      if (g.src_kind[d] != PCLEAN_GSRC_CAND && g.src_kind[d] != PCLEAN_GSRC_OBS && g.src_kind[d] != PCLEAN_GSRC_LOCAL) return g.n_locals == 0;
+    if (g.transform_src_kind == PCLEAN_GSRC_EVCTX) return g.n_locals == 0;
+  }
   return true;
+}
+
+/* Prior proposal of the own choices of a block with a Gaussian term (block_proposal.jl:42-56,62-64): an OBSERVED own
+ * choice is scored (its ChooseUniformly density enters p), an unobserved one is sampled from its prior — uniform, the
+ * proposal's and the model's densities cancel — by particle `particle` (the retained particle keeps the row's current
+ * ones, `keep`), and the observed number is scored given the sampled values.  Returns what p accumulates; loc[2] = the
+ * particle's own choices.  Uniform draw of choice l: floor(R * n_l / 2^64), R from the stream of
+ * (site PCLEAN_SITE_LOCALS(block), particle | (l + 1) << 16).  Additions in this order onto 0.0: observed choices'
+ * densities (choice 0, then 1), the Normal log-density, minus the transformation's log |derivative|. */
+template <typename ValFn>
+inline double gauss_prior_term(const World& w, const pclean_gauss& g, int block, int row, uint32_t rr, uint32_t particle,
+                               uint64_t seed, uint32_t sweep, const int32_t* keep, ValFn val, int32_t* loc) {
+  int l[2] = {0, 0};
+  double s = 0.0;
+  loc[0] = loc[1] = -1;
+  for (int i = 0; i < g.n_locals; ++i) {
+    const int o = g.local_obs_col[i] >= 0 ? w.obs[(size_t)g.local_obs_col[i] * w.n_rows + row] : -1;
+    if (o >= 0) {
+      l[i] = o;
+      s += -std::log((double)g.local_n[i]);
+    } else if (keep && keep[i] >= 0) {
+      l[i] = keep[i];
+    } else {
+      l[i] = (int)pclean_mulhi64(pclean_rand64(seed, rr, PCLEAN_SITE_LOCALS(block), particle | ((uint32_t)(i + 1) << 16), sweep),
+                                 (uint64_t)g.local_n[i]);
+    }
+    loc[i] = l[i];
+  }
+  const double xv = w.xnum[(size_t)g.x_col * w.n_rows + row];
+  if (xv != xv) return s; /* missing number: nothing to score */
+  const std::vector<double>& mu = w.mean[g.mean_table];
+  int idx = 0;
+  for (int d = 0; d < g.n_dims; ++d) idx += g.stride[d] * (g.src_kind[d] == PCLEAN_GSRC_LOCAL ? l[g.src[d]] : val(d));
+  const int u = g.transform_src_kind == PCLEAN_GSRC_LOCAL ? l[g.transform_src] : 0;
+  const double z = (xv * g.t_scale[u] - mu[idx]) / g.sigma;
+  s += -0.5 * z * z - std::log(g.sigma) - 0.91893853320467274178;
+  s -= g.t_logabsderiv[u];
+  return s;
 }
 
 /* prior draws of the sub-choices of a freshly proposed row of `node`'s table */
@@ -315,6 +367,7 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
                         int row, int64_t row_offset, const int32_t* cur /*[n_blocks]*/, int32_t* choice /*[n_blocks]*/,
                         int32_t* chosen_particle, double* logml, std::vector<NewRow>& new_rows,
                         int32_t* locals_out = nullptr /*[n_blocks][2]*/) {
+  std::vector<std::vector<int32_t>> plocals(n_blocks); /* prior proposals: every particle's own choices [P][2] */
   const bool use_mh = cfg.use_mh_instead_of_pg != 0;
   const int P = use_mh ? 2 : cfg.num_particles;
   const uint32_t rr = (uint32_t)((int64_t)row + row_offset);
@@ -398,6 +451,18 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
           if (has_dummy[bi]) corr = dummy_correction(rc, pvals[bi][p].data(), (uint32_t)p);
         }
         wts[p] += subtree_terms(rc, 0, c, excl, pvals[bi][p].data());
+        if (!b.node_gauss.empty() && b.node_gauss[0] >= 0) {
+          const pclean_gauss& g = b.gauss[b.node_gauss[0]];
+          const OTable& rt = w.table[b.nodes[0].table];
+          if (plocals[bi].empty()) plocals[bi].assign((size_t)P * 2, -1);
+          const std::vector<int32_t>& cl = w.cur_locals[bi];
+          const int32_t* keep = (p == 0 && cur[bi] >= 0 && cl.size() >= (size_t)(row + 1) * 2) ? &cl[(size_t)row * 2] : nullptr;
+          wts[p] += gauss_prior_term(w, g, bi, row, rr, (uint32_t)p, seed, sweep, keep, [&](int d) -> int {
+            if (g.src_kind[d] == PCLEAN_GSRC_CAND)
+              return c >= 0 ? rt.cols[(size_t)g.src[d] * rt.n_rows + c] : resolve_new_value(w, b, 0, g.src[d], pvals[bi][p].data());
+            return w.obs[(size_t)g.src[d] * w.n_rows + row];
+          }, &plocals[bi][(size_t)p * 2]);
+        }
         wts[p] += corr;
       }
     } else if (b.n_ctx == 0) {
@@ -439,6 +504,14 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
           }
           pch[k].swap(nc);
           pvals[k].swap(nv);
+          if (!plocals[k].empty()) {
+            std::vector<int32_t> nl((size_t)P * 2);
+            for (int p = 0; p < P; ++p) {
+              nl[(size_t)p * 2] = plocals[k][(size_t)anc[p] * 2];
+              nl[(size_t)p * 2 + 1] = plocals[k][(size_t)anc[p] * 2 + 1];
+            }
+            plocals[k].swap(nl);
+          }
         }
         for (int p = 0; p < P; ++p) wts[p] = 0.0;
       }
@@ -461,7 +534,10 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
     }
     /* own enumerated choices (locals) of the chosen particle given its referent */
     const OBlock& b = w.block[bi];
-    if (locals_out && !b.node_gauss.empty() && b.node_gauss[0] >= 0 && b.gauss[b.node_gauss[0]].n_locals > 0) {
+    if (locals_out && !cfg.use_dd_proposals && !plocals[bi].empty()) { /* prior proposals: what the chosen particle sampled */
+      locals_out[2 * bi] = plocals[bi][(size_t)c * 2];
+      locals_out[2 * bi + 1] = plocals[bi][(size_t)c * 2 + 1];
+    } else if (locals_out && !b.node_gauss.empty() && b.node_gauss[0] >= 0 && b.gauss[b.node_gauss[0]].n_locals > 0) {
       const pclean_gauss& g = b.gauss[b.node_gauss[0]];
       const OTable& rt = w.table[b.nodes[0].table];
       const int ch = pch[bi][c];

@@ -85,11 +85,13 @@ class OracleEngine:
             w = self._world(trace, lo, hi)
             cfg = self._cfg(config)
             cur = np.ascontiguousarray(trace.cur[:, lo:hi])
+            for bi in lw.locals:  # (only a prior-proposal sweep looks at them: its retained particle keeps the row's own choices)
+                w.set_cur_locals(bi, trace.locals[bi][lo:hi])
             rc = orc.lib().pco_sweep_batched(w.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep_idx), nb, C.c_int64(lo),
                                              orc._p(cur, C.c_int32), orc._p(choice, C.c_int32), orc._p(chosen, C.c_int32),
                                              orc._p(logml, C.c_double))
             if rc:
-                raise ValueError("use_dd_proposals = false is not implemented for plans with a Gaussian term")
+                raise ValueError("use_dd_proposals = false: plan shape not supported (Gaussian term off the slot or with context sources)")
             for b, blk in enumerate(lw.blocks):
                 if blk.get("score"):
                     continue

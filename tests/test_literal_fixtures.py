@@ -218,3 +218,70 @@ def test_prior_proposal_weights_flights_equal_the_literal_likelihood(oracle):
         checked += 1
         differs += abs(dd[2][i] - logml[i]) > 1e-9
     assert checked == n and differs > 0
+
+
+def test_prior_proposal_weights_rents_equal_the_literal_likelihood(oracle):
+    """use_dd_proposals = false on rents (a Gaussian term whose own choices the data-driven proposal enumerates inside the
+    candidate branch, experiments/rents/run.jl:19-25).  One particle, the retained one: it keeps the row's current county AND
+    its current own choices (room type, unit), and the log marginal likelihood estimate of the row is the likelihood of
+    its observations given them — the typo density of the county name, the ChooseUniformly density of an OBSERVED room
+    type (a sampled choice's density cancels against its proposal, block_proposal.jl:42-56), and the TransformedGaussian
+    density of the rent at the current unit — which the literal interpreter's pieces give from strings and the model
+    description.  The chosen particle reports the own choices it kept."""
+    import importlib.util
+    import literal as lit
+    from oracle_engine import OracleEngine
+    from pclean_amd.engine import InferenceConfig
+    import os
+    spec = importlib.util.spec_from_file_location("mk_rents", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                                                       "make_literal_fixtures_rents.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    S = helpers.rents_setup()
+    lw, tr, dirty, m, q = S["lw"], S["trace"], S["dirty"], S["model"], S["query"]
+    ocls = m.classes[q.cls]
+    n = 300
+    gattr = ocls.attr(lw.gauss_spec["gauss_attr"])
+    units = ocls.attr(gattr.dist.unit).dist.options
+    rooms = ocls.attr("br").dist.options
+    for i in range(n):  # a current state of the own choices: the observed room type (else one by row), units alternating
+        rt = dirty["Room Type"][i]
+        tr.locals[0][i] = (rooms.index(rt) if rt is not None else i % len(rooms), i % len(units))
+    lt = lit.lit_trace_from(lw, tr)
+    mean_of = mk.mean_lookup(lw, tr)
+    eng = OracleEngine(oracle, lw, S["obs"])
+    choice, chosen, logml, new_rows = eng.sweep(tr, InferenceConfig(1, 1, use_dd_proposals=False), 8, 0, 0, n)
+    assert np.array_equal(choice[:, :n], tr.cur[:, :n]) and not new_rows
+    assert np.array_equal(tr.pending_locals[0][:n], tr.locals[0][:n])
+    battrs = ocls.blocks[0]
+    checked = with_number = 0
+    for i in range(n):
+        row = {c: dirty[c][i] for c in q.obsmap}
+        gb = lit.GaussBlockProposal(lt, q, battrs, row, mean_of)
+        vals = lt.tables["County"][int(tr.cur[0, i])]
+        want = 0.0
+        for path, v in gb.direct.items():
+            assert v is None or vals[path] == v
+        for path, v, mt in gb.typos:
+            if v is not None:
+                want += lit.add_typos_logpdf(v, vals[path], mt)
+        own = {"br": rooms[tr.locals[0][i, 0]], gattr.dist.unit: units[tr.locals[0][i, 1]]}
+        for name in gb.own:
+            if gb.own_obs.get(name) is not None:
+                assert own[name] == gb.own_obs[name]
+                want += -np.log(len(ocls.attr(name).dist.options))
+        if gb.x is not None:
+            unit = own[gattr.dist.unit]
+            args = {a: (vals[a.split(".", 1)[1]] if "." in a else own[a]) for a in gb.look_args}
+            xb = unit.backward(gb.x)
+            want += lit.normal_logpdf(xb, mean_of(args), gattr.dist.std) - np.log(abs(unit.deriv(xb)))
+            with_number += 1
+        assert abs(logml[i] - want) <= 1e-10 * max(1.0, abs(want)), (i, logml[i], want)
+        checked += 1
+    assert checked == n and with_number > 200
+    # more particles: the others sample their own choices; the product's host code takes them from the chosen particle
+    eng.sweep(tr, InferenceConfig(1, 6, use_dd_proposals=False), 8, 1, 0, n)
+    loc = tr.pending_locals[0][:n]
+    assert ((loc[:, 0] >= 0) & (loc[:, 0] < len(rooms)) & (loc[:, 1] >= 0) & (loc[:, 1] < len(units))).all()
+    seen = np.array([dirty["Room Type"][i] is not None for i in range(n)])
+    assert (loc[seen, 0] == tr.locals[0][:n][seen, 0]).all()  # an observed own choice is never sampled
