@@ -171,6 +171,10 @@ function get_locals(c, block, n_rows)                                           
     out = Matrix{Int32}(undef, 2, n_rows)
     GC.@preserve out check(c, ccall((:pclean_get_locals, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}), c.h, block, out)); out
 end
+# current own choices of every observed row (2 x n_rows, 0-based option indices, -1 = none): what the retained particle of a
+# sweep with use_dd_proposals = false keeps (row_inference.jl:143-145; block_proposal.jl:42-56)
+set_cur_locals(c, block, locals::Matrix{Int32}) = GC.@preserve locals check(c,
+    ccall((:pclean_set_cur_locals, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Int32), c.h, block, locals, size(locals, 2)))
 
 # ---- the device-resident commit (csrc/commit.hip; row_inference.jl:169-185 + dependency_tracking.jl:26-236 for a whole
 # sweep): tables uploaded once with spare rows, their allocation state and the rows' referents stay in HBM ----------------

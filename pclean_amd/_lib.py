@@ -292,6 +292,16 @@ class HipContext:
         check(self.h, self.lib.pclean_set_node_gauss(self.h, C.c_int32(block_id), C.c_int32(node_id), C.byref(g)),
               "pclean_set_node_gauss")
 
+    def set_cur_locals(self, block_id, locals_):
+        """current own choices of EVERY observed row ([n_rows][2] int32; None clears): the retained particle of a sweep with
+        use_dd_proposals = false keeps them"""
+        if locals_ is None:
+            check(self.h, self.lib.pclean_set_cur_locals(self.h, C.c_int32(block_id), None, C.c_int32(0)), "pclean_set_cur_locals")
+            return
+        a = np.ascontiguousarray(locals_, dtype=np.int32).reshape(-1, 2)
+        check(self.h, self.lib.pclean_set_cur_locals(self.h, C.c_int32(block_id), _p(a, C.c_int32), C.c_int32(len(a))),
+              "pclean_set_cur_locals")
+
     def get_locals(self, block_id, n_rows):
         out = np.empty((n_rows, 2), dtype=np.int32)
         check(self.h, self.lib.pclean_get_locals(self.h, C.c_int32(block_id), _p(out, C.c_int32)), "pclean_get_locals")

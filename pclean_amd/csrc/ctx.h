@@ -161,6 +161,8 @@ struct Block {
   std::vector<DevBuf<uint64_t>> leaf_udummy;  // fixed-point weight of the ProposalDummyValue option per observed value
   std::vector<int> leaf_drawable;  // per node: -1 unknown, 0 the dummy cannot be drawn for any loaded row, 1 it can
   std::vector<int32_t> new_rows_host, new_vals_host, locals_host;
+  DevBuf<int32_t> cur_locals;  // [n_rows][2] current own choices of every observed row (pclean_set_cur_locals), null: none
+  int cur_locals_rows = 0;
   std::vector<int32_t> moved_rows_host, moved_choice_host;  // rows whose referent changed in the last sweep
 };
 

@@ -175,6 +175,9 @@ int pclean_overflow_fast_ok(const FastRootDev& fr, const ItemsDev& it);
 int pclean_launch_root_flags(pclean_ctx* ctx, int n_groups, const int32_t* gd, const int32_t* grp_off,
                              const int32_t* members, const int32_t* oflag, int32_t* out);
 size_t pclean_fast_desc_words(int n_groups);  // int32 words of desc_scratch for n_groups groups
+// fault hunting (PCLEAN_DEBUG_LATENT): range checks of what the Gaussian evidence term of `node` would dereference
+int pclean_debug_gauss_ev_probe(pclean_ctx* ctx, int n_items, int P, int n_nodes, const NodeDev* nds, int node, const ItemsDev& it,
+                                const int32_t* vals, int n_mean, int n_ev);
 // out[row][f] = obs_col[f][row] (f < n_terms, else -1), rows [0, n_rows): the row-major copy FastRootDev::obs_rm points into
 int pclean_build_obs_rowmajor(pclean_ctx* ctx, const int32_t* const* obs_cols, int n_terms, int n_rows, int32_t* out);
 int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_lat, const int32_t* cand_col,

@@ -21,6 +21,7 @@
 // enum_node_big_kernel — same contract for candidate sets that do not fit in
 // LDS (large option lists of StringPrior / ChooseUniformly leaves): scores are
 // recomputed per pass instead of stored (max pass, weight pass, locate pass).
+#include <vector>
 #include "../../include/pclean_detmath.h"
 #include "../../include/pclean_philox.h"
 #include <algorithm>
@@ -869,7 +870,9 @@ __global__ void prior_terms_ev_kernel(int n_items, int P, int n_nodes, const Nod
   v.item = t;
   v.row = 0;
   v.excl = -1;
-  v.ctxv = nullptr;
+  // (as item_view() does it: a RUN-TIME null.  With a literal nullptr here the Gaussian evidence term — whose value lambda has
+  // a `v.ctxv[...]` case for sources this plan does not have — faulted on address 0 although that case is never taken)
+  v.ctxv = it.ctx ? it.ctx + (size_t)t * PCLEAN_MAX_CTX : nullptr;
   v.ev_lo = it.ev_lo[t];
   v.ev_hi = it.ev_hi[t];
   const int32_t* vv = vals + (size_t)slot * n_nodes;
@@ -889,6 +892,97 @@ __global__ void prior_terms_ev_kernel(int n_items, int P, int n_nodes, const Nod
   double L = 0.0;
   for (int r = 0; r < n_roots; ++r) L += acc[roots[r]];
   w[slot] = L;
+}
+
+// fault hunting (PCLEAN_DEBUG_LATENT): the indices the Gaussian evidence term of `node` would dereference, range-checked
+// instead of dereferenced.  out[slot] = {k, n_cand, ev_lo, ev_hi, rows out of range, smallest / largest mean index, flags}
+__global__ void gauss_ev_probe_kernel(int n_slots, int P, int n_nodes, const NodeDev* __restrict__ nds, int node, ItemsDev it,
+                                      const int32_t* __restrict__ vals, int n_rows, int n_mean, int n_ev, long long* __restrict__ out, int mode) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= n_slots) return;
+  const NodeDev& nd = nds[node];
+  const GaussDev& g = nd.g;
+  const int t = slot / P;
+  const int k = vals[(size_t)slot * n_nodes + node];
+  const int lo = it.ev_lo[t], hi = it.ev_hi[t];
+  long long bad_rows = 0, min_idx = 1ll << 40, max_idx = -(1ll << 40), flags = 0;
+  if (k < 0 || k >= nd.n_cand) flags |= 1;
+  if (lo < 0 || hi > n_ev || lo > hi) flags |= 2;
+  if (!(flags & 3))
+    for (int e = lo; e < hi; ++e) {
+      const int row = it.ev_rows[e];
+      if (row < 0 || row >= n_rows) {
+        ++bad_rows;
+        continue;
+      }
+      const int32_t* evctx = it.ev_ctx ? it.ev_ctx + (size_t)e * PCLEAN_MAX_CTX : nullptr;
+      long long idx = 0;
+      for (int d = 0; d < g.n_dims; ++d) {
+        long long v = 0;
+        if (g.src_kind[d] == PCLEAN_GSRC_CAND) {
+          if (!g.src_ptr[d]) flags |= 4; else v = g.src_ptr[d][k];
+        } else if (g.src_kind[d] == PCLEAN_GSRC_OBS) {
+          if (!g.src_ptr[d]) flags |= 8; else v = g.src_ptr[d][row];
+        } else if (g.src_kind[d] == PCLEAN_GSRC_EVCTX) {
+          if (!evctx) flags |= 16; else v = evctx[g.src_slot[d]];
+        } else {
+          flags |= 32;
+        }
+        idx += (long long)g.stride[d] * v;
+      }
+      if (g.t_kind == PCLEAN_GSRC_EVCTX && evctx) {
+        const int u = evctx[g.t_src];
+        if (u < 0 || u > 3) flags |= 64;
+      }
+      min_idx = idx < min_idx ? idx : min_idx;
+      max_idx = idx > max_idx ? idx : max_idx;
+      if (idx < 0 || idx >= n_mean) flags |= 128;
+      else {
+        const double xv = g.x[row], mv = g.mu[idx];
+        if (xv == xv && !(mv == mv)) flags |= 256;
+        if (mode >= 1) {  // the real thing
+          ItemView v{};
+          v.item = t;
+          v.ctxv = (mode == 1 || !it.ctx) ? nullptr : it.ctx;  // (mode 1: a compile-time null, mode 2: a run-time one)
+          if (mode == 2) v.ctxv = it.ctx ? it.ctx + (size_t)t * PCLEAN_MAX_CTX : nullptr;
+          v.excl = -1;
+          const double gt = gauss_term(nd, v, k, row, evctx);
+          if (!(gt == gt)) flags |= 512;
+        }
+      }
+    }
+  long long* o = out + (size_t)slot * 8;
+  o[0] = k; o[1] = nd.n_cand; o[2] = lo; o[3] = hi; o[4] = bad_rows; o[5] = min_idx; o[6] = max_idx; o[7] = flags;
+}
+int pclean_debug_gauss_ev_probe(pclean_ctx* ctx, int n_items, int P, int n_nodes, const NodeDev* nds, int node, const ItemsDev& it,
+                                const int32_t* vals, int n_mean, int n_ev) {
+  const int n_slots = n_items * P;
+  long long* d = nullptr;
+  if (hipMalloc((void**)&d, (size_t)n_slots * 64) != hipSuccess) return PCLEAN_OK;
+  std::vector<long long> h((size_t)n_slots * 8);
+  for (int mode = 0; mode < 3; mode += 2) {
+    hipLaunchKernelGGL(gauss_ev_probe_kernel, dim3((n_slots + 255) / 256), dim3(256), 0, ctx->stream, n_slots, P, n_nodes, nds, node, it,
+                       vals, ctx->n_rows, n_mean, n_ev, d, mode);
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    fprintf(stderr, "[gauss probe] node %d mode %d (0: range checks, 2: gauss_term itself): %s\n", node, mode, hipGetErrorString(e));
+    fflush(stderr);
+  }
+  (void)hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  int shown = 0;
+  long long any = 0;
+  for (int sl = 0; sl < n_slots; ++sl) {
+    const long long* o = &h[(size_t)sl * 8];
+    any |= o[7];
+    if ((o[7] || o[4]) && shown < 12) {
+      fprintf(stderr, "[gauss probe] node %d slot %d: k %lld of %lld, evidence [%lld, %lld), bad rows %lld, mean index %lld..%lld of %d, flags %llx\n",
+              node, sl, o[0], o[1], o[2], o[3], o[4], o[5], o[6], n_mean, (unsigned long long)o[7]);
+      ++shown;
+    }
+  }
+  fprintf(stderr, "[gauss probe] node %d: %d slots, flags seen %llx (1 k, 2 evidence range, 4/8 null source, 16 null evidence ctx, 32 kind, 64 unit, 128 mean index)\n",
+          node, n_slots, (unsigned long long)any);
+  return PCLEAN_OK;
 }
 
 int pclean_launch_prior_terms_ev(pclean_ctx* ctx, int n_items, int P, int n_nodes, const NodeDev* nds, const AggDev* const* aggs,

@@ -474,6 +474,13 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
     // of a reference slot, current OPTION of a choice), every other particle draws each attribute from its prior;
     // weight = likelihood of the referring rows given the particle's values; final choice among the particles.
     const size_t NPi = (size_t)n_items * P;
+    static const bool lat_dbg = getenv("PCLEAN_DEBUG_LATENT") != nullptr;  // synchronise and say where we are (fault hunting)
+    auto LATDBG = [&](const char* tag, int k) {
+      if (!lat_dbg) return;
+      const hipError_t e = hipStreamSynchronize(ctx->stream);
+      fprintf(stderr, "[latent prior] block %d %s %d: %s\n", block_id, tag, k, hipGetErrorString(e));
+      fflush(stderr);
+    };
     int32_t* pv = scratch<int32_t>(ctx, NPi * nn);
     int32_t* draws = scratch<int32_t>(ctx, NPi);
     double* wl = scratch<double>(ctx, NPi);
@@ -491,6 +498,7 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
         ctx->prior_mode = false;
         return rc;
       }
+      LATDBG("prior draws of root", root);
       hipLaunchKernelGGL(retain_first_kernel, grid1(n_items), dim3(256), 0, ctx->stream, n_items, P, cur_r, draws);
       hipLaunchKernelGGL(set_node_col_kernel, grid1(NPi), dim3(256), 0, ctx->stream, (int)NPi, draws, nn, root, pv);
       if (rn.kind == PCLEAN_NODE_FK && rn.n_children > 0) {
@@ -540,8 +548,15 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
     PCLEAN_SYNC(ctx);  // h_aggs goes out of scope
     ItemsDev itd{n_items, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, d_off, d_off + 1, d_evr, d_evc, d_keys, nullptr,
                  nullptr, 0, 0, nullptr, nullptr};
+    LATDBG("aggregated evidence", nn);
+    if (lat_dbg)
+      for (int node = 0; node < nn; ++node)
+        if (node < (int)b.node_gauss.size() && b.node_gauss[node] >= 0) {
+          (void)pclean_debug_gauss_ev_probe(ctx, n_items, P, nn, nds, node, itd, pv, (int)ctx->mean[b.gauss[b.node_gauss[node]].mean_table].v.n, n_ev);
+        }
     rc = pclean_launch_prior_terms_ev(ctx, n_items, P, nn, nds, d_aggs, dnc, dcb, dch, n_roots, d_roots, itd, pv, wl);
     if (rc) return rc;
+    LATDBG("prior_terms_ev_kernel", n_items);
     DISPATCH_PMAX(P, hipLaunchKernelGGL(latent_prior_choice_kernel<PMAX>, grid1(n_items), dim3(256), 0, ctx->stream, n_items, P,
                                         use_mh, wl, d_keys, seed, sweep_idx, (uint32_t)block_id, d_chosen));
     hipLaunchKernelGGL(gather_chosen_vals_kernel, grid1((size_t)n_items * nn), dim3(256), 0, ctx->stream, n_items, P, nn,

@@ -166,11 +166,28 @@ __global__ __launch_bounds__(PU_T) void particle_update_kernel(int N, int P, con
                                                               unsigned int* __restrict__ n_new,
                                                               int32_t* __restrict__ new_list,
                                                               int32_t* __restrict__ pnewpos, int first,
-                                                              const int32_t* __restrict__ emit_rows, int only_emit) {
+                                                              const int32_t* __restrict__ emit_rows, int only_emit,
+                                                              int stage_stride) {
   __shared__ unsigned int wsum[PU_T / 64];
   __shared__ unsigned int bbase;
+  extern __shared__ int32_t pu_stage[];  // stage_stride > 0: the workgroup's rows of draws_rm, stage_stride (odd) words apart
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // The root kernels leave a row's P draws next to each other (draws_rm[i * P + p]: one or two lines per member item on the
+  // writing side); a thread walking its own P x 4 bytes issues P loads a row apart from its neighbour's — P requests per
+  // line.  The workgroup's rows are one contiguous piece: it is read once, coalesced, into LDS (rows an odd number of words
+  // apart: no bank conflicts when every lane then reads its own row).
+  if (stage_stride > 0) {
+    const int r0 = blockIdx.x * PU_T;
+    const int n_here = min(PU_T, N - r0);
+    const int n_words = n_here * P;
+    const int32_t* src = draws_rm + (size_t)r0 * P;
+    for (int k = threadIdx.x; k < n_words; k += PU_T) {
+      const int row = k / P, col = k - row * P;
+      pu_stage[row * stage_stride + col] = src[k];
+    }
+    __syncthreads();
+  }
   uint64_t newmask = 0;
   // (only_emit: the rows outside emit_rows are not this kernel's — particle_update_final_kernel takes them)
   if (i < N && !(only_emit && !emit_rows[i])) {
@@ -184,7 +201,7 @@ __global__ __launch_bounds__(PU_T) void particle_update_kernel(int N, int P, con
         d = draws_item[(size_t)item * P + p];
         l = lse_item[item];
       } else {
-        d = draws_rm[(size_t)i * P + p];
+        d = stage_stride > 0 ? pu_stage[threadIdx.x * stage_stride + p] : draws_rm[(size_t)i * P + p];
         l = lse[i];
       }
       const int c = (p == 0 && keep >= 0) ? keep : d;
@@ -582,6 +599,70 @@ __global__ __launch_bounds__(256) void tail_scatter_kernel(int n_rows, int nb, T
 
 // own enumerated choices (locals) of the chosen particle, drawn from their conditional given
 // the chosen referent: the inner draws of the nested enumeration (proposal_compiler.jl:115-127)
+// ---- prior proposals (use_dd_proposals = false) of a block whose slot carries a Gaussian term (experiments/rents/run.jl:19-25).
+// The own choices the data-driven proposal enumerates inside the candidate branch are sampled from their priors by every
+// particle (block_proposal.jl:42-56: the proposal's and the model's densities of a sampled choice cancel), an OBSERVED own
+// choice is scored (62-64), the retained particle keeps the row's current ones (cur_locals), and the observed number is
+// scored given the particle's referent and own choices.  One thread per (particle, row) slot; the oracle restates the order
+// of the additions (oracle/sweep.h: gauss_prior_term): observed choices' densities, Normal log-density, - log |derivative|.
+__global__ void gauss_prior_kernel(int n_rows, int P, GaussDev g, PlanDev plan, const int32_t* __restrict__ pchoice,
+                                   const int32_t* __restrict__ pnewpos, const int32_t* __restrict__ vals, int n_nodes,
+                                   const int32_t* __restrict__ cur_b, const int32_t* __restrict__ cur_locals, uint64_t seed,
+                                   uint32_t sweep, uint32_t block, int64_t row_offset, double* __restrict__ w,
+                                   int32_t* __restrict__ plocals) {
+  const size_t slot = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= (size_t)n_rows * P) return;
+  const int p = (int)(slot / (size_t)n_rows), i = (int)(slot % (size_t)n_rows);
+  const int choice = pchoice[slot];
+  const int32_t* v = choice >= 0 ? nullptr : vals + (size_t)pnewpos[slot] * n_nodes;
+  const bool keep = p == 0 && cur_b && cur_b[i] >= 0 && cur_locals;
+  const uint32_t rr = (uint32_t)((int64_t)i + row_offset);
+  int l[2] = {0, 0}, out[2] = {-1, -1};
+  double s = 0.0;
+  for (int k = 0; k < g.n_locals; ++k) {
+    const int o = g.local_obs[k] ? g.local_obs[k][i] : -1;
+    if (o >= 0) {
+      l[k] = o;
+      s += g.local_logp[k];
+    } else if (keep && cur_locals[2 * (size_t)i + k] >= 0) {
+      l[k] = cur_locals[2 * (size_t)i + k];
+    } else {
+      l[k] = (int)pclean_mulhi64(pclean_rand64(seed, rr, PCLEAN_SITE_LOCALS(block), (uint32_t)p | ((uint32_t)(k + 1) << 16), sweep),
+                                 (uint64_t)g.local_n[k]);
+    }
+    out[k] = l[k];
+  }
+  plocals[2 * slot] = out[0];
+  plocals[2 * slot + 1] = out[1];
+  const double xv = g.x[i];
+  if (xv == xv) {
+    int idx = 0;
+    for (int d = 0; d < g.n_dims; ++d) {
+      int val;
+      if (g.src_kind[d] == PCLEAN_GSRC_LOCAL)
+        val = l[g.src_slot[d]];
+      else if (g.src_kind[d] == PCLEAN_GSRC_CAND)
+        val = choice >= 0 ? g.src_ptr[d][choice] : resolve_new_value(plan, 0, g.src_slot[d], v);
+      else
+        val = g.src_ptr[d][i];  // PCLEAN_GSRC_OBS
+      idx += g.stride[d] * val;
+    }
+    const int u = g.t_kind == PCLEAN_GSRC_LOCAL ? l[g.t_src] : 0;
+    s += gauss_normal_logpdf(xv * g.t_scale[u], g.mu[idx], g.sigma, g.log_sigma);
+    s -= g.t_lad[u];
+  }
+  w[slot] += s;
+}
+// ... and the chosen particle's own choices
+__global__ void locals_pick_kernel(int n_rows, const int32_t* __restrict__ chosen, const int32_t* __restrict__ plocals,
+                                   int32_t* __restrict__ locals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows) return;
+  const size_t slot = (size_t)chosen[i] * n_rows + i;
+  locals[2 * i] = plocals[2 * slot];
+  locals[2 * i + 1] = plocals[2 * slot + 1];
+}
+
 __global__ void locals_tail_kernel(int n_rows, int P, GaussDev g, PlanDev plan, const int32_t* chosen,
                                    const int32_t* pchoice, const int32_t* pnewpos, const int32_t* vals, int n_nodes,
                                    uint64_t seed, uint32_t sweep, uint32_t block, int64_t row_offset, int32_t* locals) {
@@ -1229,17 +1310,32 @@ __global__ void gather_moved_kernel(int n, const int32_t* list, const int32_t* c
 // observed choices given the sampled values (62-64): the particle's weight increment is the likelihood of its sampled
 // sub-tree: AddTypos observations (plain or through a JuliaNode), noise-free observations (equality constraints: 0 or
 // -inf), the MaybeSwap observations of the referring rows of a latent class; a scoring block proposes nothing and scores as
-// always (62-64).  NOT implemented: blocks with a Gaussian term — their own choices (enumerated inside the candidate branch
-// by the data-driven proposal) would be sampled from their priors, the retained particle keeping the row's current ones.
+// always (62-64); a Gaussian term on the slot is scored at own choices sampled from their priors (gauss_prior_kernel).
 int prior_mode_supported(pclean_ctx* ctx, const Block& b, const char* who) {
   bool ok = b.valid;
   for (const pclean_term& tm : b.terms)
     ok = ok && (tm.dens_kind == PCLEAN_DENS_ADD_TYPOS || tm.dens_kind == PCLEAN_DENS_EQUAL || tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP);
-  for (int g : b.node_gauss) ok = ok && g < 0;
+  // a Gaussian term: on the slot of an observed-class block (gauss_prior_kernel scores it once per particle at the sampled
+  // own choices; its copies on the nodes of a new row's choices are there for the enumeration and are not looked at), or the
+  // evidence of a latent class (nothing enumerated: a likelihood term like any other)
+  const bool root_g = !b.node_gauss.empty() && b.node_gauss[0] >= 0;
+  for (size_t i = 0; i < b.node_gauss.size() && ok; ++i) {
+    if (b.node_gauss[i] < 0) continue;
+    const pclean_gauss& g = b.gauss[b.node_gauss[i]];
+    if (i != 0) {
+      ok = !(g.n_locals > 0 && !root_g);
+      continue;
+    }
+    bool plain = g.transform_src_kind != PCLEAN_GSRC_EVCTX;
+    for (int d = 0; d < g.n_dims; ++d)
+      plain = plain && (g.src_kind[d] == PCLEAN_GSRC_CAND || g.src_kind[d] == PCLEAN_GSRC_OBS || g.src_kind[d] == PCLEAN_GSRC_LOCAL);
+    ok = plain || g.n_locals == 0;
+  }
   if (!ok)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "%s: use_dd_proposals = false (prior proposals, block_proposal.jl:168) is implemented "
-                                            "for plans whose likelihood terms are AddTypos, equality or MaybeSwap observations and "
-                                            "for scoring blocks; this plan has a Gaussian term", who);
+                                            "for AddTypos, equality and MaybeSwap observations, scoring blocks and a Gaussian term "
+                                            "on the block's slot whose sources are the referent, observed columns and the block's "
+                                            "own choices; this plan has a Gaussian term elsewhere or with context sources", who);
   return PCLEAN_OK;
 }
 
@@ -1253,6 +1349,11 @@ int upload_plan_nodes(pclean_ctx* ctx, int bi, const NodeDev** nds, const int32_
   for (int i = 0; i < nn; ++i) {
     int rc = build_node_dev(ctx, b, i, h[i]);
     if (rc) return rc;
+    if (getenv("PCLEAN_DEBUG_LATENT"))
+      fprintf(stderr, "[plan node %d] terms %d gauss on %d dims %d locals %d x %p mu %p src %p %p %p %p kinds %d %d %d %d\n", i, h[i].n_terms,
+              h[i].g.on, h[i].g.n_dims, h[i].g.n_locals, (const void*)h[i].g.x, (const void*)h[i].g.mu, (const void*)h[i].g.src_ptr[0],
+              (const void*)h[i].g.src_ptr[1], (const void*)h[i].g.src_ptr[2], (const void*)h[i].g.src_ptr[3], h[i].g.src_kind[0],
+              h[i].g.src_kind[1], h[i].g.src_kind[2], h[i].g.src_kind[3]);
     nc[i] = b.nodes[i].n_children;
     cb[i] = b.nodes[i].child_begin;
   }
@@ -1422,6 +1523,17 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     return PCLEAN_OK;
   };
   bool hot_timed = false;
+  // particle_update_kernel stages the root kernels' row-major draws through LDS (rows of P words, an odd stride apart)
+  static const bool no_pu_stage = getenv("PCLEAN_NO_PU_STAGE") != nullptr;
+  const int pu_stage_stride = no_pu_stage ? 0 : (P | 1);
+  const size_t pu_stage_bytes = (size_t)pu_stage_stride * PU_T * sizeof(int32_t);
+  if (pu_stage_bytes > 48 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)particle_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      attr_set = true;
+    }
+  }
   bool final_fused = false;            // the last block's particle update made the final choice as well
   const int32_t* final_only_rows = nullptr;  // ... for the rows outside this flag array (the final choice kernel takes the flagged ones)
   const bool defer_final_off = false;  // (placeholder of a condition that would forbid it)
@@ -1509,6 +1621,27 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     const bool fuse_final = last_plain && !drawable;
     // ... and when only a few rows can draw one (emit_rows): those rows take the separate kernels, all the others the fused one
     const bool split_final = last_plain && drawable && emit_rows != nullptr;
+    // prior proposals, Gaussian term on the slot: scored per particle at own choices sampled from their priors, after the
+    // likelihood terms of the sampled sub-tree (pclean_launch_prior_terms) and before the dummy corrections
+    r.plocals_on = false;
+    auto gauss_prior = [&]() -> int {
+      if (b.node_gauss.empty() || b.node_gauss[0] < 0) return PCLEAN_OK;
+      if (!use_mh && bi + 1 < n_blocks && !ctx->block[bi + 1].is_score)
+        return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: use_dd_proposals = false with a Gaussian term is implemented for "
+                                                "the LAST reference-slot block of the class (the particles' own choices are not "
+                                                "carried through a resampling step)");
+      GaussDev gd;
+      const CandTable& rt = ctx->cand[b.nodes[0].table];
+      int rcg = build_gauss_dev(ctx, b.gauss[b.node_gauss[0]], &rt, gd);
+      if (rcg) return rcg;
+      if (r.plocals.alloc((size_t)NP * 2)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+      const int32_t* cl = (b.cur_locals.p && b.cur_locals_rows == ctx->n_rows) ? b.cur_locals.p + (size_t)ctx->active_begin * 2 : nullptr;
+      hipLaunchKernelGGL(gauss_prior_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, gd, r.plan, r.pchoice.p, r.pnewpos.p,
+                         r.vals.p, (int)b.nodes.size(), cur_b, cl, seed, sweep_idx, (uint32_t)bi,
+                         s->row_offset + ctx->active_begin, s->w.p, r.plocals.p);
+      r.plocals_on = true;
+      return PCLEAN_OK;
+    };
     ItemList il;
     const int32_t* excl;
     unsigned int* n_new_ctr = nullptr;  // particles of the block that proposed a NEW referent (fresh_counter)
@@ -1525,10 +1658,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       }
       HIPCHK(ctx, hipMemsetAsync(r.lse.p, 0, (size_t)N * sizeof(double), ctx->stream));
       n_new_ctr = fresh_counter(ctx);
-      hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
+      hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), pu_stage_bytes, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
                          s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0,
-                         (const int32_t*)nullptr, 0);
+                         (const int32_t*)nullptr, 0, pu_stage_stride);
       if (has_ctx) {  // the particles' contexts: read by the likelihood terms and handed to the new rows' items
         { const int rci = ensure_it_ctx(ctx, r, NP, b.n_ctx); if (rci) return rci; }
         CtxSrc cs{};
@@ -1569,9 +1702,10 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         final_fused = true;
       } else {
       n_new_ctr = fresh_counter(ctx);
-      hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, r.draws.p, r.lse.p,
+      hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), pu_stage_bytes, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
-                         s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows, split_final ? 1 : 0);
+                         s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows, split_final ? 1 : 0,
+                         pu_stage_stride);
       if (split_final) {
         DISPATCH_PMAX(P, hipLaunchKernelGGL(particle_update_final_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, r.draws.p,
                                             r.lse.p, (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b,
@@ -1642,7 +1776,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       n_new_ctr = fresh_counter(ctx);
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, (const int32_t*)nullptr,
                          (const double*)nullptr, slot_item, draws_item, lse_item, cur_b, r.pchoice.p, s->w.p,
-                         n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows, split_final ? 1 : 0);
+                         n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows, split_final ? 1 : 0, 0);
       if (split_final) {
         DISPATCH_PMAX(P, hipLaunchKernelGGL(particle_update_final_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P,
                                             (const int32_t*)nullptr, (const double*)nullptr, slot_item, draws_item, lse_item, cur_b,
@@ -1693,6 +1827,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         if (!rc)
           rc = pclean_launch_prior_terms(ctx, NP, N, nn, nds, dnc, dcb, dch, r.pchoice.p, r.pnewpos.p, r.vals.p,
                                          has_ctx ? r.it_ctx.p : nullptr, s->w.p);
+        if (!rc) rc = gauss_prior();
         if (rc) return rc;
       }
       if (drawable) {
@@ -1707,6 +1842,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       if (!rc)
         rc = pclean_launch_prior_terms(ctx, NP, N, nn, nds, dnc, dcb, dch, r.pchoice.p, r.pnewpos.p, r.vals.p,
                                        has_ctx ? r.it_ctx.p : nullptr, s->w.p);
+      if (!rc) rc = gauss_prior();
       if (rc) return rc;
     }
     ctx->prior_mode = false;
@@ -1821,9 +1957,12 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         int rc = build_gauss_dev(ctx, bb.gauss[bb.node_gauss[0]], &rt, gd);
         if (rc) return rc;
         if (r.locals.alloc((size_t)N * 2)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-        hipLaunchKernelGGL(locals_tail_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, gd, r.plan, s->chosen.p,
-                           r.pchoice.p, r.pnewpos.p, r.vals.p, (int)bb.nodes.size(), seed, sweep_idx, (uint32_t)bi,
-                           s->row_offset + ctx->active_begin, r.locals.p);
+        if (r.plocals_on)  // prior proposals: what the chosen particle sampled (or kept)
+          hipLaunchKernelGGL(locals_pick_kernel, grid1(N), dim3(256), 0, ctx->stream, N, s->chosen.p, r.plocals.p, r.locals.p);
+        else
+          hipLaunchKernelGGL(locals_tail_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, gd, r.plan, s->chosen.p,
+                             r.pchoice.p, r.pnewpos.p, r.vals.p, (int)bb.nodes.size(), seed, sweep_idx, (uint32_t)bi,
+                             s->row_offset + ctx->active_begin, r.locals.p);
         r.locals_rows = N;
         if (!defer) {  // (deferred outputs: pclean_get_locals copies them when asked)
           bb.locals_host.resize((size_t)N * 2);
@@ -1990,6 +2129,24 @@ extern "C" int pclean_get_moved(pclean_ctx* ctx, int32_t block_id, int32_t* n_ou
   if (rows_out && !b.moved_rows_host.empty()) memcpy(rows_out, b.moved_rows_host.data(), b.moved_rows_host.size() * 4);
   if (choice_out && !b.moved_choice_host.empty())
     memcpy(choice_out, b.moved_choice_host.data(), b.moved_choice_host.size() * 4);
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_set_cur_locals(pclean_ctx* ctx, int32_t block_id, const int32_t* locals, int32_t n_rows) {
+  if (!ctx || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_cur_locals: bad arguments");
+  Block& b = ctx->block[block_id];
+  if (!locals || n_rows <= 0) {
+    b.cur_locals.release();
+    b.cur_locals_rows = 0;
+    return PCLEAN_OK;
+  }
+  if (n_rows != ctx->n_rows) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_cur_locals: one pair per observed row (%d), got %d", ctx->n_rows, n_rows);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (b.cur_locals.alloc((size_t)n_rows * 2)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  HIPCHK(ctx, hipMemcpyAsync(b.cur_locals.p, locals, (size_t)n_rows * 8, hipMemcpyHostToDevice, ctx->stream));
+  PCLEAN_SYNC(ctx);  // (the caller's array may go away)
+  b.cur_locals_rows = n_rows;
   return PCLEAN_OK;
 }
 

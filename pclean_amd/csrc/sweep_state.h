@@ -26,6 +26,8 @@ struct BlockRun {  // per-block device state of one sweep
   DevBuf<double> lse;
   int n_new = 0;  // particles of the block that proposed a NEW referent
   int locals_rows = 0;  // rows of `locals` the last sweep filled (0: none)
+  DevBuf<int32_t> plocals;  // prior proposals with a Gaussian term: every particle's own choices [P][N][2]
+  bool plocals_on = false;
   size_t it_ctx_np = 0;  // shape it_ctx was last zeroed for (sweep.hip: ensure_it_ctx)
   int it_ctx_used = -1;
   bool lazy_new = false;  // their contents are sampled after the final choice, for the chosen particles only

@@ -303,6 +303,15 @@ class Engine:
             print(f"[upload] {prev[0]}: {1e3 * (now - prev[1]):.1f} ms", flush=True)
         return (cname, now)
 
+    def _upload_cur_locals(self, trace, cfg):
+        """prior proposals (use_dd_proposals = false) of a class with own enumerated choices: the retained particle keeps the
+        row's current ones (block_proposal.jl:42-56) — the data-driven proposal enumerates them and needs none"""
+        if cfg.use_dd_proposals or not self.lw.locals:
+            return
+        loc = trace._locals  # (host-owned even while the device is ahead of the trace: sweep_commit_device keeps it current)
+        for bi in self.lw.locals:
+            self.hip.set_cur_locals(bi, loc[bi])
+
     def sweep(self, trace, config, seed, sweep_idx, lo=0, hi=None, reuse_buffers=False, light=False):
         """One batched sweep over the observed rows [lo, hi) of the trace (default: all of them).
         Returns (choice, chosen_particle, logml, new_rows), all indexed relative to lo.  reuse_buffers:
@@ -320,6 +329,7 @@ class Engine:
             return (None if light else np.zeros((nb, 0), np.int32)), np.zeros(0, np.int32), np.zeros(0), {}
         self._empty_sweep = False
         self.hip.set_active_rows(lo, hi - lo)
+        self._upload_cur_locals(trace, cfg)
         if reuse_buffers and trace.cur.dtype == np.int32 and trace.cur.flags.c_contiguous:
             choice, chosen, logml = self.hip.sweep(cfg, seed, sweep_idx, trace.cur, True, window=(lo, hi), light=light)
         else:
@@ -429,6 +439,7 @@ class Engine:
         try:
             if not local_empty:
                 self.hip.set_active_rows(lo, hi - lo)
+                self._upload_cur_locals(trace, cfg)
                 self.hip.sweep_device_cur(cfg, seed, sweep_idx, len(self.lw.blocks))
             if dist:
                 world = comm.world if comm is not None else 1

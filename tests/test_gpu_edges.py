@@ -146,8 +146,7 @@ def test_use_dd_proposals_false_prior_proposals(oracle):
     their prior proposals, weight = likelihood of the sampled values (propose_non_enumerable!, 24-157).  HIP == oracle
     bit for bit on hospital (two blocks, the second with a JuliaNode context; PG and MH) and on the `people` program
     (prior draws of a StringPrior choice are the ProposalDummyValue: random strings weighed against the observation);
-    plans with a Gaussian term are refused with a message (equality constraints, MaybeSwap and scoring blocks:
-    test_gpu_flights.py)."""
+    equality constraints, MaybeSwap and scoring blocks: test_gpu_flights.py; a Gaussian term: the next test."""
     import dummy_program as dp
     S = helpers.hospital_setup(n_rows=300)
     cases = [(S["lw"], S["obs"], S["trace"], 2)]
@@ -183,12 +182,50 @@ def test_use_dd_proposals_false_prior_proposals(oracle):
             assert np.array_equal(dd[0], och) and np.array_equal(dd[1], ocp) and np.array_equal(dd[2], oml), nb
         finally:
             eng.close()
-    R = helpers.rents_setup(n_rows=60)
-    eng = Engine(R["lw"], R["obs"], dist_mode=1)
+
+
+def test_use_dd_proposals_false_with_a_gaussian_term(oracle):
+    """use_dd_proposals = false on rents: the own choices the data-driven proposal enumerates inside the candidate branch
+    (room type, unit) are sampled from their priors by every particle, an observed room type is scored, the retained
+    particle keeps the row's current ones (pclean_set_cur_locals) and the rent is scored at the particle's referent and
+    own choices (gauss_prior_kernel).  HIP == oracle bit for bit — choices, chosen particles, log marginal likelihoods,
+    new-row records and the chosen particles' own choices — for PG and MH, from a state with current own choices and from
+    one without."""
+    R = helpers.rents_setup(n_rows=400)
+    lw, obs, tr = R["lw"], R["obs"], R["trace"]
+    n = obs.shape[1]
+    eng = Engine(lw, obs, dist_mode=1)
     try:
-        eng.upload_trace(R["trace"])
-        with pytest.raises(PCleanHipError, match="Gaussian"):
-            eng.sweep(R["trace"], InferenceConfig(1, 4, use_dd_proposals=False), 1, 0)
+        eng.upload_trace(tr)
+        for state in ("no current own choices", "current own choices"):
+            if state == "current own choices":
+                rng = np.random.default_rng(4)
+                tr.locals[0][:, 0] = np.where(obs[3] >= 0, obs[3], rng.integers(0, 5, n))  # (column 3: the observed room type)
+                tr.locals[0][:, 1] = rng.integers(0, 2, n)
+            world = helpers.mirror_world(oracle, lw, obs, tr, eng)
+            world.set_cur_locals(0, tr.locals[0])
+            for P, mh in ((6, 0), (2, 1), (1, 0)):
+                cfg = InferenceConfig(1, P, use_dd_proposals=False, use_mh_instead_of_pg=bool(mh))
+                choice, chosen, logml, new_rows = eng.sweep(tr, cfg, 31, 2)
+                got_loc = tr.pending_locals[0].copy()
+                c = InferConfig(1, P, 0, 1, mh, 50, 100)
+                och, ocp, oml = _oracle_sweep(oracle, world, c, 31, 2, tr.cur)
+                assert np.array_equal(choice, och) and np.array_equal(chosen, ocp), (state, P, mh)
+                assert np.array_equal(logml, oml), (state, P, mh, np.abs(logml - oml).max())
+                assert np.array_equal(got_loc, world.get_locals(0, n)), (state, P, mh)
+                k = oracle.lib().pco_new_rows_count(0)
+                nn = len(lw.blocks[0]["nodes"])
+                orows, ovals = np.empty(k, dtype=np.int32), np.empty((k, nn), dtype=np.int32)
+                if k:
+                    oracle.lib().pco_new_rows_get(0, nn, oracle._p(orows, C.c_int32), oracle._p(ovals, C.c_int32))
+                g = new_rows.get(0, (np.zeros(0, np.int32), np.zeros((0, nn), np.int32)))
+                assert np.array_equal(g[0], orows) and np.array_equal(g[1], ovals), (state, P, mh)
+                if P == 1 and state == "current own choices":  # the retained particle kept everything
+                    assert np.array_equal(choice, tr.cur) and np.array_equal(got_loc, tr.locals[0])
+        # the data-driven sweep afterwards equals the oracle's: nothing of the prior-proposal sweeps leaks into it
+        dd = eng.sweep(tr, InferenceConfig(1, 6), 31, 2)
+        och, ocp, oml = _oracle_sweep(oracle, world, InferConfig(1, 6, 1, 1, 0, 50, 100), 31, 2, tr.cur)
+        assert np.array_equal(dd[0], och) and np.array_equal(dd[1], ocp) and np.array_equal(dd[2], oml)
     finally:
         eng.close()
 

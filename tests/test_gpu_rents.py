@@ -33,7 +33,7 @@ def oracle_sweep(oracle, world, cfg, seed, sweep, cur, n_nodes):
     choice = np.empty((nb, n), dtype=np.int32)
     chosen = np.empty(n, dtype=np.int32)
     logml = np.empty(n)
-    c = InferConfig(1, cfg.num_particles, 1, 1, int(cfg.use_mh_instead_of_pg), 50, 100)
+    c = InferConfig(1, cfg.num_particles, int(cfg.use_dd_proposals), 1, int(cfg.use_mh_instead_of_pg), 50, 100)
     oracle.lib().pco_sweep_batched(world.h, C.byref(c), C.c_uint64(seed), C.c_uint32(sweep), nb, C.c_int64(0),
                                    oracle._p(np.ascontiguousarray(cur), C.c_int32), oracle._p(choice, C.c_int32),
                                    oracle._p(chosen, C.c_int32), oracle._p(logml, C.c_double))
@@ -48,15 +48,20 @@ def oracle_sweep(oracle, world, cfg, seed, sweep, cur, n_nodes):
     return choice, chosen, logml, new_rows, world.get_locals(0, n)
 
 
-@pytest.mark.parametrize("particles,mh", [(2, True), (20, False)])
-def test_rents_sweep_and_latent_parity(oracle, particles, mh):
+@pytest.mark.parametrize("particles,mh,dd", [(2, True, True), (20, False, True), (2, True, False), (6, False, False)])
+def test_rents_sweep_and_latent_parity(oracle, particles, mh, dd):
+    """dd = False: prior proposals (use_dd_proposals = false) — County rows' attributes from their priors under the Gaussian
+    evidence of the referring rows (their own choices given), the observed class with its own choices sampled per particle
+    (gauss_prior_kernel), the retained particle keeping the row's current ones."""
+    from pclean_amd.inference import latent_current_choices
     dirty, clean, lw, obs = rents_setup(3000)
     assert lw.xnum.shape == (1, 3000) and (obs[2] < 0).sum() > 100 and (obs[3] < 0).sum() > 100  # missing State / Room Type
     eng = Engine(lw, obs, dist_mode=1)
     try:
-        cfg = InferenceConfig(1, particles, use_mh_instead_of_pg=mh, rejuv_frequency=500)
+        cfg0 = InferenceConfig(1, particles, use_mh_instead_of_pg=mh, rejuv_frequency=500)
+        cfg = InferenceConfig(1, particles, use_mh_instead_of_pg=mh, rejuv_frequency=500, use_dd_proposals=dd)
         tr = Trace(lw, obs.shape[1], 2)
-        initialize_trace(eng, tr, cfg, 2, max_batch=512)
+        initialize_trace(eng, tr, cfg0, 2, max_batch=512)
         tr.check_consistency()
         assert (tr.locals[0] >= 0).all()
         n_nodes = [len(b["nodes"]) for b in lw.blocks]
@@ -65,13 +70,14 @@ def test_rents_sweep_and_latent_parity(oracle, particles, mh):
             pl = lw.latent_plans["County"]
             live, ev_off, ev_rows, ev_ctx = build_evidence(lw, tr, "County")
             assert ev_ctx is not None and ev_ctx.shape == (len(ev_rows), 2)
-            excl = np.full((len(pl["roots"]), len(live)), -1, dtype=np.int32)
+            excl = (np.full((len(pl["roots"]), len(live)), -1, dtype=np.int32) if dd
+                    else latent_current_choices(lw, tr, "County", live, cfg))
             eng.upload_trace(tr)
             eng.hip.set_active_rows(0, -1)
             world = helpers.mirror_world(oracle, lw, obs, tr, eng)
             got = eng.hip.sweep_latent(cfg.as_c(), 5, sweep, pl["block_id"], pl["roots"], live, ev_off, ev_rows, ev_ctx,
                                        excl, len(pl["nodes"]))
-            c = InferConfig(1, particles, 1, 1, int(mh), 50, 100)
+            c = InferConfig(1, particles, int(dd), 1, int(mh), 50, 100)
             want = world.sweep_latent(c, 5, sweep, pl["block_id"], pl["roots"], live, ev_off, ev_rows, ev_ctx, excl,
                                       len(pl["nodes"]))
             assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
@@ -80,6 +86,7 @@ def test_rents_sweep_and_latent_parity(oracle, particles, mh):
             # observed class
             eng.upload_trace(tr)
             world = helpers.mirror_world(oracle, lw, obs, tr, eng)
+            world.set_cur_locals(0, tr.locals[0])
             choice, chosen, logml, new_rows = eng.sweep(tr, cfg, 5, sweep)
             locals_gpu = tr.pending_locals[0].copy()
             o = oracle_sweep(oracle, world, cfg, 5, sweep, tr.cur, n_nodes)

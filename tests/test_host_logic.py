@@ -436,6 +436,31 @@ def test_prior_proposals_end_to_end_flights(oracle):
     assert 0.0 <= evaluate_accuracy(lw, tr, dirty, clean)["f1"] < 0.5
 
 
+def test_prior_proposals_end_to_end_rents(oracle):
+    """use_dd_proposals = false on rents (Gaussian term with own enumerated choices; Gaussian evidence in the County sweeps):
+    the product's host code runs through with the oracle engine, every row ends with own choices, the trace is consistent,
+    and the data-driven proposals do better on the same budget."""
+    import helpers
+    from oracle_engine import OracleEngine
+    from pclean_amd.analysis import evaluate_accuracy
+    from pclean_amd.engine import InferenceConfig
+    from pclean_amd.inference import initialize_trace, run_inference
+    from pclean_amd.trace import Trace
+    R = helpers.rents_setup(n_rows=300)
+    lw, obs = R["lw"], R["obs"]
+    f1 = {}
+    for dd in (False, True):
+        eng = OracleEngine(oracle, lw, obs)
+        tr = Trace(lw, obs.shape[1], 1)
+        cfg = InferenceConfig(2, 4, use_dd_proposals=dd)
+        initialize_trace(eng, tr, cfg, 5, max_batch=64)
+        run_inference(eng, tr, cfg, 5)
+        tr.check_consistency()
+        assert (tr.locals[0] >= 0).all()
+        f1[dd] = evaluate_accuracy(lw, tr, R["dirty"], R["clean"])["f1"]
+    assert 0.0 <= f1[False] < f1[True]
+
+
 def test_py_moves_commute_with_the_sweep_of_the_class_own_rows(oracle):
     """A latent class without learned parameters is swept in ONE batch and its table's Pitman-Yor moves are made after
     the batch (inference.latent_sweep).  The claim behind it: those moves' conditional (the table's reference counts,
