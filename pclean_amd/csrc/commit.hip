@@ -700,10 +700,10 @@ static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_
     out->n_distinct[c->plan_block[p]] = c->h_res->n_distinct[p];
     // scratch for the next sweep: twice what this one needed
     if (2 * c->h_res->n_records[p] > c->kcap[p]) c->kcap[p] = 2 * c->h_res->n_records[p];
-    if (dist) {  // the next exchange's segments: twice the LARGEST rank's lists of this commit (every rank read the same
+    if (dist) {  // the next exchange's segments: four times the LARGEST rank's lists of this commit (every rank read the same
       // headers: the same capacities everywhere); a refused commit starts over from what a shard can hold
-      c->cap_m[p] = out->fallback ? 0 : std::max(1024, 2 * c->h_g_counts2[2 * PCC_MAX_BLOCKS + 2 * p] + 64);
-      c->cap_k[p] = out->fallback ? 0 : std::max(256, 2 * c->h_g_counts2[2 * PCC_MAX_BLOCKS + 2 * p + 1] + 64);
+      c->cap_m[p] = out->fallback ? 0 : std::max(1024, 4 * c->h_g_counts2[2 * PCC_MAX_BLOCKS + 2 * p] + 256);
+      c->cap_k[p] = out->fallback ? 0 : std::max(256, 4 * c->h_g_counts2[2 * PCC_MAX_BLOCKS + 2 * p + 1] + 256);
     }
   }
   if (dist && !out->fallback) {
