@@ -322,6 +322,34 @@ class World:
         a = np.ascontiguousarray(locals_, dtype=np.int32).reshape(-1, 2)
         self.L.pco_world_set_cur_locals(self.h, block, len(a), _p(a, C.c_int32))
 
+    PRUNED_STATS = ("root_evaluations", "served_by_the_memo", "candidates_scored_exactly", "candidates_pruned",
+                    "new_row_branches_skipped", "new_row_branches_evaluated", "child_memo_hits", "child_memo_misses",
+                    "full_enumerations")
+
+    def sweep_batched(self, cfg, seed, sweep, cur, n_rows=None, pruned=False, row_offset=0):
+        """the batched sweep over the first n_rows rows of the World (default: all); pruned: with grouping + exact pruning
+        (oracle/pruned.h).  Returns (choice [nb][n_rows], chosen, logml, stats or None)."""
+        cur = np.ascontiguousarray(cur, dtype=np.int32)
+        nb, n = cur.shape
+        n_rows = n if n_rows is None else n_rows
+        choice = np.full((nb, n), -3, dtype=np.int32)
+        chosen = np.zeros(n, dtype=np.int32)
+        logml = np.zeros(n)
+        stats = None
+        if pruned:
+            st = np.zeros(9, dtype=np.uint64)
+            rc = self.L.pco_sweep_batched_pruned(self.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep), nb, C.c_int64(row_offset),
+                                                 C.c_int(n_rows), _p(cur, C.c_int32), _p(choice, C.c_int32), _p(chosen, C.c_int32),
+                                                 _p(logml, C.c_double), _p(st, C.c_uint64))
+            stats = dict(zip(self.PRUNED_STATS, (int(x) for x in st)))
+        else:
+            assert n_rows == n
+            rc = self.L.pco_sweep_batched(self.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep), nb, C.c_int64(row_offset),
+                                          _p(cur, C.c_int32), _p(choice, C.c_int32), _p(chosen, C.c_int32), _p(logml, C.c_double))
+        if rc:
+            raise ValueError("the oracle refused the sweep")
+        return choice[:, :n_rows], chosen[:n_rows], logml[:n_rows], stats
+
     def get_locals(self, block, n_rows):
         out = np.empty((n_rows, 2), dtype=np.int32)
         self.L.pco_get_locals(block, n_rows, _p(out, C.c_int32))

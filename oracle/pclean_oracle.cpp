@@ -15,6 +15,7 @@
 #include "densities.h"
 #include "enumerate.h"
 #include "sweep.h"
+#include "pruned.h"
 
 extern "C" {
 
@@ -265,6 +266,37 @@ int pco_sweep_batched(const pco::World* w, const pclean_infer_config* cfg, uint6
     for (int b = 0; b < n_blocks; ++b) choice[(size_t)b * N + i] = ch[b];
     if (chosen) chosen[i] = cp;
     if (logml) logml[i] = ml;
+  }
+  return 0;
+}
+/* the batched sweep with grouping + exact pruning on one thread (oracle/pruned.h): the same outputs as
+ * pco_sweep_batched, bit for bit (tests/test_oracle_pruned.py); stats[9] = root evaluations asked, served by the memo,
+ * candidates scored exactly, candidates pruned, new-row branches skipped, evaluated, child memo hits, misses, full fallbacks */
+int pco_sweep_batched_pruned(const pco::World* w, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep, int n_blocks,
+                             int64_t row_offset, int n_rows, const int32_t* cur, int32_t* choice, int32_t* chosen, double* logml,
+                             uint64_t* stats) {
+  const int N = w->n_rows;
+  if (!cfg->use_dd_proposals || n_rows > N) return -1;
+  g_new_rows.clear();
+  g_locals.assign((size_t)N * n_blocks * 2, -1);
+  g_locals_blocks = n_blocks;
+  pco::Pruner pr(*w);
+  std::vector<int32_t> c(n_blocks), ch(n_blocks);
+  for (int i = 0; i < n_rows; ++i) {
+    for (int b = 0; b < n_blocks; ++b) c[b] = cur[(size_t)b * N + i];
+    int cp;
+    double ml;
+    pco::run_smc_row(*w, *cfg, seed, sweep, n_blocks, i, row_offset, c.data(), ch.data(), &cp, &ml, g_new_rows,
+                     &g_locals[(size_t)i * n_blocks * 2], &pr);
+    for (int b = 0; b < n_blocks; ++b) choice[(size_t)b * N + i] = ch[b];
+    if (chosen) chosen[i] = cp;
+    if (logml) logml[i] = ml;
+  }
+  if (stats) {
+    const pco::PrunedStats& st = pr.st;
+    const uint64_t v[9] = {st.roots, st.root_hits, st.cand_exact, st.cand_pruned, st.new_skipped, st.new_evaluated, st.child_hits,
+                           st.child_miss, st.full_fallback};
+    for (int i = 0; i < 9; ++i) stats[i] = v[i];
   }
   return 0;
 }

@@ -23,6 +23,7 @@
 #define PCLEAN_ORACLE_SWEEP_H
 
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "enumerate.h"
@@ -362,11 +363,14 @@ inline int final_choice(const std::vector<double>& w, bool use_mh, bool csmc, ui
 }
 
 /* One row of run_smc! (CSMC when cur >= 0).  Outputs the chosen referent per block and
- * the sampled contents of new rows. */
+ * the sampled contents of new rows.  pr (oracle/pruned.h: Pruner): the data-driven root enumerations go through its
+ * grouped + pruned evaluation — same results, less work (the CPU baseline's second leg). */
+struct NoPruner {};
+template <typename PR = NoPruner>
 inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t seed, uint32_t sweep, int n_blocks,
                         int row, int64_t row_offset, const int32_t* cur /*[n_blocks]*/, int32_t* choice /*[n_blocks]*/,
                         int32_t* chosen_particle, double* logml, std::vector<NewRow>& new_rows,
-                        int32_t* locals_out = nullptr /*[n_blocks][2]*/) {
+                        int32_t* locals_out = nullptr /*[n_blocks][2]*/, PR* pr = nullptr) {
   std::vector<std::vector<int32_t>> plocals(n_blocks); /* prior proposals: every particle's own choices [P][2] */
   const bool use_mh = cfg.use_mh_instead_of_pg != 0;
   const int P = use_mh ? 2 : cfg.num_particles;
@@ -418,8 +422,7 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
     };
     /* draws of particle p; returns the weight correction of the ProposalDummyValues its new row chose (0 otherwise) —
      * added AFTER the block's log marginal (the order of the two fp64 additions is part of the contract) */
-    auto finish_particle = [&](int p, const RowCtx& rc, const std::vector<double>& s, const FixSum& f) -> double {
-      int k = fix_draw(s, f, pclean_rand64(seed, rr, PCLEAN_SITE_NODE(bi, 0), (uint32_t)p, sweep));
+    auto finish_draw = [&](int p, const RowCtx& rc, int k) -> double {
       int c = k == n_root ? PCLEAN_CHOICE_NEW : k;
       if (p == 0 && cur[bi] >= 0) c = cur[bi]; /* retained particle, row_inference.jl:143-145 */
       pch[bi][p] = c;
@@ -430,6 +433,9 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
         if (has_dummy[bi]) return dummy_correction(rc, pvals[bi][p].data(), (uint32_t)p);
       }
       return 0.0;
+    };
+    auto finish_particle = [&](int p, const RowCtx& rc, const std::vector<double>& s, const FixSum& f) -> double {
+      return finish_draw(p, rc, fix_draw(s, f, pclean_rand64(seed, rr, PCLEAN_SITE_NODE(bi, 0), (uint32_t)p, sweep)));
     };
     if (!cfg.use_dd_proposals) { /* prior proposals: every particle draws on its own, weight = likelihood of the draw */
       for (int p = 0; p < P; ++p) {
@@ -467,19 +473,44 @@ inline void run_smc_row(const World& w, const pclean_infer_config& cfg, uint64_t
       }
     } else if (b.n_ctx == 0) {
       RowCtx rc{&w, bi, row, nullptr, seed, sweep, row_offset};
-      std::vector<double> s;
-      const double lse = eval_tree(rc, 0, excl, &s);
-      FixSum f = fix_sum(s);
-      for (int p = 0; p < P; ++p) {
-        const double corr = finish_particle(p, rc, s, f);
-        wts[p] += lse;
-        wts[p] += corr;
+      bool done = false;
+      if constexpr (!std::is_same<PR, NoPruner>::value) {
+        if (pr) {
+          const auto& R = pr->root(rc, excl);
+          for (int p = 0; p < P; ++p) {
+            const double corr = finish_draw(p, rc, R.draw(pclean_rand64(seed, rr, PCLEAN_SITE_NODE(bi, 0), (uint32_t)p, sweep)));
+            wts[p] += R.lse;
+            wts[p] += corr;
+          }
+          done = true;
+        }
+      }
+      if (!done) {
+        std::vector<double> s;
+        const double lse = eval_tree(rc, 0, excl, &s);
+        FixSum f = fix_sum(s);
+        for (int p = 0; p < P; ++p) {
+          const double corr = finish_particle(p, rc, s, f);
+          wts[p] += lse;
+          wts[p] += corr;
+        }
       }
     } else {
       for (int p = 0; p < P; ++p) {
         int32_t cv[PCLEAN_MAX_CTX];
         ctx_of(p, cv);
         RowCtx rc{&w, bi, row, cv, seed, sweep, row_offset};
+        bool done = false;
+        if constexpr (!std::is_same<PR, NoPruner>::value) {
+          if (pr) {
+            const auto& R = pr->root(rc, excl);
+            const double corr = finish_draw(p, rc, R.draw(pclean_rand64(seed, rr, PCLEAN_SITE_NODE(bi, 0), (uint32_t)p, sweep)));
+            wts[p] += R.lse;
+            wts[p] += corr;
+            done = true;
+          }
+        }
+        if (done) continue;
         std::vector<double> s;
         const double lse = eval_tree(rc, 0, excl, &s);
         FixSum f = fix_sum(s);
