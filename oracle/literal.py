@@ -129,6 +129,8 @@ def string_prior_logpdf(s, min_len, max_len):
 
 
 def logsumexp(xs):
+    if not xs:
+        return -math.inf
     m = max(xs)
     if m == -math.inf:
         return m

@@ -3,7 +3,10 @@ sequential sampler of oracle/literal_inference.py — the reference's schedule o
 through oracle/literal.py; nothing of pclean_amd's lowering, trace, inference or analysis code — on the programs it
 covers (hospital-shaped), with the experiment configurations, seeds and row shuffles of scripts/sequential_reference.py.
 
-usage: python scripts/literal_sequential_reference.py [hospital] [hospital_pg20] [--seeds 0,1,2] [--rows N]"""
+flights: oracle/literal_inference_flights.py (slots with noise-free observations only, keyed TimePrior proposals with dummy
+values, the MaybeSwap block, learned error probabilities).
+
+usage: python scripts/literal_sequential_reference.py [hospital] [hospital_pg20] [flights] [--seeds 0,1,2] [--rows N]"""
 import functools
 import json
 import os
@@ -28,18 +31,26 @@ class Cfg:
         self.num_iters, self.num_particles, self.use_mh_instead_of_pg, self.rejuv_frequency = iters, particles, mh, rejuv
 
 
-CONFIGS = {"hospital": dict(iters=3, mh=True, particles=2), "hospital_pg20": dict(iters=2, mh=False, particles=20)}
+CONFIGS = {"hospital": dict(iters=3, mh=True, particles=2), "hospital_pg20": dict(iters=2, mh=False, particles=20),
+           "flights": dict(iters=5, mh=True, particles=2)}
 
 
 def run(name, seed, iters, mh, particles, n_rows=None, restricted=False):
-    dirty, clean = ex.hospital_data()
+    flights = name.startswith("flights")
+    dirty, clean = ex.flights_data() if flights else ex.hospital_data()
     if n_rows:
         dirty = {c: v[:n_rows] for c, v in dirty.items()}
         clean = {c: v[:n_rows] for c, v in clean.items()}
     (dirty, clean), _ = ex.shuffle_rows([dirty, clean], seed)
-    m = ex.hospital_model(ex.possibilities_of(dirty))
-    q = ex.hospital_query(m)
-    s = LI.LiteralSampler(m, q, dirty, Cfg(iters, particles, mh), seed, restricted=restricted)
+    if flights:  # (rejuv_frequency 500: experiments/flights/run.jl)
+        import literal_inference_flights as LF
+        m = ex.flights_model(dirty)
+        q = ex.flights_query(m)
+        s = LF.FlightsLiteralSampler(m, q, dirty, Cfg(iters, particles, mh, rejuv=500), seed)
+    else:
+        m = ex.hospital_model(ex.possibilities_of(dirty))
+        q = ex.hospital_query(m)
+        s = LI.LiteralSampler(m, q, dirty, Cfg(iters, particles, mh), seed, restricted=restricted)
     t0 = time.time()
     s.initialize()
     f_init = s.accuracy(dirty, clean)["f1"]

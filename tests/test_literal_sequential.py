@@ -54,3 +54,47 @@ def test_product_sequential_runs_match_the_literal_reference(name):
         for cls in b:
             assert abs(a[cls] - b[cls]) <= max(3, b[cls] // 10), (sd, cls, a, b)
         assert abs(lit["runs"][sd]["f1"] - prod["runs"][sd]["f1"]) <= 0.01, sd
+
+
+def test_flights_literal_sampler_runs_and_keeps_its_database_consistent():
+    """oracle/literal_inference_flights.py on the first 400 rows: reference counts consistent after the initialisation and
+    after every sweep, one latent Flight per flight id and one TrackingWebsite per source (noise-free observations), the
+    Flights' times recovered from the MaybeSwap evidence (F1 from ~0 after the initialisation — new Flights draw their
+    times from the prior proposal, i.e. the dummy — to > 0.5 on this small sample), and the learned error probabilities stay probabilities."""
+    import literal_sequential_reference as lsr
+    import literal_inference_flights as LF
+    from pclean_amd import experiments as ex
+    dirty, clean = ex.flights_data()
+    dirty = {c: v[:400] for c, v in dirty.items()}
+    clean = {c: v[:400] for c, v in clean.items()}
+    (dirty, clean), _ = ex.shuffle_rows([dirty, clean], 3)
+    m = ex.flights_model(dirty)
+    q = ex.flights_query(m)
+    for mh, particles in ((True, 2), (False, 4)):
+        s = LF.FlightsLiteralSampler(m, q, dirty, lsr.Cfg(2, particles, mh, rejuv=100), 3)
+        s.initialize()
+        s.check()
+        f0 = s.accuracy(dirty, clean)["f1"]
+        for _ in range(3):
+            s.sweep()
+            s.check()
+        acc = s.accuracy(dirty, clean)
+        assert f0 < 0.05 and acc["f1"] > 0.5, (f0, acc)  # (400 rows: ~4 sources per flight; the full table reaches 0.89)
+        rows = s.latent_rows()
+        assert rows["Flight"] == len(set(dirty["flight"])) and rows["TrackingWebsite"] == len(set(dirty["src"])), rows
+        probs = s.tr.params[("Obs", "error_probs")]
+        assert probs and all(0.0 < p < 1.0 for p in probs.values())
+
+
+def test_flights_product_sequential_runs_match_the_literal_reference():
+    """eight seeds each: the literal flights sampler and the product's sequential-schedule runs agree within the north
+    star's +-0.5 pt of F1 (their random numbers differ: means are compared) and on the latent tables' sizes."""
+    lit = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_sequential.json")))["flights"]
+    prod = json.load(open(os.path.join(ROOT, "tests", "golden", "sequential_f1.json")))["flights"]
+    assert {k: lit["config"][k] for k in ("iters", "mh", "particles")} == {k: prod["config"][k] for k in ("iters", "mh", "particles")}
+    assert sorted(lit["runs"]) == sorted(prod["runs"]) and len(lit["runs"]) >= 8
+    a = np.array([lit["runs"][s]["f1"] for s in sorted(lit["runs"])])
+    b = np.array([prod["runs"][s]["f1"] for s in sorted(prod["runs"])])
+    assert abs(a.mean() - b.mean()) <= 0.005, (a.mean(), b.mean())
+    for sd in lit["runs"]:
+        assert lit["runs"][sd]["latent_rows"] == prod["runs"][sd]["latent_rows"], sd
