@@ -4,9 +4,12 @@ through oracle/literal.py; nothing of pclean_amd's lowering, trace, inference or
 covers (hospital-shaped), with the experiment configurations, seeds and row shuffles of scripts/sequential_reference.py.
 
 flights: oracle/literal_inference_flights.py (slots with noise-free observations only, keyed TimePrior proposals with dummy
-values, the MaybeSwap block, learned error probabilities).
+values, the MaybeSwap block, learned error probabilities); rents / rents_pg20 (BASELINE.json configs[2]):
+oracle/literal_inference_rents.py (own choices enumerated inside the candidate branch, TransformedGaussian observation,
+learned means).
 
-usage: python scripts/literal_sequential_reference.py [hospital] [hospital_pg20] [flights] [--seeds 0,1,2] [--rows N]"""
+usage: python scripts/literal_sequential_reference.py [hospital] [hospital_pg20] [flights] [rents] [rents_pg20] [--seeds 0,1,2]
+       [--rows N] [--out FILE]   (--out: runs in parallel write their own file; scripts/merge_goldens.py-style merge by hand)"""
 import functools
 import json
 import os
@@ -32,12 +35,13 @@ class Cfg:
 
 
 CONFIGS = {"hospital": dict(iters=3, mh=True, particles=2), "hospital_pg20": dict(iters=2, mh=False, particles=20),
-           "flights": dict(iters=5, mh=True, particles=2)}
+           "flights": dict(iters=5, mh=True, particles=2), "rents": dict(iters=1, mh=True, particles=2),
+           "rents_pg20": dict(iters=1, mh=False, particles=20)}
 
 
 def run(name, seed, iters, mh, particles, n_rows=None, restricted=False):
-    flights = name.startswith("flights")
-    dirty, clean = ex.flights_data() if flights else ex.hospital_data()
+    flights, rents = name.startswith("flights"), name.startswith("rents")
+    dirty, clean = ex.flights_data() if flights else ex.rents_data() if rents else ex.hospital_data()
     if n_rows:
         dirty = {c: v[:n_rows] for c, v in dirty.items()}
         clean = {c: v[:n_rows] for c, v in clean.items()}
@@ -47,6 +51,11 @@ def run(name, seed, iters, mh, particles, n_rows=None, restricted=False):
         m = ex.flights_model(dirty)
         q = ex.flights_query(m)
         s = LF.FlightsLiteralSampler(m, q, dirty, Cfg(iters, particles, mh, rejuv=500), seed)
+    elif rents:
+        import literal_inference_rents as LR
+        m = ex.rents_model(dirty)
+        q = ex.rents_query(m)
+        s = LR.RentsLiteralSampler(m, q, dirty, Cfg(iters, particles, mh, rejuv=500), seed)
     else:
         m = ex.hospital_model(ex.possibilities_of(dirty))
         q = ex.hospital_query(m)
@@ -73,6 +82,8 @@ if __name__ == "__main__":
             seeds = [int(x) for x in sys.argv[i + 1].split(",")]
         if a == "--rows":
             rows = int(sys.argv[i + 1])
+        if a == "--out":
+            OUT = sys.argv[i + 1]
     res = json.load(open(OUT)) if os.path.exists(OUT) and not rows else {}
     for name in names:
         res[name] = dict(config=CONFIGS[name], schedule="sequential, literal sampler on strings (oracle/literal_inference.py), "

@@ -98,3 +98,49 @@ def test_flights_product_sequential_runs_match_the_literal_reference():
     assert abs(a.mean() - b.mean()) <= 0.005, (a.mean(), b.mean())
     for sd in lit["runs"]:
         assert lit["runs"][sd]["latent_rows"] == prod["runs"][sd]["latent_rows"], sd
+
+
+def test_rents_literal_sampler_runs_and_keeps_its_database_consistent():
+    """oracle/literal_inference_rents.py on 1500 rows (MH and PG): reference counts and the referring-row index consistent
+    after the initialisation and after a sweep; every row ends with a room type and a unit; the sweep improves F1; the
+    learned means of the keys that are looked up moved from their prior towards the data."""
+    import literal_sequential_reference as lsr
+    import literal_inference_rents as LR
+    from pclean_amd import experiments as ex
+    dirty, clean = ex.rents_data()
+    dirty = {c: v[:1500] for c, v in dirty.items()}
+    clean = {c: v[:1500] for c, v in clean.items()}
+    (dirty, clean), _ = ex.shuffle_rows([dirty, clean], 2)
+    m = ex.rents_model(dirty)
+    q = ex.rents_query(m)
+    for mh, particles in ((True, 2), (False, 5)):
+        s = LR.RentsLiteralSampler(m, q, dirty, lsr.Cfg(1, particles, mh, rejuv=500), 2)
+        s.initialize()
+        s.check()
+        f0 = s.accuracy(dirty, clean)["f1"]
+        s.sweep()
+        s.check()
+        acc = s.accuracy(dirty, clean)
+        assert acc["f1"] > f0 > 0.3, (f0, acc)
+        assert all(o is not None and o["br"] in ("studio", "1br", "2br", "3br", "4br") for o in s.own)
+        seen = [i for i in range(s.n) if dirty["Room Type"][i] is not None]
+        assert all(s.own[i]["br"] == dirty["Room Type"][i] for i in seen)  # an observed own choice is never changed
+        vals = np.array(list(s.means.values()))
+        assert len(vals) > 100 and 800 < np.median(vals) < 2200
+
+
+@pytest.mark.parametrize("name", ["rents", "rents_pg20"])
+def test_rents_product_sequential_runs_match_the_literal_reference(name):
+    """BASELINE.json configs[2] (rents, PG-20) and the MH configuration of the experiment script: the literal rents sampler
+    and the product's sequential-schedule runs, same seeds and shuffles, agree within +-0.5 pt of F1 on the means and
+    within 2 % on the number of latent counties."""
+    lit = json.load(open(os.path.join(ROOT, "tests", "golden", "literal_sequential.json")))[name]
+    prod = json.load(open(os.path.join(ROOT, "tests", "golden", "sequential_f1.json")))[name]
+    assert {k: lit["config"][k] for k in ("iters", "mh", "particles")} == {k: prod["config"][k] for k in ("iters", "mh", "particles")}
+    assert sorted(lit["runs"]) == sorted(prod["runs"])
+    a = np.array([lit["runs"][s]["f1"] for s in sorted(lit["runs"])])
+    b = np.array([prod["runs"][s]["f1"] for s in sorted(prod["runs"])])
+    assert abs(a.mean() - b.mean()) <= 0.005, (a.mean(), b.mean())
+    for sd in lit["runs"]:
+        ca, cb = lit["runs"][sd]["latent_rows"]["County"], prod["runs"][sd]["latent_rows"]["County"]
+        assert abs(ca - cb) <= 0.02 * cb, (sd, ca, cb)
