@@ -12,9 +12,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-# (--distance osa: the profile runs build the bit-parallel tables — 0.45 s instead of 31 s per bench invocation, eight of them —;
-# the sweep kernels see byte tables either way, 0.48 % of whose entries differ)
-ARGS="--steps 3 --warmup 2 --no-cpu-baseline --no-dl-sample --no-steady-iterations --distance osa"
+# (bench.py's default tables: unrestricted Damerau-Levenshtein, 31 s of table build per invocation; DIST=osa for the bit-parallel ones)
+ARGS="--steps 3 --warmup 2 --no-cpu-baseline --no-dl-sample --no-steady-iterations --distance ${DIST:-dl}"
 KRE="fk_root_wave_kernel|group_desc_kernel|group_settle_kernel|group_lse_kernel|group_gate_kernel|hg_insert_kernel|hg_fill_kernel|particle_update_kernel"
 timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -- python "$ROOT/bench.py" $ARGS \
   > "$OUT/bench_trace.json" 2> "$OUT/bench_trace.log"
@@ -32,7 +31,7 @@ pass SQ2 SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR 
 pass TCC TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_REQ_sum
 # whole-step traffic: the same two counters over EVERY kernel (no include filter), fewer sweeps
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_all_$C" -- python "$ROOT/bench.py" --steps 2 --warmup 1 --no-dl-sample --distance osa \
+  timeout 900 rocprofv3 --kernel-trace --pmc $C -d "$OUT/pmc_all_$C" -- python "$ROOT/bench.py" --steps 2 --warmup 1 --no-dl-sample --distance ${DIST:-dl} \
     --no-steady-iterations --no-cpu-baseline > "$OUT/bench_all_$C.json" 2> "$OUT/bench_all_$C.log"
   echo "all $C rc=$?"
 done
