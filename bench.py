@@ -107,6 +107,7 @@ def hbm_traffic(args, world):
         if d.get("rows") != args.rows or d.get("hospitals") != args.hospitals or d.get("particles") != args.particles \
                 or world != 1 or "pair_bytes_per_launch" not in d:
             return None, None, None
+        hbm_traffic.measure_root = d.get("measure_root")  # (the longest single kernel of the step: counters of the same passes)
         return float(d["pair_bytes_per_launch"]), d.get("source"), d.get("pair_components")
     except Exception:
         return None, None, None
@@ -572,6 +573,7 @@ def main():
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_src, "traffic_components": traffic_parts,
                          "traffic_over_alg": (traffic / alg_bytes) if (traffic and alg_bytes) else None,
+                         "measure_root": getattr(hbm_traffic, "measure_root", None),
                          "kernel": "group_gate_kernel + group_desc_kernel + group_settle_kernel + worklist_pack_kernel + fk_root_wave_kernel<12> + "
                                    "group_lse_kernel (block 0 root: rows x candidate hospitals); alg bytes, launch time and counter "
                                    "traffic all cover these launches",

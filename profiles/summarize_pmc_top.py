@@ -105,6 +105,20 @@ def main():
                         avg_ms={k: merged[k]["dur"] / merged[k]["n"] for k in keys},
                         source=source + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, "
                                "2 x FETCH_SIZE + WRITE_SIZE, KiB; full-size launches of the kernels of block 0's root)")
+            # the Measure slot's root scan (the 4-term instance): the longest single kernel of the step gets its own entry
+            km = next((k for k in merged if "fk_root_wave_kernel<4," in k and "full-size" in k), None)
+            if km and hbm(km) is not None:
+                ms = merged[km]["dur"] / merged[km]["n"]
+                cm = merged[km]["counters"]
+                ent = dict(kernel=km.split(" [")[0] + " (root scan of the Measure slot, block 1): the longest single kernel of the step",
+                           avg_ms=ms, hbm_bytes_per_launch=hbm(km), GBps=hbm(km) / (ms * 1e-3) / 1e9,
+                           frac_of_hbm_peak=hbm(km) / (ms * 1e-3) / 8e12, source=source)
+                if "SQ_WAIT_ANY" in cm and "SQ_WAVE_CYCLES" in cm:
+                    ent["SQ_WAIT_ANY_over_WAVE_CYCLES"] = cm["SQ_WAIT_ANY"][1] / cm["SQ_WAVE_CYCLES"][1]
+                if "TCC_HIT_sum" in cm and "TCC_MISS_sum" in cm:
+                    ent["L2_hit_rate"] = cm["TCC_HIT_sum"][1] / (cm["TCC_HIT_sum"][1] + cm["TCC_MISS_sum"][1])
+                prev = data.get("measure_root") or {}
+                data["measure_root"] = dict(prev, **ent)  # (hand-added notes — phase shares, scan counts — stay)
             json.dump(data, open(out_json, "w"), indent=1)
 
 
