@@ -566,8 +566,9 @@ def main():
                             "distance": ("OSA (restricted DL, --distance osa): the tables of the headline in rounds 1-4; the three real "
                                          "programs and bench.py's default use unrestricted DL, 0.48 % of the synthetic pairs differ "
                                          "(DESIGN.md §3)") if args.distance == "osa"
-                            else "unrestricted Damerau-Levenshtein (dl_wave_kernel): the product's default distance; --distance osa "
-                                 "builds the restricted (bit-parallel) tables of rounds 1-4 in 0.45 s instead",
+                            else "unrestricted Damerau-Levenshtein (dl_seg_kernel: the linear-space recurrence of csrc/dl_cell.h, 1-8 lanes "
+                                 "per pair, latent strings sorted by length): the product's default distance; --distance osa builds "
+                                 "the restricted (bit-parallel) tables of rounds 1-4 in 0.45 s instead",
                             "unrestricted_dl_sample": dl_sample},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": (achieved / 8000.0) if achieved else None, "traffic": traffic,

@@ -220,7 +220,7 @@ extern "C" int pclean_build_pair_table(pclean_ctx* ctx, int32_t table_id, int32_
   if (d_obs.alloc(std::max(n_obs, 1)) || d_lat.alloc(n_lat)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   if (n_obs) HIPCHK(ctx, hipMemcpy(d_obs.p, obs_ids, n_obs * sizeof(int32_t), hipMemcpyHostToDevice));
   HIPCHK(ctx, hipMemcpy(d_lat.p, lat_ids, n_lat * sizeof(int32_t), hipMemcpyHostToDevice));
-  rc = pclean_launch_dist(ctx, pt, d_obs.p, d_lat.p, dist_mode);
+  rc = pclean_launch_dist(ctx, pt, d_obs.p, d_lat.p, dist_mode, lat_ids);
   hipError_t e = hipStreamSynchronize(ctx->stream);
   d_lat.release();
   if (rc) return rc;

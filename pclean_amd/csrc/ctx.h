@@ -249,7 +249,7 @@ inline int pclean_fail(pclean_ctx* ctx, int code, const char* fmt, ...) {
 
 // dist_kernels.hip
 int pclean_launch_dist(pclean_ctx* ctx, PairTable& pt, const int32_t* d_obs_ids, const int32_t* d_lat_ids,
-                       int dist_mode);
+                       int dist_mode, const int32_t* h_lat_ids);  // h_lat_ids: the latent string ids on the host
 // density tables (api.hip)
 int pclean_ensure_density(pclean_ctx* ctx, int max_len);
 // sweep.hip

@@ -16,7 +16,11 @@
 //   the DP-tile kernel above remains for longer ones.
 // Kernel dl_lds_kernel (unrestricted DL, Lowrance–Wagner, byte matrix in LDS) and dl_pair_kernel (same recurrence,
 //   full (la+2)x(lb+2) matrix in a lane-interleaved global scratch, for strings whose matrix does not fit in LDS).
+#include <algorithm>
+#include <numeric>
+
 #include "ctx.h"
+#include "dl_cell.h"
 
 template <typename OutT>
 __global__ void osa_tile_kernel(const uint16_t* __restrict__ sym, const int64_t* __restrict__ off,
@@ -411,14 +415,211 @@ __global__ __launch_bounds__(256) void dl_wave_kernel(const uint16_t* __restrict
   }
 }
 
+// ---- dl_seg_kernel: unrestricted Damerau-Levenshtein in linear space, NSEG lanes per pair ---------------------------------
+// The recurrence of dl_cell.h (Zhao & Sahni's form of Lowrance-Wagner: one 32-bit word of state per column) lets a LANE walk
+// its columns a row at a time with its state in LDS — no matrix, so the LDS a pair needs is 5 bytes per column instead of
+// (la + 1) bytes, and a CU holds 16 waves where dl_wave_kernel's matrices left room for 4.  A pair's columns are cut into NSEG
+// segments owned by NSEG consecutive lanes; lane s works on row (step - s) — one row behind its left neighbour, whose row
+// state (dl_cell.h: DlzRow, two packed words) it takes over by shuffle — so every lane is busy in all but the NSEG - 1 steps
+// the pipeline takes to fill and drain, whatever the length of the strings.  The latent strings arrive SORTED BY LENGTH
+// (pclean_launch_dist): the pairs of a wave have the same number of columns to within a symbol, and a launch covers one length
+// class (<= 32 NSEG symbols) with <= 32 columns per lane.  The observed string is uniform over the workgroup (LDS, read once per
+// row).  Results go to tmp[u][p] in sorted order; dl_unpermute_kernel puts the columns back.
+// tests/dl_host holds this schedule (same header, same segment pipeline) against the oracle's full-matrix DP on the CPU.
+template <int NSEG, typename SymT>
+__global__ __launch_bounds__(256) void dl_seg_kernel(const uint16_t* __restrict__ sym, const int64_t* __restrict__ off,
+                                                     const int32_t* __restrict__ obs_ids,
+                                                     const int32_t* __restrict__ lat_sorted,  // string ids of this class's pairs
+                                                     int n_obs, int n_cls, int p0, int n_lat, int segcap, int max_la, int u_chunk,
+                                                     uint8_t* __restrict__ tmp) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t dlz_smem[];
+  constexpr int SPW = 4 / (int)sizeof(SymT);  // symbols per 32-bit word of the latent strings' LDS copy
+  constexpr uint32_t SENT = sizeof(SymT) == 1 ? 0xffu : 0xffffu;  // a symbol no string holds (the host checks n_symbols)
+  uint32_t* words = dlz_smem;                                     // [segcap][256]
+  uint32_t* bs = words + (size_t)segcap * 256;                    // [segcap / SPW][256]
+  uint16_t* A = reinterpret_cast<uint16_t*>(bs + (size_t)(segcap / SPW) * 256);
+  const int tid = threadIdx.x;
+  const int s = tid % NSEG;
+  const int pl = blockIdx.x * (256 / NSEG) + tid / NSEG;  // pair of this class
+  const bool valid = pl < n_cls;
+  int lb = 0;
+  int64_t b0 = 0;
+  if (valid) {
+    const int id = lat_sorted[pl];
+    b0 = off[id];
+    lb = (int)(off[id + 1] - b0);
+  }
+  // columns per lane, uniform over the wavefront: the longest pair's share, in whole groups of four
+  int wseg = (lb + NSEG - 1) / NSEG;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) wseg = max(wseg, __shfl_xor(wseg, o, 64));
+  wseg = min((wseg + 3) & ~3, segcap);
+  const int col0 = s * wseg;  // this lane owns columns col0 + 1 .. col0 + wseg
+  for (int c = 0; c < wseg; c += SPW) {
+    uint32_t pk = 0;
+#pragma unroll
+    for (int k = 0; k < SPW; ++k) {
+      const int j = col0 + c + k + 1;
+      const uint32_t ch = (valid && j <= lb) ? (uint32_t)sym[b0 + j - 1] : SENT;
+      pk |= ch << (k * 8 * (int)sizeof(SymT));
+    }
+    bs[(size_t)(c / SPW) * 256 + tid] = pk;
+  }
+  const int s_last = lb > 0 ? (lb - 1) / wseg : 0, c_last = lb > 0 ? (lb - 1) % wseg : 0;
+  const int u0 = blockIdx.y * u_chunk, u1 = min(u0 + u_chunk, n_obs);
+  for (int u = u0; u < u1; ++u) {
+    __syncthreads();  // (the previous observed string is no longer read)
+    const int64_t a0 = off[obs_ids[u]];
+    const int la = (int)(off[obs_ids[u] + 1] - a0);
+    for (int i = tid; i < la; i += 256) A[i] = sym[a0 + i];
+    __syncthreads();
+    for (int c = 0; c < wseg; ++c) words[(size_t)c * 256 + tid] = dlz_word_row0(min(col0 + c + 1, 255));
+    uint32_t aim1 = 0xffffffffu;
+    uint32_t e1 = 0, e2 = 0;  // the row state after this lane's last column, packed (handed to lane s + 1)
+    const int steps = la + NSEG - 1;
+    for (int step = 1; step <= steps; ++step) {
+      const int i = step - s;
+      DlzRow st;
+      if (NSEG > 1) {
+        const uint32_t g1 = (uint32_t)__shfl_up((int)e1, 1, NSEG), g2 = (uint32_t)__shfl_up((int)e2, 1, NSEG);
+        st = dlz_unpack(g1, g2);
+      }
+      if (s == 0) st = dlz_row_start(i);
+      if (i >= 1 && i <= la) {
+        const uint32_t ai = A[i - 1];
+        for (int c = 0; c < wseg; c += 4) {
+          uint32_t bw[4 / SPW];
+#pragma unroll
+          for (int q = 0; q < 4 / SPW; ++q) bw[q] = bs[(size_t)(c / SPW + q) * 256 + tid];
+          uint32_t w[4];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w[k] = words[(size_t)(c + k) * 256 + tid];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t bj = (bw[k / SPW] >> ((k % SPW) * 8 * (int)sizeof(SymT))) & SENT;
+            dlz_cell(st, w[k], i, col0 + c + k + 1, ai, aim1, bj);
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) words[(size_t)(c + k) * 256 + tid] = w[k];
+        }
+        aim1 = ai;
+        if (NSEG > 1) dlz_pack(st, e1, e2);
+      }
+    }
+    if (valid && s == s_last) {
+      int d = la;  // lb == 0
+      if (lb > 0) d = la == 0 ? lb : (int)(words[(size_t)c_last * 256 + tid] & 255u);
+      tmp[(size_t)u * n_lat + p0 + pl] = (uint8_t)d;
+    }
+  }
+}
+// out[u][v] = tmp[u][pos_of[v]]: the columns back in the order of the latent domain (four per thread: one word per store;
+// the gathers stay inside one row of tmp)
+__global__ __launch_bounds__(256) void dl_unpermute_kernel(const uint8_t* __restrict__ tmp, const int32_t* __restrict__ pos_of,
+                                                           int n_lat, uint8_t* __restrict__ out) {
+  const int v4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (v4 >= n_lat) return;
+  const uint8_t* row = tmp + (size_t)blockIdx.y * n_lat;
+  uint8_t* orow = out + (size_t)blockIdx.y * n_lat;
+  uint32_t pk = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (v4 + k < n_lat) pk |= (uint32_t)row[pos_of[v4 + k]] << (8 * k);
+  if (v4 + 3 < n_lat && ((((size_t)blockIdx.y * n_lat) & 3) == 0)) {
+    *reinterpret_cast<uint32_t*>(orow + v4) = pk;
+  } else {
+    for (int k = 0; k < 4 && v4 + k < n_lat; ++k) orow[v4 + k] = (uint8_t)(pk >> (8 * k));
+  }
+}
+
 __global__ void lat_len_kernel(const int64_t* __restrict__ off, const int32_t* __restrict__ lat_ids, int n,
                                uint16_t* __restrict__ len) {
   int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v < n) len[v] = (uint16_t)(off[lat_ids[v] + 1] - off[lat_ids[v]]);
 }
 
+// unrestricted DL through dl_seg_kernel: latent strings sorted by length on the host, one launch per length class, results
+// un-permuted.  Returns 1 when it ran, 0 when the table is not its kind (strings too long, too many symbols), < 0 on error.
+static int launch_dl_seg(pclean_ctx* ctx, PairTable& pt, const int32_t* d_obs_ids, const int32_t* h_lat_ids) {
+  const int max_lb = pt.max_lat_len, max_la = pt.max_obs_len, n_lat = pt.n_lat;
+  if (pt.elem_bytes != 1 || max_lb > DLZ_MAX_LEN || max_la > DLZ_MAX_LEN || !h_lat_ids || ctx->n_symbols > 65535) return 0;
+  const bool sym8 = ctx->n_symbols <= 255;  // (0xff / 0xffff must be a symbol no string holds)
+  std::vector<int32_t> len(n_lat), perm(n_lat), pos_of(n_lat), sorted_ids(n_lat);
+  for (int v = 0; v < n_lat; ++v) len[v] = (int32_t)(ctx->h_off[h_lat_ids[v] + 1] - ctx->h_off[h_lat_ids[v]]);
+  std::iota(perm.begin(), perm.end(), 0);
+  std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return len[x] < len[y]; });
+  for (int p = 0; p < n_lat; ++p) {
+    pos_of[perm[p]] = p;
+    sorted_ids[p] = h_lat_ids[perm[p]];
+  }
+  DevBuf<int32_t> d_sorted, d_pos;
+  DevBuf<uint8_t> tmp;
+  if (d_sorted.alloc(n_lat) || d_pos.alloc(n_lat) || tmp.alloc(std::max<size_t>((size_t)pt.n_obs * n_lat, 16)))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed (DL table build)");
+  hipError_t e = hipMemcpyAsync(d_sorted.p, sorted_ids.data(), (size_t)n_lat * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(d_pos.p, pos_of.data(), (size_t)n_lat * 4, hipMemcpyHostToDevice, ctx->stream);
+  int rc = e == hipSuccess ? PCLEAN_OK : pclean_fail(ctx, PCLEAN_ERR_HIP, "copy failed: %s", hipGetErrorString(e));
+  const int u_chunk = 32;
+  // length classes: lengths <= 32 on one lane, <= 64 on two, <= 128 on four, the rest on eight (<= 32 columns per lane)
+  int p = 0;
+  while (p < n_lat && !rc) {
+    const int l0 = len[perm[p]];
+    const int nseg = l0 <= 32 ? 1 : l0 <= 64 ? 2 : l0 <= 128 ? 4 : 8;
+    const int hi = nseg == 8 ? DLZ_MAX_LEN : 32 * nseg;
+    int q = p;
+    while (q < n_lat && len[perm[q]] <= hi) ++q;
+    const int cls_max = len[perm[q - 1]];
+    const int segcap = std::max(4, (((cls_max + nseg - 1) / nseg) + 3) & ~3);
+    const size_t lds = (size_t)segcap * 256 * 4 + (size_t)segcap * 256 * (sym8 ? 1 : 2) + (size_t)std::max(max_la, 1) * 2 + 16;
+    const int n_cls = q - p, ppw = 256 / nseg;
+    dim3 grid((n_cls + ppw - 1) / ppw, (pt.n_obs + u_chunk - 1) / u_chunk);
+#define LAUNCH_DLS(NS, ST)                                                                                               \
+  do {                                                                                                                   \
+    if (lds > 48 * 1024) {                                                                                               \
+      hipError_t ea = hipFuncSetAttribute((const void*)dl_seg_kernel<NS, ST>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                          (int)lds);                                                                     \
+      if (ea != hipSuccess) rc = pclean_fail(ctx, PCLEAN_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(ea));       \
+    }                                                                                                                    \
+    if (!rc)                                                                                                             \
+      hipLaunchKernelGGL((dl_seg_kernel<NS, ST>), grid, dim3(256), lds, ctx->stream, ctx->sym.p, ctx->off.p, d_obs_ids,  \
+                         d_sorted.p + p, pt.n_obs, n_cls, p, n_lat, segcap, max_la, u_chunk, tmp.p);                     \
+  } while (0)
+#define LAUNCH_DLS_N(ST)      \
+  do {                        \
+    if (nseg == 1)            \
+      LAUNCH_DLS(1, ST);      \
+    else if (nseg == 2)       \
+      LAUNCH_DLS(2, ST);      \
+    else if (nseg == 4)       \
+      LAUNCH_DLS(4, ST);      \
+    else                      \
+      LAUNCH_DLS(8, ST);      \
+  } while (0)
+    if (sym8)
+      LAUNCH_DLS_N(uint8_t);
+    else
+      LAUNCH_DLS_N(uint16_t);
+#undef LAUNCH_DLS_N
+#undef LAUNCH_DLS
+    p = q;
+  }
+  if (!rc) {
+    hipLaunchKernelGGL(dl_unpermute_kernel, dim3((n_lat + 1023) / 1024, pt.n_obs), dim3(256), 0, ctx->stream, tmp.p, d_pos.p, n_lat,
+                       (uint8_t*)pt.d.p);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // (the host vectors and the scratch go away)
+    if (e != hipSuccess) rc = pclean_fail(ctx, PCLEAN_ERR_HIP, "DL table build failed: %s", hipGetErrorString(e));
+  } else {
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  d_sorted.release();
+  d_pos.release();
+  tmp.release();
+  return rc ? rc : 1;
+}
+
 int pclean_launch_dist(pclean_ctx* ctx, PairTable& pt, const int32_t* d_obs_ids, const int32_t* d_lat_ids,
-                       int dist_mode) {
+                       int dist_mode, const int32_t* h_lat_ids) {
   const int max_lb = pt.max_lat_len, max_la = pt.max_obs_len;
   hipLaunchKernelGGL(lat_len_kernel, dim3((pt.n_lat + 255) / 256), dim3(256), 0, ctx->stream, ctx->off.p,
                      d_lat_ids, pt.n_lat, pt.lat_len.p);
@@ -470,7 +671,15 @@ int pclean_launch_dist(pclean_ctx* ctx, PairTable& pt, const int32_t* d_obs_ids,
       return PCLEAN_OK;
     }
   }
-  if (dist_mode == PCLEAN_DIST_DL && pt.elem_bytes == 1 && max_lb <= 256 && max_la <= 255 && !getenv("PCLEAN_NO_DL_WAVE")) {
+  // unrestricted DL: the linear-space kernel (dl_seg_kernel); PCLEAN_DL_KERNEL=wave / lds / pair pick the older ones
+  const char* dlk = getenv("PCLEAN_DL_KERNEL");
+  if (dist_mode == PCLEAN_DIST_DL && (!dlk || !strcmp(dlk, "seg"))) {
+    const int rs = launch_dl_seg(ctx, pt, d_obs_ids, h_lat_ids);
+    if (rs < 0) return rs;
+    if (rs > 0) return PCLEAN_OK;
+  }
+  if (dist_mode == PCLEAN_DIST_DL && pt.elem_bytes == 1 && max_lb <= 256 && max_la <= 255 && !getenv("PCLEAN_NO_DL_WAVE") &&
+      (!dlk || !strcmp(dlk, "seg") || !strcmp(dlk, "wave"))) {
     // unrestricted DL, one pair per 16 / 32 / 64 lanes, a row at a time (dl_wave_kernel)
     const int WG = max_lb <= 16 ? 16 : max_lb <= 32 ? 32 : 64;
     const int C = WG < 64 ? 1 : (max_lb + 63) / 64;
@@ -506,7 +715,7 @@ int pclean_launch_dist(pclean_ctx* ctx, PairTable& pt, const int32_t* d_obs_ids,
       return PCLEAN_OK;
     }
   }
-  if (dist_mode == PCLEAN_DIST_DL && pt.elem_bytes == 1 && !getenv("PCLEAN_NO_DL_LDS")) {
+  if (dist_mode == PCLEAN_DIST_DL && pt.elem_bytes == 1 && !getenv("PCLEAN_NO_DL_LDS") && (!dlk || strcmp(dlk, "pair"))) {
     // unrestricted DL with the matrix in LDS (bytes), when it fits
     const size_t per_lane = (size_t)(max_la + 2) * (max_lb + 2) + (size_t)ctx->n_symbols + 2 * (size_t)std::max(max_lb, 1);
     const size_t lds = per_lane * 64;

@@ -1525,12 +1525,17 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   bool hot_timed = false;
   // particle_update_kernel stages the root kernels' row-major draws through LDS (rows of P words, an odd stride apart)
   static const bool no_pu_stage = getenv("PCLEAN_NO_PU_STAGE") != nullptr;
-  const int pu_stage_stride = no_pu_stage ? 0 : (P | 1);
+  // (P | 1) x PU_T words: 84 KB at 20 particles; beyond PU_STAGE_MAX_BYTES of LDS (P >= 37: 64 particles would ask for 266 KB
+  // of the CU's 160) the kernel reads the draws directly, as it did before the staging existed
+  constexpr size_t PU_STAGE_MAX_BYTES = 150 * 1024;
+  int pu_stage_stride = no_pu_stage ? 0 : (P | 1);
+  if ((size_t)pu_stage_stride * PU_T * sizeof(int32_t) > PU_STAGE_MAX_BYTES) pu_stage_stride = 0;
   const size_t pu_stage_bytes = (size_t)pu_stage_stride * PU_T * sizeof(int32_t);
   if (pu_stage_bytes > 48 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
-      HIPCHK(ctx, hipFuncSetAttribute((const void*)particle_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)particle_update_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      (int)PU_STAGE_MAX_BYTES));
       attr_set = true;
     }
   }
@@ -1662,6 +1667,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
                          s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0,
                          (const int32_t*)nullptr, 0, pu_stage_stride);
+      HIPCHK(ctx, hipGetLastError());
       if (has_ctx) {  // the particles' contexts: read by the likelihood terms and handed to the new rows' items
         { const int rci = ensure_it_ctx(ctx, r, NP, b.n_ctx); if (rci) return rci; }
         CtxSrc cs{};
@@ -1706,6 +1712,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
                          s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows, split_final ? 1 : 0,
                          pu_stage_stride);
+      HIPCHK(ctx, hipGetLastError());
       if (split_final) {
         DISPATCH_PMAX(P, hipLaunchKernelGGL(particle_update_final_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, r.draws.p,
                                             r.lse.p, (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b,

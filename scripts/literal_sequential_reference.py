@@ -36,12 +36,21 @@ class Cfg:
 
 CONFIGS = {"hospital": dict(iters=3, mh=True, particles=2), "hospital_pg20": dict(iters=2, mh=False, particles=20),
            "flights": dict(iters=5, mh=True, particles=2), "rents": dict(iters=1, mh=True, particles=2),
-           "rents_pg20": dict(iters=1, mh=False, particles=20)}
+           "rents_pg20": dict(iters=1, mh=False, particles=20),
+           # the headline workload's shape (scripts/sequential_reference.py: 30 000 rows of pclean_amd.synth, 300 / 3 000 true hospitals)
+           "synth_pg20": dict(iters=1, mh=False, particles=20), "synth_k3000_pg20": dict(iters=1, mh=False, particles=20)}
+SYNTH_ROWS = 30000
 
 
 def run(name, seed, iters, mh, particles, n_rows=None, restricted=False):
     flights, rents = name.startswith("flights"), name.startswith("rents")
-    dirty, clean = ex.flights_data() if flights else ex.rents_data() if rents else ex.hospital_data()
+    if name.startswith("synth"):  # the table of scripts/sequential_reference.py's synth configurations, same generator seed
+        from pclean_amd.synth import synth_hospital
+        total = n_rows or SYNTH_ROWS
+        dirty, clean, _ = synth_hospital(total, 3000 if "k3000" in name else max(total // 100, 1), 20250926)
+        n_rows = None
+    else:
+        dirty, clean = ex.flights_data() if flights else ex.rents_data() if rents else ex.hospital_data()
     if n_rows:
         dirty = {c: v[:n_rows] for c, v in dirty.items()}
         clean = {c: v[:n_rows] for c, v in clean.items()}

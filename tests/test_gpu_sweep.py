@@ -80,9 +80,10 @@ def test_score_node_parity(setup, oracle, block, node):
     assert np.array_equal(got[2], want[2]), "draws differ"
 
 
-@pytest.mark.parametrize("particles,mh", [(2, True), (20, False), (5, False)])
+@pytest.mark.parametrize("particles,mh", [(2, True), (20, False), (5, False), (40, False), (64, False)])
 def test_sweep_parity_hospital(setup, oracle, particles, mh):
-    """configs[0] (MH, 2 particles) and configs[1] (PG, 20 particles) of BASELINE.json."""
+    """configs[0] (MH, 2 particles) and configs[1] (PG, 20 particles) of BASELINE.json; 40 and 64 particles (the library's
+    maximum): particle_update_kernel's LDS staging of the draws does not fit (P >= 37) and it reads them directly."""
     lw, tr, eng, world = setup["lw"], setup["trace"], setup["engine"], setup["world"]
     cfg = InferenceConfig(1, particles, use_mh_instead_of_pg=mh)
     n_nodes = [len(b["nodes"]) for b in lw.blocks]

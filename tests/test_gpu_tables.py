@@ -151,6 +151,55 @@ def test_pair_table_long_patterns_and_dl_random(hip, oracle):
         assert np.array_equal(got, oracle.pair_table(sym, off, ids[:200], ids, mode)), mode
 
 
+def test_dl_seg_kernel_every_length_class_and_symbol_width(hip, oracle, monkeypatch):
+    """The linear-space unrestricted-DL kernel (dl_seg_kernel: latent strings sorted by length, one launch per length
+    class with 1 / 2 / 4 / 8 lanes per pair, results un-permuted) on tables that hold every class at once, with 8-bit and
+    16-bit symbols (> 255 distinct characters), rectangular shapes whose row length is not a multiple of four, and strings
+    beyond its 254 symbols (the table then takes the matrix kernels): against the oracle's DP, and against the LDS-matrix
+    kernel it replaces (PCLEAN_DL_KERNEL=wave) on every pair."""
+    rnd = np.random.default_rng(23)
+    for wide in (False, True):
+        alpha = [chr(0x4e00 + k) for k in range(300)] if wide else list("abcdx ")
+        lens = [0, 1, 2, 5, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 200, 253, 254] + [int(x) for x in rnd.integers(0, 255, size=60)]
+        base = ["".join(rnd.choice(alpha, size=n)) for n in lens]
+        muts = []
+        for w in base:  # near copies: substitutions, adjacent and gapped transpositions
+            c = list(w)
+            for _ in range(int(rnd.integers(0, 4))):
+                if len(c) > 3:
+                    q = int(rnd.integers(0, len(c) - 2))
+                    c[q], c[q + 1] = c[q + 1], c[q]
+                    if rnd.random() < 0.5:
+                        c.insert(q + 1, alpha[int(rnd.integers(len(alpha)))])
+                    if rnd.random() < 0.5:
+                        c[int(rnd.integers(len(c)))] = alpha[int(rnd.integers(len(alpha)))]
+            muts.append("".join(c)[:254])
+        pool, _ = _pool(base + muts)
+        sym, off, _, _ = pool.arrays()
+        hip.load_strings(sym, off)
+        li = np.unique(np.array([pool.index[v] for v in base + muts], dtype=np.int32))
+        oi = li[::2][:61]
+        assert len(li) % 4 != 0 or len(li[:-1]) % 4 != 0
+        for lat in (li, li[:-1], li[:-2], li[:-3]):
+            monkeypatch.setenv("PCLEAN_DL_KERNEL", "seg")
+            hip.build_pair_table(42, oi, lat, 1)
+            got = hip.get_pair_table(42, len(oi), len(lat))
+            monkeypatch.setenv("PCLEAN_DL_KERNEL", "wave")
+            hip.build_pair_table(43, oi, lat, 1)
+            old = hip.get_pair_table(43, len(oi), len(lat))
+            assert np.array_equal(got, old), (wide, len(lat), int((got != old).sum()))
+        monkeypatch.delenv("PCLEAN_DL_KERNEL")
+        assert np.array_equal(got, oracle.pair_table(sym, off, oi, lat, 1)), wide
+    # strings beyond 254 symbols: the table falls back to the matrix kernels and is still right
+    words = ["".join(rnd.choice(list("abc"), size=n)) for n in (3, 40, 255, 256, 200)]
+    pool, ids = _pool(words)
+    sym, off, _, _ = pool.arrays()
+    hip.load_strings(sym, off)
+    ids = np.unique(ids)
+    hip.build_pair_table(42, ids, ids, 1)
+    assert np.array_equal(hip.get_pair_table(42, len(ids), len(ids)), oracle.pair_table(sym, off, ids, ids, 1))
+
+
 def test_synthetic_table_osa_vs_dl(hip, capsys):
     """The 1M-row bench builds its pair tables with the (bit-parallel) restricted distance (OSA; the semantics of
     StringDistances < 0.11) while the real datasets default to unrestricted Damerau-Levenshtein.  The two flavours
