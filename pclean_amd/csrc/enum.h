@@ -158,12 +158,49 @@ struct FastRootDev {
   FastTermDev terms[PCLEAN_MAX_TERMS];
 };
 
+// Optional extra of a compact-table root launch (root_wave.hip): LAZY draws.  The last block of a sweep needs the draw of
+// the finally chosen particle alone (the final choice looks at the weights, i.e. the log marginals, only): instead of n_draws
+// draws per member item the kernel leaves every group's survivor list and fixed-point prefix (lz_k / lz_p, ROOT_LZ_CAP entries
+// per group; lz_ns[g] = their number, -1: the group's draws were all written to draws_out after all — settled, overflowed, or
+// a row of eager_rows) and pclean_launch_lazy_draws draws once per row after the final choice, from the same Philox counter.
+#define ROOT_LZ_CAP 256
+struct RootExtra {
+  int32_t* lz_k;
+  uint64_t* lz_p;
+  int32_t* lz_ns;
+  const int32_t* eager_rows;  // [rows] != 0: every draw of this row's items is wanted now (null: of no row)
+  // filled by the launch for pclean_launch_lazy_draws: per-group fixed-point totals (device, inside desc_scratch)
+  const uint64_t* g_U;
+};
 int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const ChildrenDev& ch,
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
                             int32_t* desc_scratch, int32_t* overflow_list,
                             unsigned int* scan_stats = nullptr, int n_items = 0, const double* pre_score = nullptr,
-                            bool want_worklist = true, unsigned int* wl_stat = nullptr, const int32_t* pre_obs = nullptr);
+                            bool want_worklist = true, unsigned int* wl_stat = nullptr, const int32_t* pre_obs = nullptr,
+                            RootExtra* extra = nullptr);
+// one draw per row, after the final choice, from the lists a lazy root launch left (see RootExtra): thread per member
+// position mi of the launch's grouping; uid[mi] - 1 = its group.  slot_item: [P][N] item of (particle, row), null: item = row;
+// the retained particle of a row with a current referent (cur_b[row] >= 0, particle 0) is not this kernel's.
+struct LazyDrawArgs {
+  int32_t n_pos, n_rows, n_particles, pad;
+  const int32_t* members;    // [n_pos] item of position mi (null: mi)
+  const int32_t* uid;        // [n_pos] group of position mi, + 1 (null: mi + 1)
+  const int32_t* item_row;   // [items] row of an item (null: the item)
+  const int32_t* slot_item;
+  const int32_t* chosen;     // [rows] the chosen particle
+  const int32_t* cur_b;      // [rows]
+  const int32_t* eager_rows;
+  const int32_t* draws_item; // [items][P] draws of the groups with lz_ns < 0
+  const int32_t* lz_k;
+  const uint64_t* lz_p;
+  const int32_t* lz_ns;
+  const uint64_t* g_U;
+  int32_t* pchoice;          // [P][N]: pchoice[chosen * N + row] = the draw
+  int64_t row_offset;
+  int32_t res_new, pad2;
+};
+int pclean_launch_lazy_draws(pclean_ctx* ctx, const LazyDrawArgs& a, uint64_t seed, uint32_t sweep, uint32_t site);
 // gate of the new-row branch per GROUP of `it` (grouped view), with the exact score of every group's current referent and
 // the observed values of its row (obs_out: PCLEAN_MAX_TERMS words per group, what group_desc_kernel would gather again)
 int pclean_launch_group_gate(pclean_ctx* ctx, const FastRootDev& fr, const ItemsDev& it, const GateDev& gt, int32_t* flag,

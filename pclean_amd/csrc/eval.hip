@@ -499,6 +499,9 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
   Block& b = ctx->block[block_id];
   const pclean_node& n = b.nodes[node_id];
   SweepState* s = st(ctx);
+  const SweepState::LazyReq lazy_req = s->lazy_req;  // (this evaluation's; the children's evaluations below must not see it)
+  s->lazy_req = SweepState::LazyReq();
+  s->lazy_out.valid = false;
   NodeDev nd;
   int rc = build_node_dev(ctx, b, node_id, nd);
   if (rc) return rc;
@@ -754,7 +757,14 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
                                           b.leaf_m[node_id].p, b.leaf_U[node_id].p, b.leaf_coarse[node_id].p, seed, sweep,
                                           PCLEAN_SITE_NODE(block_id, node_id), n_draws, lse_out, draws_out);
   }
-  if (!fast_tried && !scores_out && !snew_override && !ctx->force_generic && !nd.g.on && !ctx->prior_mode) {
+  // A marginal-only evaluation of a few hundred items (the nested slots of a new-row branch that passed the gate: ~250
+  // groups per 1M-row sweep) is one launch of the LDS-resident generic kernel with 1024 threads per item; the compact-table
+  // path would spend ~10 launches on it (prior rows, alive bits, descriptors, settle, scan, log-sum-exp, overflow re-run) and
+  // refresh the node's prior rows after every commit for nothing.  Same results either way (wave == generic is tested).
+  static const bool no_small_generic = getenv("PCLEAN_NO_SMALL_GENERIC") != nullptr;
+  const bool small_lse = !no_small_generic && n_draws == 0 && il.n <= 1024 && !il.ev_lo &&
+                         (size_t)(nd.n_cand + 2) * 8 + (16 + 64) * 8 <= (size_t)80 * 1024;
+  if (!fast_tried && !scores_out && !snew_override && !ctx->force_generic && !nd.g.on && !ctx->prior_mode && !small_lse) {
     if (!il.ev_lo)
       fast = try_fast_root(ctx, block_id, node_id, fr);
     else if (n.kind == PCLEAN_NODE_LEAF && n_draws <= 1 && !getenv("PCLEAN_NO_FAST_EV"))
@@ -769,6 +779,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
   }
   // Items with identical score vectors (same observed tuple, ctx and excluded row) share one
   // wavefront / workgroup: scores once, draws per member item.
+  ItemGroups ggrp;  // the grouping of the launch below (n_groups == 0: none)
   {
     const int nc = nd.n_cand + (n.kind == PCLEAN_NODE_FK ? 1 : 0);
     const bool lds_kernel = (size_t)((nc + 1) & ~1) * 8 + (16 + 64) * 8 <= 160 * 1024;
@@ -784,6 +795,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
         it.n = g.n_groups;
         it.grp_off = g.grp_off;
         it.members = g.members;
+        ggrp = g;
       }
     }
   }
@@ -855,8 +867,39 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
       s->over_rec.push_back(SweepState::OverRec{block_id, node_id, it.n, false, false, -1});  // min_items -1: a work-list record
     }
     if (fwl.wl_off > 0) --fwl.wl_off;
+    RootExtra ex{};
+    bool use_ex = false;
+    // lazy draws (the sweep's last block): lists instead of n_draws draws per member item
+    static const bool no_lazy = getenv("PCLEAN_NO_LAZY_DRAWS") != nullptr;
+    if (lazy_req.on && !no_lazy && n_draws > 1 && !it.rng_row && !it.particle && !it.out_pos && !il.ev_lo &&
+        (size_t)it.n * ROOT_LZ_CAP * 12 <= ((size_t)4 << 30)) {
+      ex.lz_k = scratch<int32_t>(ctx, (size_t)it.n * ROOT_LZ_CAP);
+      ex.lz_p = scratch<uint64_t>(ctx, (size_t)it.n * ROOT_LZ_CAP);
+      ex.lz_ns = scratch<int32_t>(ctx, (size_t)it.n);
+      if (!ex.lz_k || !ex.lz_p || !ex.lz_ns) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      ex.eager_rows = lazy_req.eager_rows;
+      use_ex = true;
+    }
     rc = pclean_launch_root_fast(ctx, fr, it, ch, seed, sweep, site, n_draws, lse_out, draws_out, oflag, over_count, desc,
-                                 over_list, scan_stats, il.n, pre_score, wl_stat != nullptr, wl_stat, pre_obs);
+                                 over_list, scan_stats, il.n, pre_score, wl_stat != nullptr, wl_stat, pre_obs, use_ex ? &ex : nullptr);
+    if (!rc && ex.lz_ns) {
+      SweepState::LazyOut& lo = s->lazy_out;
+      lo.valid = true;
+      lo.site = site;
+      lo.args = LazyDrawArgs{};
+      lo.args.n_pos = il.n;
+      lo.args.members = it.grp_off ? it.members : nullptr;
+      lo.args.uid = it.grp_off ? ggrp.uid : nullptr;
+      lo.args.item_row = il.row;
+      lo.args.eager_rows = lazy_req.eager_rows;
+      lo.args.draws_item = draws_out;
+      lo.args.lz_k = ex.lz_k;
+      lo.args.lz_p = ex.lz_p;
+      lo.args.lz_ns = ex.lz_ns;
+      lo.args.g_U = ex.g_U;
+      lo.args.row_offset = it.row_offset;
+      lo.args.res_new = fr.is_leaf ? fr.n_cand - 1 : PCLEAN_CHOICE_NEW;
+    }
     if (time_it) {
       (void)hipEventRecord(s->ev1, ctx->stream);
       s->dbg_desc = desc;

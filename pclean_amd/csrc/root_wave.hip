@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, 
                                                            uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out,
                                                            unsigned int* __restrict__ scan_stats,
                                                            int32_t* __restrict__ worklist, unsigned int* __restrict__ work_n,
-                                                           int seg_cap) {
+                                                           int seg_cap, int32_t* __restrict__ lz_ns) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = tid / SETTLE_L, l = tid % SETTLE_L;
   const int lane = threadIdx.x & 63, base = lane & ~(SETTLE_L - 1);
@@ -642,6 +642,7 @@ __global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, 
       d[7] = flags | 8;
       g_m[g] = hi;
       g_U[g] = PCLEAN_FIX_ONE;
+      if (lz_ns) lz_ns[g] = -1;  // (lazy draws: this group's are all written, right here)
     }
     const int m_lo = word(0), m_hi = word(1), t0 = word(2);
     const int n_out = (m_hi - m_lo) * n_draws;
@@ -782,11 +783,13 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     int chunk, const int32_t* __restrict__ gd, unsigned int* __restrict__ chunk_ctr, double* __restrict__ g_m,
     uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out, int32_t* __restrict__ overflow_flag,
     unsigned int* __restrict__ overflow_count, int32_t* __restrict__ overflow_list,
-    unsigned int* __restrict__ scan_stats, const int32_t* __restrict__ worklist) {
+    unsigned int* __restrict__ scan_stats, const int32_t* __restrict__ worklist, int32_t* __restrict__ lz_k,
+    uint64_t* __restrict__ lz_p, int32_t* __restrict__ lz_ns, const int32_t* __restrict__ eager_rows) {
   // exact scores and, later, the fixed-point prefix share one array: entry j is converted in place by lane j
   __shared__ uint64_t s_pref[WPG][CAP + 8];
   __shared__ int32_t s_k[WPG][CAP + 8];
   __shared__ int32_t s_blk[WPG][WAVE_BLK_CAP];
+  static_assert(CAP <= ROOT_LZ_CAP, "a group's survivor list fits its slot of the lazy-draw lists");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint64_t* pref = s_pref[wave];
   double* scv = reinterpret_cast<double*>(s_pref[wave]);
@@ -1311,6 +1314,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
       if (lane == 0) {
         base_o = (int)atomicAdd(overflow_count, (unsigned int)n_mem_o);
         g_m[g_id] = __builtin_nan("");
+        if (lz_ns) lz_ns[g_id] = -1;  // (lazy draws: the re-run writes every draw of these items)
       }
       base_o = __builtin_amdgcn_readfirstlane(base_o);
       if (n_mem_o == 1) {
@@ -1330,8 +1334,23 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
         g_m[g_id] = m;
         g_U[g_id] = U;
       }
+      // ---- LAZY draws (RootExtra): the list and its prefix are kept, one draw per row follows the final choice ---------
+      bool lazy = false;
+      if (lz_ns) {
+        lazy = n_draws > 0 && !(eager_rows && eager_rows[__builtin_amdgcn_readlane(dv, 3)] != 0);
+        if (lazy) {  // (scalar bases + lane offsets: per-lane 64-bit bases would be held across the group loop and spilled)
+          uint64_t bk = (uint64_t)lz_k + (uint64_t)(uint32_t)g_id * (uint64_t)(ROOT_LZ_CAP * 4);
+          uint64_t bp = (uint64_t)lz_p + (uint64_t)(uint32_t)g_id * (uint64_t)(ROOT_LZ_CAP * 8);
+          asm volatile("" : "+s"(bk), "+s"(bp));
+          for (int j = lane; j < ns; j += 64) {
+            ((__attribute__((address_space(1))) int32_t*)bk)[j] = ksv[j];
+            ((__attribute__((address_space(1))) uint64_t*)bp)[j] = pref[j];
+          }
+        }
+        if (lane == 0) lz_ns[g_id] = lazy ? ns : -1;
+      }
       // ---- draws of every (member item, draw) pair of the group ------------------------------------------------------
-      if (n_draws > 0) {
+      if (n_draws > 0 && !lazy) {
         const int res_new = fr.is_leaf ? fr.n_cand - 1 : PCLEAN_CHOICE_NEW;
         // A DECIDED group: the total is exactly one unit (PCLEAN_FIX_ONE) — the maximum's own weight — so every other
         // entry has fixed-point weight 0 and every draw, whatever its random number (x < U), returns the first entry
@@ -1609,7 +1628,7 @@ int pclean_launch_root_flags(pclean_ctx* ctx, int n_groups, const int32_t* gd, c
 
 typedef void (*wave_kernel_t)(const FastRootDev, const WaveItems, uint64_t, uint32_t, uint32_t, int, int, int, const int32_t*,
                               unsigned int*, double*, uint64_t*, int32_t*, int32_t*, unsigned int*, int32_t*, unsigned int*,
-                              const int32_t*);
+                              const int32_t*, int32_t*, uint64_t*, int32_t*, const int32_t*);
 
 static wave_kernel_t pick_kernel(int n_terms) {
   if (n_terms <= 2) return fk_root_wave_kernel<2, WAVE_SURV_CAP, 4>;
@@ -1630,7 +1649,8 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
                             uint64_t seed, uint32_t sweep, uint32_t site, int n_draws, double* lse_out,
                             int32_t* draws_out, int32_t* overflow_flag, unsigned int* overflow_count,
                             int32_t* desc_scratch, int32_t* overflow_list, unsigned int* scan_stats, int n_items,
-                            const double* pre_score, bool want_worklist, unsigned int* wl_stat, const int32_t* pre_obs) {
+                            const double* pre_score, bool want_worklist, unsigned int* wl_stat, const int32_t* pre_obs,
+                            RootExtra* extra) {
   if (it.n <= 0) return PCLEAN_OK;
   const size_t ng = (size_t)it.n;
   unsigned int* chunk_ctr = reinterpret_cast<unsigned int*>(desc_scratch + ng * GD_STRIDE);
@@ -1646,8 +1666,10 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   // for the launch pair.  Kept for the next round: the settling belongs in a kernel with a few lanes per group.
   static const bool want_resolve = getenv("PCLEAN_RESOLVE_GROUPS") != nullptr;
   const bool resolve = n_draws > 0 && want_resolve && (!it.grp_off || n_items > 0);
+  const bool lazy = extra && extra->lz_ns && n_draws > 0 && !resolve;
   hipLaunchKernelGGL(group_desc_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, fr, it, ch, it.n,
                      desc_scratch, chunk_ctr, g_m, g_U, resolve ? g_res : nullptr, scan_stats, pre_score, pre_obs);
+  if (extra) extra->g_U = g_U;
   // the easy groups settled by a few lanes each (group_settle_kernel): launches that draw, large enough to matter
   static const bool no_settle = getenv("PCLEAN_NO_SETTLE") != nullptr;
   const bool settle = !no_settle && !resolve && n_draws > 0 && !fr.is_leaf && fr.n_pre >= 1 && fr.n_pre <= 3 && fr.cstride > 0 &&
@@ -1699,13 +1721,14 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
     const int seg_cap = (int)((n_wg / WL_SEGS + 1) * 16);  // 16 groups per workgroup, workgroups dealt round-robin
     int32_t* seg_list = worklist + ng;
     hipLaunchKernelGGL(group_settle_kernel, dim3(n_wg), dim3(256), 0, ctx->stream, sa, ws, it.n, n_draws, desc_scratch, g_m, g_U,
-                       draws_out, scan_stats, use_worklist ? seg_list : nullptr, chunk_ctr, seg_cap);
+                       draws_out, scan_stats, use_worklist ? seg_list : nullptr, chunk_ctr, seg_cap, lazy ? extra->lz_ns : nullptr);
     if (use_worklist)
       hipLaunchKernelGGL(worklist_pack_kernel, dim3(1), dim3(1024), 0, ctx->stream, seg_list, seg_cap, chunk_ctr, worklist, wl_stat);
   }
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * wpg), 0, ctx->stream, fr, wi, seed, sweep, site, n_draws, it.n, chunk, desc_scratch,
                      chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count, overflow_list, scan_stats,
-                     use_worklist ? worklist : nullptr);
+                     use_worklist ? worklist : nullptr, lazy ? extra->lz_k : nullptr, lazy ? extra->lz_p : nullptr,
+                     lazy ? extra->lz_ns : nullptr, lazy ? extra->eager_rows : nullptr);
 #ifdef WAVE_PHASE_CLOCK
   if (it.n > 100000) {
     unsigned long long h[16];
@@ -1716,8 +1739,8 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
     for (int i = 0; i < 6; ++i) tot += (double)h[i];
     fprintf(stderr, "[wave clk] groups %d terms %d waves %llu (grid %d WGs): ", it.n, fr.n_terms, h[8], wgs);
     for (int i = 0; i < 6; ++i) fprintf(stderr, "%s %.1f%% ", nm[i], 100.0 * (double)h[i] / tot);
-    fprintf(stderr, "| cycles/group %.0f, groups seen %llu; full scans %llu, cached scans %llu, decided groups %llu, survivors scored %llu; two-level scans %llu, passing blocks %llu\n",
-            tot / (double)h[7], h[7], h[9], h[10], h[12], h[11], h[13], h[14]);
+    fprintf(stderr, "| cycles/group %.0f, groups seen %llu; full scans %llu, cached scans %llu, decided groups %llu, survivors scored %llu; two-level scans %llu, passing blocks %llu; chunk %d, lazy %d\n",
+            tot / (double)h[7], h[7], h[9], h[10], h[12], h[11], h[13], h[14], chunk, lazy ? 1 : 0);
     memset(h, 0, sizeof h);
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wave_clk), h, sizeof h);
   }
@@ -1731,6 +1754,50 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   if (lse_out)
     hipLaunchKernelGGL(group_lse_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, it.n, it.grp_off, it.members,
                        it.out_pos, g_m, g_U, lse_out);
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
+
+// ---- one draw per row after the final choice (RootExtra: lazy draws) --------------------------------------------------------
+// Thread per member position of the root launch's grouping (the positions of a group are adjacent: its threads probe the same
+// few cache lines of the group's prefix).  The draw is the one the scan kernel would have made for (item, chosen particle):
+// same Philox counter (row, site, particle, sweep), same multiply-high against the group's total, same search.
+__global__ __launch_bounds__(256) void lazy_draw_kernel(const LazyDrawArgs a, uint64_t seed, uint32_t sweep, uint32_t site) {
+  const int mi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mi >= a.n_pos) return;
+  const int tm = a.members ? a.members[mi] : mi;
+  const int row = a.item_row ? a.item_row[tm] : tm;
+  if (a.eager_rows && a.eager_rows[row] != 0) return;  // (those rows' particles were updated one by one, with every draw)
+  const int c = a.chosen[row];
+  if (a.slot_item && a.slot_item[(size_t)c * a.n_rows + row] != tm) return;  // another item carries the chosen particle's context
+  if (c == 0 && a.cur_b && a.cur_b[row] >= 0) return;  // the retained particle keeps its referent (row_inference.jl:143-145)
+  const int g = a.uid ? a.uid[mi] - 1 : mi;
+  const int ns = a.lz_ns[g];
+  int32_t res;
+  if (ns < 0) {
+    res = a.draws_item[(size_t)tm * a.n_particles + c];
+  } else {
+    res = a.res_new;
+    const uint64_t U = a.g_U[g];
+    if (U != 0) {
+      const uint64_t x = pclean_mulhi64(pclean_rand64(seed, (uint32_t)((int64_t)row + a.row_offset), site, (uint32_t)c, sweep), U);
+      const uint64_t* pref = a.lz_p + (size_t)g * ROOT_LZ_CAP;
+      int lo = 0, hi = ns;  // smallest index with prefix > x (index ns = the new row)
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (pref[mid] > x)
+          hi = mid;
+        else
+          lo = mid + 1;
+      }
+      if (lo < ns) res = a.lz_k[(size_t)g * ROOT_LZ_CAP + lo];
+    }
+  }
+  a.pchoice[(size_t)c * a.n_rows + row] = res;
+}
+int pclean_launch_lazy_draws(pclean_ctx* ctx, const LazyDrawArgs& a, uint64_t seed, uint32_t sweep, uint32_t site) {
+  if (a.n_pos <= 0) return PCLEAN_OK;
+  hipLaunchKernelGGL(lazy_draw_kernel, dim3((a.n_pos + 255) / 256), dim3(256), 0, ctx->stream, a, seed, sweep, site);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }

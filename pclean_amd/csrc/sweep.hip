@@ -147,6 +147,111 @@ __global__ void ctx_fill_kernel(int N, int P, int n_ctx, const int32_t* __restri
     }
   }
 }
+// ---- the three kernels above in ONE pass (gather_ctx + ctx_count + scan + ctx_fill: 6 dispatches, 0.19 ms per 1M rows x 20
+// particles).  One thread per row: the context of every particle (written to it_ctx as before), compared with particle 0's.
+// Item i is row i's PRIMARY item (particle 0's context: nearly every row has no other); each further distinct context of a
+// row becomes an EXTRA item N + k, k from one atomic per workgroup — no scan, no second pass.  The numbering of the extra
+// items follows the workgroups' arrival: nothing downstream depends on item order (scores are per item, draws are keyed by
+// (row, particle)).  Extra items beyond extra_cap are counted, not written: the host re-runs with room (read_count).
+__global__ __launch_bounds__(256) void ctx_items_kernel(int N, int P, CtxSrc cs, const int32_t* __restrict__ cur_b,
+                                                        int32_t* __restrict__ it_ctx, int32_t* __restrict__ slot_item,
+                                                        int32_t* __restrict__ row, int32_t* __restrict__ ctxv,
+                                                        int32_t* __restrict__ excl, unsigned int* __restrict__ n_extra,
+                                                        int extra_cap) {
+  __shared__ unsigned int wcnt[4];
+  __shared__ unsigned int bbase;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t NP = (size_t)N * P;
+  int c0[PCLEAN_MAX_CTX] = {0, 0, 0, 0};
+  static_assert(PCLEAN_MAX_CTX == 4, "c0 initialiser");
+  unsigned int mine = 0;  // extra items of this row
+  if (i < N) {
+    bool all_same = true;
+    for (int p = 0; p < P; ++p) {
+      const size_t sp = (size_t)p * N + i;
+      for (int s = 0; s < cs.n_ctx; ++s) {
+        int32_t v;
+        const int choice = cs.pchoice[s][sp];
+        if (choice >= 0)
+          v = cs.root_col[s][choice];
+        else
+          v = resolve_new_value(cs.plan[s], 0, cs.col[s], cs.vals[s] + (size_t)cs.pnewpos[s][sp] * cs.n_nodes[s]);
+        it_ctx[(size_t)s * NP + sp] = v;
+        if (p == 0)
+          c0[s] = v;
+        else
+          all_same &= v == c0[s];
+      }
+    }
+    row[i] = i;
+    excl[i] = cur_b ? cur_b[i] : -1;
+    for (int k = 0; k < PCLEAN_MAX_CTX; ++k) ctxv[(size_t)i * PCLEAN_MAX_CTX + k] = c0[k];
+    if (all_same) {
+      for (int p = 0; p < P; ++p) slot_item[(size_t)p * N + i] = i;
+    } else {  // representatives: first particle with the same context tuple (this thread's own writes to it_ctx: cache hits)
+      slot_item[i] = i;
+      for (int p = 1; p < P; ++p) {
+        const size_t sp = (size_t)p * N + i;
+        int q = 0;
+        for (; q < p; ++q) {
+          bool same = true;
+          for (int k = 0; k < cs.n_ctx; ++k) same &= it_ctx[(size_t)k * NP + (size_t)q * N + i] == it_ctx[(size_t)k * NP + sp];
+          if (same) break;
+        }
+        if (q == p) {
+          slot_item[sp] = -1 - (int)mine;  // the row's mine-th extra item: numbered below
+          ++mine;
+        } else {
+          slot_item[sp] = slot_item[(size_t)q * N + i];
+        }
+      }
+    }
+  }
+  const unsigned long long any = __ballot(mine != 0u);
+  unsigned int incl = mine;
+  if (any) {
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned int x = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += x;
+    }
+  }
+  if (lane == 63) wcnt[wave] = any ? incl : 0u;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    bbase = tot ? atomicAdd(n_extra, tot) : 0u;
+  }
+  __syncthreads();
+  if (!mine) return;
+  unsigned int base = bbase + incl - mine;
+  for (int w = 0; w < wave; ++w) base += wcnt[w];
+  for (int p = 1; p < P; ++p) {
+    const size_t sp = (size_t)p * N + i;
+    const int si = slot_item[sp];
+    if (si >= 0) continue;
+    // (a particle that shares an extra item reads the representative's entry: resolved when the representative was, since
+    // representatives come first — q < p)
+    int q = 0;
+    for (; q < p; ++q) {
+      bool same = true;
+      for (int k = 0; k < cs.n_ctx; ++k) same &= it_ctx[(size_t)k * NP + (size_t)q * N + i] == it_ctx[(size_t)k * NP + sp];
+      if (same) break;
+    }
+    if (q < p) {
+      slot_item[sp] = slot_item[(size_t)q * N + i];
+      continue;
+    }
+    const unsigned int e = base + (unsigned int)(-1 - si);
+    const int j = N + (int)e;
+    slot_item[sp] = j;
+    if (e < (unsigned int)extra_cap) {
+      row[j] = i;
+      excl[j] = cur_b ? cur_b[i] : -1;
+      for (int k = 0; k < PCLEAN_MAX_CTX; ++k) ctxv[(size_t)j * PCLEAN_MAX_CTX + k] = k < cs.n_ctx ? it_ctx[(size_t)k * NP + sp] : 0;
+    }
+  }
+}
 // (PU_T = 1024 threads per workgroup: the ONE returning atomic per workgroup on the same counter is served at ~30 ns
 // apiece at the memory side — 3 900 workgroups of 256 were a 0.12 ms floor of a 0.17 ms kernel)
 #define PU_T 1024
@@ -167,7 +272,10 @@ __global__ __launch_bounds__(PU_T) void particle_update_kernel(int N, int P, con
                                                               int32_t* __restrict__ new_list,
                                                               int32_t* __restrict__ pnewpos, int first,
                                                               const int32_t* __restrict__ emit_rows, int only_emit,
-                                                              int stage_stride) {
+                                                              int stage_stride, const double* __restrict__ w_uni, int skip_w) {
+  // w_uni: every particle of row i carries the weight 0.0 + w_uni[i] so far and w was never written (pclean_sweep: the first
+  // block's log marginal is shared by a row's particles); skip_w: this launch leaves it that way (nothing stored: 8 P bytes
+  // per row that the next block would only read back)
   __shared__ unsigned int wsum[PU_T / 64];
   __shared__ unsigned int bbase;
   extern __shared__ int32_t pu_stage[];  // stage_stride > 0: the workgroup's rows of draws_rm, stage_stride (odd) words apart
@@ -206,7 +314,7 @@ __global__ __launch_bounds__(PU_T) void particle_update_kernel(int N, int P, con
       }
       const int c = (p == 0 && keep >= 0) ? keep : d;
       pchoice[sp] = c;
-      w[sp] = first ? 0.0 + l : w[sp] + l;  // (first block of the sweep: the weights start at +0.0)
+      if (!skip_w) w[sp] = first ? 0.0 + l : (w_uni ? (0.0 + w_uni[i]) + l : w[sp] + l);  // (first block: the weights start at +0.0)
       if (c == PCLEAN_CHOICE_NEW) newmask |= 1ull << p;
       // a row without any possible candidate (log marginal -inf or NaN): bit 31 of the counter tells the host, which then
       // runs the resampling step it would otherwise know to be a no-op (pclean_sweep: equal_weights)
@@ -307,6 +415,13 @@ __global__ void score_block_kernel(int n_rows, int P, ScoreBlockDev sb, double* 
   w[slot] += acc;
 }
 
+// the weights a launch of particle_update_kernel with skip_w did not store: w[p][i] = 0.0 + w_uni[i]
+__global__ void materialise_w_kernel(int N, int P, const double* __restrict__ w_uni, double* __restrict__ w) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double v = 0.0 + w_uni[i];
+  for (int p = 0; p < P; ++p) w[(size_t)p * N + i] = v;
+}
 __global__ void add_weight_kernel(size_t n, const double* lse, double* w) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) w[t] += lse[t];
@@ -445,11 +560,14 @@ __global__ __launch_bounds__(256) void particle_update_final_kernel(
     const int32_t* __restrict__ draws_item, const double* __restrict__ lse_item, const int32_t* __restrict__ cur_b,
     int32_t* __restrict__ pchoice, const double* __restrict__ w, int first, int use_mh, const int32_t* __restrict__ csmc_flag,
     uint64_t seed, uint32_t sweep, int64_t row_offset, int32_t* __restrict__ chosen, const double* __restrict__ logml_acc,
-    double* __restrict__ logml, const int32_t* __restrict__ skip_rows) {
+    double* __restrict__ logml, const int32_t* __restrict__ skip_rows, int lazy, const double* __restrict__ w_uni) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   if (skip_rows && skip_rows[i]) return;  // (a row that can draw a dummy value: the separate kernels, with the weight corrections between them)
   const int keep = cur_b ? cur_b[i] : -1;
+  // lazy: the root kernels left lists, not draws (enum.h: RootExtra) — the chosen particle's referent is drawn afterwards
+  // (lazy_draw_kernel); only the retained particle's is known here
+  if (lazy && keep >= 0) pchoice[i] = keep;
   FixW<PMAX> f;
   double wv[PMAX];
   f.m = -__builtin_inf();
@@ -462,14 +580,14 @@ __global__ __launch_bounds__(256) void particle_update_final_kernel(
       double l;
       if (slot_item) {
         const int item = slot_item[sp];
-        d = draws_item[(size_t)item * P + p];
+        d = lazy ? 0 : draws_item[(size_t)item * P + p];
         l = lse_item[item];
       } else {
-        d = draws_rm[(size_t)i * P + p];
+        d = lazy ? 0 : draws_rm[(size_t)i * P + p];
         l = lse[i];
       }
-      pchoice[sp] = (p == 0 && keep >= 0) ? keep : d;
-      wv[p] = first ? 0.0 + l : w[sp] + l;
+      if (!lazy) pchoice[sp] = (p == 0 && keep >= 0) ? keep : d;
+      wv[p] = first ? 0.0 + l : (w_uni ? (0.0 + w_uni[i]) + l : w[sp] + l);  // (w_uni: see particle_update_kernel)
       f.m = fmax(f.m, wv[p]);
     }
   }
@@ -1539,6 +1657,17 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       attr_set = true;
     }
   }
+  // The first block's log marginal is shared by the particles of a row (no context yet to tell them apart): its launch of
+  // particle_update_kernel stores no weights (w_uni = that block's lse; 160 MB written and read back per 1M rows x 20
+  // particles otherwise) and the next block's update starts from it.  Whoever touches individual weights in between (dummy
+  // corrections, a resampling step, a scoring block, the separate final choice) gets them materialised first.
+  static const bool no_w_uni = getenv("PCLEAN_NO_UNIFORM_W") != nullptr;
+  const double* w_uni = nullptr;
+  auto materialise_w = [&]() {
+    if (!w_uni) return;
+    hipLaunchKernelGGL(materialise_w_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, w_uni, s->w.p);
+    w_uni = nullptr;
+  };
   bool final_fused = false;            // the last block's particle update made the final choice as well
   const int32_t* final_only_rows = nullptr;  // ... for the rows outside this flag array (the final choice kernel takes the flagged ones)
   const bool defer_final_off = false;  // (placeholder of a condition that would forbid it)
@@ -1584,6 +1713,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         if (!rc2) rc2 = make_src(st_.key_block, st_.key_col, sb.t[k].key);
       }
       if (rc2) return rc2;
+      materialise_w();
       hipLaunchKernelGGL(score_block_kernel, grid1(NP), dim3(256), 0, ctx->stream, N, P, sb, s->w.p);
       continue;
     }
@@ -1650,6 +1780,17 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     ItemList il;
     const int32_t* excl;
     unsigned int* n_new_ctr = nullptr;  // particles of the block that proposed a NEW referent (fresh_counter)
+    SweepState::LazyOut lazy;           // the root kernels left lists instead of draws (last block: enum.h RootExtra)
+    auto lazy_draws = [&]() -> int {    // ... and the chosen particles' draws follow the fused final choice
+      if (!lazy.valid) return PCLEAN_OK;
+      ProfScope psl(ctx, "lazy_draws");
+      lazy.args.n_rows = N;
+      lazy.args.n_particles = P;
+      lazy.args.chosen = s->chosen.p;
+      lazy.args.cur_b = cur_b;
+      lazy.args.pchoice = r.pchoice.p;
+      return pclean_launch_lazy_draws(ctx, lazy.args, seed, sweep_idx, lazy.site);
+    };
     if (prior_mode) {
       // every (row, particle) draws its referent from the CRP prior; the block's log marginal plays no part
       il = ItemList{N, nullptr, nullptr, nullptr, nullptr};
@@ -1666,7 +1807,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), pu_stage_bytes, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
                          s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0,
-                         (const int32_t*)nullptr, 0, pu_stage_stride);
+                         (const int32_t*)nullptr, 0, pu_stage_stride, (const double*)nullptr, 0);
       HIPCHK(ctx, hipGetLastError());
       if (has_ctx) {  // the particles' contexts: read by the likelihood terms and handed to the new rows' items
         { const int rci = ensure_it_ctx(ctx, r, NP, b.n_ctx); if (rci) return rci; }
@@ -1692,8 +1833,12 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       il = ItemList{N, nullptr, nullptr, nullptr, nullptr};  // draws row-major [N][P]: one 80-byte store per row
       excl = cur_b;
       if (r.draws.alloc(NP) || r.lse.alloc(N)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+      if (fuse_final || split_final) s->lazy_req = SweepState::LazyReq{true, split_final ? emit_rows : nullptr};
       rc = eval_node(ctx, bi, 0, il, excl, seed, sweep_idx, P, r.lse.p, r.draws.p, nullptr, nullptr, bi == 0);
+      s->lazy_req = SweepState::LazyReq();
       if (rc) return rc;
+      lazy = s->lazy_out;
+      s->lazy_out.valid = false;
       if (bi == 0) {  // (the elapsed time of the launch is read at the end of the call: no synchronisation here)
         hot_timed = true;
         ctx->timing.hot_kernel_launches += 1;
@@ -1704,22 +1849,30 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
                                             r.lse.p, (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b,
                                             r.pchoice.p, s->w.p, (w_by_first_block && bi == 0) ? 1 : 0, use_mh, cur_base, seed,
                                             sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->logml_acc.p, s->logml.p,
-                                            (const int32_t*)nullptr));
+                                            (const int32_t*)nullptr, lazy.valid ? 1 : 0, w_uni));
         final_fused = true;
+        { const int rcl = lazy_draws(); if (rcl) return rcl; }
       } else {
       n_new_ctr = fresh_counter(ctx);
+      // (the first block of several: its weights are the block's log marginal for every particle of a row — not stored)
+      const bool skip_w = bi == 0 && w_by_first_block && bi < n_blocks - 1 && !split_final && !emit_rows && !no_w_uni;
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), pu_stage_bytes, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
                          s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows, split_final ? 1 : 0,
-                         pu_stage_stride);
+                         pu_stage_stride, w_uni, skip_w ? 1 : 0);
       HIPCHK(ctx, hipGetLastError());
+      if (skip_w)
+        w_uni = r.lse.p;
+      else if (!split_final)
+        w_uni = nullptr;  // (every row's weights are in w now)
       if (split_final) {
         DISPATCH_PMAX(P, hipLaunchKernelGGL(particle_update_final_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, r.draws.p,
                                             r.lse.p, (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b,
                                             r.pchoice.p, s->w.p, (w_by_first_block && bi == 0) ? 1 : 0, use_mh, cur_base, seed,
                                             sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->logml_acc.p, s->logml.p,
-                                            emit_rows));
+                                            emit_rows, lazy.valid ? 1 : 0, w_uni));
         final_only_rows = emit_rows;
+        { const int rcl = lazy_draws(); if (rcl) return rcl; }
       }
       }
     } else {
@@ -1742,15 +1895,41 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       }
       // One enumeration per distinct (row, context): particles whose earlier choices give the same
       // context share the candidate scores and differ only in their Philox draws.
-      int32_t* rep = scratch<int32_t>(ctx, NP);
       int32_t* slot_item = scratch<int32_t>(ctx, NP);
+      if (!slot_item) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      unsigned int n_items = 0;
+      int32_t *d_row = nullptr, *d_ctx = nullptr, *d_excl = nullptr;
+      static const bool no_fused_items = getenv("PCLEAN_NO_FUSED_CTX_ITEMS") != nullptr;
+      if (!no_fused_items) {
+        // one pass (ctx_items_kernel): item i = row i with particle 0's context, extra items behind them; room for the extra
+        // items from the last sweep's number (a sweep that needs more runs the kernel again)
+        ProfScope ps(ctx, "ctx_items");
+        for (int attempt = 0;; ++attempt) {
+          const int cap = std::max(r.ctx_extra_cap, 4096);
+          d_row = scratch<int32_t>(ctx, (size_t)N + cap);
+          d_ctx = scratch<int32_t>(ctx, ((size_t)N + cap) * PCLEAN_MAX_CTX);
+          d_excl = scratch<int32_t>(ctx, (size_t)N + cap);
+          unsigned int* extra_ctr = fresh_counter(ctx);
+          if (!d_row || !d_ctx || !d_excl || !extra_ctr) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+          hipLaunchKernelGGL(ctx_items_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, cs, cur_b, r.it_ctx.p, slot_item, d_row, d_ctx,
+                             d_excl, extra_ctr, cap);
+          unsigned int n_extra = 0;
+          PCLEAN_READ_COUNT(ctx, extra_ctr, &n_extra);
+          r.ctx_extra_cap = (int)std::min<size_t>((size_t)n_extra * 2 + 4096, NP);
+          if (n_extra <= (unsigned int)cap) {
+            n_items = (unsigned int)N + n_extra;
+            break;
+          }
+          if (attempt >= 2) return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_sweep: the context items did not fit twice in a row");
+        }
+      } else {
+      int32_t* rep = scratch<int32_t>(ctx, NP);
       int32_t* n_distinct = scratch<int32_t>(ctx, (size_t)N + 1);
       int32_t* off = scratch<int32_t>(ctx, (size_t)N + 1);
       size_t tmp_scan = 0;
       HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_scan, n_distinct, off, N + 1, ctx->stream));
       unsigned char* tmp = scratch<unsigned char>(ctx, tmp_scan);
-      if (!rep || !slot_item || !n_distinct || !off || !tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-      unsigned int n_items = 0;
+      if (!rep || !n_distinct || !off || !tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
       {
         ProfScope ps(ctx, "ctx_items");
         hipLaunchKernelGGL(gather_ctx_kernel, grid1(NP), dim3(256), 0, ctx->stream, NP, cs, r.it_ctx.p);
@@ -1759,38 +1938,48 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         HIPCHK(ctx, hipcub::DeviceScan::ExclusiveSum(tmp, tmp_scan, n_distinct, off, N + 1, ctx->stream));
         PCLEAN_READ_COUNT(ctx, off + N, &n_items);
       }
-      int32_t* d_row = scratch<int32_t>(ctx, n_items);
-      int32_t* d_ctx = scratch<int32_t>(ctx, (size_t)n_items * PCLEAN_MAX_CTX);
-      int32_t* d_excl = scratch<int32_t>(ctx, n_items);
-      double* lse_item = scratch<double>(ctx, n_items);
-      int32_t* draws_item = scratch<int32_t>(ctx, (size_t)n_items * P);
-      if (!d_row || !d_ctx || !d_excl || !lse_item || !draws_item)
-        return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      d_row = scratch<int32_t>(ctx, n_items);
+      d_ctx = scratch<int32_t>(ctx, (size_t)n_items * PCLEAN_MAX_CTX);
+      d_excl = scratch<int32_t>(ctx, n_items);
+      if (!d_row || !d_ctx || !d_excl) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
       hipLaunchKernelGGL(ctx_fill_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, (int)b.n_ctx, r.it_ctx.p, rep, off, cur_b, slot_item,
                          d_row, d_ctx, d_excl);
+      }
+      double* lse_item = scratch<double>(ctx, n_items);
+      int32_t* draws_item = scratch<int32_t>(ctx, (size_t)n_items * P);
+      if (!lse_item || !draws_item) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
       il = ItemList{(int)n_items, d_row, d_ctx, nullptr, nullptr};
+      if (fuse_final || split_final) s->lazy_req = SweepState::LazyReq{true, split_final ? emit_rows : nullptr};
       rc = eval_node(ctx, bi, 0, il, d_excl, seed, sweep_idx, P, lse_item, draws_item, nullptr, nullptr, false);
+      s->lazy_req = SweepState::LazyReq();
       if (rc) return rc;
+      lazy = s->lazy_out;
+      s->lazy_out.valid = false;
+      lazy.args.slot_item = slot_item;
       ProfScope ps(ctx, "particle_update");
       if (fuse_final) {
         DISPATCH_PMAX(P, hipLaunchKernelGGL(particle_update_final_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P,
                                             (const int32_t*)nullptr, (const double*)nullptr, slot_item, draws_item, lse_item, cur_b,
                                             r.pchoice.p, s->w.p, (w_by_first_block && bi == 0) ? 1 : 0, use_mh, cur_base, seed,
                                             sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->logml_acc.p, s->logml.p,
-                                            (const int32_t*)nullptr));
+                                            (const int32_t*)nullptr, lazy.valid ? 1 : 0, w_uni));
         final_fused = true;
+        { const int rcl = lazy_draws(); if (rcl) return rcl; }
       } else {
       n_new_ctr = fresh_counter(ctx);
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, (const int32_t*)nullptr,
                          (const double*)nullptr, slot_item, draws_item, lse_item, cur_b, r.pchoice.p, s->w.p,
-                         n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows, split_final ? 1 : 0, 0);
+                         n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows, split_final ? 1 : 0, 0,
+                         w_uni, 0);
+      if (!split_final) w_uni = nullptr;  // (every row's weights are in w now)
       if (split_final) {
         DISPATCH_PMAX(P, hipLaunchKernelGGL(particle_update_final_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P,
                                             (const int32_t*)nullptr, (const double*)nullptr, slot_item, draws_item, lse_item, cur_b,
                                             r.pchoice.p, s->w.p, (w_by_first_block && bi == 0) ? 1 : 0, use_mh, cur_base, seed,
                                             sweep_idx, s->row_offset + ctx->active_begin, s->chosen.p, s->logml_acc.p, s->logml.p,
-                                            emit_rows));
+                                            emit_rows, lazy.valid ? 1 : 0, w_uni));
         final_only_rows = emit_rows;
+        { const int rcl = lazy_draws(); if (rcl) return rcl; }
       }
       }
     }
@@ -1838,6 +2027,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         if (rc) return rc;
       }
       if (drawable) {
+        if (!split_final) materialise_w();  // (split: the flagged rows' weights were stored, nobody looks at the others')
         rc = apply_dummy_corrections(ctx, bi, r.new_slots.p, r.vals.p, (int)n_new, N, seed, sweep_idx, s->w.p);
         if (rc) return rc;
       }
@@ -1868,6 +2058,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     static const bool always_resample = getenv("PCLEAN_ALWAYS_RESAMPLE") != nullptr;
     if (!use_mh && bi < n_blocks - 1 && grp_here != grp_next && (!equal_weights || always_resample)) {  // (the slots of one model block: no resampling in between)
       ProfScope ps(ctx, "resample");
+      materialise_w();
       DISPATCH_PMAX(P, hipLaunchKernelGGL(maybe_resample_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p,
                                           (size_t)1, (size_t)N, 1, cur_b, seed, sweep_idx, (uint32_t)bi,
                                           s->row_offset + ctx->active_begin, s->ancestors.p, s->logml_inc.p,
@@ -1889,6 +2080,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   // got a new referent (hipcub select keeps ascending row order), ONE read-back of the counts
   {
     ProfScope ps(ctx, "final_choice_and_outputs");
+    if (!final_fused && !final_only_rows) materialise_w();  // (never pending here: a plain update of every row stored them)
     if (!final_fused)
     DISPATCH_PMAX(P, hipLaunchKernelGGL(final_choice_kernel<PMAX>, grid1(N), dim3(256), 0, ctx->stream, N, P, s->w.p,
                                         (size_t)1, (size_t)N, use_mh, 1, cur_base, seed, sweep_idx,

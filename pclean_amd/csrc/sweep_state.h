@@ -31,6 +31,7 @@ struct BlockRun {  // per-block device state of one sweep
   size_t it_ctx_np = 0;  // shape it_ctx was last zeroed for (sweep.hip: ensure_it_ctx)
   int it_ctx_used = -1;
   bool lazy_new = false;  // their contents are sampled after the final choice, for the chosen particles only
+  int ctx_extra_cap = 0;  // room for the extra context items of the next sweep (sweep.hip: ctx_items_kernel)
   DevBuf<int32_t> plan_kind, plan_nrows, plan_cmb, plan_colmap;
   DevBuf<const int32_t*> plan_cols;
   PlanDev plan{};
@@ -145,6 +146,11 @@ struct SweepState {
   DevBuf<int16_t> dummy_dp;
   DevBuf<unsigned int> dummy_ctr;  // [0] matrices handed out by the running launch, [1] set when they ran out
   bool dummy_used = false;
+  // lazy draws of a sweep's last block (enum.h: RootExtra).  pclean_sweep sets lazy_req before the block's root evaluation;
+  // eval_node takes it (nested evaluations never see it) and, when the compact-table kernels honoured it, leaves lazy_out for
+  // pclean_launch_lazy_draws (the sweep fills in what only it knows: chosen particles, slot_item, pchoice, ...)
+  struct LazyReq { bool on = false; const int32_t* eager_rows = nullptr; } lazy_req;
+  struct LazyOut { bool valid = false; LazyDrawArgs args{}; uint32_t site = 0; } lazy_out;
   // block 0's root scan of the last pclean_sweep (pclean_debug_root_flags; the scratch stays valid until the next call)
   const int32_t* dbg_desc = nullptr;
   const int32_t* dbg_grp_off = nullptr;

@@ -1,0 +1,82 @@
+"""Run-to-run and path-to-path determinism of the observed-class sweep (advisor r5): the hash grouping numbers its groups in
+the order the workgroups arrive, the gate of the new-row branch pauses by its own history, the extra context items of a block
+are numbered by an atomic counter — every consumer must be independent of all that.  The same sweeps (a 40 000-row synthetic
+table from its own initialisation: several thousand groups, moved rows, new referents; sweep + host commit, three times) run
+in fresh processes under
+  * the product's defaults, twice,
+  * PCLEAN_SORT_GROUPS=1 (radix-sort grouping), PCLEAN_GATE_ALWAYS=1 (no gate pauses),
+  * the round-5 paths of this round's changes (PCLEAN_NO_LAZY_DRAWS, PCLEAN_NO_UNIFORM_W, PCLEAN_NO_SMALL_GENERIC,
+    PCLEAN_NO_FUSED_CTX_ITEMS),
+and every output (chosen referents, chosen particles, log marginal likelihood estimates, new-row records, the committed
+state) must be bit-identical: one SHA-256 over all of them per process."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import hashlib, sys
+import numpy as np
+sys.path[:0] = [ROOT, ROOT + "/tests"]
+import helpers
+from pclean_amd.engine import Engine, InferenceConfig
+from pclean_amd.inference import initialize_trace
+from pclean_amd.parallel import Comm, exchange_and_commit
+from pclean_amd.trace import Trace
+dirty, clean, lw, obs, _ = helpers.truth_workload(40000, 400, 11)
+eng = Engine(lw, obs)
+h = hashlib.sha256()
+try:
+    cfg = InferenceConfig(1, 20)
+    tr = Trace(lw, obs.shape[1], 5)
+    initialize_trace(eng, tr, cfg, 5, max_batch=4096)
+    for sweep in range(3):
+        eng.upload_trace(tr)
+        choice, chosen, logml, new_rows = eng.sweep(tr, cfg, 77, sweep)
+        stats = eng.sweep_stats(tr)
+        for a in (choice, chosen, logml):
+            h.update(np.ascontiguousarray(a).tobytes())
+        for b in sorted(new_rows):
+            h.update(np.ascontiguousarray(new_rows[b][0]).tobytes())
+            h.update(np.ascontiguousarray(new_rows[b][1]).tobytes())
+        exchange_and_commit(tr, lw, Comm(), 0, choice, stats, new_rows)
+        h.update(np.ascontiguousarray(tr.cur).tobytes())
+        for c in sorted(tr.tables):
+            t = tr.tables[c]
+            h.update(np.ascontiguousarray(t.counts[:t.n]).tobytes())
+    print("DIGEST", h.hexdigest(), int((choice != tr.cur).sum()), {c: int(t.n_live) for c, t in tr.tables.items()})
+finally:
+    eng.close()
+'''
+
+
+def _run(extra_env):
+    env = dict(os.environ)
+    env.update(extra_env)
+    out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1]
+    return line.split()[1], line
+
+
+def test_sweeps_are_bit_identical_across_runs_and_paths(capsys):
+    variants = {
+        "default": {},
+        "default again": {},
+        "sorted groups": {"PCLEAN_SORT_GROUPS": "1"},
+        "gate always": {"PCLEAN_GATE_ALWAYS": "1"},
+        "round-5 paths": {"PCLEAN_NO_LAZY_DRAWS": "1", "PCLEAN_NO_UNIFORM_W": "1", "PCLEAN_NO_SMALL_GENERIC": "1",
+                          "PCLEAN_NO_FUSED_CTX_ITEMS": "1"},
+        "generic kernels": {"PCLEAN_NO_DEDUP": "1", "PCLEAN_NO_GATE": "1", "PCLEAN_NO_MEMO": "1"},
+    }
+    digests = {}
+    for name, env in variants.items():
+        digests[name], line = _run(env)
+        with capsys.disabled():
+            print(f"\n[determinism] {name}: {line}")
+    assert len(set(digests.values())) == 1, digests
