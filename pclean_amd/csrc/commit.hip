@@ -16,7 +16,7 @@ __device__ long long pcc_prof_t[64];
 __device__ int pcc_prof_n;
 #define PCC_STAMP(name)                                                   \
   do {                                                                    \
-    if (tid == 0 && pcc_prof_n < 64) pcc_prof_t[pcc_prof_n++] = (long long)wall_clock64(); \
+    if (tid == 0 && blockIdx.x == 0 && pcc_prof_n < 64) pcc_prof_t[pcc_prof_n++] = (long long)wall_clock64(); \
   } while (0)
 #define PCC_CUR_SEPARATE
 #include "commit_core.h"
@@ -70,6 +70,8 @@ struct CommitState {
       newid[PCC_MAX_BLOCKS], recpos[PCC_MAX_BLOCKS];
   DevBuf<PccResult> d_res;
   DevBuf<PccSums> d_sums;
+  DevBuf<int> d_bar;   // arrival counter of pcc_commit_mw_kernel's barriers (monotone) ...
+  int bar_count = 0;   // ... and its value when the next launch starts
   // several ranks (pclean_commit_device_dist): segment capacities (the same on every rank: from the window's size, then
   // from the last commit's global totals), the all-gather buffers, the gathered lists and the gathered-form blocks
   int cap_m[PCC_MAX_BLOCKS] = {0}, cap_k[PCC_MAX_BLOCKS] = {0};
@@ -100,6 +102,7 @@ void pclean_commit_state_free(pclean_ctx* ctx) {
   }
   c->d_tables.release(); c->d_plans.release(); c->d_blocks.release(); c->d_states.release(); c->d_res.release();
   c->d_sums.release();
+  c->d_bar.release();
   for (int b = 0; b < PCC_MAX_BLOCKS; ++b) {
     c->d_colmap[b].release(); c->ht[b].release(); c->rep[b].release(); c->flags[b].release(); c->scan[b].release();
     c->base[b].release(); c->newid[b].release(); c->recpos[b].release();
@@ -143,6 +146,63 @@ __global__ __launch_bounds__(1024) void pcc_commit_kernel(PccTable* tb, int n_sl
       tb[s].state[PCC_ST_NCHG] = 0;
     }
   pcc_commit(tb, n_slots, plans, blocks, n_blocks, res, part, (int)threadIdx.x, (int)blockDim.x);
+}
+
+// ---- one workgroup PER PLAN, when every plan's tables are its own (PccPlan::exclusive: hospital's Hospital / Measure slots,
+// every program of this image).  The one-workgroup kernel above walks the plans one after the other (1M rows: 90 us of
+// hashing the Measure slot's new-row records, then 65 us of reference counts + garbage collection of the Hospital plan,
+// then the Measure plan's creation and collection); their phases touch disjoint tables and disjoint scratch, so they run
+// side by side.  What they share — "is the commit refused?", decided before anything is modified — goes through a barrier
+// across the workgroups: a monotone device counter (never reset: the host passes the value it starts from), every
+// workgroup's thread 0 arrives and spins; the grid is one workgroup per plan (<= 16), always co-resident.
+__device__ void pcc_mw_barrier(int* ctr, int target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(ctr, 1);
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+    __threadfence();
+  }
+  __syncthreads();
+}
+__global__ __launch_bounds__(1024) void pcc_commit_mw_kernel(PccTable* tb, int n_slots, const PccPlan* plans, const PccBlock* blocks,
+                                                             int n_blocks, PccResult* res, int gathered, int* bar, int bar0) {
+  __shared__ int32_t part[1025];
+  const int tid = (int)threadIdx.x, nt = (int)blockDim.x, bi = (int)blockIdx.x;
+  if (bi == 0 && tid == 0) {  // what pcc_commit's first lines and the one-workgroup kernel's do
+    pcc_prof_n = 0;
+    if (!gathered) res->fallback_in = 0;
+    for (int s = 0; s < n_slots; ++s) {
+      tb[s].state[PCC_ST_COLS_CHANGED] = 0;
+      tb[s].state[PCC_ST_CREATED] = 0;
+      tb[s].state[PCC_ST_DELETED] = 0;
+      tb[s].state[PCC_ST_NCHG] = 0;
+    }
+    res->fallback = res->fallback_in;
+    res->n_changed = 0;
+    for (int s = 0; s < PCC_MAX_SLOTS; ++s) res->alloc_upper[s] = 0;
+    for (int b = 0; b < PCC_MAX_BLOCKS; ++b) res->n_records[b] = res->n_distinct[b] = res->n_nested[b] = 0;
+  }
+  pcc_mw_barrier(bar, bar0 + n_blocks);
+  if (res->fallback) {  // (uniform: written before the barrier) — the second barrier's arrivals are still made: the host counts them
+    if (tid == 0) atomicAdd(bar, 1);
+    return;
+  }
+  pcc_prepare_block(tb, plans[bi], blocks[bi], bi, res, tid, nt);
+  __syncthreads();
+  if (tid == 0) {  // the capacity of this plan's own tables (pcc_commit's check; every table has one user)
+    const PccPlan& pl = plans[bi];
+    for (int u = 0; u < pl.n_used; ++u) {
+      const int s = pl.used_slot[u];
+      const int a = res->alloc_upper[s];
+      if (a == 0) continue;
+      if (tb[s].state[PCC_ST_NHW] + (a > tb[s].state[PCC_ST_NFREE] ? a - tb[s].state[PCC_ST_NFREE] : 0) > tb[s].stride)
+        atomicOr(&res->fallback, PCC_FB_CAPACITY);
+    }
+  }
+  pcc_mw_barrier(bar, bar0 + 2 * n_blocks);
+  if (res->fallback) return;
+  pcc_apply_block(tb, plans[bi], blocks[bi], bi, res, part, tid, nt);
 }
 
 // the moved rows' current referents, after the commit kernel decided the created rows' ids (grid.y = plan)
@@ -667,8 +727,27 @@ static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_
     cur_rows = 0;
     for (int p = 0; p < c->n_plans; ++p) cur_rows = std::max<int64_t>(cur_rows, (int64_t)L.cap_m[p] * world);
   }
-  hipLaunchKernelGGL(pcc_commit_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_tables.p, c->n_slots, c->d_plans.p,
-                     commit_blocks, c->n_plans, c->d_res.p, dist ? 1 : 0);
+  // one workgroup per plan when no two plans share a table (pcc_commit_mw_kernel), else one workgroup for everything
+  static const bool no_mw = getenv("PCLEAN_COMMIT_ONE_WG") != nullptr;
+  bool all_exclusive = c->n_plans > 1 && !no_mw;
+  for (int p = 0; p < c->n_plans; ++p) all_exclusive = all_exclusive && c->h_plans[p].exclusive != 0;
+  if (all_exclusive && !c->d_bar.p) {
+    if (c->d_bar.alloc(16)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+    HIPCHK(ctx, hipMemsetAsync(c->d_bar.p, 0, 16 * sizeof(int), ctx->stream));
+    c->bar_count = 0;
+  }
+  if (all_exclusive) {
+    if (c->bar_count > (1 << 30)) {  // (never in practice: 2 x plans per commit)
+      HIPCHK(ctx, hipMemsetAsync(c->d_bar.p, 0, 16 * sizeof(int), ctx->stream));
+      c->bar_count = 0;
+    }
+    hipLaunchKernelGGL(pcc_commit_mw_kernel, dim3(c->n_plans), dim3(1024), 0, ctx->stream, c->d_tables.p, c->n_slots, c->d_plans.p,
+                       commit_blocks, c->n_plans, c->d_res.p, dist ? 1 : 0, c->d_bar.p, c->bar_count);
+    c->bar_count += 2 * c->n_plans;
+  } else {
+    hipLaunchKernelGGL(pcc_commit_kernel, dim3(1), dim3(1024), 0, ctx->stream, c->d_tables.p, c->n_slots, c->d_plans.p,
+                       commit_blocks, c->n_plans, c->d_res.p, dist ? 1 : 0);
+  }
   hipLaunchKernelGGL(pcc_cur_kernel, dim3(std::max(1, std::min(1024, (cur_rows + 255) / 256)), c->n_plans), dim3(256), 0, ctx->stream,
                      commit_blocks, c->d_res.p);
   int rc = launch_refresh(ctx, c);

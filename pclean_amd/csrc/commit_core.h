@@ -568,7 +568,7 @@ PCC_FN void pcc_apply_block(PccTable* tb, const PccPlan& pl, const PccBlock& b, 
 #ifndef PCC_CUR_SEPARATE
   pcc_update_cur(b, tid, nt);
 #endif
-  if (tid == 0) res->n_changed += n_moved;
+  if (tid == 0) PCC_ADD32(&res->n_changed, n_moved);  // (atomic: the plans may run on a workgroup each)
   PCC_BARRIER();
   PCC_STAMP("cur");
   // 7. garbage collection

@@ -763,7 +763,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
   // refresh the node's prior rows after every commit for nothing.  Same results either way (wave == generic is tested).
   static const bool no_small_generic = getenv("PCLEAN_NO_SMALL_GENERIC") != nullptr;
   const bool small_lse = !no_small_generic && n_draws == 0 && il.n <= 1024 && !il.ev_lo &&
-                         (size_t)(nd.n_cand + 2) * 8 + (16 + 64) * 8 <= (size_t)80 * 1024;
+                         (size_t)(nd.n_cand + 2) * 8 + (16 + 64) * 8 <= (size_t)160 * 1024;
   if (!fast_tried && !scores_out && !snew_override && !ctx->force_generic && !nd.g.on && !ctx->prior_mode && !small_lse) {
     if (!il.ev_lo)
       fast = try_fast_root(ctx, block_id, node_id, fr);

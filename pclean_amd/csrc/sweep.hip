@@ -46,6 +46,12 @@ int read_count(pclean_ctx* ctx, const void* dev, void* out, const char* func, in
   }
   const unsigned int seq = ++s->poll_seq;
   hipLaunchKernelGGL(publish_count_kernel, dim3(1), dim3(1), 0, ctx->stream, (const unsigned int*)dev, s->d_poll, seq);
+  if (s->on_first_wait) {  // (work for another stream that the host queues while the device is still behind it)
+    std::function<int()> f;
+    f.swap(s->on_first_wait);
+    const int rcf = f();
+    if (rcf) return rcf;
+  }
   volatile unsigned int* h = s->h_poll;
   for (long spins = 0; h[1] != seq; ++spins)
     if (spins > 2000000) {  // (a failed launch would spin for ever: let the runtime report it)
@@ -1640,6 +1646,18 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     prefetching = true;
     return PCLEAN_OK;
   };
+  struct FirstWaitGuard {  // (the hook refers to this frame: no exit of the call leaves it behind; and an error exit between
+    SweepState* st_;       // the fork and the join still joins the side stream: its work must not overlap the next call)
+    pclean_ctx* c_;
+    bool* prefetching_;
+    ~FirstWaitGuard() {
+      st_->on_first_wait = nullptr;
+      if (*prefetching_) (void)hipStreamWaitEvent(c_->stream, st_->pre_join, 0);
+    }
+  } first_wait_guard{s, ctx, &prefetching};
+  static const bool late_prefetch = getenv("PCLEAN_LATE_COMPACT_PREFETCH") != nullptr;
+  if (!late_prefetch)
+    s->on_first_wait = [&]() -> int { return prefetch_started ? PCLEAN_OK : start_prefetch(); };
   bool hot_timed = false;
   // particle_update_kernel stages the root kernels' row-major draws through LDS (rows of P words, an odd stride apart)
   static const bool no_pu_stage = getenv("PCLEAN_NO_PU_STAGE") != nullptr;

@@ -1,6 +1,7 @@
 // Per-context state of the sweep entry points (sweep.hip, eval.hip, latent.hip) that other translation units of the library read
 // (commit.hip: the device-resident commit consumes a sweep's device-side outputs).  Not part of the ABI.
 #pragma once
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -87,6 +88,9 @@ struct SweepState {
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evs = nullptr, eve = nullptr;
   hipEvent_t evg0 = nullptr, evg1 = nullptr;  // around group_gate_kernel of the timed root (part of its launch group)
   hipStream_t pre_stream = nullptr;           // compact-table refresh of the later blocks' roots, beside block 0 (pclean_sweep)
+  // ... queued by the host the first time it WAITS for the device in the running sweep (read_count): the enqueue costs no
+  // critical-path time, and the refresh runs beside the first block's grouping instead of beside its root scan
+  std::function<int()> on_first_wait;
   hipEvent_t pre_fork = nullptr, pre_join = nullptr;
   bool gate_timed = false;
   // memo tables of option-list marginals (leaf_memo_*): key = block * 64 + node
