@@ -247,6 +247,8 @@ int pclean_launch_prior_terms_ev(pclean_ctx* ctx, int n_items, int P, int n_node
                                  const int32_t* n_children, const int32_t* child_begin, const int32_t* children, int n_roots,
                                  const int32_t* roots, const ItemsDev& it, const int32_t* vals, double* w);
 // option list of a LEAF node scored against evidence sets (enum_kernels.hip: ev_leaf_block_kernel)
+// ... or a reference slot (FK node; ch = the marginals of its new-row branch's children, null for an option list)
 int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const FastRootDev& fr, uint64_t seed,
                           uint32_t sweep, uint32_t site, int n_draws, double* lse_out, int32_t* draws_out,
-                          int32_t* overflow_flag, unsigned int* overflow_count, int32_t* overflow_list = nullptr);
+                          int32_t* overflow_flag, unsigned int* overflow_count, int32_t* overflow_list = nullptr,
+                          const ChildrenDev* ch = nullptr);

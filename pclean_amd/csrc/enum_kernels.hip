@@ -269,22 +269,27 @@ int pclean_launch_gate(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
 #define EV_SURV_CAP 2048
 #define EV_FIX_CUTOFF 28.5
 
-__global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
+// Round 6: REFERENCE SLOTS too (nd.kind == PCLEAN_NODE_FK: a latent Place re-choosing its County against the ~260 observed
+// rows below it): the candidates' priors are the CRP terms (candidate_score handles the excluded referent), the "new row"
+// candidate (new_score: the children's marginals, evaluated before) is one more entry behind the survivors and one more
+// lower bound of the maximum, and the largest prior of the inequality is the slot's (with / without an excluded reference).
+__global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it, const ChildrenDev ch,
                                                              const FastRootDev fr, uint64_t seed, uint32_t sweep,
                                                              uint32_t site, int n_draws, double* __restrict__ lse_out,
                                                              int32_t* __restrict__ draws_out,
                                                              int32_t* __restrict__ overflow_flag,
                                                              unsigned int* __restrict__ overflow_count,
                                                              int32_t* __restrict__ overflow_list) {
-  __shared__ uint64_t s_pref[EV_SURV_CAP];  // exact scores (as doubles), then the fixed-point inclusive prefix
+  __shared__ uint64_t s_pref[EV_SURV_CAP + 1];  // exact scores (as doubles), then the fixed-point inclusive prefix (+ the new row)
   __shared__ int32_t s_k[EV_SURV_CAP];
   __shared__ uint64_t s_w64[EV_W];
   __shared__ double s_wd[EV_W];
   __shared__ int s_wi[EV_W];
-  __shared__ double s_bound;
+  __shared__ double s_bound, s_new;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   double* scv = reinterpret_cast<double*>(s_pref);
   const int n = nd.n_cand;
+  const bool fk = nd.kind == PCLEAN_NODE_FK;
   const int nquads = fr.kpad >> 4;
   const int draw_is = it.draw_is ? it.draw_is : n_draws;
   for (int t = blockIdx.x; t < it.n; t += gridDim.x) {
@@ -330,15 +335,23 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
     }
     if (lane == 0) s_w64[wave] = best;
     __syncthreads();
+    const int to = it.out_pos ? it.out_pos[t] : t;
     if (tid == 0) {
       for (int w = 1; w < EV_W; ++w) best = s_w64[w] < best ? s_w64[w] : best;
-      s_bound = best != ~0ull ? candidate_score(nd, dn, it, v, (int)(uint32_t)best) - 1.0 : -__builtin_inf();
+      double bd = best != ~0ull ? candidate_score(nd, dn, it, v, (int)(uint32_t)best) - 1.0 : -__builtin_inf();
+      double sn = -__builtin_inf();
+      if (fk) {  // the new-row candidate is a candidate too: its exact score bounds the maximum from below
+        sn = new_score(nd, ch, v, to);
+        bd = fmax(bd, sn);
+      }
+      s_new = sn;
+      s_bound = bd;
     }
     __syncthreads();
     const double bound = s_bound;
     uint32_t dcut = 0xffffffffu;
     if (fr.inv_c > 0.0 && bound > -__builtin_inf()) {
-      const double x = (fr.prior_max_n - bound + EV_FIX_CUTOFF) * fr.inv_c;
+      const double x = ((fk && v.excl >= 0 ? fr.prior_max_e : fr.prior_max_n) - bound + EV_FIX_CUTOFF) * fr.inv_c;
       if (x >= 0.0 && x < 4.0e9) dcut = (uint32_t)x + 2u;
     }
     // ---- pass B: survivors in ascending option order
@@ -373,7 +386,6 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
       ns += round_total;
       __syncthreads();  // s_wi is rewritten by the next round
     }
-    const int to = it.out_pos ? it.out_pos[t] : t;
     if (ns > EV_SURV_CAP) {
       if (tid == 0) {
         overflow_flag[to] = PCLEAN_CHOICE_NEW;
@@ -389,15 +401,21 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
       scv[j] = sc;
       m = fmax(m, sc);
     }
+    const int n_e = ns + (fk ? 1 : 0);  // entries of the prefix: the survivors in ascending order, then the new row
+    if (fk && tid == 0) {
+      scv[ns] = s_new;
+      m = fmax(m, s_new);
+    }
+    __syncthreads();  // (scv[ns] is read by the thread that owns entry ns below)
     m = wave_max(m);
     if (lane == 0) s_wd[wave] = m;
     __syncthreads();
     m = s_wd[0];
     for (int w = 1; w < EV_W; ++w) m = fmax(m, s_wd[w]);
     uint64_t carry = 0;
-    for (int j0 = 0; j0 < ns; j0 += EV_T) {
+    for (int j0 = 0; j0 < n_e; j0 += EV_T) {
       const int j = j0 + tid;
-      const uint64_t u = (j < ns && m != -__builtin_inf()) ? pclean_fixw(scv[j] - m) : 0ull;
+      const uint64_t u = (j < n_e && m != -__builtin_inf()) ? pclean_fixw(scv[j] - m) : 0ull;
       unsigned long long incl = u;
       for (int sh = 1; sh < 64; sh <<= 1) {
         const unsigned long long x = __shfl_up(incl, sh, 64);
@@ -411,7 +429,7 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
         if (w < wave) base += s_w64[w];
         chunk_total += s_w64[w];
       }
-      if (j < ns) s_pref[j] = base + incl;  // entry j: read as a score by this thread only, above
+      if (j < n_e) s_pref[j] = base + incl;  // entry j: read as a score by this thread only, above
       carry += chunk_total;
     }
     const uint64_t U = carry;
@@ -419,12 +437,12 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
     if (tid == 0) {
       if (lse_out) lse_out[to] = pclean_lse_from_fix(m, U);
       if (n_draws > 0) {
-        int32_t res = n - 1;
+        int32_t res = fk ? PCLEAN_CHOICE_NEW : n - 1;
         if (U != 0) {
           const uint32_t rng_row = it.rng_row ? (uint32_t)it.rng_row[t] : (uint32_t)((int64_t)v.row + it.row_offset);
           const uint32_t pid = it.particle ? (uint32_t)it.particle[t] : 0u;
           const uint64_t x = pclean_mulhi64(pclean_rand64(seed, rng_row, site, pid, sweep), U);
-          int a = 0, b = ns - 1;  // smallest index with prefix > x
+          int a = 0, b = n_e - 1;  // smallest index with prefix > x
           while (a < b) {
             const int mid = (a + b) >> 1;
             if (s_pref[mid] > x)
@@ -432,7 +450,7 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
             else
               a = mid + 1;
           }
-          res = s_k[a];
+          res = (fk && a == ns) ? PCLEAN_CHOICE_NEW : s_k[a];
         }
         draws_out[(size_t)to * draw_is] = res;
       }
@@ -443,12 +461,15 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
 
 int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const FastRootDev& fr, uint64_t seed,
                           uint32_t sweep, uint32_t site, int n_draws, double* lse_out, int32_t* draws_out,
-                          int32_t* overflow_flag, unsigned int* overflow_count, int32_t* overflow_list) {
+                          int32_t* overflow_flag, unsigned int* overflow_count, int32_t* overflow_list, const ChildrenDev* ch) {
   if (it.n <= 0) return PCLEAN_OK;
   if (n_draws > 1) return pclean_fail(ctx, PCLEAN_ERR_ARG, "evidence-set option lists draw at most once per item");
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
   const int wgs = std::min(256 * 8, it.n);
-  hipLaunchKernelGGL(ev_leaf_block_kernel, dim3(wgs), dim3(EV_T), 0, ctx->stream, nd, dn, it, fr, seed, sweep, site, n_draws,
+  if ((nd.kind == PCLEAN_NODE_FK) != (ch != nullptr))
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "evidence-set scan: a reference slot comes with its children's marginals, an option list without");
+  const ChildrenDev none{};
+  hipLaunchKernelGGL(ev_leaf_block_kernel, dim3(wgs), dim3(EV_T), 0, ctx->stream, nd, dn, it, ch ? *ch : none, fr, seed, sweep, site, n_draws,
                      lse_out, draws_out, overflow_flag, overflow_count, overflow_list);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;

@@ -767,7 +767,12 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
   if (!fast_tried && !scores_out && !snew_override && !ctx->force_generic && !nd.g.on && !ctx->prior_mode && !small_lse) {
     if (!il.ev_lo)
       fast = try_fast_root(ctx, block_id, node_id, fr);
-    else if (n.kind == PCLEAN_NODE_LEAF && n_draws <= 1 && !getenv("PCLEAN_NO_FAST_EV"))
+    // option lists, and since round 6 reference slots — those only for launches of >= 1024 items (a one-batch class sweep:
+    // the latent Places re-choosing their County, 20 ms -> 1.6 ms): the slot's candidate-compact tables have to be rebuilt
+    // after every commit that wrote the referred table's columns (measured on the Hospital sub-batches of 333 rows:
+    // 0.32 ms of rebuild per call against the 0.29 ms of generic enumeration it would replace)
+    else if ((n.kind == PCLEAN_NODE_LEAF || (il.n >= 1024 && !getenv("PCLEAN_NO_FAST_EV_SLOTS"))) && n_draws <= 1 &&
+             !getenv("PCLEAN_NO_FAST_EV"))
       fast_ev = try_fast_root(ctx, block_id, node_id, fr, true);
     if (fast < 0) return fast;
     if (fast_ev < 0) return fast_ev;
@@ -922,7 +927,8 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
   } else {
     {
       ProfScope ps(ctx, "evidence_option_scan");
-      rc = pclean_launch_ev_leaf(ctx, nd, it, fr, seed, sweep, site, n_draws, lse_out, draws_out, oflag, over_count, over_list);
+      rc = pclean_launch_ev_leaf(ctx, nd, it, fr, seed, sweep, site, n_draws, lse_out, draws_out, oflag, over_count, over_list,
+                                 n.kind == PCLEAN_NODE_FK ? &ch : nullptr);
     }
     if (!rc && ev_list_mode) {
       ProfScope ps2(ctx, "overflow_rerun");

@@ -625,30 +625,39 @@ class Trace:
 
     @staticmethod
     def _py_prepare(counts):
-        """The count-only pieces of pitman_yor_score (shared by the three evaluations of one hyper-parameter move)."""
-        counts = np.asarray(counts, dtype=np.float64)
-        n_obj = np.arange(1, counts.size + 1, dtype=np.float64)
-        before = np.concatenate([[0.0], np.cumsum(counts)[:-1]])
-        big = counts > 1
-        c, b = counts[big], before[big]
-        return counts.size, n_obj, before, c, b
+        """The count-only pieces of pitman_yor_score (shared by the three evaluations of one hyper-parameter move):
+        number of clusters K, number of customers N, and the counts-of-counts of the clusters with more than one customer
+        (a table of 10^4 latent rows holds a few hundred distinct counts)."""
+        counts = np.asarray(counts, dtype=np.int64)
+        big = counts[counts > 1]
+        c, h = np.unique(big, return_counts=True) if big.size else (np.zeros(0, np.int64), np.zeros(0, np.int64))
+        return int(counts.size), float(counts.sum()), c.astype(np.float64), h.astype(np.float64)
 
     @staticmethod
     def _py_score_prepared(strength, discount, prep):
+        """trace.jl:65-78 in closed form, O(number of DISTINCT counts).  The reference walks the clusters in table order:
+        cluster j (1-based) starts with log(j d + s) - log(n + s) and its i-th join adds log(i - d) - log(n + i + s), n = the
+        customers before it.  The denominators are log(n' + s) for n' = 0 .. N-1, each exactly once whatever the order:
+        lgamma(N + s) - lgamma(s).  The joins of a cluster of size c: lgamma(c - d) - lgamma(1 - d), by counts-of-counts.
+        The cluster starts: sum_j log(j d + s) = K log d + lgamma(K + 1 + s/d) - lgamma(1 + s/d) (d > 0), K log s (d = 0) —
+        summed term by term when s/d is so large that the two log-gammas cancel badly."""
         from scipy.special import gammaln
-        size, n_obj, before, c, b = prep
-        if size == 0:
+        K, N, c, h = prep
+        if K == 0:
             return 0.0
-        lp = np.sum(np.log(n_obj * discount + strength) - np.log(before + strength))
-        lp += np.sum(gammaln(c - discount) - gammaln(1.0 - discount))
-        lp -= np.sum(gammaln(b + c + strength) - gammaln(b + 1.0 + strength))
+        if discount > 0.0 and strength / discount < 1e6:
+            r = strength / discount
+            lp = K * np.log(discount) + float(gammaln(K + 1.0 + r) - gammaln(1.0 + r))
+        else:
+            lp = float(np.sum(np.log(np.arange(1, K + 1, dtype=np.float64) * discount + strength)))
+        if c.size:
+            lp += float(np.sum(h * (gammaln(c - discount) - gammaln(1.0 - discount))))
+        lp -= float(gammaln(N + strength) - gammaln(strength))
         return float(lp)
 
     @staticmethod
     def pitman_yor_score(strength, discount, counts):
-        """trace.jl:65-78, vectorised (O(K)): counts in table order (cluster j is the j-th object).  The joins of
-        a cluster of size c that started after `before` customers, sum_{i=1}^{c-1} log(i - d) - log(before + i + s),
-        are written with log-gamma differences."""
+        """trace.jl:65-78 (the score does not depend on the order of the clusters: see _py_score_prepared)."""
         return Trace._py_score_prepared(strength, discount, Trace._py_prepare(counts))
 
     def resample_py_params(self, t):
