@@ -182,3 +182,92 @@ def test_lowering_refuses_what_it_cannot_state():
     units[0] = Cubic()
     with pytest.raises(NotImplementedError):
         L.lower(rm, rq, {c: list(dirty[c]) for c in rq.columns})
+
+
+# ---- the Julia text itself (never executed here: no Julia in the image) -------------------------------------------------------
+JL = os.path.join(ROOT, "julia", "PCleanHIP.jl")
+
+
+def _julia_functions(text):
+    import re
+    names = set(re.findall(r"^\s*function\s+([A-Za-z_][A-Za-z_0-9]*!?)", text, flags=re.M))
+    names |= set(re.findall(r"^([A-Za-z_][A-Za-z_0-9]*!?)\([^=\n]*\)\s*=", text, flags=re.M))
+    return names
+
+
+def test_julia_section_states_every_function_of_the_transliteration():
+    """tests/julia_lowering.py and section 3 of PCleanHIP.jl are the same algorithm function by function: every function of the
+    Python walk exists under the same name (with Julia's `!` where it mutates) in the Julia file"""
+    import inspect
+    text = open(JL).read()
+    jl = _julia_functions(text)
+    mine = [n for n, f in inspect.getmembers(L, inspect.isfunction) if f.__module__ == L.__name__]
+    assert len(mine) >= 25
+    missing = [n for n in mine if n not in jl and n + "!" not in jl]
+    assert not missing, missing
+    # the guards the Python walk raises exist as error(...) texts on the Julia side
+    for msg in ("one value of this slot, at most one of an earlier slot", "context must come from an earlier slot",
+                "keyed atoms need their key attribute observed directly", "only linear Transformations",
+                "a block without a reference slot may only hold MaybeSwap observations", "exactly one candidate-side index value may be unobserved",
+                "at most two enumerated own choices", "one Gaussian observation per block"):
+        assert msg in text and msg in open(L.__file__).read(), msg
+
+
+def test_julia_ccalls_name_exported_symbols_only():
+    """every `ccall((:pclean_..., lib)` of the Julia file names a function include/pclean_hip.h declares"""
+    import re
+    text = open(JL).read()
+    header = open(os.path.join(ROOT, "include", "pclean_hip.h")).read()
+    syms = set(re.findall(r"ccall\(\(:([a-z_0-9]+),\s*lib\)", text))
+    assert len(syms) >= 30
+    declared = set(re.findall(r"\b(pclean_[a-z_0-9]+)\s*\(", header))
+    assert syms <= declared, sorted(syms - declared)
+
+
+def test_julia_text_is_balanced():
+    """cheap syntax hygiene for a file that cannot be parsed here: brackets balance outside strings and comments, and every
+    block opener at the start of a statement has its `end`"""
+    import re
+    text = open(JL).read()
+    text = re.sub(r'"(?:\\.|[^"\\])*"', '""', text, flags=re.S)   # strings (docstrings may span lines)
+    text = re.sub(r"'(?:\\.|[^'\\])'", "''", text)              # chars
+    depth = {"(": 0, "[": 0, "{": 0}
+    close = {")": "(", "]": "[", "}": "{"}
+    for ln, line in enumerate(text.split("\n"), start=1):
+        if re.match(r"^(function |end$|struct |mutable struct )", line):   # a top-level statement starts with everything closed
+            assert all(v == 0 for v in depth.values()), (ln, line, depth)
+        s = line.split("#")[0]
+        for ch in s:
+            if ch in depth:
+                depth[ch] += 1
+            elif ch in close:
+                depth[close[ch]] -= 1
+                assert depth[close[ch]] >= 0, (ln, line)
+    assert depth == {"(": 0, "[": 0, "{": 0}, depth
+
+
+def test_julia_block_keywords_balance():
+    """function / for / if / while / begin / struct / let / try / do / module at bracket depth 0 (comprehension `for`s and index
+    `end`s live inside brackets) pair up with `end`, and every top-level definition starts with all blocks closed"""
+    import re
+    text = open(JL).read()
+    text = re.sub(r'"(?:\\.|[^"\\])*"', '""', text, flags=re.S)
+    text = re.sub(r"'(?:\\.|[^'\\])'", "''", text)
+    tok = re.compile(r"[A-Za-z_][A-Za-z_0-9!]*|[\(\)\[\]\{\}]")
+    depth, stack = 0, []
+    for ln, line in enumerate(text.split("\n"), start=1):
+        line = line.split("#")[0]
+        if re.match(r"^(function |struct |mutable struct )", line):
+            assert [t for t, _ in stack] == ["module"], (ln, stack)
+        for m in tok.finditer(line):
+            t = m.group(0)
+            if t in "([{":
+                depth += 1
+            elif t in ")]}":
+                depth -= 1
+            elif depth == 0 and t in ("function", "for", "if", "while", "begin", "struct", "let", "try", "do", "module", "quote"):
+                stack.append((t, ln))
+            elif depth == 0 and t == "end":
+                assert stack, ("end without opener", ln)
+                stack.pop()
+    assert not stack, stack
