@@ -474,6 +474,22 @@ def main():
             f"step as 1 window {ms_1:.2f} ms, as 2 half windows {ms_2:.2f} ms -> fixed {max(ms_2 - ms_1, 0):.2f} ms, "
             f"row-proportional {max(2 * ms_1 - ms_2, 0):.2f} ms per step and rank")
 
+    # ---- several ranks: what every rank's exchange moved, how often its device commit was refused (rank 0 prints them) ------
+    per_rank = None
+    if comm.dist is not None:
+        mine = {"rank": rank, "rows": int(shard_bounds(args.rows, rank, world)[1] - shard_bounds(args.rows, rank, world)[0]),
+                "device_commits": (eng._dc or {}).get("commits"), "device_commit_refusals": (eng._dc or {}).get("fallbacks"),
+                "step_fixed_ms": max(ms_2 - ms_1, 0.0), "step_proportional_ms": max(2 * ms_1 - ms_2, 0.0)}
+        if getattr(eng, "_dev_comm", False):
+            cs = eng.hip.comm_stats()
+            mine.update({"allgather_calls": cs["allgather_calls"], "allgather_bytes_sent_last": cs["allgather_bytes_per_rank_last"],
+                         "allgather_bytes_received_last": cs["allgather_bytes_per_rank_last"] * world,
+                         "allgather_device_ms_mean": cs["allgather_device_ms"] / max(cs["allgather_calls"], 1),
+                         "allreduce_calls": cs["allreduce_calls"], "allreduce_bytes_last": cs["allreduce_bytes_last"],
+                         "allreduce_device_ms_mean": cs["allreduce_device_ms"] / max(cs["allreduce_calls"], 1)})
+        per_rank = [None] * world
+        comm.dist.all_gather_object(per_rank, mine)
+
     # ---- per-phase profile of one more (untimed) sweep ----------------------------------------------------------
     eng.hip.set_profiling(True)
     step(args.warmup + args.steps)
@@ -559,7 +575,21 @@ def main():
                        # refreshes) vs what does: from the same sweep run as two half windows (2 x fixed + proportional)
                        "step_fixed_ms": max(ms_2 - ms_1, 0.0), "step_proportional_ms": max(2 * ms_1 - ms_2, 0.0),
                        "ms_per_step_2_windows": ms_2, "ms_per_step_1_window_same_loop": ms_1, "fixed_split_sweeps": n_half,
-                       "collective_ms_fused_allreduce": coll_ms},
+                       "collective_ms_fused_allreduce": coll_ms,
+                       # several ranks (also PCLEAN_FORCE_DIST=1 on one): per rank its shard, refused device commits, the fixed
+                       # capacity all-gather of moved rows + new-row records (bytes of the last one, mean device time from HIP events
+                       # on the library's stream) and the fused all-reduce of the delta counts
+                       "per_rank": per_rank,
+                       # the decomposition a strong-scaling number comes with: on N ranks a step costs fixed + collectives +
+                       # proportional / N; `--scaling weak` in a separate invocation measures rows-per-rank fixed instead
+                       "scaling_model": {"fixed_ms": max(ms_2 - ms_1, 0.0), "proportional_ms": max(2 * ms_1 - ms_2, 0.0),
+                                         "collectives_device_ms": (sum((r or {}).get(k, 0.0) or 0.0 for r in per_rank[:1]
+                                                                       for k in ("allgather_device_ms_mean", "allreduce_device_ms_mean"))
+                                                                   if per_rank else None),
+                                         "projected_speedup_at": {str(n): ms_1 / (max(ms_2 - ms_1, 0.0) + max(2 * ms_1 - ms_2, 0.0) / n)
+                                                                  for n in (2, 4, 8)} if ms_1 > 0 and world == 1 else None,
+                                         "note": "one-GPU split of the same sweep run as two half windows; the projection leaves the "
+                                                 "collectives out (two small ones per step) and is printed for world == 1 only"}},
             "f1": acc["f1"], "accuracy": acc,
             "table_build": {"seconds": eng.pair_build_s, "pairs": eng.pair_count, "dp_cells": eng.pair_cells,
                             "dp_cells_per_s": eng.pair_cells / max(eng.pair_build_s, 1e-9),

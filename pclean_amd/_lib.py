@@ -571,6 +571,14 @@ class HipContext:
     def comm_destroy(self):
         check(self.h, self.lib.pclean_comm_destroy(self.h), "pclean_comm_destroy")
 
+    def comm_stats(self):
+        """what this context's collectives moved: calls, bytes of the last one, device milliseconds of all of them"""
+        out = np.zeros(8, dtype=np.int64)
+        check(self.h, self.lib.pclean_comm_get_stats(self.h, _p(out, C.c_int64)), "pclean_comm_get_stats")
+        return {"allgather_calls": int(out[0]), "allgather_bytes_per_rank_last": int(out[1]), "allgather_device_ms": out[2] / 1e6,
+                "allreduce_calls": int(out[3]), "allreduce_bytes_last": int(out[4]), "allreduce_device_ms": out[5] / 1e6,
+                "n_ranks": int(out[6]), "rank": int(out[7])}
+
     def get_moved(self, block_id):
         n = C.c_int32()
         check(self.h, self.lib.pclean_get_moved(self.h, C.c_int32(block_id), C.byref(n), None, None), "pclean_get_moved")

@@ -141,14 +141,60 @@ int pclean_comm_allreduce_stats_queue(pclean_ctx* ctx, int32_t n_tables, const i
   size_t total = 0;
   return allreduce_stats_queue(ctx, n_tables, table_ids, local_is_zero, nullptr, &total);
 }
+// ---- what the collectives moved and how long they took on the device -------------------------------------------------
+// which = 0: all-gather, 1: all-reduce.  fold: the pending pair's elapsed time goes into the total (the collective it brackets
+// was queued a whole sweep ago when the next one arrives: the wait is not one)
+static void comm_stats_fold(pclean_ctx* ctx, int which) {
+  pclean_ctx::CommStats& cs = ctx->comm_stats;
+  bool& pending = which == 0 ? cs.ag_pending : cs.ar_pending;
+  if (!pending) return;
+  float ms = 0.0f;
+  if (hipEventSynchronize(cs.ev[2 * which + 1]) == hipSuccess &&
+      hipEventElapsedTime(&ms, cs.ev[2 * which], cs.ev[2 * which + 1]) == hipSuccess)
+    (which == 0 ? cs.ag_us : cs.ar_us) += 1e3 * (double)ms;
+  pending = false;
+}
+static void comm_stats_begin(pclean_ctx* ctx, int which) {
+  pclean_ctx::CommStats& cs = ctx->comm_stats;
+  comm_stats_fold(ctx, which);
+  for (int i = 0; i < 2; ++i)
+    if (!cs.ev[2 * which + i] && hipEventCreate(&cs.ev[2 * which + i]) != hipSuccess) cs.ev[2 * which + i] = nullptr;
+  if (cs.ev[2 * which] && cs.ev[2 * which + 1]) (void)hipEventRecord(cs.ev[2 * which], ctx->stream);
+}
+static void comm_stats_end(pclean_ctx* ctx, int which) {
+  pclean_ctx::CommStats& cs = ctx->comm_stats;
+  if (cs.ev[2 * which] && cs.ev[2 * which + 1] && hipEventRecord(cs.ev[2 * which + 1], ctx->stream) == hipSuccess)
+    (which == 0 ? cs.ag_pending : cs.ar_pending) = true;
+}
+extern "C" int pclean_comm_get_stats(pclean_ctx* ctx, int64_t out[8]) {
+  if (!ctx || !out) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_comm_get_stats: bad arguments");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  comm_stats_fold(ctx, 0);
+  comm_stats_fold(ctx, 1);
+  const pclean_ctx::CommStats& cs = ctx->comm_stats;
+  out[0] = (int64_t)cs.ag_calls;
+  out[1] = (int64_t)cs.ag_bytes_last;
+  out[2] = (int64_t)(cs.ag_us * 1e3);  // ns
+  out[3] = (int64_t)cs.ar_calls;
+  out[4] = (int64_t)cs.ar_elems_last * 8;
+  out[5] = (int64_t)(cs.ar_us * 1e3);
+  out[6] = ctx->comm_ranks;
+  out[7] = ctx->comm_rank;
+  return PCLEAN_OK;
+}
+
 // all-gather of words_per_rank int32 words per rank (rank r's words land at recv + r * words_per_rank); queued, no sync
 int pclean_comm_allgather_i32(pclean_ctx* ctx, const int32_t* send, int32_t* recv, size_t words_per_rank) {
   if (!ctx->rccl_comm) return pclean_fail(ctx, PCLEAN_ERR_STATE, "all-gather: call pclean_comm_init first");
   Rccl* r = rccl(ctx);
   if (!r) return PCLEAN_ERR_STATE;
   if (!r->all_gather) return pclean_fail(ctx, PCLEAN_ERR_STATE, "ncclAllGather missing in librccl.so");
+  comm_stats_begin(ctx, 0);
   const int rc = r->all_gather(send, recv, words_per_rank, kNcclInt32, ctx->rccl_comm, ctx->stream);
   if (rc) return rccl_fail(ctx, r, "ncclAllGather", rc);
+  comm_stats_end(ctx, 0);
+  ctx->comm_stats.ag_calls += 1;
+  ctx->comm_stats.ag_bytes_last = (uint64_t)words_per_rank * 4u;
   return PCLEAN_OK;
 }
 static int allreduce_stats_queue(pclean_ctx* ctx, int32_t n_tables, const int32_t* table_ids, int32_t local_is_zero, int64_t* out,
@@ -177,8 +223,12 @@ static int allreduce_stats_queue(pclean_ctx* ctx, int32_t n_tables, const int32_
                          ctx->stats_pack.p + off);
     off += (size_t)t.n_rows;
   }
+  comm_stats_begin(ctx, 1);
   const int rc = r->all_reduce(ctx->stats_pack.p, ctx->stats_pack.p, total, kNcclInt64, kNcclSum, ctx->rccl_comm, ctx->stream);
   if (rc) return rccl_fail(ctx, r, "ncclAllReduce", rc);
+  comm_stats_end(ctx, 1);
+  ctx->comm_stats.ar_calls += 1;
+  ctx->comm_stats.ar_elems_last = (uint64_t)total;
   off = 0;
   for (int i = 0; i < n_tables; ++i) {
     CandTable& t = ctx->cand[table_ids[i]];
@@ -199,5 +249,11 @@ extern "C" int pclean_comm_destroy(pclean_ctx* ctx) {
   ctx->rccl_comm = nullptr;
   ctx->comm_ranks = 0;
   ctx->comm_rank = 0;
+  for (hipEvent_t& e : ctx->comm_stats.ev)
+    if (e) {
+      (void)hipEventDestroy(e);
+      e = nullptr;
+    }
+  ctx->comm_stats.ag_pending = ctx->comm_stats.ar_pending = false;
   return PCLEAN_OK;
 }

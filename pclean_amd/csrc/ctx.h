@@ -225,6 +225,14 @@ struct pclean_ctx {
   void* rccl_comm = nullptr;    // ncclComm_t of pclean_comm_init (comm.hip)
   DevBuf<int64_t> stats_pack;   // pclean_allreduce_stats_fused: the tables' delta counts as one vector
   int32_t comm_ranks = 0, comm_rank = 0;
+  // what the collectives of this context moved (pclean_comm_get_stats): HIP events around the last all-gather / all-reduce on
+  // the library's stream, folded into the totals when the next one is queued or the statistics are read
+  struct CommStats {
+    uint64_t ag_calls = 0, ag_bytes_last = 0, ar_calls = 0, ar_elems_last = 0;
+    double ag_us = 0.0, ar_us = 0.0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // all-gather begin / end, all-reduce begin / end
+    bool ag_pending = false, ar_pending = false;
+  } comm_stats;
 };
 
 inline int pclean_fail(pclean_ctx* ctx, int code, const char* fmt, ...) {

@@ -610,6 +610,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
             s->gate_timed = true;
           }
           unsigned int* need_ctr = fresh_counter(ctx);
+          if (!need_ctr) return pclean_fail(ctx, PCLEAN_ERR_HIP, "counter bank: device alloc failed");
           hipLaunchKernelGGL(compact_new_kernel, grid1(ng), dim3(256), 0, ctx->stream, (size_t)ng, flag, 1, need_ctr, list_g,
                              nullptr);
           PCLEAN_READ_COUNT(ctx, need_ctr, &n_need);
@@ -676,6 +677,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
         rc = pclean_launch_gate(ctx, nd, it, gt, flag);
         if (rc) return rc;
         unsigned int* need_ctr = fresh_counter(ctx);
+        if (!need_ctr) return pclean_fail(ctx, PCLEAN_ERR_HIP, "counter bank: device alloc failed");
         hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, flag, 1, need_ctr, list,
                            nullptr);
         PCLEAN_READ_COUNT(ctx, need_ctr, &n_need);
@@ -1646,6 +1648,7 @@ static int eval_node_lse(pclean_ctx* ctx, int block_id, int node_id, const ItemL
   if (!flag || !list || s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   hipLaunchKernelGGL(memo_lookup_kernel, grid1(N), dim3(256), 0, ctx->stream, N, kc, il.row, il.ctx, md, lse_out, flag);
   unsigned int* miss_ctr = fresh_counter(ctx);
+  if (!miss_ctr) return pclean_fail(ctx, PCLEAN_ERR_HIP, "counter bank: device alloc failed");
   hipLaunchKernelGGL(compact_new_kernel, grid1(N), dim3(256), 0, ctx->stream, (size_t)N, flag, 1, miss_ctr, list, nullptr);
   unsigned int n_miss = 0;
   PCLEAN_READ_COUNT(ctx, miss_ctr, &n_miss);
@@ -1736,6 +1739,7 @@ int sample_children(pclean_ctx* ctx, int block_id, int node_id, const ItemList& 
     if (cn.kind == PCLEAN_NODE_FK && cn.n_children > 0) {
       // rows of this child that were themselves proposed as NEW
       unsigned int* new_ctr = fresh_counter(ctx);
+      if (!new_ctr) return pclean_fail(ctx, PCLEAN_ERR_HIP, "counter bank: device alloc failed");
       hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, draws, 0, new_ctr, nullptr,
                          nullptr);
       unsigned int cnt = 0;
@@ -1748,8 +1752,9 @@ int sample_children(pclean_ctx* ctx, int block_id, int node_id, const ItemList& 
         int32_t* org = scratch<int32_t>(ctx, cnt);
         int32_t* sub_excl = scratch<int32_t>(ctx, cnt);
         if (!list || !row || !cx || !part || !org || !sub_excl) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-        hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, draws, 1,
-                           fresh_counter(ctx), list, nullptr);
+        unsigned int* list_ctr = fresh_counter(ctx);
+        if (!list_ctr) return pclean_fail(ctx, PCLEAN_ERR_HIP, "counter bank: device alloc failed");
+        hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, draws, 1, list_ctr, list, nullptr);
         int32_t* evl = il.ev_lo ? scratch<int32_t>(ctx, cnt) : nullptr;
         int32_t* evh = il.ev_lo ? scratch<int32_t>(ctx, cnt) : nullptr;
         int32_t* rng = il.rng_row ? scratch<int32_t>(ctx, cnt) : nullptr;

@@ -1011,6 +1011,7 @@ void pclean_sweep_state_free(pclean_ctx* ctx) {
   s->dummy_dp.release();
   s->dummy_ctr.release();
   s->over_ctr.release();
+  for (auto& b : s->more_banks) b.release();
   for (auto e : s->prof_ev) (void)hipEventDestroy(e);
   if (s->ev0) (void)hipEventDestroy(s->ev0);
   if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -1822,6 +1823,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       }
       HIPCHK(ctx, hipMemsetAsync(r.lse.p, 0, (size_t)N * sizeof(double), ctx->stream));
       n_new_ctr = fresh_counter(ctx);
+      if (!n_new_ctr) return pclean_fail(ctx, PCLEAN_ERR_HIP, "counter bank: device alloc failed");
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), pu_stage_bytes, ctx->stream, N, P, r.draws.p, r.lse.p,
                          (const int32_t*)nullptr, (const int32_t*)nullptr, (const double*)nullptr, cur_b, r.pchoice.p,
                          s->w.p, n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0,
@@ -1872,6 +1874,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         { const int rcl = lazy_draws(); if (rcl) return rcl; }
       } else {
       n_new_ctr = fresh_counter(ctx);
+      if (!n_new_ctr) return pclean_fail(ctx, PCLEAN_ERR_HIP, "counter bank: device alloc failed");
       // (the first block of several: its weights are the block's log marginal for every particle of a row — not stored)
       const bool skip_w = bi == 0 && w_by_first_block && bi < n_blocks - 1 && !split_final && !emit_rows && !no_w_uni;
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), pu_stage_bytes, ctx->stream, N, P, r.draws.p, r.lse.p,
@@ -1985,6 +1988,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         { const int rcl = lazy_draws(); if (rcl) return rcl; }
       } else {
       n_new_ctr = fresh_counter(ctx);
+      if (!n_new_ctr) return pclean_fail(ctx, PCLEAN_ERR_HIP, "counter bank: device alloc failed");
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), 0, ctx->stream, N, P, (const int32_t*)nullptr,
                          (const double*)nullptr, slot_item, draws_item, lse_item, cur_b, r.pchoice.p, s->w.p,
                          n_new_ctr, r.new_slots.p, r.pnewpos.p, (w_by_first_block && bi == 0) ? 1 : 0, emit_rows, split_final ? 1 : 0, 0,

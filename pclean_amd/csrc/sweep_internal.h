@@ -89,9 +89,20 @@ static unsigned int* fresh_counter(pclean_ctx* ctx) {
   SweepState* s = st(ctx);
   if (!s->over_ctr.p) return nullptr;
   unsigned int* bank = s->over_ctr.p + OVER_SLOTS + STAT_WORDS;
-  if (s->bank_used < CTR_BANK) return bank + s->bank_used++;
-  (void)hipMemsetAsync(bank + CTR_BANK - 1, 0, sizeof(unsigned int), ctx->stream);
-  return bank + CTR_BANK - 1;
+  // (PCLEAN_CTR_BANK: a smaller first bank, so that tests reach the growth path below)
+  static const int first = [] {
+    const char* e = getenv("PCLEAN_CTR_BANK");
+    return e ? std::max(1, std::min(atoi(e), CTR_BANK)) : CTR_BANK;
+  }();
+  if (s->bank_used < first) return bank + s->bank_used++;
+  // more than CTR_BANK counted launches in one call (hundreds of nested option lists x re-runs): further banks, allocated
+  // once and zeroed at their first use in a call; a counter is never handed out twice within a call
+  const int idx = s->bank_used - first, b = idx / CTR_BANK, o = idx % CTR_BANK;
+  while ((int)s->more_banks.size() <= b) s->more_banks.emplace_back();
+  if (s->more_banks[b].alloc(CTR_BANK)) return nullptr;  // (callers report the allocation failure)
+  if (o == 0 && hipMemsetAsync(s->more_banks[b].p, 0, CTR_BANK * sizeof(unsigned int), ctx->stream) != hipSuccess) return nullptr;
+  ++s->bank_used;
+  return s->more_banks[b].p + o;
 }
 
 // ---- per-phase profile (pclean_set_profiling): HIP events on the library's stream around groups of launches

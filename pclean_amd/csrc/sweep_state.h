@@ -4,6 +4,7 @@
 #include <functional>
 #include <map>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "ctx.h"
@@ -136,6 +137,7 @@ struct SweepState {
   bool scan_stats_used = false;
   int bank_used = 0;               // counters of the bank (the tail of over_ctr) handed out by the running call
   DevBuf<unsigned int> over_ctr;   // [OVER_SLOTS + STAT_WORDS]: the tail = scan statistics of the timed root launch
+  std::deque<DevBuf<unsigned int>> more_banks;  // further counter banks of a call that used up the first (fresh_counter)
   struct OverRec { int block, node, n_items; bool time_it, leaf; int min_items; };  // min_items: from how many items on the "does the pre-filter pay" rule applies
   std::vector<OverRec> over_rec;
   // pclean_sweep_latent: the option lists of a latent row are independent given its evidence — each is evaluated on one

@@ -73,6 +73,8 @@ def test_sweeps_are_bit_identical_across_runs_and_paths(capsys):
         "round-5 paths": {"PCLEAN_NO_LAZY_DRAWS": "1", "PCLEAN_NO_UNIFORM_W": "1", "PCLEAN_NO_SMALL_GENERIC": "1",
                           "PCLEAN_NO_FUSED_CTX_ITEMS": "1"},
         "generic kernels": {"PCLEAN_NO_DEDUP": "1", "PCLEAN_NO_GATE": "1", "PCLEAN_NO_MEMO": "1"},
+        # a first counter bank of 2 slots: every later counted launch takes its counter from a grown bank (fresh_counter)
+        "counter bank exhausted": {"PCLEAN_CTR_BANK": "2"},
     }
     digests = {}
     for name, env in variants.items():
