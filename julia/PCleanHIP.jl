@@ -182,7 +182,7 @@ set_cur_locals(c, block, locals::Matrix{Int32}) = GC.@preserve locals check(c,
 # sweep): tables uploaded once with spare rows, their allocation state and the rows' referents stay in HBM ----------------
 struct CCommitSlot; table_id::Int32; n_hw::Int32; n_free::Int32; cols_changed::Int32; created::Int32; deleted::Int32
                     total::Int64; live::Int64; max_count::Int64; end
-struct CCommitSummary; fallback::Int32; n_changed::Int32; n_slots::Int32; pad::Int32
+struct CCommitSummary; fallback::Int32; n_changed::Int32; n_slots::Int32; stats_reduced::Int32
                        n_records::NTuple{16,Int32}; n_distinct::NTuple{16,Int32}; slot::NTuple{16,CCommitSlot}; end
 prepare(c, ev_blocks::Integer=0) = check(c, ccall((:pclean_prepare, lib), Cint, (Ptr{Cvoid}, UInt32), c.h, ev_blocks))
 function commit_enable(c, n_blocks)                                                                      # false: this plan commits on the host

@@ -74,7 +74,7 @@ class CommitSlot(C.Structure):
 
 
 class CommitSummary(C.Structure):
-    _fields_ = [("fallback", C.c_int32), ("n_changed", C.c_int32), ("n_slots", C.c_int32), ("pad", C.c_int32),
+    _fields_ = [("fallback", C.c_int32), ("n_changed", C.c_int32), ("n_slots", C.c_int32), ("stats_reduced", C.c_int32),
                 ("n_records", C.c_int32 * 16), ("n_distinct", C.c_int32 * 16), ("slot", CommitSlot * 16)]
 
 

@@ -627,20 +627,13 @@ static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_
   }
   HIPCHK(ctx, hipMemcpyAsync(c->d_blocks.p, c->h_blocks, sizeof(PccBlock) * c->n_plans, hipMemcpyHostToDevice, ctx->stream));
   const PccBlock* commit_blocks = c->d_blocks.p;
+  bool stats_reduced = false;
   int cur_rows = N;  // rows pcc_cur_kernel's grid is sized for
   if (dist) {
-    // 1. the delta reference counts of the root tables, summed over the ranks (in place)
-    int32_t tids[PCC_MAX_BLOCKS];
-    int n_t = 0;
-    for (int p = 0; p < c->n_plans; ++p) {
-      const int t = ctx->block[c->plan_block[p]].nodes[0].table;
-      bool seen = false;
-      for (int k = 0; k < n_t; ++k) seen |= tids[k] == t;
-      if (!seen) tids[n_t++] = t;
-    }
-    int rc = pclean_comm_allreduce_stats_queue(ctx, n_t, tids, local_empty ? 1 : 0);
-    if (rc) return rc;
-    // 2. this rank's lists -> its segment; all-gather; the concatenated lists
+    // Everything that can fail on ONE rank alone (allocations, layout) comes first: once the first collective is queued a
+    // rank that returned early would leave the others waiting in the next one.  (A failure after this point is an RCCL /
+    // HIP error: the communicator is unusable on every rank anyway.)
+    // 1. this rank's lists -> its segment (layout + buffers)
     PccSegLayout L{};
     L.n_plans = c->n_plans;
     int32_t off = 0;
@@ -716,6 +709,20 @@ static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_
     }
     HIPCHK(ctx, hipMemcpyAsync(c->d_blocks_g.p, c->h_blocks_g, sizeof(PccBlock) * c->n_plans, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(c->d_res.p, 0, sizeof(PccResult), ctx->stream));
+    // 2. the delta reference counts of the root tables, summed over the ranks (in place): from here on the device buffers
+    //    hold the SUMS — a refused commit tells its caller so (summary.stats_reduced), the host exchange must not sum again
+    int32_t tids[PCC_MAX_BLOCKS];
+    int n_t = 0;
+    for (int p = 0; p < c->n_plans; ++p) {
+      const int t = ctx->block[c->plan_block[p]].nodes[0].table;
+      bool seen = false;
+      for (int k = 0; k < n_t; ++k) seen |= tids[k] == t;
+      if (!seen) tids[n_t++] = t;
+    }
+    int rc = pclean_comm_allreduce_stats_queue(ctx, n_t, tids, local_empty ? 1 : 0);
+    if (rc) return rc;
+    stats_reduced = true;
+    // 3. all-gather of the segments; the concatenated lists
     hipLaunchKernelGGL(pcc_pack_kernel, dim3(64, c->n_plans), dim3(256), 0, ctx->stream, L, c->d_blocks.p, local_empty ? 1 : 0,
                        c->seg.p);
     rc = pclean_comm_allgather_i32(ctx, c->seg.p, c->seg_all.p, (size_t)L.seg_words);
@@ -774,6 +781,7 @@ static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_
   out->fallback = c->h_res->fallback;
   out->n_changed = c->h_res->n_changed;
   out->n_slots = c->n_slots;
+  out->stats_reduced = stats_reduced ? 1 : 0;
   for (int p = 0; p < c->n_plans; ++p) {
     out->n_records[c->plan_block[p]] = c->h_res->n_records[p];
     out->n_distinct[c->plan_block[p]] = c->h_res->n_distinct[p];

@@ -457,7 +457,7 @@ class Engine:
             if not local_empty:
                 self.hip.sweep_fetch()
             # (several ranks: the delta reference counts in the device buffers are already summed over the ranks)
-            self._stats_reduced_on_device = dist
+            self._stats_reduced_on_device = bool(summ.stats_reduced)
             return None  # (a table about to outgrow its capacity gets more room at the next upload: upload_trace)
         if os.environ.get("PCLEAN_DEBUG_COMMIT"):
             print("[pclean] device commit: changed", summ.n_changed, "records", list(summ.n_records[:len(self.lw.blocks)]),
