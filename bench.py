@@ -560,7 +560,12 @@ def main():
                        "parallelism": f"rows sharded over {world} GPU(s)",
                        "init": f"the build's own initialize_trace from an empty trace (batches <= {args.init_batch})"
                                + ("" if args.no_full_iteration else " + 1 full run_inference iteration"),
-                       "init_s": init_s, "f1_after_init": acc_init["f1"], "full_iteration_ms": full_ms,
+                       "init_s": init_s, "f1_after_init": acc_init["f1"],
+                       "f1_reference": f"none at this setting: the +-0.5 pt band against the sequential references is tested with the "
+                                       f"product's default initialisation batches (<= 256 rows) on <= 50 000 rows "
+                                       f"(tests/test_gpu_f1_vs_sequential.py); this run initialises in batches <= {args.init_batch}, "
+                                       "and a larger initialisation batch moves F1 upwards (DESIGN.md §9) — the f1 below "
+                                       "is a sanity figure for the timed state, not a parity claim", "full_iteration_ms": full_ms,
                        "full_iteration_steady_ms": full_steady_ms, "prepare_ms": prepare_ms,
                        "device_ms_per_step": dev_ms / args.steps,
                        "commit": (("device-resident on every rank (pclean_commit_device_dist): delta counts all-reduced, moved rows and "

