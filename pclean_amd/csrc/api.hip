@@ -384,6 +384,10 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
   const bool keep_cols = !cols && (int64_t)n_rows * n_cols > 0;
   if (keep_cols && (!t.valid || t.is_options || t.n_rows != n_rows || t.n_cols != n_cols))
     return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_set_table: cols == NULL needs a previous upload of the same shape");
+  const bool same_shape = t.valid && !t.is_options && t.n_rows == n_rows && t.n_cols == n_cols;
+  const bool mirror_was_stale = t.h_mirror_stale;  // (a device commit moved the device columns on: h_cols is not what they hold)
+  const uint64_t prev_cols_version = t.cols_version;
+  int32_t upload_delta_n = -1;
   t.is_options = false;
   t.is_options_1col = false;
   t.n_used = 0;  // (pclean_commit_set_table_state tells)
@@ -418,12 +422,35 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
   // through the library's page-locked staging area (ctx.h: HostStage), on the library's stream, one wait at the end
   {
     const size_t b_cols = (n && !keep_cols) ? n * sizeof(int32_t) : 0, b_r = (size_t)n_rows * 8;
-    if (ctx->stage.grow(b_cols + 3 * b_r + 4 * 256)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "page-locked staging alloc failed");
+    if (ctx->stage.grow(b_cols + 3 * b_r + (size_t)n_rows / 2 + 8 * 256)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "page-locked staging alloc failed");
     ctx->stage.rewind();
     if (b_cols) {
       void* h = ctx->stage.take(b_cols);
       memcpy(h, cols, b_cols);
       HIPCHK(ctx, hipMemcpyAsync(t.cols.p, h, b_cols, hipMemcpyHostToDevice, ctx->stream));
+      // which rows differ from the previous upload of the same shape (the compact byte tables built from it are then
+      // refreshed for those rows alone: eval.hip, try_fast_root)
+      static const bool no_upload_delta = getenv("PCLEAN_NO_UPLOAD_DELTA") != nullptr;
+      if (same_shape && !mirror_was_stale && !no_upload_delta && t.h_cols.size() == n) {
+        std::vector<int32_t> rows;
+        const size_t limit = (size_t)n_rows / 8;
+        for (int k = 0; k < n_rows && rows.size() <= limit; ++k)
+          for (int c = 0; c < n_cols; ++c)
+            if (cols[(size_t)c * n_rows + k] != t.h_cols[(size_t)c * n_rows + k]) {
+              rows.push_back(k);
+              break;
+            }
+        if (rows.size() <= limit) {
+          upload_delta_n = (int32_t)rows.size();
+          if (upload_delta_n > 0) {
+            if (t.upload_delta_rows.alloc(rows.size())) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+            void* hr = ctx->stage.take(rows.size() * sizeof(int32_t));
+            memcpy(hr, rows.data(), rows.size() * sizeof(int32_t));
+            HIPCHK(ctx, hipMemcpyAsync(t.upload_delta_rows.p, hr, rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+          }
+        }
+      }
+      t.h_cols.assign(cols, cols + n);
     }
     dbg_c = dbg_ms();
     if (n_rows) {
@@ -448,7 +475,11 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
   t.version = ++g_pclean_version;
   if (!keep_cols) {
     t.cols_version = t.version;
-    t.cols_delta_n = -1;
+    t.cols_delta_n = upload_delta_n;
+    if (upload_delta_n >= 0) {
+      t.cols_delta_base = prev_cols_version;
+      t.cols_delta_rows = t.upload_delta_rows.p;
+    }
   }
   if (dbg_upload && dbg_ms() > 1.0)
     fprintf(stderr, "[pclean_set_table] table %d (%d x %d, cols %s): alloc %.2f, host logs %.2f, cols copy %.2f, rest %.2f ms\n", table_id,

@@ -114,6 +114,10 @@ struct CandTable {
   uint64_t cols_delta_base = 0;
   int32_t cols_delta_n = -1;
   const int32_t* cols_delta_rows = nullptr;
+  // ... or a re-upload of the same shape that differs from the previous one in a few rows (pclean_set_table compares with
+  // h_cols, the columns as last uploaded: a latent sub-batch's host commit creates / collects a handful of rows)
+  std::vector<int32_t> h_cols;
+  DevBuf<int32_t> upload_delta_rows;
   bool h_mirror_stale = false;  // the device arrays moved on without the host mirrors (pclean_commit_device)
   double h_lse = 0.0;         // options: log-sum of logp (+1e-9), valid for version h_lse_ver (eval.hip: subtree_ub)
   uint64_t h_lse_ver = 0;

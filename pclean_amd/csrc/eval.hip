@@ -311,10 +311,12 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
       // built from the columns as they were before the last device commit, which wrote a few rows: refresh those rows
       // (and the block minima), not the whole table
       ProfScope psd(ctx, "compact_table_update");
-      int rc = pclean_update_compact(ctx, pt.d.p, pt.n_obs, pt.n_lat, t.cols.p + (size_t)tm.cand_col * t.n_rows, pt.lat_len.p,
+      int rc = PCLEAN_OK;
+      if (t.cols_delta_n > 0)
+        rc = pclean_update_compact(ctx, pt.d.p, pt.n_obs, pt.n_lat, t.cols.p + (size_t)tm.cand_col * t.n_rows, pt.lat_len.p,
                                      t.cols_delta_rows, t.cols_delta_n, kpad, f.comp[i].p, f.clen[i].p);
       if (rc) return rc;
-      rc = pclean_build_compact_min(ctx, f.comp[i].p, pt.n_obs, kpad, cstride, f.cblk[i].p);
+      if (t.cols_delta_n > 0) rc = pclean_build_compact_min(ctx, f.comp[i].p, pt.n_obs, kpad, cstride, f.cblk[i].p);
       if (rc) return rc;
       f.ver[i] = ver;
     }
@@ -767,13 +769,15 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
   const bool small_lse = !no_small_generic && n_draws == 0 && il.n <= 1024 && !il.ev_lo &&
                          (size_t)(nd.n_cand + 2) * 8 + (16 + 64) * 8 <= (size_t)160 * 1024;
   if (!fast_tried && !scores_out && !snew_override && !ctx->force_generic && !nd.g.on && !ctx->prior_mode && !small_lse) {
+    static const int ev_slot_min_items = getenv("PCLEAN_EV_SLOT_MIN_ITEMS") ? atoi(getenv("PCLEAN_EV_SLOT_MIN_ITEMS")) : 64;
     if (!il.ev_lo)
       fast = try_fast_root(ctx, block_id, node_id, fr);
-    // option lists, and since round 6 reference slots — those only for launches of >= 1024 items (a one-batch class sweep:
-    // the latent Places re-choosing their County, 20 ms -> 1.6 ms): the slot's candidate-compact tables have to be rebuilt
-    // after every commit that wrote the referred table's columns (measured on the Hospital sub-batches of 333 rows:
-    // 0.32 ms of rebuild per call against the 0.29 ms of generic enumeration it would replace)
-    else if ((n.kind == PCLEAN_NODE_LEAF || (il.n >= 1024 && !getenv("PCLEAN_NO_FAST_EV_SLOTS"))) && n_draws <= 1 &&
+    // option lists, and since round 6 reference slots (the latent Places re-choosing their County in one batch, 20 ms ->
+    // 1.6 ms).  The slot's candidate-compact tables follow the referred table's columns: a sub-batch's host commit re-uploads
+    // them with a handful of rows created / collected, and pclean_set_table hands the changed rows on (cols_delta_*) so that
+    // the tables are refreshed for those rows alone — rebuilt whole they cost 0.32 ms per call against the 0.29 ms of generic
+    // enumeration they replace (Hospital sub-batches of 333 rows), which is what PCLEAN_EV_SLOT_MIN_ITEMS=1024 goes back to
+    else if ((n.kind == PCLEAN_NODE_LEAF || (il.n >= ev_slot_min_items && !getenv("PCLEAN_NO_FAST_EV_SLOTS"))) && n_draws <= 1 &&
              !getenv("PCLEAN_NO_FAST_EV"))
       fast_ev = try_fast_root(ctx, block_id, node_id, fr, true);
     if (fast < 0) return fast;
