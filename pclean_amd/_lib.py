@@ -64,7 +64,7 @@ class RootStats(C.Structure):
                 ("kpad", C.c_int32), ("n_terms", C.c_int32), ("n_pre", C.c_int32), ("n_draws", C.c_int32),
                 ("pre_obs_col", C.c_int32 * 3), ("overflow_items", C.c_int32), ("cstride", C.c_int32),
                 ("full_scans", C.c_int32), ("fine_blocks", C.c_int32), ("scored_terms", C.c_int32),
-                ("resolved_groups", C.c_int32), ("pre_scored", C.c_int32)]
+                ("resolved_groups", C.c_int32), ("pre_scored", C.c_int32), ("lazy_entries", C.c_int32)]
 
 
 class CommitSlot(C.Structure):
@@ -691,6 +691,10 @@ class HipContext:
         r = RootStats()
         check(self.h, self.lib.pclean_get_root_stats(self.h, C.byref(r)), "pclean_get_root_stats")
         return r
+
+    def set_timed_block(self, block_id):
+        """which block's root launch group get_timing().hot_kernel_* / get_root_stats() describe (default 0)"""
+        check(self.h, self.lib.pclean_set_timed_block(self.h, C.c_int32(int(block_id))), "pclean_set_timed_block")
 
     def set_profiling(self, on):
         check(self.h, self.lib.pclean_set_profiling(self.h, C.c_int32(int(on))), "pclean_set_profiling")

@@ -222,6 +222,7 @@ struct pclean_ctx {
   HostStage stage;               // page-locked staging of caller arrays (table uploads, latent-sweep inputs / outputs)
   const int32_t* obs_override = nullptr;  // eval.hip: ensure_leaf_cache scores "item t observes value t"
   int32_t active_begin = 0, active_count = -1;  // pclean_set_active_rows window (-1 = all rows)
+  int32_t timed_block = 0;  // the block whose root launch group pclean_timing / pclean_root_stats describe (pclean_set_timed_block)
   bool prior_mode = false;     // sweep.hip / latent.hip: the running sweep proposes from the priors (use_dd_proposals = false)
   bool force_generic = false;  // debug: never take the compact-table root kernel
   bool no_item_agg = false;    // debug: aggregate evidence with the global sort + run-length encoding only

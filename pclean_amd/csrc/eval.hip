@@ -862,7 +862,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
   if (fast) {
     int32_t* desc = scratch<int32_t>(ctx, pclean_fast_desc_words(it.n));
     if (!desc) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-    ProfScope ps(ctx, time_it ? "root_scan_block0" : (n.kind == PCLEAN_NODE_FK ? "slot_scan" : "option_scan"));
+    ProfScope ps(ctx, (time_it && block_id == 0) ? "root_scan_block0" : (n.kind == PCLEAN_NODE_FK ? "slot_scan" : "option_scan"));
     if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
     unsigned int* scan_stats = nullptr;
     if (time_it && s->over_ctr.p) {  // the timed launch (block 0's root): what it read, for bench.py's byte model

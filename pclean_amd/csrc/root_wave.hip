@@ -875,7 +875,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
   unsigned long long clk_t = __builtin_readcyclecounter();
   unsigned long long cnt_acc[6] = {0, 0, 0, 0, 0, 0};  // full scans, cached scans, survivors, -, -, -
 #endif
-  unsigned int st_scans = 0, st_blocks = 0, st_terms = 0;  // bench.py's byte model: what the launch really read
+  unsigned int st_scans = 0, st_blocks = 0, st_terms = 0, st_lazy = 0;  // bench.py's byte model: what the launch really read / wrote
   int g = 0, g_end = 0;
   resolve(grab(), g, g_end);
   int raw_next = steal < 8 ? grab() : 0;
@@ -1348,6 +1348,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
           }
         }
         if (lane == 0) lz_ns[g_id] = lazy ? ns : -1;
+        if (lazy) st_lazy += (unsigned int)ns;
       }
       // ---- draws of every (member item, draw) pair of the group ------------------------------------------------------
       if (n_draws > 0 && !lazy) {
@@ -1429,6 +1430,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     atomicAdd(&sl[0], st_scans);
     atomicAdd(&sl[1], st_blocks);
     atomicAdd(&sl[2], st_terms);
+    if (st_lazy) atomicAdd(&sl[4], st_lazy);
   }
 #ifdef WAVE_PHASE_CLOCK
   clk_acc[6] = __builtin_readcyclecounter() - clk_t;

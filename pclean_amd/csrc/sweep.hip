@@ -1079,9 +1079,10 @@ void apply_over_stats(pclean_ctx* ctx) {  // after that synchronisation
   }
   s->over_rec.clear();
   if (s->scan_stats_used) {
-    unsigned long long tot[4] = {0, 0, 0, 0};  // 64 slots a cache line apart (root_wave.hip: WAVE_STAT_SLOTS)
+    unsigned long long tot[5] = {0, 0, 0, 0, 0};  // 64 slots a cache line apart (root_wave.hip: WAVE_STAT_SLOTS)
     for (int sl = 0; sl < 64; ++sl)
-      for (int i = 0; i < 4; ++i) tot[i] += s->h_over[OVER_SLOTS + sl * 32 + i];
+      for (int i = 0; i < 5; ++i) tot[i] += s->h_over[OVER_SLOTS + sl * 32 + i];
+    ctx->root_stats.lazy_entries = (int32_t)tot[4];
     ctx->root_stats.full_scans = (int32_t)tot[0];
     ctx->root_stats.fine_blocks = (int32_t)tot[1];
     ctx->root_stats.scored_terms = (int32_t)tot[2];
@@ -1854,12 +1855,12 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       excl = cur_b;
       if (r.draws.alloc(NP) || r.lse.alloc(N)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
       if (fuse_final || split_final) s->lazy_req = SweepState::LazyReq{true, split_final ? emit_rows : nullptr};
-      rc = eval_node(ctx, bi, 0, il, excl, seed, sweep_idx, P, r.lse.p, r.draws.p, nullptr, nullptr, bi == 0);
+      rc = eval_node(ctx, bi, 0, il, excl, seed, sweep_idx, P, r.lse.p, r.draws.p, nullptr, nullptr, bi == ctx->timed_block);
       s->lazy_req = SweepState::LazyReq();
       if (rc) return rc;
       lazy = s->lazy_out;
       s->lazy_out.valid = false;
-      if (bi == 0) {  // (the elapsed time of the launch is read at the end of the call: no synchronisation here)
+      if (bi == ctx->timed_block) {  // (the elapsed time of the launch is read at the end of the call: no synchronisation here)
         hot_timed = true;
         ctx->timing.hot_kernel_launches += 1;
       }
@@ -1971,9 +1972,13 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       if (!lse_item || !draws_item) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
       il = ItemList{(int)n_items, d_row, d_ctx, nullptr, nullptr};
       if (fuse_final || split_final) s->lazy_req = SweepState::LazyReq{true, split_final ? emit_rows : nullptr};
-      rc = eval_node(ctx, bi, 0, il, d_excl, seed, sweep_idx, P, lse_item, draws_item, nullptr, nullptr, false);
+      rc = eval_node(ctx, bi, 0, il, d_excl, seed, sweep_idx, P, lse_item, draws_item, nullptr, nullptr, bi == ctx->timed_block);
       s->lazy_req = SweepState::LazyReq();
       if (rc) return rc;
+      if (bi == ctx->timed_block) {
+        hot_timed = true;
+        ctx->timing.hot_kernel_launches += 1;
+      }
       lazy = s->lazy_out;
       s->lazy_out.valid = false;
       lazy.args.slot_item = slot_item;
@@ -2208,7 +2213,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   {
     // bytes(row) = sum_b [4 F_b + (K_b+1)(8 F_b + 4)] + 8 P (full enumeration); reported beside the
     // byte model of the implemented algorithm (bench.py)
-    const Block& b0 = ctx->block[0];
+    const Block& b0 = ctx->block[(ctx->timed_block >= 0 && ctx->timed_block < n_blocks && !ctx->block[ctx->timed_block].is_score) ? ctx->timed_block : 0];
     const double F = b0.nodes[0].n_terms, K = ctx->cand[b0.nodes[0].table].n_rows;
     ctx->timing.hot_kernel_alg_bytes = (double)N * (4.0 * F + (K + 1.0) * (8.0 * F + 4.0) + 8.0 * P);
   }
@@ -2418,6 +2423,12 @@ extern "C" int pclean_set_cur_stride(pclean_ctx* ctx, int64_t stride) {
 extern "C" int pclean_get_root_stats(pclean_ctx* ctx, pclean_root_stats* out) {
   if (!ctx || !out) return PCLEAN_ERR_ARG;
   *out = ctx->root_stats;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_set_timed_block(pclean_ctx* ctx, int32_t block_id) {
+  if (!ctx || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_set_timed_block: bad block");
+  ctx->timed_block = block_id;
   return PCLEAN_OK;
 }
 

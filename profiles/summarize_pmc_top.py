@@ -28,6 +28,7 @@ def main():
     source = args[args.index("--source") + 1] if "--source" in args else "profiles/r02_pmc_top_kernels.txt"
     dbs = [a for a in args if a.endswith(".db")]
     merged = {}
+    bygrid = {}  # (kernel, grid) -> the same totals: the group kernels run once per block, told apart by their grids
     for path in dbs:
         db = sqlite3.connect(path)
         cur = db.cursor()
@@ -51,13 +52,14 @@ def main():
             # within a factor 2 of the kernel's longest launch are its full-size launches, the rest is "[small]"
             if any(t in k for t in ("fk_root_wave_kernel", "enum_node", "ev_leaf_wave", "group_desc", "group_settle", "group_lse", "group_gate", "gate_new", "particle_update", "hg_insert", "hg_fill", "overflow_lds")):
                 k += " [full-size]" if dur * 2 >= longest[k] else " [small]"
-            m = merged.setdefault(k, dict(n=0, dur=0.0, counters={}))
-            m["n"] += 1
-            m["dur"] += dur / 1e6
-            for cname, v in pmc.get(ev, {}).items():
-                c = m["counters"].setdefault(cname, [0, 0.0])
-                c[0] += 1
-                c[1] += v
+            for m in (merged.setdefault(k, dict(n=0, dur=0.0, counters={})),
+                      bygrid.setdefault((short(name), grid), dict(n=0, dur=0.0, counters={}))):
+                m["n"] += 1
+                m["dur"] += dur / 1e6
+                for cname, v in pmc.get(ev, {}).items():
+                    c = m["counters"].setdefault(cname, [0, 0.0])
+                    c[0] += 1
+                    c[1] += v
     names = sorted(merged, key=lambda k: -merged[k]["dur"])[:top]
     names += [k for k in merged if "fk_root_wave_kernel" in k and "full-size" in k and k not in names]  # the dominant sweep kernels, always
     print(f"{'kernel':72s} {'disp':>6s} {'avg_ms':>9s}  counters (average per dispatch)")
@@ -117,8 +119,37 @@ def main():
                     ent["SQ_WAIT_ANY_over_WAVE_CYCLES"] = cm["SQ_WAIT_ANY"][1] / cm["SQ_WAVE_CYCLES"][1]
                 if "TCC_HIT_sum" in cm and "TCC_MISS_sum" in cm:
                     ent["L2_hit_rate"] = cm["TCC_HIT_sum"][1] / (cm["TCC_HIT_sum"][1] + cm["TCC_MISS_sum"][1])
+                # ... and the launch GROUP bench.py times for it (pclean_set_timed_block): the group kernels of the Measure slot
+                # are the instances whose grid is the second of the two large ones (block 0's root has more groups)
+                def hbm_of(m):
+                    c = m["counters"]
+                    if "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                        return None
+                    return (2 * c["FETCH_SIZE"][1] / c["FETCH_SIZE"][0] + c["WRITE_SIZE"][1] / c["WRITE_SIZE"][0]) * 1024
+
+                desc = sorted(((g, m) for (k, g), m in bygrid.items() if k.startswith("group_desc_kernel") and g > 50000),
+                              key=lambda gm: -gm[1]["dur"])
+                if desc:
+                    g0 = max(g for g, _ in desc[:2])
+                    gm_ = [g for g, _ in desc if g < 0.8 * g0]
+                    if gm_:
+                        gm = gm_[0]
+                        comp = {km: hbm(km)}
+                        ms_g = {km: ms}
+                        for pat, scale in (("group_desc_kernel", 1), ("group_lse_kernel", 1), ("group_settle_kernel", 16)):
+                            cand = [(g, m) for (k, g), m in bygrid.items() if k.startswith(pat) and abs(g / scale - gm) <= 0.05 * gm]
+                            if cand:
+                                g_, m_ = max(cand, key=lambda x: x[1]["n"])
+                                if hbm_of(m_) is not None:
+                                    comp[f"{pat} [grid {g_}]"] = hbm_of(m_)
+                                    ms_g[f"{pat} [grid {g_}]"] = m_["dur"] / m_["n"]
+                        ent["group_bytes_per_launch"] = sum(comp.values())
+                        ent["group_components"] = comp
+                        ent["group_avg_ms"] = ms_g
                 prev = data.get("measure_root") or {}
-                data["measure_root"] = dict(prev, **ent)  # (hand-added notes — phase shares, scan counts — stay)
+                for stale in ("groups", "full_scans", "survivors_scored_exactly", "SQ_ACTIVE_INST_ANY_over_WAVE_CYCLES", "note"):
+                    prev.pop(stale, None)  # (hand-added in round 5 from that round's phase clock: not this run's)
+                data["measure_root"] = dict(prev, **ent)
             json.dump(data, open(out_json, "w"), indent=1)
 
 
