@@ -43,7 +43,7 @@ fi
 cd "$ROOT"
 T=$(find "$OUT/trace" -name "*.db" | head -1)
 python profiles/summarize_rocpd.py "$T" "$OUT/kernel_trace.txt" > /dev/null
-python profiles/timeline.py "$T" 0 1 > "$OUT/sweep_timeline.txt" 2>&1
+python profiles/timeline.py "$T" 0 3 > "$OUT/sweep_timeline.txt" 2>&1  # (a sweep inside the loop of whole-window sweeps: the last ones straddle host-side bookkeeping of bench.py)
 python profiles/summarize_pmc_top.py $(find "$OUT"/pmc_FETCH "$OUT"/pmc_WRITE "$OUT"/pmc_SQ "$OUT"/pmc_SQ2 "$OUT"/pmc_TCC -name "*.db") \
   --top 12 --source "profiles/${TAG}_pmc_root_kernels.txt" --json "$OUT/hbm_traffic.json" > "$OUT/pmc_root_kernels.txt" 2>&1
 python profiles/step_traffic.py $(find "$OUT"/pmc_all_FETCH_SIZE -name "*.db" | head -1) $(find "$OUT"/pmc_all_WRITE_SIZE -name "*.db" | head -1) \
