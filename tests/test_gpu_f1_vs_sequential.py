@@ -78,7 +78,16 @@ def test_batched_gpu_f1_matches_the_sequential_reference(name, capsys):
     if name in lit:  # ... and of the INDEPENDENT literal sequential reference (oracle/literal_inference.py)
         with capsys.disabled():
             print(f"[f1 vs literal sequential] {name}: literal reference mean {lit[name]['f1_mean']:.4f}")
-        assert abs(np.mean(got) - lit[name]["f1_mean"]) <= 0.005, (got, lit[name]["f1_mean"])
+        if name.startswith("synth"):
+            # heavy-tailed F1 (tests/test_literal_sequential.py::test_synthetic_shape_stands_between_two_references): six
+            # 30 000-row literal runs pin the mean to about a point — two standard errors of the paired differences
+            dl = np.asarray(got) - np.asarray([lit[name]["runs"][str(sd)]["f1"] for sd in seeds])
+            se = dl.std(ddof=1) / np.sqrt(len(dl))
+            with capsys.disabled():
+                print(f"[f1 vs literal sequential] {name}: difference of means {100 * dl.mean():+.2f} pt (paired s.e. {100 * se:.2f} pt)")
+            assert abs(dl.mean()) <= 2 * se + 0.005, (dl.mean(), se)
+        else:
+            assert abs(np.mean(got) - lit[name]["f1_mean"]) <= 0.005, (got, lit[name]["f1_mean"])
     # ... and no seed further below the reference's MEAN than three of the reference's own standard deviations + 0.5 pt (the
     # reference's seeds spread by more than a point themselves: rents PG-20 0.6654 .. 0.6862, s.d. 0.7 pt)
     floor = float(np.mean(want) - 3.0 * np.std(want, ddof=1) - 0.005)
@@ -100,3 +109,25 @@ def test_initialisation_in_1024_row_batches_is_reported_not_asserted(capsys):
         print(f"\n[f1 vs sequential, init batches <= 1024] {name}: {np.round(got, 4).tolist()} vs {np.round(want, 4).tolist()}: "
               f"{100 * diff:+.2f} pt (outside the +-0.5 pt band by construction: reported)")
     assert abs(diff) <= 0.015, (diff, got, want)
+
+
+
+def test_synthetic_shape_at_3000_rows_between_two_references(capsys):
+    """18 seeds of the synthetic hospital program at 3 000 rows (PG-20): the batched GPU runs against BOTH sequential
+    references of tests/golden/synth3k_two_references.json — the independent literal sampler and the product's sequential runs.
+    F1 is heavy-tailed here (about a quarter of the seeds lose points to one wrongly cleaned shared value), so: means within two
+    standard errors of the paired differences (and within 1.5 pt), medians within 0.3 pt, a comparable share of bad seeds."""
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "synth3k_two_references.json")))
+    seeds = sorted(d["literal"], key=int)
+    got = np.array([_gpu_f1("synth_pg20", int(sd), 1, False, 20, 3000) for sd in seeds])
+    for ref in ("literal", "product_sequential"):
+        want = np.array([d[ref][sd]["f1"] for sd in seeds])
+        diff = got - want
+        se = diff.std(ddof=1) / np.sqrt(len(diff))
+        with capsys.disabled():
+            print(f"\n[synth 3 000 rows vs {ref}] GPU mean {got.mean():.4f} median {np.median(got):.4f} bad seeds {(got < 0.97).sum()} | "
+                  f"reference mean {want.mean():.4f} median {np.median(want):.4f} bad seeds {(want < 0.97).sum()} | "
+                  f"difference {100 * diff.mean():+.2f} pt (paired s.e. {100 * se:.2f} pt)")
+        assert abs(diff.mean()) <= 2 * se and abs(diff.mean()) <= 0.015, (ref, diff.mean(), se)
+        assert abs(np.median(got) - np.median(want)) <= 0.003, (ref, np.median(got), np.median(want))
+    assert (got < 0.97).sum() <= len(seeds) // 2
