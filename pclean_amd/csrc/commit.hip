@@ -504,7 +504,10 @@ static int launch_refresh(pclean_ctx* ctx, CommitState* c) {
   HIPCHK(ctx, hipMemsetAsync(c->d_sums.p, 0, sizeof(PccSums), ctx->stream));
   hipLaunchKernelGGL(pcc_refresh_kernel, dim3((max_stride + 255) / 256, c->n_slots), dim3(256), 0, ctx->stream, ra, c->d_res.p,
                      c->d_sums.p);
-  HIPCHK(ctx, hipMemcpyAsync(c->h_sums, c->d_sums.p, sizeof(PccSums), hipMemcpyDeviceToHost, ctx->stream));
+  {
+    const int rcs = d2h_small(ctx, c->h_sums, c->d_sums.p, sizeof(PccSums));  // (flushed by the caller's pclean_sweep_finish_queue / d2h_flush)
+    if (rcs) return rcs;
+  }
   return PCLEAN_OK;
 }
 
@@ -759,10 +762,11 @@ static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_
                      commit_blocks, c->d_res.p);
   int rc = launch_refresh(ctx, c);
   if (rc) return rc;
-  HIPCHK(ctx, hipMemcpyAsync(c->h_res, c->d_res.p, sizeof(PccResult), hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(c->h_states, c->d_states.p, sizeof(int32_t) * PCC_MAX_SLOTS * PCC_ST_WORDS, hipMemcpyDeviceToHost,
-                             ctx->stream));
-  rc = pclean_sweep_finish_queue(ctx);
+  rc = d2h_small(ctx, c->h_res, c->d_res.p, sizeof(PccResult));
+  if (!rc) rc = d2h_small(ctx, c->h_states, c->d_states.p, sizeof(int32_t) * PCC_MAX_SLOTS * PCC_ST_WORDS);
+  if (rc) return rc;
+  rc = pclean_sweep_finish_queue(ctx);  // (its read-backs and the three above: one kernel)
+  if (!rc) rc = d2h_flush(ctx);         // (no sweep before the call, a rank without rows: nothing of the sweep's was queued)
   if (rc) return rc;
   HIPCHK(ctx, hipGetLastError());
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // the ONE synchronisation of sweep + commit
@@ -805,6 +809,7 @@ static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_
       if (rc) return rc;
     }
     rc = launch_refresh(ctx, c);
+    if (!rc) rc = d2h_flush(ctx);
     if (rc) return rc;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   }

@@ -699,7 +699,8 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   HIPCHK(ctx, hipMemcpyAsync(h_chosen, d_chosen, b_keys, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipMemcpyAsync(h_vals, d_vals, b_vals, hipMemcpyDeviceToHost, ctx->stream));
   {
-    const int rcq = queue_over_copy(ctx);  // the sync-free re-runs' counts ride on the call's one synchronisation
+    int rcq = queue_over_copy(ctx);  // the sync-free re-runs' counts ride on the call's one synchronisation
+    if (!rcq) rcq = d2h_flush(ctx);
     if (rcq) return rcq;
   }
   PCLEAN_SYNC(ctx);

@@ -119,13 +119,22 @@ __global__ void compact_len_kernel(const uint16_t* __restrict__ lat_len, const i
 }
 __global__ void priors_kernel(const int64_t* __restrict__ counts, const double* __restrict__ logc_full, int n_cand,
                               int kpad, double logden_e, double logden_n, double* __restrict__ prior_e,
-                              double* __restrict__ prior_n) {
+                              double* __restrict__ prior_n, uint16_t* __restrict__ alive) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= kpad) return;
   // FK table: live rows only; option table (counts == null): every option, prior = its log-probability
   const bool live = k < n_cand && (counts ? counts[k] != 0 : true);
-  prior_n[k] = live ? logc_full[k] - logden_n : -__builtin_inf();
-  if (prior_e) prior_e[k] = live ? logc_full[k] - logden_e : -__builtin_inf();
+  const double pn = live ? logc_full[k] - logden_n : -__builtin_inf();
+  if (k < kpad) {
+    prior_n[k] = pn;
+    if (prior_e) prior_e[k] = live ? logc_full[k] - logden_e : -__builtin_inf();
+  }
+  // bit e of alive[q] = candidate 16 q + e can carry weight (live row / option with a finite prior): the wavefront's 64
+  // candidates are four words (kpad is a multiple of 16, the block size a multiple of 64)
+  if (alive) {
+    const uint64_t m = __ballot(pn > -__builtin_inf());
+    const int lane = threadIdx.x & 63;
+    if ((lane & 15) == 0 && k < kpad) alive[k >> 4] = (uint16_t)(m >> lane);
+  }
 }
 // bit e of alive[q] = candidate 16 q + e can carry weight (live row / option with a finite prior)
 __global__ void alive_kernel(const double* __restrict__ prior_n, int kpad, uint16_t* __restrict__ alive) {
@@ -183,9 +192,10 @@ int pclean_build_compact_min(pclean_ctx* ctx, const uint8_t* comp, int n_obs, in
 }
 int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* logc_full, int n_cand, int kpad,
                         double logden_e, double logden_n, double* prior_e, double* prior_n, uint16_t* alive) {
+  static const bool unfused = getenv("PCLEAN_NO_FUSED_PRIORS") != nullptr;
   hipLaunchKernelGGL(priors_kernel, dim3((kpad + 255) / 256), dim3(256), 0, ctx->stream, counts, logc_full, n_cand,
-                     kpad, logden_e, logden_n, prior_e, prior_n);
-  hipLaunchKernelGGL(alive_kernel, dim3(((kpad >> 4) + 255) / 256), dim3(256), 0, ctx->stream, prior_n, kpad, alive);
+                     kpad, logden_e, logden_n, prior_e, prior_n, unfused ? (uint16_t*)nullptr : alive);
+  if (unfused) hipLaunchKernelGGL(alive_kernel, dim3(((kpad >> 4) + 255) / 256), dim3(256), 0, ctx->stream, prior_n, kpad, alive);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }

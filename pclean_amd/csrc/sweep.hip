@@ -1042,17 +1042,57 @@ int begin_call(pclean_ctx* ctx) {
 }
 // End of such a call, after its last stream synchronisation has been queued: the overflow counts of the sync-free
 // launches go into the statistics and the "does the pre-filter pay for this option list" heuristic.
+__global__ void publish_regions_kernel(const SweepState::PubRegions pr) {
+  const int r = blockIdx.x;
+  const uint32_t* __restrict__ src = pr.src[r];
+  uint32_t* __restrict__ dst = pr.dst[r];
+  for (uint32_t i = threadIdx.x; i < pr.words[r]; i += blockDim.x) dst[i] = src[i];
+}
+int d2h_small(pclean_ctx* ctx, void* host, const void* dev, size_t bytes, void* host_base) {
+  SweepState* s = st(ctx);
+  static const bool off = getenv("PCLEAN_NO_PUBLISH_REGIONS") != nullptr;
+  if (bytes == 0) return PCLEAN_OK;
+  void* mapped = nullptr;
+  if (!off && (bytes & 3) == 0 && bytes <= (size_t)(1 << 20) && s->pub.n < 12) {
+    void* base = host_base ? host_base : host;
+    auto it = s->pub_map.find(base);
+    if (it != s->pub_map.end()) {
+      mapped = it->second;
+    } else {
+      if (hipHostGetDevicePointer(&mapped, base, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        mapped = nullptr;
+      }
+      s->pub_map[base] = mapped;  // (null: not mappable, remembered)
+    }
+    if (mapped) mapped = static_cast<char*>(mapped) + (static_cast<char*>(host) - static_cast<char*>(base));
+  }
+  if (!mapped) {
+    HIPCHK(ctx, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    return PCLEAN_OK;
+  }
+  const int k = s->pub.n++;
+  s->pub.src[k] = static_cast<const uint32_t*>(dev);
+  s->pub.dst[k] = static_cast<uint32_t*>(mapped);
+  s->pub.words[k] = (uint32_t)(bytes >> 2);
+  return PCLEAN_OK;
+}
+int d2h_flush(pclean_ctx* ctx) {
+  SweepState* s = st(ctx);
+  if (s->pub.n == 0) return PCLEAN_OK;
+  hipLaunchKernelGGL(publish_regions_kernel, dim3(s->pub.n), dim3(256), 0, ctx->stream, s->pub);
+  s->pub.n = 0;
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
 int queue_over_copy(pclean_ctx* ctx) {  // before a stream synchronisation of the caller
   SweepState* s = st(ctx);
   if (s->over_rec.empty() && !s->scan_stats_used) return PCLEAN_OK;
   if (!s->h_over) HIPCHK(ctx, hipHostMalloc((void**)&s->h_over, (OVER_SLOTS + STAT_WORDS) * sizeof(unsigned int), hipHostMallocDefault));
-  if (!s->over_rec.empty())
-    HIPCHK(ctx, hipMemcpyAsync(s->h_over, s->over_ctr.p, s->over_rec.size() * sizeof(unsigned int), hipMemcpyDeviceToHost,
-                               ctx->stream));
-  if (s->scan_stats_used)
-    HIPCHK(ctx, hipMemcpyAsync(s->h_over + OVER_SLOTS, s->over_ctr.p + OVER_SLOTS, STAT_WORDS * sizeof(unsigned int),
-                               hipMemcpyDeviceToHost, ctx->stream));
-  return PCLEAN_OK;
+  int rc = PCLEAN_OK;
+  if (!s->over_rec.empty()) rc = d2h_small(ctx, s->h_over, s->over_ctr.p, s->over_rec.size() * sizeof(unsigned int));
+  if (!rc && s->scan_stats_used) rc = d2h_small(ctx, s->h_over + OVER_SLOTS, s->over_ctr.p + OVER_SLOTS, STAT_WORDS * sizeof(unsigned int), s->h_over);
+  return rc;
 }
 void apply_over_stats(pclean_ctx* ctx) {  // after that synchronisation
   SweepState* s = st(ctx);
@@ -1093,6 +1133,7 @@ void apply_over_stats(pclean_ctx* ctx) {  // after that synchronisation
 int finish_call(pclean_ctx* ctx) {
   if (st(ctx)->over_rec.empty() && !st(ctx)->scan_stats_used) return PCLEAN_OK;
   int rc = queue_over_copy(ctx);
+  if (!rc) rc = d2h_flush(ctx);
   if (rc) return rc;
   PCLEAN_SYNC(ctx);
   apply_over_stats(ctx);
@@ -2236,15 +2277,14 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
 int pclean_sweep_finish_queue(pclean_ctx* ctx) {
   SweepState* s = st(ctx);
   if (!s->outputs_pending) return PCLEAN_OK;
-  HIPCHK(ctx, hipMemcpyAsync(s->h_counts, s->tail_counts.p, 2 * s->last_blocks * sizeof(int32_t), hipMemcpyDeviceToHost,
-                             ctx->stream));
+  int rc = d2h_small(ctx, s->h_counts, s->tail_counts.p, 2 * s->last_blocks * sizeof(int32_t));
+  if (rc) return rc;
   const int rco = queue_over_copy(ctx);
   if (rco) return rco;
   s->h_counts[3 * PCLEAN_MAX_BLOCKS] = 0;
-  if (s->dummy_used)
-    HIPCHK(ctx, hipMemcpyAsync(s->h_counts + 3 * PCLEAN_MAX_BLOCKS, s->dummy_ctr.p + 1, sizeof(int32_t), hipMemcpyDeviceToHost,
-                               ctx->stream));
-  return PCLEAN_OK;
+  if (s->dummy_used) rc = d2h_small(ctx, s->h_counts + 3 * PCLEAN_MAX_BLOCKS, s->dummy_ctr.p + 1, sizeof(int32_t), s->h_counts);
+  if (rc) return rc;
+  return d2h_flush(ctx);  // (everything a caller queued before this call rides along)
 }
 // 2. after the caller's stream synchronisation: statistics, timing, error flags
 int pclean_sweep_finish_synced(pclean_ctx* ctx) {

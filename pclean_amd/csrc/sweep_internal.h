@@ -282,6 +282,10 @@ static __global__ void gather_i32_kernel(int n, const int32_t* list, const int32
 // ---- functions defined in one translation unit and called from another ------------------------------------------------
 int begin_call(pclean_ctx* ctx);
 int queue_over_copy(pclean_ctx* ctx);
+// Small device -> page-locked-host read-backs that ride on ONE synchronisation: queued, then written by ONE kernel through the
+// host buffers' device mappings (d2h_flush) instead of one blit dispatch each (six 5-us copies back to back after a commit).
+// A buffer that is not page-locked / mapped, an odd size or a full queue: hipMemcpyAsync right away.
+// (declared in sweep_state.h: d2h_small(ctx, host, dev, bytes, host_base = the allocation `host` lies in), d2h_flush(ctx))
 void apply_over_stats(pclean_ctx* ctx);
 int finish_call(pclean_ctx* ctx);
 void prof_collect(pclean_ctx* ctx);

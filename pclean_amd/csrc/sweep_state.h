@@ -137,7 +137,10 @@ struct SweepState {
   bool scan_stats_used = false;
   int bank_used = 0;               // counters of the bank (the tail of over_ctr) handed out by the running call
   DevBuf<unsigned int> over_ctr;   // [OVER_SLOTS + STAT_WORDS]: the tail = scan statistics of the timed root launch
-  std::deque<DevBuf<unsigned int>> more_banks;  // further counter banks of a call that used up the first (fresh_counter)
+  std::deque<DevBuf<unsigned int>> more_banks;
+  // queued small read-backs (d2h_small / d2h_flush, sweep.hip) and the device mappings of the host buffers seen so far
+  struct PubRegions { const uint32_t* src[12]; uint32_t* dst[12]; uint32_t words[12]; int n; } pub = {};
+  std::map<void*, void*> pub_map;  // further counter banks of a call that used up the first (fresh_counter)
   struct OverRec { int block, node, n_items; bool time_it, leaf; int min_items; };  // min_items: from how many items on the "does the pre-filter pay" rule applies
   std::vector<OverRec> over_rec;
   // pclean_sweep_latent: the option lists of a latent row are independent given its evidence — each is evaluated on one
@@ -176,5 +179,8 @@ static SweepState* st(pclean_ctx* ctx) {
 
 // sweep.hip: the three steps that end a sweep (see there)
 int pclean_sweep_finish_queue(pclean_ctx* ctx);
+// small read-backs riding on one synchronisation (sweep.hip; see sweep_internal.h)
+int d2h_small(pclean_ctx* ctx, void* host, const void* dev, size_t bytes, void* host_base = nullptr);
+int d2h_flush(pclean_ctx* ctx);
 int pclean_sweep_finish_synced(pclean_ctx* ctx);
 int pclean_sweep_fetch_lists(pclean_ctx* ctx);
