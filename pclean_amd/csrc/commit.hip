@@ -501,7 +501,7 @@ static int launch_refresh(pclean_ctx* ctx, CommitState* c) {
     ra.t[si] = PccRefresh{t.counts.p, t.logc_full.p, t.logc_m1.p, s.lut.p, s.lut_n, t.n_rows};
     max_stride = std::max(max_stride, t.n_rows);
   }
-  HIPCHK(ctx, hipMemsetAsync(c->d_sums.p, 0, sizeof(PccSums), ctx->stream));
+  { const int rcz = dev_zero(ctx, c->d_sums.p, sizeof(PccSums)); if (rcz) return rcz; }
   hipLaunchKernelGGL(pcc_refresh_kernel, dim3((max_stride + 255) / 256, c->n_slots), dim3(256), 0, ctx->stream, ra, c->d_res.p,
                      c->d_sums.p);
   {
@@ -711,7 +711,7 @@ static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_
       pb.cur = ctx->dev_cur.p + (size_t)bi * ctx->n_rows;
     }
     HIPCHK(ctx, hipMemcpyAsync(c->d_blocks_g.p, c->h_blocks_g, sizeof(PccBlock) * c->n_plans, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemsetAsync(c->d_res.p, 0, sizeof(PccResult), ctx->stream));
+    { const int rcz = dev_zero(ctx, c->d_res.p, sizeof(PccResult)); if (rcz) return rcz; }
     // 2. the delta reference counts of the root tables, summed over the ranks (in place): from here on the device buffers
     //    hold the SUMS — a refused commit tells its caller so (summary.stats_reduced), the host exchange must not sum again
     int32_t tids[PCC_MAX_BLOCKS];

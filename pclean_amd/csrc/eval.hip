@@ -855,10 +855,10 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
     if (!over_list) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
     s->over_rec.push_back(SweepState::OverRec{block_id, node_id, il.n, time_it, n.kind == PCLEAN_NODE_LEAF, fast_ev ? 64 : 1024});
   } else {
-    HIPCHK(ctx, hipMemsetAsync(s->counter.p + 1, 0, sizeof(unsigned int), ctx->stream));
+    { const int rcz = dev_zero(ctx, s->counter.p + 1, sizeof(unsigned int)); if (rcz) return rcz; }
   }
   if (!ev_list_mode)  // (the list stands for the markers there)
-    HIPCHK(ctx, hipMemsetAsync(oflag, 0, (size_t)il.n * sizeof(int32_t), ctx->stream));  // kernels only set overflow markers
+    { const int rcz = dev_zero(ctx, oflag, (size_t)il.n * sizeof(int32_t)); if (rcz) return rcz; }  // kernels only set overflow markers
   if (fast) {
     int32_t* desc = scratch<int32_t>(ctx, pclean_fast_desc_words(it.n));
     if (!desc) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
@@ -976,7 +976,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
     int32_t* rng2 = il.rng_row ? scratch<int32_t>(ctx, n_over) : nullptr;
     if (!list || !row2 || !excl2 || !ctx2 || !part2 || (il.ev_lo && (!evl2 || !evh2 || !org2)) || (il.rng_row && !rng2))
       return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
-    HIPCHK(ctx, hipMemsetAsync(s->counter.p + 1, 0, sizeof(unsigned int), ctx->stream));
+    { const int rcz = dev_zero(ctx, s->counter.p + 1, sizeof(unsigned int)); if (rcz) return rcz; }
     hipLaunchKernelGGL(compact_new_kernel, grid1(il.n), dim3(256), 0, ctx->stream, (size_t)il.n, oflag, 1,
                        s->counter.p + 1, list, nullptr);
     hipLaunchKernelGGL(sub_items_kernel, grid1(n_over), dim3(256), 0, ctx->stream, (int)n_over, list, il.row, il.ctx, excl,
@@ -1394,7 +1394,7 @@ static int make_item_groups_hash(pclean_ctx* ctx, const ItemList& il, const int3
   uint32_t wbits = HG_WBITS;
   while ((1u << wbits) > cap) --wbits;
   HashGroupDev hg{rep, want_members ? (unsigned int*)(rep + cap) : nullptr, cap - 1, split_m, wbits};
-  HIPCHK(ctx, hipMemsetAsync(rep, 0, (size_t)cap * (want_members ? 2 : 1) * sizeof(int32_t), ctx->stream));
+  { const int rcz = dev_zero(ctx, rep, (size_t)cap * (want_members ? 2 : 1) * sizeof(int32_t)); if (rcz) return rcz; }
   hipLaunchKernelGGL(hg_insert_kernel, grid1(n), dim3(256), 0, ctx->stream, n, kc, il.row, il.ctx, excl, hg, slot_of, pos_of);
   int32_t n_unique = 0;
   if (want_members) {

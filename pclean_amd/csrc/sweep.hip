@@ -1035,13 +1035,37 @@ int begin_call(pclean_ctx* ctx) {
   ctx->prior_mode = false;
   s->over_rec.clear();
   if (s->over_ctr.alloc(OVER_SLOTS + STAT_WORDS + CTR_BANK)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
-  HIPCHK(ctx, hipMemsetAsync(s->over_ctr.p, 0, (OVER_SLOTS + STAT_WORDS + CTR_BANK) * sizeof(unsigned int), ctx->stream));
+  { const int rcz = dev_zero(ctx, s->over_ctr.p, (OVER_SLOTS + STAT_WORDS + CTR_BANK) * sizeof(unsigned int)); if (rcz) return rcz; }
   s->bank_used = 0;
   s->scan_stats_used = false;
   return PCLEAN_OK;
 }
 // End of such a call, after its last stream synchronisation has been queued: the overflow counts of the sync-free
 // launches go into the statistics and the "does the pre-filter pay for this option list" heuristic.
+__global__ void dev_zero_kernel(uint4* __restrict__ p16, size_t n16, unsigned char* __restrict__ tail, int n_tail) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p16[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && (int)threadIdx.x < n_tail) tail[threadIdx.x] = 0;
+}
+int dev_zero(pclean_ctx* ctx, void* p, size_t bytes) {
+  static const bool off = getenv("PCLEAN_NO_ZERO_KERNEL") != nullptr;
+  if (bytes == 0) return PCLEAN_OK;
+  unsigned char* b = static_cast<unsigned char*>(p);
+  const size_t head = (16 - ((uintptr_t)b & 15)) & 15;  // bytes before the first 16-byte boundary
+  if (!off && bytes <= 256) {  // a counter or two, wherever they lie
+    hipLaunchKernelGGL(dev_zero_kernel, dim3(1), dim3(256), 0, ctx->stream, (uint4*)nullptr, (size_t)0, b, (int)bytes);
+    return PCLEAN_OK;
+  }
+  if (off || head > 0) {  // (every buffer the sweeps zero is hipMalloc'ed or 16-byte aligned inside one: the general case keeps the API)
+    HIPCHK(ctx, hipMemsetAsync(p, 0, bytes, ctx->stream));
+    return PCLEAN_OK;
+  }
+  const size_t n16 = bytes >> 4;
+  const int n_tail = (int)(bytes & 15);
+  const unsigned int blocks = (unsigned int)std::min<size_t>(std::max<size_t>((n16 + 255) / 256, 1), 4096);
+  hipLaunchKernelGGL(dev_zero_kernel, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<uint4*>(b), n16, b + (n16 << 4), n_tail);
+  return PCLEAN_OK;
+}
 __global__ void publish_regions_kernel(const SweepState::PubRegions pr) {
   const int r = blockIdx.x;
   const uint32_t* __restrict__ src = pr.src[r];
@@ -1662,8 +1686,8 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
   // particle weights start at +0.0: the first block's particle_update_kernel stores instead of accumulating (a sweep that
   // begins with a scoring block accumulates onto zeros)
   const bool w_by_first_block = !ctx->block[0].is_score;
-  if (!w_by_first_block) HIPCHK(ctx, hipMemsetAsync(s->w.p, 0, NP * sizeof(double), ctx->stream));
-  HIPCHK(ctx, hipMemsetAsync(s->logml_acc.p, 0, (size_t)N * sizeof(double), ctx->stream));
+  if (!w_by_first_block) { const int rcz = dev_zero(ctx, s->w.p, NP * sizeof(double)); if (rcz) return rcz; }
+  { const int rcz = dev_zero(ctx, s->logml_acc.p, (size_t)N * sizeof(double)); if (rcz) return rcz; }
   ctx->timing = pclean_timing{};
   // the later blocks' root tables refresh on a side stream while block 0 runs (eval.hip: prefetch_fast_root): enqueued
   // once block 0's kernels are (see the block loop), so that the host time of those launches is not block 0's
@@ -1863,7 +1887,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         ctx->prior_mode = false;
         return rc;
       }
-      HIPCHK(ctx, hipMemsetAsync(r.lse.p, 0, (size_t)N * sizeof(double), ctx->stream));
+      { const int rcz = dev_zero(ctx, r.lse.p, (size_t)N * sizeof(double)); if (rcz) return rcz; }
       n_new_ctr = fresh_counter(ctx);
       if (!n_new_ctr) return pclean_fail(ctx, PCLEAN_ERR_HIP, "counter bank: device alloc failed");
       hipLaunchKernelGGL(particle_update_kernel, dim3((N + PU_T - 1) / PU_T), dim3(PU_T), pu_stage_bytes, ctx->stream, N, P, r.draws.p, r.lse.p,

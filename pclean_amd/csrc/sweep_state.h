@@ -182,5 +182,8 @@ int pclean_sweep_finish_queue(pclean_ctx* ctx);
 // small read-backs riding on one synchronisation (sweep.hip; see sweep_internal.h)
 int d2h_small(pclean_ctx* ctx, void* host, const void* dev, size_t bytes, void* host_base = nullptr);
 int d2h_flush(pclean_ctx* ctx);
+// zero bytes of device memory with a plain kernel on the library's stream (hipMemsetAsync costs ~2x the host time of a launch:
+// pointer look-ups before its blit kernel is queued; a sweep zeroes nine small buffers)
+int dev_zero(pclean_ctx* ctx, void* p, size_t bytes);
 int pclean_sweep_finish_synced(pclean_ctx* ctx);
 int pclean_sweep_fetch_lists(pclean_ctx* ctx);

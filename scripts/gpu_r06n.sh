@@ -8,7 +8,7 @@ cd "$ROOT"
 timeout 2400 python -m pytest tests/test_gpu_commit.py tests/test_gpu_determinism.py tests/test_gpu_sweep.py tests/test_gpu_inference.py tests/test_gpu_edges.py tests/test_gpu_fullsize.py tests/test_gpu_rents.py tests/test_gpu_flights.py -m gpu -q --tb=short -p no:cacheprovider -x > "$OUT/pytest.log" 2>&1
 echo "pytest rc=$?"; tail -n 4 "$OUT/pytest.log"
 for V in new old; do
-  E=""; [ $V = old ] && E="PCLEAN_NO_PUBLISH_REGIONS=1 PCLEAN_NO_FUSED_PRIORS=1"
+  E=""; [ $V = old ] && E="PCLEAN_NO_PUBLISH_REGIONS=1 PCLEAN_NO_FUSED_PRIORS=1 PCLEAN_NO_ZERO_KERNEL=1"
   env $E timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dl-sample --distance osa > "$OUT/bench_$V.json" 2> "$OUT/bench_$V.log"
   python - "$OUT/bench_$V.json" <<'PY'
 import json,sys
