@@ -84,3 +84,56 @@ def test_sweeps_are_bit_identical_across_runs_and_paths(capsys):
         with capsys.disabled():
             print(f"\n[determinism] {name}: {line}")
     assert len(set(digests.values())) == 1, digests
+
+
+# ---- a whole run_inference (observed class on the device-resident commit, every latent class with its sub-batches, host
+# commits, parameter moves) under this round's latent-path switches ----------------------------------------------------------
+SCRIPT_FULL = r'''
+import hashlib, sys
+import numpy as np
+sys.path[:0] = [ROOT, ROOT + "/tests"]
+import helpers
+from pclean_amd.engine import Engine, InferenceConfig
+from pclean_amd.inference import initialize_trace, run_inference
+from pclean_amd.trace import Trace
+dirty, clean, lw, obs, _ = helpers.truth_workload(20000, 200, 13)
+eng = Engine(lw, obs)
+h = hashlib.sha256()
+try:
+    cfg = InferenceConfig(2, 5)
+    tr = Trace(lw, obs.shape[1], 3)
+    initialize_trace(eng, tr, cfg, 3, max_batch=2048)
+    run_inference(eng, tr, cfg, 3)
+    tr.check_consistency()
+    h.update(np.ascontiguousarray(tr.cur).tobytes())
+    for c in sorted(tr.tables):
+        t = tr.tables[c]
+        h.update(np.ascontiguousarray(t.counts[:t.n]).tobytes())
+        h.update(np.ascontiguousarray(t.cols[:, :t.n]).tobytes())
+    print("DIGEST", h.hexdigest(), {c: int(t.n_live) for c, t in tr.tables.items()})
+finally:
+    eng.close()
+'''
+
+
+def test_full_inference_is_bit_identical_across_the_latent_path_switches(capsys):
+    variants = {
+        "default": {},
+        "no changed-row deltas of re-uploaded tables": {"PCLEAN_NO_UPLOAD_DELTA": "1"},
+        "reference slots of latent sweeps by the generic kernel": {"PCLEAN_NO_FAST_EV_SLOTS": "1"},
+        "evidence scans for slots only from 1024 items on": {"PCLEAN_EV_SLOT_MIN_ITEMS": "1024"},
+        "common prior in the evidence cut": {"PCLEAN_NO_EV_PRIOR_CUT": "1"},
+        "no evidence scans at all": {"PCLEAN_NO_FAST_EV": "1"},
+        "read-backs by copies, hipMemsetAsync": {"PCLEAN_NO_PUBLISH_REGIONS": "1", "PCLEAN_NO_ZERO_KERNEL": "1", "PCLEAN_NO_FUSED_PRIORS": "1"},
+    }
+    digests = {}
+    for name, env in variants.items():
+        e = dict(os.environ)
+        e.update(env)
+        out = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + SCRIPT_FULL], env=e, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1]
+        digests[name] = line.split()[1]
+        with capsys.disabled():
+            print(f"\n[determinism, full inference] {name}: {line}")
+    assert len(set(digests.values())) == 1, digests
