@@ -794,7 +794,7 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
     uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out, int32_t* __restrict__ overflow_flag,
     unsigned int* __restrict__ overflow_count, int32_t* __restrict__ overflow_list,
     unsigned int* __restrict__ scan_stats, const int32_t* __restrict__ worklist, int32_t* __restrict__ lz_k,
-    uint64_t* __restrict__ lz_p, int32_t* __restrict__ lz_ns, const int32_t* __restrict__ eager_rows) {
+    uint64_t* __restrict__ lz_p, int32_t* __restrict__ lz_ns, const int32_t* __restrict__ eager_rows, int dense_mode) {
   // exact scores and, later, the fixed-point prefix share one array: entry j is converted in place by lane j
   __shared__ uint64_t s_pref[WPG][CAP + 8];
   __shared__ int32_t s_k[WPG][CAP + 8];
@@ -869,6 +869,8 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
       c = __builtin_amdgcn_readfirstlane(r);
     }
   };
+  int dense_skip = 0;  // scans left that go straight to the streaming filter (see the scan)
+  const bool dense_on = dense_mode != 0;
   // cache of the last scan (per wave): pre-filter observed values, scanned cut-off, survivors in ksv
   int c_o0 = -2, c_o1 = -2, c_o2 = -2, c_ns = 0;
   uint32_t c_cut = 0;
@@ -1005,7 +1007,10 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
         const uint32_t addc = 0x01010101u * (127u - cs);
         ns = 0;
         bool fine_done = false;
-        if (cst != 0u) {
+        // (dense_skip: the wave's last two-level scan found three blocks in four passing — a table of near-identical rows, the
+        // Measure slot — so the coarse level is a round trip for nothing: the next scans stream the rows whole, then it is tried again)
+        if (cst != 0u && dense_skip > 0) --dense_skip;
+        else if (cst != 0u) {
           int nb = 0;  // passing blocks -> blk[], ascending
           for (int kb0 = 0; kb0 < kblk; kb0 += 64) {
             const int kb = kb0 + lane;
@@ -1022,7 +1027,9 @@ __global__ __launch_bounds__(64 * WPG, WPG == 4 ? WAVE_MIN_WAVES : 1) void fk_ro
           cnt_acc[4] += nb <= WAVE_BLK_CAP ? 1 : 0;
           cnt_acc[5] += (unsigned long long)min(nb, 100000);
 #endif
-          if (nb <= WAVE_BLK_CAP) {
+          if (dense_on && nb * 4 >= kblk * 3 && kblk >= 8) {
+            dense_skip = 64;
+          } else if (nb <= WAVE_BLK_CAP) {
             fine_done = true;
             st_blocks += (unsigned int)nb;
             for (int i0 = 0; i0 < nb; i0 += 16) {  // 16 blocks x 4 quads per pass, in ascending candidate order
@@ -1640,7 +1647,7 @@ int pclean_launch_root_flags(pclean_ctx* ctx, int n_groups, const int32_t* gd, c
 
 typedef void (*wave_kernel_t)(const FastRootDev, const WaveItems, uint64_t, uint32_t, uint32_t, int, int, int, const int32_t*,
                               unsigned int*, double*, uint64_t*, int32_t*, int32_t*, unsigned int*, int32_t*, unsigned int*,
-                              const int32_t*, int32_t*, uint64_t*, int32_t*, const int32_t*);
+                              const int32_t*, int32_t*, uint64_t*, int32_t*, const int32_t*, int);
 
 static wave_kernel_t pick_kernel(int n_terms) {
   if (n_terms <= 2) return fk_root_wave_kernel<2, WAVE_SURV_CAP, 4>;
@@ -1689,6 +1696,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   // persistent grid = what is resident at once (a workgroup that starts late would find the counters drained anyway)
   const int wpg = 4;
   wave_kernel_t kern = pick_kernel(fr.n_terms);
+  static const bool no_dense = getenv("PCLEAN_NO_DENSE_SCAN") != nullptr;  // (A/B: the survivor sets are the same either way)
   static int resident[17] = {0};  // per kernel variant (indexed by its term capacity), queried once
   const int variant = fr.n_terms <= 2 ? 2 : fr.n_terms <= 4 ? 4 : fr.n_terms <= 8 ? 8 : fr.n_terms <= 12 ? 12 : 16;
   int& res = resident[variant];
@@ -1740,7 +1748,7 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
   hipLaunchKernelGGL(kern, dim3(wgs), dim3(64 * wpg), 0, ctx->stream, fr, wi, seed, sweep, site, n_draws, it.n, chunk, desc_scratch,
                      chunk_ctr, g_m, g_U, draws_out, overflow_flag, overflow_count, overflow_list, scan_stats,
                      use_worklist ? worklist : nullptr, lazy ? extra->lz_k : nullptr, lazy ? extra->lz_p : nullptr,
-                     lazy ? extra->lz_ns : nullptr, lazy ? extra->eager_rows : nullptr);
+                     lazy ? extra->lz_ns : nullptr, lazy ? extra->eager_rows : nullptr, no_dense ? 0 : 1);
 #ifdef WAVE_PHASE_CLOCK
   if (it.n > 100000) {
     unsigned long long h[16];

@@ -75,6 +75,7 @@ def test_sweeps_are_bit_identical_across_runs_and_paths(capsys):
         "generic kernels": {"PCLEAN_NO_DEDUP": "1", "PCLEAN_NO_GATE": "1", "PCLEAN_NO_MEMO": "1"},
         # a first counter bank of 2 slots: every later counted launch takes its counter from a grown bank (fresh_counter)
         "counter bank exhausted": {"PCLEAN_CTR_BANK": "2"},
+        "two-level scans only": {"PCLEAN_NO_DENSE_SCAN": "1"},
         "read-backs by copies, separate alive kernel, hipMemsetAsync": {"PCLEAN_NO_PUBLISH_REGIONS": "1", "PCLEAN_NO_FUSED_PRIORS": "1",
                                                                         "PCLEAN_NO_ZERO_KERNEL": "1"},
     }
