@@ -692,6 +692,14 @@ class HipContext:
         check(self.h, self.lib.pclean_get_root_stats(self.h, C.byref(r)), "pclean_get_root_stats")
         return r
 
+    def argsort_ids(self, ids, id_max):
+        """np.argsort(ids, kind="stable") for ids in [-1, id_max] on the device (pclean_argsort_ids)"""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        out = np.empty(len(ids), dtype=np.int32)
+        check(self.h, self.lib.pclean_argsort_ids(self.h, C.c_int32(len(ids)), _p(ids, C.c_int32), C.c_int32(int(id_max)),
+                                                  _p(out, C.c_int32)), "pclean_argsort_ids")
+        return out
+
     def set_timed_block(self, block_id):
         """which block's root launch group get_timing().hot_kernel_* / get_root_stats() describe (default 0)"""
         check(self.h, self.lib.pclean_set_timed_block(self.h, C.c_int32(int(block_id))), "pclean_set_timed_block")

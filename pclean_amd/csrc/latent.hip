@@ -400,6 +400,52 @@ struct SideFork {
   }
 };
 
+// ---- stable argsort of small integer ids (the evidence CSR of a latent class: observed rows ordered by the latent row they
+// refer to, inference.jl:60-81's "every row of the class with everything that refers to it") -------------------------------
+__global__ void ids_to_keys_kernel(int n, const int32_t* __restrict__ ids, uint32_t* __restrict__ key, int32_t* __restrict__ idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  key[i] = (uint32_t)(ids[i] + 1);  // (-1 = no referent sorts first)
+  idx[i] = i;
+}
+extern "C" int pclean_argsort_ids(pclean_ctx* ctx, int32_t n, const int32_t* ids, int32_t id_max, int32_t* order_out) {
+  if (!ctx || n < 0 || (n > 0 && (!ids || !order_out)) || id_max < -1)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_argsort_ids: bad arguments");
+  if (n == 0) return PCLEAN_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  SweepState* s = st(ctx);
+  int rc = begin_call(ctx);
+  if (rc) return rc;
+  int32_t* d_ids = scratch<int32_t>(ctx, n);
+  uint32_t* key = scratch<uint32_t>(ctx, n);
+  uint32_t* key_s = scratch<uint32_t>(ctx, n);
+  int32_t* idx = scratch<int32_t>(ctx, n);
+  int32_t* idx_s = scratch<int32_t>(ctx, n);
+  if (!d_ids || !key || !key_s || !idx || !idx_s) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  int bits = 1;
+  while (bits < 32 && ((uint64_t)1 << bits) <= (uint64_t)id_max + 1ull) ++bits;
+  size_t tmp_bytes = 0;
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key, key_s, idx, idx_s, n, 0, bits, ctx->stream));
+  unsigned char* tmp = scratch<unsigned char>(ctx, std::max<size_t>(tmp_bytes, 16));
+  if (!tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  const size_t bytes = (size_t)n * sizeof(int32_t);
+  if (ctx->stage.grow(2 * bytes + 1024)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "page-locked staging alloc failed");
+  ctx->stage.rewind();
+  void* h_in = ctx->stage.take(bytes);
+  void* h_out = ctx->stage.take(bytes);
+  if (!h_in || !h_out) return pclean_fail(ctx, PCLEAN_ERR_HIP, "page-locked staging alloc failed");
+  memcpy(h_in, ids, bytes);
+  HIPCHK(ctx, hipMemcpyAsync(d_ids, h_in, bytes, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(ids_to_keys_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, n, d_ids, key, idx);
+  // (LSD radix sort: stable — rows of one latent row stay in ascending order, as np.argsort(kind="stable") leaves them)
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key, key_s, idx, idx_s, n, 0, bits, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(h_out, idx_s, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PCLEAN_SYNC(ctx);
+  memcpy(order_out, h_out, bytes);
+  (void)s;
+  return PCLEAN_OK;
+}
+
 extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
                                    int32_t block_id, int32_t n_roots, const int32_t* roots, int32_t n_items,
                                    const int32_t* keys, const int32_t* ev_off, const int32_t* ev_rows,

@@ -71,15 +71,19 @@ def stable_argsort_ids(keys):
     return np.argsort(keys, kind="stable")
 
 
-def build_evidence(lw, trace, cname):
+def build_evidence(lw, trace, cname, argsort=None):
     """CSR of observed rows referring (transitively) to each live row of latent class cname,
-    plus the per-evidence-row ctx value of the cross-block JuliaNode terms."""
+    plus the per-evidence-row ctx value of the cross-block JuliaNode terms.  argsort(ids, id_max): a stable argsort of small
+    ids (the engine's device radix sort, pclean_argsort_ids, from 2^17 rows on; default: NumPy's, stable_argsort_ids)."""
     pl = lw.latent_plans[cname]
     bi = pl["src_block"]
     root_cls = lw.blocks[bi]["root_class"]
     t = trace.tables[cname]
     keys = _follow(lw, trace, root_cls, trace.cur[bi], pl["path"])
-    order = stable_argsort_ids(keys).astype(np.int32)
+    if argsort is not None and len(keys) >= (1 << 17):
+        order = argsort(keys, t.n)
+    else:
+        order = stable_argsort_ids(keys).astype(np.int32)
     counts = np.bincount(keys, minlength=t.n)
     live = np.nonzero(t.live[:t.n])[0].astype(np.int32)
     off_all = np.zeros(t.n + 1, dtype=np.int64)
@@ -424,8 +428,9 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
     lw = engine.lw
     pl = lw.latent_plans[cname]
     from ._lib import _ctx_cols
+    dev_sort = getattr(getattr(engine, "hip", None), "argsort_ids", None) if not os.environ.get("PCLEAN_HOST_ARGSORT") else None
     with _timed(f"latent/{cname}/build_evidence"):
-        live, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname)
+        live, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname, dev_sort)
         ev_ctx = _ctx_cols(ev_ctx)  # padded to the library's width once, not in every sub-batch's call
     if len(live) == 0:
         return 0
@@ -469,7 +474,7 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
             if _after_commit(engine, trace, seed):
                 pl = lw.latent_plans[cname]  # (the lowered model was rebuilt in place)
                 # placeholders became drawn strings: per-evidence-row ctx values may have held a dummy's id
-                live2, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname)
+                live2, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname, dev_sort)
                 ev_ctx = _ctx_cols(ev_ctx)
                 assert np.array_equal(live2, live)
     for _ in range(deferred_moves):

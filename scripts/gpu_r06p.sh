@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 6, call P: evidence CSRs sorted on the device: tests + iteration profile with / without
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/r06p
+mkdir -p "$OUT"
+cd "$ROOT"
+timeout 1800 python -m pytest tests/test_gpu_edges.py tests/test_gpu_inference.py tests/test_gpu_determinism.py tests/test_gpu_rents.py tests/test_gpu_flights.py -m gpu -q --tb=short -p no:cacheprovider -x > "$OUT/pytest.log" 2>&1
+echo "pytest rc=$?"; tail -n 3 "$OUT/pytest.log"
+for V in dev host dev host; do
+  E=""; [ $V = host ] && E="PCLEAN_HOST_ARGSORT=1"
+  env $E timeout 900 python scripts/profile_iteration.py --no-cprofile > "$OUT/iter_$V.log" 2> "$OUT/iter_$V.err"
+  echo "$V rc=$?"; grep -v "^\[pclean\]" "$OUT/iter_$V.log" | grep "full iteration" | cut -c1-900
+done

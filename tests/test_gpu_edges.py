@@ -316,3 +316,18 @@ def test_evidence_aggregation_paths_at_the_lds_capacity(oracle):
         assert seen_big  # some class had an evidence set between 1 025 and 2 048 rows
     finally:
         eng.close()
+
+
+def test_device_argsort_of_ids_is_numpys_stable_argsort():
+    """pclean_argsort_ids (the evidence CSR's sort): same permutation as np.argsort(kind="stable") for every size, with ids of
+    -1 (no referent), a single id, more than 2^16 ids"""
+    hip = HipContext(0)
+    try:
+        rng = np.random.default_rng(5)
+        for n, id_max in ((1, 0), (2, 5), (1000, 7), (70000, 70000), (300001, 10660), (1 << 20, 3)):
+            ids = rng.integers(-1, id_max + 1, size=n).astype(np.int32)
+            got = hip.argsort_ids(ids, id_max)
+            assert np.array_equal(got, np.argsort(ids, kind="stable")), (n, id_max)
+        assert len(hip.argsort_ids(np.zeros(0, np.int32), 0)) == 0
+    finally:
+        hip.close()
