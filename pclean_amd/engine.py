@@ -237,7 +237,8 @@ class Engine:
                 t_dbg = self._debug_upload(t_dbg, cname)
             cols, counts = t.view()
             cap = t.n
-            if dc is not None and cname in dc["tables"]:
+            in_dc = dc is not None and cname in dc["tables"]
+            if in_dc:
                 # device-resident commit: the table is uploaded with spare rows (count 0: dead candidates, weight exactly 0)
                 # so that the device can create rows without changing any array's shape
                 cap = dc["cap"].get(cname, 0)
@@ -245,26 +246,31 @@ class Engine:
                 dc["created"][cname] = max(grown, dc["created"].get(cname, 0))
                 if t.n + self._slack_min(cname, t) > cap:
                     cap = dc["cap"][cname] = self._capacity(cname, t)
-                if cap > t.n:
-                    pc = np.zeros((t.n_cols, cap), dtype=np.int32)
-                    pc[:, :t.n] = cols
-                    pk = np.zeros(cap, dtype=np.int64)
-                    pk[:t.n] = counts
-                    cols, counts = pc, pk
             key = (cname, cap)
             prev = last.get(("table", cname))
             alloc = (t.n, len(t.free))
-            if t.cols_dirty or self._uploaded_shape.get(cname) != key:
+            need_cols = t.cols_dirty or self._uploaded_shape.get(cname) != key
+            # (the comparison comes before any padding: most tables of most sub-batches have not moved)
+            if not need_cols and prev is not None and prev[1] == (t.strength, t.discount) and len(prev[0]) >= t.n \
+                    and np.array_equal(prev[0][:t.n], counts) and not prev[0][t.n:].any() \
+                    and (not in_dc or dc["alloc"].get(cname) == alloc):
+                continue  # nothing moved in this table
+            if in_dc and cap > t.n:
+                pk = np.zeros(cap, dtype=np.int64)
+                pk[:t.n] = counts
+                counts = pk
+                if need_cols:
+                    pc = np.zeros((t.n_cols, cap), dtype=np.int32)
+                    pc[:, :t.n] = cols
+                    cols = pc
+            if need_cols:
                 hip.set_table(lw.table_id[cname], np.ascontiguousarray(cols), counts, t.strength, t.discount)
                 t.cols_dirty = False
                 self._uploaded_shape[cname] = key
-            elif prev is not None and prev[1] == (t.strength, t.discount) and np.array_equal(prev[0], counts) \
-                    and (dc is None or cname not in dc["tables"] or dc["alloc"].get(cname) == alloc):
-                continue  # nothing moved in this table
             else:  # only reference counts moved: keep the device columns and their compact byte tables
                 hip.set_table(lw.table_id[cname], None, counts, t.strength, t.discount, n_cols=t.n_cols)
             last[("table", cname)] = (counts.copy(), (t.strength, t.discount))
-            if dc is not None and cname in dc["tables"]:
+            if in_dc:
                 hip.commit_set_table_state(lw.table_id[cname], t.n, t.free)
                 dc["alloc"][cname] = alloc
         if dbg:
