@@ -227,6 +227,12 @@ function commit_pull_table(c, table, cap, n_cols)                               
         (Ptr{Cvoid}, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int64}, Ptr{UInt8}, Ptr{Int32}, Ptr{Int32}), c.h, table, state, cols, counts, live, free, origin))
     state, cols, counts, live, free[1:state[2]], origin
 end
+# stable argsort of small ids on the device (0-based permutation; the sort behind evidence_csr at 10^6 rows)
+function argsort_ids(c, ids::Vector{Int32}, id_max)
+    out = Vector{Int32}(undef, length(ids))
+    GC.@preserve ids out check(c, ccall((:pclean_argsort_ids, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Int32, Ptr{Int32}),
+                                        c.h, length(ids), ids, id_max, out)); out
+end
 # the remaining entry points (pclean_allreduce_stats_fused, pclean_random_*, the debug probes) bind the same way; signatures in
 # include/pclean_hip.h, tested Python bindings in pclean_amd/_lib.py.
 
