@@ -251,4 +251,5 @@ int pclean_launch_prior_terms_ev(pclean_ctx* ctx, int n_items, int P, int n_node
 int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const FastRootDev& fr, uint64_t seed,
                           uint32_t sweep, uint32_t site, int n_draws, double* lse_out, int32_t* draws_out,
                           int32_t* overflow_flag, unsigned int* overflow_count, int32_t* overflow_list = nullptr,
-                          const ChildrenDev* ch = nullptr);
+                          const ChildrenDev* ch = nullptr, uint32_t* dsum = nullptr);  // dsum: [it.n][kpad] zeroed scratch: the
+                                                                                        // weighted sums by a chip-wide kernel first

@@ -279,7 +279,8 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
                                                              int32_t* __restrict__ draws_out,
                                                              int32_t* __restrict__ overflow_flag,
                                                              unsigned int* __restrict__ overflow_count,
-                                                             int32_t* __restrict__ overflow_list, int prior_cut) {
+                                                             int32_t* __restrict__ overflow_list, int prior_cut,
+                                                             const uint32_t* __restrict__ dsum) {
   __shared__ uint64_t s_pref[EV_SURV_CAP + 1];  // exact scores (as doubles), then the fixed-point inclusive prefix (+ the new row)
   __shared__ int32_t s_k[EV_SURV_CAP];
   __shared__ uint64_t s_w64[EV_W];
@@ -297,6 +298,18 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
     const int oi = it.ev_item ? it.ev_item[t] : t;
     // weighted distance sums of the 16 options of quad q over the entries of the plain (compact-table) terms
     auto wsum = [&](int q, uint32_t* acc) {
+      if (dsum) {  // summed beforehand by ev_wsum_kernel (a few latent rows with evidence sets of 10^5 rows and more)
+        const uint4* ds = reinterpret_cast<const uint4*>(dsum + (size_t)t * fr.kpad) + ((size_t)q << 2);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const uint4 c = ds[w];
+          acc[4 * w] = c.x;
+          acc[4 * w + 1] = c.y;
+          acc[4 * w + 2] = c.z;
+          acc[4 * w + 3] = c.w;
+        }
+        return;
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0u;
       for (int f = 0; f < fr.n_terms; ++f) {
@@ -473,9 +486,48 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
   }
 }
 
+// The weighted distance sums D(k) of ev_leaf_block_kernel for launches of a FEW latent rows with huge evidence sets (the one
+// HospitalType row that 10^6 observed rows refer to: options x distinct evidence entries = 4 x 10^8 byte products in ONE
+// workgroup, 12 ms): a grid over (quads of options, item, slices of the evidence entries), every thread adds its slice's
+// share of 16 options with integer atomics — the sums are the same whatever the split.
+__global__ __launch_bounds__(256) void ev_wsum_kernel(const FastRootDev fr, const ItemsDev it, uint32_t* __restrict__ dsum) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+  const int nquads = fr.kpad >> 4;
+  if (q >= nquads) return;
+  const int oi = it.ev_item ? it.ev_item[t] : t;
+  uint32_t acc[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0u;
+  bool any = false;
+  for (int f = 0; f < fr.n_terms; ++f) {
+    if (!fr.terms[f].comp) continue;
+    const AggDev ag = it.agg[f];
+    const int r1 = ag.end ? ag.end[oi] : ag.off[oi + 1];
+    for (int r = ag.off[oi] + (int)blockIdx.z; r < r1; r += (int)gridDim.z) {
+      const uint64_t key = ag.key[r];
+      const int o = (int)(key & 0xffffffull) - 1;
+      if (o < 0) continue;
+      const uint32_t mult = (uint32_t)ag.cnt[r];
+      const uint4 c = reinterpret_cast<const uint4*>(fr.terms[f].comp + (size_t)o * fr.kpad)[q];
+      const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * w + e] += mult * ((cw[w] >> (8 * e)) & 0xffu);
+      any = true;
+    }
+  }
+  if (!any) return;
+  uint32_t* d = dsum + (size_t)t * fr.kpad + ((size_t)q << 4);
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    if (acc[e]) atomicAdd(&d[e], acc[e]);
+}
+
 int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const FastRootDev& fr, uint64_t seed,
                           uint32_t sweep, uint32_t site, int n_draws, double* lse_out, int32_t* draws_out,
-                          int32_t* overflow_flag, unsigned int* overflow_count, int32_t* overflow_list, const ChildrenDev* ch) {
+                          int32_t* overflow_flag, unsigned int* overflow_count, int32_t* overflow_list, const ChildrenDev* ch,
+                          uint32_t* dsum) {
   if (it.n <= 0) return PCLEAN_OK;
   if (n_draws > 1) return pclean_fail(ctx, PCLEAN_ERR_ARG, "evidence-set option lists draw at most once per item");
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
@@ -484,8 +536,13 @@ int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it
   if ((nd.kind == PCLEAN_NODE_FK) != (ch != nullptr))
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "evidence-set scan: a reference slot comes with its children's marginals, an option list without");
   const ChildrenDev none{};
+  if (dsum) {  // (zeroed by the caller) the sums first, over the whole chip
+    const int nquads = fr.kpad >> 4;
+    const int slices = std::max(1, std::min(64, 2048 / std::max(it.n * ((nquads + 255) / 256), 1)));
+    hipLaunchKernelGGL(ev_wsum_kernel, dim3((nquads + 255) / 256, it.n, slices), dim3(256), 0, ctx->stream, fr, it, dsum);
+  }
   hipLaunchKernelGGL(ev_leaf_block_kernel, dim3(wgs), dim3(EV_T), 0, ctx->stream, nd, dn, it, ch ? *ch : none, fr, seed, sweep, site, n_draws,
-                     lse_out, draws_out, overflow_flag, overflow_count, overflow_list, no_prior_cut ? 0 : 1);
+                     lse_out, draws_out, overflow_flag, overflow_count, overflow_list, no_prior_cut ? 0 : 1, (const uint32_t*)dsum);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }

@@ -933,8 +933,18 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
   } else {
     {
       ProfScope ps(ctx, "evidence_option_scan");
+      // a handful of latent rows with evidence sets of 10^4 rows and more each: one workgroup per row would walk options x
+      // evidence entries alone (12 ms for the one HospitalType row of the 1M-row table) — the sums come from a chip-wide kernel
+      uint32_t* dsum = nullptr;
+      static const bool no_split = getenv("PCLEAN_NO_EV_SPLIT") != nullptr;
+      if (!no_split && il.n <= 64 && s->lat_max_ev >= 16384 && fr.kpad >= 256 && (size_t)il.n * fr.kpad * 4 <= ((size_t)1 << 28)) {
+        dsum = scratch<uint32_t>(ctx, (size_t)il.n * fr.kpad);
+        if (!dsum) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+        const int rcz = dev_zero(ctx, dsum, (size_t)il.n * fr.kpad * sizeof(uint32_t));
+        if (rcz) return rcz;
+      }
       rc = pclean_launch_ev_leaf(ctx, nd, it, fr, seed, sweep, site, n_draws, lse_out, draws_out, oflag, over_count, over_list,
-                                 n.kind == PCLEAN_NODE_FK ? &ch : nullptr);
+                                 n.kind == PCLEAN_NODE_FK ? &ch : nullptr, dsum);
     }
     if (!rc && ev_list_mode) {
       ProfScope ps2(ctx, "overflow_rerun");

@@ -125,6 +125,7 @@ def test_full_inference_is_bit_identical_across_the_latent_path_switches(capsys)
         "evidence scans for slots only from 1024 items on": {"PCLEAN_EV_SLOT_MIN_ITEMS": "1024"},
         "common prior in the evidence cut": {"PCLEAN_NO_EV_PRIOR_CUT": "1"},
         "no evidence scans at all": {"PCLEAN_NO_FAST_EV": "1"},
+        "weighted sums of huge evidence sets by the row's own workgroup": {"PCLEAN_NO_EV_SPLIT": "1"},
         "read-backs by copies, hipMemsetAsync": {"PCLEAN_NO_PUBLISH_REGIONS": "1", "PCLEAN_NO_ZERO_KERNEL": "1", "PCLEAN_NO_FUSED_PRIORS": "1"},
     }
     digests = {}
