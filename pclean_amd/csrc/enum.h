@@ -98,6 +98,9 @@ struct ItemsDev {
   // takes item sel[b] and retires when b >= *sel_n — the list and its length never leave the device.  Null: item b.
   const int32_t* sel;
   const unsigned int* sel_n;
+  // grouped launch: group of member position mi, + 1 (the grouping's uid; null: not at hand) — per-member outputs of a
+  // launch whose groups were not cut into pieces (lazy draws) go by position, not by a walk over a group's members
+  const int32_t* grp_uid;
 };
 
 // Log-marginals of the children of a "new row": either one value per item, or a
@@ -229,7 +232,9 @@ int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* lo
 
 int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const ChildrenDev& ch, uint64_t seed,
                        uint32_t sweep, uint32_t site, int n_draws, double* lse_out, double* scores_out,
-                       int32_t* draws_out);
+                       int32_t* draws_out, double* scores_tmp = nullptr);
+// doubles of scratch (scores_tmp) with which the launch above computes its scores one candidate per thread first; 0: not used
+size_t pclean_enum_split_scores(const NodeDev& nd, const ItemsDev& it);
 // cacheable option lists: per-observed-value (maximum, total, coarse prefix) and draws through them (enum_kernels.hip)
 int pclean_leaf_coarse_blocks(int n_options);
 int pclean_launch_leaf_coarse_build(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, int n_blocks, double* lse_out,

@@ -268,12 +268,16 @@ int pclean_launch_gate(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
 #define EV_W (EV_T / 64)
 #define EV_SURV_CAP 2048
 #define EV_FIX_CUTOFF 28.5
+#define EV_ENT_CAP 512     // evidence entries of an item kept in LDS (more: read through the aggregated arrays)
 
 // Round 6: REFERENCE SLOTS too (nd.kind == PCLEAN_NODE_FK: a latent Place re-choosing its County against the ~260 observed
 // rows below it): the candidates' priors are the CRP terms (candidate_score handles the excluded referent), the "new row"
 // candidate (new_score: the children's marginals, evaluated before) is one more entry behind the survivors and one more
 // lower bound of the maximum, and the largest prior of the inequality is the slot's (with / without an excluded reference).
-__global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it, const ChildrenDev ch,
+// EV_QB = quads of options per thread whose byte-row loads are in flight together, MINW = waves per SIMD the register
+// allocation aims at: <4, 2> one workgroup per CU with 256 registers, <2, 4> two with 128 (launches of more rows than CUs)
+template <int EV_QB, int MINW>
+__global__ __launch_bounds__(EV_T, MINW) void ev_leaf_block_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it, const ChildrenDev ch,
                                                              const FastRootDev fr, uint64_t seed, uint32_t sweep,
                                                              uint32_t site, int n_draws, double* __restrict__ lse_out,
                                                              int32_t* __restrict__ draws_out,
@@ -283,6 +287,11 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
                                                              const uint32_t* __restrict__ dsum) {
   __shared__ uint64_t s_pref[EV_SURV_CAP + 1];  // exact scores (as doubles), then the fixed-point inclusive prefix (+ the new row)
   __shared__ int32_t s_k[EV_SURV_CAP];
+  // the item's evidence entries of the plain terms, once per item: byte row of the entry's observed value and its multiplicity
+  // (the passes below walk them for every quad of options: read through the aggregated arrays they were a chain of two
+  // dependent loads per (quad, entry), one quad at a time)
+  __shared__ uint64_t s_erow[EV_ENT_CAP];
+  __shared__ uint32_t s_emul[EV_ENT_CAP];
   __shared__ uint64_t s_w64[EV_W];
   __shared__ double s_wd[EV_W];
   __shared__ int s_wi[EV_W];
@@ -296,6 +305,26 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
   for (int t = blockIdx.x; t < it.n; t += gridDim.x) {
     const ItemView v = item_view(nd, it, t);
     const int oi = it.ev_item ? it.ev_item[t] : t;
+    // ---- the entries -> LDS (uniform counts: every thread reads the same offsets)
+    int n_ent = 0;
+    if (!dsum) {
+      for (int f = 0; f < fr.n_terms; ++f) {
+        if (!fr.terms[f].comp) continue;
+        const AggDev ag = it.agg[f];
+        const int r0 = ag.off[oi], r1 = ag.end ? ag.end[oi] : ag.off[oi + 1];
+        for (int r = r0 + tid; r < r1; r += EV_T) {
+          const int idx = n_ent + (r - r0);
+          if (idx < EV_ENT_CAP) {
+            const int o = (int)(ag.key[r] & 0xffffffull) - 1;
+            s_erow[idx] = o < 0 ? (uint64_t)fr.zero_row : (uint64_t)(fr.terms[f].comp + (size_t)o * fr.kpad);
+            s_emul[idx] = o < 0 ? 0u : (uint32_t)ag.cnt[r];
+          }
+        }
+        n_ent += r1 - r0;
+      }
+    }
+    const bool ent_lds = !dsum && n_ent <= EV_ENT_CAP;
+    __syncthreads();
     // weighted distance sums of the 16 options of quad q over the entries of the plain (compact-table) terms
     auto wsum = [&](int q, uint32_t* acc) {
       if (dsum) {  // summed beforehand by ev_wsum_kernel (a few latent rows with evidence sets of 10^5 rows and more)
@@ -330,16 +359,50 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
         }
       }
     };
+    // ... of the EV_QB quads qb, qb + EV_T, ... at once: per entry the EV_QB loads are in flight together (integer sums: the
+    // same whatever the order)
+    auto wsum_batch = [&](int qb, uint32_t (*acc)[16]) {
+      if (!ent_lds) {
+#pragma unroll
+        for (int u = 0; u < EV_QB; ++u)
+          if (qb + u * EV_T < nquads) wsum(qb + u * EV_T, acc[u]);
+        return;
+      }
+#pragma unroll
+      for (int u = 0; u < EV_QB; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[u][e] = 0u;
+      for (int r = 0; r < n_ent; ++r) {
+        const uint4* row = reinterpret_cast<const uint4*>(s_erow[r]);
+        const uint32_t mult = s_emul[r];
+        uint4 c[EV_QB];
+#pragma unroll
+        for (int u = 0; u < EV_QB; ++u) c[u] = qb + u * EV_T < nquads ? row[qb + u * EV_T] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int u = 0; u < EV_QB; ++u) {
+          const uint32_t cw[4] = {c[u].x, c[u].y, c[u].z, c[u].w};
+#pragma unroll
+          for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[u][4 * w + e] += mult * ((cw[w] >> (8 * e)) & 0xffu);
+        }
+      }
+    };
     // ---- pass A: the live option with the smallest weighted distance -> lower bound of the maximum
     uint64_t best = ~0ull;
-    for (int q = tid; q < nquads; q += EV_T) {
-      uint32_t acc[16];
-      wsum(q, acc);
-      const uint32_t al = fr.alive[q];
+    for (int qb = tid; qb < nquads; qb += EV_QB * EV_T) {
+      uint32_t acc[EV_QB][16];
+      wsum_batch(qb, acc);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const uint64_t key = ((uint64_t)acc[e] << 32) | (uint32_t)((q << 4) + e);
-        if (((al >> e) & 1u) && key < best) best = key;
+      for (int u = 0; u < EV_QB; ++u) {
+        const int q = qb + u * EV_T;
+        if (q >= nquads) break;
+        const uint32_t al = fr.alive[q];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const uint64_t key = ((uint64_t)acc[u][e] << 32) | (uint32_t)((q << 4) + e);
+          if (((al >> e) & 1u) && key < best) best = key;
+        }
       }
     }
     for (int sh = 32; sh > 0; sh >>= 1) {
@@ -369,49 +432,62 @@ __global__ __launch_bounds__(EV_T) void ev_leaf_block_kernel(const NodeDev nd, c
       if (x >= 0.0 && x < 4.0e9) dcut = (uint32_t)x + 2u;
       if (prior_cut) pri = (fk && v.excl >= 0) ? fr.prior_e : fr.prior_n;
     }
-    // ---- pass B: survivors in ascending option order
+    // ---- pass B: survivors in ascending option order (rounds of EV_T quads, EV_QB rounds summed at a time)
     int ns = 0;
-    for (int q0 = 0; q0 < nquads; q0 += EV_T) {
-      const int q = q0 + tid;
-      uint32_t mask16 = 0;
-      if (q < nquads) {
-        uint32_t acc[16];
-        wsum(q, acc);
+    for (int q0 = 0; q0 < nquads; q0 += EV_QB * EV_T) {
+      uint32_t masks[EV_QB];
+      {
+        uint32_t acc[EV_QB][16];
+        wsum_batch(q0 + tid, acc);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) mask16 |= (acc[e] <= dcut ? 1u : 0u) << e;
-        mask16 &= (uint32_t)fr.alive[q];
-        // the same inequality with the option's OWN prior in place of the largest one: score(k) <= prior(k) - c_min D(k).
-        // A latent row with one or two referring rows has a weak bound (the best option's letter-model prior is tens of
-        // nats below the shortest string's): under the common cut every option within ~20 edits survived and the row went
-        // to the generic kernel (a fifth of a Hospital sub-batch's time for 7 % of its rows)
-        if (pri && mask16) {
+        for (int u = 0; u < EV_QB; ++u) {
+          const int q = q0 + u * EV_T + tid;
+          uint32_t mask16 = 0;
+          if (q < nquads) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e)
-            if ((mask16 >> e) & 1u) {
-              const double x = (pri[(q << 4) + e] - bound + EV_FIX_CUTOFF) * fr.inv_c + 2.0;
-              if (!((double)acc[e] <= x)) mask16 &= ~(1u << e);
+            for (int e = 0; e < 16; ++e) mask16 |= (acc[u][e] <= dcut ? 1u : 0u) << e;
+            mask16 &= (uint32_t)fr.alive[q];
+            // the same inequality with the option's OWN prior in place of the largest one: score(k) <= prior(k) - c_min D(k).
+            // A latent row with one or two referring rows has a weak bound (the best option's letter-model prior is tens of
+            // nats below the shortest string's): under the common cut every option within ~20 edits survived and the row went
+            // to the generic kernel (a fifth of a Hospital sub-batch's time for 7 % of its rows)
+            if (pri && mask16) {
+#pragma unroll
+              for (int e = 0; e < 16; ++e)
+                if ((mask16 >> e) & 1u) {
+                  const double x = (pri[(q << 4) + e] - bound + EV_FIX_CUTOFF) * fr.inv_c + 2.0;
+                  if (!((double)acc[u][e] <= x)) mask16 &= ~(1u << e);
+                }
             }
+          }
+          masks[u] = mask16;
         }
       }
-      const int cnt = __builtin_popcount(mask16);
-      int incl = cnt;
-      for (int sh = 1; sh < 64; sh <<= 1) {
-        const int x = __shfl_up(incl, sh, 64);
-        if (lane >= sh) incl += x;
+#pragma unroll
+      for (int u = 0; u < EV_QB; ++u) {
+        if (q0 + u * EV_T >= nquads) break;  // (uniform)
+        const int q = q0 + u * EV_T + tid;
+        const uint32_t mask16 = masks[u];
+        const int cnt = __builtin_popcount(mask16);
+        int incl = cnt;
+        for (int sh = 1; sh < 64; sh <<= 1) {
+          const int x = __shfl_up(incl, sh, 64);
+          if (lane >= sh) incl += x;
+        }
+        if (lane == 63) s_wi[wave] = incl;
+        __syncthreads();
+        int pos = ns + incl - cnt, round_total = 0;
+        for (int w = 0; w < EV_W; ++w) {
+          if (w < wave) pos += s_wi[w];
+          round_total += s_wi[w];
+        }
+        for (uint32_t mm = mask16; mm; mm &= mm - 1) {
+          if (pos < EV_SURV_CAP) s_k[pos] = (q << 4) + __builtin_ctz(mm);
+          ++pos;
+        }
+        ns += round_total;
+        __syncthreads();  // s_wi is rewritten by the next round
       }
-      if (lane == 63) s_wi[wave] = incl;
-      __syncthreads();
-      int pos = ns + incl - cnt, round_total = 0;
-      for (int w = 0; w < EV_W; ++w) {
-        if (w < wave) pos += s_wi[w];
-        round_total += s_wi[w];
-      }
-      for (uint32_t mm = mask16; mm; mm &= mm - 1) {
-        if (pos < EV_SURV_CAP) s_k[pos] = (q << 4) + __builtin_ctz(mm);
-        ++pos;
-      }
-      ns += round_total;
-      __syncthreads();  // s_wi is rewritten by the next round
     }
     if (ns > EV_SURV_CAP) {
       if (tid == 0) {
@@ -541,7 +617,10 @@ int pclean_launch_ev_leaf(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it
     const int slices = std::max(1, std::min(64, 2048 / std::max(it.n * ((nquads + 255) / 256), 1)));
     hipLaunchKernelGGL(ev_wsum_kernel, dim3((nquads + 255) / 256, it.n, slices), dim3(256), 0, ctx->stream, fr, it, dsum);
   }
-  hipLaunchKernelGGL(ev_leaf_block_kernel, dim3(wgs), dim3(EV_T), 0, ctx->stream, nd, dn, it, ch ? *ch : none, fr, seed, sweep, site, n_draws,
+  static const int force_qb = getenv("PCLEAN_EV_QB") ? atoi(getenv("PCLEAN_EV_QB")) : 0;  // (A/B: 1 = the one-quad walk, 2, 4)
+  const int qb = force_qb ? force_qb : (it.n > 256 ? 2 : 4);
+  auto kern = qb == 1 ? ev_leaf_block_kernel<1, 3> : qb == 2 ? ev_leaf_block_kernel<2, 4> : ev_leaf_block_kernel<4, 2>;
+  hipLaunchKernelGGL(kern, dim3(wgs), dim3(EV_T), 0, ctx->stream, nd, dn, it, ch ? *ch : none, fr, seed, sweep, site, n_draws,
                      lse_out, draws_out, overflow_flag, overflow_count, overflow_list, no_prior_cut ? 0 : 1, (const uint32_t*)dsum);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
@@ -574,11 +653,13 @@ __global__ __launch_bounds__(BT) void enum_node_kernel(const NodeDev nd, const D
                                                         uint32_t site, int n_draws, int item_base,
                                                         double* __restrict__ lse_out,
                                                         double* __restrict__ scores_out,
-                                                        int32_t* __restrict__ draws_out) {
+                                                        int32_t* __restrict__ draws_out,
+                                                        const double* __restrict__ scores_in, int slot_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   int g = blockIdx.x + item_base;
+  const int slot_in = g;  // (scores_in: row of the scores enum_scores_kernel left for this workgroup)
   if (it.sel) {  // (never together with groups)
     if ((unsigned int)g >= *it.sel_n) return;
     g = it.sel[g];
@@ -597,17 +678,26 @@ __global__ __launch_bounds__(BT) void enum_node_kernel(const NodeDev nd, const D
 
   // ---- phase 1: scores ----------------------------------------------------
   double lmax = -__builtin_inf();
-  for (int k = tid; k < n; k += BT) {
-    const double sk = candidate_score(nd, dn, it, v, k);
-    s[k] = sk;
-    if (scores_out) scores_out[(size_t)to * nc + k] = sk;
-    lmax = fmax(lmax, sk);
-  }
-  if (fk && tid == 0) {
-    const double sn = new_score(nd, ch, v, to);
-    s[n] = sn;
-    if (scores_out) scores_out[(size_t)to * nc + n] = sn;
-    lmax = fmax(lmax, sn);
+  if (scores_in && slot_in < slot_cap) {  // computed beforehand by enum_scores_kernel, one candidate per thread over the whole chip
+    const double* si = scores_in + (size_t)slot_in * nc;
+    for (int k = tid; k < nc; k += BT) {
+      const double sk = si[k];
+      s[k] = sk;
+      lmax = fmax(lmax, sk);
+    }
+  } else {
+    for (int k = tid; k < n; k += BT) {
+      const double sk = candidate_score(nd, dn, it, v, k);
+      s[k] = sk;
+      if (scores_out) scores_out[(size_t)to * nc + k] = sk;
+      lmax = fmax(lmax, sk);
+    }
+    if (fk && tid == 0) {
+      const double sn = new_score(nd, ch, v, to);
+      s[n] = sn;
+      if (scores_out) scores_out[(size_t)to * nc + n] = sn;
+      lmax = fmax(lmax, sn);
+    }
   }
   // ---- phase 2: max ----------------------------------------------------------
   lmax = wave_max(lmax);
@@ -670,6 +760,35 @@ __global__ __launch_bounds__(BT) void enum_node_kernel(const NodeDev nd, const D
   }
 }
 
+// Few items with long candidate lists and evidence sets (a latent sub-batch's rows the evidence scan could not settle, the
+// generic launches of its other nodes): one workgroup per item walks ~10 candidates per thread, each a chain of dependent
+// gathers through the aggregated evidence and the pair tables — 60-100 us of latency with most of the chip idle.  Here the
+// exact scores come from ONE CANDIDATE PER THREAD over (item, candidate) — the same candidate_score() / new_score(), so the
+// same bits — and enum_node_kernel's workgroup per item starts from them (scores_in).  Workgroup (x, y): candidates
+// 256 x .. 256 x + 255 of the slots y, y + gridDim.y, ...; an indirect launch stops at the list's length.
+__global__ __launch_bounds__(256) void enum_scores_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it, const ChildrenDev ch,
+                                                          double* __restrict__ scores, int slot_cap) {
+  const int n = nd.n_cand;
+  const bool fk = nd.kind == PCLEAN_NODE_FK;
+  const int nc = n + (fk ? 1 : 0);
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nc) return;
+  // (slot_cap: rows of `scores`; the workgroups of later slots compute their scores themselves)
+  const int n_slots = min(it.sel ? (int)min(*it.sel_n, (unsigned int)it.n) : it.n, slot_cap);
+  for (int slot = blockIdx.y; slot < n_slots; slot += gridDim.y) {
+    const int t = it.sel ? it.sel[slot] : slot;
+    const ItemView v = item_view(nd, it, t);
+    double sk;
+    if (k < n) {
+      sk = candidate_score(nd, dn, it, v, k);
+    } else {
+      const int to = it.out_pos ? it.out_pos[t] : t;
+      sk = new_score(nd, ch, v, to);
+    }
+    scores[(size_t)slot * nc + k] = sk;
+  }
+}
+
 // BT threads per item: 256 for launches that fill the chip, 1024 for the few-item launches of the latent sweeps (the
 // re-run of a sub-batch's overflowed rows: a dozen workgroups, each walking the whole option list three times)
 template <int BT>
@@ -678,12 +797,14 @@ __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, con
                                                             uint32_t site, int n_draws, int item_base,
                                                             double* __restrict__ lse_out,
                                                             double* __restrict__ scores_out,
-                                                            int32_t* __restrict__ draws_out) {
+                                                            int32_t* __restrict__ draws_out,
+                                                            const double* __restrict__ scores_in, int slot_cap) {
   __shared__ double red[BT / 64];
   __shared__ uint64_t wsum[BT / 64];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   int t = blockIdx.x + item_base;
+  const int slot_in = t;  // (scores_in: row of the scores enum_scores_kernel left for this workgroup)
   if (it.sel) {
     if ((unsigned int)t >= *it.sel_n) return;
     t = it.sel[t];
@@ -693,12 +814,16 @@ __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, con
   const bool fk = nd.kind == PCLEAN_NODE_FK;
   const int nc = n + (fk ? 1 : 0);
   const ItemView v = item_view(nd, it, t);
-  const double sn = fk ? new_score(nd, ch, v, to) : -__builtin_inf();
+  // the three passes below re-compute a score wherever they need it — or read it from the row enum_scores_kernel left (a list
+  // beyond LDS of a few-item launch: 40 candidates per thread and pass, each a chain of gathers, became three streamed reads)
+  const double* si = (scores_in && slot_in < slot_cap) ? scores_in + (size_t)slot_in * nc : nullptr;
+  const double sn = !fk ? -__builtin_inf() : (si ? si[n] : new_score(nd, ch, v, to));
+  auto score_of = [&](int k) -> double { return si ? si[k] : candidate_score(nd, dn, it, v, k); };
 
   // pass A: max (lane-strided, coalesced)
   double lmax = -__builtin_inf();
   for (int k = tid; k < n; k += BT) {
-    const double sk = candidate_score(nd, dn, it, v, k);
+    const double sk = score_of(k);
     if (scores_out) scores_out[(size_t)to * nc + k] = sk;
     lmax = fmax(lmax, sk);
   }
@@ -718,7 +843,7 @@ __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, con
   uint64_t part = 0;
   if (m != -__builtin_inf())
     for (int k = lo; k < hi; ++k) {
-      const double sk = (k == n) ? sn : candidate_score(nd, dn, it, v, k);
+      const double sk = (k == n) ? sn : score_of(k);
       part += pclean_fixw(sk - m);
     }
   uint64_t U;
@@ -741,7 +866,7 @@ __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, con
         uint64_t acc = pre;
         int k = lo;
         for (; k < hi; ++k) {
-          const double sk = (k == n) ? sn : candidate_score(nd, dn, it, v, k);
+          const double sk = (k == n) ? sn : score_of(k);
           acc += pclean_fixw(sk - m);
           if (acc > x) break;
         }
@@ -1090,9 +1215,27 @@ int pclean_launch_prior_terms_ev(pclean_ctx* ctx, int n_items, int P, int n_node
   return PCLEAN_OK;
 }
 
+// rows of the split launch's score scratch: every item of a direct launch within 256 MB, and of an indirect one (its
+// device-side list is usually a few per cent of the items) at most 64 — later workgroups compute their scores themselves
+static int pclean_enum_split_slots(const ItemsDev& it, int nc) {
+  const size_t fit = std::max<size_t>(((size_t)32 << 20) / (size_t)std::max(nc, 1), 1);
+  return (int)std::min<size_t>(std::min<size_t>((size_t)it.n, fit), it.sel ? 64 : (size_t)it.n);
+}
+// doubles of scratch with which pclean_launch_enum computes the scores of this launch one candidate per thread first
+// (enum_scores_kernel); 0: the launch would not use them (many items, short lists, no evidence sets, scores beyond LDS)
+size_t pclean_enum_split_scores(const NodeDev& nd, const ItemsDev& it) {
+  static const bool off = getenv("PCLEAN_NO_ENUM_SPLIT") != nullptr;
+  const int nc = nd.n_cand + (nd.kind == PCLEAN_NODE_FK ? 1 : 0);
+  const size_t lds = (size_t)((nc + 1) & ~1) * 8 + (16 + 64) * 8;
+  const bool few = it.n <= 1024 || (it.sel && it.n <= 16384);
+  (void)lds;
+  if (off || !few || it.grp_off || !it.ev_lo || nc < 2048) return 0;
+  return (size_t)pclean_enum_split_slots(it, nc) * nc;
+}
+
 int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const ChildrenDev& ch, uint64_t seed,
                        uint32_t sweep, uint32_t site, int n_draws, double* lse_out, double* scores_out,
-                       int32_t* draws_out) {
+                       int32_t* draws_out, double* scores_tmp) {
   if (it.n <= 0) return PCLEAN_OK;
   const int nc = nd.n_cand + (nd.kind == PCLEAN_NODE_FK ? 1 : 0);
   const size_t lds = (size_t)((nc + 1) & ~1) * 8 + (16 + 64) * 8;
@@ -1112,12 +1255,20 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
   if (it.sel && it.grp_off) return pclean_fail(ctx, PCLEAN_ERR_ARG, "indirect launches are not grouped");
   if (lds > 160 * 1024 || (lds > big_from && !it.grp_off && !scores_out && n_draws <= 1 && (!few || big_few))) {
     if (few) {  // too few workgroups to fill the chip: more threads per item
+      const double* scores_in = nullptr;
+      int slot_cap = 0;
+      if (scores_tmp && !it.grp_off && !scores_out) {  // ... and the scores first, one candidate per thread (enum_scores_kernel)
+        slot_cap = pclean_enum_split_slots(it, nc);
+        hipLaunchKernelGGL(enum_scores_kernel, dim3((nc + 255) / 256, std::min(slot_cap, 1024)), dim3(256), 0, ctx->stream, nd, dn, it,
+                           ch, scores_tmp, slot_cap);
+        scores_in = scores_tmp;
+      }
       hipLaunchKernelGGL(enum_node_big_kernel<1024>, dim3(it.n), dim3(1024), 0, ctx->stream, nd, dn, it, ch, seed, sweep, site,
-                         n_draws, 0, lse_out, scores_out, draws_out);
+                         n_draws, 0, lse_out, scores_out, draws_out, scores_in, slot_cap);
     } else {
       for (int base = 0; base < it.n; base += kMaxBlocks)
         hipLaunchKernelGGL(enum_node_big_kernel<256>, dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), 0, ctx->stream, nd,
-                           dn, it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out);
+                           dn, it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out, (const double*)nullptr, 0);
     }
   } else {
     static bool attr_set = false;
@@ -1129,12 +1280,21 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
       attr_set = true;
     }
     if (few) {  // (groups or items) too few workgroups to fill the chip: more threads per item
+      // ... and, with scratch for them (pclean_enum_split_scores), the scores first, one candidate per thread
+      const double* scores_in = nullptr;
+      int slot_cap = 0;
+      if (scores_tmp && !it.grp_off && !scores_out) {
+        slot_cap = pclean_enum_split_slots(it, nc);
+        hipLaunchKernelGGL(enum_scores_kernel, dim3((nc + 255) / 256, std::min(slot_cap, 1024)), dim3(256), 0, ctx->stream, nd, dn, it,
+                           ch, scores_tmp, slot_cap);
+        scores_in = scores_tmp;
+      }
       hipLaunchKernelGGL(enum_node_kernel<1024>, dim3(it.n), dim3(1024), lds, ctx->stream, nd, dn, it, ch, seed, sweep, site,
-                         n_draws, 0, lse_out, scores_out, draws_out);
+                         n_draws, 0, lse_out, scores_out, draws_out, scores_in, slot_cap);
     } else {
       for (int base = 0; base < it.n; base += kMaxBlocks)
         hipLaunchKernelGGL(enum_node_kernel<256>, dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), lds, ctx->stream, nd, dn,
-                           it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out);
+                           it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out, (const double*)nullptr, 0);
     }
   }
   HIPCHK(ctx, hipGetLastError());

@@ -495,6 +495,12 @@ __global__ void group_scatter_f64_kernel(int n, const int32_t* list, const int32
   for (int mi = grp_off[g]; mi < hi; ++mi) dst[members[mi]] = v;
 }
 
+// ... of EVERY group, by member position (uid[mi] - 1 = the group of position mi): no thread walks a large group alone
+__global__ void member_scatter_f64_kernel(int n_pos, const int32_t* uid, const int32_t* members, const double* src, double* dst) {
+  const int mi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mi < n_pos) dst[members[mi]] = src[uid[mi] - 1];
+}
+
 int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, const int32_t* excl,
                      uint64_t seed, uint32_t sweep, int n_draws, double* lse_out, int32_t* draws_out,
                      double* scores_out, const double* snew_override, bool time_it) {
@@ -504,6 +510,17 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
   const SweepState::LazyReq lazy_req = s->lazy_req;  // (this evaluation's; the children's evaluations below must not see it)
   s->lazy_req = SweepState::LazyReq();
   s->lazy_out.valid = false;
+  // lazy draws (the sweep's last block, see RootExtra): asked for and possible for this list of items
+  static const bool no_lazy = getenv("PCLEAN_NO_LAZY_DRAWS") != nullptr;
+  const bool lazy_ok = lazy_req.on && !no_lazy && n_draws > 1 && !il.rng_row && !il.ev_lo;
+  // groups of a compact-table launch: a large group is cut into pieces of at most ~2 x 256 / n_draws member items (a wave
+  // writes n_draws draws per member, see item_head_kernel) — unless the launch leaves lists instead of draws: nothing is
+  // written per member then, and the pieces (a third of the Measure slot's groups) were descriptors, hand-outs and list
+  // copies for nothing (PCLEAN_LAZY_SPLIT=1: cut them all the same)
+  static const bool lazy_split = getenv("PCLEAN_LAZY_SPLIT") != nullptr;
+  // (il.n bounds the number of groups: the lists of the launch are sure to fit, see the launch below)
+  const bool lazy_sure = lazy_ok && (size_t)il.n * ROOT_LZ_CAP * 12 <= ((size_t)4 << 30);
+  const int fast_split_m = (lazy_sure && !lazy_split) ? 0 : std::max(4, 256 / std::max(n_draws, 1));
   NodeDev nd;
   int rc = build_node_dev(ctx, b, node_id, nd);
   if (rc) return rc;
@@ -580,7 +597,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
         if (fast < 0) return fast;
         fast_tried = true;
         if (fast) {
-          rc = make_item_groups(ctx, block_id, node_id, il, excl, g_pre, std::max(4, 256 / std::max(n_draws, 1)));
+          rc = make_item_groups(ctx, block_id, node_id, il, excl, g_pre, fast_split_m);
           if (rc) return rc;
           groups_tried = true;
           pre_grouped = g_pre.n_groups > 0;
@@ -664,8 +681,12 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
           if (!dst) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
           rc = eval_node_lse(ctx, block_id, cid, sil, child_excl, seed, sweep, dst);
           if (rc) return rc;
-          hipLaunchKernelGGL(group_scatter_f64_kernel, grid1(sil.n), dim3(256), 0, ctx->stream, sil.n, list_g, g_pre.grp_off,
-                             g_pre.members, dst, child_lse);
+          if (!list_g && g_pre.uid && fast_split_m == 0)  // (unsplit groups may be large)
+            hipLaunchKernelGGL(member_scatter_f64_kernel, grid1(il.n), dim3(256), 0, ctx->stream, il.n, g_pre.uid, g_pre.members, dst,
+                               child_lse);
+          else
+            hipLaunchKernelGGL(group_scatter_f64_kernel, grid1(sil.n), dim3(256), 0, ctx->stream, sil.n, list_g, g_pre.grp_off,
+                               g_pre.members, dst, child_lse);
         }
       } else {
       int32_t* list = nullptr;
@@ -799,13 +820,14 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
       ItemGroups g = g_pre;
       // wave kernel: at most ~2 x 256 draws per group (see item_head_kernel)
       if (!groups_tried) {
-        rc = make_item_groups(ctx, block_id, node_id, il, excl, g, fast ? std::max(4, 256 / std::max(n_draws, 1)) : 0);
+        rc = make_item_groups(ctx, block_id, node_id, il, excl, g, fast ? fast_split_m : 0);
         if (rc) return rc;
       }
       if (g.n_groups > 0) {
         it.n = g.n_groups;
         it.grp_off = g.grp_off;
         it.members = g.members;
+        if (fast && fast_split_m == 0) it.grp_uid = g.uid;  // (unsplit groups: per-member outputs by position)
         ggrp = g;
       }
     }
@@ -831,7 +853,12 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
   if (!fast && !fast_ev) {
     ProfScope ps(ctx, n.kind == PCLEAN_NODE_FK ? "enum_fk_generic" : "enum_leaf_generic");
     if (time_it) (void)hipEventRecord(s->ev0, ctx->stream);
-    rc = pclean_launch_enum(ctx, nd, it, ch, seed, sweep, site, n_draws, lse_out, scores_out, draws_out);
+    double* sc_tmp = nullptr;  // (few items with evidence sets and long lists: the scores one candidate per thread first)
+    if (!scores_out) {
+      const size_t sc_n = pclean_enum_split_scores(nd, it);
+      if (sc_n && !(sc_tmp = scratch<double>(ctx, sc_n))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+    }
+    rc = pclean_launch_enum(ctx, nd, it, ch, seed, sweep, site, n_draws, lse_out, scores_out, draws_out, sc_tmp);
     if (time_it) (void)hipEventRecord(s->ev1, ctx->stream);
     return rc;
   }
@@ -881,8 +908,7 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
     RootExtra ex{};
     bool use_ex = false;
     // lazy draws (the sweep's last block): lists instead of n_draws draws per member item
-    static const bool no_lazy = getenv("PCLEAN_NO_LAZY_DRAWS") != nullptr;
-    if (lazy_req.on && !no_lazy && n_draws > 1 && !it.rng_row && !it.particle && !it.out_pos && !il.ev_lo &&
+    if (lazy_ok && !it.particle && !it.out_pos &&
         (size_t)it.n * ROOT_LZ_CAP * 12 <= ((size_t)4 << 30)) {
       ex.lz_k = scratch<int32_t>(ctx, (size_t)it.n * ROOT_LZ_CAP);
       ex.lz_p = scratch<uint64_t>(ctx, (size_t)it.n * ROOT_LZ_CAP);
@@ -951,7 +977,10 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
       ItemsDev itr = it;
       itr.sel = over_list;
       itr.sel_n = over_count;
-      return pclean_launch_enum(ctx, nd, itr, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out);
+      double* sc_tmp = nullptr;
+      const size_t sc_n = pclean_enum_split_scores(nd, itr);
+      if (sc_n && !(sc_tmp = scratch<double>(ctx, sc_n))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      return pclean_launch_enum(ctx, nd, itr, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out, sc_tmp);
     }
   }
   if (rc) return rc;
@@ -1004,7 +1033,12 @@ int eval_node(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, co
       done = pclean_launch_overflow_fast(ctx, fr, it2, ch, seed, sweep, site, n_draws, lse_out, draws_out, nullptr, nullptr);
       if (done < 0) return done;
     }
-    if (!done) rc = pclean_launch_enum(ctx, nd, it2, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out);
+    if (!done) {
+      double* sc_tmp = nullptr;
+      const size_t sc_n = pclean_enum_split_scores(nd, it2);
+      if (sc_n && !(sc_tmp = scratch<double>(ctx, sc_n))) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+      rc = pclean_launch_enum(ctx, nd, it2, ch, seed, sweep, site, n_draws, lse_out, nullptr, draws_out, sc_tmp);
+    }
   }
   return rc;
 }

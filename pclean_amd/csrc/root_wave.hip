@@ -560,7 +560,8 @@ __global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, 
                                                            uint64_t* __restrict__ g_U, int32_t* __restrict__ draws_out,
                                                            unsigned int* __restrict__ scan_stats,
                                                            int32_t* __restrict__ worklist, unsigned int* __restrict__ work_n,
-                                                           int seg_cap, int32_t* __restrict__ lz_ns) {
+                                                           int seg_cap, int32_t* __restrict__ lz_ns, int32_t* __restrict__ lz_k,
+                                                           uint64_t* __restrict__ lz_p, const int32_t* __restrict__ eager_rows) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = tid / SETTLE_L, l = tid % SETTLE_L;
   const int lane = threadIdx.x & 63, base = lane & ~(SETTLE_L - 1);
@@ -648,14 +649,22 @@ __global__ __launch_bounds__(256) void group_settle_kernel(const SettleArgs sa, 
   const bool settled = eligible && (b_excl & gmask) != 0ull && (b_other & gmask) == 0ull;
   if (settled) {
     const int res_val = sn > score_cur ? PCLEAN_CHOICE_NEW : excl;
+    // lazy draws: a settled group's list is its one live entry with the whole mass (or no entry at all: the new row), and
+    // lazy_draw_kernel's search returns it for every random number — no draw is written per member here (the groups of a
+    // lazy launch are not cut into pieces); the rows of eager_rows get every draw now, as in the scan kernel
+    const bool lazy = lz_ns && !(eager_rows && eager_rows[word(3)] != 0);
     if (l == 0) {
       d[7] = flags | 8;
       g_m[g] = hi;
       g_U[g] = PCLEAN_FIX_ONE;
-      if (lz_ns) lz_ns[g] = -1;  // (lazy draws: this group's are all written, right here)
+      if (lz_ns) lz_ns[g] = !lazy ? -1 : (res_val == excl ? 1 : 0);
+      if (lazy && res_val == excl) {
+        lz_k[(size_t)g * ROOT_LZ_CAP] = excl;
+        lz_p[(size_t)g * ROOT_LZ_CAP] = PCLEAN_FIX_ONE;
+      }
     }
     const int m_lo = word(0), m_hi = word(1), t0 = word(2);
-    const int n_out = (m_hi - m_lo) * n_draws;
+    const int n_out = lazy ? 0 : (m_hi - m_lo) * n_draws;
     for (int q = l; q < n_out; q += SETTLE_L) {
       const int mi = m_lo + q / n_draws, j = q % n_draws;
       const int tm = wi.members ? wi.members[mi] : t0;
@@ -1476,6 +1485,20 @@ __global__ void group_lse_kernel(int n_groups, const int32_t* __restrict__ grp_o
   for (int mi = grp_off[g]; mi < hi; ++mi) lse_out[out_pos ? out_pos[members[mi]] : members[mi]] = lse;
 }
 
+// the same by MEMBER POSITION (uid[mi] - 1 = the group of position mi): a launch whose groups are not cut into pieces may hold
+// groups of thousands of rows, and a thread walking one of them alone was the launch group's tail
+__global__ void member_lse_kernel(int n_pos, const int32_t* __restrict__ uid, const int32_t* __restrict__ members,
+                                  const int32_t* __restrict__ out_pos, const double* __restrict__ g_m,
+                                  const uint64_t* __restrict__ g_U, double* __restrict__ lse_out) {
+  const int mi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (mi >= n_pos) return;
+  const int g = uid[mi] - 1;
+  const double m = g_m[g];
+  if (m != m) return;  // overflowed group: the re-run writes its items
+  const int tm = members[mi];
+  lse_out[out_pos ? out_pos[tm] : tm] = pclean_lse_from_fix(m, g_U[g]);
+}
+
 // ---- overflow_lds_kernel: the items whose pre-filter survivor list overflowed (flat posteriors), re-run over ALL
 // candidates.  Same contract and results as enum_node_kernel (enum_kernels.hip) — scores in LDS, fixed-point
 // weights in place, chunk sums + block scan, binary-search draws — but phase 1 scores through the candidate-compact
@@ -1741,7 +1764,8 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
     const int seg_cap = (int)((n_wg / WL_SEGS + 1) * 16);  // 16 groups per workgroup, workgroups dealt round-robin
     int32_t* seg_list = worklist + ng;
     hipLaunchKernelGGL(group_settle_kernel, dim3(n_wg), dim3(256), 0, ctx->stream, sa, ws, it.n, n_draws, desc_scratch, g_m, g_U,
-                       draws_out, scan_stats, use_worklist ? seg_list : nullptr, chunk_ctr, seg_cap, lazy ? extra->lz_ns : nullptr);
+                       draws_out, scan_stats, use_worklist ? seg_list : nullptr, chunk_ctr, seg_cap, lazy ? extra->lz_ns : nullptr,
+                       lazy ? extra->lz_k : nullptr, lazy ? extra->lz_p : nullptr, lazy ? extra->eager_rows : nullptr);
     if (use_worklist)
       hipLaunchKernelGGL(worklist_pack_kernel, dim3(1), dim3(1024), 0, ctx->stream, seg_list, seg_cap, chunk_ctr, worklist, wl_stat);
   }
@@ -1771,7 +1795,10 @@ int pclean_launch_root_fast(pclean_ctx* ctx, const FastRootDev& fr, const ItemsD
                        it.grp_off, it.members, it.out_pos, g_res, n_draws, it.draw_is ? it.draw_is : n_draws,
                        it.draw_ds ? it.draw_ds : 1, draws_out);
   }
-  if (lse_out)
+  if (lse_out && it.grp_off && it.grp_uid && n_items > 0)
+    hipLaunchKernelGGL(member_lse_kernel, dim3((n_items + 255) / 256), dim3(256), 0, ctx->stream, n_items, it.grp_uid, it.members,
+                       it.out_pos, g_m, g_U, lse_out);
+  else if (lse_out)
     hipLaunchKernelGGL(group_lse_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, it.n, it.grp_off, it.members,
                        it.out_pos, g_m, g_U, lse_out);
   HIPCHK(ctx, hipGetLastError());
