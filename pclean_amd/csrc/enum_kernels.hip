@@ -31,6 +31,7 @@
 
 #define HALF_LOG26 1.629048269010741
 #define ADD_TYPOS_IMPOSSIBLE (-1e5)
+#define CS_TC 4  // terms of a candidate whose gathers are in flight together (candidate_score)
 
 __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -121,27 +122,75 @@ __device__ __forceinline__ double candidate_score_ev(const NodeDev& nd, const De
     const TermDev& tm = nd.terms[ti];
     const AggDev ag = it.agg[ti];
     const int r1 = ag.end ? ag.end[oi] : ag.off[oi + 1];
-    for (int r = ag.off[oi]; r < r1; ++r) {
-      const uint64_t key = ag.key[r];
-      const int o = (int)(key & 0xffffffull) - 1;
-      const int ec = (int)((key >> 24) & 0xffffull);
-      const double mult = (double)ag.cnt[r];
-      if (tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP) {
+    if (tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP) {
+      for (int r = ag.off[oi]; r < r1; ++r) {
+        const uint64_t key = ag.key[r];
+        const int o = (int)(key & 0xffffffull) - 1;
+        const int ec = (int)((key >> 24) & 0xffffull);
+        const double mult = (double)ag.cnt[r];
         const int val = tm.cand_col[k];
         const int c = tm.ctx_mode == 0 ? v.ctxv[tm.ctx_slot] : ec;
         const int d = o < 0 ? 1 : (int)tm.pair[(size_t)o * tm.n_lat + val];
         sk += mult * maybe_swap_density(tm, dn, o, d, val, k, c);
-        continue;
       }
-      if (o < 0) continue;
-      int val = tm.cand_col[k];
-      if (tm.ctx_slot >= 0) {
-        const int c = tm.ctx_mode == 0 ? v.ctxv[tm.ctx_slot] : ec;
-        val = tm.ctx_mode == 2 ? tm.fn[(size_t)val * tm.fn_nb + c] : tm.fn[(size_t)c * tm.fn_nb + val];
+      continue;
+    }
+    // the entries CS_TC at a time (see candidate_score): keys and multiplicities, then the pair bytes and word lengths, then
+    // the density pieces — each step's loads in flight together; additions in entry order
+    const int val0 = tm.cand_col[k];
+    const int cv = (tm.ctx_slot >= 0 && tm.ctx_mode == 0) ? v.ctxv[tm.ctx_slot] : 0;
+    for (int rb = ag.off[oi]; rb < r1; rb += CS_TC) {
+      int o[CS_TC], val[CS_TC], d[CS_TC], L[CS_TC];
+      double mult[CS_TC], a[CS_TC], b[CS_TC];
+#pragma unroll
+      for (int u = 0; u < CS_TC; ++u) {
+        o[u] = -1;
+        val[u] = val0;
+        mult[u] = 0.0;
+        if (rb + u < r1) {
+          const uint64_t key = ag.key[rb + u];
+          o[u] = (int)(key & 0xffffffull) - 1;
+          mult[u] = (double)ag.cnt[rb + u];
+          if (tm.ctx_slot >= 0 && o[u] >= 0) {
+            const int c = tm.ctx_mode == 0 ? cv : (int)((key >> 24) & 0xffffull);
+            val[u] = tm.ctx_mode == 2 ? tm.fn[(size_t)val0 * tm.fn_nb + c] : tm.fn[(size_t)c * tm.fn_nb + val0];
+          }
+        }
       }
-      const size_t idx = (size_t)o * tm.n_lat + val;
-      const int d = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
-      sk += mult * term_density(tm, dn, d, val);
+#pragma unroll
+      for (int u = 0; u < CS_TC; ++u) {
+        d[u] = 0;
+        L[u] = 0;
+        if (o[u] >= 0) {
+          const size_t idx = (size_t)o[u] * tm.n_lat + val[u];
+          d[u] = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
+          if (tm.dens_kind != PCLEAN_DENS_EQUAL) L[u] = tm.lat_len[val[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < CS_TC; ++u) {
+        a[u] = 0.0;
+        b[u] = 0.0;
+        if (o[u] >= 0 && tm.dens_kind != PCLEAN_DENS_EQUAL && !(tm.max_typos >= 0 && d[u] > tm.max_typos)) {
+          a[u] = dn.nb[(size_t)((L[u] + 4) / 5) * dn.nb_stride + d[u]];
+          b[u] = dn.logl[L[u]];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < CS_TC; ++u) {
+        if (o[u] < 0) continue;  // (missing observation, or past the item's last entry)
+        double l;  // (term_density's operations, on the values loaded above)
+        if (tm.dens_kind == PCLEAN_DENS_EQUAL) {
+          l = d[u] == 0 ? 0.0 : -__builtin_inf();
+        } else if (tm.max_typos >= 0 && d[u] > tm.max_typos) {
+          l = ADD_TYPOS_IMPOSSIBLE;
+        } else {
+          l = a[u];
+          l -= b[u] * (double)d[u];
+          l -= HALF_LOG26 * (double)d[u];
+        }
+        sk += mult[u] * l;
+      }
     }
   }
   if (nd.g.on)
@@ -164,15 +213,61 @@ __device__ __forceinline__ double candidate_score(const NodeDev& nd, const DensD
     sk = nd.logc_full[k];
   }
   if (v.ev_lo >= 0) return candidate_score_ev(nd, dn, it, v, k, sk);
-  for (int ti = 0; ti < nd.n_terms; ++ti) {
-    const TermDev& tm = nd.terms[ti];
-    const int o = tm.obs_col[v.row];
-    if (o < 0) continue;  // explicitly missing observation (add_typos.jl:51-53)
-    int val = tm.cand_col[k];
-    if (tm.ctx_slot >= 0) val = tm.fn[(size_t)v.ctxv[tm.ctx_slot] * tm.fn_nb + val];
-    const size_t idx = (size_t)o * tm.n_lat + val;
-    const int d = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
-    sk += term_density(tm, dn, d, val);
+  // The terms CS_TC at a time: a term is a chain of dependent gathers (candidate column -> pair byte and word length ->
+  // density pieces), and walked one after the other the chains of a candidate's terms added up — these kernels wait for
+  // memory, nothing else.  Every load of a step is issued for the whole chunk before any is used; the additions keep the
+  // plan order (same operations on the same values: the same bits).
+  for (int t0 = 0; t0 < nd.n_terms; t0 += CS_TC) {
+    int o[CS_TC], val[CS_TC], d[CS_TC], L[CS_TC];
+    double a[CS_TC], b[CS_TC];
+#pragma unroll
+    for (int u = 0; u < CS_TC; ++u) {
+      const TermDev& tm = nd.terms[min(t0 + u, nd.n_terms - 1)];
+      o[u] = t0 + u < nd.n_terms ? tm.obs_col[v.row] : -1;  // (< 0: explicitly missing observation, add_typos.jl:51-53)
+      val[u] = o[u] >= 0 ? tm.cand_col[k] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < CS_TC; ++u) {
+      const TermDev& tm = nd.terms[min(t0 + u, nd.n_terms - 1)];
+      if (o[u] >= 0 && tm.ctx_slot >= 0) val[u] = tm.fn[(size_t)v.ctxv[tm.ctx_slot] * tm.fn_nb + val[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < CS_TC; ++u) {
+      const TermDev& tm = nd.terms[min(t0 + u, nd.n_terms - 1)];
+      d[u] = 0;
+      L[u] = 0;
+      if (o[u] >= 0) {
+        const size_t idx = (size_t)o[u] * tm.n_lat + val[u];
+        d[u] = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
+        if (tm.dens_kind != PCLEAN_DENS_EQUAL) L[u] = tm.lat_len[val[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CS_TC; ++u) {
+      const TermDev& tm = nd.terms[min(t0 + u, nd.n_terms - 1)];
+      a[u] = 0.0;
+      b[u] = 0.0;
+      if (o[u] >= 0 && tm.dens_kind != PCLEAN_DENS_EQUAL && !(tm.max_typos >= 0 && d[u] > tm.max_typos)) {
+        a[u] = dn.nb[(size_t)((L[u] + 4) / 5) * dn.nb_stride + d[u]];
+        b[u] = dn.logl[L[u]];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < CS_TC; ++u) {
+      if (o[u] < 0) continue;
+      const TermDev& tm = nd.terms[min(t0 + u, nd.n_terms - 1)];
+      double l;  // (term_density's operations, on the values loaded above)
+      if (tm.dens_kind == PCLEAN_DENS_EQUAL) {
+        l = d[u] == 0 ? 0.0 : -__builtin_inf();
+      } else if (tm.max_typos >= 0 && d[u] > tm.max_typos) {
+        l = ADD_TYPOS_IMPOSSIBLE;
+      } else {
+        l = a[u];
+        l -= b[u] * (double)d[u];
+        l -= HALF_LOG26 * (double)d[u];
+      }
+      sk += l;
+    }
   }
   if (nd.g.on && sk > -__builtin_inf()) sk += gauss_term(nd, v, k, v.row, nullptr);
   return sk;
@@ -1229,7 +1324,10 @@ size_t pclean_enum_split_scores(const NodeDev& nd, const ItemsDev& it) {
   const size_t lds = (size_t)((nc + 1) & ~1) * 8 + (16 + 64) * 8;
   const bool few = it.n <= 1024 || (it.sel && it.n <= 16384);
   (void)lds;
-  if (off || !few || it.grp_off || !it.ev_lo || nc < 2048) return 0;
+  // (without evidence sets a candidate is one short chain of gathers: worth the extra launch for a handful of long lists only —
+  // the nested slots of a new-row branch, seven groups x 14 000 candidates per 1M-row sweep)
+  if (off || !few || it.grp_off || nc < 2048) return 0;
+  if (!it.ev_lo && (it.n > 64 || nc < 4096)) return 0;
   return (size_t)pclean_enum_split_slots(it, nc) * nc;
 }
 
@@ -1251,7 +1349,10 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
   // 0.40 ms per launch on the Hospital sub-batches)
   static const bool big_few = getenv("PCLEAN_BIG_FEW_ITEMS") != nullptr;
   // (an indirect launch runs as many workgroups as its device-side list holds — the items a scan could not settle, few)
-  const bool few = it.n <= 1024 || (it.sel && it.n <= 16384);
+  // (... and a launch whose score arrays leave room for fewer than eight workgroups of 256 threads on a CU — lists from ~2 500
+  // candidates on: the kernels wait for gathers, and 1024 threads per item keep twice to four times the waves in flight)
+  static const bool no_wide = getenv("PCLEAN_NO_WIDE_ENUM") != nullptr;
+  const bool few = it.n <= 1024 || (it.sel && it.n <= 16384) || (!no_wide && lds > 20 * 1024 && it.n <= 65536);
   if (it.sel && it.grp_off) return pclean_fail(ctx, PCLEAN_ERR_ARG, "indirect launches are not grouped");
   if (lds > 160 * 1024 || (lds > big_from && !it.grp_off && !scores_out && n_draws <= 1 && (!few || big_few))) {
     if (few) {  // too few workgroups to fill the chip: more threads per item
