@@ -31,7 +31,7 @@
 
 #define HALF_LOG26 1.629048269010741
 #define ADD_TYPOS_IMPOSSIBLE (-1e5)
-#define CS_TC 4  // terms of a candidate whose gathers are in flight together (candidate_score)
+#define CS_TC 4  // evidence entries of a term whose gathers are in flight together (candidate_score_ev)
 
 __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
@@ -135,8 +135,10 @@ __device__ __forceinline__ double candidate_score_ev(const NodeDev& nd, const De
       }
       continue;
     }
-    // the entries CS_TC at a time (see candidate_score): keys and multiplicities, then the pair bytes and word lengths, then
-    // the density pieces — each step's loads in flight together; additions in entry order
+    // the entries CS_TC at a time: an entry is a chain of dependent gathers (key -> pair byte and word length -> density
+    // pieces), and walked one after the other the chains added up — these kernels wait for memory, nothing else.  Keys and
+    // multiplicities, then the pair bytes and word lengths, then the density pieces: each step's loads are issued for the
+    // whole chunk before any is used; the additions keep the entry order (same operations on the same values: same bits)
     const int val0 = tm.cand_col[k];
     const int cv = (tm.ctx_slot >= 0 && tm.ctx_mode == 0) ? v.ctxv[tm.ctx_slot] : 0;
     for (int rb = ag.off[oi]; rb < r1; rb += CS_TC) {
@@ -213,61 +215,15 @@ __device__ __forceinline__ double candidate_score(const NodeDev& nd, const DensD
     sk = nd.logc_full[k];
   }
   if (v.ev_lo >= 0) return candidate_score_ev(nd, dn, it, v, k, sk);
-  // The terms CS_TC at a time: a term is a chain of dependent gathers (candidate column -> pair byte and word length ->
-  // density pieces), and walked one after the other the chains of a candidate's terms added up — these kernels wait for
-  // memory, nothing else.  Every load of a step is issued for the whole chunk before any is used; the additions keep the
-  // plan order (same operations on the same values: the same bits).
-  for (int t0 = 0; t0 < nd.n_terms; t0 += CS_TC) {
-    int o[CS_TC], val[CS_TC], d[CS_TC], L[CS_TC];
-    double a[CS_TC], b[CS_TC];
-#pragma unroll
-    for (int u = 0; u < CS_TC; ++u) {
-      const TermDev& tm = nd.terms[min(t0 + u, nd.n_terms - 1)];
-      o[u] = t0 + u < nd.n_terms ? tm.obs_col[v.row] : -1;  // (< 0: explicitly missing observation, add_typos.jl:51-53)
-      val[u] = o[u] >= 0 ? tm.cand_col[k] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < CS_TC; ++u) {
-      const TermDev& tm = nd.terms[min(t0 + u, nd.n_terms - 1)];
-      if (o[u] >= 0 && tm.ctx_slot >= 0) val[u] = tm.fn[(size_t)v.ctxv[tm.ctx_slot] * tm.fn_nb + val[u]];
-    }
-#pragma unroll
-    for (int u = 0; u < CS_TC; ++u) {
-      const TermDev& tm = nd.terms[min(t0 + u, nd.n_terms - 1)];
-      d[u] = 0;
-      L[u] = 0;
-      if (o[u] >= 0) {
-        const size_t idx = (size_t)o[u] * tm.n_lat + val[u];
-        d[u] = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
-        if (tm.dens_kind != PCLEAN_DENS_EQUAL) L[u] = tm.lat_len[val[u]];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < CS_TC; ++u) {
-      const TermDev& tm = nd.terms[min(t0 + u, nd.n_terms - 1)];
-      a[u] = 0.0;
-      b[u] = 0.0;
-      if (o[u] >= 0 && tm.dens_kind != PCLEAN_DENS_EQUAL && !(tm.max_typos >= 0 && d[u] > tm.max_typos)) {
-        a[u] = dn.nb[(size_t)((L[u] + 4) / 5) * dn.nb_stride + d[u]];
-        b[u] = dn.logl[L[u]];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < CS_TC; ++u) {
-      if (o[u] < 0) continue;
-      const TermDev& tm = nd.terms[min(t0 + u, nd.n_terms - 1)];
-      double l;  // (term_density's operations, on the values loaded above)
-      if (tm.dens_kind == PCLEAN_DENS_EQUAL) {
-        l = d[u] == 0 ? 0.0 : -__builtin_inf();
-      } else if (tm.max_typos >= 0 && d[u] > tm.max_typos) {
-        l = ADD_TYPOS_IMPOSSIBLE;
-      } else {
-        l = a[u];
-        l -= b[u] * (double)d[u];
-        l -= HALF_LOG26 * (double)d[u];
-      }
-      sk += l;
-    }
+  for (int ti = 0; ti < nd.n_terms; ++ti) {
+    const TermDev& tm = nd.terms[ti];
+    const int o = tm.obs_col[v.row];
+    if (o < 0) continue;  // explicitly missing observation (add_typos.jl:51-53)
+    int val = tm.cand_col[k];
+    if (tm.ctx_slot >= 0) val = tm.fn[(size_t)v.ctxv[tm.ctx_slot] * tm.fn_nb + val];
+    const size_t idx = (size_t)o * tm.n_lat + val;
+    const int d = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
+    sk += term_density(tm, dn, d, val);
   }
   if (nd.g.on && sk > -__builtin_inf()) sk += gauss_term(nd, v, k, v.row, nullptr);
   return sk;
@@ -913,12 +869,11 @@ __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, con
   // beyond LDS of a few-item launch: 40 candidates per thread and pass, each a chain of gathers, became three streamed reads)
   const double* si = (scores_in && slot_in < slot_cap) ? scores_in + (size_t)slot_in * nc : nullptr;
   const double sn = !fk ? -__builtin_inf() : (si ? si[n] : new_score(nd, ch, v, to));
-  auto score_of = [&](int k) -> double { return si ? si[k] : candidate_score(nd, dn, it, v, k); };
 
   // pass A: max (lane-strided, coalesced)
   double lmax = -__builtin_inf();
   for (int k = tid; k < n; k += BT) {
-    const double sk = score_of(k);
+    const double sk = si ? si[k] : candidate_score(nd, dn, it, v, k);
     if (scores_out) scores_out[(size_t)to * nc + k] = sk;
     lmax = fmax(lmax, sk);
   }
@@ -938,7 +893,7 @@ __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, con
   uint64_t part = 0;
   if (m != -__builtin_inf())
     for (int k = lo; k < hi; ++k) {
-      const double sk = (k == n) ? sn : score_of(k);
+      const double sk = (k == n) ? sn : (si ? si[k] : candidate_score(nd, dn, it, v, k));
       part += pclean_fixw(sk - m);
     }
   uint64_t U;
@@ -961,7 +916,7 @@ __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, con
         uint64_t acc = pre;
         int k = lo;
         for (; k < hi; ++k) {
-          const double sk = (k == n) ? sn : score_of(k);
+          const double sk = (k == n) ? sn : (si ? si[k] : candidate_score(nd, dn, it, v, k));
           acc += pclean_fixw(sk - m);
           if (acc > x) break;
         }
