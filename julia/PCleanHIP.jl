@@ -162,6 +162,7 @@ struct CGauss
     n_locals::Int32; local_n::NTuple{2,Int32}; local_obs_col::NTuple{2,Int32}
     transform_src_kind::Int32; transform_src::Int32; fixed_locals::Int32; pad::Int32
     t_scale::NTuple{4,Float64}; t_logabsderiv::NTuple{4,Float64}; sigma::Float64
+    t_x_col::NTuple{4,Int32}; t_lad_col::NTuple{4,Int32}                      # non-linear Transformations: numeric columns of backward(x) / log|deriv|, -1 = the linear form
 end
 load_numeric_columns(c, x::Matrix{Float64}) = GC.@preserve x check(c,                                    # x: n_rows x n_cols, NaN = missing
     ccall((:pclean_load_numeric_columns, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Float64}), c.h, size(x, 1), size(x, 2), x))
@@ -644,6 +645,8 @@ function lower_gaussian!(lw::Lowered, bi::Int, blk::LBlock, ocm::PCleanClass, na
         b1 = Float64(u.backward(1.0)); d1 = Float64(u.deriv(b1))
         lin = abs(Float64(u.backward(0.0))) <= 1e-12 && all(x -> abs(u.backward(x) - x * b1) <= 1e-9 * max(1.0, abs(x * b1)) &&
               abs(u.deriv(u.backward(x)) - d1) <= 1e-9 * max(1.0, abs(d1)), (0.5, 2.0, -3.0, 1267.0))
+        # (the Python host, model.py: _lower_gaussian, also takes non-linear ones: backward(x) and log|deriv| of every row as two more
+        #  numeric columns, pclean_gauss.t_x_col / t_lad_col — not transcribed here)
         lin || error("TransformedGaussian: only linear Transformations (backward(x) = c x)")
         push!(t_scale, b1); push!(t_lad, log(abs(d1)))
     end
@@ -827,7 +830,7 @@ function cgauss(s::GaussSpec; mean_table=0)
     pad4(x, fill_) = ntuple(i -> i <= length(x) ? x[i] : fill_, 4); pad2(x, fill_) = ntuple(i -> i <= length(x) ? x[i] : fill_, 2)
     CGauss(s.x_col, mean_table, length(s.kinds), pad4(Int32[GSRC[k[1]] for k in s.kinds], Int32(0)), pad4(Int32[k[2] for k in s.kinds], Int32(0)),
            pad4(s.strides, Int32(0)), s.n_locals, pad2(s.local_n, Int32(1)), pad2(s.local_obs, Int32(-1)), GSRC[s.transform[1]], s.transform[2], 0, 0,
-           pad4(s.t_scale, 1.0), pad4(s.t_lad, 0.0), s.sigma)
+           pad4(s.t_scale, 1.0), pad4(s.t_lad, 0.0), s.sigma, ntuple(_ -> Int32(-1), 4), ntuple(_ -> Int32(-1), 4))
 end
 "observed columns as the library wants them: n_rows x n_cols, value index in the column's observed domain, -1 missing"
 function encode_observations(lw::Lowered, data)

@@ -159,9 +159,11 @@ inline GaussCombos gauss_combo_scores(const World& w, const pclean_gauss& g, int
       else if (g.transform_src_kind == PCLEAN_GSRC_EVCTX)
         u = evctx[g.transform_src];
       double s = lp[0] + lp[1];
-      const double z = (xv * g.t_scale[u] - mu[idx]) / g.sigma;
+      /* (a non-linear Transformation: backward(x) and log|deriv(backward(x))| per row, pclean_gauss::t_x_col / t_lad_col) */
+      const double bx = g.t_x_col[u] >= 0 ? w.xnum[(size_t)g.t_x_col[u] * w.n_rows + row] : xv * g.t_scale[u];
+      const double z = (bx - mu[idx]) / g.sigma;
       s += -0.5 * z * z - log_sigma - 0.91893853320467274178;
-      s -= g.t_logabsderiv[u];
+      s -= g.t_lad_col[u] >= 0 ? w.xnum[(size_t)g.t_lad_col[u] * w.n_rows + row] : g.t_logabsderiv[u];
       out.sc[out.n] = s;
       out.codes[out.n] = l0 * 16 + l1;
       ++out.n;

@@ -165,9 +165,10 @@ inline double gauss_prior_term(const World& w, const pclean_gauss& g, int block,
   int idx = 0;
   for (int d = 0; d < g.n_dims; ++d) idx += g.stride[d] * (g.src_kind[d] == PCLEAN_GSRC_LOCAL ? l[g.src[d]] : val(d));
   const int u = g.transform_src_kind == PCLEAN_GSRC_LOCAL ? l[g.transform_src] : 0;
-  const double z = (xv * g.t_scale[u] - mu[idx]) / g.sigma;
+  const double bx = g.t_x_col[u] >= 0 ? w.xnum[(size_t)g.t_x_col[u] * w.n_rows + row] : xv * g.t_scale[u];
+  const double z = (bx - mu[idx]) / g.sigma;
   s += -0.5 * z * z - std::log(g.sigma) - 0.91893853320467274178;
-  s -= g.t_logabsderiv[u];
+  s -= g.t_lad_col[u] >= 0 ? w.xnum[(size_t)g.t_lad_col[u] * w.n_rows + row] : g.t_logabsderiv[u];
   return s;
 }
 

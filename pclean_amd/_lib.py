@@ -42,7 +42,8 @@ class Gauss(C.Structure):
                 ("src", C.c_int32 * 4), ("stride", C.c_int32 * 4), ("n_locals", C.c_int32), ("local_n", C.c_int32 * 2),
                 ("local_obs_col", C.c_int32 * 2), ("transform_src_kind", C.c_int32), ("transform_src", C.c_int32),
                 ("fixed_locals", C.c_int32), ("pad", C.c_int32), ("t_scale", C.c_double * 4),
-                ("t_logabsderiv", C.c_double * 4), ("sigma", C.c_double)]
+                ("t_logabsderiv", C.c_double * 4), ("sigma", C.c_double), ("t_x_col", C.c_int32 * 4),
+                ("t_lad_col", C.c_int32 * 4)]
 
 
 GSRC = {"cand": 0, "obs": 1, "local": 2, "itemctx": 3, "evctx": 4}

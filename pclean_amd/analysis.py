@@ -28,7 +28,7 @@ def reconstructed_pool_ids(lowered, trace, row_slice=None):
             spec = lw.gauss_spec
             bi = next(iter(lw.locals))
             u = np.maximum(trace.locals[bi][:, spec["t_local"]], 0)
-            out[col] = ("numeric", np.round(lw.xnum[spec["x_col"]][:trace.cur.shape[1]] * np.asarray(spec["t_scale"])[u]))
+            out[col] = ("numeric", np.round(lw.gauss_backward(np.arange(trace.cur.shape[1]), u)))
             continue
         if "." in ref:
             head, rest = ref.split(".", 1)

@@ -30,6 +30,8 @@ struct GaussDev {
   double local_logp[2];
   int32_t t_src, pad;
   double t_scale[4], t_lad[4];
+  const double* tx[4];  // non-linear transformation u: backward_u(x) / log|deriv_u(backward_u(x))| of every row (indexed like x);
+  const double* tl[4];  // null: x * t_scale[u] / t_lad[u]
   double sigma, log_sigma;
 };
 
@@ -225,6 +227,9 @@ int pclean_build_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_
 // block minima of a compact table: cmin[o][kb] = min of comp[o][64 kb .. 64 kb + 63] (root_wave.hip: the coarse level
 // of the pre-filter scan)
 int pclean_build_compact_min(pclean_ctx* ctx, const uint8_t* comp, int n_obs, int kpad, int cstride, uint8_t* cmin);
+// ... of the blocks holding the candidates rows[0 .. n_rows) (after pclean_update_compact), or of every block when the rows are many
+int pclean_update_compact_min(pclean_ctx* ctx, const uint8_t* comp, int n_obs, int kpad, int cstride, const int32_t* rows,
+                              int n_rows, uint8_t* cmin);
 int pclean_update_compact(pclean_ctx* ctx, const uint8_t* pair, int n_obs, int n_lat, const int32_t* cand_col,
                           const uint16_t* lat_len, const int32_t* rows, int n_rows, int kpad, uint8_t* comp, uint8_t* clen);
 int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* logc_full, int n_cand, int kpad,

@@ -42,6 +42,13 @@ int build_gauss_dev(pclean_ctx* ctx, const pclean_gauss& g, const CandTable* t, 
   for (int u = 0; u < 4; ++u) {
     d.t_scale[u] = g.t_scale[u];
     d.t_lad[u] = g.t_logabsderiv[u];
+    d.tx[u] = d.tl[u] = nullptr;
+    if (g.t_x_col[u] >= 0 || g.t_lad_col[u] >= 0) {  // a non-linear Transformation: both per-row columns
+      if (g.t_x_col[u] < 0 || g.t_x_col[u] >= ctx->n_xcols || g.t_lad_col[u] < 0 || g.t_lad_col[u] >= ctx->n_xcols)
+        return pclean_fail(ctx, PCLEAN_ERR_ARG, "gauss: transformation column out of range");
+      d.tx[u] = ctx->xnum.p + (size_t)g.t_x_col[u] * ctx->n_rows + ctx->active_begin;
+      d.tl[u] = ctx->xnum.p + (size_t)g.t_lad_col[u] * ctx->n_rows + ctx->active_begin;
+    }
   }
   d.sigma = g.sigma;
   d.log_sigma = std::log(g.sigma);
@@ -316,7 +323,8 @@ static int try_fast_root(pclean_ctx* ctx, int block_id, int node_id, FastRootDev
         rc = pclean_update_compact(ctx, pt.d.p, pt.n_obs, pt.n_lat, t.cols.p + (size_t)tm.cand_col * t.n_rows, pt.lat_len.p,
                                      t.cols_delta_rows, t.cols_delta_n, kpad, f.comp[i].p, f.clen[i].p);
       if (rc) return rc;
-      if (t.cols_delta_n > 0) rc = pclean_build_compact_min(ctx, f.comp[i].p, pt.n_obs, kpad, cstride, f.cblk[i].p);
+      if (t.cols_delta_n > 0)
+        rc = pclean_update_compact_min(ctx, f.comp[i].p, pt.n_obs, kpad, cstride, t.cols_delta_rows, t.cols_delta_n, f.cblk[i].p);
       if (rc) return rc;
       f.ver[i] = ver;
     }

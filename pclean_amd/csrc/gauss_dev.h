@@ -51,8 +51,8 @@ __device__ __forceinline__ int gauss_combo_scores(const GaussDev& g, int row, co
       else if (g.t_kind == PCLEAN_GSRC_EVCTX)
         u = evctx[g.t_src];
       double s = lp[0] + lp[1];
-      s += gauss_normal_logpdf(xv * g.t_scale[u], g.mu[idx], g.sigma, g.log_sigma);
-      s -= g.t_lad[u];
+      s += gauss_normal_logpdf(g.tx[u] ? g.tx[u][row] : xv * g.t_scale[u], g.mu[idx], g.sigma, g.log_sigma);
+      s -= g.tl[u] ? g.tl[u][row] : g.t_lad[u];
       sc[n] = s;
       codes[n] = l0 * 16 + l1;
       ++n;

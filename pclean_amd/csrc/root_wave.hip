@@ -190,6 +190,41 @@ int pclean_build_compact_min(pclean_ctx* ctx, const uint8_t* comp, int n_obs, in
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }
+// ... of the blocks that hold the candidates rows[0 .. n_rows) alone (after compact_update_kernel wrote those candidates'
+// bytes): thread (j, o) recomputes block rows[j] / 64 of row o — several rows of one block write the same value
+__global__ void compact_min_rows_kernel(const uint8_t* __restrict__ comp, int kpad, int cstride, const int32_t* __restrict__ rows,
+                                        int n_rows, uint8_t* __restrict__ cmin) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int o = blockIdx.y;
+  if (j >= n_rows) return;
+  const int kb = rows[j] >> 6;
+  uint32_t m = 255u;
+  const int q0 = kb * 4, nq = kpad >> 4;
+  for (int q = q0; q < q0 + 4 && q < nq; ++q) {
+    const uint4 c = reinterpret_cast<const uint4*>(comp + (size_t)o * kpad)[q];
+    const uint32_t cw[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m = min(m, (cw[w] >> (8 * e)) & 0xffu);
+  }
+  cmin[(size_t)o * cstride + kb] = (uint8_t)m;
+}
+int pclean_update_compact_min(pclean_ctx* ctx, const uint8_t* comp, int n_obs, int kpad, int cstride, const int32_t* rows,
+                              int n_rows, uint8_t* cmin) {
+  if (n_rows <= 0) return PCLEAN_OK;
+  // a few rows of a table of thousands (a latent sub-batch's commit): their blocks; a tenth of the table and more (the Measure
+  // rows an observed-class commit wrote): every block is touched anyway — the whole rows, coalesced
+  static const bool no_rows = getenv("PCLEAN_NO_COMPACT_MIN_ROWS") != nullptr;
+  if (no_rows || (size_t)n_rows * 64 * 2 > (size_t)kpad) return pclean_build_compact_min(ctx, comp, n_obs, kpad, cstride, cmin);
+  for (int o0 = 0; o0 < n_obs; o0 += 65535) {
+    const int no = std::min(65535, n_obs - o0);
+    hipLaunchKernelGGL(compact_min_rows_kernel, dim3((n_rows + 63) / 64, no), dim3(64), 0, ctx->stream, comp + (size_t)o0 * kpad,
+                       kpad, cstride, rows, n_rows, cmin + (size_t)o0 * cstride);
+  }
+  HIPCHK(ctx, hipGetLastError());
+  return PCLEAN_OK;
+}
 int pclean_build_priors(pclean_ctx* ctx, const int64_t* counts, const double* logc_full, int n_cand, int kpad,
                         double logden_e, double logden_n, double* prior_e, double* prior_n, uint16_t* alive) {
   static const bool unfused = getenv("PCLEAN_NO_FUSED_PRIORS") != nullptr;

@@ -772,8 +772,8 @@ __global__ void gauss_prior_kernel(int n_rows, int P, GaussDev g, PlanDev plan, 
       idx += g.stride[d] * val;
     }
     const int u = g.t_kind == PCLEAN_GSRC_LOCAL ? l[g.t_src] : 0;
-    s += gauss_normal_logpdf(xv * g.t_scale[u], g.mu[idx], g.sigma, g.log_sigma);
-    s -= g.t_lad[u];
+    s += gauss_normal_logpdf(g.tx[u] ? g.tx[u][i] : xv * g.t_scale[u], g.mu[idx], g.sigma, g.log_sigma);
+    s -= g.tl[u] ? g.tl[u][i] : g.t_lad[u];
   }
   w[slot] += s;
 }

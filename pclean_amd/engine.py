@@ -30,6 +30,8 @@ def make_gauss(spec, mean_table_id=0):
     for u in range(4):
         g.t_scale[u] = spec["t_scale"][u] if u < len(spec["t_scale"]) else 1.0
         g.t_logabsderiv[u] = spec["t_lad"][u] if u < len(spec["t_lad"]) else 0.0
+        g.t_x_col[u] = spec["t_x_col"][u] if u < len(spec.get("t_x_col", ())) else -1  # (non-linear units: derived columns)
+        g.t_lad_col[u] = spec["t_lad_col"][u] if u < len(spec.get("t_lad_col", ())) else -1
     g.sigma = spec["sigma"]
     return g
 

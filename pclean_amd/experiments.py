@@ -128,8 +128,9 @@ def rents_data():
     return dirty, clean
 
 
-def rents_model(dirty):
-    """experiments/rents/run.jl:5-27."""
+def rents_model(dirty, units=None):
+    """experiments/rents/run.jl:5-27.  units: other Transformations for `unit` to choose from (tests of the lowering's
+    non-linear path: the reference's type takes any forward / backward / deriv, transformed_gaussian.jl:5-9)."""
     from .model import IndexedLookup, IndexedMeanParameter, TransformedGaussian, Transformation, Unmodeled
     poss = {}
     for k, c in zip(dirty["CountyKey"], dirty["County"]):
@@ -138,8 +139,9 @@ def rents_model(dirty):
             poss[k].append(c)
     states = list(dict.fromkeys(v for v in dirty["State"] if v is not None))  # load_data.jl:17
     room_types = ["studio", "1br", "2br", "3br", "4br"]
-    units = [Transformation(lambda x: x, lambda x: x, lambda x: 1.0),
-             Transformation(lambda x: x / 1000.0, lambda x: x * 1000.0, lambda x: 1 / 1000.0)]
+    if units is None:
+        units = [Transformation(lambda x: x, lambda x: x, lambda x: 1.0),
+                 Transformation(lambda x: x / 1000.0, lambda x: x * 1000.0, lambda x: 1 / 1000.0)]
     m = Model()
     c = m.add_class("County")
     c.param("state_pops", ProportionsParameter())

@@ -329,6 +329,7 @@ class LoweredModel:
         self.direct_obs = {}   # obs name -> (path or own attr name) observed without noise (clean == dirty)
         self.numeric_obs = {}  # own TransformedGaussian attr -> numeric column index
         self.num_cols = []
+        self.num_derived = []  # (source numeric column, Transformation, "backward" | "logabsderiv"): see _lower_gaussian
         for col, dirty in self.query.obsmap.items():
             own = None
             if "." not in dirty:
@@ -360,6 +361,19 @@ class LoweredModel:
         self._never_missing = {dirty for col, dirty in self.query.obsmap.items()
                                if all(v is not None for v in dirty_columns[col])}
 
+    def gauss_backward(self, rows, unit_idx):
+        """unit.backward(x) of the Gaussian observation of `rows` under the Transformation options unit_idx (one per row):
+        x * c for the linear ones, the derived column for the others (transformed_gaussian.jl:16, 27-34)."""
+        spec = self.gauss_spec
+        rows = np.asarray(rows)
+        unit_idx = np.asarray(unit_idx)
+        x = self.xnum[spec["x_col"], rows] * np.asarray(spec["t_scale"])[unit_idx]
+        for ui, col in enumerate(spec.get("t_x_col", ())):
+            if col >= 0:
+                sel = unit_idx == ui
+                x[sel] = self.xnum[col, rows[sel]]
+        return x
+
     def relower(self, extra_latent):
         """Grow latent domains by the strings of extra_latent {(class, attribute): [strings]} and rebuild every
         derived table IN PLACE (pair / fn / equality tables, plans): value ids held by a trace stay valid, callers
@@ -377,6 +391,17 @@ class LoweredModel:
         n_rows = len(next(iter(dirty_columns.values())))
         self.xnum = np.array([[np.nan if v is None else float(v) for v in dirty_columns[c]] for c in self.num_cols],
                              dtype=np.float64).reshape(len(self.num_cols), n_rows)
+        derived = getattr(self, "num_derived", [])
+        if derived:  # backward(x) / log|deriv(backward(x))| of the non-linear Transformations, row by row (_lower_gaussian)
+            rows = []
+            for src, unit, what in derived:
+                col = np.full(n_rows, np.nan)
+                for i, x in enumerate(self.xnum[src]):
+                    if x == x:
+                        bx = float(unit.backward(float(x)))
+                        col[i] = bx if what == "backward" else float(np.log(abs(float(unit.deriv(bx)))))
+                rows.append(col)
+            self.xnum = np.vstack([self.xnum, np.array(rows, dtype=np.float64).reshape(len(rows), n_rows)])
         obs = np.full((len(self.obs_cols), n_rows), -1, dtype=np.int32)
         for j, dirty in enumerate(self.obs_cols):
             dom = self.obs_dom[dirty]
@@ -763,18 +788,24 @@ class LoweredModel:
             raise NotImplementedError("TransformedGaussian mean must be an IndexedLookup")
         unit_attr = ocls.attr(g.dist.unit)
         units = unit_attr.dist.options
+        if len(units) > 4:
+            raise NotImplementedError("at most four Transformations to choose from (pclean_gauss::t_scale[4])")
+        # A LINEAR unit (backward(x) = c x, |deriv| constant: the rents program's) is evaluated by the kernels as x * c and a
+        # constant log|deriv|.  Any other Transformation (transformed_gaussian.jl:5-9 takes arbitrary functions, 15-16
+        # evaluates them per observation): x is DATA, so backward(x) and log|deriv(backward(x))| of every row are two
+        # more numeric columns, evaluated once on the host (encode_observations) and read by the kernels per row.
+        t_linear = []
         for u in units:
-            # The kernels evaluate backward(x) as x * backward(1) and log|deriv| as a constant
-            # (transformed_gaussian.jl:15-16 evaluates both per observation): only linear units qualify.
             probes = (0.5, 2.0, -3.0, 1267.0)
-            b1 = float(u.backward(1.0))
-            d1 = float(u.deriv(b1))
-            lin = abs(float(u.backward(0.0))) <= 1e-12 and all(
-                abs(float(u.backward(x)) - x * b1) <= 1e-9 * max(1.0, abs(x * b1)) and
-                abs(float(u.deriv(u.backward(x))) - d1) <= 1e-9 * max(1.0, abs(d1)) for x in probes)
-            if not lin:
-                raise NotImplementedError("TransformedGaussian: only linear Transformations (backward(x) = c*x) are "
-                                          "supported by the HIP path")
+            try:
+                b1 = float(u.backward(1.0))
+                d1 = float(u.deriv(b1))
+                lin = abs(float(u.backward(0.0))) <= 1e-12 and all(
+                    abs(float(u.backward(x)) - x * b1) <= 1e-9 * max(1.0, abs(x * b1)) and
+                    abs(float(u.deriv(u.backward(x))) - d1) <= 1e-9 * max(1.0, abs(d1)) for x in probes)
+            except (ValueError, ZeroDivisionError, OverflowError, FloatingPointError):
+                lin = False  # (a probe outside the function's domain: log of a negative number ...)
+            t_linear.append(bool(lin))
         locs = []  # own enumerated choices: index arguments that are own attrs, plus the unit
         dims = []  # (kind, payload, n_values)
         for arg in look.args:
@@ -793,6 +824,8 @@ class LoweredModel:
             locs.append(g.dist.unit)
         if len(locs) > 2:
             raise NotImplementedError("at most two enumerated own choices")
+        if int(np.prod([len(ocls.attr(l).dist.options) for l in locs])) > 16:
+            raise NotImplementedError("at most 16 combinations of the enumerated own choices (gauss_combo_scores: sc[16])")
         strides, acc = [], 1
         for d in reversed(dims):
             strides.append(acc)
@@ -803,8 +836,17 @@ class LoweredModel:
                     strides=strides, locals=locs, local_n=[len(ocls.attr(l).dist.options) for l in locs],
                     local_obs=[self.obs_index.get(l, -1) if l in self.direct_obs else -1 for l in locs],
                     t_local=locs.index(g.dist.unit), sigma=g.dist.std, gauss_attr=g.name,
-                    t_scale=[float(u.backward(1.0)) for u in units],
-                    t_lad=[float(np.log(abs(u.deriv(u.backward(1.0))))) for u in units], units=units)
+                    t_scale=[float(u.backward(1.0)) if lin else 1.0 for u, lin in zip(units, t_linear)],
+                    t_lad=[float(np.log(abs(u.deriv(u.backward(1.0))))) if lin else 0.0 for u, lin in zip(units, t_linear)],
+                    units=units, t_linear=t_linear, t_x_col=[-1] * len(units), t_lad_col=[-1] * len(units))
+        # derived numeric columns of the non-linear units: appended behind the observed ones (encode_observations)
+        self.num_derived = []
+        for ui, lin in enumerate(t_linear):
+            if not lin:
+                spec["t_x_col"][ui] = len(self.num_cols) + len(self.num_derived)
+                self.num_derived.append((spec["x_col"], units[ui], "backward"))
+                spec["t_lad_col"][ui] = len(self.num_cols) + len(self.num_derived)
+                self.num_derived.append((spec["x_col"], units[ui], "logabsderiv"))
         self.gauss_spec = spec
         # (a) block root: candidate-side index values come from the candidate's columns
         rc = root_fk.target

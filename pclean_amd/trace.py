@@ -287,7 +287,7 @@ class Trace:
                 idx += st * t.cols[lw.colidx[root][d[1]], self.cur[bi][rows]]
             else:
                 idx += st * self.locals[bi][rows, d[1]]
-        x = lw.xnum[spec["x_col"], rows] * np.asarray(spec["t_scale"])[self.locals[bi][rows, spec["t_local"]]]
+        x = lw.gauss_backward(rows, self.locals[bi][rows, spec["t_local"]])
         ok = ~np.isnan(x)
         return rows[ok], idx[ok], x[ok]
 

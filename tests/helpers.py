@@ -37,14 +37,14 @@ def hospital_setup(n_rows=None, seed=0):
     return dict(dirty=dirty, clean=clean, model=m, query=q, lw=lw, obs=obs, trace=tr)
 
 
-def rents_setup(n_rows=600, seed=3):
+def rents_setup(n_rows=600, seed=3, units=None):
     """rents (experiments/rents/run.jl) on the first n_rows rows, latent state from the clean values (a clean county
     name that never occurs undamaged falls back to the dirty cell) — the deterministic state of the literal
     interpreter's rents fixtures (tests/golden/literal_scores_rents.json)."""
     dirty, clean = ex.rents_data()
     dirty = {c: v[:n_rows] for c, v in dirty.items()}
     clean = {c: v[:n_rows] for c, v in clean.items()}
-    m = ex.rents_model(dirty)
+    m = ex.rents_model(dirty, units)
     q = ex.rents_query(m)
     lw = LoweredModel(m, q, dirty)
     obs = lw.encode_observations(dirty)

@@ -18,11 +18,11 @@ from pclean_amd.trace import Trace
 pytestmark = pytest.mark.gpu
 
 
-def rents_setup(n_rows):
+def rents_setup(n_rows, units=None):
     dirty, clean = ex.rents_data()
     dirty = {c: v[:n_rows] for c, v in dirty.items()}
     clean = {c: v[:n_rows] for c, v in clean.items()}
-    m = ex.rents_model(dirty)
+    m = ex.rents_model(dirty, units)
     q = ex.rents_query(m)
     lw = LoweredModel(m, q, dirty)
     return dirty, clean, lw, lw.encode_observations(dirty)
@@ -48,14 +48,23 @@ def oracle_sweep(oracle, world, cfg, seed, sweep, cur, n_nodes):
     return choice, chosen, logml, new_rows, world.get_locals(0, n)
 
 
-@pytest.mark.parametrize("particles,mh,dd", [(2, True, True), (20, False, True), (2, True, False), (6, False, False)])
-def test_rents_sweep_and_latent_parity(oracle, particles, mh, dd):
+@pytest.mark.parametrize("particles,mh,dd,nonlinear", [(2, True, True, False), (20, False, True, False), (2, True, False, False),
+                                                       (6, False, False, False), (6, False, True, True), (4, False, False, True)])
+def test_rents_sweep_and_latent_parity(oracle, particles, mh, dd, nonlinear):
     """dd = False: prior proposals (use_dd_proposals = false) — County rows' attributes from their priors under the Gaussian
     evidence of the referring rows (their own choices given), the observed class with its own choices sampled per particle
-    (gauss_prior_kernel), the retained particle keeping the row's current ones."""
+    (gauss_prior_kernel), the retained particle keeping the row's current ones.
+    nonlinear: `unit` chooses among dollars, square-root dollars and log-dollars — Transformations that are not linear
+    (transformed_gaussian.jl:5-9): backward(x) and log|deriv| come from the lowering's derived numeric columns
+    (tests/test_nonlinear_transformation.py holds the C++ oracle's reading of them against the literal interpreter)."""
     from pclean_amd.inference import latent_current_choices
-    dirty, clean, lw, obs = rents_setup(3000)
-    assert lw.xnum.shape == (1, 3000) and (obs[2] < 0).sum() > 100 and (obs[3] < 0).sum() > 100  # missing State / Room Type
+    units = None
+    if nonlinear:
+        from test_nonlinear_transformation import nonlinear_units
+        units = nonlinear_units()
+    dirty, clean, lw, obs = rents_setup(3000, units)
+    assert lw.xnum.shape == (5 if nonlinear else 1, 3000)
+    assert (obs[2] < 0).sum() > 100 and (obs[3] < 0).sum() > 100  # missing State / Room Type
     eng = Engine(lw, obs, dist_mode=1)
     try:
         cfg0 = InferenceConfig(1, particles, use_mh_instead_of_pg=mh, rejuv_frequency=500)
