@@ -401,7 +401,10 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   dbg_a = dbg_ms();
   int64_t total = 0, live = 0;
-  t.h_counts.assign(counts, counts + n_rows);
+  // (a latent class is re-uploaded after every sub-batch of its sweep with a handful of counts moved: a row whose count and
+  // discount are what the previous upload held keeps its two logarithms — the same function of the same arguments)
+  const bool keep_logs = same_shape && t.discount == discount && t.h_counts.size() == (size_t)n_rows &&
+                         t.h_logc_full.size() == (size_t)n_rows && t.h_logc_m1.size() == (size_t)n_rows;
   t.h_logc_full.resize(n_rows);
   t.h_logc_m1.resize(n_rows);
   for (int k = 0; k < n_rows; ++k) {
@@ -409,9 +412,11 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
     if (c < 0) return pclean_fail(ctx, PCLEAN_ERR_ARG, "negative reference count");
     total += c;
     live += c > 0;
+    if (keep_logs && t.h_counts[k] == c) continue;
     t.h_logc_full[k] = c > 0 ? std::log((double)c - discount) : kNegInf;
     t.h_logc_m1[k] = c > 1 ? std::log((double)(c - 1) - discount) : kNegInf;
   }
+  t.h_counts.assign(counts, counts + n_rows);
   t.scal[0] = std::log((double)total + strength);
   t.scal[1] = std::log((double)(total - 1) + strength);
   t.scal[2] = std::log(strength + discount * (double)live);

@@ -58,9 +58,23 @@ struct AggTermArgs {
   int32_t* cnt[PCLEAN_MAX_TERMS];
   int32_t* end[PCLEAN_MAX_TERMS];
 };
+// every term of every node of a latent plan at once (ensure_agg_all)
+#define AGG_ALL_MAX 48
+struct AggAllArgs {
+  const int32_t* obs_col[AGG_ALL_MAX];
+  int32_t ctx_slot[AGG_ALL_MAX];
+  uint64_t* uniq[AGG_ALL_MAX];
+  int32_t* cnt[AGG_ALL_MAX];
+  int32_t* end[AGG_ALL_MAX];
+};
+struct AggAllPack {
+  AggDev a[AGG_ALL_MAX];
+  int32_t dst[AGG_ALL_MAX];  // where entry i goes in the per-node arrays: node * PCLEAN_MAX_TERMS + term
+};
+template <typename Args>
 __global__ __launch_bounds__(256) void agg_item_kernel(int n_items, const int32_t* __restrict__ ev_off,
                                                        const int32_t* __restrict__ ev_rows, const int32_t* __restrict__ ev_ctx,
-                                                       AggTermArgs a) {
+                                                       Args a) {
   __shared__ uint64_t s_key[AGG_LDS_CAP];
   __shared__ int32_t s_run[AGG_LDS_CAP];  // run id of sorted position i, then the run lengths
   __shared__ int s_w[4];
@@ -138,6 +152,10 @@ __global__ void write_agg_kernel(AggPack p, int n, AggDev* dst) {
   const int i = threadIdx.x;
   if (i < n) dst[i] = p.a[i];
 }
+__global__ void write_agg_all_kernel(AggAllPack p, int n, AggDev* dst) {
+  const int i = threadIdx.x;
+  if (i < n) dst[p.dst[i]] = p.a[i];
+}
 
 // A per-evidence-row ctx value occupies 16 bits of an aggregation key (agg_key_kernel / agg_item_kernel): its domain
 // (the ctx side of the term's fn table, or the error-probability table of a MaybeSwap term) must stay below 2^16 or runs
@@ -152,6 +170,68 @@ static int agg_ctx_fits(pclean_ctx* ctx, const pclean_term& tm, int ctx_slot) {
   if (dom >= (1 << 16))
     return pclean_fail(ctx, PCLEAN_ERR_CAPACITY, "evidence aggregation: a per-evidence-row ctx domain of %lld values does not "
                                                  "fit the 16 key bits", (long long)dom);
+  return PCLEAN_OK;
+}
+
+// The aggregated evidence of EVERY node of the plan in one launch, at the start of a pclean_sweep_latent call whose items fit
+// the LDS aggregation (the sub-batches of a large latent class: a dozen nodes each, one ~25 us launch + one pointer-table
+// write per node was 12 ms of a Hospital class sweep).  Whatever this leaves out (a plan with more terms than AGG_ALL_MAX, a
+// term without its per-evidence-row ctx, ...) is built, or refused, by ensure_agg when a node asks for it.
+static int ensure_agg_all(pclean_ctx* ctx, int block_id, const int32_t* ev_rows, const int32_t* ev_ctx) {
+  static const bool off = getenv("PCLEAN_NO_AGG_ALL") != nullptr;
+  SweepState* s = st(ctx);
+  const Block& b = ctx->block[block_id];
+  const int n_ev = s->lat_ev, n_items = s->lat_items, n_nodes = (int)b.nodes.size();
+  if (off || n_ev <= 0 || n_items <= 0 || n_items >= (1 << 24) || s->lat_max_ev > AGG_LDS_CAP || ctx->no_item_agg) return PCLEAN_OK;
+  int total = 0;
+  for (int node = 0; node < n_nodes; ++node) {
+    const pclean_node& n = b.nodes[node];
+    if (n.n_terms > PCLEAN_MAX_TERMS) return PCLEAN_OK;
+    for (int ti = 0; ti < n.n_terms; ++ti) {
+      const pclean_term& tm = b.terms[n.term_begin + ti];
+      const PairTable& pt = ctx->pair[tm.pair_table];
+      const int ctx_slot = (tm.ctx_slot >= 0 && tm.ctx_mode != 0) ? tm.ctx_slot : -1;
+      if (tm.obs_col < 0 || tm.obs_col >= ctx->n_cols || (pt.valid && pt.n_obs + 1 >= (1 << 24)) || (ctx_slot >= 0 && !ev_ctx)) return PCLEAN_OK;
+      if (ctx_slot >= 0) {  // (16 key bits per ctx value: agg_ctx_fits, which fails the call — left to ensure_agg)
+        int64_t dom = 0;
+        if (tm.dens_kind == PCLEAN_DENS_MAYBE_SWAP)
+          dom = ctx->n_prob;
+        else if (tm.fn_table >= 0 && tm.fn_table < PCLEAN_MAX_TABLES && ctx->fn[tm.fn_table].valid)
+          dom = tm.ctx_mode == 2 ? ctx->fn[tm.fn_table].n_b : ctx->fn[tm.fn_table].n_a;
+        if (dom >= (1 << 16)) return PCLEAN_OK;
+      }
+    }
+    total += n.n_terms;
+  }
+  if (total <= 0 || total > AGG_ALL_MAX) return PCLEAN_OK;
+  ProfScope ps(ctx, "evidence_aggregation");
+  AggDev* dst = (AggDev*)scratch<unsigned char>(ctx, sizeof(AggDev) * PCLEAN_MAX_TERMS * (size_t)n_nodes);
+  uint64_t* uniq = scratch<uint64_t>(ctx, (size_t)n_ev * total);
+  int32_t* cnt = scratch<int32_t>(ctx, (size_t)n_ev * total);
+  int32_t* end = scratch<int32_t>(ctx, (size_t)n_items * total);
+  if (!dst || !uniq || !cnt || !end) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  AggAllArgs at{};
+  AggAllPack pack{};
+  int k = 0;
+  for (int node = 0; node < n_nodes; ++node) {
+    const pclean_node& n = b.nodes[node];
+    for (int ti = 0; ti < n.n_terms; ++ti, ++k) {
+      const pclean_term& tm = b.terms[n.term_begin + ti];
+      at.obs_col[k] = ctx->obs.p + (size_t)tm.obs_col * ctx->n_rows;
+      at.ctx_slot[k] = (tm.ctx_slot >= 0 && tm.ctx_mode != 0) ? tm.ctx_slot : -1;
+      at.uniq[k] = uniq + (size_t)n_ev * k;
+      at.cnt[k] = cnt + (size_t)n_ev * k;
+      at.end[k] = end + (size_t)n_items * k;
+      pack.a[k] = AggDev{at.uniq[k], at.cnt[k], s->lat_off, at.end[k]};
+      pack.dst[k] = node * PCLEAN_MAX_TERMS + ti;
+    }
+  }
+  hipLaunchKernelGGL(agg_item_kernel<AggAllArgs>, dim3(n_items, total), dim3(256), 0, ctx->stream, n_items, s->lat_off, ev_rows,
+                     ev_ctx, at);
+  hipLaunchKernelGGL(write_agg_all_kernel, dim3(1), dim3(64), 0, ctx->stream, pack, total, dst);
+  HIPCHK(ctx, hipGetLastError());
+  for (int node = 0; node < n_nodes; ++node)
+    if (b.nodes[node].n_terms > 0) s->lat_agg[node] = dst + (size_t)node * PCLEAN_MAX_TERMS;
   return PCLEAN_OK;
 }
 
@@ -190,8 +270,8 @@ int ensure_agg(pclean_ctx* ctx, int block_id, int node_id, const ItemList& il, c
       if (!at.uniq[ti] || !at.cnt[ti] || !at.end[ti]) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
       pack.a[ti] = AggDev{at.uniq[ti], at.cnt[ti], s->lat_off, at.end[ti]};
     }
-    hipLaunchKernelGGL(agg_item_kernel, dim3(n_items, n.n_terms), dim3(256), 0, ctx->stream, n_items, s->lat_off, il.ev_rows,
-                       il.ev_ctx, at);
+    hipLaunchKernelGGL(agg_item_kernel<AggTermArgs>, dim3(n_items, n.n_terms), dim3(256), 0, ctx->stream, n_items, s->lat_off,
+                       il.ev_rows, il.ev_ctx, at);
     hipLaunchKernelGGL(write_agg_kernel, dim3(1), dim3(64), 0, ctx->stream, pack, n.n_terms, dst);
     HIPCHK(ctx, hipGetLastError());
     s->lat_agg[node_id] = dst;
@@ -515,6 +595,7 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   s->lat_max_ev = 0;
   for (int t = 0; t < n_items; ++t) s->lat_max_ev = std::max(s->lat_max_ev, ev_off[t + 1] - ev_off[t]);
   s->lat_agg.clear();
+  { const int rca = ensure_agg_all(ctx, block_id, d_evr, d_evc); if (rca) return rca; }
   if (!cfg->use_dd_proposals) {
     // Prior proposals (block_proposal.jl:168): particle 0 keeps the row's current values (excl[r][t]: current referent
     // of a reference slot, current OPTION of a choice), every other particle draws each attribute from its prior;
