@@ -234,6 +234,33 @@ function argsort_ids(c, ids::Vector{Int32}, id_max)
     GC.@preserve ids out check(c, ccall((:pclean_argsort_ids, lib), Cint, (Ptr{Cvoid}, Int32, Ptr{Int32}, Int32, Ptr{Int32}),
                                         c.h, length(ids), ids, id_max, out)); out
 end
+# Evidence sets of a latent class built on the device (pclean_build_evidence): needs the referents on the device (set_cur /
+# the device-resident commit) and the tables as uploaded.  steps = [(table id, reference-slot column)] from block cur_block's
+# root table down to the class, sources = [(block, table id, value column)] of the per-row ctx values.  Returns the offsets
+# (n_target_rows + 1, 0-based positions into the ordered rows that stay on the device).
+function build_evidence!(c, cur_block, steps::Vector{Tuple{Int32,Int32}}, n_target_rows, sources::Vector{Tuple{Int32,Int32,Int32}})
+    st = Int32[a for (a, _) in steps]; sc = Int32[b for (_, b) in steps]
+    sb = Int32[a for (a, _, _) in sources]; stb = Int32[b for (_, b, _) in sources]; scl = Int32[d for (_, _, d) in sources]
+    off = Vector{Int32}(undef, n_target_rows + 1)
+    GC.@preserve st sc sb stb scl off check(c, ccall((:pclean_build_evidence, lib), Cint,
+        (Ptr{Cvoid}, Int32, Int32, Ptr{Int32}, Ptr{Int32}, Int32, Int32, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+        c.h, cur_block, length(st), st, sc, n_target_rows, length(sb), sb, stb, scl, off)); off
+end
+function get_evidence(c, ev_begin, n)                                                                    # resident rows -> host (checks)
+    rows = Vector{Int32}(undef, n); cx = Matrix{Int32}(undef, MAX_CTX, n)
+    GC.@preserve rows cx check(c, ccall((:pclean_get_evidence, lib), Cint, (Ptr{Cvoid}, Int32, Int32, Ptr{Int32}, Ptr{Int32}),
+                                        c.h, ev_begin, n, rows, cx)); rows, cx
+end
+# sweep_latent! over rows ev_begin + ev_off[t] .. of the resident evidence (ev_off[1] == 0)
+function sweep_latent_resident!(c, cfg, seed, sweep_idx, block, roots::Vector{Int32}, keys::Vector{Int32}, ev_off::Vector{Int32},
+                                ev_begin, excl::Matrix{Int32}, n_nodes)
+    n = length(keys); chosen = zeros(Int32, n); vals = fill(Int32(-2), n_nodes, n); cc = Ref(CConfig(cfg))
+    GC.@preserve roots keys ev_off excl chosen vals check(c, ccall((:pclean_sweep_latent_resident, lib), Cint,
+        (Ptr{Cvoid}, Ref{CConfig}, UInt64, UInt32, Int32, Int32, Ptr{Int32}, Int32, Ptr{Int32}, Ptr{Int32}, Int32,
+         Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+        c.h, cc, seed, sweep_idx, block, length(roots), roots, n, keys, ev_off, ev_begin, excl, chosen, vals))
+    chosen, vals
+end
 # the remaining entry points (pclean_allreduce_stats_fused, pclean_random_*, the debug probes) bind the same way; signatures in
 # include/pclean_hip.h, tested Python bindings in pclean_amd/_lib.py.
 

@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PCLEAN_HIP_LIB") or os.path.join(HERE, "libpclean_hip.so")
 
 MAX_CTX = 4
+EV_MAX_STEPS = 4  # PCLEAN_EV_MAX_STEPS
 CHOICE_NEW = -1
 DIST_OSA, DIST_DL = 0, 1
 DENS_ADD_TYPOS, DENS_EQUAL, DENS_MAYBE_SWAP = 0, 1, 2
@@ -700,6 +701,45 @@ class HipContext:
         check(self.h, self.lib.pclean_argsort_ids(self.h, C.c_int32(len(ids)), _p(ids, C.c_int32), C.c_int32(int(id_max)),
                                                   _p(out, C.c_int32)), "pclean_argsort_ids")
         return out
+
+    def build_evidence(self, cur_block, steps, n_target_rows, sources):
+        """pclean_build_evidence: steps = [(table id, reference-slot column)], sources = [(block, table id, value column)];
+        returns off (int32 [n_target_rows + 1]); the ordered rows and their ctx values stay on the device"""
+        st = np.ascontiguousarray([s[0] for s in steps], dtype=np.int32)
+        sc = np.ascontiguousarray([s[1] for s in steps], dtype=np.int32)
+        sb = np.ascontiguousarray([s[0] for s in sources], dtype=np.int32)
+        stb = np.ascontiguousarray([s[1] for s in sources], dtype=np.int32)
+        scl = np.ascontiguousarray([s[2] for s in sources], dtype=np.int32)
+        off = np.empty(int(n_target_rows) + 1, dtype=np.int32)
+        check(self.h, self.lib.pclean_build_evidence(
+            self.h, C.c_int32(int(cur_block)), C.c_int32(len(st)), _p(st, C.c_int32) if len(st) else None,
+            _p(sc, C.c_int32) if len(sc) else None, C.c_int32(int(n_target_rows)), C.c_int32(len(sb)),
+            _p(sb, C.c_int32) if len(sb) else None, _p(stb, C.c_int32) if len(sb) else None,
+            _p(scl, C.c_int32) if len(sb) else None, _p(off, C.c_int32)), "pclean_build_evidence")
+        return off
+
+    def get_evidence(self, begin, n, with_ctx=True):
+        """rows [begin, begin + n) of the resident evidence: (observed row ids, ctx values [n][MAX_CTX] or None)"""
+        rows = np.empty(int(n), dtype=np.int32)
+        cx = np.empty((int(n), MAX_CTX), dtype=np.int32) if with_ctx else None
+        check(self.h, self.lib.pclean_get_evidence(self.h, C.c_int32(int(begin)), C.c_int32(int(n)), _p(rows, C.c_int32),
+                                                   _p(cx, C.c_int32) if with_ctx else None), "pclean_get_evidence")
+        return rows, cx
+
+    def sweep_latent_resident(self, cfg, seed, sweep_idx, block_id, roots, keys, ev_off, ev_begin, excl, n_nodes):
+        """pclean_sweep_latent over rows [ev_begin + ev_off[t], ev_begin + ev_off[t + 1]) of the resident evidence"""
+        roots = np.ascontiguousarray(roots, dtype=np.int32)
+        keys = np.ascontiguousarray(keys, dtype=np.int32)
+        ev_off = np.ascontiguousarray(ev_off, dtype=np.int32)
+        excl = np.ascontiguousarray(excl, dtype=np.int32)  # [n_roots][n_items]
+        n = len(keys)
+        chosen = np.zeros(n, dtype=np.int32)
+        vals = np.full((n, n_nodes), -2, dtype=np.int32)
+        check(self.h, self.lib.pclean_sweep_latent_resident(
+            self.h, C.byref(cfg), C.c_uint64(seed), C.c_uint32(sweep_idx), C.c_int32(block_id), C.c_int32(len(roots)),
+            _p(roots, C.c_int32), C.c_int32(n), _p(keys, C.c_int32), _p(ev_off, C.c_int32), C.c_int32(int(ev_begin)),
+            _p(excl, C.c_int32), _p(chosen, C.c_int32), _p(vals, C.c_int32)), "pclean_sweep_latent_resident")
+        return chosen, vals
 
     def set_timed_block(self, block_id):
         """which block's root launch group get_timing().hot_kernel_* / get_root_stats() describe (default 0)"""

@@ -217,6 +217,11 @@ struct pclean_ctx {
   DevBuf<int32_t> dev_cur;
   int32_t dev_cur_blocks = 0;
   bool dev_cur_valid = false;
+  // evidence CSR of a latent class built on the device (pclean_build_evidence): the observed rows ordered by the latent row
+  // they refer to and their per-row context values, kept for the sub-batches of the class sweep (pclean_sweep_latent_resident)
+  DevBuf<int32_t> ev_res_rows, ev_res_ctx;
+  int32_t ev_res_n = 0;         // rows held (0: nothing resident)
+  bool ev_res_has_ctx = false;
   bool defer_outputs = false;   // pclean_set_sweep_mode bit 0
   void* commit_state = nullptr;  // owned by commit.hip
   HostStage stage;               // page-locked staging of caller arrays (table uploads, latent-sweep inputs / outputs)

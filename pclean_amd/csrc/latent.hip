@@ -526,10 +526,13 @@ extern "C" int pclean_argsort_ids(pclean_ctx* ctx, int32_t n, const int32_t* ids
   return PCLEAN_OK;
 }
 
-extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
-                                   int32_t block_id, int32_t n_roots, const int32_t* roots, int32_t n_items,
-                                   const int32_t* keys, const int32_t* ev_off, const int32_t* ev_rows,
-                                   const int32_t* ev_ctx, const int32_t* excl, int32_t* chosen, int32_t* vals) {
+// res_rows / res_ctx: the items' evidence rows (and per-row ctx values) already on the device (pclean_sweep_latent_resident);
+// the host arrays ev_rows / ev_ctx are not looked at then (has_ctx says whether the plan's terms read per-row ctx values)
+static int sweep_latent_impl(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
+                             int32_t block_id, int32_t n_roots, const int32_t* roots, int32_t n_items,
+                             const int32_t* keys, const int32_t* ev_off, const int32_t* ev_rows,
+                             const int32_t* ev_ctx, const int32_t* excl, int32_t* chosen, int32_t* vals,
+                             const int32_t* res_rows, const int32_t* res_ctx) {
   if (!ctx || !cfg || block_id < 0 || block_id >= PCLEAN_MAX_BLOCKS || !ctx->block[block_id].valid || n_roots <= 0 ||
       !roots || n_items < 0 || !keys || !ev_off || !excl || !chosen || !vals)
     return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: bad arguments");
@@ -554,11 +557,16 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   }
   if (s->counter.alloc(4)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
   const int n_ev = ev_off[n_items];
-  if (n_ev > 0 && !ev_rows) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: evidence rows missing");
+  if (n_ev > 0 && !ev_rows && !res_rows) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent: evidence rows missing");
+  if (res_rows) {  // (resident evidence: nothing of it is staged)
+    ev_rows = nullptr;
+    ev_ctx = nullptr;
+  }
   int32_t* d_keys = scratch<int32_t>(ctx, n_items);
   int32_t* d_off = scratch<int32_t>(ctx, (size_t)n_items + 1);
-  int32_t* d_evr = scratch<int32_t>(ctx, std::max(n_ev, 1));
-  int32_t* d_evc = ev_ctx ? scratch<int32_t>(ctx, (size_t)std::max(n_ev, 1) * PCLEAN_MAX_CTX) : nullptr;
+  int32_t* d_evr = res_rows ? const_cast<int32_t*>(res_rows) : scratch<int32_t>(ctx, std::max(n_ev, 1));
+  int32_t* d_evc = res_rows ? const_cast<int32_t*>(res_ctx)
+                            : (ev_ctx ? scratch<int32_t>(ctx, (size_t)std::max(n_ev, 1) * PCLEAN_MAX_CTX) : nullptr);
   int32_t* d_excl = scratch<int32_t>(ctx, (size_t)n_roots * n_items);
   int32_t* d_chosen = scratch<int32_t>(ctx, n_items);
   int32_t* d_vals = scratch<int32_t>(ctx, (size_t)n_items * nn);
@@ -566,7 +574,7 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   if (!d_keys || !d_off || !d_evr || (ev_ctx && !d_evc) || !d_excl || !d_chosen || !d_vals || !d_flag)
     return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
   // inputs and outputs travel through the library's page-locked staging area (ctx.h: HostStage — never the caller's pages)
-  const size_t b_keys = (size_t)n_items * 4, b_off = ((size_t)n_items + 1) * 4, b_evr = (size_t)n_ev * 4,
+  const size_t b_keys = (size_t)n_items * 4, b_off = ((size_t)n_items + 1) * 4, b_evr = res_rows ? 0 : (size_t)n_ev * 4,
                b_evc = (ev_ctx && n_ev) ? (size_t)n_ev * PCLEAN_MAX_CTX * 4 : 0, b_excl = (size_t)n_roots * n_items * 4,
                b_vals = (size_t)n_items * nn * 4;
   if (ctx->stage.grow(2 * b_keys + b_off + b_evr + b_evc + b_excl + b_vals + 8 * 256))
@@ -837,6 +845,169 @@ extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* c
   s->lat_agg.clear();
   if (s->prof_on) prof_collect(ctx);
   return finish_call(ctx);
+}
+
+extern "C" int pclean_sweep_latent(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
+                                   int32_t block_id, int32_t n_roots, const int32_t* roots, int32_t n_items,
+                                   const int32_t* keys, const int32_t* ev_off, const int32_t* ev_rows,
+                                   const int32_t* ev_ctx, const int32_t* excl, int32_t* chosen, int32_t* vals) {
+  return sweep_latent_impl(ctx, cfg, seed, sweep_idx, block_id, n_roots, roots, n_items, keys, ev_off, ev_rows, ev_ctx, excl,
+                           chosen, vals, nullptr, nullptr);
+}
+
+// ---- the evidence CSR of a latent class on the device ----------------------------------------------------------------
+// What the host's build_evidence (inference.py) does with NumPy on 10^6 rows per class and iteration — follow the reference
+// slots from every observed row to the class's row, order the observed rows by that row (stable), gather the per-row context
+// values — with the referents and the tables where they already are (pclean_set_cur / the device-resident commit,
+// pclean_set_table).  The ordered rows and their ctx values stay on the device for the sub-batches of the class sweep.
+struct EvFollowDev {
+  int32_t n_steps;
+  const int32_t* col[PCLEAN_EV_MAX_STEPS];  // step s: the reference-slot column of the table the walk stands in
+  int32_t n_rows[PCLEAN_EV_MAX_STEPS];
+};
+struct EvSrcDev {
+  int32_t n;
+  const int32_t* cur[PCLEAN_MAX_CTX];  // the observed rows' referents in the source's block
+  const int32_t* col[PCLEAN_MAX_CTX];  // the value column of that block's root table
+  int32_t n_rows[PCLEAN_MAX_CTX];
+};
+__global__ void ev_follow_kernel(int n, const int32_t* __restrict__ cur, EvFollowDev f, uint32_t* __restrict__ key,
+                                 int32_t* __restrict__ idx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int k = cur[i];
+  for (int s = 0; s < f.n_steps; ++s) k = (k >= 0 && k < f.n_rows[s]) ? f.col[s][k] : -1;
+  key[i] = (uint32_t)(k + 1);  // (-1 = no referent sorts first)
+  idx[i] = i;
+}
+// off[k] = number of sorted keys below k + 1 = first position of latent row k's evidence rows, k = 0 .. n_target
+__global__ void ev_offsets_kernel(int n, const uint32_t* __restrict__ key_s, int n_target, int32_t* __restrict__ off) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > n_target) return;
+  const uint32_t want = (uint32_t)k + 1u;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (key_s[mid] < want) lo = mid + 1; else hi = mid;
+  }
+  off[k] = lo;
+}
+__global__ void ev_ctx_kernel(int n, const int32_t* __restrict__ order, EvSrcDev sv, int32_t* __restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int r = order[e];
+  int32_t v[PCLEAN_MAX_CTX];
+#pragma unroll
+  for (int q = 0; q < PCLEAN_MAX_CTX; ++q) {
+    v[q] = 0;
+    if (q < sv.n) {
+      const int k = sv.cur[q][r];
+      v[q] = (k >= 0 && k < sv.n_rows[q]) ? sv.col[q][k] : 0;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PCLEAN_MAX_CTX; ++q) out[(size_t)e * PCLEAN_MAX_CTX + q] = v[q];
+}
+
+extern "C" int pclean_build_evidence(pclean_ctx* ctx, int32_t cur_block, int32_t n_steps, const int32_t* step_table,
+                                     const int32_t* step_col, int32_t n_target_rows, int32_t n_src, const int32_t* src_block,
+                                     const int32_t* src_table, const int32_t* src_col, int32_t* off_out) {
+  if (!ctx || n_steps < 0 || n_steps > PCLEAN_EV_MAX_STEPS || (n_steps > 0 && (!step_table || !step_col)) || n_target_rows < 0 ||
+      n_src < 0 || n_src > PCLEAN_MAX_CTX || (n_src > 0 && (!src_block || !src_table || !src_col)) || !off_out)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_build_evidence: bad arguments");
+  if (!ctx->dev_cur_valid || cur_block < 0 || cur_block >= ctx->dev_cur_blocks || ctx->n_rows <= 0)
+    return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_build_evidence: no device-resident referents (pclean_set_cur)");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  ctx->ev_res_n = 0;
+  const int n = ctx->n_rows;
+  EvFollowDev f{};
+  f.n_steps = n_steps;
+  for (int s = 0; s < n_steps; ++s) {
+    if (step_table[s] < 0 || step_table[s] >= PCLEAN_MAX_TABLES || !ctx->cand[step_table[s]].valid ||
+        ctx->cand[step_table[s]].is_options || step_col[s] < 0 || step_col[s] >= ctx->cand[step_table[s]].n_cols)
+      return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_build_evidence: bad step %d", s);
+    const CandTable& t = ctx->cand[step_table[s]];
+    f.col[s] = t.cols.p + (size_t)step_col[s] * t.n_rows;
+    f.n_rows[s] = t.n_rows;
+  }
+  EvSrcDev sv{};
+  sv.n = n_src;
+  for (int q = 0; q < n_src; ++q) {
+    if (src_block[q] < 0 || src_block[q] >= ctx->dev_cur_blocks || src_table[q] < 0 || src_table[q] >= PCLEAN_MAX_TABLES ||
+        !ctx->cand[src_table[q]].valid || ctx->cand[src_table[q]].is_options || src_col[q] < 0 ||
+        src_col[q] >= ctx->cand[src_table[q]].n_cols)
+      return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_build_evidence: bad ctx source %d", q);
+    const CandTable& t = ctx->cand[src_table[q]];
+    sv.cur[q] = ctx->dev_cur.p + (size_t)src_block[q] * ctx->n_rows;
+    sv.col[q] = t.cols.p + (size_t)src_col[q] * t.n_rows;
+    sv.n_rows[q] = t.n_rows;
+  }
+  int rc = begin_call(ctx);
+  if (rc) return rc;
+  if (ctx->ev_res_rows.n < (size_t)n && ctx->ev_res_rows.alloc((size_t)n + (size_t)n / 16))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  if (n_src > 0 && ctx->ev_res_ctx.n < (size_t)n * PCLEAN_MAX_CTX && ctx->ev_res_ctx.alloc(((size_t)n + (size_t)n / 16) * PCLEAN_MAX_CTX))
+    return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
+  uint32_t* key = scratch<uint32_t>(ctx, n);
+  uint32_t* key_s = scratch<uint32_t>(ctx, n);
+  int32_t* idx = scratch<int32_t>(ctx, n);
+  int32_t* d_off = scratch<int32_t>(ctx, (size_t)n_target_rows + 1);
+  if (!key || !key_s || !idx || !d_off) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  int bits = 1;
+  while (bits < 32 && ((uint64_t)1 << bits) <= (uint64_t)n_target_rows + 1ull) ++bits;
+  size_t tmp_bytes = 0;
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, key, key_s, idx, ctx->ev_res_rows.p, n, 0, bits, ctx->stream));
+  unsigned char* tmp = scratch<unsigned char>(ctx, std::max<size_t>(tmp_bytes, 16));
+  if (!tmp) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  const size_t b_off = ((size_t)n_target_rows + 1) * sizeof(int32_t);
+  if (ctx->stage.grow(b_off + 1024)) return pclean_fail(ctx, PCLEAN_ERR_HIP, "page-locked staging alloc failed");
+  ctx->stage.rewind();
+  void* h_off = ctx->stage.take(b_off);
+  if (!h_off) return pclean_fail(ctx, PCLEAN_ERR_HIP, "page-locked staging alloc failed");
+  hipLaunchKernelGGL(ev_follow_kernel, grid1(n), dim3(256), 0, ctx->stream, n, ctx->dev_cur.p + (size_t)cur_block * ctx->n_rows, f,
+                     key, idx);
+  // (LSD radix sort: stable — the rows of one latent row stay in ascending order, as np.argsort(kind="stable") leaves them)
+  HIPCHK(ctx, hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, key, key_s, idx, ctx->ev_res_rows.p, n, 0, bits, ctx->stream));
+  hipLaunchKernelGGL(ev_offsets_kernel, grid1((size_t)n_target_rows + 1), dim3(256), 0, ctx->stream, n, key_s, n_target_rows, d_off);
+  if (n_src > 0)
+    hipLaunchKernelGGL(ev_ctx_kernel, grid1(n), dim3(256), 0, ctx->stream, n, ctx->ev_res_rows.p, sv, ctx->ev_res_ctx.p);
+  HIPCHK(ctx, hipGetLastError());
+  HIPCHK(ctx, hipMemcpyAsync(h_off, d_off, b_off, hipMemcpyDeviceToHost, ctx->stream));
+  PCLEAN_SYNC(ctx);
+  memcpy(off_out, h_off, b_off);
+  ctx->ev_res_n = n;
+  ctx->ev_res_has_ctx = n_src > 0;
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_get_evidence(pclean_ctx* ctx, int32_t begin, int32_t n, int32_t* rows_out, int32_t* ctx_out) {
+  if (!ctx || begin < 0 || n < 0 || (n > 0 && !rows_out)) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_get_evidence: bad arguments");
+  if ((int64_t)begin + n > ctx->ev_res_n) return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_get_evidence: range outside the resident evidence");
+  if (n == 0) return PCLEAN_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpyAsync(rows_out, ctx->ev_res_rows.p + begin, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (ctx_out) {
+    if (ctx->ev_res_has_ctx)
+      HIPCHK(ctx, hipMemcpyAsync(ctx_out, ctx->ev_res_ctx.p + (size_t)begin * PCLEAN_MAX_CTX, (size_t)n * PCLEAN_MAX_CTX * 4,
+                                 hipMemcpyDeviceToHost, ctx->stream));
+    else
+      memset(ctx_out, 0, (size_t)n * PCLEAN_MAX_CTX * 4);
+  }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return PCLEAN_OK;
+}
+
+extern "C" int pclean_sweep_latent_resident(pclean_ctx* ctx, const pclean_infer_config* cfg, uint64_t seed, uint32_t sweep_idx,
+                                            int32_t block_id, int32_t n_roots, const int32_t* roots, int32_t n_items,
+                                            const int32_t* keys, const int32_t* ev_off, int32_t ev_begin,
+                                            const int32_t* excl, int32_t* chosen, int32_t* vals) {
+  if (!ctx || !ev_off || n_items < 0) return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent_resident: bad arguments");
+  if (ctx->ev_res_n <= 0) return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_sweep_latent_resident: no resident evidence (pclean_build_evidence)");
+  if (ev_begin < 0 || ev_off[0] != 0 || ev_off[n_items] < 0 || (int64_t)ev_begin + ev_off[n_items] > ctx->ev_res_n)
+    return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep_latent_resident: evidence range outside the resident rows");
+  return sweep_latent_impl(ctx, cfg, seed, sweep_idx, block_id, n_roots, roots, n_items, keys, ev_off, nullptr, nullptr, excl,
+                           chosen, vals, ctx->ev_res_rows.p + ev_begin,
+                           ctx->ev_res_has_ctx ? ctx->ev_res_ctx.p + (size_t)ev_begin * PCLEAN_MAX_CTX : nullptr);
 }
 
 // pclean_score_node for EVIDENCE SETS: item t is a latent row scored against the observed rows

@@ -564,14 +564,55 @@ class Engine:
                     for bi, blk in enumerate(self.lw.blocks) if not blk.get("score")}
         return {bi: self.hip.get_moved(bi) for bi, blk in enumerate(self.lw.blocks) if not blk.get("score")}
 
-    def sweep_latent(self, trace, cname, config, seed, sweep_idx, live, ev_off, ev_rows, ev_ctx, excl):
+    def sweep_latent(self, trace, cname, config, seed, sweep_idx, live, ev_off, ev_rows, ev_ctx, excl, ev_begin=None):
         """Rejuvenation of the latent rows `live` of class cname against their evidence sets
-        (pclean_sweep_latent).  Returns (chosen particle, sampled node values) per latent row."""
+        (pclean_sweep_latent).  Returns (chosen particle, sampled node values) per latent row.  ev_begin (with ev_rows
+        None): the rows' evidence starts at that position of the evidence build_evidence_device left on the device."""
         pl = self.lw.latent_plans[cname]
         cfg = config.as_c() if isinstance(config, InferenceConfig) else config
         self.hip.set_active_rows(0, -1)
+        if ev_begin is not None:
+            return self.hip.sweep_latent_resident(cfg, seed, sweep_idx, pl["block_id"], pl["roots"], live, ev_off, ev_begin,
+                                                  excl, len(pl["nodes"]))
         return self.hip.sweep_latent(cfg, seed, sweep_idx, pl["block_id"], pl["roots"], live, ev_off, ev_rows, ev_ctx,
                                      excl, len(pl["nodes"]))
+
+    def build_evidence_device(self, trace, cname):
+        """inference.build_evidence on the device (pclean_build_evidence): returns (live, ev_off, None, None) with the ordered
+        evidence rows and their per-row ctx values left in HBM for sweep_latent(..., ev_rows=None, ev_begin=...), or None
+        when this class / state takes the host path (no device-resident referents, MaybeSwap / Gaussian evidence contexts,
+        a walk longer than the library's, references to dead rows).  Same arrays as the host path, element for element
+        (tests/test_gpu_edges.py::test_device_evidence_equals_host)."""
+        lw = self.lw
+        dc = getattr(self, "_dc", None)
+        if dc is None or os.environ.get("PCLEAN_HOST_EVIDENCE"):
+            return None
+        pl = lw.latent_plans[cname]
+        if cname in lw.latent_ev_prob or cname in getattr(lw, "latent_ev_locals", {}):
+            return None
+        bi = pl["src_block"]
+        steps, cn = [], lw.blocks[bi]["root_class"]
+        for step in [p for p in pl["path"].split(".") if p]:
+            j = lw.colidx[cn][step]
+            steps.append((lw.table_id[cn], j))
+            cn = lw.layout[cn][j].target
+        sources = []
+        for ob, col in pl.get("ctx_sources", []):
+            sources.append((ob, lw.table_id[lw.blocks[ob]["root_class"]], col))
+        if len(steps) > _lib.EV_MAX_STEPS or len(sources) > _lib.MAX_CTX or cn != cname:
+            return None
+        t = trace.tables[cname]  # (a trace that device commits left behind pulls here)
+        self.upload_trace(trace)
+        self._sync_cur(trace)
+        off = self.hip.build_evidence(bi, steps, t.n, sources)
+        counts = np.diff(off)
+        if off[0] != 0 or int(off[-1]) != trace.cur.shape[1] or counts[~t.live[:t.n]].any():
+            return None  # rows without a referent / referring to dead rows: the host path filters them
+        live = np.nonzero(t.live[:t.n])[0].astype(np.int32)
+        ev_off = np.zeros(len(live) + 1, dtype=np.int32)
+        np.cumsum(counts[live], out=ev_off[1:])
+        # (dead rows hold no evidence: the live rows' groups are contiguous in the resident order, live row j's at ev_off[j])
+        return live, ev_off, None, None
 
     def init_device_comm(self, comm):
         """Bind the library's own RCCL communicator to the ranks of `comm` (parallel.Comm over torch.distributed):

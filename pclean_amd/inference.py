@@ -30,6 +30,9 @@ from contextlib import contextmanager as _cm
 TIMERS = _dd(float)
 # PCLEAN_HOST_COMMIT=1: commit every observed-class sweep on the host (the path of several ranks, of refused device commits)
 DEVICE_COMMIT = not os.environ.get("PCLEAN_HOST_COMMIT")
+# observed rows from which a latent class's evidence sets are built on the device (Engine.build_evidence_device; below:
+# NumPy on the host is as fast as the round trip); PCLEAN_HOST_EVIDENCE=1 keeps the host path at every size
+DEVICE_EVIDENCE_MIN_ROWS = 1 << 17
 
 
 @_cm
@@ -429,9 +432,20 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
     pl = lw.latent_plans[cname]
     from ._lib import _ctx_cols
     dev_sort = getattr(getattr(engine, "hip", None), "argsort_ids", None) if not os.environ.get("PCLEAN_HOST_ARGSORT") else None
+
+    def evidence():
+        # on the device when the observed rows' referents and the tables live there (Engine.build_evidence_device: the
+        # ordered rows and their ctx values never cross PCIe; ev_rows is None then), else with NumPy on the host
+        dev = getattr(engine, "build_evidence_device", None)
+        if dev is not None and trace.cur.shape[1] >= DEVICE_EVIDENCE_MIN_ROWS:
+            got = dev(trace, cname)
+            if got is not None:
+                return got
+        live_, off_, rows_, ctx_ = build_evidence(lw, trace, cname, dev_sort)
+        return live_, off_, rows_, _ctx_cols(ctx_)  # padded to the library's width once, not in every sub-batch's call
+
     with _timed(f"latent/{cname}/build_evidence"):
-        live, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname, dev_sort)
-        ev_ctx = _ctx_cols(ev_ctx)  # padded to the library's width once, not in every sub-batch's call
+        live, ev_off, ev_rows, ev_ctx = evidence()
     if len(live) == 0:
         return 0
     t = trace.tables[cname]
@@ -462,10 +476,15 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
         vals = np.zeros((0, len(pl["nodes"])), np.int32)
         if hi > lo:
             with _timed(f"latent/{cname}/gpu_sweep"):
-                chosen, vals = engine.sweep_latent(trace, cname, config, seed, sweep_idx, live[lo:hi],
-                                                   ev_off[lo:hi + 1] - e0, ev_rows[e0:e1],
-                                                   None if ev_ctx is None else ev_ctx[e0:e1],
-                                                   np.ascontiguousarray(excl[:, lo - b0:hi - b0]))
+                if ev_rows is None:  # (resident evidence)
+                    chosen, vals = engine.sweep_latent(trace, cname, config, seed, sweep_idx, live[lo:hi],
+                                                       ev_off[lo:hi + 1] - e0, None, None,
+                                                       np.ascontiguousarray(excl[:, lo - b0:hi - b0]), ev_begin=e0)
+                else:
+                    chosen, vals = engine.sweep_latent(trace, cname, config, seed, sweep_idx, live[lo:hi],
+                                                       ev_off[lo:hi + 1] - e0, ev_rows[e0:e1],
+                                                       None if ev_ctx is None else ev_ctx[e0:e1],
+                                                       np.ascontiguousarray(excl[:, lo - b0:hi - b0]))
         if comm.world > 1:
             chosen = comm.allgather_varlen_i32(chosen)
             vals = comm.allgather_varlen_i32(vals).reshape(-1, len(pl["nodes"]))
@@ -474,8 +493,7 @@ def latent_sweep(engine, trace, cname, config, seed, sweep_idx, comm=None, max_s
             if _after_commit(engine, trace, seed):
                 pl = lw.latent_plans[cname]  # (the lowered model was rebuilt in place)
                 # placeholders became drawn strings: per-evidence-row ctx values may have held a dummy's id
-                live2, ev_off, ev_rows, ev_ctx = build_evidence(lw, trace, cname, dev_sort)
-                ev_ctx = _ctx_cols(ev_ctx)
+                live2, ev_off, ev_rows, ev_ctx = evidence()
                 assert np.array_equal(live2, live)
     for _ in range(deferred_moves):
         resample_class_parameters(trace, cname)

@@ -331,3 +331,77 @@ def test_device_argsort_of_ids_is_numpys_stable_argsort():
         assert len(hip.argsort_ids(np.zeros(0, np.int32), 0)) == 0
     finally:
         hip.close()
+
+
+def test_device_evidence_equals_host():
+    """pclean_build_evidence (the evidence sets of a latent class built on the device from the device-resident referents and
+    tables) against inference.build_evidence (NumPy on the host): same live rows, offsets, ordered rows and per-row ctx values,
+    element for element, for every latent class of the synthetic hospital program — after the initialisation, after a device
+    commit of an observed sweep (the referents then exist on the device alone until the host pulls them) and after a latent
+    class's own sweep moved referents; pclean_sweep_latent_resident gives pclean_sweep_latent's result; a full run_inference
+    iteration ends in the same trace whichever path builds the sets."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from pclean_amd import inference as inf
+    from pclean_amd._lib import _ctx_cols
+    dirty, clean, lw, obs = bench.build_workload(6000, 60, 7)
+    cfg = InferenceConfig(1, 4)
+
+    def check_all(eng, tr, sweep_too):
+        for cname in lw.model.class_order:
+            if cname not in lw.latent_plans:
+                continue
+            pl = lw.latent_plans[cname]
+            got = eng.build_evidence_device(tr, cname)  # (first: a trace the device is ahead of is pulled in here)
+            assert got is not None, cname
+            live, ev_off, ev_rows, ev_ctx = inf.build_evidence(lw, tr, cname)
+            assert np.array_equal(got[0], live) and np.array_equal(got[1], ev_off) and got[2] is None, cname
+            rows, cx = eng.hip.get_evidence(0, len(ev_rows))
+            assert np.array_equal(rows, ev_rows), cname
+            want_cx = _ctx_cols(ev_ctx)
+            assert np.array_equal(cx, want_cx if want_cx is not None else np.zeros_like(cx)), cname
+            if not sweep_too:
+                continue
+            excl = inf.latent_current_choices(lw, tr, cname, live, cfg)
+            lo, hi = len(live) // 3, len(live)  # (a sub-range: ev_begin > 0)
+            e0, e1 = int(ev_off[lo]), int(ev_off[hi])
+            a = eng.sweep_latent(tr, cname, cfg, 11, 0, live[lo:hi], ev_off[lo:hi + 1] - e0, ev_rows[e0:e1],
+                                 None if ev_ctx is None else ev_ctx[e0:e1], np.ascontiguousarray(excl[:, lo:hi]))
+            b = eng.sweep_latent(tr, cname, cfg, 11, 0, live[lo:hi], ev_off[lo:hi + 1] - e0, None, None,
+                                 np.ascontiguousarray(excl[:, lo:hi]), ev_begin=e0)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), cname
+
+    eng = Engine(lw, obs, dist_mode=0)
+    try:
+        tr = Trace(lw, obs.shape[1], 7)
+        inf.initialize_trace(eng, tr, cfg, 7)
+        assert eng.enable_device_commit(tr), getattr(eng, "_dc_why", "")
+        check_all(eng, tr, True)
+        inf.observed_sweep(eng, tr, cfg, 7, 0)  # device commit: the trace is behind the device now
+        check_all(eng, tr, False)
+        inf.latent_sweep(eng, tr, "Hospital", cfg, 7, 0)
+        inf.latent_sweep(eng, tr, "Place", cfg, 7, 0)
+        check_all(eng, tr, True)
+    finally:
+        eng.close()
+    # the same iteration with the sets built on the device and on the host: identical traces
+    ends = []
+    for min_rows in (0, 1 << 30):
+        old = inf.DEVICE_EVIDENCE_MIN_ROWS
+        inf.DEVICE_EVIDENCE_MIN_ROWS = min_rows
+        eng = Engine(lw, obs, dist_mode=0)
+        try:
+            tr = Trace(lw, obs.shape[1], 7)
+            inf.initialize_trace(eng, tr, cfg, 7)
+            eng.prepare(tr)
+            inf.run_inference(eng, tr, InferenceConfig(2, 4), 7)
+            ends.append((tr.cur.copy(), {c: (t.cols[:, :t.n].copy(), t.counts[:t.n].copy(), t.live[:t.n].copy())
+                                        for c, t in tr.tables.items()}))
+        finally:
+            inf.DEVICE_EVIDENCE_MIN_ROWS = old
+            eng.close()
+    assert np.array_equal(ends[0][0], ends[1][0])
+    for c in ends[0][1]:
+        for x, y in zip(ends[0][1][c], ends[1][1][c]):
+            assert np.array_equal(x, y), c
