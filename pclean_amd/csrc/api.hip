@@ -40,6 +40,7 @@ extern "C" int pclean_ctx_destroy(pclean_ctx* ctx) {
   pclean_commit_state_free(ctx);
   pclean_sweep_state_free(ctx);
   ctx->stage.release();
+  ctx->ustage.release();
   ctx->stats_pack.release();
   ctx->sym.release();
   ctx->off.release();
@@ -385,7 +386,7 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
   if (keep_cols && (!t.valid || t.is_options || t.n_rows != n_rows || t.n_cols != n_cols))
     return pclean_fail(ctx, PCLEAN_ERR_STATE, "pclean_set_table: cols == NULL needs a previous upload of the same shape");
   const bool same_shape = t.valid && !t.is_options && t.n_rows == n_rows && t.n_cols == n_cols;
-  const bool mirror_was_stale = t.h_mirror_stale;  // (a device commit moved the device columns on: h_cols is not what they hold)
+  const bool mirror_was_stale = t.h_cols_stale;  // (a device commit wrote value columns: h_cols is not what the device holds)
   const uint64_t prev_cols_version = t.cols_version;
   int32_t upload_delta_n = -1;
   t.is_options = false;
@@ -433,19 +434,28 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
       void* h = ctx->stage.take(b_cols);
       memcpy(h, cols, b_cols);
       HIPCHK(ctx, hipMemcpyAsync(t.cols.p, h, b_cols, hipMemcpyHostToDevice, ctx->stream));
-      // which rows differ from the previous upload of the same shape (the compact byte tables built from it are then
-      // refreshed for those rows alone: eval.hip, try_fast_root)
+      // which rows differ from the previous upload of the same shape, and in which columns (the compact byte tables built
+      // from it are then refreshed for those rows alone: eval.hip, try_fast_root)
       static const bool no_upload_delta = getenv("PCLEAN_NO_UPLOAD_DELTA") != nullptr;
+      std::vector<int32_t> rows;
+      std::vector<uint64_t> masks;  // bit min(c, 63) of masks[q]: column c of rows[q] changed
+      bool diffed = false;
       if (same_shape && !mirror_was_stale && !no_upload_delta && t.h_cols.size() == n) {
-        std::vector<int32_t> rows;
-        const size_t limit = (size_t)n_rows / 8;
-        for (int k = 0; k < n_rows && rows.size() <= limit; ++k)
-          for (int c = 0; c < n_cols; ++c)
-            if (cols[(size_t)c * n_rows + k] != t.h_cols[(size_t)c * n_rows + k]) {
-              rows.push_back(k);
-              break;
-            }
-        if (rows.size() <= limit) {
+        diffed = true;
+        std::vector<uint64_t> m((size_t)n_rows, 0);
+        for (int c = 0; c < n_cols; ++c) {  // (column-major arrays: one sequential pass per column)
+          const int32_t* a = cols + (size_t)c * n_rows;
+          const int32_t* b0 = t.h_cols.data() + (size_t)c * n_rows;
+          const uint64_t bit = 1ull << std::min(c, 63);
+          for (int k = 0; k < n_rows; ++k)
+            if (a[k] != b0[k]) m[k] |= bit;
+        }
+        for (int k = 0; k < n_rows; ++k)
+          if (m[k]) {
+            rows.push_back(k);
+            masks.push_back(m[k]);
+          }
+        if (rows.size() <= (size_t)n_rows / 8) {  // the delta of this upload alone, whatever the column (t.cols_delta_*)
           upload_delta_n = (int32_t)rows.size();
           if (upload_delta_n > 0) {
             if (t.upload_delta_rows.alloc(rows.size())) return pclean_fail(ctx, PCLEAN_ERR_HIP, "device alloc failed");
@@ -456,6 +466,19 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
         }
       }
       t.h_cols.assign(cols, cols + n);
+      t.h_cols_stale = false;
+      // the chain of deltas (ctx.h): this upload's joins it, or — rows unknown — ends it
+      if (!diffed || (!t.delta_log.empty() && t.delta_log.back().next != prev_cols_version)) t.delta_log.clear();
+      if (diffed) {
+        if (t.delta_log.size() >= 256) t.delta_log.erase(t.delta_log.begin(), t.delta_log.begin() + 128);
+        t.delta_log.push_back(CandTable::DeltaEntry{prev_cols_version, 0, std::move(rows), std::move(masks)});  // (next: below)
+      }
+      t.union_n = -1;
+      static const bool dbg_chain = getenv("PCLEAN_DEBUG_CHAIN") != nullptr;
+      if (dbg_chain)
+        fprintf(stderr, "[chain] set_table %d (%d rows): same_shape %d mirror_stale %d delta %d -> log %zu (%zu rows in the last entry)\n",
+                table_id, n_rows, (int)same_shape, (int)mirror_was_stale, upload_delta_n, t.delta_log.size(),
+                t.delta_log.empty() ? (size_t)0 : t.delta_log.back().rows.size());
     }
     dbg_c = dbg_ms();
     if (n_rows) {
@@ -480,6 +503,7 @@ extern "C" int pclean_set_table(pclean_ctx* ctx, int32_t table_id, int32_t n_row
   t.version = ++g_pclean_version;
   if (!keep_cols) {
     t.cols_version = t.version;
+    if (!t.delta_log.empty()) t.delta_log.back().next = t.cols_version;
     t.cols_delta_n = upload_delta_n;
     if (upload_delta_n >= 0) {
       t.cols_delta_base = prev_cols_version;

@@ -461,7 +461,7 @@ extern "C" int pclean_commit_pull_table(pclean_ctx* ctx, int32_t table_id, int32
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int si = c->slot_of_table[table_id];
   CommitSlot& s = c->slot[si];
-  const CandTable& t = ctx->cand[table_id];
+  CandTable& t = ctx->cand[table_id];
   const size_t st = (size_t)t.n_rows;
   HIPCHK(ctx, hipMemcpyAsync(state8, c->d_states.p + (size_t)si * PCC_ST_WORDS, PCC_ST_WORDS * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (cols && st) HIPCHK(ctx, hipMemcpyAsync(cols, t.cols.p, st * t.n_cols * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -473,6 +473,12 @@ extern "C" int pclean_commit_pull_table(pclean_ctx* ctx, int32_t table_id, int32
     HIPCHK(ctx, hipMemsetAsync(s.origin.p, 0, st * 16, ctx->stream));
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  // the host holds the device's columns again: the library's mirror with them, so that the host's next re-upload can say
+  // which rows it changed (pclean_set_table: the chain of deltas the compact byte tables are refreshed along)
+  if (cols && st && t.h_cols_stale && t.h_cols.size() == st * (size_t)t.n_cols) {
+    memcpy(t.h_cols.data(), cols, st * (size_t)t.n_cols * 4);
+    t.h_cols_stale = false;
+  }
   return PCLEAN_OK;
 }
 
@@ -833,7 +839,14 @@ static int commit_device_impl(pclean_ctx* ctx, int32_t n_blocks, uint32_t sweep_
       t.cols_delta_base = t.cols_version;
       t.cols_delta_n = w[PCC_ST_NCHG];
       t.cols_delta_rows = cs.chg.p;
+      t.commit_delta_base = t.cols_version;
+      t.commit_delta_n = w[PCC_ST_NCHG];
+      t.commit_delta_rows = cs.chg.p;
       t.cols_version = t.version;
+      t.commit_delta_next = t.cols_version;
+      t.h_cols_stale = true;  // (until the host pulls the table: pclean_commit_pull_table)
+      t.delta_log.clear();
+      t.union_n = -1;
     }
     pclean_commit_slot& o = out->slot[si];
     o.table_id = cs.table_id;

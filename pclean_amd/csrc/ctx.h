@@ -119,6 +119,27 @@ struct CandTable {
   std::vector<int32_t> h_cols;
   DevBuf<int32_t> upload_delta_rows;
   bool h_mirror_stale = false;  // the device arrays moved on without the host mirrors (pclean_commit_device)
+  bool h_cols_stale = false;    // ... the value columns among them (a commit that created rows; pclean_commit_pull_table
+                                // brings h_cols up to date again)
+  // The chain of the host re-uploads' deltas: entry i leads from cols_version `base` to `next` by rewriting `rows`, entry
+  // i + 1 starts where entry i ends, the last one ends at cols_version.  A consumer built from ANY version on the chain (the
+  // observed class's compact byte tables, last refreshed before the 32 sub-batch uploads of a latent class sweep) refreshes
+  // the union of the rows since then instead of rebuilding (cols_union, eval.hip: try_fast_root).
+  // the device commit's own delta (rows it wrote, a device list that lives until the table's next commit): the chain's link
+  // before the first host re-upload that follows it
+  uint64_t commit_delta_base = 0, commit_delta_next = 0;
+  int32_t commit_delta_n = -1;
+  const int32_t* commit_delta_rows = nullptr;
+  struct DeltaEntry {
+    uint64_t base, next;
+    std::vector<int32_t> rows;
+    std::vector<uint64_t> masks;  // bit min(c, 63): column c of the row changed (a Place that moved to another of a hundred
+                                  // identical County rows rewrites a reference column that no byte table is built from)
+  };
+  std::vector<DeltaEntry> delta_log;
+  DevBuf<int32_t> union_rows;  // memo of the last union asked for: rows differing between union_base and union_head
+  uint64_t union_base = 0, union_head = 0, union_mask = 0;
+  int32_t union_n = -1;
   double h_lse = 0.0;         // options: log-sum of logp (+1e-9), valid for version h_lse_ver (eval.hip: subtree_ub)
   uint64_t h_lse_ver = 0;
 };
@@ -225,6 +246,8 @@ struct pclean_ctx {
   bool defer_outputs = false;   // pclean_set_sweep_mode bit 0
   void* commit_state = nullptr;  // owned by commit.hip
   HostStage stage;               // page-locked staging of caller arrays (table uploads, latent-sweep inputs / outputs)
+  HostStage ustage;              // ... of the row unions of CandTable::delta_log (asked for in the middle of a sweep call,
+                                 // while `stage` holds the call's inputs and outputs)
   const int32_t* obs_override = nullptr;  // eval.hip: ensure_leaf_cache scores "item t observes value t"
   int32_t active_begin = 0, active_count = -1;  // pclean_set_active_rows window (-1 = all rows)
   int32_t timed_block = 0;  // the block whose root launch group pclean_timing / pclean_root_stats describe (pclean_set_timed_block)

@@ -31,8 +31,9 @@ TIMERS = _dd(float)
 # PCLEAN_HOST_COMMIT=1: commit every observed-class sweep on the host (the path of several ranks, of refused device commits)
 DEVICE_COMMIT = not os.environ.get("PCLEAN_HOST_COMMIT")
 # observed rows from which a latent class's evidence sets are built on the device (Engine.build_evidence_device; below:
-# NumPy on the host is as fast as the round trip); PCLEAN_HOST_EVIDENCE=1 keeps the host path at every size
-DEVICE_EVIDENCE_MIN_ROWS = 1 << 17
+# NumPy on the host is as fast as the round trip; PCLEAN_DEVICE_EVIDENCE_MIN_ROWS overrides); PCLEAN_HOST_EVIDENCE=1 keeps the host
+# path at every size
+DEVICE_EVIDENCE_MIN_ROWS = int(os.environ.get("PCLEAN_DEVICE_EVIDENCE_MIN_ROWS", 1 << 17))
 
 
 @_cm

@@ -49,6 +49,18 @@ for cname in lw.model.class_order:
     eng.hip.set_profiling(False)
     print(f"{cname}: {1e3 * dt:.1f} ms host; device phases (ms/intervals): "
           + ", ".join(f"{k} {v[0]:.1f}/{v[1]}" for k, v in sorted(ph.items(), key=lambda kv: -kv[1][0]) if v[0] > 0.05))
+# the observed class's sweep as an iteration runs it: right after the latent classes' sweeps moved the tables
+eng.hip.set_profiling(True)
+t0 = time.perf_counter()
+inf.observed_sweep(eng, tr, cfg, seed + 3, 0)
+dt = time.perf_counter() - t0
+ph = eng.hip.get_profile()
+eng.hip.set_profiling(False)
+print(f"{lw.query.cls} (after the latent sweeps): {1e3 * dt:.1f} ms host; device phases (ms/intervals): "
+      + ", ".join(f"{k} {v[0]:.2f}/{v[1]}" for k, v in sorted(ph.items(), key=lambda kv: -kv[1][0]) if v[0] > 0.02))
+t0 = time.perf_counter()
+inf.observed_sweep(eng, tr, cfg, seed + 4, 0)
+print(f"{lw.query.cls} (again, nothing moved in between): {1e3 * (time.perf_counter() - t0):.1f} ms host")
 if not args.no_cprofile:
     pr = cProfile.Profile()
     pr.enable()

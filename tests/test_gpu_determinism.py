@@ -127,6 +127,8 @@ def test_full_inference_is_bit_identical_across_the_latent_path_switches(capsys)
         "no evidence scans at all": {"PCLEAN_NO_FAST_EV": "1"},
         "weighted sums of huge evidence sets by the row's own workgroup": {"PCLEAN_NO_EV_SPLIT": "1"},
         "read-backs by copies, hipMemsetAsync": {"PCLEAN_NO_PUBLISH_REGIONS": "1", "PCLEAN_NO_ZERO_KERNEL": "1", "PCLEAN_NO_FUSED_PRIORS": "1"},
+        "evidence sets built on the device": {"PCLEAN_DEVICE_EVIDENCE_MIN_ROWS": "0"},
+        "compact tables rebuilt, not refreshed along the chain of upload deltas": {"PCLEAN_NO_DELTA_CHAIN": "1"},
     }
     digests = {}
     for name, env in variants.items():
