@@ -31,6 +31,7 @@
 
 #define HALF_LOG26 1.629048269010741
 #define ADD_TYPOS_IMPOSSIBLE (-1e5)
+#define ENUM_CPT 4  // candidates a thread of enum_node_kernel scores at a time (candidate_score_batch)
 #define CS_TC 4  // evidence entries of a term whose gathers are in flight together (candidate_score_ev)
 
 __device__ __forceinline__ double wave_max(double v) {
@@ -227,6 +228,90 @@ __device__ __forceinline__ double candidate_score(const NodeDev& nd, const DensD
   }
   if (nd.g.on && sk > -__builtin_inf()) sk += gauss_term(nd, v, k, v.row, nullptr);
   return sk;
+}
+
+// candidate_score() of CPT candidates of one item at once (single-row items without a Gaussian term): the same operations per
+// candidate in the same order, but every level of the gather chain (candidate column -> ctx function -> pair entry + length ->
+// density pieces) is loaded for the whole batch before the next level is touched.  A thread that scores its candidates one
+// after the other waits for ~4 dependent round trips per term and candidate; a load under a per-candidate condition becomes
+// a branch with its own wait, so every load here is unconditional on a safe index and what must not count is selected away.
+// kk[c] < n_cand for every c (the caller repeats a valid candidate for the slots beyond the list).
+template <int CPT>
+__device__ __forceinline__ void candidate_score_batch(const NodeDev& nd, const DensDev& dn, const ItemView& v, const int* kk,
+                                                      double* sk) {
+  bool on[CPT];
+  if (nd.kind == PCLEAN_NODE_FK) {
+    long long cnt[CPT];
+    double lf[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      cnt[c] = (long long)nd.counts[kk[c]];
+      lf[c] = nd.logc_full[kk[c]];
+    }
+    const double pr_excl = (v.excl >= 0 && !v.deleted) ? nd.logc_m1[v.excl] - v.logden : -__builtin_inf();
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      on[c] = cnt[c] != 0;  // (a free slot: -inf, and no defined values to look up)
+      sk[c] = !on[c] ? -__builtin_inf() : (kk[c] == v.excl ? pr_excl : lf[c] - v.logden);
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      sk[c] = nd.logc_full[kk[c]];
+      on[c] = true;
+    }
+  }
+  for (int ti = 0; ti < nd.n_terms; ++ti) {
+    const TermDev& tm = nd.terms[ti];
+    const int o = tm.obs_col[v.row];
+    if (o < 0) continue;  // explicitly missing observation (add_typos.jl:51-53)
+    int val[CPT], d[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) val[c] = tm.cand_col[kk[c]];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) val[c] = on[c] ? val[c] : 0;
+    if (tm.ctx_slot >= 0) {
+      const int32_t* fr = tm.fn + (size_t)v.ctxv[tm.ctx_slot] * tm.fn_nb;
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) val[c] = fr[val[c]];
+    }
+    const size_t base = (size_t)o * tm.n_lat;
+    const bool typos = tm.dens_kind != PCLEAN_DENS_EQUAL;
+    int L[CPT];
+    if (typos) {
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) L[c] = tm.lat_len[val[c]];
+    }
+    if (tm.elem_bytes == 1) {
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) d[c] = (int)tm.pair[base + val[c]];
+    } else {
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) d[c] = (int)((const uint16_t*)tm.pair)[base + val[c]];
+    }
+    if (!typos) {
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) sk[c] += !on[c] ? 0.0 : (d[c] == 0 ? 0.0 : -__builtin_inf());
+      continue;
+    }
+    const int mt = tm.max_typos;
+    double nbv[CPT], ll[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {  // term_density(): the same three operations on the same values
+      const bool far = mt >= 0 && d[c] > mt;
+      const int r = (L[c] + 4) / 5;
+      nbv[c] = dn.nb[(size_t)r * dn.nb_stride + (far ? 0 : d[c])];
+      ll[c] = dn.logl[L[c]];
+    }
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      double l = nbv[c];
+      l -= ll[c] * (double)d[c];
+      l -= HALF_LOG26 * (double)d[c];
+      if (mt >= 0 && d[c] > mt) l = ADD_TYPOS_IMPOSSIBLE;
+      sk[c] += on[c] ? l : 0.0;  // (sk is -inf where on is false: adding 0.0 changes nothing)
+    }
+  }
 }
 
 // likelihood terms of candidate k alone, added in candidate_score()'s order onto 0.0 — what p accumulates for a value
@@ -737,11 +822,28 @@ __global__ __launch_bounds__(BT) void enum_node_kernel(const NodeDev nd, const D
       lmax = fmax(lmax, sk);
     }
   } else {
-    for (int k = tid; k < n; k += BT) {
-      const double sk = candidate_score(nd, dn, it, v, k);
-      s[k] = sk;
-      if (scores_out) scores_out[(size_t)to * nc + k] = sk;
-      lmax = fmax(lmax, sk);
+    if (v.ev_lo < 0 && !nd.g.on && n > BT) {  // several candidates per thread: their gather chains level by level
+      for (int k0 = tid; k0 < n; k0 += BT * ENUM_CPT) {
+        int kk[ENUM_CPT];
+        double sc[ENUM_CPT];
+#pragma unroll
+        for (int c = 0; c < ENUM_CPT; ++c) kk[c] = k0 + c * BT < n ? k0 + c * BT : k0;
+        candidate_score_batch<ENUM_CPT>(nd, dn, v, kk, sc);
+#pragma unroll
+        for (int c = 0; c < ENUM_CPT; ++c)
+          if (k0 + c * BT < n) {
+            s[kk[c]] = sc[c];
+            if (scores_out) scores_out[(size_t)to * nc + kk[c]] = sc[c];
+            lmax = fmax(lmax, sc[c]);
+          }
+      }
+    } else {
+      for (int k = tid; k < n; k += BT) {
+        const double sk = candidate_score(nd, dn, it, v, k);
+        s[k] = sk;
+        if (scores_out) scores_out[(size_t)to * nc + k] = sk;
+        lmax = fmax(lmax, sk);
+      }
     }
     if (fk && tid == 0) {
       const double sn = new_score(nd, ch, v, to);

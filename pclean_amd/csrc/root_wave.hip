@@ -270,6 +270,51 @@ __device__ __forceinline__ double fast_exact_score(const FastRootDev& fr, const 
   return b;
 }
 
+// fast_exact_score() with every term's loads in flight together (one candidate per thread: group_gate_kernel,
+// group_desc_kernel): the byte distance and the length of ALL terms first, then all the density-table entries — two round
+// trips instead of two per term.  The loads are unconditional (a term the node does not have, a context term and a missing
+// observation read the zero row: a load under a condition becomes a branch with its own wait); what does not count is left
+// out of the sum, whose additions keep plan order: the same value as fast_exact_score(), bit for bit.
+__device__ __forceinline__ double fast_exact_score_mlp(const FastRootDev& fr, const int* o, int ctx0, int ctx1, int k, double pr) {
+  int d[PCLEAN_MAX_TERMS], L[PCLEAN_MAX_TERMS];
+  bool sat = false;
+#pragma unroll
+  for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) {
+    const bool plain = f < fr.n_terms && fr.terms[f].ctx_slot < 0;  // (wave-uniform)
+    const uint8_t* crow = (plain && o[f] >= 0) ? fr.terms[f].comp + (size_t)o[f] * fr.kpad : fr.zero_row;
+    const uint8_t* cl = plain ? fr.terms[f].clen : fr.zero_row;
+    d[f] = crow[k];
+    L[f] = cl[k];
+  }
+#pragma unroll
+  for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) sat |= d[f] == PRE_CLAMP;  // (the zero row never is)
+  if (sat) {  // saturated bytes (rare): the true distances
+#pragma unroll
+    for (int f = 0; f < PCLEAN_MAX_TERMS; ++f)
+      if (d[f] == PRE_CLAMP) d[f] = fr.terms[f].pair[(size_t)o[f] * fr.terms[f].n_lat + fr.terms[f].cand_col[k]];
+  }
+  double l[PCLEAN_MAX_TERMS];
+#pragma unroll
+  for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) {
+    const int mt = f < fr.n_terms ? fr.terms[f].max_typos : -1;
+    l[f] = fr.atd[(size_t)L[f] * fr.atd_stride + ((mt >= 0 && d[f] > mt) ? 0 : d[f])];  // (beyond the limit: not looked up)
+  }
+  double b = pr;
+#pragma unroll
+  for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) {
+    if (f < fr.n_terms) {
+      if (fr.terms[f].ctx_slot >= 0) {  // (wave-uniform: a JuliaNode term goes through fn[ctx][.])
+        if (o[f] >= 0) b += wave_term_dens(fr, fr.terms[f], o[f], ctx0, ctx1, k);
+      } else {
+        const int mt = fr.terms[f].max_typos;
+        const double lf = (mt >= 0 && d[f] > mt) ? ADD_TYPOS_IMPOSSIBLE : l[f];
+        if (o[f] >= 0) b += lf;  // an explicitly missing observation contributes nothing (add_typos.jl:51-53)
+      }
+    }
+  }
+  return b;
+}
+
 // observed values of `row` for the node's terms (-1 beyond n_terms): from the row-major copy when there is one
 __device__ __forceinline__ void load_row_obs(const FastRootDev& fr, int row, int* o) {
   static_assert(PCLEAN_MAX_TERMS == 16, "four 16-byte loads");
@@ -348,7 +393,7 @@ __global__ void group_desc_kernel(const FastRootDev fr, const ItemsDev it, const
     // the current referent's exact score: the same operations in the same order as the scan kernel's own scoring of
     // candidate excl, so the scan kernel takes it from the descriptor when that candidate is its only survivor
     // (group_gate_kernel computed it already when the gate of the new-row branch ran on the groups: same function, same bits)
-    score_cur = pre_score ? pre_score[g] : fast_exact_score(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]);
+    score_cur = pre_score ? pre_score[g] : fast_exact_score_mlp(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]);
     have_cur = true;
     bound = score_cur - 1.0;
   }
@@ -508,7 +553,7 @@ __global__ void group_gate_kernel(const FastRootDev fr, const ItemsDev it, const
     for (int q = 0; q < 4; ++q) po[q] = make_int4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
   }
   if (excl >= 0 && !deleted && fr.logc_m1) {
-    sc = fast_exact_score(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]);
+    sc = fast_exact_score_mlp(fr, o, ctx0, ctx1, excl, fr.logc_m1[excl] - fr.scal[1]);
     double ub = fr.scal[2] - fr.scal[1];
     for (int c = 0; c < gt.n; ++c) {
       if (gt.cache[c]) {
@@ -1540,6 +1585,7 @@ __global__ void member_lse_kernel(int n_pos, const int32_t* __restrict__ uid, co
 // byte rows (fast_exact_score: coalesced byte loads, one density-table lookup per term) instead of the generic
 // kernel's dependent gather chains (candidate column -> pair byte -> length -> density pieces), which made 27
 // overflowed rows cost 0.56 ms of every 1M-row sweep.  One workgroup per item; items are not grouped.
+#define OVF_CPT 6   // candidates a thread of overflow_lds_kernel scores at a time (their loads in flight together)
 #define OVF_T 1024  // threads per workgroup of overflow_lds_kernel (one workgroup per CU: the scores fill its LDS)
 __global__ __launch_bounds__(OVF_T) void overflow_lds_kernel(const FastRootDev fr, const ItemsDev it, const ChildrenDev ch,
                                                            uint64_t seed, uint32_t sweep, uint32_t site, int n_draws,
@@ -1567,18 +1613,76 @@ __global__ __launch_bounds__(OVF_T) void overflow_lds_kernel(const FastRootDev f
   const int ctx0 = it.ctx ? it.ctx[(size_t)t * PCLEAN_MAX_CTX] : 0;
   const int ctx1 = it.ctx ? it.ctx[(size_t)t * PCLEAN_MAX_CTX + 1] : 0;
   int o[PCLEAN_MAX_TERMS];
-  for (int f = 0; f < PCLEAN_MAX_TERMS; ++f) o[f] = f < fr.n_terms ? fr.terms[f].obs_col[row] : -1;
+  load_row_obs(fr, row, o);
   const bool deleted = excl >= 0 && fr.counts && fr.counts[excl] <= 1;
   const double* prior = (excl >= 0 && fr.prior_e) ? fr.prior_e : fr.prior_n;
   // ---- phase 1: exact scores, prior first, terms in plan order (candidate_score's operation order)
+  // OVF_CPT candidates per thread at a time, term by term: the byte / length loads of the whole batch are in flight together,
+  // then its density loads — one candidate at a time was a chain of ~3 dependent round trips per term and candidate (20
+  // overflowed rows of block 0: 0.10 ms of every 1M-row sweep on 20 CUs).  Each candidate's additions keep plan order.
   double lmax = -__builtin_inf();
-  #pragma unroll 2
-  for (int k = tid; k < n; k += OVF_T) {
-    double pr = prior[k];
-    if (k == excl) pr = deleted ? -__builtin_inf() : fr.logc_m1[excl] - fr.scal[1];
-    const double sk = pr == -__builtin_inf() ? pr : fast_exact_score(fr, o, ctx0, ctx1, k, pr);
-    s[k] = sk;
-    lmax = fmax(lmax, sk);
+  const double pr_excl = excl >= 0 ? (deleted ? -__builtin_inf() : fr.logc_m1[excl] - fr.scal[1]) : 0.0;
+  for (int k0 = tid; k0 < n; k0 += OVF_T * OVF_CPT) {
+    // (every load below is unconditional — a candidate beyond n re-reads k0, a free slot's bytes are defined — and what must
+    // not count is selected away afterwards: a load under a condition becomes a branch with its own wait, one round trip each)
+    int kk[OVF_CPT];
+    double b[OVF_CPT];
+    bool in[OVF_CPT], on[OVF_CPT];
+#pragma unroll
+    for (int c = 0; c < OVF_CPT; ++c) {
+      const int k = k0 + c * OVF_T;
+      in[c] = k < n;
+      kk[c] = in[c] ? k : k0;
+    }
+#pragma unroll
+    for (int c = 0; c < OVF_CPT; ++c) b[c] = prior[kk[c]];
+#pragma unroll
+    for (int c = 0; c < OVF_CPT; ++c) {
+      b[c] = kk[c] == excl ? pr_excl : b[c];
+      on[c] = in[c] && b[c] != -__builtin_inf();  // (free slots: no defined values to look up)
+    }
+    for (int f = 0; f < fr.n_terms; ++f) {
+      const int of = o[f];
+      if (of < 0) continue;  // an explicitly missing observation contributes nothing (add_typos.jl:51-53)
+      const FastTermDev& tm = fr.terms[f];
+      if (tm.ctx_slot >= 0) {
+#pragma unroll
+        for (int c = 0; c < OVF_CPT; ++c)
+          if (on[c]) b[c] += wave_term_dens(fr, tm, of, ctx0, ctx1, kk[c]);
+        continue;
+      }
+      const uint8_t* crow = tm.comp + (size_t)of * fr.kpad;
+      const uint8_t* clen = tm.clen;
+      const int mt = tm.max_typos;
+      int d[OVF_CPT], L[OVF_CPT];
+#pragma unroll
+      for (int c = 0; c < OVF_CPT; ++c) {
+        d[c] = (int)crow[kk[c]];
+        L[c] = (int)clen[kk[c]];
+      }
+      bool sat = false;
+#pragma unroll
+      for (int c = 0; c < OVF_CPT; ++c) sat |= on[c] && d[c] == PRE_CLAMP;
+      if (sat) {  // saturated bytes (rare): the true distances
+#pragma unroll
+        for (int c = 0; c < OVF_CPT; ++c)
+          if (on[c] && d[c] == PRE_CLAMP) d[c] = tm.pair[(size_t)of * tm.n_lat + tm.cand_col[kk[c]]];
+      }
+      double l[OVF_CPT];
+#pragma unroll
+      for (int c = 0; c < OVF_CPT; ++c) l[c] = fr.atd[(size_t)L[c] * fr.atd_stride + ((on[c] && !(mt >= 0 && d[c] > mt)) ? d[c] : 0)];
+#pragma unroll
+      for (int c = 0; c < OVF_CPT; ++c) {
+        const double lc = (mt >= 0 && d[c] > mt) ? ADD_TYPOS_IMPOSSIBLE : l[c];
+        b[c] += on[c] ? lc : 0.0;  // (b is -inf or never stored where on is false: adding 0.0 changes nothing)
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < OVF_CPT; ++c)
+      if (in[c]) {
+        s[kk[c]] = b[c];
+        lmax = fmax(lmax, b[c]);
+      }
   }
   if (fk && tid == 0) {  // new_score() of enum_kernels.hip
     const double logden = excl >= 0 ? fr.scal[1] : fr.scal[0];

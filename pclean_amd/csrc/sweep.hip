@@ -159,6 +159,7 @@ __global__ void ctx_fill_kernel(int N, int P, int n_ctx, const int32_t* __restri
 // row becomes an EXTRA item N + k, k from one atomic per workgroup — no scan, no second pass.  The numbering of the extra
 // items follows the workgroups' arrival: nothing downstream depends on item order (scores are per item, draws are keyed by
 // (row, particle)).  Extra items beyond extra_cap are counted, not written: the host re-runs with room (read_count).
+#define CI_PC 8  // particles of a row whose loads ctx_items_kernel has in flight together
 __global__ __launch_bounds__(256) void ctx_items_kernel(int N, int P, CtxSrc cs, const int32_t* __restrict__ cur_b,
                                                         int32_t* __restrict__ it_ctx, int32_t* __restrict__ slot_item,
                                                         int32_t* __restrict__ row, int32_t* __restrict__ ctxv,
@@ -174,20 +175,36 @@ __global__ __launch_bounds__(256) void ctx_items_kernel(int N, int P, CtxSrc cs,
   unsigned int mine = 0;  // extra items of this row
   if (i < N) {
     bool all_same = true;
-    for (int p = 0; p < P; ++p) {
-      const size_t sp = (size_t)p * N + i;
-      for (int s = 0; s < cs.n_ctx; ++s) {
-        int32_t v;
-        const int choice = cs.pchoice[s][sp];
-        if (choice >= 0)
-          v = cs.root_col[s][choice];
-        else
-          v = resolve_new_value(cs.plan[s], 0, cs.col[s], cs.vals[s] + (size_t)cs.pnewpos[s][sp] * cs.n_nodes[s]);
-        it_ctx[(size_t)s * NP + sp] = v;
-        if (p == 0)
-          c0[s] = v;
-        else
-          all_same &= v == c0[s];
+    // CI_PC particles at a time: their choices, then their referents' context values, each level loaded together and
+    // unconditionally (slots beyond P re-read particle P - 1, a NEW choice reads row 0 and is resolved afterwards) — one
+    // particle after the other was a chain of 2 P dependent round trips per row
+    for (int p0 = 0; p0 < P; p0 += CI_PC) {
+#pragma unroll
+      for (int s = 0; s < PCLEAN_MAX_CTX; ++s) {
+        if (s >= cs.n_ctx) break;
+        int ch[CI_PC];
+        int32_t v[CI_PC];
+#pragma unroll
+        for (int u = 0; u < CI_PC; ++u) ch[u] = cs.pchoice[s][(size_t)min(p0 + u, P - 1) * N + i];
+#pragma unroll
+        for (int u = 0; u < CI_PC; ++u) v[u] = cs.root_col[s][ch[u] >= 0 ? ch[u] : 0];
+        bool any_new = false;
+#pragma unroll
+        for (int u = 0; u < CI_PC; ++u) any_new |= ch[u] < 0;
+        if (any_new) {
+#pragma unroll
+          for (int u = 0; u < CI_PC; ++u)
+            if (ch[u] < 0 && p0 + u < P)
+              v[u] = resolve_new_value(cs.plan[s], 0, cs.col[s],
+                                       cs.vals[s] + (size_t)cs.pnewpos[s][(size_t)(p0 + u) * N + i] * cs.n_nodes[s]);
+        }
+        if (p0 == 0) c0[s] = v[0];
+#pragma unroll
+        for (int u = 0; u < CI_PC; ++u)
+          if (p0 + u < P) {
+            it_ctx[(size_t)s * NP + (size_t)(p0 + u) * N + i] = v[u];
+            all_same &= v[u] == c0[s];
+          }
       }
     }
     row[i] = i;
@@ -508,6 +525,8 @@ __global__ void maybe_resample_kernel(int n_rows, int P, const double* logw, siz
 // increment of the resampling step is accumulated here as well
 struct AncestorArrays {  // the particle-major arrays a resampling step permutes, by value (no upload, no synchronisation)
   int32_t* p[2 * PCLEAN_MAX_BLOCKS];
+  int64_t* pairs[PCLEAN_MAX_BLOCKS];  // the particles' own choices of prior proposals (gauss_prior_kernel: two int32 per slot)
+  int n_pairs;
 };
 __global__ void apply_ancestors_kernel(int n_rows, int P, const int32_t* ancestors, int n_arrays, AncestorArrays arrays,
                                        double* w, const int32_t* did, const double* logml_inc, double* logml_acc) {
@@ -520,6 +539,12 @@ __global__ void apply_ancestors_kernel(int n_rows, int P, const int32_t* ancesto
     int32_t* arr = arrays.p[a] + i;
     for (int p = 0; p < P; ++p) tmp[p] = arr[(size_t)ancestors[(size_t)p * n_rows + i] * n_rows];
     for (int p = 0; p < P; ++p) arr[(size_t)p * n_rows] = tmp[p];
+  }
+  for (int a = 0; a < arrays.n_pairs; ++a) {  // (oracle/sweep.h: plocals follow their particles)
+    int64_t* arr = arrays.pairs[a] + i;
+    int64_t t2[MAXP];
+    for (int p = 0; p < P; ++p) t2[p] = arr[(size_t)ancestors[(size_t)p * n_rows + i] * n_rows];
+    for (int p = 0; p < P; ++p) arr[(size_t)p * n_rows] = t2[p];
   }
   for (int p = 0; p < P; ++p) w[(size_t)p * n_rows + i] = 0.0;
 }
@@ -577,23 +602,52 @@ __global__ __launch_bounds__(256) void particle_update_final_kernel(
   FixW<PMAX> f;
   double wv[PMAX];
   f.m = -__builtin_inf();
+  // Every particle's loads of one level are issued together and unconditionally (the slots beyond P re-read particle P - 1;
+  // their values are never used): a load under `p < P` is a branch with its own wait, and the row's 2 P dependent loads
+  // (item of the slot, then the item's log marginal) were a serial chain of 2 P round trips per thread.
+  int dv[PMAX];
+  double lv[PMAX], wp[PMAX];
+  const size_t Ns = (size_t)N;
+  if (slot_item) {
+    int itm[PMAX];
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) itm[p] = slot_item[(size_t)(p < P ? p : P - 1) * Ns + i];
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) lv[p] = lse_item[itm[p]];
+    if (!lazy) {
+#pragma unroll
+      for (int p = 0; p < PMAX; ++p) dv[p] = draws_item[(size_t)itm[p] * P + (p < P ? p : P - 1)];
+    }
+  } else {
+    const double l0 = lse[i];
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) lv[p] = l0;
+    if (!lazy) {
+#pragma unroll
+      for (int p = 0; p < PMAX; ++p) dv[p] = draws_rm[(size_t)i * P + (p < P ? p : P - 1)];
+    }
+  }
+  if (lazy) {
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) dv[p] = 0;
+  }
+  if (first) {
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) wp[p] = 0.0;
+  } else if (w_uni) {  // (see particle_update_kernel)
+    const double wu = 0.0 + w_uni[i];
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) wp[p] = wu;
+  } else {
+#pragma unroll
+    for (int p = 0; p < PMAX; ++p) wp[p] = w[(size_t)(p < P ? p : P - 1) * Ns + i];
+  }
 #pragma unroll
   for (int p = 0; p < PMAX; ++p) {
     wv[p] = 0.0;
     if (p < P) {
-      const size_t sp = (size_t)p * N + i;
-      int d;
-      double l;
-      if (slot_item) {
-        const int item = slot_item[sp];
-        d = lazy ? 0 : draws_item[(size_t)item * P + p];
-        l = lse_item[item];
-      } else {
-        d = lazy ? 0 : draws_rm[(size_t)i * P + p];
-        l = lse[i];
-      }
-      if (!lazy) pchoice[sp] = (p == 0 && keep >= 0) ? keep : d;
-      wv[p] = first ? 0.0 + l : (w_uni ? (0.0 + w_uni[i]) + l : w[sp] + l);  // (w_uni: see particle_update_kernel)
+      if (!lazy) pchoice[(size_t)p * Ns + i] = (p == 0 && keep >= 0) ? keep : dv[p];
+      wv[p] = wp[p] + lv[p];
       f.m = fmax(f.m, wv[p]);
     }
   }
@@ -1846,10 +1900,6 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
     r.plocals_on = false;
     auto gauss_prior = [&]() -> int {
       if (b.node_gauss.empty() || b.node_gauss[0] < 0) return PCLEAN_OK;
-      if (!use_mh && bi + 1 < n_blocks && !ctx->block[bi + 1].is_score)
-        return pclean_fail(ctx, PCLEAN_ERR_ARG, "pclean_sweep: use_dd_proposals = false with a Gaussian term is implemented for "
-                                                "the LAST reference-slot block of the class (the particles' own choices are not "
-                                                "carried through a resampling step)");
       GaussDev gd;
       const CandTable& rt = ctx->cand[b.nodes[0].table];
       int rcg = build_gauss_dev(ctx, b.gauss[b.node_gauss[0]], &rt, gd);
@@ -2161,6 +2211,7 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
         if (ctx->block[k].is_score) continue;
         arrs.p[n_arr++] = s->run[k].pchoice.p;
         arrs.p[n_arr++] = s->run[k].pnewpos.p;
+        if (s->run[k].plocals_on) arrs.pairs[arrs.n_pairs++] = reinterpret_cast<int64_t*>(s->run[k].plocals.p);
       }
       hipLaunchKernelGGL(apply_ancestors_kernel, grid1(N), dim3(256), 0, ctx->stream, N, P, s->ancestors.p, n_arr, arrs, s->w.p,
                          s->did.p, s->logml_inc.p, s->logml_acc.p);
@@ -2232,7 +2283,11 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       if (bb.is_score) continue;
       const int32_t* cur_b = cur_base + (size_t)bi * cur_ld;
       CandTable& rt = ctx->cand[bb.nodes[0].table];
-      const int hist_rows = rt.n_rows <= 12288 ? rt.n_rows : 0;  // (48 KB of LDS per workgroup at most)
+      // (an LDS histogram per workgroup: a few rows take most of the moves — 28 true measures for 1M records.  It covers the
+      // rows below the table's high-water mark only: nobody refers to, or chooses, the spare capacity behind it, and zeroing
+      // + flushing the counters of 8 240 rows in each of 4 000 workgroups was 0.05 ms per sweep)
+      const int rows_in_use = (rt.n_used > 0 && rt.n_used <= rt.n_rows) ? std::min(rt.n_rows, (rt.n_used + 63) & ~63) : rt.n_rows;
+      const int hist_rows = rt.n_rows <= 12288 ? rows_in_use : 0;  // (48 KB of LDS per workgroup at most; larger tables: plain atomics)
       hipLaunchKernelGGL(finalize_block_kernel, grid1(N), dim3(256), (size_t)hist_rows * sizeof(int32_t), ctx->stream, N,
                          s->chosen.p, r.pchoice.p, r.pnewpos.p, cur_b, r.choice.p, r.chosen_newpos.p,
                          (unsigned long long*)rt.stats.p, hist_rows, r.moved_flag.p, r.new_flag.p,

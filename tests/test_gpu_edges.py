@@ -230,6 +230,40 @@ def test_use_dd_proposals_false_with_a_gaussian_term(oracle):
         eng.close()
 
 
+def test_use_dd_proposals_false_gaussian_block_followed_by_another_slot(oracle):
+    """Prior proposals under particle Gibbs when ANOTHER reference-slot block follows the one with the Gaussian term
+    (tests/rents_two_slots.py): the resampling step between the two blocks (row_inference.jl:139-151) permutes the
+    particles, and the own choices each particle sampled for the Gaussian term follow it (apply_ancestors_kernel) — the
+    chosen particle's own choices, the choices of both blocks and the log marginal likelihoods equal the oracle's bit for
+    bit (P = 6 and 20: most rows are resampled; MH for the two-particle path)."""
+    import rents_two_slots as r2
+    R = r2.setup(n_rows=400)
+    lw, obs, tr = R["lw"], R["obs"], R["trace"]
+    n = obs.shape[1]
+    eng = Engine(lw, obs, dist_mode=1)
+    try:
+        eng.upload_trace(tr)
+        rng = np.random.default_rng(4)
+        tr.locals[0][:, 0] = np.where(obs[3] >= 0, obs[3], rng.integers(0, 5, n))
+        tr.locals[0][:, 1] = rng.integers(0, 2, n)
+        world = helpers.mirror_world(oracle, lw, obs, tr, eng)
+        world.set_cur_locals(0, tr.locals[0])
+        spread = 0
+        for P, mh in ((6, 0), (20, 0), (2, 1)):
+            cfg = InferenceConfig(1, P, use_dd_proposals=False, use_mh_instead_of_pg=bool(mh))
+            choice, chosen, logml, new_rows = eng.sweep(tr, cfg, 31, 2)
+            got_loc = tr.pending_locals[0].copy()
+            c = InferConfig(1, P, 0, 1, mh, 50, 100)
+            och, ocp, oml = _oracle_sweep(oracle, world, c, 31, 2, tr.cur)
+            assert np.array_equal(choice, och) and np.array_equal(chosen, ocp), (P, mh)
+            assert np.array_equal(logml, oml), (P, mh, np.abs(logml - oml).max())
+            assert np.array_equal(got_loc, world.get_locals(0, n)), (P, mh)
+            spread += int((chosen > 0).sum())
+        assert spread > n // 4  # (the chosen particles are not the retained ones: the permutation was exercised)
+    finally:
+        eng.close()
+
+
 def test_new_branch_gate_light_outputs_and_profile(oracle):
     """The gate of the new-row branch (gate_new_kernel) only skips work whose fixed-point weight is exactly 0:
     a sweep with the gate forced on for every list equals the sweep without it and the oracle, bit for bit.
