@@ -142,48 +142,63 @@ __device__ __forceinline__ double candidate_score_ev(const NodeDev& nd, const De
     // whole chunk before any is used; the additions keep the entry order (same operations on the same values: same bits)
     const int val0 = tm.cand_col[k];
     const int cv = (tm.ctx_slot >= 0 && tm.ctx_mode == 0) ? v.ctxv[tm.ctx_slot] : 0;
+    const bool typos = tm.dens_kind != PCLEAN_DENS_EQUAL;
     for (int rb = ag.off[oi]; rb < r1; rb += CS_TC) {
+      // (every load of a step unconditional, on a safe index — an entry past the item's last repeats the last one, a missing
+      // observation reads row 0 — and what must not count selected away: a load under a per-entry condition is a branch with
+      // its own wait, which put the chunk's chains one behind the other again)
       int o[CS_TC], val[CS_TC], d[CS_TC], L[CS_TC];
       double mult[CS_TC], a[CS_TC], b[CS_TC];
+      int ec[CS_TC], cn[CS_TC];
 #pragma unroll
       for (int u = 0; u < CS_TC; ++u) {
-        o[u] = -1;
+        const int r = min(rb + u, r1 - 1);
+        const uint64_t key = ag.key[r];
+        cn[u] = ag.cnt[r];
+        o[u] = (int)(key & 0xffffffull) - 1;
+        ec[u] = (int)((key >> 24) & 0xffffull);
+      }
+#pragma unroll
+      for (int u = 0; u < CS_TC; ++u) {
+        const bool in = rb + u < r1;
+        o[u] = in ? o[u] : -1;
+        mult[u] = in ? (double)cn[u] : 0.0;
         val[u] = val0;
-        mult[u] = 0.0;
-        if (rb + u < r1) {
-          const uint64_t key = ag.key[rb + u];
-          o[u] = (int)(key & 0xffffffull) - 1;
-          mult[u] = (double)ag.cnt[rb + u];
-          if (tm.ctx_slot >= 0 && o[u] >= 0) {
-            const int c = tm.ctx_mode == 0 ? cv : (int)((key >> 24) & 0xffffull);
-            val[u] = tm.ctx_mode == 2 ? tm.fn[(size_t)val0 * tm.fn_nb + c] : tm.fn[(size_t)c * tm.fn_nb + val0];
-          }
+      }
+      if (tm.ctx_slot >= 0) {  // (wave-uniform)
+#pragma unroll
+        for (int u = 0; u < CS_TC; ++u) {
+          const int c = o[u] < 0 ? 0 : (tm.ctx_mode == 0 ? cv : ec[u]);
+          const int fv = tm.ctx_mode == 2 ? tm.fn[(size_t)val0 * tm.fn_nb + c] : tm.fn[(size_t)c * tm.fn_nb + val0];
+          val[u] = o[u] >= 0 ? fv : val0;
         }
       }
+      if (typos) {
 #pragma unroll
-      for (int u = 0; u < CS_TC; ++u) {
-        d[u] = 0;
-        L[u] = 0;
-        if (o[u] >= 0) {
-          const size_t idx = (size_t)o[u] * tm.n_lat + val[u];
-          d[u] = tm.elem_bytes == 1 ? (int)tm.pair[idx] : (int)((const uint16_t*)tm.pair)[idx];
-          if (tm.dens_kind != PCLEAN_DENS_EQUAL) L[u] = tm.lat_len[val[u]];
-        }
+        for (int u = 0; u < CS_TC; ++u) L[u] = tm.lat_len[val[u]];
+      } else {
+#pragma unroll
+        for (int u = 0; u < CS_TC; ++u) L[u] = 0;
       }
+      if (tm.elem_bytes == 1) {
 #pragma unroll
-      for (int u = 0; u < CS_TC; ++u) {
-        a[u] = 0.0;
-        b[u] = 0.0;
-        if (o[u] >= 0 && tm.dens_kind != PCLEAN_DENS_EQUAL && !(tm.max_typos >= 0 && d[u] > tm.max_typos)) {
-          a[u] = dn.nb[(size_t)((L[u] + 4) / 5) * dn.nb_stride + d[u]];
+        for (int u = 0; u < CS_TC; ++u) d[u] = (int)tm.pair[(size_t)(o[u] >= 0 ? o[u] : 0) * tm.n_lat + val[u]];
+      } else {
+#pragma unroll
+        for (int u = 0; u < CS_TC; ++u) d[u] = (int)((const uint16_t*)tm.pair)[(size_t)(o[u] >= 0 ? o[u] : 0) * tm.n_lat + val[u]];
+      }
+      if (typos) {
+#pragma unroll
+        for (int u = 0; u < CS_TC; ++u) {
+          const bool look = o[u] >= 0 && !(tm.max_typos >= 0 && d[u] > tm.max_typos);
+          a[u] = dn.nb[(size_t)((L[u] + 4) / 5) * dn.nb_stride + (look ? d[u] : 0)];
           b[u] = dn.logl[L[u]];
         }
       }
 #pragma unroll
       for (int u = 0; u < CS_TC; ++u) {
-        if (o[u] < 0) continue;  // (missing observation, or past the item's last entry)
         double l;  // (term_density's operations, on the values loaded above)
-        if (tm.dens_kind == PCLEAN_DENS_EQUAL) {
+        if (!typos) {
           l = d[u] == 0 ? 0.0 : -__builtin_inf();
         } else if (tm.max_typos >= 0 && d[u] > tm.max_typos) {
           l = ADD_TYPOS_IMPOSSIBLE;
@@ -192,7 +207,7 @@ __device__ __forceinline__ double candidate_score_ev(const NodeDev& nd, const De
           l -= b[u] * (double)d[u];
           l -= HALF_LOG26 * (double)d[u];
         }
-        sk += mult[u] * l;
+        if (o[u] >= 0) sk += mult[u] * l;  // (not: a missing observation, or past the item's last entry)
       }
     }
   }
@@ -203,6 +218,9 @@ __device__ __forceinline__ double candidate_score_ev(const NodeDev& nd, const De
   return sk;
 }
 
+// (EV = false: a launch whose items are single rows — the evidence path is compiled out of the kernel, which keeps the
+// registers of enum_node_kernel's single-row instances where they were before candidate_score_ev held a chunk's loads in flight)
+template <bool EV = true>
 __device__ __forceinline__ double candidate_score(const NodeDev& nd, const DensDev& dn, const ItemsDev& it,
                                                   const ItemView& v, int k) {
   double sk;
@@ -215,7 +233,7 @@ __device__ __forceinline__ double candidate_score(const NodeDev& nd, const DensD
   } else {
     sk = nd.logc_full[k];
   }
-  if (v.ev_lo >= 0) return candidate_score_ev(nd, dn, it, v, k, sk);
+  if (EV && v.ev_lo >= 0) return candidate_score_ev(nd, dn, it, v, k, sk);
   for (int ti = 0; ti < nd.n_terms; ++ti) {
     const TermDev& tm = nd.terms[ti];
     const int o = tm.obs_col[v.row];
@@ -357,6 +375,7 @@ __device__ __forceinline__ double new_score(const NodeDev& nd, const ChildrenDev
 // score is <= ub, and ub < score(e) - 28.5 <= max - 28.5 makes its fixed-point weight exactly 0
 // (pclean_fixw).  Such items skip the evaluation of the children: flag 0.  flag = PCLEAN_CHOICE_NEW (the
 // compaction marker) for items that need them.
+template <bool EV>
 __global__ void gate_new_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it, const GateDev gt,
                                 int32_t* __restrict__ flag) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -364,7 +383,7 @@ __global__ void gate_new_kernel(const NodeDev nd, const DensDev dn, const ItemsD
   const ItemView v = item_view(nd, it, t);
   bool need = true;
   if (v.excl >= 0 && !v.deleted) {
-    const double bound = candidate_score(nd, dn, it, v, v.excl);
+    const double bound = candidate_score<EV>(nd, dn, it, v, v.excl);
     double ub = nd.scal[2] - v.logden;
     for (int c = 0; c < gt.n; ++c) {
       if (gt.cache[c] && v.ev_lo < 0) {
@@ -382,7 +401,10 @@ __global__ void gate_new_kernel(const NodeDev nd, const DensDev dn, const ItemsD
 int pclean_launch_gate(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, const GateDev& gt, int32_t* flag) {
   if (it.n <= 0) return PCLEAN_OK;
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
-  hipLaunchKernelGGL(gate_new_kernel, dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, nd, dn, it, gt, flag);
+  if (it.ev_lo)
+    hipLaunchKernelGGL((gate_new_kernel<true>), dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, nd, dn, it, gt, flag);
+  else
+    hipLaunchKernelGGL((gate_new_kernel<false>), dim3((it.n + 255) / 256), dim3(256), 0, ctx->stream, nd, dn, it, gt, flag);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
 }
@@ -404,6 +426,7 @@ int pclean_launch_gate(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
 #define EV_W (EV_T / 64)
 #define EV_SURV_CAP 2048
 #define EV_FIX_CUTOFF 28.5
+#define EV_RU 2            // evidence entries whose byte-row loads are in flight together (wsum_batch)
 #define EV_ENT_CAP 512     // evidence entries of an item kept in LDS (more: read through the aggregated arrays)
 
 // Round 6: REFERENCE SLOTS too (nd.kind == PCLEAN_NODE_FK: a latent Place re-choosing its County against the ~260 observed
@@ -508,26 +531,41 @@ __global__ __launch_bounds__(EV_T, MINW) void ev_leaf_block_kernel(const NodeDev
       for (int u = 0; u < EV_QB; ++u)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[u][e] = 0u;
-      for (int r = 0; r < n_ent; ++r) {
-        const uint4* row = reinterpret_cast<const uint4*>(s_erow[r]);
-        const uint32_t mult = s_emul[r];
-        uint4 c[EV_QB];
+      // EV_RU entries at a time, every load unconditional (a quad beyond the list re-reads the last one — its sums are never
+      // looked at —, an entry beyond the set repeats the last with multiplicity 0): one entry after the other, each load
+      // behind its own condition, was a serial chain of n_ent round trips per pass — 260 of them for a Hospital's evidence
+      int qs[EV_QB];
 #pragma unroll
-        for (int u = 0; u < EV_QB; ++u) c[u] = qb + u * EV_T < nquads ? row[qb + u * EV_T] : make_uint4(0u, 0u, 0u, 0u);
+      for (int u = 0; u < EV_QB; ++u) qs[u] = min(qb + u * EV_T, nquads - 1);
+      for (int r = 0; r < n_ent; r += EV_RU) {
+        uint4 c[EV_RU][EV_QB];
+        uint32_t mult[EV_RU];
 #pragma unroll
-        for (int u = 0; u < EV_QB; ++u) {
-          const uint32_t cw[4] = {c[u].x, c[u].y, c[u].z, c[u].w};
+        for (int x = 0; x < EV_RU; ++x) {
+          const int rr = min(r + x, n_ent - 1);
+          const uint4* row = reinterpret_cast<const uint4*>(s_erow[rr]);
+          mult[x] = r + x < n_ent ? s_emul[rr] : 0u;
 #pragma unroll
-          for (int w = 0; w < 4; ++w)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[u][4 * w + e] += mult * ((cw[w] >> (8 * e)) & 0xffu);
+          for (int u = 0; u < EV_QB; ++u) c[x][u] = row[qs[u]];
         }
+#pragma unroll
+        for (int x = 0; x < EV_RU; ++x)
+#pragma unroll
+          for (int u = 0; u < EV_QB; ++u) {
+            const uint32_t cw[4] = {c[x][u].x, c[x][u].y, c[x][u].z, c[x][u].w};
+#pragma unroll
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[u][4 * w + e] += mult[x] * ((cw[w] >> (8 * e)) & 0xffu);
+          }
       }
     };
     // ---- pass A: the live option with the smallest weighted distance -> lower bound of the maximum
+    // (one_round: the whole list is one batch per thread — pass B looks at the very sums pass A made, which are kept)
+    const bool one_round = nquads <= EV_QB * EV_T;
+    uint32_t acc[EV_QB][16];
     uint64_t best = ~0ull;
     for (int qb = tid; qb < nquads; qb += EV_QB * EV_T) {
-      uint32_t acc[EV_QB][16];
       wsum_batch(qb, acc);
 #pragma unroll
       for (int u = 0; u < EV_QB; ++u) {
@@ -573,8 +611,7 @@ __global__ __launch_bounds__(EV_T, MINW) void ev_leaf_block_kernel(const NodeDev
     for (int q0 = 0; q0 < nquads; q0 += EV_QB * EV_T) {
       uint32_t masks[EV_QB];
       {
-        uint32_t acc[EV_QB][16];
-        wsum_batch(q0 + tid, acc);
+        if (!one_round) wsum_batch(q0 + tid, acc);  // (one_round: pass A's sums of the same quads; a thread without a quad masks nothing)
 #pragma unroll
         for (int u = 0; u < EV_QB; ++u) {
           const int q = q0 + u * EV_T + tid;
@@ -783,7 +820,7 @@ __device__ __forceinline__ uint64_t block_excl_scan(uint64_t part, uint64_t* wsu
   return base + incl - part;
 }
 
-template <int BT>
+template <int BT, bool EV>
 __global__ __launch_bounds__(BT) void enum_node_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
                                                         const ChildrenDev ch, uint64_t seed, uint32_t sweep,
                                                         uint32_t site, int n_draws, int item_base,
@@ -822,7 +859,7 @@ __global__ __launch_bounds__(BT) void enum_node_kernel(const NodeDev nd, const D
       lmax = fmax(lmax, sk);
     }
   } else {
-    if (v.ev_lo < 0 && !nd.g.on && n > BT) {  // several candidates per thread: their gather chains level by level
+    if ((!EV || v.ev_lo < 0) && !nd.g.on && n > BT) {  // several candidates per thread: their gather chains level by level
       for (int k0 = tid; k0 < n; k0 += BT * ENUM_CPT) {
         int kk[ENUM_CPT];
         double sc[ENUM_CPT];
@@ -839,7 +876,7 @@ __global__ __launch_bounds__(BT) void enum_node_kernel(const NodeDev nd, const D
       }
     } else {
       for (int k = tid; k < n; k += BT) {
-        const double sk = candidate_score(nd, dn, it, v, k);
+        const double sk = candidate_score<EV>(nd, dn, it, v, k);
         s[k] = sk;
         if (scores_out) scores_out[(size_t)to * nc + k] = sk;
         lmax = fmax(lmax, sk);
@@ -919,6 +956,7 @@ __global__ __launch_bounds__(BT) void enum_node_kernel(const NodeDev nd, const D
 // exact scores come from ONE CANDIDATE PER THREAD over (item, candidate) — the same candidate_score() / new_score(), so the
 // same bits — and enum_node_kernel's workgroup per item starts from them (scores_in).  Workgroup (x, y): candidates
 // 256 x .. 256 x + 255 of the slots y, y + gridDim.y, ...; an indirect launch stops at the list's length.
+template <bool EV>
 __global__ __launch_bounds__(256) void enum_scores_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it, const ChildrenDev ch,
                                                           double* __restrict__ scores, int slot_cap) {
   const int n = nd.n_cand;
@@ -933,7 +971,7 @@ __global__ __launch_bounds__(256) void enum_scores_kernel(const NodeDev nd, cons
     const ItemView v = item_view(nd, it, t);
     double sk;
     if (k < n) {
-      sk = candidate_score(nd, dn, it, v, k);
+      sk = candidate_score<EV>(nd, dn, it, v, k);
     } else {
       const int to = it.out_pos ? it.out_pos[t] : t;
       sk = new_score(nd, ch, v, to);
@@ -944,7 +982,7 @@ __global__ __launch_bounds__(256) void enum_scores_kernel(const NodeDev nd, cons
 
 // BT threads per item: 256 for launches that fill the chip, 1024 for the few-item launches of the latent sweeps (the
 // re-run of a sub-batch's overflowed rows: a dozen workgroups, each walking the whole option list three times)
-template <int BT>
+template <int BT, bool EV>
 __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
                                                             const ChildrenDev ch, uint64_t seed, uint32_t sweep,
                                                             uint32_t site, int n_draws, int item_base,
@@ -975,7 +1013,7 @@ __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, con
   // pass A: max (lane-strided, coalesced)
   double lmax = -__builtin_inf();
   for (int k = tid; k < n; k += BT) {
-    const double sk = si ? si[k] : candidate_score(nd, dn, it, v, k);
+    const double sk = si ? si[k] : candidate_score<EV>(nd, dn, it, v, k);
     if (scores_out) scores_out[(size_t)to * nc + k] = sk;
     lmax = fmax(lmax, sk);
   }
@@ -995,7 +1033,7 @@ __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, con
   uint64_t part = 0;
   if (m != -__builtin_inf())
     for (int k = lo; k < hi; ++k) {
-      const double sk = (k == n) ? sn : (si ? si[k] : candidate_score(nd, dn, it, v, k));
+      const double sk = (k == n) ? sn : (si ? si[k] : candidate_score<EV>(nd, dn, it, v, k));
       part += pclean_fixw(sk - m);
     }
   uint64_t U;
@@ -1018,7 +1056,7 @@ __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, con
         uint64_t acc = pre;
         int k = lo;
         for (; k < hi; ++k) {
-          const double sk = (k == n) ? sn : (si ? si[k] : candidate_score(nd, dn, it, v, k));
+          const double sk = (k == n) ? sn : (si ? si[k] : candidate_score<EV>(nd, dn, it, v, k));
           acc += pclean_fixw(sk - m);
           if (acc > x) break;
         }
@@ -1038,6 +1076,7 @@ __global__ __launch_bounds__(BT) void enum_node_big_kernel(const NodeDev nd, con
 // m + log(U 2^-40) is what the generic kernels return, bit for bit.
 #define LEAF_CB 256
 
+template <bool EV>
 __global__ __launch_bounds__(256) void leaf_coarse_build_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
                                                                 int n_blocks, double* __restrict__ lse_out,
                                                                 double* __restrict__ m_out, uint64_t* __restrict__ U_out,
@@ -1050,7 +1089,7 @@ __global__ __launch_bounds__(256) void leaf_coarse_build_kernel(const NodeDev nd
   const int n = nd.n_cand;
   const ItemView v = item_view(nd, it, t);
   double lmax = -__builtin_inf();
-  for (int k = tid; k < n; k += 256) lmax = fmax(lmax, candidate_score(nd, dn, it, v, k));
+  for (int k = tid; k < n; k += 256) lmax = fmax(lmax, candidate_score<EV>(nd, dn, it, v, k));
   lmax = wave_max(lmax);
   if (lane == 0) red[wave] = lmax;
   __syncthreads();
@@ -1059,7 +1098,7 @@ __global__ __launch_bounds__(256) void leaf_coarse_build_kernel(const NodeDev nd
   for (int b = 0; b < n_blocks; ++b) {
     const int k = b * LEAF_CB + tid;
     uint64_t u = 0;
-    if (k < n && m != -__builtin_inf()) u = pclean_fixw(candidate_score(nd, dn, it, v, k) - m);
+    if (k < n && m != -__builtin_inf()) u = pclean_fixw(candidate_score<EV>(nd, dn, it, v, k) - m);
     if (k == dummy_k && udummy_out) udummy_out[t] = u;  // weight of the ProposalDummyValue option (0: it cannot be drawn)
     for (int o = 32; o > 0; o >>= 1) u += __shfl_xor((unsigned long long)u, o, 64);
     __syncthreads();  // wsum of the previous block has been read
@@ -1076,6 +1115,7 @@ __global__ __launch_bounds__(256) void leaf_coarse_build_kernel(const NodeDev nd
 }
 
 // one wavefront per (item, draw): coarse search, then the exact weights of the LEAF_CB options of the block found
+template <bool EV>
 __global__ __launch_bounds__(256) void leaf_coarse_draw_kernel(const NodeDev nd, const DensDev dn, const ItemsDev it,
                                                                const int32_t* __restrict__ obs_col, int n_obs,
                                                                int n_blocks, const double* __restrict__ lse_c,
@@ -1121,7 +1161,7 @@ __global__ __launch_bounds__(256) void leaf_coarse_draw_kernel(const NodeDev nd,
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int k = a * LEAF_CB + lane * 4 + e;
-        u4[e] = k < n ? pclean_fixw(candidate_score(nd, dn, it, v, k) - m) : 0ull;
+        u4[e] = k < n ? pclean_fixw(candidate_score<EV>(nd, dn, it, v, k) - m) : 0ull;
         mine += u4[e];
       }
       unsigned long long incl = mine;
@@ -1147,7 +1187,11 @@ int pclean_launch_leaf_coarse_build(pclean_ctx* ctx, const NodeDev& nd, const It
                                     double* m_out, uint64_t* U_out, uint64_t* coarse, int dummy_k, uint64_t* udummy_out) {
   if (it.n <= 0) return PCLEAN_OK;
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
-  hipLaunchKernelGGL(leaf_coarse_build_kernel, dim3(it.n), dim3(256), 0, ctx->stream, nd, dn, it, n_blocks, lse_out, m_out,
+  if (it.ev_lo)
+    hipLaunchKernelGGL((leaf_coarse_build_kernel<true>), dim3(it.n), dim3(256), 0, ctx->stream, nd, dn, it, n_blocks, lse_out, m_out,
+                     U_out, coarse, dummy_k, udummy_out);
+  else
+    hipLaunchKernelGGL((leaf_coarse_build_kernel<false>), dim3(it.n), dim3(256), 0, ctx->stream, nd, dn, it, n_blocks, lse_out, m_out,
                      U_out, coarse, dummy_k, udummy_out);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
@@ -1162,7 +1206,11 @@ int pclean_launch_leaf_coarse_draw(pclean_ctx* ctx, const NodeDev& nd, const Ite
   DensDev dn{ctx->nb.p, ctx->logl.p, ctx->max_d + 1, 0, ctx->prob_same.p, ctx->prob_diff.p, ctx->logn.p};
   const long long pairs = (long long)it.n * std::max(n_draws, 1);
   const int wgs = (int)std::min<long long>((pairs + 3) / 4, 256 * 8);
-  hipLaunchKernelGGL(leaf_coarse_draw_kernel, dim3(wgs), dim3(256), 0, ctx->stream, nd, dn, it, obs_col, n_obs, n_blocks,
+  if (it.ev_lo)
+    hipLaunchKernelGGL((leaf_coarse_draw_kernel<true>), dim3(wgs), dim3(256), 0, ctx->stream, nd, dn, it, obs_col, n_obs, n_blocks,
+                     lse_c, m_c, U_c, coarse, seed, sweep, site, n_draws, lse_out, draws_out);
+  else
+    hipLaunchKernelGGL((leaf_coarse_draw_kernel<false>), dim3(wgs), dim3(256), 0, ctx->stream, nd, dn, it, obs_col, n_obs, n_blocks,
                      lse_c, m_c, U_c, coarse, seed, sweep, site, n_draws, lse_out, draws_out);
   HIPCHK(ctx, hipGetLastError());
   return PCLEAN_OK;
@@ -1417,24 +1465,36 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
       int slot_cap = 0;
       if (scores_tmp && !it.grp_off && !scores_out) {  // ... and the scores first, one candidate per thread (enum_scores_kernel)
         slot_cap = pclean_enum_split_slots(it, nc);
-        hipLaunchKernelGGL(enum_scores_kernel, dim3((nc + 255) / 256, std::min(slot_cap, 1024)), dim3(256), 0, ctx->stream, nd, dn, it,
+        if (it.ev_lo)
+          hipLaunchKernelGGL((enum_scores_kernel<true>), dim3((nc + 255) / 256, std::min(slot_cap, 1024)), dim3(256), 0, ctx->stream, nd, dn, it,
+                           ch, scores_tmp, slot_cap);
+        else
+          hipLaunchKernelGGL((enum_scores_kernel<false>), dim3((nc + 255) / 256, std::min(slot_cap, 1024)), dim3(256), 0, ctx->stream, nd, dn, it,
                            ch, scores_tmp, slot_cap);
         scores_in = scores_tmp;
       }
-      hipLaunchKernelGGL(enum_node_big_kernel<1024>, dim3(it.n), dim3(1024), 0, ctx->stream, nd, dn, it, ch, seed, sweep, site,
+      if (it.ev_lo)
+        hipLaunchKernelGGL((enum_node_big_kernel<1024, true>), dim3(it.n), dim3(1024), 0, ctx->stream, nd, dn, it, ch, seed, sweep, site,
+                         n_draws, 0, lse_out, scores_out, draws_out, scores_in, slot_cap);
+      else
+        hipLaunchKernelGGL((enum_node_big_kernel<1024, false>), dim3(it.n), dim3(1024), 0, ctx->stream, nd, dn, it, ch, seed, sweep, site,
                          n_draws, 0, lse_out, scores_out, draws_out, scores_in, slot_cap);
     } else {
       for (int base = 0; base < it.n; base += kMaxBlocks)
-        hipLaunchKernelGGL(enum_node_big_kernel<256>, dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), 0, ctx->stream, nd,
+        if (it.ev_lo)
+          hipLaunchKernelGGL((enum_node_big_kernel<256, true>), dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), 0, ctx->stream, nd,
+                           dn, it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out, (const double*)nullptr, 0);
+        else
+          hipLaunchKernelGGL((enum_node_big_kernel<256, false>), dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), 0, ctx->stream, nd,
                            dn, it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out, (const double*)nullptr, 0);
     }
   } else {
     static bool attr_set = false;
     if (!attr_set) {
-      HIPCHK(ctx, hipFuncSetAttribute((const void*)enum_node_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024));
-      HIPCHK(ctx, hipFuncSetAttribute((const void*)enum_node_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024));
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)enum_node_kernel<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)enum_node_kernel<1024, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)enum_node_kernel<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      HIPCHK(ctx, hipFuncSetAttribute((const void*)enum_node_kernel<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
     if (few) {  // (groups or items) too few workgroups to fill the chip: more threads per item
@@ -1443,16 +1503,28 @@ int pclean_launch_enum(pclean_ctx* ctx, const NodeDev& nd, const ItemsDev& it, c
       int slot_cap = 0;
       if (scores_tmp && !it.grp_off && !scores_out) {
         slot_cap = pclean_enum_split_slots(it, nc);
-        hipLaunchKernelGGL(enum_scores_kernel, dim3((nc + 255) / 256, std::min(slot_cap, 1024)), dim3(256), 0, ctx->stream, nd, dn, it,
+        if (it.ev_lo)
+          hipLaunchKernelGGL((enum_scores_kernel<true>), dim3((nc + 255) / 256, std::min(slot_cap, 1024)), dim3(256), 0, ctx->stream, nd, dn, it,
+                           ch, scores_tmp, slot_cap);
+        else
+          hipLaunchKernelGGL((enum_scores_kernel<false>), dim3((nc + 255) / 256, std::min(slot_cap, 1024)), dim3(256), 0, ctx->stream, nd, dn, it,
                            ch, scores_tmp, slot_cap);
         scores_in = scores_tmp;
       }
-      hipLaunchKernelGGL(enum_node_kernel<1024>, dim3(it.n), dim3(1024), lds, ctx->stream, nd, dn, it, ch, seed, sweep, site,
-                         n_draws, 0, lse_out, scores_out, draws_out, scores_in, slot_cap);
+      if (it.ev_lo)
+        hipLaunchKernelGGL((enum_node_kernel<1024, true>), dim3(it.n), dim3(1024), lds, ctx->stream, nd, dn, it, ch, seed, sweep, site,
+                           n_draws, 0, lse_out, scores_out, draws_out, scores_in, slot_cap);
+      else
+        hipLaunchKernelGGL((enum_node_kernel<1024, false>), dim3(it.n), dim3(1024), lds, ctx->stream, nd, dn, it, ch, seed, sweep, site,
+                           n_draws, 0, lse_out, scores_out, draws_out, scores_in, slot_cap);
     } else {
       for (int base = 0; base < it.n; base += kMaxBlocks)
-        hipLaunchKernelGGL(enum_node_kernel<256>, dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), lds, ctx->stream, nd, dn,
-                           it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out, (const double*)nullptr, 0);
+        if (it.ev_lo)
+          hipLaunchKernelGGL((enum_node_kernel<256, true>), dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), lds, ctx->stream, nd, dn,
+                             it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out, (const double*)nullptr, 0);
+        else
+          hipLaunchKernelGGL((enum_node_kernel<256, false>), dim3(std::min(kMaxBlocks, it.n - base)), dim3(256), lds, ctx->stream, nd, dn,
+                             it, ch, seed, sweep, site, n_draws, base, lse_out, scores_out, draws_out, (const double*)nullptr, 0);
     }
   }
   HIPCHK(ctx, hipGetLastError());

@@ -2287,7 +2287,8 @@ extern "C" int pclean_sweep(pclean_ctx* ctx, const pclean_infer_config* cfg, uin
       // rows below the table's high-water mark only: nobody refers to, or chooses, the spare capacity behind it, and zeroing
       // + flushing the counters of 8 240 rows in each of 4 000 workgroups was 0.05 ms per sweep)
       const int rows_in_use = (rt.n_used > 0 && rt.n_used <= rt.n_rows) ? std::min(rt.n_rows, (rt.n_used + 63) & ~63) : rt.n_rows;
-      const int hist_rows = rt.n_rows <= 12288 ? rows_in_use : 0;  // (48 KB of LDS per workgroup at most; larger tables: plain atomics)
+      static const bool no_hist = getenv("PCLEAN_NO_HIST") != nullptr;  // (measurement switch: plain atomics for every table)
+      const int hist_rows = (rt.n_rows <= 12288 && !no_hist) ? rows_in_use : 0;  // (48 KB of LDS per workgroup at most; larger tables: plain atomics)
       hipLaunchKernelGGL(finalize_block_kernel, grid1(N), dim3(256), (size_t)hist_rows * sizeof(int32_t), ctx->stream, N,
                          s->chosen.p, r.pchoice.p, r.pnewpos.p, cur_b, r.choice.p, r.chosen_newpos.p,
                          (unsigned long long*)rt.stats.p, hist_rows, r.moved_flag.p, r.new_flag.p,
