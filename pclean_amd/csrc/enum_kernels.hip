@@ -31,7 +31,7 @@
 
 #define HALF_LOG26 1.629048269010741
 #define ADD_TYPOS_IMPOSSIBLE (-1e5)
-#define ENUM_CPT 4  // candidates a thread of enum_node_kernel scores at a time (candidate_score_batch)
+#define ENUM_CPT 5  // candidates a thread of enum_node_kernel scores at a time (candidate_score_batch)
 #define CS_TC 4  // evidence entries of a term whose gathers are in flight together (candidate_score_ev)
 
 __device__ __forceinline__ double wave_max(double v) {
