@@ -182,10 +182,10 @@ __device__ __forceinline__ double candidate_score_ev(const NodeDev& nd, const De
       }
       if (tm.elem_bytes == 1) {
 #pragma unroll
-        for (int u = 0; u < CS_TC; ++u) d[u] = (int)tm.pair[(size_t)(o[u] >= 0 ? o[u] : 0) * tm.n_lat + val[u]];
+        for (int u = 0; u < CS_TC; ++u) d[u] = (int)tm.pair[o[u] >= 0 ? (size_t)o[u] * tm.n_lat + val[u] : (size_t)0];  // (entry 0: there even when the column holds no observation at all)
       } else {
 #pragma unroll
-        for (int u = 0; u < CS_TC; ++u) d[u] = (int)((const uint16_t*)tm.pair)[(size_t)(o[u] >= 0 ? o[u] : 0) * tm.n_lat + val[u]];
+        for (int u = 0; u < CS_TC; ++u) d[u] = (int)((const uint16_t*)tm.pair)[o[u] >= 0 ? (size_t)o[u] * tm.n_lat + val[u] : (size_t)0];
       }
       if (typos) {
 #pragma unroll

@@ -1508,7 +1508,7 @@ __global__ void hg_fill_kernel(int n, uint32_t cap, const uint64_t* __restrict__
   const int at = off0 + pos;
   members[at] = i;
   uid[at] = g0 + piece + 1;
-  head[at] = first ? 1 : 0;
+  if (head) head[at] = first ? 1 : 0;
   if (first) grp_off[g0 + piece] = at;
 }
 // group ids only: uid_of_item[i], and the attributes of every group's representative
@@ -1567,15 +1567,16 @@ static int make_item_groups_hash(pclean_ctx* ctx, const ItemList& il, const int3
   g.hg_slot_of = slot_of;
   if (!want_members) return PCLEAN_OK;
   int32_t* members = scratch<int32_t>(ctx, n);
-  int32_t* head = scratch<int32_t>(ctx, n);
   int32_t* uid = scratch<int32_t>(ctx, n);
   int32_t* grp_off = scratch<int32_t>(ctx, (size_t)n_unique + 1);
-  if (!members || !head || !uid || !grp_off) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  if (!members || !uid || !grp_off) return pclean_fail(ctx, PCLEAN_ERR_HIP, "scratch alloc failed");
+  // (no `head` flags: their only reader is item_unique_kernel, which the hash path never reaches — hg_unique_kernel takes the
+  // representatives from the table itself; a third scattered 4-byte write per item for nothing)
   hipLaunchKernelGGL(hg_fill_kernel, grid1(n), dim3(256), 0, ctx->stream, n, cap, incl, hg.cnt, slot_of, pos_of, split_m, members,
-                     head, uid, grp_off);
+                     (int32_t*)nullptr, uid, grp_off);
   g.grp_off = grp_off;
   g.members = members;
-  g.head = head;
+  g.head = nullptr;
   g.uid = uid;
   return PCLEAN_OK;
 }
