@@ -76,6 +76,8 @@ def test_sweeps_are_bit_identical_across_runs_and_paths(capsys):
         # a first counter bank of 2 slots: every later counted launch takes its counter from a grown bank (fresh_counter)
         "counter bank exhausted": {"PCLEAN_CTR_BANK": "2"},
         "two-level scans only": {"PCLEAN_NO_DENSE_SCAN": "1"},
+        # the sweep's delta reference counts by plain atomics for every table (finalize_block_kernel without its LDS histogram)
+        "delta counts without the histogram": {"PCLEAN_NO_HIST": "1"},
         "read-backs by copies, separate alive kernel, hipMemsetAsync": {"PCLEAN_NO_PUBLISH_REGIONS": "1", "PCLEAN_NO_FUSED_PRIORS": "1",
                                                                         "PCLEAN_NO_ZERO_KERNEL": "1"},
     }
