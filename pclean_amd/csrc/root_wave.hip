@@ -54,7 +54,7 @@
 #define WAVE_TC 6              // terms whose loads are in flight together in the exact scoring
 #endif
 #ifndef WAVE_CHUNK
-#define WAVE_CHUNK 8           // consecutive groups a wave takes at a time
+#define WAVE_CHUNK 4           // consecutive groups a wave takes at a time (PCLEAN_WAVE_CHUNK; measured at the end of round 6 on the Measure slot's 97 k groups: 1 / 2 / 3 / 4 / 6 / 8 / 16 / 32 -> 0.467 / 0.441 / 0.435 / 0.437 / 0.455 / 0.479 / 0.566 / 0.891 ms for its launch group — the balance over the waves matters more than the few list reuses a longer run of neighbours adds)
 #endif
 #ifndef WAVE_MIN_WAVES
 #define WAVE_MIN_WAVES 5       // resident workgroups per CU the register allocation aims at (measured: 5 beats 6, 7 and 8)
